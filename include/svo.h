@@ -1,0 +1,106 @@
+/*
+ * svo.h -- C ABI of libsvo_hip.so: the MI355X (gfx950) stereo-VO + pose-graph hot path.
+ *
+ * This is the drop-in boundary for the hot path of Gautham-JS/ROS_Stereo_SLAM.  The
+ * reference has no FFI of its own: its hot path is the member surface of
+ * include/visualSLAM.h:152-178 and include/poseGraph.h:62-66, which call straight into
+ * OpenCV and g2o.  Each entry point below names the reference interface it replaces
+ * (file:line relative to the reference checkout).  The C++ adaptors in
+ * include/svo_compat/ rebuild the reference's member functions on top of this ABI;
+ * INTEGRATION.md shows the binding a maintainer adds.
+ *
+ * Conventions
+ *  - plain pointers and sizes, no C++ or torch types; every function returns an int
+ *    status (SVO_OK == 0, negative = error; svo_last_error() holds the text).
+ *  - `mem` says where the caller's arrays live: SVO_MEM_HOST (the library stages through
+ *    its own device scratch and synchronises before returning) or SVO_MEM_DEVICE (HBM
+ *    pointers on the context's device; work is queued on the context's stream and the
+ *    call returns without synchronising -- use svo_ctx_sync()).
+ *  - one svo_ctx per device; it owns the HIP stream, scratch buffers and kernel timers.
+ *    No global state.  A context is not re-entrant (the reference is single-threaded on
+ *    this path too: src/VisualSLAM.cpp:54-200 runs on the main thread).
+ *  - images: H x W x C uint8, interleaved channels, row stride W*C (cv::Mat CV_8UC3
+ *    continuous, as src/keyFrameManagement.cpp:48-71 loads them).  Points: float32 x,y
+ *    (cv::Point2f) / x,y,z (cv::Point3f).  Camera matrices, rvec/tvec, [R|t]: float64.
+ *  - there is NO CPU fallback: without a gfx950 device svo_ctx_create() fails with
+ *    SVO_ERR_NO_DEVICE and nothing else can be called.
+ */
+#ifndef SVO_H
+#define SVO_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVO_VERSION 100
+
+enum {
+    SVO_OK = 0,
+    SVO_ERR_ARG = -1,
+    SVO_ERR_HIP = -2,
+    SVO_ERR_CAPACITY = -3,
+    SVO_ERR_NO_DEVICE = -4,
+    SVO_ERR_TRACKING_LOST = -5, /* the reference's SHUTDOWN_FLAG, keyFrameManagement.cpp:89-92 */
+    SVO_ERR_STATE = -6
+};
+enum { SVO_MEM_HOST = 0, SVO_MEM_DEVICE = 1 };
+
+/* kernel ids for svo_ctx_kernel_time() */
+enum {
+    SVO_K_PYRAMID = 0,
+    SVO_K_LK = 1,
+    SVO_K_FRANSAC = 2,
+    SVO_K_TRIANGULATE = 3,
+    SVO_K_PNP = 4,
+    SVO_K_POSEGRAPH = 5,
+    SVO_K_ANMS = 6,
+    SVO_K_COUNT = 7
+};
+
+typedef struct svo_ctx svo_ctx;
+typedef struct svo_pyramid svo_pyramid;
+
+int svo_version(void);
+const char *svo_last_error(void);
+
+/* ---- context ----------------------------------------------------------------------------- */
+int svo_ctx_create(int device, svo_ctx **out);
+int svo_ctx_destroy(svo_ctx *ctx);
+int svo_ctx_sync(svo_ctx *ctx);
+/* the hipStream_t all work of this context is queued on */
+void *svo_ctx_stream(svo_ctx *ctx);
+/* per-kernel HIP-event timing on the context's stream (bench.py's roofline leg) */
+int svo_ctx_enable_kernel_timing(svo_ctx *ctx, int enable);
+int svo_ctx_kernel_time(svo_ctx *ctx, int kernel_id, double *total_ms, int *launches);
+int svo_ctx_reset_kernel_time(svo_ctx *ctx);
+
+/* ---- image pyramid ----------------------------------------------------------------------- */
+/* Replaces the pyramid cv::calcOpticalFlowPyrLK rebuilds on every call
+ * (src/tracking.cpp:18,52).  A pyramid is built once per image and reused for the
+ * (t-1 -> t), (t -> t+1) and (left -> right) trackings that read it.                       */
+int svo_pyramid_create(svo_ctx *ctx, int width, int height, int channels, int levels,
+                       svo_pyramid **out);
+int svo_pyramid_destroy(svo_ctx *ctx, svo_pyramid *pyr);
+int svo_pyramid_build(svo_ctx *ctx, svo_pyramid *pyr, const uint8_t *image, int mem);
+/* copy one level out (tests).  out holds w*h*c bytes. */
+int svo_pyramid_get_level(svo_ctx *ctx, const svo_pyramid *pyr, int level, uint8_t *out,
+                          int mem, int *w, int *h);
+
+/* ---- dense grid sampler: visualSLAM::denseKeypointExtractor, src/tracking.cpp:4-12 ------- */
+int svo_grid_keypoints(svo_ctx *ctx, int rows, int cols, int step, float *out_xy, int cap,
+                       int mem, int *count);
+
+/* ---- pyramidal Lucas-Kanade: cv::calcOpticalFlowPyrLK with defaults ----------------------- */
+/* replaces the calls at src/tracking.cpp:18 (denseLKtracking) and :52
+ * (PyrLKtrackFrame2Frame).  21x21 window, 4 levels, 30 iterations / 0.01, minEig 1e-4.
+ * err and min_eig may be NULL.  min_eig is the level-0 minimum eigenvalue (ANMS response). */
+int svo_lk_track(svo_ctx *ctx, const svo_pyramid *prev, const svo_pyramid *next,
+                 const float *prev_pts, int n, float *next_pts, uint8_t *status, float *err,
+                 float *min_eig, int mem);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,179 @@
+/*
+ * svo_oracle.h -- CPU restatement (plain C) of the stereo-VO + pose-graph hot path of
+ * Gautham-JS/ROS_Stereo_SLAM.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may link, load or call anything in oracle/.  The
+ * product path (ros_stereo_slam_amd/csrc, libsvo_hip.so) never includes this header.
+ *
+ * PARITY UNPINNED: the arithmetic of the reference path lives in OpenCV (video, calib3d)
+ * and g2o (types_slam3d, solver_eigen), which are un-vendored, un-pinned and absent from
+ * /root/reference and from this image; the reference holds no tests, golden vectors or
+ * fixtures for this path.  Each function below cites the reference
+ * call site it stands in for and restates the published upstream algorithm; the
+ * restatement is pinned by analytic known-answer tests (tests/test_oracle_*.py) and by
+ * numpy/scipy cross-checks whose generator scripts are committed under tests/golden/.
+ */
+#ifndef SVO_ORACLE_H
+#define SVO_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- image pyramid + pyramidal Lucas-Kanade ------------------------------------------ */
+/* stands in for cv::calcOpticalFlowPyrLK with all defaults, reference call sites
+ * src/tracking.cpp:18 (left->right) and src/tracking.cpp:52 (t-1 -> t).                 */
+
+#define ORC_LK_WIN 21
+#define ORC_LK_MAX_LEVELS 8
+
+typedef struct {
+    int win;            /* square window side, 21                                        */
+    int max_level;      /* 3 -> 4 levels                                                 */
+    int max_count;      /* 30                                                            */
+    double epsilon;     /* 0.01 (compared squared)                                       */
+    double min_eig_thr; /* 1e-4                                                          */
+} orc_lk_params;
+
+void orc_lk_default_params(orc_lk_params *p);
+
+/* level sizes of the pyramid: ((w+1)/2, (h+1)/2) per level */
+void orc_pyr_sizes(int w, int h, int levels, int *ws, int *hs);
+/* one pyrDown: 5x5 [1 4 6 4 1]/16 separable, BORDER_REFLECT_101, (sum+128)>>8 */
+void orc_pyr_down(const uint8_t *src, int w, int h, int c, uint8_t *dst);
+/* Scharr derivative image, int16 interleaved (dx,dy) per channel, size h*w*c*2 */
+void orc_scharr(const uint8_t *src, int w, int h, int c, int16_t *dst);
+
+/* Full tracker.  prev/next: h*w*c uint8 interleaved, row stride w*c.
+ * pts: n*2 float32.  status: n uint8.  err: n float32.  min_eig (optional, may be NULL):
+ * level-0 minimum eigenvalue (the ANMS response the build supplies).
+ * Returns 0, or -1 on bad arguments. */
+int orc_lk_track(const uint8_t *prev, const uint8_t *next, int w, int h, int c,
+                 const float *prev_pts, int n, float *next_pts, uint8_t *status,
+                 float *err, float *min_eig, const orc_lk_params *params);
+
+/* ---- dense grid sampler: src/tracking.cpp:4-12 ---------------------------------------- */
+/* returns count; writes x,y pairs (float) if out != NULL (capacity cap points) */
+int orc_grid_keypoints(int rows, int cols, int step, float *out_xy, int cap);
+
+/* ---- ANMS: src/ANMS.cpp:18-67 ---------------------------------------------------------- */
+/* in: n keypoints (x,y,response).  out_idx: indices into the INPUT array of the kept
+ * keypoints, in the output order of the reference (response-sorted).  Returns count kept.
+ * Deviations: stable sort (ties keep input order); returns all when
+ * n <= num_to_keep (reference early-outs on n < k and reads OOB at n == k).              */
+int orc_anms(const float *xy, const float *response, int n, int num_to_keep, int *out_idx,
+             double *out_radii /* optional, per sorted kp */);
+
+/* ---- counter-based RNG shared by both RANSACs (SURVEY 7 "hard parts", A.4) ------------- */
+uint32_t orc_rng_u32(uint64_t seed, uint32_t iter, uint32_t draw);
+
+/* ---- fundamental-matrix RANSAC: src/tracking.cpp:34 and :75 ---------------------------- */
+/* stands in for cv::findFundamentalMat(p1,p2,FM_RANSAC,thr,conf,mask).
+ * mask: n uint8 (1 inlier).  F: 9 doubles row-major (best 7-point model, F[8]==1 scale).
+ * Returns number of inliers (0 => no model, mask zeroed).                                */
+typedef struct {
+    double threshold;   /* px (3.0 stereo, 1.0 temporal)                                  */
+    double confidence;  /* 0.99                                                           */
+    int max_iters;      /* 1000                                                           */
+    uint64_t seed;
+} orc_fransac_params;
+
+int orc_fransac(const float *p1, const float *p2, int n, const orc_fransac_params *prm,
+                uint8_t *mask, double *F, int *iters_run);
+/* 7-point solver on 7 correspondences: returns number of models (0..3), F's row-major */
+int orc_seven_point(const double *x1 /*7x2*/, const double *x2 /*7x2*/, double *F /*3x9*/);
+/* symmetric epipolar error of OpenCV's FMEstimatorCallback::computeError (float result) */
+float orc_f_error(const double *F, float x1, float y1, float x2, float y2);
+
+/* ---- DLT triangulation: src/triangulation.cpp:142-160 ---------------------------------- */
+/* P1,P2: 3x4 row-major double.  x1,x2: n*2 float.  out_xyz: n*3 float (float
+ * dehomogenisation of the float-rounded homogeneous vector, as the reference does).
+ * out_h (optional): n*4 float homogeneous (unit norm, sign arbitrary).                   */
+void orc_triangulate(const double *P1, const double *P2, const float *x1, const float *x2,
+                     int n, float *out_xyz, float *out_h);
+/* builds P1=K[I|0], P2=K[I|(-b,0,0)] from fx,fy,cx,cy,baseline (triangulation.cpp:142-149) */
+void orc_stereo_projections(double fx, double fy, double cx, double cy, double baseline,
+                            double *P1, double *P2);
+
+/* rigid transform, 3x4 double [R|t] applied to float points: keyFrameManagement.cpp:20-30 */
+void orc_transform_points(const double *Rt, const float *in_xyz, int n, float *out_xyz);
+/* colour gather img.at<Vec3b>(int(y),int(x)) as 3 floats: include/monoUtils.h:180-193 */
+void orc_get_colors(const uint8_t *img, int w, int h, int c, const float *xy, int n,
+                    float *out_bgr);
+
+/* ---- Rodrigues + pose composition: src/VisualSLAM.cpp:70-74 ---------------------------- */
+void orc_rodrigues(const double *rvec, double *R /*9 row-major*/);
+void orc_rodrigues_inv(const double *R, double *rvec);
+/* R_out = R(rvec)^T, t_out = -R_out * tvec */
+void orc_compose_camera_pose(const double *rvec, const double *tvec, double *R, double *t);
+
+/* ---- PnP RANSAC: src/keyFrameManagement.cpp:84,88 --------------------------------------- */
+typedef struct {
+    int iterations;      /* 100                                                           */
+    double reproj_err;   /* 1.0 (retry 8.0)                                               */
+    double confidence;   /* 0.99 (retry 0.98)                                             */
+    uint64_t seed;
+    int refine_iters;    /* LM iterations on the inlier set, 20                           */
+} orc_pnp_params;
+
+/* obj: n*3 float (world), img: n*2 float (pixels), K = fx,fy,cx,cy.
+ * rvec,tvec: 3 doubles each.  inliers: n ints capacity; returns inlier count (0 = fail).  */
+int orc_pnp_ransac(const float *obj, const float *img, int n, const double *K4,
+                   const orc_pnp_params *prm, double *rvec, double *tvec, int *inliers,
+                   int *iters_run);
+/* EPnP on m (>=4) correspondences (double).  Returns 0 on success. */
+int orc_epnp(const double *obj, const double *img, int m, const double *K4, double *R,
+             double *t);
+/* LM refinement of (rvec,tvec) over the given points; returns final RMS reprojection error */
+double orc_pnp_refine(const float *obj, const float *img, const int *idx, int m,
+                      const double *K4, double *rvec, double *tvec, int max_iters);
+
+/* ---- SE3 pose graph: include/poseGraph.h:69-138 ------------------------------------------ */
+/* poses: 7 doubles per vertex (tx ty tz qx qy qz qw), g2o VERTEX_SE3:QUAT order.          */
+typedef struct orc_posegraph orc_posegraph;
+orc_posegraph *orc_pg_create(void);
+void orc_pg_destroy(orc_posegraph *g);
+void orc_pg_initialize(orc_posegraph *g);                         /* poseGraph.h:69-84   */
+void orc_pg_augment_node(orc_posegraph *g, const double *pose7);  /* poseGraph.h:87-111  */
+void orc_pg_add_loop_closure(orc_posegraph *g, int from_id);      /* poseGraph.h:113-126 */
+/* runs `iters` Gauss-Newton iterations; chi2 (optional) receives iters+1 values */
+int orc_pg_optimize(orc_posegraph *g, int iters, double *chi2);    /* poseGraph.h:128-138 */
+int orc_pg_num_vertices(const orc_posegraph *g);
+int orc_pg_num_edges(const orc_posegraph *g);
+void orc_pg_get_estimates(const orc_posegraph *g, double *pose7_out);
+void orc_pg_get_edge(const orc_posegraph *g, int e, int *from, int *to, double *meas7);
+/* edge error (6) and analytic Jacobians (6x6 row-major each) -- exposed for tests */
+void orc_se3_edge_error(const double *Xi7, const double *Xj7, const double *Z7, double *e6,
+                        double *Ji, double *Jj);
+void orc_se3_oplus(const double *X7, const double *v6, double *Xout7);
+int orc_pg_write_g2o(const orc_posegraph *g, const char *path);  /* poseGraph.h:140-179 */
+
+/* ---- front-end frame loop: src/VisualSLAM.cpp:54-169 -------------------------------------- */
+typedef struct {
+    double fx, fy, cx, cy, baseline;
+    int grid_step;          /* 30 in the reference (triangulation.cpp:89)                 */
+    int anms_keep;          /* 0 = no ANMS (reference), else keep this many               */
+    int keyframe_min_inliers; /* 200 (VisualSLAM.cpp:120)                                 */
+    double f_thr_stereo, f_thr_temporal; /* 3.0, 1.0                                      */
+    uint64_t seed;
+} orc_vo_params;
+void orc_vo_default_params(orc_vo_params *p);
+
+typedef struct orc_vo orc_vo;
+orc_vo *orc_vo_create(const orc_vo_params *p, int w, int h, int c);
+void orc_vo_destroy(orc_vo *v);
+/* first frame: stereo triangulate, identity pose.  Returns #map points. */
+int orc_vo_init(orc_vo *v, const uint8_t *left, const uint8_t *right);
+/* next frame.  right may be NULL only if no keyframe is needed (returns -2 then).
+ * force_keyframe mirrors LC_FLAG.  Outputs R (9), t (3) camera-in-world, inlier count,
+ * keyframe flag.  Returns 0 ok, -1 shutdown (tracking lost).                              */
+int orc_vo_track(orc_vo *v, const uint8_t *left, const uint8_t *right, int force_keyframe,
+                 double *R, double *t, int *n_inliers, int *was_keyframe, int *n_tracked);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,9 @@
+"""MI355X-native stereo-VO + pose-graph hot path (drop-in for the hot loop of
+Gautham-JS/ROS_Stereo_SLAM).  The product is ``libsvo_hip.so`` (HIP kernels for gfx950
+behind the C ABI of ``include/svo.h``); this package is the thin host binding plus the
+synthetic-sequence generator the benchmark and the tests use.
+"""
+from . import capi, synth  # noqa: F401
+from .capi import Context, Pyramid, SvoError  # noqa: F401
+
+__all__ = ["capi", "synth", "Context", "Pyramid", "SvoError"]

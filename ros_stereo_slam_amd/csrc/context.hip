@@ -1,0 +1,195 @@
+// context.hip -- svo_ctx: device, stream, scratch, kernel timers, error text.
+#include <cstdarg>
+
+#include "svo_internal.h"
+
+static thread_local char g_err[512] = "";
+
+void svo_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int DevBuf::ensure(size_t bytes)
+{
+    if (bytes <= cap)
+        return SVO_OK;
+    if (p)
+        (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes < 4096 ? 4096 : bytes + bytes / 4;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+        svo_set_error("hipMalloc(%zu) -> %s", want, hipGetErrorString(e));
+        return SVO_ERR_HIP;
+    }
+    cap = want;
+    return SVO_OK;
+}
+
+void DevBuf::release()
+{
+    if (p)
+        (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+}
+
+ScopedKernelTime::ScopedKernelTime(svo_ctx *c, int kid) : ctx(c), id(kid)
+{
+    if (!ctx->timing)
+        return;
+    KernelTimer &t = ctx->timers[id];
+    if (!t.pool.empty()) {
+        a = t.pool.back().first;
+        b = t.pool.back().second;
+        t.pool.pop_back();
+    } else {
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+            a = b = nullptr;
+            return;
+        }
+    }
+    (void)hipEventRecord(a, ctx->stream);
+}
+
+ScopedKernelTime::~ScopedKernelTime()
+{
+    if (!a)
+        return;
+    (void)hipEventRecord(b, ctx->stream);
+    ctx->timers[id].pending.emplace_back(a, b);
+}
+
+int svo_resolve_timers(svo_ctx *ctx)
+{
+    for (int k = 0; k < SVO_K_COUNT; k++) {
+        KernelTimer &t = ctx->timers[k];
+        for (auto &pr : t.pending) {
+            float ms = 0.f;
+            if (hipEventSynchronize(pr.second) == hipSuccess &&
+                hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+                t.total_ms += ms;
+                t.launches++;
+            }
+            t.pool.push_back(pr);
+        }
+        t.pending.clear();
+    }
+    return SVO_OK;
+}
+
+extern "C" {
+
+int svo_version(void) { return SVO_VERSION; }
+const char *svo_last_error(void) { return g_err; }
+
+int svo_ctx_create(int device, svo_ctx **out)
+{
+    SVO_CHECK_ARG(out != nullptr);
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        svo_set_error("no HIP device available (%s); libsvo_hip has no CPU fallback",
+                      e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+        return SVO_ERR_NO_DEVICE;
+    }
+    SVO_CHECK_ARG(device >= 0 && device < count);
+    SVO_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    SVO_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        svo_set_error("device %d is %s; this library carries gfx950 code objects only", device,
+                      prop.gcnArchName);
+        return SVO_ERR_NO_DEVICE;
+    }
+    svo_ctx *ctx = new svo_ctx();
+    ctx->device = device;
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete ctx;
+        svo_set_error("hipStreamCreate -> %s", hipGetErrorString(e));
+        return SVO_ERR_HIP;
+    }
+    ctx->pinned_bytes = 1 << 16;
+    e = hipHostMalloc(&ctx->pinned, ctx->pinned_bytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        svo_set_error("hipHostMalloc -> %s", hipGetErrorString(e));
+        return SVO_ERR_HIP;
+    }
+    *out = ctx;
+    return SVO_OK;
+}
+
+int svo_ctx_destroy(svo_ctx *ctx)
+{
+    if (!ctx)
+        return SVO_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    svo_resolve_timers(ctx);
+    for (int k = 0; k < SVO_K_COUNT; k++)
+        for (auto &pr : ctx->timers[k].pool) {
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+    DevBuf *bufs[] = {&ctx->s_img, &ctx->s_a, &ctx->s_b, &ctx->s_c, &ctx->s_d, &ctx->s_e,
+                      &ctx->s_f,   &ctx->s_g, &ctx->w_a, &ctx->w_b, &ctx->w_c, &ctx->w_d,
+                      &ctx->w_e};
+    for (DevBuf *b : bufs)
+        b->release();
+    if (ctx->pinned)
+        (void)hipHostFree(ctx->pinned);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return SVO_OK;
+}
+
+int svo_ctx_sync(svo_ctx *ctx)
+{
+    SVO_CHECK_ARG(ctx != nullptr);
+    SVO_HIP(hipStreamSynchronize(ctx->stream));
+    return SVO_OK;
+}
+
+void *svo_ctx_stream(svo_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int svo_ctx_enable_kernel_timing(svo_ctx *ctx, int enable)
+{
+    SVO_CHECK_ARG(ctx != nullptr);
+    ctx->timing = enable != 0;
+    return SVO_OK;
+}
+
+int svo_ctx_kernel_time(svo_ctx *ctx, int kernel_id, double *total_ms, int *launches)
+{
+    SVO_CHECK_ARG(ctx != nullptr && kernel_id >= 0 && kernel_id < SVO_K_COUNT);
+    SVO_HIP(hipStreamSynchronize(ctx->stream));
+    svo_resolve_timers(ctx);
+    if (total_ms)
+        *total_ms = ctx->timers[kernel_id].total_ms;
+    if (launches)
+        *launches = ctx->timers[kernel_id].launches;
+    return SVO_OK;
+}
+
+int svo_ctx_reset_kernel_time(svo_ctx *ctx)
+{
+    SVO_CHECK_ARG(ctx != nullptr);
+    SVO_HIP(hipStreamSynchronize(ctx->stream));
+    svo_resolve_timers(ctx);
+    for (int k = 0; k < SVO_K_COUNT; k++) {
+        ctx->timers[k].total_ms = 0;
+        ctx->timers[k].launches = 0;
+    }
+    return SVO_OK;
+}
+
+}  // extern "C"

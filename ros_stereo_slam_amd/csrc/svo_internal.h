@@ -1,0 +1,97 @@
+// svo_internal.h -- shared host-side declarations of libsvo_hip.so (not installed).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/svo.h"
+
+#define SVO_MAX_LEVELS 4
+#define SVO_LK_WIN 21
+
+void svo_set_error(const char *fmt, ...);
+
+#define SVO_HIP(call)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            svo_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); \
+            return SVO_ERR_HIP;                                                               \
+        }                                                                                     \
+    } while (0)
+
+#define SVO_CHECK_ARG(cond)                                                  \
+    do {                                                                     \
+        if (!(cond)) {                                                       \
+            svo_set_error("%s:%d bad argument: %s", __FILE__, __LINE__, #cond); \
+            return SVO_ERR_ARG;                                              \
+        }                                                                    \
+    } while (0)
+
+// device-visible description of one pyramid (passed to kernels by value)
+struct PyrDev {
+    const uint8_t *lvl[SVO_MAX_LEVELS];
+    int w[SVO_MAX_LEVELS];
+    int h[SVO_MAX_LEVELS];
+    int levels;
+    int c;
+};
+
+struct svo_pyramid {
+    int w, h, c, levels;
+    uint8_t *base;   // one HBM allocation, levels back to back (256-B aligned each)
+    size_t off[SVO_MAX_LEVELS];
+    size_t bytes;
+    PyrDev dev;
+};
+
+// growable device scratch
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes);
+    void release();
+    template <class T> T *as() { return reinterpret_cast<T *>(p); }
+};
+
+struct KernelTimer {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+    double total_ms = 0;
+    int launches = 0;
+};
+
+struct svo_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool timing = false;
+    KernelTimer timers[SVO_K_COUNT];
+    // staging buffers for SVO_MEM_HOST calls
+    DevBuf s_img, s_a, s_b, s_c, s_d, s_e, s_f, s_g;
+    // work buffers used inside multi-kernel entry points
+    DevBuf w_a, w_b, w_c, w_d, w_e;
+    void *pinned = nullptr;  // small pinned host block for scalar read-backs
+    size_t pinned_bytes = 0;
+};
+
+// scoped timer: records events around a kernel when ctx->timing is on
+struct ScopedKernelTime {
+    svo_ctx *ctx;
+    int id;
+    hipEvent_t a = nullptr, b = nullptr;
+    ScopedKernelTime(svo_ctx *c, int kid);
+    ~ScopedKernelTime();
+};
+int svo_resolve_timers(svo_ctx *ctx);
+
+// pyramid.hip
+int svo_launch_pyr_down(svo_ctx *ctx, const uint8_t *src, int w, int h, int c, uint8_t *dst);
+// lk.hip
+int svo_launch_lk(svo_ctx *ctx, const PyrDev &prev, const PyrDev &next, const float *prev_pts,
+                  int n, float *next_pts, uint8_t *status, float *err, float *min_eig);
+int svo_launch_grid(svo_ctx *ctx, int rows, int cols, int step, float *out_xy, int cap);

@@ -1,0 +1,212 @@
+"""Synthetic stereo sequences with ground-truth poses.
+
+No dataset ships with the reference (``.MISSING_LARGE_BLOBS``) and none can be fetched, so
+the benchmark and the parity tests ray-cast an analytic world: a ground plane below the
+camera, two side walls (optionally two end walls, which turns the corridor into a yard a
+trajectory can loop in) and a constant sky.  Surface albedo is seeded value noise of the
+world coordinates, band-limited against the pixel footprint so that far texture does not
+alias.  Camera intrinsics default to the reference's KITTI values
+(``include/visualSLAM.h:68,82-87``): fx = fy = 718.856, cx = 607.1928, cy = 185.2157,
+baseline 0.54 m, 1241 x 376.
+
+Conventions: camera frame x right, y down, z forward (KITTI); a pose is camera-in-world,
+``X_w = R @ X_c + t``.  The right camera sits at ``+baseline`` along the camera x axis,
+matching ``P2 = K [I | (-b, 0, 0)]`` of ``src/triangulation.cpp:142-149``.
+"""
+from __future__ import annotations
+
+import dataclasses
+
+import numpy as np
+
+KITTI_K = (718.856, 718.856, 607.1928, 185.2157)
+KITTI_BASELINE = 0.54
+KITTI_SIZE = (1241, 376)
+DEFAULT_SEED = 20261003
+
+
+def _hash2(ix: np.ndarray, iy: np.ndarray, seed: int) -> np.ndarray:
+    """Integer lattice hash -> float in [0, 1).  Pure uint32 arithmetic (deterministic)."""
+    with np.errstate(over="ignore"):
+        h = ix.astype(np.uint32) * np.uint32(0x9E3779B1) ^ iy.astype(np.uint32) * np.uint32(0x85EBCA77)
+        h ^= np.uint32(seed & 0xFFFFFFFF)
+        h ^= h >> np.uint32(15)
+        h *= np.uint32(0x2C1B3C6D)
+        h ^= h >> np.uint32(12)
+        h *= np.uint32(0x297A2D39)
+        h ^= h >> np.uint32(15)
+    return (h >> np.uint32(8)).astype(np.float64) * (1.0 / (1 << 24))
+
+
+def _value_noise(u: np.ndarray, v: np.ndarray, seed: int) -> np.ndarray:
+    """Smooth value noise with unit lattice spacing, range [0, 1)."""
+    fu, fv = np.floor(u), np.floor(v)
+    iu, iv = fu.astype(np.int64), fv.astype(np.int64)
+    a, b = u - fu, v - fv
+    a = a * a * (3.0 - 2.0 * a)
+    b = b * b * (3.0 - 2.0 * b)
+    n00 = _hash2(iu, iv, seed)
+    n10 = _hash2(iu + 1, iv, seed)
+    n01 = _hash2(iu, iv + 1, seed)
+    n11 = _hash2(iu + 1, iv + 1, seed)
+    return (n00 * (1 - a) + n10 * a) * (1 - b) + (n01 * (1 - a) + n11 * a) * b
+
+
+@dataclasses.dataclass
+class Scene:
+    """Ground plane y = +ground_y, walls x = +-wall_x, optional end walls z = z_min / z_max."""
+
+    seed: int = DEFAULT_SEED
+    ground_y: float = 1.65
+    wall_x: float = 6.0
+    z_min: float | None = None
+    z_max: float | None = None
+    wavelengths: tuple = (1.2, 0.45, 0.15)
+    sky: int = 128
+
+    def albedo(self, u, v, footprint, surface_id):
+        """Value-noise albedo in [0,255]; octaves fade out when the pixel footprint nears them."""
+        acc = np.zeros_like(u)
+        wsum = np.zeros_like(u)
+        amp = 1.0
+        for k, wl in enumerate(self.wavelengths):
+            fade = np.clip(1.5 - 2.0 * footprint / wl, 0.0, 1.0)
+            n = _value_noise(u / wl, v / wl, self.seed + 7919 * surface_id + 104729 * k)
+            acc += amp * fade * (n - 0.5)
+            wsum += amp
+            amp *= 0.7
+        return np.clip(128.0 + 230.0 * acc / wsum * 1.6, 0, 255)
+
+    def render(self, R, t, K=KITTI_K, size=KITTI_SIZE, channels=3):
+        """Ray-cast one view.  Returns (H, W, C) uint8 and the depth map (z in camera frame)."""
+        fx, fy, cx, cy = K
+        w, h = size
+        R = np.asarray(R, np.float64).reshape(3, 3)
+        t = np.asarray(t, np.float64).reshape(3)
+        uu, vv = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
+        dc = np.stack([(uu - cx) / fx, (vv - cy) / fy, np.ones_like(uu)], -1)
+        dw = dc @ R.T
+        best_t = np.full((h, w), np.inf)
+        tex_u = np.zeros((h, w))
+        tex_v = np.zeros((h, w))
+        surf = np.zeros((h, w), np.int64)
+
+        def hit(tt, valid, u, v, sid):
+            nonlocal best_t, tex_u, tex_v, surf
+            m = valid & (tt > 1e-6) & (tt < best_t)
+            best_t = np.where(m, tt, best_t)
+            tex_u = np.where(m, u, tex_u)
+            tex_v = np.where(m, v, tex_v)
+            surf = np.where(m, sid, surf)
+
+        with np.errstate(divide="ignore", invalid="ignore"):
+            tt = (self.ground_y - t[1]) / dw[..., 1]
+            hit(tt, dw[..., 1] > 1e-9, t[0] + tt * dw[..., 0], t[2] + tt * dw[..., 2], 1)
+            for sid, xw in ((2, -self.wall_x), (3, self.wall_x)):
+                tt = (xw - t[0]) / dw[..., 0]
+                yw = t[1] + tt * dw[..., 1]
+                hit(tt, (np.abs(dw[..., 0]) > 1e-9) & (yw < self.ground_y) & (yw > self.ground_y - 8.0),
+                    yw, t[2] + tt * dw[..., 2], sid)
+            for sid, zw in ((4, self.z_min), (5, self.z_max)):
+                if zw is None:
+                    continue
+                tt = (zw - t[2]) / dw[..., 2]
+                yw = t[1] + tt * dw[..., 1]
+                hit(tt, (np.abs(dw[..., 2]) > 1e-9) & (yw < self.ground_y) & (yw > self.ground_y - 8.0),
+                    t[0] + tt * dw[..., 0], yw, sid)
+        found = np.isfinite(best_t)
+        depth = np.where(found, best_t, 0.0)  # dc has z = 1, so ray parameter == camera depth
+        footprint = depth / fx * 1.5
+        grey = np.zeros((h, w))
+        for sid in (1, 2, 3, 4, 5):
+            m = surf == sid
+            if m.any():
+                grey = np.where(m, self.albedo(tex_u, tex_v, footprint, sid), grey)
+        grey = np.where(found, grey, float(self.sky))
+        img = np.rint(grey).astype(np.uint8)
+        img = np.repeat(img[..., None], channels, axis=2)
+        return np.ascontiguousarray(img), depth
+
+    def stereo(self, R, t, K=KITTI_K, size=KITTI_SIZE, channels=3, baseline=KITTI_BASELINE):
+        R = np.asarray(R, np.float64).reshape(3, 3)
+        t = np.asarray(t, np.float64).reshape(3)
+        left, depth = self.render(R, t, K, size, channels)
+        right, _ = self.render(R, t + R @ np.array([baseline, 0.0, 0.0]), K, size, channels)
+        return left, right, depth
+
+
+def rot_y(a: float) -> np.ndarray:
+    c, s = np.cos(a), np.sin(a)
+    return np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]], np.float64)
+
+
+def corridor_trajectory(n: int, step: float = 0.9, yaw_amp: float = 0.02, sway: float = 0.6,
+                        period: float = 60.0):
+    """Forward motion along +z with slow sinusoidal yaw and lateral sway.  Returns [(R, t)]."""
+    poses = []
+    for i in range(n):
+        ph = 2 * np.pi * i / period
+        yaw = yaw_amp * period / (2 * np.pi) * 0.25 * np.sin(ph)
+        x = sway * np.sin(ph * 0.5)
+        poses.append((rot_y(yaw), np.array([x, 0.0, step * i])))
+    return poses
+
+
+def loop_trajectory(n: int, half_x: float = 14.0, half_z: float = 30.0, radius: float = 8.0,
+                    step: float = 0.9):
+    """Rounded-rectangle loop (camera looks along its direction of travel).  Returns [(R, t)].
+
+    Use with ``Scene(wall_x=half_x+8, z_min=-half_z-8, z_max=half_z+8)``.
+    """
+    # build the closed path as straight segments + quarter circles, parametrised by arc length
+    sx, sz = half_x - radius, half_z - radius
+    segs = []  # (kind, length, data)
+    segs.append(("line", 2 * sz, (np.array([half_x, -sz]), np.array([0.0, 1.0]))))
+    segs.append(("arc", 0.5 * np.pi * radius, (np.array([sx, sz]), 0.0)))
+    segs.append(("line", 2 * sx, (np.array([sx, half_z]), np.array([-1.0, 0.0]))))
+    segs.append(("arc", 0.5 * np.pi * radius, (np.array([-sx, sz]), 0.5 * np.pi)))
+    segs.append(("line", 2 * sz, (np.array([-half_x, sz]), np.array([0.0, -1.0]))))
+    segs.append(("arc", 0.5 * np.pi * radius, (np.array([-sx, -sz]), np.pi)))
+    segs.append(("line", 2 * sx, (np.array([-sx, -half_z]), np.array([1.0, 0.0]))))
+    segs.append(("arc", 0.5 * np.pi * radius, (np.array([sx, -sz]), 1.5 * np.pi)))
+    total = sum(s[1] for s in segs)
+    poses = []
+    for i in range(n):
+        s = (step * i) % total
+        for kind, length, data in segs:
+            if s <= length:
+                if kind == "line":
+                    p0, d = data
+                    pos = p0 + d * s
+                    heading = d
+                else:
+                    c, a0 = data
+                    a = a0 + s / radius
+                    pos = c + radius * np.array([np.cos(a), np.sin(a)])
+                    heading = np.array([-np.sin(a), np.cos(a)])
+                break
+            s -= length
+        yaw = np.arctan2(heading[0], heading[1])  # rotation about y taking +z to heading
+        poses.append((rot_y(yaw), np.array([pos[0], 0.0, pos[1]])))
+    return poses
+
+
+def textured_pair(w: int, h: int, c: int, shift=(0.0, 0.0), seed: int = 1, wavelength: float = 9.0):
+    """Two images of one band-limited texture, the second shifted by ``shift`` pixels
+    (image2(x, y) = image1(x - dx, y - dy)); the analytic flow is ``shift`` everywhere."""
+    uu, vv = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
+
+    def tex(u, v):
+        acc = 0.0
+        amp, wl = 1.0, wavelength * 4
+        for k in range(3):
+            acc = acc + amp * (_value_noise(u / wl, v / wl, seed + 31 * k) - 0.5)
+            amp *= 0.6
+            wl *= 0.5
+        return np.clip(128 + 200 * acc / 1.96, 0, 255)
+
+    a = np.rint(tex(uu, vv)).astype(np.uint8)
+    b = np.rint(tex(uu - shift[0], vv - shift[1])).astype(np.uint8)
+    a = np.ascontiguousarray(np.repeat(a[..., None], c, 2))
+    b = np.ascontiguousarray(np.repeat(b[..., None], c, 2))
+    return a, b

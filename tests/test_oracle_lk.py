@@ -1,0 +1,107 @@
+"""Pins the CPU oracle's pyramid / Scharr / LK restatement (reference call sites
+src/tracking.cpp:18,52) with known-answer tests and independent numpy/scipy restatements.
+The reference holds no fixtures for this path: parity is unpinned, these
+tests are what the oracle stands on."""
+import numpy as np
+import pytest
+import scipy.ndimage as ndi
+
+from ros_stereo_slam_amd import synth
+
+
+def _np_pyr_down(img):
+    k = np.array([1, 4, 6, 4, 1], np.int64)
+    out = []
+    for ch in range(img.shape[2]):
+        a = img[..., ch].astype(np.int64)
+        a = ndi.correlate1d(a, k, axis=1, mode="mirror")
+        a = ndi.correlate1d(a, k, axis=0, mode="mirror")
+        out.append(((a + 128) >> 8)[::2, ::2])
+    return np.stack(out, -1).astype(np.uint8)
+
+
+@pytest.mark.parametrize("shape", [(47, 156, 3), (94, 311, 1), (60, 81, 3), (51, 50, 4)])
+def test_pyr_down_matches_numpy(orc, shape):
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, shape, dtype=np.uint8)
+    assert np.array_equal(orc.pyr_down(img), _np_pyr_down(img))
+
+
+def test_pyr_sizes():
+    assert orc_sizes(1241, 376) == ([1241, 621, 311, 156], [376, 188, 94, 47])
+
+
+def orc_sizes(w, h):
+    from oracle import orc as o
+    return o.pyr_sizes(w, h, 4)
+
+
+@pytest.mark.parametrize("shape", [(40, 50, 3), (33, 47, 1)])
+def test_scharr_matches_scipy(orc, shape):
+    rng = np.random.default_rng(7)
+    img = rng.integers(0, 256, shape, dtype=np.uint8)
+    got = orc.scharr(img)
+    smooth = np.array([3, 10, 3], np.int64)
+    diff = np.array([-1, 0, 1], np.int64)
+    for ch in range(shape[2]):
+        a = img[..., ch].astype(np.int64)
+        dx = ndi.correlate1d(ndi.correlate1d(a, smooth, axis=0, mode="mirror"), diff, axis=1, mode="mirror")
+        dy = ndi.correlate1d(ndi.correlate1d(a, diff, axis=0, mode="mirror"), smooth, axis=1, mode="mirror")
+        assert np.array_equal(got[..., ch, 0], dx)
+        assert np.array_equal(got[..., ch, 1], dy)
+
+
+@pytest.mark.parametrize("c", [1, 3])
+@pytest.mark.parametrize("shift", [(0.0, 0.0), (2.3, -1.4), (-6.75, 3.2), (11.5, 7.25)])
+def test_lk_recovers_analytic_shift(orc, c, shift):
+    a, b = synth.textured_pair(320, 200, c, shift=shift, seed=3)
+    pts = orc.grid_keypoints(200, 320, 20)
+    inner = (pts[:, 0] > 45) & (pts[:, 0] < 275) & (pts[:, 1] > 45) & (pts[:, 1] < 155)
+    out, st, err, me = orc.lk_track(a, b, pts)
+    assert st[inner].all()
+    d = (out - pts)[inner] - np.array(shift, np.float32)
+    assert np.abs(d).max() < 0.12, np.abs(d).max()
+    assert np.abs(d).mean() < 0.04
+    if shift == (0.0, 0.0):
+        assert np.abs(out - pts)[st == 1].max() == 0.0
+        assert err[st == 1].max() == 0.0
+
+
+def test_lk_low_texture_and_border_status(orc):
+    a, b = synth.textured_pair(200, 160, 3, shift=(1.0, 0.5), seed=9)
+    a[60:110, 70:130] = 100  # flat patch: minEig below threshold
+    b[60:110, 70:130] = 100
+    pts = np.array([[100, 85],      # centre of the flat patch -> status 0
+                    [30, 30],       # textured -> status 1
+                    [-40.0, 50.0],  # window entirely left of the image -> status 0
+                    [199.0, 159.0],  # corner: window straddles the border, still inside the padding
+                    [400.0, 80.0]], np.float32)
+    out, st, err, me = orc.lk_track(a, b, pts)
+    assert st[0] == 0 and me[0] < 1e-4
+    assert st[1] == 1
+    assert st[2] == 0 and st[4] == 0
+    assert err[0] == 0 and err[2] == 0
+
+
+def test_lk_channel_count_changes_min_eig_not_flow(orc):
+    """OpenCV sums the normal equations over channels but normalises minEig by the window
+    area only: replicated BGR triples minEig, leaves the flow."""
+    a1, b1 = synth.textured_pair(240, 160, 1, shift=(1.7, 0.9), seed=4)
+    a3, b3 = np.repeat(a1, 3, 2), np.repeat(b1, 3, 2)
+    pts = orc.grid_keypoints(160, 240, 25)
+    o1, s1, _, m1 = orc.lk_track(a1, b1, pts)
+    o3, s3, _, m3 = orc.lk_track(a3, b3, pts)
+    ok = (s1 == 1) & (s3 == 1)
+    assert ok.sum() > 10
+    assert np.allclose(m3[ok], 3 * m1[ok], rtol=1e-5)
+    assert np.abs(o1[ok] - o3[ok]).max() < 2e-2
+
+
+def test_grid_matches_reference_loop(orc):
+    # src/tracking.cpp:4-12 on 1241x376: step 30 -> 40 x 11 = 440; step 10 -> 4428; step 7 -> 9152
+    for step, n in ((30, 440), (20, 1037), (10, 4428), (7, 9152)):
+        g = orc.grid_keypoints(376, 1241, step)
+        assert len(g) == n
+        assert g[0].tolist() == [step, step]
+        ref = [(x, y) for y in range(step, 376 - step, step) for x in range(step, 1241 - step, step)]
+        assert np.array_equal(g, np.array(ref, np.float32))
