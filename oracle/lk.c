@@ -156,6 +156,10 @@ static int16_t *pad_deriv(const int16_t *src, int w, int h, int c)
 static inline int cv_round_f(float v) { return (int)lrintf(v); } /* round-half-even */
 static inline int cv_floor_f(float v) { return (int)floorf(v); }
 
+/* optional instrumentation: per-point iteration count summed over levels (tests/bench) */
+static int *g_iter_counter = 0;
+void orc_lk_set_iter_counter(int *buf) { g_iter_counter = buf; }
+
 typedef struct {
     int w, h;
     uint8_t *img;   /* unpadded level */
@@ -317,6 +321,8 @@ int orc_lk_track(const uint8_t *prev, const uint8_t *next, int w, int h, int c,
                 iw10 = cv_round_f((1.f - a) * b * (1 << W_BITS));
                 iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
                 int64_t sb1 = 0, sb2 = 0;
+                if (g_iter_counter)
+                    g_iter_counter[p]++;
                 for (int y = 0; y < win; y++)
                     for (int x = 0; x < win; x++)
                         for (int ch = 0; ch < c; ch++) {

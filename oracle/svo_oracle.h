@@ -55,6 +55,9 @@ int orc_lk_track(const uint8_t *prev, const uint8_t *next, int w, int h, int c,
                  const float *prev_pts, int n, float *next_pts, uint8_t *status,
                  float *err, float *min_eig, const orc_lk_params *params);
 
+/* instrumentation: if set, buf[p] accumulates the iteration count of point p over levels */
+void orc_lk_set_iter_counter(int *buf);
+
 /* ---- dense grid sampler: src/tracking.cpp:4-12 ---------------------------------------- */
 /* returns count; writes x,y pairs (float) if out != NULL (capacity cap points) */
 int orc_grid_keypoints(int rows, int cols, int step, float *out_xy, int cap);

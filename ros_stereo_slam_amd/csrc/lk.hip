@@ -9,8 +9,8 @@
 // of one point depend on each other, points never do).  Lane l owns window row l/3 and a
 // 7-pixel segment (l%3) of it, i.e. 7*C patch elements that stay in VGPRs for the whole
 // level (template patch I and both derivative patches).  Per level a wave
-//   1. stages the 24x24 neighbourhood of the previous image in LDS (row-contiguous loads,
-//      reflect-101 border), derives the 22x22 Scharr tile LDS->LDS (zero outside the
+//   1. stages the 24x24 neighbourhood of the previous image in LDS (aligned 16-byte row
+//      loads from the padded pyramid level, no border arithmetic), derives the 22x22 Scharr tile LDS->LDS (zero outside the
 //      image, as OpenCV pads the derivative buffer), builds its patch registers and the
 //      2x2 normal matrix;
 //   2. stages a (22+2*JR)^2 tile of the next image around the current guess and iterates
@@ -31,7 +31,8 @@ constexpr int TS = WIN + 1 + 2 * JR;   // 32: J tile side
 constexpr int PT = WIN + 3;            // 24: previous-image tile side (Scharr + bilinear halo)
 constexpr int DT = WIN + 1;            // 22: derivative tile side
 constexpr int SEG = 7;                 // pixels per lane; 3 lanes per window row
-constexpr int WAVES = 4;               // waves (= keypoints) per workgroup
+constexpr int WAVES = 1;               // waves (= keypoints) per workgroup: a slow point never
+                                       // holds the LDS of finished neighbours
 constexpr int W_BITS = 14;
 
 struct LkParams {
@@ -41,20 +42,22 @@ struct LkParams {
     float min_eig_thr;
 };
 
+// An LDS tile keeps the 16-byte-aligned row segments exactly as loaded: row r, byte b of
+// the tile lives at r*ROW + shift + b, where shift = (address of the tile origin) & 15 is
+// the same for every row because the level pitch is a multiple of 16.
+template <int C, int SIDE> struct Tile {
+    static constexpr int ROWB = SIDE * C;
+    static constexpr int VEC = (ROWB + 15 + 15) / 16;  // 16-byte vectors per row, any shift
+    static constexpr int ROW = VEC * 16;
+    static constexpr int BYTES = SIDE * ROW;
+};
 template <int C> struct Lds {
-    static constexpr int T_BYTES = ((PT * PT * C + 15) / 16) * 16;
+    static constexpr int T_BYTES = Tile<C, PT>::BYTES;
     static constexpr int D_BYTES = DT * DT * C * 4;
-    static constexpr int J_BYTES = TS * TS * C;
+    static constexpr int J_BYTES = Tile<C, TS>::BYTES;
     static constexpr int A = T_BYTES + D_BYTES;
     static constexpr int WAVE_BYTES = (((A > J_BYTES ? A : J_BYTES) + 15) / 16) * 16;
 };
-
-__device__ __forceinline__ int reflect101(int p, int len)
-{
-    while (p < 0 || p >= len)
-        p = p < 0 ? -p : 2 * (len - 1) - p;
-    return p;
-}
 
 // LDS produced by some lanes of a wave and consumed by others of the SAME wave: LDS
 // instructions of one wave execute in order; this only stops the compiler from moving
@@ -66,15 +69,27 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ long long wave_sum_i64(long long v)
+// Exact sum over the 64 lanes of a per-lane int32 partial (|v| < 2^30).  The partial is split
+// into its low 16 bits and its (signed) high part; each half is summed with DPP butterflies
+// inside the 16-lane rows (no carries can occur: 64 * 2^16 < 2^31) and the four row totals
+// are combined on the scalar unit.  Result is wave-uniform.
+__device__ __forceinline__ int row16_sum(int v)
 {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        int lo = __shfl_xor((int)(v & 0xffffffffll), off);
-        int hi = __shfl_xor((int)(v >> 32), off);
-        v += ((long long)hi << 32) | (long long)(unsigned)lo;
-    }
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);  // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);  // row_mirror
     return v;
+}
+__device__ __forceinline__ long long wave_sum_i64(int v)
+{
+    int lo = row16_sum(v & 0xffff);
+    int hi = row16_sum(v >> 16);
+    int slo = __builtin_amdgcn_readlane(lo, 0) + __builtin_amdgcn_readlane(lo, 16) +
+              __builtin_amdgcn_readlane(lo, 32) + __builtin_amdgcn_readlane(lo, 48);
+    int shi = __builtin_amdgcn_readlane(hi, 0) + __builtin_amdgcn_readlane(hi, 16) +
+              __builtin_amdgcn_readlane(hi, 32) + __builtin_amdgcn_readlane(hi, 48);
+    return (long long)shi * 65536ll + (long long)slo;
 }
 
 __device__ __forceinline__ void bilinear_weights(float a, float b, int &w00, int &w01, int &w10,
@@ -86,51 +101,123 @@ __device__ __forceinline__ void bilinear_weights(float a, float b, int &w00, int
     w11 = (1 << W_BITS) - w00 - w01 - w10;
 }
 
-template <int C>
-__device__ __forceinline__ void stage_tile(uint8_t *tile, int side, const uint8_t *__restrict__ img,
-                                           int lw, int lh, int ox, int oy, int lane)
+// Stage a SIDE x SIDE pixel tile whose top-left pixel is (ox, oy) into LDS with aligned
+// 16-byte loads (global_load_dwordx4 -> ds_write_b128).  Returns the byte shift of the tile.
+template <int C, int SIDE>
+__device__ __forceinline__ int stage_tile(uint8_t *tile, const uint8_t *__restrict__ lvl, int pitch, int ox,
+                                          int oy, int lane)
 {
-    const int rowb = side * C;
-    for (int i = lane; i < side * rowb; i += 64) {
-        int r = i / rowb, cc = i - r * rowb;
-        int px = cc / C, ch = cc - px * C;
-        int X = reflect101(ox + px, lw), Y = reflect101(oy + r, lh);
-        tile[i] = img[((size_t)Y * lw + X) * C + ch];
+    using TL = Tile<C, SIDE>;
+    const uint8_t *origin = lvl + (ptrdiff_t)oy * pitch + (ptrdiff_t)ox * C;
+    const int shift = (int)(reinterpret_cast<uintptr_t>(origin) & 15);
+    const uint8_t *a16 = origin - shift;
+    constexpr int N = SIDE * TL::VEC;
+    constexpr int ITER = (N + 63) / 64;
+    uint4 v[ITER];
+#pragma unroll
+    for (int k = 0; k < ITER; k++) {
+        int i = lane + 64 * k;
+        if (N % 64 != 0 && i >= N)
+            i = N - 1;
+        int r = i / TL::VEC, vv = i - r * TL::VEC;
+        v[k] = *reinterpret_cast<const uint4 *>(a16 + (ptrdiff_t)r * pitch + vv * 16);
     }
+#pragma unroll
+    for (int k = 0; k < ITER; k++) {
+        int i = lane + 64 * k;
+        if (N % 64 == 0 || i < N)
+            *reinterpret_cast<uint4 *>(tile + i * 16) = v[k];
+    }
+    return shift;
 }
 
-// sum over this lane's 7*C elements of (J - I) * {Ix, Iy}   (or |J - I| when ABS)
+// Read (SEG+1)*C consecutive LDS bytes into registers as individual ds_read_u8.  Left to the
+// compiler these byte loads are merged into b64/b128 reads that are misaligned (tile shift +
+// 3-byte pixels) and replay at 64 cycles each.  No wait inside: the caller issues
+// lds_wait_all() before the first use (cdna_hip_programming.md section 5.7).
+template <int C> __device__ __forceinline__ void lds_read_row_bytes(unsigned addr, int (&r)[(SEG + 1) * C]);
+template <> __device__ __forceinline__ void lds_read_row_bytes<1>(unsigned addr, int (&r)[8])
+{
+    asm volatile("ds_read_u8 %0, %8 offset:0\n\tds_read_u8 %1, %8 offset:1\n\tds_read_u8 %2, %8 offset:2\n\t"
+                 "ds_read_u8 %3, %8 offset:3\n\tds_read_u8 %4, %8 offset:4\n\tds_read_u8 %5, %8 offset:5\n\t"
+                 "ds_read_u8 %6, %8 offset:6\n\tds_read_u8 %7, %8 offset:7"
+                 : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]),
+                   "=&v"(r[7])
+                 : "v"(addr));
+}
+template <> __device__ __forceinline__ void lds_read_row_bytes<3>(unsigned addr, int (&r)[24])
+{
+    asm volatile("ds_read_u8 %0, %24 offset:0\n\tds_read_u8 %1, %24 offset:1\n\tds_read_u8 %2, %24 offset:2\n\t"
+                 "ds_read_u8 %3, %24 offset:3\n\tds_read_u8 %4, %24 offset:4\n\tds_read_u8 %5, %24 offset:5\n\t"
+                 "ds_read_u8 %6, %24 offset:6\n\tds_read_u8 %7, %24 offset:7\n\tds_read_u8 %8, %24 offset:8\n\t"
+                 "ds_read_u8 %9, %24 offset:9\n\tds_read_u8 %10, %24 offset:10\n\tds_read_u8 %11, %24 offset:11\n\t"
+                 "ds_read_u8 %12, %24 offset:12\n\tds_read_u8 %13, %24 offset:13\n\tds_read_u8 %14, %24 offset:14\n\t"
+                 "ds_read_u8 %15, %24 offset:15\n\tds_read_u8 %16, %24 offset:16\n\tds_read_u8 %17, %24 offset:17\n\t"
+                 "ds_read_u8 %18, %24 offset:18\n\tds_read_u8 %19, %24 offset:19\n\tds_read_u8 %20, %24 offset:20\n\t"
+                 "ds_read_u8 %21, %24 offset:21\n\tds_read_u8 %22, %24 offset:22\n\tds_read_u8 %23, %24 offset:23"
+                 : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]),
+                   "=&v"(r[7]), "=&v"(r[8]), "=&v"(r[9]), "=&v"(r[10]), "=&v"(r[11]), "=&v"(r[12]), "=&v"(r[13]),
+                   "=&v"(r[14]), "=&v"(r[15]), "=&v"(r[16]), "=&v"(r[17]), "=&v"(r[18]), "=&v"(r[19]),
+                   "=&v"(r[20]), "=&v"(r[21]), "=&v"(r[22]), "=&v"(r[23])
+                 : "v"(addr));
+}
+__device__ __forceinline__ void lds_wait_all()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);  // nothing may be hoisted above the wait
+}
+// LDS byte offset of a pointer into the dynamic shared segment
+__device__ __forceinline__ unsigned lds_offset(const void *p)
+{
+    return (unsigned)(uintptr_t)p;  // the low 32 bits of a generic LDS address are the LDS offset
+}
+
+typedef short short2v __attribute__((ext_vector_type(2)));
+constexpr int npairs(int c) { return (SEG * c + 1) / 2; }
+
+// One lane's share of  sum (J - I) * {Ix, Iy}  (or sum |J - I| when ABS) over its 7*C patch
+// elements.  Patch registers hold element PAIRS as packed int16 (I is 14 bits, derivatives
+// 13 bits): the bilinear samples of two elements are packed, subtracted with one
+// v_pk_sub_i16 and fed to v_dot2_i32_i16 against the packed derivatives.
 template <int C, bool ABS>
-__device__ __forceinline__ void lane_residual(const uint8_t *tj, int tx, int ty, int w00, int w01,
-                                              int w10, int w11, const int (&Iv)[SEG * C],
-                                              const int (&Ix)[SEG * C], const int (&Iy)[SEG * C],
+__device__ __forceinline__ void lane_residual(const uint8_t *tj, int tx, int ty, int w00, int w01, int w10,
+                                              int w11, const int (&Ivp)[npairs(C)],
+                                              const int (&Ixp)[npairs(C)], const int (&Iyp)[npairs(C)],
                                               int &s1, int &s2)
 {
-    const uint8_t *q0 = tj + (ty * TS + tx) * C;
-    const uint8_t *q1 = q0 + TS * C;
+    const unsigned q0 = lds_offset(tj) + ty * Tile<C, TS>::ROW + tx * C;  // tj includes the tile shift
     int r0[(SEG + 1) * C], r1[(SEG + 1) * C];
-#pragma unroll
-    for (int k = 0; k < (SEG + 1) * C; k++) {
-        r0[k] = q0[k];
-        r1[k] = q1[k];
-    }
+    lds_read_row_bytes<C>(q0, r0);
+    lds_read_row_bytes<C>(q0 + Tile<C, TS>::ROW, r1);
+    lds_wait_all();
     s1 = 0;
     s2 = 0;
+    constexpr int RND = 1 << (W_BITS - 5 - 1);
 #pragma unroll
-    for (int k = 0; k < SEG * C; k++) {
-        int v = r0[k] * w00 + r0[k + C] * w01 + r1[k] * w10 + r1[k + C] * w11;
-        int diff = ((v + (1 << (W_BITS - 5 - 1))) >> (W_BITS - 5)) - Iv[k];
+    for (int j = 0; j < npairs(C); j++) {
+        const int k0 = 2 * j, k1 = 2 * j + 1;
+        // pixel <= 255, -1 <= weight <= 2^14 (the fourth weight, 2^14 minus three rounded
+        // ones, can be -1): signed 24-bit multiply-adds are exact and full rate; the sum
+        // plus the rounding constant is never negative.
+        int v0 = (__mul24(r0[k0], w00) + __mul24(r0[k0 + C], w01) + __mul24(r1[k0], w10) +
+                  __mul24(r1[k0 + C], w11) + RND) >> (W_BITS - 5);
+        int v1 = 0;
+        if (k1 < SEG * C)
+            v1 = (__mul24(r0[k1], w00) + __mul24(r0[k1 + C], w01) + __mul24(r1[k1], w10) +
+                  __mul24(r1[k1 + C], w11) + RND) >> (W_BITS - 5);
+        const short2v d = __builtin_bit_cast(short2v, v0 | (v1 << 16)) - __builtin_bit_cast(short2v, Ivp[j]);
         if (ABS) {
-            s1 += diff < 0 ? -diff : diff;
+            int d0 = d.x, d1 = d.y;
+            s1 += (d0 < 0 ? -d0 : d0) + (k1 < SEG * C ? (d1 < 0 ? -d1 : d1) : 0);
         } else {
-            s1 += diff * Ix[k];
-            s2 += diff * Iy[k];
+            s1 = __builtin_amdgcn_sdot2(d, __builtin_bit_cast(short2v, Ixp[j]), s1, false);
+            s2 = __builtin_amdgcn_sdot2(d, __builtin_bit_cast(short2v, Iyp[j]), s2, false);
         }
     }
 }
 
 template <int C>
-__global__ __launch_bounds__(64 * WAVES) void lk_track_kernel(
+__global__ __launch_bounds__(64 * WAVES, 3) void lk_track_kernel(
     PyrDev prev, PyrDev next, const float *__restrict__ prev_pts, int n,
     float *__restrict__ next_pts, uint8_t *__restrict__ status, float *__restrict__ err,
     float *__restrict__ min_eig_out, LkParams prm)
@@ -145,6 +232,7 @@ __global__ __launch_bounds__(64 * WAVES) void lk_track_kernel(
     int *D = reinterpret_cast<int *>(lds + Lds<C>::T_BYTES);    // DT x DT x C packed (dx | dy<<16)
     uint8_t *TJ = lds;                                          // TS x TS x C bytes (reuses T/D)
 
+    constexpr int TROW = Tile<C, PT>::ROW;
     const bool active = lane < 3 * WIN;
     const int wy = active ? lane / 3 : WIN - 1;  // window row of this lane
     const int ws = active ? lane - 3 * wy : 0;   // segment
@@ -162,6 +250,7 @@ __global__ __launch_bounds__(64 * WAVES) void lk_track_kernel(
         const int lw = prev.w[level], lh = prev.h[level];
         const uint8_t *I = prev.lvl[level];
         const uint8_t *J = next.lvl[level];
+        const int pitch = prev.pitch[level];
         const float scale = 1.f / (float)(1 << level);
         float px = ptx * scale, py = pty * scale;
         float nxp, nyp;
@@ -189,7 +278,7 @@ __global__ __launch_bounds__(64 * WAVES) void lk_track_kernel(
 
         // ---- 1. previous-image tile, Scharr tile, patch registers, normal matrix ----
         wave_lds_sync();
-        stage_tile<C>(T, PT, I, lw, lh, ipx - 1, ipy - 1, lane);
+        const uint8_t *Ts = T + stage_tile<C, PT>(T, I, pitch, ipx - 1, ipy - 1, lane);
         wave_lds_sync();
         for (int i = lane; i < DT * DT * C; i += 64) {
             int yy = i / (DT * C), cc = i - yy * (DT * C);
@@ -197,10 +286,10 @@ __global__ __launch_bounds__(64 * WAVES) void lk_track_kernel(
             int X = ipx + xx, Y = ipy + yy;
             int packed = 0;
             if (X >= 0 && X < lw && Y >= 0 && Y < lh) {
-                const uint8_t *t = T + (yy * PT + xx) * C + ch;  // top-left of the 3x3
+                const uint8_t *t = Ts + yy * TROW + xx * C + ch;  // top-left of the 3x3
                 int a0 = t[0], a1 = t[C], a2 = t[2 * C];
-                int b0 = t[PT * C], b2 = t[PT * C + 2 * C];
-                int c0 = t[2 * PT * C], c1 = t[2 * PT * C + C], c2 = t[2 * PT * C + 2 * C];
+                int b0 = t[TROW], b2 = t[TROW + 2 * C];
+                int c0 = t[2 * TROW], c1 = t[2 * TROW + C], c2 = t[2 * TROW + 2 * C];
                 int dx = 3 * (a2 - a0) + 10 * (b2 - b0) + 3 * (c2 - c0);
                 int dy = 3 * (c0 - a0) + 10 * (c1 - a1) + 3 * (c2 - a2);
                 packed = (dx & 0xffff) | (dy << 16);
@@ -209,28 +298,44 @@ __global__ __launch_bounds__(64 * WAVES) void lk_track_kernel(
         }
         wave_lds_sync();
 
-        int Iv[SEG * C], Ix[SEG * C], Iy[SEG * C];
+        int Ivp[npairs(C)], Ixp[npairs(C)], Iyp[npairs(C)];  // packed int16 pairs (low = even element)
         int a11 = 0, a12 = 0, a22 = 0;
         {
-            const uint8_t *t0 = T + ((wy + 1) * PT + (wx + 1)) * C;
-            const uint8_t *t1 = t0 + PT * C;
+            int t0[(SEG + 1) * C], t1[(SEG + 1) * C];
+            {
+                const unsigned ta = lds_offset(Ts) + (wy + 1) * TROW + (wx + 1) * C;
+                lds_read_row_bytes<C>(ta, t0);
+                lds_read_row_bytes<C>(ta + TROW, t1);
+                lds_wait_all();
+            }
             const int *d0 = D + (wy * DT + wx) * C;
             const int *d1 = d0 + DT * C;
 #pragma unroll
-            for (int k = 0; k < SEG * C; k++) {
-                int v = t0[k] * w00 + t0[k + C] * w01 + t1[k] * w10 + t1[k + C] * w11;
-                Iv[k] = (v + (1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
-                int p00 = d0[k], p01 = d0[k + C], p10 = d1[k], p11 = d1[k + C];
-                int gx = (int)(short)(p00 & 0xffff) * w00 + (int)(short)(p01 & 0xffff) * w01 +
-                         (int)(short)(p10 & 0xffff) * w10 + (int)(short)(p11 & 0xffff) * w11;
-                int gy = (p00 >> 16) * w00 + (p01 >> 16) * w01 + (p10 >> 16) * w10 + (p11 >> 16) * w11;
-                int ix = (gx + (1 << (W_BITS - 1))) >> W_BITS;
-                int iy = (gy + (1 << (W_BITS - 1))) >> W_BITS;
-                Ix[k] = ix;
-                Iy[k] = iy;
-                a11 += ix * ix;
-                a12 += ix * iy;
-                a22 += iy * iy;
+            for (int j = 0; j < npairs(C); j++) {
+                int iv[2] = {0, 0}, ix[2] = {0, 0}, iy[2] = {0, 0};
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const int k = 2 * j + e;
+                    if (k < SEG * C) {
+                        int v = __mul24(t0[k], w00) + __mul24(t0[k + C], w01) + __mul24(t1[k], w10) +
+                                __mul24(t1[k + C], w11);
+                        iv[e] = (v + (1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+                        int p00 = d0[k], p01 = d0[k + C], p10 = d1[k], p11 = d1[k + C];
+                        // |derivative| <= 4080 < 2^12, weight <= 2^14: signed 24-bit multiplies are exact
+                        int gx = __mul24((int)(short)(p00 & 0xffff), w00) + __mul24((int)(short)(p01 & 0xffff), w01) +
+                                 __mul24((int)(short)(p10 & 0xffff), w10) + __mul24((int)(short)(p11 & 0xffff), w11);
+                        int gy = __mul24(p00 >> 16, w00) + __mul24(p01 >> 16, w01) + __mul24(p10 >> 16, w10) +
+                                 __mul24(p11 >> 16, w11);
+                        ix[e] = (gx + (1 << (W_BITS - 1))) >> W_BITS;
+                        iy[e] = (gy + (1 << (W_BITS - 1))) >> W_BITS;
+                        a11 += __mul24(ix[e], ix[e]);
+                        a12 += __mul24(ix[e], iy[e]);
+                        a22 += __mul24(iy[e], iy[e]);
+                    }
+                }
+                Ivp[j] = iv[0] | (iv[1] << 16);
+                Ixp[j] = (ix[0] & 0xffff) | (ix[1] << 16);
+                Iyp[j] = (iy[0] & 0xffff) | (iy[1] << 16);
             }
         }
         if (!active) {
@@ -260,6 +365,7 @@ __global__ __launch_bounds__(64 * WAVES) void lk_track_kernel(
         float pdx = 0.f, pdy = 0.f;
         int ox = 0, oy = 0;
         bool have_tile = false;
+        const uint8_t *TJs = TJ;
         for (int j = 0; j < prm.max_count; j++) {
             const int inx = (int)floorf(nxp), iny = (int)floorf(nyp);
             if (inx < -WIN || inx >= lw || iny < -WIN || iny >= lh) {
@@ -271,13 +377,13 @@ __global__ __launch_bounds__(64 * WAVES) void lk_track_kernel(
                 ox = inx - JR;
                 oy = iny - JR;
                 wave_lds_sync();
-                stage_tile<C>(TJ, TS, J, lw, lh, ox, oy, lane);
+                TJs = TJ + stage_tile<C, TS>(TJ, J, pitch, ox, oy, lane);
                 wave_lds_sync();
                 have_tile = true;
             }
             bilinear_weights(nxp - (float)inx, nyp - (float)iny, w00, w01, w10, w11);
             int s1, s2;
-            lane_residual<C, false>(TJ, inx - ox + wx, iny - oy + wy, w00, w01, w10, w11, Iv, Ix, Iy,
+            lane_residual<C, false>(TJs, inx - ox + wx, iny - oy + wy, w00, w01, w10, w11, Ivp, Ixp, Iyp,
                                     s1, s2);
             if (!active) {
                 s1 = 0;
@@ -315,17 +421,17 @@ __global__ __launch_bounds__(64 * WAVES) void lk_track_kernel(
                 ox = iqx - JR;
                 oy = iqy - JR;
                 wave_lds_sync();
-                stage_tile<C>(TJ, TS, J, lw, lh, ox, oy, lane);
+                TJs = TJ + stage_tile<C, TS>(TJ, J, pitch, ox, oy, lane);
                 wave_lds_sync();
                 have_tile = true;
             }
             bilinear_weights(qx - (float)iqx, qy - (float)iqy, w00, w01, w10, w11);
             int s1, s2;
-            lane_residual<C, true>(TJ, iqx - ox + wx, iqy - oy + wy, w00, w01, w10, w11, Iv, Ix, Iy, s1,
+            lane_residual<C, true>(TJs, iqx - ox + wx, iqy - oy + wy, w00, w01, w10, w11, Ivp, Ixp, Iyp, s1,
                                    s2);
             if (!active)
                 s1 = 0;
-            const long long sabs = wave_sum_i64(s1);
+            const long long sabs = wave_sum_i64(s1);  // < 2^24
             errv = (float)sabs / (float)(32 * WIN * C * WIN);
         }
     }

@@ -1,11 +1,14 @@
 // pyramid.hip -- 5-tap Gaussian pyramid (the pyrDown cv::calcOpticalFlowPyrLK applies to
 // both images on every call; reference call sites src/tracking.cpp:18,52).
 //
-// One workgroup produces a 32x8-pixel output tile.  Its (2*32+3) x (2*8+3) source tile is
-// staged in LDS with coalesced row loads (consecutive lanes -> consecutive bytes of one
-// image row), the separable [1 4 6 4 1] filter runs LDS -> LDS (horizontal, uint16) and
-// LDS -> HBM (vertical, (sum+128)>>8).  BORDER_REFLECT_101 is applied while staging.
-// HBM traffic per level: source read ~once (+ halo), destination written once.
+// HBM layout: every level is stored with a reflect-101 border of SVO_PYR_PAD pixels and a
+// 16-byte-aligned row pitch (what cv::buildOpticalFlowPyramid does with pyrBorder =
+// BORDER_REFLECT_101), so the LK kernel stages its tiles with aligned 16-byte loads.
+//
+// Kernels: pad_copy (image -> padded level 0), pyr_down (one workgroup per 32x8 output
+// tile; the (2*32+3) x (2*8+3) source tile is staged in LDS with row-contiguous loads, the
+// separable [1 4 6 4 1] filter runs LDS -> LDS (horizontal, uint16) and LDS -> HBM
+// (vertical, (sum+128)>>8)), fill_border (levels 1..3 in one launch).
 #include "svo_internal.h"
 
 namespace {
@@ -24,9 +27,9 @@ constexpr int TW = 32, TH = 8;
 constexpr int SW = 2 * TW + 3, SH = 2 * TH + 3;
 
 template <int C>
-__global__ __launch_bounds__(256) void pyr_down_kernel(const uint8_t *__restrict__ src, int w,
-                                                       int h, uint8_t *__restrict__ dst, int dw,
-                                                       int dh)
+__global__ __launch_bounds__(256) void pyr_down_kernel(const uint8_t *__restrict__ src, int spitch,
+                                                       int w, int h, uint8_t *__restrict__ dst,
+                                                       int dpitch, int dw, int dh)
 {
     constexpr int SROW = ((SW * C + 3) / 4) * 4;
     __shared__ uint8_t s_src[SH * SROW];
@@ -39,7 +42,7 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const uint8_t *__restrict
         int px = cc / C, ch = cc - px * C;
         int sx = reflect101(2 * ox - 2 + px, w);
         int sy = reflect101(2 * oy - 2 + r, h);
-        s_src[r * SROW + cc] = src[((size_t)sy * w + sx) * C + ch];
+        s_src[r * SROW + cc] = src[(size_t)sy * spitch + sx * C + ch];
     }
     __syncthreads();
     for (int i = tid; i < SH * TW * C; i += 256) {
@@ -55,33 +58,118 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const uint8_t *__restrict
         if (X < dw && Y < dh) {
             int v = s_h[2 * y][cc] + 4 * s_h[2 * y + 1][cc] + 6 * s_h[2 * y + 2][cc] +
                     4 * s_h[2 * y + 3][cc] + s_h[2 * y + 4][cc];
-            dst[((size_t)Y * dw + X) * C + (cc % C)] = (uint8_t)((v + 128) >> 8);
+            dst[(size_t)Y * dpitch + X * C + (cc % C)] = (uint8_t)((v + 128) >> 8);
         }
+    }
+}
+
+
+// image (row stride w*C) -> padded level 0, one thread per output dword
+template <int C>
+__global__ __launch_bounds__(256) void pad_copy_kernel(const uint8_t *__restrict__ src, int w, int h,
+                                                       uint8_t *__restrict__ padded, int pitch)
+{
+    const int dwords_per_row = pitch >> 2;
+    const int row = blockIdx.y;  // 0 .. h + 2*PAD - 1
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= dwords_per_row)
+        return;
+    const int Y = reflect101(row - SVO_PYR_PAD, h);
+    const uint8_t *srow = src + (size_t)Y * w * C;
+    uint32_t out = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        int cb = d * 4 + b;
+        int px = cb / C, ch = cb - px * C;
+        if (px < w + 2 * SVO_PYR_PAD) {
+            int X = reflect101(px - SVO_PYR_PAD, w);
+            out |= (uint32_t)srow[X * C + ch] << (8 * b);
+        }
+    }
+    reinterpret_cast<uint32_t *>(padded + (size_t)row * pitch)[d] = out;
+}
+
+struct BorderJob {
+    uint8_t *padded[SVO_MAX_LEVELS];
+    int pitch[SVO_MAX_LEVELS], w[SVO_MAX_LEVELS], h[SVO_MAX_LEVELS];
+};
+
+// fills the reflect-101 border of levels 1.. (blockIdx.z = level - 1) from their interior
+template <int C>
+__global__ __launch_bounds__(256) void fill_border_kernel(BorderJob job)
+{
+    const int l = blockIdx.z + 1;
+    const int w = job.w[l], h = job.h[l], pitch = job.pitch[l];
+    const int row = blockIdx.y;
+    if (row >= h + 2 * SVO_PYR_PAD)
+        return;
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= (pitch >> 2))
+        return;
+    const bool interior_row = row >= SVO_PYR_PAD && row < SVO_PYR_PAD + h;
+    const int cb0 = d * 4;
+    if (interior_row && cb0 >= SVO_PYR_PAD * C && cb0 + 3 < (SVO_PYR_PAD + w) * C)
+        return;  // dword entirely inside the image: already written by pyr_down
+    uint8_t *prow = job.padded[l] + (size_t)row * pitch;
+    const int Y = reflect101(row - SVO_PYR_PAD, h);
+    const uint8_t *srow = job.padded[l] + (size_t)(Y + SVO_PYR_PAD) * pitch + SVO_PYR_PAD * C;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        int cb = cb0 + b;
+        int px = cb / C, ch = cb - px * C;
+        bool inside = interior_row && px >= SVO_PYR_PAD && px < SVO_PYR_PAD + w;
+        if (inside)
+            continue;
+        uint8_t v = 0;
+        if (px < w + 2 * SVO_PYR_PAD)
+            v = srow[reflect101(px - SVO_PYR_PAD, w) * C + ch];
+        prow[cb] = v;
     }
 }
 
 }  // namespace
 
-int svo_launch_pyr_down(svo_ctx *ctx, const uint8_t *src, int w, int h, int c, uint8_t *dst)
+template <int C> static int build_levels(svo_ctx *ctx, svo_pyramid *pyr, const uint8_t *d_image)
 {
-    int dw = (w + 1) / 2, dh = (h + 1) / 2;
-    dim3 grid((dw + TW - 1) / TW, (dh + TH - 1) / TH);
-    switch (c) {
-    case 1:
-        hipLaunchKernelGGL(pyr_down_kernel<1>, grid, dim3(256), 0, ctx->stream, src, w, h, dst, dw, dh);
-        break;
-    case 3:
-        hipLaunchKernelGGL(pyr_down_kernel<3>, grid, dim3(256), 0, ctx->stream, src, w, h, dst, dw, dh);
-        break;
-    case 4:
-        hipLaunchKernelGGL(pyr_down_kernel<4>, grid, dim3(256), 0, ctx->stream, src, w, h, dst, dw, dh);
-        break;
-    default:
-        svo_set_error("pyr_down: unsupported channel count %d (1, 3 or 4)", c);
-        return SVO_ERR_ARG;
+    const PyrDev &d = pyr->dev;
+    {
+        dim3 grid(((d.pitch[0] >> 2) + 255) / 256, d.h[0] + 2 * SVO_PYR_PAD);
+        hipLaunchKernelGGL(pad_copy_kernel<C>, grid, dim3(256), 0, ctx->stream, d_image, d.w[0], d.h[0],
+                           pyr->base + pyr->off[0], d.pitch[0]);
+    }
+    for (int l = 1; l < pyr->levels; l++) {
+        dim3 grid((d.w[l] + TW - 1) / TW, (d.h[l] + TH - 1) / TH);
+        hipLaunchKernelGGL(pyr_down_kernel<C>, grid, dim3(256), 0, ctx->stream, pyr->origin(l - 1),
+                           d.pitch[l - 1], d.w[l - 1], d.h[l - 1], pyr->origin(l), d.pitch[l], d.w[l], d.h[l]);
+    }
+    if (pyr->levels > 1) {
+        BorderJob job;
+        for (int l = 0; l < SVO_MAX_LEVELS; l++) {
+            job.padded[l] = l < pyr->levels ? pyr->base + pyr->off[l] : nullptr;
+            job.pitch[l] = d.pitch[l];
+            job.w[l] = d.w[l];
+            job.h[l] = d.h[l];
+        }
+        dim3 grid(((d.pitch[1] >> 2) + 255) / 256, d.h[1] + 2 * SVO_PYR_PAD, pyr->levels - 1);
+        hipLaunchKernelGGL(fill_border_kernel<C>, grid, dim3(256), 0, ctx->stream, job);
     }
     SVO_HIP(hipGetLastError());
     return SVO_OK;
+}
+
+int svo_build_pyramid_from_device(svo_ctx *ctx, svo_pyramid *pyr, const uint8_t *d_image)
+{
+    ScopedKernelTime t(ctx, SVO_K_PYRAMID);
+    switch (pyr->c) {
+    case 1:
+        return build_levels<1>(ctx, pyr, d_image);
+    case 3:
+        return build_levels<3>(ctx, pyr, d_image);
+    case 4:
+        return build_levels<4>(ctx, pyr, d_image);
+    }
+    svo_set_error("pyramid: unsupported channel count %d (1, 3 or 4)", pyr->c);
+    return SVO_ERR_ARG;
 }
 
 extern "C" {
@@ -93,6 +181,7 @@ int svo_pyramid_create(svo_ctx *ctx, int width, int height, int channels, int le
     SVO_CHECK_ARG(width >= 2 * SVO_LK_WIN + 2 && height >= 2 * SVO_LK_WIN + 2);
     SVO_CHECK_ARG(channels == 1 || channels == 3 || channels == 4);
     SVO_CHECK_ARG(levels >= 1 && levels <= SVO_MAX_LEVELS);
+    SVO_CHECK_ARG((width >> (levels - 1)) >= 2 && (height >> (levels - 1)) >= 2);
     SVO_HIP(hipSetDevice(ctx->device));
     svo_pyramid *p = new svo_pyramid();
     p->w = width;
@@ -101,25 +190,34 @@ int svo_pyramid_create(svo_ctx *ctx, int width, int height, int channels, int le
     p->levels = levels;
     size_t off = 0;
     int w = width, h = height;
-    for (int l = 0; l < levels; l++) {
+    for (int l = 0; l < SVO_MAX_LEVELS; l++) {
         p->off[l] = off;
         p->dev.w[l] = w;
         p->dev.h[l] = h;
-        off += ((size_t)w * h * channels + 255) & ~(size_t)255;
+        p->dev.pitch[l] = (((w + 2 * SVO_PYR_PAD) * channels + 15) / 16) * 16;
+        if (l < levels)
+            off += ((size_t)p->dev.pitch[l] * (h + 2 * SVO_PYR_PAD) + 255) & ~(size_t)255;
         w = (w + 1) / 2;
         h = (h + 1) / 2;
     }
-    p->bytes = off;
+    p->bytes = off + 256;  // slack: 16-byte tile loads may run a few bytes past the last row
     hipError_t e = hipMalloc((void **)&p->base, p->bytes);
     if (e != hipSuccess) {
         delete p;
         svo_set_error("hipMalloc pyramid -> %s", hipGetErrorString(e));
         return SVO_ERR_HIP;
     }
-    for (int l = 0; l < SVO_MAX_LEVELS; l++)
-        p->dev.lvl[l] = l < levels ? p->base + p->off[l] : nullptr;
+    e = hipMemsetAsync(p->base, 0, p->bytes, ctx->stream);
+    if (e != hipSuccess) {
+        (void)hipFree(p->base);
+        delete p;
+        svo_set_error("hipMemset pyramid -> %s", hipGetErrorString(e));
+        return SVO_ERR_HIP;
+    }
     p->dev.levels = levels;
     p->dev.c = channels;
+    for (int l = 0; l < SVO_MAX_LEVELS; l++)
+        p->dev.lvl[l] = l < levels ? p->origin(l) : nullptr;
     *out = p;
     return SVO_OK;
 }
@@ -143,18 +241,17 @@ int svo_pyramid_build(svo_ctx *ctx, svo_pyramid *pyr, const uint8_t *image, int 
     SVO_CHECK_ARG(ctx && pyr && image);
     SVO_CHECK_ARG(mem == SVO_MEM_HOST || mem == SVO_MEM_DEVICE);
     const size_t l0 = (size_t)pyr->w * pyr->h * pyr->c;
-    SVO_HIP(hipMemcpyAsync(pyr->base, image, l0,
-                           mem == SVO_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice,
-                           ctx->stream));
-    {
-        ScopedKernelTime t(ctx, SVO_K_PYRAMID);
-        for (int l = 1; l < pyr->levels; l++) {
-            int rc = svo_launch_pyr_down(ctx, pyr->base + pyr->off[l - 1], pyr->dev.w[l - 1],
-                                         pyr->dev.h[l - 1], pyr->c, pyr->base + pyr->off[l]);
-            if (rc != SVO_OK)
-                return rc;
-        }
+    const uint8_t *d_image = image;
+    if (mem == SVO_MEM_HOST) {
+        int rc = ctx->s_img.ensure(l0);
+        if (rc)
+            return rc;
+        SVO_HIP(hipMemcpyAsync(ctx->s_img.p, image, l0, hipMemcpyHostToDevice, ctx->stream));
+        d_image = ctx->s_img.as<uint8_t>();
     }
+    int rc = svo_build_pyramid_from_device(ctx, pyr, d_image);
+    if (rc)
+        return rc;
     if (mem == SVO_MEM_HOST)
         SVO_HIP(hipStreamSynchronize(ctx->stream));
     return SVO_OK;
@@ -169,10 +266,11 @@ int svo_pyramid_get_level(svo_ctx *ctx, const svo_pyramid *pyr, int level, uint8
     if (h)
         *h = pyr->dev.h[level];
     if (out) {
-        size_t sz = (size_t)pyr->dev.w[level] * pyr->dev.h[level] * pyr->c;
-        SVO_HIP(hipMemcpyAsync(out, pyr->base + pyr->off[level], sz,
-                               mem == SVO_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice,
-                               ctx->stream));
+        const size_t rowb = (size_t)pyr->dev.w[level] * pyr->c;
+        SVO_HIP(hipMemcpy2DAsync(out, rowb, pyr->origin(level), pyr->dev.pitch[level], rowb,
+                                 pyr->dev.h[level],
+                                 mem == SVO_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice,
+                                 ctx->stream));
         if (mem == SVO_MEM_HOST)
             SVO_HIP(hipStreamSynchronize(ctx->stream));
     }

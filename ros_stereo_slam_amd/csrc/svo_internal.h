@@ -13,6 +13,10 @@
 
 #define SVO_MAX_LEVELS 4
 #define SVO_LK_WIN 21
+// Every pyramid level is stored with a reflect-101 border of SVO_PYR_PAD pixels on each
+// side and a 16-byte-aligned row pitch, so the LK kernel stages tiles with aligned 16-byte
+// loads and no border arithmetic (the furthest it reaches outside the image is 26 px).
+#define SVO_PYR_PAD 32
 
 void svo_set_error(const char *fmt, ...);
 
@@ -35,7 +39,8 @@ void svo_set_error(const char *fmt, ...);
 
 // device-visible description of one pyramid (passed to kernels by value)
 struct PyrDev {
-    const uint8_t *lvl[SVO_MAX_LEVELS];
+    const uint8_t *lvl[SVO_MAX_LEVELS];  // address of pixel (0,0); rows/cols -PAD..size+PAD-1 are valid
+    int pitch[SVO_MAX_LEVELS];           // bytes per row, multiple of 16
     int w[SVO_MAX_LEVELS];
     int h[SVO_MAX_LEVELS];
     int levels;
@@ -44,8 +49,12 @@ struct PyrDev {
 
 struct svo_pyramid {
     int w, h, c, levels;
-    uint8_t *base;   // one HBM allocation, levels back to back (256-B aligned each)
-    size_t off[SVO_MAX_LEVELS];
+    uint8_t *base;   // one HBM allocation, padded levels back to back (256-B aligned each)
+    size_t off[SVO_MAX_LEVELS];  // offset of each level's padded buffer
+    uint8_t *origin(int l) const
+    {
+        return base + off[l] + (size_t)SVO_PYR_PAD * dev.pitch[l] + (size_t)SVO_PYR_PAD * c;
+    }
     size_t bytes;
     PyrDev dev;
 };
@@ -90,7 +99,7 @@ struct ScopedKernelTime {
 int svo_resolve_timers(svo_ctx *ctx);
 
 // pyramid.hip
-int svo_launch_pyr_down(svo_ctx *ctx, const uint8_t *src, int w, int h, int c, uint8_t *dst);
+int svo_build_pyramid_from_device(svo_ctx *ctx, svo_pyramid *pyr, const uint8_t *d_image);
 // lk.hip
 int svo_launch_lk(svo_ctx *ctx, const PyrDev &prev, const PyrDev &next, const float *prev_pts,
                   int n, float *next_pts, uint8_t *status, float *err, float *min_eig);
