@@ -131,6 +131,16 @@ __device__ __forceinline__ int stage_tile(uint8_t *tile, const uint8_t *__restri
     return shift;
 }
 
+// d = a * b + c with 24-bit signed operands (full-rate v_mad_i32_i24).  hipcc has no builtin
+// for it and lowers __mul24 to sign-extension + quarter-rate v_mul_lo_u32 when it cannot
+// prove the operand ranges, so it is spelled out.  Exact here: |a|,|b| < 2^23 by construction.
+__device__ __forceinline__ int mad24(int a, int b, int c)
+{
+    int d;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
 // Read (SEG+1)*C consecutive LDS bytes into registers as individual ds_read_u8.  Left to the
 // compiler these byte loads are merged into b64/b128 reads that are misaligned (tile shift +
 // 3-byte pixels) and replay at 64 cycles each.  No wait inside: the caller issues
@@ -199,12 +209,12 @@ __device__ __forceinline__ void lane_residual(const uint8_t *tj, int tx, int ty,
         // pixel <= 255, -1 <= weight <= 2^14 (the fourth weight, 2^14 minus three rounded
         // ones, can be -1): signed 24-bit multiply-adds are exact and full rate; the sum
         // plus the rounding constant is never negative.
-        int v0 = (__mul24(r0[k0], w00) + __mul24(r0[k0 + C], w01) + __mul24(r1[k0], w10) +
-                  __mul24(r1[k0 + C], w11) + RND) >> (W_BITS - 5);
+        int v0 = mad24(r0[k0], w00, mad24(r0[k0 + C], w01, mad24(r1[k0], w10, mad24(r1[k0 + C], w11, RND)))) >>
+                 (W_BITS - 5);
         int v1 = 0;
         if (k1 < SEG * C)
-            v1 = (__mul24(r0[k1], w00) + __mul24(r0[k1 + C], w01) + __mul24(r1[k1], w10) +
-                  __mul24(r1[k1 + C], w11) + RND) >> (W_BITS - 5);
+            v1 = mad24(r0[k1], w00, mad24(r0[k1 + C], w01, mad24(r1[k1], w10, mad24(r1[k1 + C], w11, RND)))) >>
+                 (W_BITS - 5);
         const short2v d = __builtin_bit_cast(short2v, v0 | (v1 << 16)) - __builtin_bit_cast(short2v, Ivp[j]);
         if (ABS) {
             int d0 = d.x, d1 = d.y;
@@ -317,20 +327,19 @@ __global__ __launch_bounds__(64 * WAVES, 3) void lk_track_kernel(
                 for (int e = 0; e < 2; e++) {
                     const int k = 2 * j + e;
                     if (k < SEG * C) {
-                        int v = __mul24(t0[k], w00) + __mul24(t0[k + C], w01) + __mul24(t1[k], w10) +
-                                __mul24(t1[k + C], w11);
-                        iv[e] = (v + (1 << (W_BITS - 5 - 1))) >> (W_BITS - 5);
+                        iv[e] = mad24(t0[k], w00, mad24(t0[k + C], w01, mad24(t1[k], w10,
+                                      mad24(t1[k + C], w11, 1 << (W_BITS - 5 - 1))))) >> (W_BITS - 5);
                         int p00 = d0[k], p01 = d0[k + C], p10 = d1[k], p11 = d1[k + C];
                         // |derivative| <= 4080 < 2^12, weight <= 2^14: signed 24-bit multiplies are exact
-                        int gx = __mul24((int)(short)(p00 & 0xffff), w00) + __mul24((int)(short)(p01 & 0xffff), w01) +
-                                 __mul24((int)(short)(p10 & 0xffff), w10) + __mul24((int)(short)(p11 & 0xffff), w11);
-                        int gy = __mul24(p00 >> 16, w00) + __mul24(p01 >> 16, w01) + __mul24(p10 >> 16, w10) +
-                                 __mul24(p11 >> 16, w11);
-                        ix[e] = (gx + (1 << (W_BITS - 1))) >> W_BITS;
-                        iy[e] = (gy + (1 << (W_BITS - 1))) >> W_BITS;
-                        a11 += __mul24(ix[e], ix[e]);
-                        a12 += __mul24(ix[e], iy[e]);
-                        a22 += __mul24(iy[e], iy[e]);
+                        constexpr int RD = 1 << (W_BITS - 1);
+                        int gx = mad24((int)(short)(p00 & 0xffff), w00, mad24((int)(short)(p01 & 0xffff), w01,
+                                 mad24((int)(short)(p10 & 0xffff), w10, mad24((int)(short)(p11 & 0xffff), w11, RD))));
+                        int gy = mad24(p00 >> 16, w00, mad24(p01 >> 16, w01, mad24(p10 >> 16, w10, mad24(p11 >> 16, w11, RD))));
+                        ix[e] = gx >> W_BITS;
+                        iy[e] = gy >> W_BITS;
+                        a11 = mad24(ix[e], ix[e], a11);
+                        a12 = mad24(ix[e], iy[e], a12);
+                        a22 = mad24(iy[e], iy[e], a22);
                     }
                 }
                 Ivp[j] = iv[0] | (iv[1] << 16);
