@@ -100,6 +100,40 @@ int svo_lk_track(svo_ctx *ctx, const svo_pyramid *prev, const svo_pyramid *next,
                  const float *prev_pts, int n, float *next_pts, uint8_t *status, float *err,
                  float *min_eig, int mem);
 
+/* ---- order-preserving compaction by a byte mask -------------------------------------------- */
+/* replaces the push_back filters of src/tracking.cpp:20-27 (status), :35-42 and :66-84 (mask).
+ * Up to three float arrays (a, b, c; stride = floats per element, NULL to skip) are compacted
+ * with one mask; rows with mask == 1 are kept in order.  count: host int (SVO_MEM_HOST) or
+ * device int (SVO_MEM_DEVICE).                                                              */
+int svo_compact(svo_ctx *ctx, const uint8_t *mask, int n, const float *in_a, int stride_a, float *out_a,
+                const float *in_b, int stride_b, float *out_b, const float *in_c, int stride_c, float *out_c,
+                int *count, int mem);
+
+/* ---- fundamental-matrix RANSAC: cv::findFundamentalMat(p1,p2,FM_RANSAC,thr,conf,mask) ------ */
+/* replaces src/tracking.cpp:34 (FmatThresholding: thr 3.0, conf 0.99) and :75
+ * (PyrLKtrackFrame2Frame: method 8 == FM_RANSAC, thr 1.0, conf 0.99).  max_iters is OpenCV's
+ * fixed 1000.  mask: n bytes (1 = inlier).  F9 (optional): the winning 7-point model, row
+ * major, unit Frobenius norm.  inlier_count / iters_run (optional): host or device ints
+ * following `mem`.  Sampling is a counter-based generator keyed by (seed, iteration).        */
+int svo_fransac(svo_ctx *ctx, const float *p1, const float *p2, int n, double threshold,
+                double confidence, int max_iters, uint64_t seed, uint8_t *mask, double *F9,
+                int *inlier_count, int *iters_run, int mem);
+
+/* ---- stereo triangulation: src/triangulation.cpp:142-160 ------------------------------------ */
+/* P1 = K[I|0], P2 = K[I|(-b,0,0)^T] (3x4 row-major doubles, HOST memory always). */
+int svo_stereo_projections(double fx, double fy, double cx, double cy, double baseline, double *P1,
+                           double *P2);
+/* cv::triangulatePoints + float dehomogenisation.  out_xyz: n*3 floats; out_h4 (optional): the
+ * unit-norm homogeneous vectors (sign arbitrary).  P1/P2 are host pointers.                  */
+int svo_triangulate(svo_ctx *ctx, const double *P1, const double *P2, const float *x1, const float *x2,
+                    int n, float *out_xyz, float *out_h4, int mem);
+/* visualSLAM::update3dtransformation / the loop of insertKeyFrames,
+ * src/keyFrameManagement.cpp:20-30,33-46.  Rt: 3x4 row-major doubles in HOST memory.          */
+int svo_transform_points(svo_ctx *ctx, const double *Rt, const float *in_xyz, int n, float *out_xyz,
+                         int mem);
+/* getColors, include/monoUtils.h:180-193: B,G,R of level 0 at (int(y), int(x)) as floats.      */
+int svo_get_colors(svo_ctx *ctx, const svo_pyramid *pyr, const float *xy, int n, float *out_bgr, int mem);
+
 #ifdef __cplusplus
 }
 #endif

@@ -79,3 +79,97 @@ def grid_keypoints(rows, cols, step) -> np.ndarray:
     out = np.empty((n, 2), np.float32)
     load().orc_grid_keypoints(rows, cols, step, _p(out), n)
     return out
+
+
+# ---- two-view geometry -------------------------------------------------------------------
+class FransacParams(C.Structure):
+    _fields_ = [("threshold", C.c_double), ("confidence", C.c_double), ("max_iters", C.c_int),
+                ("seed", C.c_uint64)]
+
+
+def rng_u32(seed, it, draw):
+    f = load().orc_rng_u32
+    f.restype = C.c_uint32
+    f.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
+    return f(seed, it, draw)
+
+
+def seven_point(x1, x2):
+    x1 = np.ascontiguousarray(x1, np.float64).reshape(7, 2)
+    x2 = np.ascontiguousarray(x2, np.float64).reshape(7, 2)
+    F = np.zeros((3, 9))
+    n = load().orc_seven_point(_p(x1), _p(x2), _p(F))
+    return F[:n].reshape(n, 3, 3)
+
+
+def fransac(p1, p2, threshold, confidence=0.99, max_iters=1000, seed=0):
+    p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2)
+    p2 = np.ascontiguousarray(p2, np.float32).reshape(-1, 2)
+    n = len(p1)
+    mask = np.zeros(n, np.uint8)
+    F = np.zeros(9)
+    iters = C.c_int()
+    prm = FransacParams(threshold, confidence, max_iters, seed)
+    cnt = load().orc_fransac(_p(p1), _p(p2), n, C.byref(prm), _p(mask), _p(F), C.byref(iters))
+    return cnt, mask, F.reshape(3, 3), iters.value
+
+
+def f_error(F, p1, p2):
+    f = load().orc_f_error
+    f.restype = C.c_float
+    f.argtypes = [C.c_void_p] + [C.c_float] * 4
+    F = np.ascontiguousarray(F, np.float64)
+    return np.array([f(_p(F), a[0], a[1], b[0], b[1]) for a, b in zip(p1, p2)], np.float32)
+
+
+def stereo_projections(fx, fy, cx, cy, baseline):
+    P1, P2 = np.zeros((3, 4)), np.zeros((3, 4))
+    f = load().orc_stereo_projections
+    f.argtypes = [C.c_double] * 5 + [C.c_void_p] * 2
+    f(fx, fy, cx, cy, baseline, _p(P1), _p(P2))
+    return P1, P2
+
+
+def triangulate(P1, P2, x1, x2):
+    x1 = np.ascontiguousarray(x1, np.float32).reshape(-1, 2)
+    x2 = np.ascontiguousarray(x2, np.float32).reshape(-1, 2)
+    n = len(x1)
+    xyz = np.zeros((n, 3), np.float32)
+    h = np.zeros((n, 4), np.float32)
+    load().orc_triangulate(_p(np.ascontiguousarray(P1, np.float64)), _p(np.ascontiguousarray(P2, np.float64)),
+                           _p(x1), _p(x2), n, _p(xyz), _p(h))
+    return xyz, h
+
+
+def transform_points(Rt, xyz):
+    xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+    out = np.zeros_like(xyz)
+    load().orc_transform_points(_p(np.ascontiguousarray(Rt, np.float64)), _p(xyz), len(xyz), _p(out))
+    return out
+
+
+def get_colors(img, xy):
+    h, w, c = img.shape
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    out = np.zeros((len(xy), 3), np.float32)
+    load().orc_get_colors(_p(np.ascontiguousarray(img)), w, h, c, _p(xy), len(xy), _p(out))
+    return out
+
+
+def rodrigues(rvec):
+    R = np.zeros((3, 3))
+    load().orc_rodrigues(_p(np.ascontiguousarray(rvec, np.float64)), _p(R))
+    return R
+
+
+def rodrigues_inv(R):
+    r = np.zeros(3)
+    load().orc_rodrigues_inv(_p(np.ascontiguousarray(R, np.float64)), _p(r))
+    return r
+
+
+def compose_camera_pose(rvec, tvec):
+    R, t = np.zeros((3, 3)), np.zeros(3)
+    load().orc_compose_camera_pose(_p(np.ascontiguousarray(rvec, np.float64)),
+                                   _p(np.ascontiguousarray(tvec, np.float64)), _p(R), _p(t))
+    return R, t

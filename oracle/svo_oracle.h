@@ -73,6 +73,11 @@ int orc_anms(const float *xy, const float *response, int n, int num_to_keep, int
 /* ---- counter-based RNG shared by both RANSACs (SURVEY 7 "hard parts", A.4) ------------- */
 uint32_t orc_rng_u32(uint64_t seed, uint32_t iter, uint32_t draw);
 
+/* m distinct indices in [0,n) for RANSAC iteration `iter` (no degeneracy check); 1 = ok */
+int orc_draw_subset_plain(uint64_t seed, uint32_t iter, int n, int m, int *idx);
+/* cv RANSACUpdateNumIters */
+int orc_update_num_iters(double p, double ep, int model_points, int max_iters);
+
 /* ---- fundamental-matrix RANSAC: src/tracking.cpp:34 and :75 ---------------------------- */
 /* stands in for cv::findFundamentalMat(p1,p2,FM_RANSAC,thr,conf,mask).
  * mask: n uint8 (1 inlier).  F: 9 doubles row-major (best 7-point model, F[8]==1 scale).
@@ -86,6 +91,8 @@ typedef struct {
 
 int orc_fransac(const float *p1, const float *p2, int n, const orc_fransac_params *prm,
                 uint8_t *mask, double *F, int *iters_run);
+/* the 7-sample of iteration `iter` (collinearity-checked, re-drawn); 1 = ok */
+int orc_fransac_draw(const float *p1, const float *p2, int n, uint64_t seed, uint32_t iter, int *idx7);
 /* 7-point solver on 7 correspondences: returns number of models (0..3), F's row-major */
 int orc_seven_point(const double *x1 /*7x2*/, const double *x2 /*7x2*/, double *F /*3x9*/);
 /* symmetric epipolar error of OpenCV's FMEstimatorCallback::computeError (float result) */

@@ -171,3 +171,79 @@ class Context:
         """Device-pointer form (torch tensors or raw addresses); asynchronous on the ctx stream."""
         _check(self.lib.svo_lk_track(self._h, prev._h, nxt._h, _ptr(pts), n, _ptr(out), _ptr(status),
                                      _ptr(err), _ptr(mineig), MEM_DEVICE))
+
+
+# ---- phase-2 entry points: compaction, F-RANSAC, triangulation (host-array forms) ----------
+def _ctx_method(fn):
+    setattr(Context, fn.__name__, fn)
+    return fn
+
+
+@_ctx_method
+def compact(self, mask, *arrays):
+    """Order-preserving compaction of up to three float arrays by a byte mask."""
+    mask = np.ascontiguousarray(mask, np.uint8)
+    n = mask.shape[0]
+    arrs = [np.ascontiguousarray(a, np.float32).reshape(n, -1) for a in arrays]
+    assert 1 <= len(arrs) <= 3
+    outs = [np.empty_like(a) for a in arrs]
+    args = []
+    for k in range(3):
+        if k < len(arrs):
+            args += [_ptr(arrs[k]), arrs[k].shape[1], _ptr(outs[k])]
+        else:
+            args += [None, 0, None]
+    cnt = C.c_int()
+    _check(self.lib.svo_compact(self._h, _ptr(mask), n, *args, C.byref(cnt), MEM_HOST))
+    return [o[:cnt.value] for o in outs]
+
+
+@_ctx_method
+def fransac(self, p1, p2, threshold, confidence=0.99, max_iters=1000, seed=0):
+    p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2)
+    p2 = np.ascontiguousarray(p2, np.float32).reshape(-1, 2)
+    n = p1.shape[0]
+    mask = np.zeros(n, np.uint8)
+    F = np.zeros(9)
+    cnt, iters = C.c_int(), C.c_int()
+    _check(self.lib.svo_fransac(self._h, _ptr(p1), _ptr(p2), n, C.c_double(threshold), C.c_double(confidence),
+                                max_iters, C.c_uint64(seed), _ptr(mask), _ptr(F), C.byref(cnt), C.byref(iters),
+                                MEM_HOST))
+    return cnt.value, mask, F.reshape(3, 3), iters.value
+
+
+def stereo_projections(fx, fy, cx, cy, baseline):
+    P1, P2 = np.zeros((3, 4)), np.zeros((3, 4))
+    _check(load().svo_stereo_projections(C.c_double(fx), C.c_double(fy), C.c_double(cx), C.c_double(cy),
+                                         C.c_double(baseline), _ptr(P1), _ptr(P2)))
+    return P1, P2
+
+
+@_ctx_method
+def triangulate(self, P1, P2, x1, x2):
+    x1 = np.ascontiguousarray(x1, np.float32).reshape(-1, 2)
+    x2 = np.ascontiguousarray(x2, np.float32).reshape(-1, 2)
+    n = x1.shape[0]
+    xyz = np.empty((n, 3), np.float32)
+    h = np.empty((n, 4), np.float32)
+    _check(self.lib.svo_triangulate(self._h, _ptr(np.ascontiguousarray(P1, np.float64)),
+                                    _ptr(np.ascontiguousarray(P2, np.float64)), _ptr(x1), _ptr(x2), n,
+                                    _ptr(xyz), _ptr(h), MEM_HOST))
+    return xyz, h
+
+
+@_ctx_method
+def transform_points(self, Rt, xyz):
+    xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+    out = np.empty_like(xyz)
+    _check(self.lib.svo_transform_points(self._h, _ptr(np.ascontiguousarray(Rt, np.float64)), _ptr(xyz),
+                                         xyz.shape[0], _ptr(out), MEM_HOST))
+    return out
+
+
+@_ctx_method
+def get_colors(self, pyr, xy):
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    out = np.empty((xy.shape[0], 3), np.float32)
+    _check(self.lib.svo_get_colors(self._h, pyr._h, _ptr(xy), xy.shape[0], _ptr(out), MEM_HOST))
+    return out

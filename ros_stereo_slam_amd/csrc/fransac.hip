@@ -1,0 +1,528 @@
+// fransac.hip -- fundamental-matrix RANSAC for gfx950.
+//
+// Replaces cv::findFundamentalMat(p1, p2, FM_RANSAC, thr, 0.99, mask) as the reference
+// calls it at src/tracking.cpp:34 (FmatThresholding, 3 px) and src/tracking.cpp:75
+// (PyrLKtrackFrame2Frame, method 8 == FM_RANSAC, 1 px).  Only the mask is consumed there.
+//
+// Structure (all on the context's stream, no host round trip):
+//   solve   one THREAD per RANSAC iteration: counter-based 7-sample (collinear samples
+//           re-drawn), 7x9 Gauss-Jordan in LDS ([element][thread] layout, conflict-free),
+//           cubic det(l*F1 + (1-l)*F2) = 0, up to three unit-norm models to HBM.
+//   score   one WAVEFRONT per model: the N correspondences strided over the 64 lanes,
+//           symmetric epipolar distance in f64, inlier count reduced with DPP.
+//   select  one thread replays the SEQUENTIAL loop over the counts (first-best-wins,
+//           adaptive iteration bound) so the answer equals the serial algorithm's.
+//   mask    one thread per correspondence against the winning model.
+// solve/score/select run in two phases (iterations [0,64) and [64,max)); phase-two
+// kernels return at once when the adaptive bound was reached in phase one, which is the
+// common case at VO inlier ratios (0.99 confidence, 85% inliers -> 12 iterations).
+#include "ransac_common.cuh"
+#include "svo_internal.h"
+
+using namespace svo;
+
+namespace {
+
+constexpr int M = 7;
+constexpr int SOLVE_T = 64;
+constexpr int PHASE_A = 64;
+
+__device__ __forceinline__ double det3(const double *m)
+{
+    return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) +
+           m[2] * (m[3] * m[7] - m[4] * m[6]);
+}
+
+__device__ int solve_cubic(const double *c, double *r)
+{
+    int n = 0;
+    const double a = c[0], b = c[1], cc = c[2], d = c[3];
+    const double scale = fabs(a) + fabs(b) + fabs(cc) + fabs(d);
+    if (scale == 0)
+        return 0;
+    if (fabs(a) <= 1e-14 * scale) {
+        if (fabs(b) <= 1e-14 * scale) {
+            if (fabs(cc) <= 1e-14 * scale)
+                return 0;
+            r[0] = -d / cc;
+            n = 1;
+        } else {
+            double disc = cc * cc - 4 * b * d;
+            if (disc < 0)
+                return 0;
+            double sq = sqrt(disc);
+            r[0] = (-cc + sq) / (2 * b);
+            r[1] = (-cc - sq) / (2 * b);
+            n = 2;
+        }
+    } else {
+        const double a1 = b / a, a2 = cc / a, a3 = d / a;
+        const double Q = (a1 * a1 - 3 * a2) * (1. / 9);
+        const double R = (2 * a1 * a1 * a1 - 9 * a1 * a2 + 27 * a3) * (1. / 54);
+        const double Qcubed = Q * Q * Q, dd = Qcubed - R * R;
+        if (dd > 0) {
+            double theta = acos(R / sqrt(Qcubed));
+            double sqrtQ = sqrt(Q);
+            double t0 = -2 * sqrtQ, t1 = theta * (1. / 3), t2 = a1 * (1. / 3);
+            r[0] = t0 * cos(t1) - t2;
+            r[1] = t0 * cos(t1 + 2. * 3.14159265358979323846 / 3) - t2;
+            r[2] = t0 * cos(t1 + 4. * 3.14159265358979323846 / 3) - t2;
+            n = 3;
+        } else if (dd == 0) {
+            double e = cbrt(fabs(R));
+            if (R > 0)
+                e = -e;
+            r[0] = 2 * e - a1 * (1. / 3);
+            r[1] = -e - a1 * (1. / 3);
+            n = 2;
+        } else {
+            double e = cbrt(sqrt(-dd) + fabs(R));
+            if (R > 0)
+                e = -e;
+            r[0] = (e + Q / e) - a1 * (1. / 3);
+            n = 1;
+        }
+    }
+    for (int k = 0; k < 3; k++)
+        if (k < n)
+            for (int it = 0; it < 2; it++) {  // Newton polish: irons out libm differences
+                double x = r[k];
+                double f = ((a * x + b) * x + cc) * x + d;
+                double fp = (3 * a * x + 2 * b) * x + cc;
+                if (fabs(fp) > 1e-300)
+                    r[k] = x - f / fp;
+            }
+    return n;
+}
+
+// cv haveCollinearPoints: the LAST sample point against every pair of earlier ones
+__device__ bool collinear_last(const float *__restrict__ p, const int (&idx)[M])
+{
+    const double xi = p[2 * idx[M - 1]], yi = p[2 * idx[M - 1] + 1];
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < M - 1; j++) {
+        const double dx1 = (double)p[2 * idx[j]] - xi, dy1 = (double)p[2 * idx[j] + 1] - yi;
+#pragma unroll
+        for (int k = 0; k < j; k++) {
+            const double dx2 = (double)p[2 * idx[k]] - xi, dy2 = (double)p[2 * idx[k] + 1] - yi;
+            if (fabs(dx2 * dy1 - dy2 * dx1) <=
+                (double)FLT_EPSILON * (fabs(dx1) + fabs(dy1) + fabs(dx2) + fabs(dy2)))
+                bad = true;
+        }
+    }
+    return bad;
+}
+
+__global__ __launch_bounds__(SOLVE_T) void fr_solve_kernel(const float *__restrict__ p1,
+                                                           const float *__restrict__ p2, int n_host,
+                                                           const int *__restrict__ d_n, uint64_t seed, int it0,
+                                                           int it1, const RansacState *__restrict__ st,
+                                                           double *__restrict__ Fout, int *__restrict__ nmodels)
+{
+    __shared__ double sA[63][SOLVE_T];
+    __shared__ double sV[18][SOLVE_T];
+    __shared__ int sPerm[9][SOLVE_T];
+    const int t = threadIdx.x;
+    const int it = it0 + blockIdx.x * SOLVE_T + t;
+    if (it0 > 0 && st->done)
+        return;
+    if (it >= it1)
+        return;
+    const int n = d_n ? *d_n : n_host;
+    if (n < M) {
+        nmodels[it] = -1;
+        return;
+    }
+    // ---- sample: M distinct indices, degenerate samples re-drawn ----
+    int idx[M];
+    bool ok = false;
+    uint32_t draw = 0;
+    for (int attempt = 0; attempt < kMaxAttempts && !ok; attempt++) {
+        int guard = 0;
+        bool filled = true;
+#pragma unroll
+        for (int slot = 0; slot < M; slot++) {
+            int v = 0;
+            bool got = false;
+            while (!got && guard < kMaxDraws) {
+                v = (int)(rng_u32(seed, (uint32_t)it, draw++) % (uint32_t)n);
+                guard++;
+                bool dup = false;
+#pragma unroll
+                for (int j = 0; j < M; j++)
+                    if (j < slot && idx[j] == v)
+                        dup = true;
+                got = !dup;
+            }
+            if (!got)
+                filled = false;
+            idx[slot] = v;
+        }
+        if (!filled)
+            break;
+        ok = !collinear_last(p1, idx) && !collinear_last(p2, idx);
+    }
+    if (!ok) {
+        nmodels[it] = -1;  // getSubset failed: the sequential loop stops here
+        return;
+    }
+    // ---- 7x9 epipolar system in LDS, Gauss-Jordan with full pivoting ----
+#pragma unroll
+    for (int i = 0; i < M; i++) {
+        const double u0 = p1[2 * idx[i]], v0 = p1[2 * idx[i] + 1];
+        const double u1 = p2[2 * idx[i]], v1 = p2[2 * idx[i] + 1];
+        sA[i * 9 + 0][t] = u1 * u0;
+        sA[i * 9 + 1][t] = u1 * v0;
+        sA[i * 9 + 2][t] = u1;
+        sA[i * 9 + 3][t] = v1 * u0;
+        sA[i * 9 + 4][t] = v1 * v0;
+        sA[i * 9 + 5][t] = v1;
+        sA[i * 9 + 6][t] = u0;
+        sA[i * 9 + 7][t] = v0;
+        sA[i * 9 + 8][t] = 1.;
+    }
+    for (int j = 0; j < 9; j++)
+        sPerm[j][t] = j;
+    bool singular = false;
+    for (int k = 0; k < M && !singular; k++) {
+        int pr = k, pc = k;
+        double best = -1;
+        for (int i = k; i < M; i++)
+            for (int j = k; j < 9; j++) {
+                double v = fabs(sA[i * 9 + j][t]);
+                if (v > best) {
+                    best = v;
+                    pr = i;
+                    pc = j;
+                }
+            }
+        if (best < 1e-12) {
+            singular = true;
+            break;
+        }
+        if (pr != k)
+            for (int j = 0; j < 9; j++) {
+                double tmp = sA[k * 9 + j][t];
+                sA[k * 9 + j][t] = sA[pr * 9 + j][t];
+                sA[pr * 9 + j][t] = tmp;
+            }
+        if (pc != k) {
+            for (int i = 0; i < M; i++) {
+                double tmp = sA[i * 9 + k][t];
+                sA[i * 9 + k][t] = sA[i * 9 + pc][t];
+                sA[i * 9 + pc][t] = tmp;
+            }
+            int tp = sPerm[k][t];
+            sPerm[k][t] = sPerm[pc][t];
+            sPerm[pc][t] = tp;
+        }
+        const double inv = 1. / sA[k * 9 + k][t];
+        for (int j = 0; j < 9; j++)
+            sA[k * 9 + j][t] *= inv;
+        for (int i = 0; i < M; i++)
+            if (i != k) {
+                const double f = sA[i * 9 + k][t];
+                if (f != 0)
+                    for (int j = 0; j < 9; j++)
+                        sA[i * 9 + j][t] -= f * sA[k * 9 + j][t];
+            }
+    }
+    if (singular) {
+        nmodels[it] = 0;
+        return;
+    }
+    for (int k = 0; k < M; k++) {
+        const int c = sPerm[k][t];
+        sV[c][t] = -sA[k * 9 + 7][t];
+        sV[9 + c][t] = -sA[k * 9 + 8][t];
+    }
+    {
+        const int c7 = sPerm[7][t], c8 = sPerm[8][t];
+        sV[c7][t] = 1;
+        sV[9 + c7][t] = 0;
+        sV[c8][t] = 0;
+        sV[9 + c8][t] = 1;
+    }
+    double G[9], H[9], Mx[9], c[4];
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const double f1 = sV[i][t], f2 = sV[9 + i][t];
+        G[i] = f1 - f2;
+        H[i] = f2;
+    }
+    c[0] = det3(G);
+    c[3] = det3(H);
+    c[1] = 0;
+    c[2] = 0;
+#pragma unroll
+    for (int row = 0; row < 3; row++) {
+#pragma unroll
+        for (int i = 0; i < 9; i++)
+            Mx[i] = (i / 3 == row) ? H[i] : G[i];
+        c[1] += det3(Mx);
+#pragma unroll
+        for (int i = 0; i < 9; i++)
+            Mx[i] = (i / 3 == row) ? G[i] : H[i];
+        c[2] += det3(Mx);
+    }
+    double roots[3] = {0, 0, 0};
+    const int nr = solve_cubic(c, roots);
+    int nm = 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        if (k < nr) {
+            double Fk[9], nrm = 0;
+#pragma unroll
+            for (int i = 0; i < 9; i++) {
+                Fk[i] = H[i] + roots[k] * G[i];
+                nrm += Fk[i] * Fk[i];
+            }
+            nrm = sqrt(nrm);
+            if (nrm > 1e-300 && isfinite(nrm)) {
+                double *dst = Fout + ((size_t)it * 3 + nm) * 9;
+#pragma unroll
+                for (int i = 0; i < 9; i++)
+                    dst[i] = Fk[i] / nrm;
+                nm++;
+            }
+        }
+    }
+    nmodels[it] = nm;
+}
+
+// cv FMEstimatorCallback::computeError for one correspondence (float result)
+__device__ __forceinline__ float f_error(const double (&F)[9], float x1, float y1, float x2, float y2)
+{
+    double a, b, c, d1, d2, s1, s2;
+    a = F[0] * x1 + F[1] * y1 + F[2];
+    b = F[3] * x1 + F[4] * y1 + F[5];
+    c = F[6] * x1 + F[7] * y1 + F[8];
+    s2 = 1. / (a * a + b * b);
+    d2 = x2 * a + y2 * b + c;
+    a = F[0] * x2 + F[3] * y2 + F[6];
+    b = F[1] * x2 + F[4] * y2 + F[7];
+    c = F[2] * x2 + F[5] * y2 + F[8];
+    s1 = 1. / (a * a + b * b);
+    d1 = x1 * a + y1 * b + c;
+    const double e1 = d1 * d1 * s1, e2 = d2 * d2 * s2;
+    return (float)(e1 > e2 ? e1 : e2);
+}
+
+__global__ __launch_bounds__(256) void fr_score_kernel(const float2 *__restrict__ p1,
+                                                       const float2 *__restrict__ p2, int n_host,
+                                                       const int *__restrict__ d_n, int it0, int it1,
+                                                       const RansacState *__restrict__ st,
+                                                       const double *__restrict__ Fm,
+                                                       const int *__restrict__ nmodels, float thr,
+                                                       int *__restrict__ counts)
+{
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int it = it0 + w / 3, k = w - (w / 3) * 3;
+    if (it >= it1)
+        return;
+    if (it0 > 0 && st->done)
+        return;
+    const int nm = nmodels[it];
+    if (k >= nm) {
+        if (lane == 0)
+            counts[it * 3 + k] = 0;
+        return;
+    }
+    const int n = d_n ? *d_n : n_host;
+    double F[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+        F[i] = Fm[((size_t)it * 3 + k) * 9 + i];
+    int cnt = 0;
+    for (int i = lane; i < n; i += 64) {
+        const float2 a = p1[i], b = p2[i];
+        cnt += f_error(F, a.x, a.y, b.x, b.y) <= thr ? 1 : 0;
+    }
+    cnt = wave_sum_small(cnt);
+    if (lane == 0)
+        counts[it * 3 + k] = cnt;
+}
+
+// replays the sequential RANSAC loop over iterations [st->next_iter, it_end)
+__global__ void fr_select_kernel(RansacState *st, int first, int it_end, int max_iters, int n_host,
+                                 const int *__restrict__ d_n, double confidence,
+                                 const int *__restrict__ nmodels, const int *__restrict__ counts,
+                                 int model_points)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0)
+        return;
+    RansacState s;
+    if (first) {
+        s.niters = max_iters;
+        s.next_iter = 0;
+        s.best_iter = -1;
+        s.best_model = 0;
+        s.best_count = 0;
+        s.done = 0;
+        s.iters_run = 0;
+        s.pad = 0;
+    } else {
+        s = *st;
+        if (s.done)
+            return;
+    }
+    const int n = d_n ? *d_n : n_host;
+    int it = s.next_iter;
+    if (n < model_points) {
+        s.done = 1;
+    } else {
+        for (; it < it_end; it++) {
+            if (it >= s.niters) {
+                s.done = 1;
+                break;
+            }
+            const int nm = nmodels[it];
+            if (nm < 0) {
+                s.done = 1;
+                break;
+            }
+            for (int k = 0; k < nm; k++) {
+                const int c = counts[it * 3 + k];
+                const int floor_cnt = s.best_count > model_points - 1 ? s.best_count : model_points - 1;
+                if (c > floor_cnt) {
+                    s.best_count = c;
+                    s.best_iter = it;
+                    s.best_model = k;
+                    s.niters = update_num_iters(confidence, (double)(n - c) / n, model_points, s.niters);
+                }
+            }
+        }
+        if (it >= s.niters || it >= max_iters)
+            s.done = 1;
+    }
+    s.next_iter = it;
+    s.iters_run = it;
+    *st = s;
+}
+
+__global__ __launch_bounds__(256) void fr_mask_kernel(const float2 *__restrict__ p1,
+                                                      const float2 *__restrict__ p2, int n_host,
+                                                      const int *__restrict__ d_n,
+                                                      const RansacState *__restrict__ st,
+                                                      const double *__restrict__ Fm, float thr,
+                                                      uint8_t *__restrict__ mask, double *__restrict__ Fbest,
+                                                      int *__restrict__ out_count, int *__restrict__ out_iters)
+{
+    const int n = d_n ? *d_n : n_host;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const RansacState s = *st;
+    double F[9];
+    const bool have = s.best_iter >= 0 && s.best_count > 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++)
+        F[k] = have ? Fm[((size_t)s.best_iter * 3 + s.best_model) * 9 + k] : 0.;
+    if (i == 0) {
+        if (out_count)
+            *out_count = have ? s.best_count : 0;
+        if (out_iters)
+            *out_iters = s.iters_run;
+        if (Fbest)
+            for (int k = 0; k < 9; k++)
+                Fbest[k] = F[k];
+    }
+    if (i >= n_host)  // n_host is the capacity the grid was sized for
+        return;
+    uint8_t m = 0;
+    if (have && i < n) {
+        const float2 a = p1[i], b = p2[i];
+        m = f_error(F, a.x, a.y, b.x, b.y) <= thr ? 1 : 0;
+    }
+    mask[i] = m;
+}
+
+}  // namespace
+
+// device-pointer form used by the C ABI and by the fused front-end.  `cap` sizes the grids
+// (the number of correspondences is *d_n when d_n != nullptr, else cap).
+int svo_launch_fransac(svo_ctx *ctx, const float *p1, const float *p2, int cap, const int *d_n,
+                       double threshold, double confidence, int max_iters, uint64_t seed, uint8_t *mask,
+                       double *d_F, int *d_count, int *d_iters)
+{
+    if (cap <= 0)
+        return SVO_OK;
+    if (max_iters < 1)
+        max_iters = 1;
+    int rc;
+    const size_t f_bytes = (size_t)max_iters * 27 * sizeof(double);
+    const size_t i_bytes = (size_t)max_iters * 4 * sizeof(int) + 64;
+    if ((rc = ctx->w_a.ensure(f_bytes)) || (rc = ctx->w_b.ensure(i_bytes)))
+        return rc;
+    double *Fm = ctx->w_a.as<double>();
+    RansacState *st = reinterpret_cast<RansacState *>(ctx->w_b.p);
+    int *nmodels = ctx->w_b.as<int>() + 16;
+    int *counts = nmodels + max_iters;
+    const float thr = (float)(threshold * threshold);
+    ScopedKernelTime tm(ctx, SVO_K_FRANSAC);
+    const int bounds[3] = {0, max_iters < PHASE_A ? max_iters : PHASE_A, max_iters};
+    for (int ph = 0; ph < 2; ph++) {
+        const int it0 = bounds[ph], it1 = bounds[ph + 1];
+        if (it1 <= it0)
+            continue;
+        const int iters = it1 - it0;
+        hipLaunchKernelGGL(fr_solve_kernel, dim3((iters + SOLVE_T - 1) / SOLVE_T), dim3(SOLVE_T), 0, ctx->stream,
+                           p1, p2, cap, d_n, seed, it0, it1, st, Fm, nmodels);
+        hipLaunchKernelGGL(fr_score_kernel, dim3((iters * 3 + 3) / 4), dim3(256), 0, ctx->stream,
+                           reinterpret_cast<const float2 *>(p1), reinterpret_cast<const float2 *>(p2), cap, d_n, it0,
+                           it1, st, Fm, nmodels, thr, counts);
+        hipLaunchKernelGGL(fr_select_kernel, dim3(1), dim3(64), 0, ctx->stream, st, ph == 0 ? 1 : 0, it1, max_iters,
+                           cap, d_n, confidence, nmodels, counts, M);
+    }
+    hipLaunchKernelGGL(fr_mask_kernel, dim3((cap + 255) / 256), dim3(256), 0, ctx->stream,
+                       reinterpret_cast<const float2 *>(p1), reinterpret_cast<const float2 *>(p2), cap, d_n, st, Fm,
+                       thr, mask, d_F, d_count, d_iters);
+    SVO_HIP(hipGetLastError());
+    return SVO_OK;
+}
+
+extern "C" int svo_fransac(svo_ctx *ctx, const float *p1, const float *p2, int n, double threshold,
+                           double confidence, int max_iters, uint64_t seed, uint8_t *mask, double *F9,
+                           int *inlier_count, int *iters_run, int mem)
+{
+    SVO_CHECK_ARG(ctx && n >= 0 && threshold > 0 && max_iters > 0);
+    SVO_CHECK_ARG(mem == SVO_MEM_HOST || mem == SVO_MEM_DEVICE);
+    if (n == 0) {
+        if (mem == SVO_MEM_HOST) {
+            if (inlier_count)
+                *inlier_count = 0;
+            if (iters_run)
+                *iters_run = 0;
+        }
+        return SVO_OK;
+    }
+    SVO_CHECK_ARG(p1 && p2 && mask);
+    if (mem == SVO_MEM_DEVICE)
+        return svo_launch_fransac(ctx, p1, p2, n, nullptr, threshold, confidence, max_iters, seed, mask, F9,
+                                  inlier_count, iters_run);
+    int rc;
+    if ((rc = ctx->s_a.ensure((size_t)n * 8)) || (rc = ctx->s_b.ensure((size_t)n * 8)) ||
+        (rc = ctx->s_c.ensure((size_t)n)) || (rc = ctx->s_d.ensure(256)))
+        return rc;
+    SVO_HIP(hipMemcpyAsync(ctx->s_a.p, p1, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    SVO_HIP(hipMemcpyAsync(ctx->s_b.p, p2, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    double *dF = ctx->s_d.as<double>();
+    int *dcnt = reinterpret_cast<int *>(dF + 9), *dit = dcnt + 1;
+    rc = svo_launch_fransac(ctx, ctx->s_a.as<float>(), ctx->s_b.as<float>(), n, nullptr, threshold, confidence,
+                            max_iters, seed, ctx->s_c.as<uint8_t>(), dF, dcnt, dit);
+    if (rc)
+        return rc;
+    SVO_HIP(hipMemcpyAsync(mask, ctx->s_c.p, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    SVO_HIP(hipMemcpyAsync(ctx->pinned, dF, 9 * sizeof(double) + 2 * sizeof(int), hipMemcpyDeviceToHost,
+                           ctx->stream));
+    SVO_HIP(hipStreamSynchronize(ctx->stream));
+    const double *hF = reinterpret_cast<const double *>(ctx->pinned);
+    const int *hI = reinterpret_cast<const int *>(hF + 9);
+    if (F9)
+        memcpy(F9, hF, 9 * sizeof(double));
+    if (inlier_count)
+        *inlier_count = hI[0];
+    if (iters_run)
+        *iters_run = hI[1];
+    return SVO_OK;
+}

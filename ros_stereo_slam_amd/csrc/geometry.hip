@@ -1,0 +1,402 @@
+// geometry.hip -- per-point geometry kernels of the keyframe path, plus the order-preserving
+// mask compaction the reference does with push_back loops.
+//
+//   triangulate   cv::triangulatePoints(P1,P2,x1,x2) + float dehomogenisation,
+//                 src/triangulation.cpp:142-160 (DLT: 4x4 system per point, right singular
+//                 vector of the smallest singular value by one-sided Jacobi, all in
+//                 registers; negative-depth and w~0 points are NOT filtered, as upstream)
+//   transform     [R|t] (3x4 double) applied to float points, src/keyFrameManagement.cpp:20-30
+//   colours       img.at<Vec3b>(int(y), int(x)) as 3 floats, include/monoUtils.h:180-193
+//   compact       src/tracking.cpp:20-27, 35-42, 66-84 (status / mask filters)
+// All are one thread per point, bandwidth-trivial (tens of bytes per point).
+#include <cfloat>
+
+#include "svo_internal.h"
+
+namespace {
+
+struct Mat34 {
+    double m[12];
+};
+
+// right singular vector of the smallest singular value of a 4x4 matrix (Hestenes Jacobi)
+__device__ void smallest_right_singular_vector4(double (&A)[4][4], double (&v)[4])
+{
+    double V[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            V[i][j] = i == j ? 1. : 0.;
+    for (int sweep = 0; sweep < 30; sweep++) {
+        bool rotated = false;
+#pragma unroll
+        for (int p = 0; p < 3; p++)
+#pragma unroll
+            for (int q = p + 1; q < 4; q++) {
+                double al = 0, be = 0, ga = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    al += A[i][p] * A[i][p];
+                    be += A[i][q] * A[i][q];
+                    ga += A[i][p] * A[i][q];
+                }
+                if (fabs(ga) <= DBL_EPSILON * sqrt(al * be) || ga == 0)
+                    continue;
+                rotated = true;
+                const double zeta = (be - al) / (2. * ga);
+                const double t = (zeta >= 0 ? 1. : -1.) / (fabs(zeta) + sqrt(1. + zeta * zeta));
+                const double c = 1. / sqrt(1. + t * t), s = c * t;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const double ap = A[i][p], aq = A[i][q];
+                    A[i][p] = c * ap - s * aq;
+                    A[i][q] = s * ap + c * aq;
+                    const double vp = V[i][p], vq = V[i][q];
+                    V[i][p] = c * vp - s * vq;
+                    V[i][q] = s * vp + c * vq;
+                }
+            }
+        if (!rotated)
+            break;
+    }
+    int best = 0;
+    double bn = DBL_MAX;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        double nn = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+            nn += A[i][j] * A[i][j];
+        if (nn < bn) {
+            bn = nn;
+            best = j;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+        v[i] = best == 0 ? V[i][0] : best == 1 ? V[i][1] : best == 2 ? V[i][2] : V[i][3];
+}
+
+__global__ __launch_bounds__(128) void triangulate_kernel(Mat34 P1, Mat34 P2, const float2 *__restrict__ x1,
+                                                          const float2 *__restrict__ x2, int n_host,
+                                                          const int *__restrict__ d_n, float *__restrict__ out_xyz,
+                                                          float *__restrict__ out_h, Mat34 Rt, int apply_rt,
+                                                          float *__restrict__ out_world)
+{
+    const int n = d_n ? *d_n : n_host;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    double A[4][4], v[4];
+    const float2 a = x1[i], b = x2[i];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        A[0][k] = (double)a.x * P1.m[8 + k] - P1.m[k];
+        A[1][k] = (double)a.y * P1.m[8 + k] - P1.m[4 + k];
+        A[2][k] = (double)b.x * P2.m[8 + k] - P2.m[k];
+        A[3][k] = (double)b.y * P2.m[8 + k] - P2.m[4 + k];
+    }
+    smallest_right_singular_vector4(A, v);
+    const float h0 = (float)v[0], h1 = (float)v[1], h2 = (float)v[2], h3 = (float)v[3];
+    if (out_h) {
+        out_h[4 * i] = h0;
+        out_h[4 * i + 1] = h1;
+        out_h[4 * i + 2] = h2;
+        out_h[4 * i + 3] = h3;
+    }
+    const float x = h0 / h3, y = h1 / h3, z = h2 / h3;
+    out_xyz[3 * i] = x;
+    out_xyz[3 * i + 1] = y;
+    out_xyz[3 * i + 2] = z;
+    if (apply_rt) {
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+            out_world[3 * i + r] =
+                (float)(Rt.m[4 * r] * x + Rt.m[4 * r + 1] * y + Rt.m[4 * r + 2] * z + Rt.m[4 * r + 3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void transform_kernel(Mat34 Rt, const float *__restrict__ in, int n_host,
+                                                        const int *__restrict__ d_n, float *__restrict__ out)
+{
+    const int n = d_n ? *d_n : n_host;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const float x = in[3 * i], y = in[3 * i + 1], z = in[3 * i + 2];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+        out[3 * i + r] = (float)(Rt.m[4 * r] * x + Rt.m[4 * r + 1] * y + Rt.m[4 * r + 2] * z + Rt.m[4 * r + 3]);
+}
+
+__global__ __launch_bounds__(256) void colors_kernel(const uint8_t *__restrict__ lvl0, int pitch, int w, int h,
+                                                     int c, const float2 *__restrict__ xy, int n_host,
+                                                     const int *__restrict__ d_n, float *__restrict__ out)
+{
+    const int n = d_n ? *d_n : n_host;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    int x = (int)xy[i].x, y = (int)xy[i].y;
+    x = x < 0 ? 0 : (x >= w ? w - 1 : x);  // the reference reads out of bounds here; clamped
+    y = y < 0 ? 0 : (y >= h ? h - 1 : y);
+    const uint8_t *px = lvl0 + (size_t)y * pitch + x * c;
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        out[3 * i + k] = (float)px[c >= 3 ? k : 0];
+}
+
+// Order-preserving compaction of up to three float arrays by a byte mask: one workgroup,
+// each thread owns a contiguous chunk; wave-level scan with DPP-free shuffles is not needed
+// at these sizes (N <= a few 10^4), a two-level LDS scan is enough.
+struct CompactArgs {
+    const float *in[3];
+    float *out[3];
+    int stride[3];
+};
+
+__global__ __launch_bounds__(1024) void compact_kernel(const uint8_t *__restrict__ mask, int n_host,
+                                                       const int *__restrict__ d_n, CompactArgs args,
+                                                       int *__restrict__ d_count)
+{
+    __shared__ int s_sum[1024];
+    const int n = d_n ? *d_n : n_host;
+    const int t = threadIdx.x;
+    const int per = (n + 1023) / 1024;
+    const int b = t * per, e = min(b + per, n);
+    int cnt = 0;
+    for (int i = b; i < e; i++)
+        cnt += mask[i] == 1;
+    s_sum[t] = cnt;
+    __syncthreads();
+    // inclusive scan over 1024 partials (Hillis-Steele)
+    for (int off = 1; off < 1024; off <<= 1) {
+        int v = t >= off ? s_sum[t - off] : 0;
+        __syncthreads();
+        s_sum[t] += v;
+        __syncthreads();
+    }
+    int pos = s_sum[t] - cnt;
+    if (t == 1023 && d_count)
+        *d_count = s_sum[1023];
+    for (int i = b; i < e; i++)
+        if (mask[i] == 1) {
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+                if (args.in[a]) {
+                    const int st = args.stride[a];
+                    for (int k = 0; k < st; k++)
+                        args.out[a][(size_t)pos * st + k] = args.in[a][(size_t)i * st + k];
+                }
+            pos++;
+        }
+}
+
+Mat34 to_mat34(const double *p)
+{
+    Mat34 m;
+    if (p)
+        memcpy(m.m, p, sizeof(m.m));
+    else
+        memset(m.m, 0, sizeof(m.m));
+    return m;
+}
+
+}  // namespace
+
+int svo_launch_triangulate(svo_ctx *ctx, const double *P1, const double *P2, const float *x1, const float *x2,
+                           int cap, const int *d_n, float *out_xyz, float *out_h, const double *Rt,
+                           float *out_world)
+{
+    if (cap <= 0)
+        return SVO_OK;
+    ScopedKernelTime tm(ctx, SVO_K_TRIANGULATE);
+    hipLaunchKernelGGL(triangulate_kernel, dim3((cap + 127) / 128), dim3(128), 0, ctx->stream, to_mat34(P1),
+                       to_mat34(P2), reinterpret_cast<const float2 *>(x1), reinterpret_cast<const float2 *>(x2), cap,
+                       d_n, out_xyz, out_h, to_mat34(Rt), (Rt && out_world) ? 1 : 0, out_world);
+    SVO_HIP(hipGetLastError());
+    return SVO_OK;
+}
+
+int svo_launch_transform(svo_ctx *ctx, const double *Rt, const float *in, int cap, const int *d_n, float *out)
+{
+    if (cap <= 0)
+        return SVO_OK;
+    hipLaunchKernelGGL(transform_kernel, dim3((cap + 255) / 256), dim3(256), 0, ctx->stream, to_mat34(Rt), in, cap,
+                       d_n, out);
+    SVO_HIP(hipGetLastError());
+    return SVO_OK;
+}
+
+int svo_launch_colors(svo_ctx *ctx, const svo_pyramid *pyr, const float *xy, int cap, const int *d_n, float *out)
+{
+    if (cap <= 0)
+        return SVO_OK;
+    hipLaunchKernelGGL(colors_kernel, dim3((cap + 255) / 256), dim3(256), 0, ctx->stream, pyr->dev.lvl[0],
+                       pyr->dev.pitch[0], pyr->w, pyr->h, pyr->c, reinterpret_cast<const float2 *>(xy), cap, d_n,
+                       out);
+    SVO_HIP(hipGetLastError());
+    return SVO_OK;
+}
+
+int svo_launch_compact(svo_ctx *ctx, const uint8_t *mask, int cap, const int *d_n, const float *in_a, int stride_a,
+                       float *out_a, const float *in_b, int stride_b, float *out_b, const float *in_c, int stride_c,
+                       float *out_c, int *d_count)
+{
+    CompactArgs args;
+    args.in[0] = in_a;
+    args.out[0] = out_a;
+    args.stride[0] = stride_a;
+    args.in[1] = in_b;
+    args.out[1] = out_b;
+    args.stride[1] = stride_b;
+    args.in[2] = in_c;
+    args.out[2] = out_c;
+    args.stride[2] = stride_c;
+    hipLaunchKernelGGL(compact_kernel, dim3(1), dim3(1024), 0, ctx->stream, mask, cap, d_n, args, d_count);
+    SVO_HIP(hipGetLastError());
+    return SVO_OK;
+}
+
+extern "C" {
+
+int svo_stereo_projections(double fx, double fy, double cx, double cy, double baseline, double *P1, double *P2)
+{
+    SVO_CHECK_ARG(P1 && P2);
+    const double K[9] = {fx, 0, cx, 0, fy, cy, 0, 0, 1};
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) {
+            P1[4 * i + j] = K[3 * i + j];
+            P2[4 * i + j] = K[3 * i + j];
+        }
+        P1[4 * i + 3] = 0;
+        P2[4 * i + 3] = K[3 * i] * (-baseline);
+    }
+    return SVO_OK;
+}
+
+int svo_triangulate(svo_ctx *ctx, const double *P1, const double *P2, const float *x1, const float *x2, int n,
+                    float *out_xyz, float *out_h4, int mem)
+{
+    SVO_CHECK_ARG(ctx && P1 && P2 && n >= 0);
+    SVO_CHECK_ARG(mem == SVO_MEM_HOST || mem == SVO_MEM_DEVICE);
+    if (n == 0)
+        return SVO_OK;
+    SVO_CHECK_ARG(x1 && x2 && out_xyz);
+    if (mem == SVO_MEM_DEVICE)
+        return svo_launch_triangulate(ctx, P1, P2, x1, x2, n, nullptr, out_xyz, out_h4, nullptr, nullptr);
+    int rc;
+    if ((rc = ctx->s_a.ensure((size_t)n * 8)) || (rc = ctx->s_b.ensure((size_t)n * 8)) ||
+        (rc = ctx->s_c.ensure((size_t)n * 12)) || (rc = ctx->s_d.ensure((size_t)n * 16)))
+        return rc;
+    SVO_HIP(hipMemcpyAsync(ctx->s_a.p, x1, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    SVO_HIP(hipMemcpyAsync(ctx->s_b.p, x2, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    rc = svo_launch_triangulate(ctx, P1, P2, ctx->s_a.as<float>(), ctx->s_b.as<float>(), n, nullptr,
+                                ctx->s_c.as<float>(), ctx->s_d.as<float>(), nullptr, nullptr);
+    if (rc)
+        return rc;
+    SVO_HIP(hipMemcpyAsync(out_xyz, ctx->s_c.p, (size_t)n * 12, hipMemcpyDeviceToHost, ctx->stream));
+    if (out_h4)
+        SVO_HIP(hipMemcpyAsync(out_h4, ctx->s_d.p, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
+    SVO_HIP(hipStreamSynchronize(ctx->stream));
+    return SVO_OK;
+}
+
+int svo_transform_points(svo_ctx *ctx, const double *Rt, const float *in_xyz, int n, float *out_xyz, int mem)
+{
+    SVO_CHECK_ARG(ctx && Rt && n >= 0);
+    SVO_CHECK_ARG(mem == SVO_MEM_HOST || mem == SVO_MEM_DEVICE);
+    if (n == 0)
+        return SVO_OK;
+    SVO_CHECK_ARG(in_xyz && out_xyz);
+    if (mem == SVO_MEM_DEVICE)
+        return svo_launch_transform(ctx, Rt, in_xyz, n, nullptr, out_xyz);
+    int rc;
+    if ((rc = ctx->s_a.ensure((size_t)n * 12)) || (rc = ctx->s_b.ensure((size_t)n * 12)))
+        return rc;
+    SVO_HIP(hipMemcpyAsync(ctx->s_a.p, in_xyz, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
+    rc = svo_launch_transform(ctx, Rt, ctx->s_a.as<float>(), n, nullptr, ctx->s_b.as<float>());
+    if (rc)
+        return rc;
+    SVO_HIP(hipMemcpyAsync(out_xyz, ctx->s_b.p, (size_t)n * 12, hipMemcpyDeviceToHost, ctx->stream));
+    SVO_HIP(hipStreamSynchronize(ctx->stream));
+    return SVO_OK;
+}
+
+int svo_get_colors(svo_ctx *ctx, const svo_pyramid *pyr, const float *xy, int n, float *out_bgr, int mem)
+{
+    SVO_CHECK_ARG(ctx && pyr && n >= 0);
+    SVO_CHECK_ARG(mem == SVO_MEM_HOST || mem == SVO_MEM_DEVICE);
+    if (n == 0)
+        return SVO_OK;
+    SVO_CHECK_ARG(xy && out_bgr);
+    if (mem == SVO_MEM_DEVICE)
+        return svo_launch_colors(ctx, pyr, xy, n, nullptr, out_bgr);
+    int rc;
+    if ((rc = ctx->s_a.ensure((size_t)n * 8)) || (rc = ctx->s_b.ensure((size_t)n * 12)))
+        return rc;
+    SVO_HIP(hipMemcpyAsync(ctx->s_a.p, xy, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+    rc = svo_launch_colors(ctx, pyr, ctx->s_a.as<float>(), n, nullptr, ctx->s_b.as<float>());
+    if (rc)
+        return rc;
+    SVO_HIP(hipMemcpyAsync(out_bgr, ctx->s_b.p, (size_t)n * 12, hipMemcpyDeviceToHost, ctx->stream));
+    SVO_HIP(hipStreamSynchronize(ctx->stream));
+    return SVO_OK;
+}
+
+int svo_compact(svo_ctx *ctx, const uint8_t *mask, int n, const float *in_a, int stride_a, float *out_a,
+                const float *in_b, int stride_b, float *out_b, const float *in_c, int stride_c, float *out_c,
+                int *count, int mem)
+{
+    SVO_CHECK_ARG(ctx && n >= 0);
+    SVO_CHECK_ARG(mem == SVO_MEM_HOST || mem == SVO_MEM_DEVICE);
+    SVO_CHECK_ARG(stride_a >= 0 && stride_b >= 0 && stride_c >= 0 && stride_a <= 8 && stride_b <= 8 && stride_c <= 8);
+    if (n == 0) {
+        if (count && mem == SVO_MEM_HOST)
+            *count = 0;
+        return SVO_OK;
+    }
+    SVO_CHECK_ARG(mask);
+    if (mem == SVO_MEM_DEVICE)
+        return svo_launch_compact(ctx, mask, n, nullptr, in_a, stride_a, out_a, in_b, stride_b, out_b, in_c,
+                                  stride_c, out_c, count);
+    const float *in[3] = {in_a, in_b, in_c};
+    float *out[3] = {out_a, out_b, out_c};
+    const int st[3] = {stride_a, stride_b, stride_c};
+    DevBuf *bi[3] = {&ctx->s_a, &ctx->s_b, &ctx->s_c};
+    DevBuf *bo[3] = {&ctx->s_d, &ctx->s_e, &ctx->s_f};
+    int rc;
+    const size_t count_off = ((size_t)n + 63) & ~(size_t)63;  // the count lives behind the mask bytes
+    if ((rc = ctx->s_g.ensure(count_off + 64)))
+        return rc;
+    SVO_HIP(hipMemcpyAsync(ctx->s_g.p, mask, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    const float *din[3] = {nullptr, nullptr, nullptr};
+    float *dout[3] = {nullptr, nullptr, nullptr};
+    for (int a = 0; a < 3; a++)
+        if (in[a] && out[a] && st[a] > 0) {
+            size_t bytes = (size_t)n * st[a] * 4;
+            if ((rc = bi[a]->ensure(bytes)) || (rc = bo[a]->ensure(bytes)))
+                return rc;
+            SVO_HIP(hipMemcpyAsync(bi[a]->p, in[a], bytes, hipMemcpyHostToDevice, ctx->stream));
+            din[a] = bi[a]->as<float>();
+            dout[a] = bo[a]->as<float>();
+        }
+    int *dcount = reinterpret_cast<int *>(ctx->s_g.as<uint8_t>() + count_off);
+    rc = svo_launch_compact(ctx, ctx->s_g.as<uint8_t>(), n, nullptr, din[0], st[0], dout[0], din[1], st[1], dout[1],
+                            din[2], st[2], dout[2], dcount);
+    if (rc)
+        return rc;
+    SVO_HIP(hipMemcpyAsync(ctx->pinned, dcount, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    SVO_HIP(hipStreamSynchronize(ctx->stream));
+    const int k = *reinterpret_cast<int *>(ctx->pinned);
+    for (int a = 0; a < 3; a++)
+        if (dout[a])
+            SVO_HIP(hipMemcpyAsync(out[a], dout[a], (size_t)k * st[a] * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SVO_HIP(hipStreamSynchronize(ctx->stream));
+    if (count)
+        *count = k;
+    return SVO_OK;
+}
+
+}  // extern "C"

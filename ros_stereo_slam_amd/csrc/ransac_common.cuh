@@ -1,0 +1,64 @@
+// ransac_common.cuh -- device helpers shared by the F-matrix and PnP RANSAC kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstdint>
+
+namespace svo {
+
+// Counter-based generator: draw k of RANSAC iteration i is a pure function of
+// (seed, i, k), so every iteration can be evaluated concurrently and the SEQUENTIAL
+// algorithm (first-best-wins, adaptive iteration count) is reproduced afterwards.
+__host__ __device__ __forceinline__ uint32_t rng_u32(uint64_t seed, uint32_t iter, uint32_t draw)
+{
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * ((((uint64_t)iter << 32) | draw) + 1ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (uint32_t)(z >> 32);
+}
+
+constexpr int kMaxAttempts = 8;
+constexpr int kMaxDraws = 64;
+
+// cv RANSACUpdateNumIters
+__device__ __forceinline__ int update_num_iters(double p, double ep, int model_points, int max_iters)
+{
+    p = p < 0 ? 0 : (p > 1 ? 1 : p);
+    ep = ep < 0 ? 0 : (ep > 1 ? 1 : ep);
+    double num = 1. - p;
+    if (num < DBL_MIN)
+        num = DBL_MIN;
+    double denom = 1. - pow(1. - ep, (double)model_points);
+    if (denom < DBL_MIN)
+        return 0;
+    num = log(num);
+    denom = log(denom);
+    return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)rint(num / denom);
+}
+
+// running state of the sequential RANSAC loop, kept in HBM between the phase kernels
+struct RansacState {
+    int niters;      // current iteration bound (starts at max_iters)
+    int next_iter;   // first iteration the select pass has not looked at yet
+    int best_iter;   // -1 = none
+    int best_model;
+    int best_count;
+    int done;        // 1: loop finished (next_iter >= niters or a subset draw failed)
+    int iters_run;
+    int pad;
+};
+
+// exact wave-wide integer sum (values small enough that no carry handling is needed)
+__device__ __forceinline__ int wave_sum_small(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);  // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);  // row_mirror
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) +
+           __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+}
+
+}  // namespace svo

@@ -104,3 +104,17 @@ int svo_build_pyramid_from_device(svo_ctx *ctx, svo_pyramid *pyr, const uint8_t 
 int svo_launch_lk(svo_ctx *ctx, const PyrDev &prev, const PyrDev &next, const float *prev_pts,
                   int n, float *next_pts, uint8_t *status, float *err, float *min_eig);
 int svo_launch_grid(svo_ctx *ctx, int rows, int cols, int step, float *out_xy, int cap);
+
+// fransac.hip
+int svo_launch_fransac(svo_ctx *ctx, const float *p1, const float *p2, int cap, const int *d_n,
+                       double threshold, double confidence, int max_iters, uint64_t seed, uint8_t *mask,
+                       double *d_F, int *d_count, int *d_iters);
+// geometry.hip
+int svo_launch_triangulate(svo_ctx *ctx, const double *P1, const double *P2, const float *x1, const float *x2,
+                           int cap, const int *d_n, float *out_xyz, float *out_h, const double *Rt,
+                           float *out_world);
+int svo_launch_transform(svo_ctx *ctx, const double *Rt, const float *in, int cap, const int *d_n, float *out);
+int svo_launch_colors(svo_ctx *ctx, const svo_pyramid *pyr, const float *xy, int cap, const int *d_n, float *out);
+int svo_launch_compact(svo_ctx *ctx, const uint8_t *mask, int cap, const int *d_n, const float *in_a, int stride_a,
+                       float *out_a, const float *in_b, int stride_b, float *out_b, const float *in_c, int stride_c,
+                       float *out_c, int *d_count);

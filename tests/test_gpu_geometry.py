@@ -1,0 +1,122 @@
+"""GPU parity for compaction, F-RANSAC, triangulation, rigid transform and colour gather
+(through the C ABI) against the CPU oracle."""
+import numpy as np
+import pytest
+from scipy.spatial.transform import Rotation as Rot
+
+from geom_fixtures import BASELINE, K4, project, scene_points, two_view
+from ros_stereo_slam_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n", [1, 7, 1000, 4428, 20000])
+def test_compact_order_preserving(ctx, n):
+    rng = np.random.default_rng(n)
+    mask = (rng.uniform(size=n) < 0.7).astype(np.uint8)
+    mask[rng.integers(0, n, max(1, n // 50))] = 2  # only ==1 is kept (status / mask are 0 or 1 upstream)
+    a = rng.normal(size=(n, 2)).astype(np.float32)
+    b = rng.normal(size=(n, 3)).astype(np.float32)
+    c = rng.normal(size=(n, 2)).astype(np.float32)
+    oa, ob, oc = ctx.compact(mask, a, b, c)
+    keep = mask == 1
+    assert np.array_equal(oa, a[keep]) and np.array_equal(ob, b[keep]) and np.array_equal(oc, c[keep])
+    (only,) = ctx.compact(mask, a)
+    assert np.array_equal(only, a[keep])
+
+
+def test_compact_all_and_none(ctx):
+    a = np.arange(20, dtype=np.float32).reshape(10, 2)
+    assert len(ctx.compact(np.zeros(10, np.uint8), a)[0]) == 0
+    assert np.array_equal(ctx.compact(np.ones(10, np.uint8), a)[0], a)
+
+
+@pytest.mark.parametrize("thr", [1.0, 3.0])
+@pytest.mark.parametrize("seed", [1, 42, 77])
+def test_fransac_matches_oracle(ctx, orc, thr, seed):
+    x1, x2, gt, *_ = two_view(n=1200, n_out=300, seed=seed, noise=0.15)
+    gc, gmask, gF, git = ctx.fransac(x1, x2, thr, seed=seed)
+    oc, omask, oF, oit = orc.fransac(x1, x2, thr, seed=seed)
+    # same samples, same sequential semantics: iteration count and winner agree
+    assert git == oit
+    # masks may differ only for correspondences within float noise of the threshold
+    diff = np.nonzero(gmask != omask)[0]
+    assert len(diff) <= 2, diff
+    if len(diff):
+        e = orc.f_error(oF, x1[diff], x2[diff])
+        assert np.all(np.abs(e - thr * thr) < 1e-3 * thr * thr)
+    assert abs(gc - oc) <= 2
+    # same model up to sign
+    s = np.sign(np.sum(gF * oF))
+    assert np.abs(gF * s - oF).max() < 1e-7
+    assert (gmask.astype(bool) & gt).sum() >= 0.85 * gt.sum()
+
+
+def test_fransac_low_inlier_ratio_runs_phase_two(ctx, orc):
+    """40% inliers: the adaptive bound stays above 64, so the second phase must run."""
+    x1, x2, gt, *_ = two_view(n=800, n_out=480, seed=3, noise=0.1)
+    gc, gmask, gF, git = ctx.fransac(x1, x2, 1.0, seed=11)
+    oc, omask, oF, oit = orc.fransac(x1, x2, 1.0, seed=11)
+    assert oit > 64 and git == oit
+    assert (gmask != omask).sum() <= 2
+    assert (gmask.astype(bool) & gt).sum() >= 0.80 * gt.sum()
+
+
+def test_fransac_degenerate(ctx):
+    x1, x2, *_ = two_view(n=6, n_out=0)
+    cnt, mask, F, it = ctx.fransac(x1, x2, 1.0)
+    assert cnt == 0 and mask.sum() == 0
+    cnt, mask, F, it = ctx.fransac(np.zeros((0, 2)), np.zeros((0, 2)), 1.0)
+    assert cnt == 0
+
+
+def test_fransac_full_size(ctx, orc):
+    """BASELINE size: 4096 correspondences."""
+    x1, x2, gt, *_ = two_view(n=4096, n_out=500, seed=8, noise=0.2)
+    gc, gmask, gF, git = ctx.fransac(x1, x2, 1.0, seed=2)
+    oc, omask, oF, oit = orc.fransac(x1, x2, 1.0, seed=2)
+    assert git == oit and (gmask != omask).sum() <= 3
+
+
+def test_triangulate_matches_oracle(ctx, orc):
+    P1, P2 = capi.stereo_projections(*K4, BASELINE)
+    o1, o2 = orc.stereo_projections(*K4, BASELINE)
+    assert np.array_equal(P1, o1) and np.array_equal(P2, o2)
+    X = scene_points(4428, 3)
+    rng = np.random.default_rng(0)
+    a = project(X).astype(np.float32)
+    b = (project(X, np.eye(3), np.array([-BASELINE, 0, 0])) + rng.normal(0, 0.3, (4428, 2))).astype(np.float32)
+    gx, gh = ctx.triangulate(P1, P2, a, b)
+    ox, oh = orc.triangulate(P1, P2, a, b)
+    sign = np.sign(np.sum(gh * oh, axis=1, keepdims=True))
+    assert np.abs(gh * sign - oh).max() < 1e-6
+    assert np.allclose(gx, ox, rtol=1e-5, atol=1e-5)
+
+
+def test_triangulate_degenerate_points_are_kept(ctx, orc):
+    """Zero disparity (point at infinity) and negative disparity are not filtered upstream."""
+    P1, P2 = capi.stereo_projections(*K4, BASELINE)
+    a = np.array([[600, 180], [300, 100]], np.float32)
+    b = np.array([[600, 180], [310, 100]], np.float32)  # zero / negative disparity
+    gx, _ = ctx.triangulate(P1, P2, a, b)
+    ox, _ = orc.triangulate(P1, P2, a, b)
+    assert gx.shape == (2, 3)
+    assert gx[1, 2] < 0 and ox[1, 2] < 0
+    assert np.allclose(gx[1], ox[1], rtol=1e-4)
+
+
+def test_transform_points_bit_exact(ctx, orc):
+    rng = np.random.default_rng(1)
+    Rt = np.c_[Rot.from_rotvec([0.2, -0.1, 0.3]).as_matrix(), [1.5, -0.2, 10.0]]
+    pts = rng.uniform(-50, 50, (5000, 3)).astype(np.float32)
+    assert np.array_equal(ctx.transform_points(Rt, pts).view(np.uint32), orc.transform_points(Rt, pts).view(np.uint32))
+
+
+@pytest.mark.parametrize("c", [1, 3])
+def test_get_colors(ctx, orc, c):
+    rng = np.random.default_rng(2)
+    img = rng.integers(0, 256, (120, 160, c), dtype=np.uint8)
+    pyr = ctx.pyramid(160, 120, c).build(img)
+    xy = rng.uniform([0, 0], [159.99, 119.99], (500, 2)).astype(np.float32)
+    assert np.array_equal(ctx.get_colors(pyr, xy), orc.get_colors(img, xy))
+    pyr.close()
