@@ -134,6 +134,24 @@ int svo_transform_points(svo_ctx *ctx, const double *Rt, const float *in_xyz, in
 /* getColors, include/monoUtils.h:180-193: B,G,R of level 0 at (int(y), int(x)) as floats.      */
 int svo_get_colors(svo_ctx *ctx, const svo_pyramid *pyr, const float *xy, int n, float *out_bgr, int mem);
 
+/* ---- ANMS: adaptiveNonMaximalSuppresion(keypoints, numToKeep), src/ANMS.cpp:18-67 ------------ */
+/* xy: n*2 floats, response: n floats (the reference's grid keypoints carry response 0; the
+ * front-end passes the level-0 LK minimum eigenvalue).  out_idx: n ints capacity, receives the
+ * input indices of the kept keypoints in the reference's output order (response-sorted).
+ * count: host or device int following `mem`.                                                  */
+int svo_anms(svo_ctx *ctx, const float *xy, const float *response, int n, int num_to_keep, int *out_idx,
+             int *count, int mem);
+
+/* ---- PnP-RANSAC: cv::solvePnPRansac(obj,img,K,0,rvec,tvec,false,its,thr,conf,inliers) --------- */
+/* replaces src/keyFrameManagement.cpp:84 (100, 1.0, 0.99) and :88 (100, 8.0, 0.98).
+ * obj: n*3 floats (world), img: n*2 floats, K4 = {fx, fy, cx, cy} (HOST doubles), no
+ * distortion.  rvec/tvec/n_inliers/iters_run are HOST outputs in both memory modes (the caller
+ * branches on them, src/keyFrameManagement.cpp:85, src/VisualSLAM.cpp:120); `inliers`
+ * (n ints capacity, ascending indices) follows `mem`.  The call synchronises.                 */
+int svo_pnp_ransac(svo_ctx *ctx, const float *obj, const float *img, int n, const double *K4,
+                   int iterations, double reproj_err, double confidence, uint64_t seed, double *rvec,
+                   double *tvec, int *inliers, int *n_inliers, int *iters_run, int mem);
+
 #ifdef __cplusplus
 }
 #endif

@@ -173,3 +173,139 @@ def compose_camera_pose(rvec, tvec):
     load().orc_compose_camera_pose(_p(np.ascontiguousarray(rvec, np.float64)),
                                    _p(np.ascontiguousarray(tvec, np.float64)), _p(R), _p(t))
     return R, t
+
+
+# ---- PnP ------------------------------------------------------------------------------------
+class PnpParams(C.Structure):
+    _fields_ = [("iterations", C.c_int), ("reproj_err", C.c_double), ("confidence", C.c_double),
+                ("seed", C.c_uint64), ("refine_iters", C.c_int)]
+
+
+def epnp(obj, img, K4):
+    obj = np.ascontiguousarray(obj, np.float64).reshape(-1, 3)
+    img = np.ascontiguousarray(img, np.float64).reshape(-1, 2)
+    R, t = np.zeros((3, 3)), np.zeros(3)
+    rc = load().orc_epnp(_p(obj), _p(img), len(obj), _p(np.ascontiguousarray(K4, np.float64)), _p(R), _p(t))
+    return rc, R, t
+
+
+def pnp_hypothesis(obj, img, K4, seed, it):
+    obj = np.ascontiguousarray(obj, np.float32).reshape(-1, 3)
+    img = np.ascontiguousarray(img, np.float32).reshape(-1, 2)
+    R, t = np.zeros((3, 3)), np.zeros(3)
+    f = load().orc_pnp_hypothesis
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]
+    rc = f(_p(obj), _p(img), len(obj), _p(np.ascontiguousarray(K4, np.float64)), seed, it, _p(R), _p(t))
+    return rc, R, t
+
+
+def pnp_ransac(obj, img, K4, iterations=100, reproj_err=1.0, confidence=0.99, seed=0, refine_iters=20):
+    obj = np.ascontiguousarray(obj, np.float32).reshape(-1, 3)
+    img = np.ascontiguousarray(img, np.float32).reshape(-1, 2)
+    n = len(obj)
+    rvec, tvec = np.zeros(3), np.zeros(3)
+    inl = np.zeros(max(n, 1), np.int32)
+    iters = C.c_int()
+    prm = PnpParams(iterations, reproj_err, confidence, seed, refine_iters)
+    cnt = load().orc_pnp_ransac(_p(obj), _p(img), n, _p(np.ascontiguousarray(K4, np.float64)), C.byref(prm),
+                                _p(rvec), _p(tvec), _p(inl), C.byref(iters))
+    return cnt, rvec, tvec, inl[:cnt].copy(), iters.value
+
+
+def pnp_refine(obj, img, idx, K4, rvec, tvec, max_iters=20):
+    obj = np.ascontiguousarray(obj, np.float32).reshape(-1, 3)
+    img = np.ascontiguousarray(img, np.float32).reshape(-1, 2)
+    idx = np.ascontiguousarray(idx, np.int32)
+    rvec, tvec = np.array(rvec, np.float64), np.array(tvec, np.float64)
+    f = load().orc_pnp_refine
+    f.restype = C.c_double
+    rms = f(_p(obj), _p(img), _p(idx), len(idx), _p(np.ascontiguousarray(K4, np.float64)), _p(rvec), _p(tvec),
+            max_iters)
+    return rms, rvec, tvec
+
+
+def jacobi_eigen_sym(A, sweeps=12):
+    A = np.array(A, np.float64)
+    n = A.shape[0]
+    V, w = np.zeros((n, n)), np.zeros(n)
+    load().orc_jacobi_eigen_sym(n, _p(A), _p(V), _p(w), sweeps)
+    return w, V
+
+
+def anms(xy, response, num_to_keep):
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    response = np.ascontiguousarray(response, np.float32)
+    n = len(xy)
+    idx = np.zeros(max(n, 1), np.int32)
+    radii = np.zeros(max(n, 1), np.float64)
+    k = load().orc_anms(_p(xy), _p(response), n, num_to_keep, _p(idx), _p(radii))
+    return idx[:k].copy(), radii[:n]
+
+
+# ---- front-end frame loop -----------------------------------------------------------------
+class VoParams(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("baseline", C.c_double), ("grid_step", C.c_int), ("anms_keep", C.c_int),
+                ("keyframe_min_inliers", C.c_int), ("f_thr_stereo", C.c_double),
+                ("f_thr_temporal", C.c_double), ("seed", C.c_uint64)]
+
+
+class VO:
+    """Oracle front-end (src/VisualSLAM.cpp:11-169)."""
+
+    def __init__(self, w, h, c, grid_step=30, anms_keep=0, keyframe_min_inliers=200, seed=0, K4=None,
+                 baseline=None):
+        lib = load()
+        self.prm = VoParams()
+        lib.orc_vo_default_params(C.byref(self.prm))
+        self.prm.grid_step, self.prm.anms_keep = grid_step, anms_keep
+        self.prm.keyframe_min_inliers, self.prm.seed = keyframe_min_inliers, seed
+        if K4 is not None:
+            self.prm.fx, self.prm.fy, self.prm.cx, self.prm.cy = K4
+        if baseline is not None:
+            self.prm.baseline = baseline
+        lib.orc_vo_create.restype = C.c_void_p
+        self._h = C.c_void_p(lib.orc_vo_create(C.byref(self.prm), w, h, c))
+        self.lib = lib
+
+    def init(self, left, right):
+        return self.lib.orc_vo_init(self._h, _p(np.ascontiguousarray(left)), _p(np.ascontiguousarray(right)))
+
+    def localize(self, left):
+        R, t = np.zeros((3, 3)), np.zeros(3)
+        ninl, ntrk = C.c_int(), C.c_int()
+        rc = self.lib.orc_vo_localize(self._h, _p(np.ascontiguousarray(left)), _p(R), _p(t), C.byref(ninl),
+                                      C.byref(ntrk))
+        return rc, R, t, ninl.value, ntrk.value
+
+    def update(self, left, right, R, t, n_inliers, force_keyframe=False):
+        kf = C.c_int()
+        rc = self.lib.orc_vo_update(self._h, _p(np.ascontiguousarray(left)),
+                                    _p(np.ascontiguousarray(right)) if right is not None else None,
+                                    _p(np.ascontiguousarray(R, np.float64)), _p(np.ascontiguousarray(t, np.float64)),
+                                    n_inliers, int(force_keyframe), C.byref(kf))
+        return rc, bool(kf.value)
+
+    def track(self, left, right, force_keyframe=False):
+        rc, R, t, ninl, ntrk = self.localize(left)
+        if rc:
+            return rc, R, t, ninl, False, ntrk
+        rc, kf = self.update(left, right, R, t, ninl, force_keyframe)
+        return rc, R, t, ninl, kf, ntrk
+
+    def ref(self):
+        n = self.lib.orc_vo_num_ref(self._h)
+        a, b = np.zeros((n, 2), np.float32), np.zeros((n, 3), np.float32)
+        self.lib.orc_vo_get_ref(self._h, _p(a), _p(b))
+        return a, b
+
+    def close(self):
+        if self._h:
+            self.lib.orc_vo_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

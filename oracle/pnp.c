@@ -1,0 +1,732 @@
+/*
+ * oracle/pnp.c -- CPU restatement of cv::solvePnPRansac as the reference calls it
+ * (TEST INFRASTRUCTURE; see svo_oracle.h.  PARITY UNPINNED.)
+ *
+ * Reference call sites: src/keyFrameManagement.cpp:84
+ *   solvePnPRansac(obj, img, K, dist=0, rvec, tvec, false, 100, 1.0, 0.99, inliers)
+ * and the retry at :88 with (100, 8.0, 0.98).  Default flags = SOLVEPNP_ITERATIVE.
+ *
+ * Upstream algorithm restated: RANSAC over 5-point samples solved
+ * by EPnP (Lepetit/Moreno-Noguer/Fua: 4 control points from the PCA of the sample,
+ * barycentric coordinates, 2n x 12 system M, the four eigenvectors of M^T M with the
+ * smallest eigenvalues, betas from the N = 1, 2, 3 linearisations each polished by 5
+ * Gauss-Newton steps on the 6 control-point distances, rigid alignment by the SVD of the
+ * 3x3 cross-covariance, best reprojection error wins); inlier iff the squared
+ * reprojection error (float) <= (float)thr^2; at most `iterations` iterations with the
+ * adaptive bound log(1-conf)/log(1-w^5); then one iterative refinement (Levenberg-
+ * Marquardt on the reprojection error) over the inliers of the best hypothesis, seeded
+ * with that hypothesis.  Outputs rvec/tvec (double) and the inlier index list.
+ *
+ * Stated deviations: counter-based sampling (see geometry.c); symmetric eigenproblems and
+ * the 3x3 SVD use cyclic Jacobi with a fixed round-robin pair order (cv::SVD is a Jacobi
+ * method too, with a different sweep order); least-squares sub-problems go through the
+ * normal equations + Jacobi pseudo-inverse; the refinement perturbs the pose on the left
+ * (R <- exp(dw) R) instead of differentiating through Rodrigues -- same minimiser.
+ */
+#include "svo_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+int orc_draw_subset_plain(uint64_t seed, uint32_t iter, int n, int m, int *idx);
+int orc_update_num_iters(double p, double ep, int model_points, int max_iters);
+
+/* ---- cyclic Jacobi for symmetric matrices, round-robin ("tournament") pair order ------- */
+/* The pair schedule is the one a wavefront executes in parallel on the GPU: n-1 rounds
+ * (n even; odd n is padded with an idle player) of n/2 disjoint pairs.                    */
+static int rr_pairs(int n, int round, int (*pairs)[2])
+{
+    int m = n + (n & 1), cnt = 0;
+    for (int k = 0; k < m / 2; k++) {
+        int a = k == 0 ? m - 1 : (round + k) % (m - 1);
+        int b = k == 0 ? round % (m - 1) : (round - k + (m - 1)) % (m - 1);
+        if (a >= n || b >= n)
+            continue;
+        pairs[cnt][0] = a < b ? a : b;
+        pairs[cnt][1] = a < b ? b : a;
+        cnt++;
+    }
+    return cnt;
+}
+
+/* A (n x n, row-major, symmetric) -> eigenvalues w (diagonal), eigenvectors = COLUMNS of V.
+ * Per round: the rotations of all (disjoint) pairs are computed from the current matrix,
+ * then ALL column updates, then ALL row updates, then V -- the order a wavefront applies
+ * them in parallel, so both implementations round identically.                            */
+void orc_jacobi_eigen_sym(int n, double *A, double *V, double *w, int sweeps)
+{
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++)
+            V[i * n + j] = i == j;
+    int m = n + (n & 1);
+    int pairs[16][2];
+    double cs[16][2];
+    for (int s = 0; s < sweeps; s++)
+        for (int r = 0; r < m - 1; r++) {
+            int np = rr_pairs(n, r, pairs);
+            for (int e = 0; e < np; e++) {
+                int p = pairs[e][0], q = pairs[e][1];
+                double apq = A[p * n + q];
+                if (apq == 0.) {
+                    cs[e][0] = 1.;
+                    cs[e][1] = 0.;
+                    continue;
+                }
+                double app = A[p * n + p], aqq = A[q * n + q];
+                double theta = (aqq - app) / (2. * apq);
+                double t = (theta >= 0 ? 1. : -1.) / (fabs(theta) + sqrt(theta * theta + 1.));
+                double c = 1. / sqrt(t * t + 1.);
+                cs[e][0] = c;
+                cs[e][1] = t * c;
+            }
+            for (int e = 0; e < np; e++) { /* columns p,q:  A <- A J */
+                int p = pairs[e][0], q = pairs[e][1];
+                double c = cs[e][0], sn = cs[e][1];
+                for (int k = 0; k < n; k++) {
+                    double akp = A[k * n + p], akq = A[k * n + q];
+                    A[k * n + p] = c * akp - sn * akq;
+                    A[k * n + q] = sn * akp + c * akq;
+                }
+            }
+            for (int e = 0; e < np; e++) { /* rows p,q:  A <- J^T A */
+                int p = pairs[e][0], q = pairs[e][1];
+                double c = cs[e][0], sn = cs[e][1];
+                for (int k = 0; k < n; k++) {
+                    double apk = A[p * n + k], aqk = A[q * n + k];
+                    A[p * n + k] = c * apk - sn * aqk;
+                    A[q * n + k] = sn * apk + c * aqk;
+                }
+            }
+            for (int e = 0; e < np; e++) {
+                int p = pairs[e][0], q = pairs[e][1];
+                double c = cs[e][0], sn = cs[e][1];
+                for (int k = 0; k < n; k++) {
+                    double vkp = V[k * n + p], vkq = V[k * n + q];
+                    V[k * n + p] = c * vkp - sn * vkq;
+                    V[k * n + q] = sn * vkp + c * vkq;
+                }
+            }
+        }
+    for (int i = 0; i < n; i++)
+        w[i] = A[i * n + i];
+}
+
+/* min ||A x - b|| (m x n, n <= 5) through the normal equations, Tikhonov-damped by 1e-14 of
+ * the mean diagonal (stands in for the SVD / QR solves of upstream EPnP; a singular system
+ * yields x = 0) and solved by Cholesky.                                                    */
+static void lstsq_small(int m, int n, const double *A, const double *b, double *x)
+{
+    double N[25], rhs[5], L[25], y[5];
+    double tr = 0;
+    for (int i = 0; i < n; i++) {
+        for (int j = 0; j < n; j++) {
+            double s = 0;
+            for (int k = 0; k < m; k++)
+                s += A[k * n + i] * A[k * n + j];
+            N[i * n + j] = s;
+        }
+        double s = 0;
+        for (int k = 0; k < m; k++)
+            s += A[k * n + i] * b[k];
+        rhs[i] = s;
+        tr += N[i * n + i];
+    }
+    const double damp = 1e-14 * tr / n;
+    for (int i = 0; i < n; i++)
+        x[i] = 0;
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j <= i; j++) {
+            double s = N[i * n + j] + (i == j ? damp : 0.);
+            for (int k = 0; k < j; k++)
+                s -= L[i * n + k] * L[j * n + k];
+            if (i == j) {
+                if (!(s > 0))
+                    return;
+                L[i * n + i] = sqrt(s);
+            } else
+                L[i * n + j] = s / L[j * n + j];
+        }
+    for (int i = 0; i < n; i++) {
+        double s = rhs[i];
+        for (int k = 0; k < i; k++)
+            s -= L[i * n + k] * y[k];
+        y[i] = s / L[i * n + i];
+    }
+    for (int i = n - 1; i >= 0; i--) {
+        double s = y[i];
+        for (int k = i + 1; k < n; k++)
+            s -= L[k * n + i] * x[k];
+        x[i] = s / L[i * n + i];
+    }
+}
+
+/* SVD of a 3x3 matrix by one-sided Jacobi: A = U diag(s) V^T */
+static void svd3(const double *Ain, double *U, double *Vout)
+{
+    double A[9], V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    memcpy(A, Ain, sizeof(A));
+    static const int PQ[3][2] = {{0, 1}, {0, 2}, {1, 2}};
+    for (int sweep = 0; sweep < 30; sweep++) {
+        int rotated = 0;
+        for (int e = 0; e < 3; e++) {
+            int p = PQ[e][0], q = PQ[e][1];
+            double al = 0, be = 0, ga = 0;
+            for (int i = 0; i < 3; i++) {
+                al += A[3 * i + p] * A[3 * i + p];
+                be += A[3 * i + q] * A[3 * i + q];
+                ga += A[3 * i + p] * A[3 * i + q];
+            }
+            if (ga == 0 || fabs(ga) <= DBL_EPSILON * sqrt(al * be))
+                continue;
+            rotated = 1;
+            double zeta = (be - al) / (2. * ga);
+            double t = (zeta >= 0 ? 1. : -1.) / (fabs(zeta) + sqrt(1. + zeta * zeta));
+            double c = 1. / sqrt(1. + t * t), s = c * t;
+            for (int i = 0; i < 3; i++) {
+                double ap = A[3 * i + p], aq = A[3 * i + q];
+                A[3 * i + p] = c * ap - s * aq;
+                A[3 * i + q] = s * ap + c * aq;
+                double vp = V[3 * i + p], vq = V[3 * i + q];
+                V[3 * i + p] = c * vp - s * vq;
+                V[3 * i + q] = s * vp + c * vq;
+            }
+        }
+        if (!rotated)
+            break;
+    }
+    /* columns of A are u_j * s_j; order by decreasing norm, rebuild a right-handed U */
+    double nrm[3];
+    int ord[3] = {0, 1, 2};
+    for (int j = 0; j < 3; j++)
+        nrm[j] = sqrt(A[j] * A[j] + A[3 + j] * A[3 + j] + A[6 + j] * A[6 + j]);
+    for (int a = 0; a < 2; a++)
+        for (int b = a + 1; b < 3; b++)
+            if (nrm[ord[b]] > nrm[ord[a]]) {
+                int t = ord[a];
+                ord[a] = ord[b];
+                ord[b] = t;
+            }
+    double Uc[3][3], Vc[3][3];
+    for (int k = 0; k < 3; k++) {
+        int j = ord[k];
+        for (int i = 0; i < 3; i++) {
+            Vc[k][i] = V[3 * i + j];
+            Uc[k][i] = nrm[j] > 0 ? A[3 * i + j] / nrm[j] : 0;
+        }
+    }
+    /* a (near-)zero singular value leaves its u undefined: complete the basis */
+    if (!(nrm[ord[2]] > 1e-12 * nrm[ord[0]])) {
+        Uc[2][0] = Uc[0][1] * Uc[1][2] - Uc[0][2] * Uc[1][1];
+        Uc[2][1] = Uc[0][2] * Uc[1][0] - Uc[0][0] * Uc[1][2];
+        Uc[2][2] = Uc[0][0] * Uc[1][1] - Uc[0][1] * Uc[1][0];
+    }
+    for (int k = 0; k < 3; k++)
+        for (int i = 0; i < 3; i++) {
+            U[3 * i + k] = Uc[k][i];
+            Vout[3 * i + k] = Vc[k][i];
+        }
+}
+
+/* ---- EPnP -------------------------------------------------------------------------------- */
+#define EPNP_MAXN 16
+
+static double dot3(const double *a, const double *b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+static void compute_rt_from_betas(const double *v[4], const double *betas, const double (*alphas)[4],
+                                  const double (*pws)[3], int n, double *R, double *t, double (*pcs)[3])
+{
+    double ccs[4][3];
+    for (int i = 0; i < 4; i++)
+        for (int k = 0; k < 3; k++)
+            ccs[i][k] = 0;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++)
+            for (int k = 0; k < 3; k++)
+                ccs[j][k] += betas[i] * v[i][3 * j + k];
+    for (int i = 0; i < n; i++)
+        for (int k = 0; k < 3; k++)
+            pcs[i][k] = alphas[i][0] * ccs[0][k] + alphas[i][1] * ccs[1][k] + alphas[i][2] * ccs[2][k] +
+                        alphas[i][3] * ccs[3][k];
+    if (pcs[0][2] < 0.)
+        for (int i = 0; i < n; i++)
+            for (int k = 0; k < 3; k++)
+                pcs[i][k] = -pcs[i][k];
+    double pc0[3] = {0, 0, 0}, pw0[3] = {0, 0, 0};
+    for (int i = 0; i < n; i++)
+        for (int k = 0; k < 3; k++) {
+            pc0[k] += pcs[i][k];
+            pw0[k] += pws[i][k];
+        }
+    for (int k = 0; k < 3; k++) {
+        pc0[k] /= n;
+        pw0[k] /= n;
+    }
+    double ABt[9] = {0};
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < 3; j++)
+            for (int k = 0; k < 3; k++)
+                ABt[3 * j + k] += (pcs[i][j] - pc0[j]) * (pws[i][k] - pw0[k]);
+    double U[9], V[9];
+    svd3(ABt, U, V);
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            R[3 * i + j] = U[3 * i] * V[3 * j] + U[3 * i + 1] * V[3 * j + 1] + U[3 * i + 2] * V[3 * j + 2];
+    double det = R[0] * (R[4] * R[8] - R[5] * R[7]) - R[1] * (R[3] * R[8] - R[5] * R[6]) +
+                 R[2] * (R[3] * R[7] - R[4] * R[6]);
+    if (det < 0) {
+        R[6] = -R[6];
+        R[7] = -R[7];
+        R[8] = -R[8];
+    }
+    for (int i = 0; i < 3; i++)
+        t[i] = pc0[i] - dot3(R + 3 * i, pw0);
+}
+
+static double reprojection_error(const double *R, const double *t, const double (*pws)[3], const double (*us)[2],
+                                 int n, const double *K4)
+{
+    double sum = 0;
+    for (int i = 0; i < n; i++) {
+        double Xc = dot3(R, pws[i]) + t[0], Yc = dot3(R + 3, pws[i]) + t[1];
+        double inv_Zc = 1.0 / (dot3(R + 6, pws[i]) + t[2]);
+        double ue = K4[2] + K4[0] * Xc * inv_Zc, ve = K4[3] + K4[1] * Yc * inv_Zc;
+        double du = us[i][0] - ue, dv = us[i][1] - ve;
+        sum += sqrt(du * du + dv * dv);
+    }
+    return sum / n;
+}
+
+static void gauss_newton_betas(const double (*L)[10], const double *rho, double *b)
+{
+    for (int it = 0; it < 5; it++) {
+        double A[24], r[6], x[4];
+        for (int i = 0; i < 6; i++) {
+            const double *l = L[i];
+            A[4 * i + 0] = 2 * l[0] * b[0] + l[1] * b[1] + l[3] * b[2] + l[6] * b[3];
+            A[4 * i + 1] = l[1] * b[0] + 2 * l[2] * b[1] + l[4] * b[2] + l[7] * b[3];
+            A[4 * i + 2] = l[3] * b[0] + l[4] * b[1] + 2 * l[5] * b[2] + l[8] * b[3];
+            A[4 * i + 3] = l[6] * b[0] + l[7] * b[1] + l[8] * b[2] + 2 * l[9] * b[3];
+            r[i] = rho[i] - (l[0] * b[0] * b[0] + l[1] * b[0] * b[1] + l[2] * b[1] * b[1] + l[3] * b[0] * b[2] +
+                             l[4] * b[1] * b[2] + l[5] * b[2] * b[2] + l[6] * b[0] * b[3] + l[7] * b[1] * b[3] +
+                             l[8] * b[2] * b[3] + l[9] * b[3] * b[3]);
+        }
+        lstsq_small(6, 4, A, r, x);
+        for (int k = 0; k < 4; k++)
+            b[k] += x[k];
+    }
+}
+
+int orc_epnp(const double *obj, const double *img, int n, const double *K4, double *R, double *t)
+{
+    if (n < 4 || n > EPNP_MAXN)
+        return -1;
+    const double fu = K4[0], fv = K4[1], uc = K4[2], vc = K4[3];
+    double pws[EPNP_MAXN][3], us[EPNP_MAXN][2], alphas[EPNP_MAXN][4], cws[4][3];
+    for (int i = 0; i < n; i++) {
+        for (int k = 0; k < 3; k++)
+            pws[i][k] = obj[3 * i + k];
+        us[i][0] = img[2 * i];
+        us[i][1] = img[2 * i + 1];
+    }
+    /* control points: centroid + principal directions scaled by sqrt(lambda/n) */
+    for (int k = 0; k < 3; k++) {
+        cws[0][k] = 0;
+        for (int i = 0; i < n; i++)
+            cws[0][k] += pws[i][k];
+        cws[0][k] /= n;
+    }
+    double C[9] = {0}, Vc[9], wc[3];
+    for (int i = 0; i < n; i++)
+        for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++)
+                C[3 * a + b] += (pws[i][a] - cws[0][a]) * (pws[i][b] - cws[0][b]);
+    orc_jacobi_eigen_sym(3, C, Vc, wc, 10);
+    int ord[3] = {0, 1, 2};
+    for (int a = 0; a < 2; a++)
+        for (int b = a + 1; b < 3; b++)
+            if (wc[ord[b]] > wc[ord[a]]) {
+                int tt = ord[a];
+                ord[a] = ord[b];
+                ord[b] = tt;
+            }
+    for (int i = 1; i < 4; i++) {
+        double lam = wc[ord[i - 1]];
+        double k = sqrt((lam > 0 ? lam : 0) / n);
+        for (int j = 0; j < 3; j++)
+            cws[i][j] = cws[0][j] + k * Vc[3 * j + ord[i - 1]];
+    }
+    /* barycentric coordinates */
+    double CC[9], CCi[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 1; j < 4; j++)
+            CC[3 * i + j - 1] = cws[j][i] - cws[0][i];
+    double det = CC[0] * (CC[4] * CC[8] - CC[5] * CC[7]) - CC[1] * (CC[3] * CC[8] - CC[5] * CC[6]) +
+                 CC[2] * (CC[3] * CC[7] - CC[4] * CC[6]);
+    double scale = fabs(CC[0]) + fabs(CC[4]) + fabs(CC[8]) + fabs(CC[1]) + fabs(CC[2]) + fabs(CC[3]) +
+                   fabs(CC[5]) + fabs(CC[6]) + fabs(CC[7]);
+    if (!(fabs(det) > 1e-18 * scale * scale * scale) || !isfinite(det))
+        return -2; /* coplanar / coincident sample: no control-point basis */
+    double id = 1. / det;
+    CCi[0] = (CC[4] * CC[8] - CC[5] * CC[7]) * id;
+    CCi[1] = (CC[2] * CC[7] - CC[1] * CC[8]) * id;
+    CCi[2] = (CC[1] * CC[5] - CC[2] * CC[4]) * id;
+    CCi[3] = (CC[5] * CC[6] - CC[3] * CC[8]) * id;
+    CCi[4] = (CC[0] * CC[8] - CC[2] * CC[6]) * id;
+    CCi[5] = (CC[2] * CC[3] - CC[0] * CC[5]) * id;
+    CCi[6] = (CC[3] * CC[7] - CC[4] * CC[6]) * id;
+    CCi[7] = (CC[1] * CC[6] - CC[0] * CC[7]) * id;
+    CCi[8] = (CC[0] * CC[4] - CC[1] * CC[3]) * id;
+    for (int i = 0; i < n; i++) {
+        double d[3] = {pws[i][0] - cws[0][0], pws[i][1] - cws[0][1], pws[i][2] - cws[0][2]};
+        for (int j = 0; j < 3; j++)
+            alphas[i][1 + j] = CCi[3 * j] * d[0] + CCi[3 * j + 1] * d[1] + CCi[3 * j + 2] * d[2];
+        alphas[i][0] = 1.0 - alphas[i][1] - alphas[i][2] - alphas[i][3];
+    }
+    /* M^T M */
+    double M[2 * EPNP_MAXN][12], MtM[144], Ve[144], we[12];
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < 4; j++) {
+            M[2 * i][3 * j] = alphas[i][j] * fu;
+            M[2 * i][3 * j + 1] = 0;
+            M[2 * i][3 * j + 2] = alphas[i][j] * (uc - us[i][0]);
+            M[2 * i + 1][3 * j] = 0;
+            M[2 * i + 1][3 * j + 1] = alphas[i][j] * fv;
+            M[2 * i + 1][3 * j + 2] = alphas[i][j] * (vc - us[i][1]);
+        }
+    for (int a = 0; a < 12; a++)
+        for (int b = 0; b < 12; b++) {
+            double s = 0;
+            for (int r = 0; r < 2 * n; r++)
+                s += M[r][a] * M[r][b];
+            MtM[12 * a + b] = s;
+        }
+    orc_jacobi_eigen_sym(12, MtM, Ve, we, 12);
+    /* the four smallest eigenvalues, ascending (ties: lower index first) */
+    int sel[4];
+    char used[12] = {0};
+    for (int k = 0; k < 4; k++) {
+        int best = -1;
+        for (int e = 0; e < 12; e++)
+            if (!used[e] && (best < 0 || we[e] < we[best]))
+                best = e;
+        used[best] = 1;
+        sel[k] = best;
+    }
+    double vbuf[4][12];
+    const double *v[4];
+    for (int k = 0; k < 4; k++) {
+        for (int i = 0; i < 12; i++)
+            vbuf[k][i] = Ve[12 * i + sel[k]];
+        v[k] = vbuf[k];
+    }
+    /* L (6x10) and rho */
+    static const int PA[6] = {0, 0, 0, 1, 1, 2}, PB[6] = {1, 2, 3, 2, 3, 3};
+    double L[6][10], rho[6], dv[4][6][3];
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 6; j++)
+            for (int k = 0; k < 3; k++)
+                dv[i][j][k] = v[i][3 * PA[j] + k] - v[i][3 * PB[j] + k];
+    for (int i = 0; i < 6; i++) {
+        L[i][0] = dot3(dv[0][i], dv[0][i]);
+        L[i][1] = 2. * dot3(dv[0][i], dv[1][i]);
+        L[i][2] = dot3(dv[1][i], dv[1][i]);
+        L[i][3] = 2. * dot3(dv[0][i], dv[2][i]);
+        L[i][4] = 2. * dot3(dv[1][i], dv[2][i]);
+        L[i][5] = dot3(dv[2][i], dv[2][i]);
+        L[i][6] = 2. * dot3(dv[0][i], dv[3][i]);
+        L[i][7] = 2. * dot3(dv[1][i], dv[3][i]);
+        L[i][8] = 2. * dot3(dv[2][i], dv[3][i]);
+        L[i][9] = dot3(dv[3][i], dv[3][i]);
+        double d[3] = {cws[PA[i]][0] - cws[PB[i]][0], cws[PA[i]][1] - cws[PB[i]][1], cws[PA[i]][2] - cws[PB[i]][2]};
+        rho[i] = dot3(d, d);
+    }
+    double betas[3][4], Rs[3][9], ts[3][3], errs[3], pcs[EPNP_MAXN][3];
+    /* approx 1: betas_approx = [B11 B12 B13 B14] */
+    {
+        double A[24], x[4];
+        for (int i = 0; i < 6; i++) {
+            A[4 * i] = L[i][0];
+            A[4 * i + 1] = L[i][1];
+            A[4 * i + 2] = L[i][3];
+            A[4 * i + 3] = L[i][6];
+        }
+        lstsq_small(6, 4, A, rho, x);
+        double *b = betas[0];
+        if (x[0] < 0) {
+            b[0] = sqrt(-x[0]);
+            b[1] = -x[1] / b[0];
+            b[2] = -x[2] / b[0];
+            b[3] = -x[3] / b[0];
+        } else {
+            b[0] = sqrt(x[0]);
+            b[1] = x[1] / b[0];
+            b[2] = x[2] / b[0];
+            b[3] = x[3] / b[0];
+        }
+    }
+    /* approx 2: [B11 B12 B22] */
+    {
+        double A[18], x[3];
+        for (int i = 0; i < 6; i++) {
+            A[3 * i] = L[i][0];
+            A[3 * i + 1] = L[i][1];
+            A[3 * i + 2] = L[i][2];
+        }
+        lstsq_small(6, 3, A, rho, x);
+        double *b = betas[1];
+        if (x[0] < 0) {
+            b[0] = sqrt(-x[0]);
+            b[1] = x[2] < 0 ? sqrt(-x[2]) : 0.;
+        } else {
+            b[0] = sqrt(x[0]);
+            b[1] = x[2] > 0 ? sqrt(x[2]) : 0.;
+        }
+        if (x[1] < 0)
+            b[0] = -b[0];
+        b[2] = 0.;
+        b[3] = 0.;
+    }
+    /* approx 3: [B11 B12 B22 B13 B23] */
+    {
+        double A[30], x[5];
+        for (int i = 0; i < 6; i++)
+            for (int k = 0; k < 5; k++)
+                A[5 * i + k] = L[i][k];
+        lstsq_small(6, 5, A, rho, x);
+        double *b = betas[2];
+        if (x[0] < 0) {
+            b[0] = sqrt(-x[0]);
+            b[1] = x[2] < 0 ? sqrt(-x[2]) : 0.;
+        } else {
+            b[0] = sqrt(x[0]);
+            b[1] = x[2] > 0 ? sqrt(x[2]) : 0.;
+        }
+        if (x[1] < 0)
+            b[0] = -b[0];
+        b[2] = x[3] / b[0];
+        b[3] = 0.;
+    }
+    int best = -1;
+    for (int a = 0; a < 3; a++) {
+        gauss_newton_betas(L, rho, betas[a]);
+        compute_rt_from_betas(v, betas[a], alphas, pws, n, Rs[a], ts[a], pcs);
+        errs[a] = reprojection_error(Rs[a], ts[a], pws, us, n, K4);
+        if (isfinite(errs[a]) && (best < 0 || errs[a] < errs[best]))
+            best = a;
+    }
+    if (best < 0)
+        return -3;
+    memcpy(R, Rs[best], sizeof(double) * 9);
+    memcpy(t, ts[best], sizeof(double) * 3);
+    for (int i = 0; i < 9; i++)
+        if (!isfinite(R[i]))
+            return -3;
+    return 0;
+}
+
+/* ---- reprojection error as PnPRansacCallback::computeError ------------------------------- */
+static inline float reproj_err_sq(const double *R, const double *t, const double *K4, const float *X, const float *x)
+{
+    double Xc = R[0] * X[0] + R[1] * X[1] + R[2] * X[2] + t[0];
+    double Yc = R[3] * X[0] + R[4] * X[1] + R[5] * X[2] + t[1];
+    double Zc = R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + t[2];
+    double z = Zc != 0 ? 1. / Zc : 1.;
+    float px = (float)(Xc * z * K4[0] + K4[2]), py = (float)(Yc * z * K4[1] + K4[3]);
+    float dx = x[0] - px, dy = x[1] - py;
+    return (float)((double)dx * dx + (double)dy * dy);
+}
+float orc_reproj_err_sq(const double *R, const double *t, const double *K4, const float *X, const float *x)
+{
+    return reproj_err_sq(R, t, K4, X, x);
+}
+
+/* ---- Levenberg-Marquardt refinement of (R, t) over a point subset ------------------------ */
+static int chol6_solve(const double *Ain, const double *b, double *x)
+{
+    double L[36];
+    memset(L, 0, sizeof(L));
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j <= i; j++) {
+            double s = Ain[6 * i + j];
+            for (int k = 0; k < j; k++)
+                s -= L[6 * i + k] * L[6 * j + k];
+            if (i == j) {
+                if (!(s > 0))
+                    return 0;
+                L[6 * i + i] = sqrt(s);
+            } else
+                L[6 * i + j] = s / L[6 * j + j];
+        }
+    double y[6];
+    for (int i = 0; i < 6; i++) {
+        double s = b[i];
+        for (int k = 0; k < i; k++)
+            s -= L[6 * i + k] * y[k];
+        y[i] = s / L[6 * i + i];
+    }
+    for (int i = 5; i >= 0; i--) {
+        double s = y[i];
+        for (int k = i + 1; k < 6; k++)
+            s -= L[6 * k + i] * x[k];
+        x[i] = s / L[6 * i + i];
+    }
+    return 1;
+}
+
+/* accumulates J^T J (upper+lower), J^T r and the squared error for the pose (R,t) */
+static double pnp_normal_eq(const float *obj, const float *img, const int *idx, int m, const double *K4,
+                            const double *R, const double *t, double *JtJ, double *Jtr)
+{
+    double err = 0;
+    if (JtJ)
+        memset(JtJ, 0, sizeof(double) * 36);
+    if (Jtr)
+        memset(Jtr, 0, sizeof(double) * 6);
+    for (int e = 0; e < m; e++) {
+        const int i = idx ? idx[e] : e;
+        const float *X = obj + 3 * i;
+        double rx = R[0] * X[0] + R[1] * X[1] + R[2] * X[2];
+        double ry = R[3] * X[0] + R[4] * X[1] + R[5] * X[2];
+        double rz = R[6] * X[0] + R[7] * X[1] + R[8] * X[2];
+        double Xc = rx + t[0], Yc = ry + t[1], Zc = rz + t[2];
+        double iz = 1. / Zc;
+        double u = K4[0] * Xc * iz + K4[2], v = K4[1] * Yc * iz + K4[3];
+        double ru = u - img[2 * i], rv = v - img[2 * i + 1];
+        err += ru * ru + rv * rv;
+        if (!JtJ)
+            continue;
+        /* d(u,v)/d(Xc,Yc,Zc) */
+        double a0 = K4[0] * iz, a2 = -K4[0] * Xc * iz * iz;
+        double b1 = K4[1] * iz, b2 = -K4[1] * Yc * iz * iz;
+        /* dXc/dw = -[R X]x, dXc/dt = I */
+        double Ju[6] = {a2 * ry, a0 * rz - a2 * rx, -a0 * ry, a0, 0, a2};
+        double Jv[6] = {-b1 * rz + b2 * ry, -b2 * rx, b1 * rx, 0, b1, b2};
+        for (int p = 0; p < 6; p++) {
+            for (int q = 0; q < 6; q++)
+                JtJ[6 * p + q] += Ju[p] * Ju[q] + Jv[p] * Jv[q];
+            Jtr[p] += Ju[p] * ru + Jv[p] * rv;
+        }
+    }
+    return err;
+}
+
+double orc_pnp_refine_Rt(const float *obj, const float *img, const int *idx, int m, const double *K4,
+                         double *R, double *t, int max_iters)
+{
+    double JtJ[36], Jtr[6], lambda = 1e-3;
+    double err = pnp_normal_eq(obj, img, idx, m, K4, R, t, JtJ, Jtr);
+    for (int it = 0; it < max_iters; it++) {
+        double A[36], d[6];
+        memcpy(A, JtJ, sizeof(A));
+        for (int k = 0; k < 6; k++)
+            A[7 * k] += lambda * JtJ[7 * k] + 1e-300;
+        double nb[6];
+        for (int k = 0; k < 6; k++)
+            nb[k] = -Jtr[k];
+        if (!chol6_solve(A, nb, d)) {
+            lambda *= 10;
+            if (lambda > 1e12)
+                break;
+            continue;
+        }
+        double dR[9], Rn[9], tn[3];
+        orc_rodrigues(d, dR);
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++)
+                Rn[3 * i + j] = dR[3 * i] * R[j] + dR[3 * i + 1] * R[3 + j] + dR[3 * i + 2] * R[6 + j];
+        for (int k = 0; k < 3; k++)
+            tn[k] = t[k] + d[3 + k];
+        double e2 = pnp_normal_eq(obj, img, idx, m, K4, Rn, tn, 0, 0);
+        if (e2 < err || !(err == err)) {
+            memcpy(R, Rn, sizeof(Rn));
+            memcpy(t, tn, sizeof(tn));
+            double step = 0, scale = 0;
+            for (int k = 0; k < 6; k++)
+                step += d[k] * d[k];
+            scale = 1. + t[0] * t[0] + t[1] * t[1] + t[2] * t[2];
+            double prev = err;
+            err = pnp_normal_eq(obj, img, idx, m, K4, R, t, JtJ, Jtr);
+            lambda *= 0.1;
+            if (lambda < 1e-12)
+                lambda = 1e-12;
+            if (step <= 1e-20 * scale || prev - err <= 1e-14 * prev)
+                break;
+        } else {
+            lambda *= 10;
+            if (lambda > 1e12)
+                break;
+        }
+    }
+    return sqrt(err / (m > 0 ? m : 1));
+}
+
+double orc_pnp_refine(const float *obj, const float *img, const int *idx, int m, const double *K4, double *rvec,
+                      double *tvec, int max_iters)
+{
+    double R[9];
+    orc_rodrigues(rvec, R);
+    double rms = orc_pnp_refine_Rt(obj, img, idx, m, K4, R, tvec, max_iters);
+    orc_rodrigues_inv(R, rvec);
+    return rms;
+}
+
+/* hypothesis of RANSAC iteration `it`: 0 ok (R,t filled), <0 no model */
+int orc_pnp_hypothesis(const float *obj, const float *img, int n, const double *K4, uint64_t seed, int it,
+                       double *R, double *t)
+{
+    int idx[5];
+    if (!orc_draw_subset_plain(seed, (uint32_t)it, n, 5, idx))
+        return -1;
+    double o[15], u[10];
+    for (int k = 0; k < 5; k++) {
+        for (int c = 0; c < 3; c++)
+            o[3 * k + c] = obj[3 * idx[k] + c];
+        u[2 * k] = img[2 * idx[k]];
+        u[2 * k + 1] = img[2 * idx[k] + 1];
+    }
+    return orc_epnp(o, u, 5, K4, R, t) == 0 ? 0 : -2;
+}
+
+int orc_pnp_ransac(const float *obj, const float *img, int n, const double *K4, const orc_pnp_params *prm,
+                   double *rvec, double *tvec, int *inliers, int *iters_run)
+{
+    const int M = 5;
+    if (iters_run)
+        *iters_run = 0;
+    if (n < M)
+        return 0;
+    const float thr = (float)(prm->reproj_err * prm->reproj_err);
+    int niters = prm->iterations, best_count = 0, it;
+    double bestR[9], bestT[3];
+    for (it = 0; it < niters; it++) {
+        double R[9], t[3];
+        int rc = orc_pnp_hypothesis(obj, img, n, K4, prm->seed, it, R, t);
+        if (rc == -1)
+            break;
+        if (rc != 0)
+            continue;
+        int count = 0;
+        for (int i = 0; i < n; i++)
+            count += reproj_err_sq(R, t, K4, obj + 3 * i, img + 2 * i) <= thr;
+        if (count > (best_count > M - 1 ? best_count : M - 1)) {
+            best_count = count;
+            memcpy(bestR, R, sizeof(R));
+            memcpy(bestT, t, sizeof(t));
+            niters = orc_update_num_iters(prm->confidence, (double)(n - count) / n, M, niters);
+        }
+    }
+    if (iters_run)
+        *iters_run = it;
+    if (best_count <= 0)
+        return 0;
+    int k = 0;
+    for (int i = 0; i < n; i++)
+        if (reproj_err_sq(bestR, bestT, K4, obj + 3 * i, img + 2 * i) <= thr)
+            inliers[k++] = i;
+    orc_pnp_refine_Rt(obj, img, inliers, k, K4, bestR, bestT, prm->refine_iters > 0 ? prm->refine_iters : 20);
+    orc_rodrigues_inv(bestR, rvec);
+    memcpy(tvec, bestT, sizeof(bestT));
+    return k;
+}

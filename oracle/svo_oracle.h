@@ -137,6 +137,15 @@ int orc_pnp_ransac(const float *obj, const float *img, int n, const double *K4,
 /* EPnP on m (>=4) correspondences (double).  Returns 0 on success. */
 int orc_epnp(const double *obj, const double *img, int m, const double *K4, double *R,
              double *t);
+/* cyclic Jacobi (round-robin pair order) for symmetric n x n; eigenvectors = columns of V */
+void orc_jacobi_eigen_sym(int n, double *A, double *V, double *w, int sweeps);
+/* squared reprojection error as PnPRansacCallback::computeError (float) */
+float orc_reproj_err_sq(const double *R, const double *t, const double *K4, const float *X, const float *x);
+/* the EPnP hypothesis of RANSAC iteration `it` (0 ok; -1 sampling failed; -2 no model) */
+int orc_pnp_hypothesis(const float *obj, const float *img, int n, const double *K4, uint64_t seed, int it,
+                       double *R, double *t);
+double orc_pnp_refine_Rt(const float *obj, const float *img, const int *idx, int m, const double *K4,
+                         double *R, double *t, int max_iters);
 /* LM refinement of (rvec,tvec) over the given points; returns final RMS reprojection error */
 double orc_pnp_refine(const float *obj, const float *img, const int *idx, int m,
                       const double *K4, double *rvec, double *tvec, int max_iters);
@@ -180,6 +189,14 @@ int orc_vo_init(orc_vo *v, const uint8_t *left, const uint8_t *right);
 /* next frame.  right may be NULL only if no keyframe is needed (returns -2 then).
  * force_keyframe mirrors LC_FLAG.  Outputs R (9), t (3) camera-in-world, inlier count,
  * keyframe flag.  Returns 0 ok, -1 shutdown (tracking lost).                              */
+/* the two halves of a frame: localisation (LK + F-RANSAC + PnP-RANSAC + pose composition,
+ * VisualSLAM.cpp:64-74) and the keyframe decision / reference update (VisualSLAM.cpp:93-152)
+ * with the pose the caller settled on (the pose graph may re-anchor t in between).         */
+int orc_vo_localize(orc_vo *v, const uint8_t *left, double *R, double *t, int *n_inliers, int *n_tracked);
+int orc_vo_update(orc_vo *v, const uint8_t *left, const uint8_t *right, const double *R, const double *t,
+                  int n_inliers, int force_keyframe, int *was_keyframe);
+int orc_vo_num_ref(const orc_vo *v);
+void orc_vo_get_ref(const orc_vo *v, float *ref2d, float *ref3d);
 int orc_vo_track(orc_vo *v, const uint8_t *left, const uint8_t *right, int force_keyframe,
                  double *R, double *t, int *n_inliers, int *was_keyframe, int *n_tracked);
 

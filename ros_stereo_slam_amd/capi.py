@@ -247,3 +247,28 @@ def get_colors(self, pyr, xy):
     out = np.empty((xy.shape[0], 3), np.float32)
     _check(self.lib.svo_get_colors(self._h, pyr._h, _ptr(xy), xy.shape[0], _ptr(out), MEM_HOST))
     return out
+
+
+@_ctx_method
+def anms(self, xy, response, num_to_keep):
+    xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+    response = np.ascontiguousarray(response, np.float32)
+    n = xy.shape[0]
+    idx = np.zeros(max(n, 1), np.int32)
+    cnt = C.c_int()
+    _check(self.lib.svo_anms(self._h, _ptr(xy), _ptr(response), n, num_to_keep, _ptr(idx), C.byref(cnt), MEM_HOST))
+    return idx[:cnt.value].copy()
+
+
+@_ctx_method
+def pnp_ransac(self, obj, img, K4, iterations=100, reproj_err=1.0, confidence=0.99, seed=0):
+    obj = np.ascontiguousarray(obj, np.float32).reshape(-1, 3)
+    img = np.ascontiguousarray(img, np.float32).reshape(-1, 2)
+    n = obj.shape[0]
+    rvec, tvec = np.zeros(3), np.zeros(3)
+    inl = np.zeros(max(n, 1), np.int32)
+    cnt, iters = C.c_int(), C.c_int()
+    _check(self.lib.svo_pnp_ransac(self._h, _ptr(obj), _ptr(img), n, _ptr(np.ascontiguousarray(K4, np.float64)),
+                                   iterations, C.c_double(reproj_err), C.c_double(confidence), C.c_uint64(seed),
+                                   _ptr(rvec), _ptr(tvec), _ptr(inl), C.byref(cnt), C.byref(iters), MEM_HOST))
+    return cnt.value, rvec, tvec, inl[:cnt.value].copy(), iters.value

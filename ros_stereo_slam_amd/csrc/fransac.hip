@@ -345,63 +345,6 @@ __global__ __launch_bounds__(256) void fr_score_kernel(const float2 *__restrict_
         counts[it * 3 + k] = cnt;
 }
 
-// replays the sequential RANSAC loop over iterations [st->next_iter, it_end)
-__global__ void fr_select_kernel(RansacState *st, int first, int it_end, int max_iters, int n_host,
-                                 const int *__restrict__ d_n, double confidence,
-                                 const int *__restrict__ nmodels, const int *__restrict__ counts,
-                                 int model_points)
-{
-    if (threadIdx.x != 0 || blockIdx.x != 0)
-        return;
-    RansacState s;
-    if (first) {
-        s.niters = max_iters;
-        s.next_iter = 0;
-        s.best_iter = -1;
-        s.best_model = 0;
-        s.best_count = 0;
-        s.done = 0;
-        s.iters_run = 0;
-        s.pad = 0;
-    } else {
-        s = *st;
-        if (s.done)
-            return;
-    }
-    const int n = d_n ? *d_n : n_host;
-    int it = s.next_iter;
-    if (n < model_points) {
-        s.done = 1;
-    } else {
-        for (; it < it_end; it++) {
-            if (it >= s.niters) {
-                s.done = 1;
-                break;
-            }
-            const int nm = nmodels[it];
-            if (nm < 0) {
-                s.done = 1;
-                break;
-            }
-            for (int k = 0; k < nm; k++) {
-                const int c = counts[it * 3 + k];
-                const int floor_cnt = s.best_count > model_points - 1 ? s.best_count : model_points - 1;
-                if (c > floor_cnt) {
-                    s.best_count = c;
-                    s.best_iter = it;
-                    s.best_model = k;
-                    s.niters = update_num_iters(confidence, (double)(n - c) / n, model_points, s.niters);
-                }
-            }
-        }
-        if (it >= s.niters || it >= max_iters)
-            s.done = 1;
-    }
-    s.next_iter = it;
-    s.iters_run = it;
-    *st = s;
-}
-
 __global__ __launch_bounds__(256) void fr_mask_kernel(const float2 *__restrict__ p1,
                                                       const float2 *__restrict__ p2, int n_host,
                                                       const int *__restrict__ d_n,
@@ -471,7 +414,7 @@ int svo_launch_fransac(svo_ctx *ctx, const float *p1, const float *p2, int cap, 
         hipLaunchKernelGGL(fr_score_kernel, dim3((iters * 3 + 3) / 4), dim3(256), 0, ctx->stream,
                            reinterpret_cast<const float2 *>(p1), reinterpret_cast<const float2 *>(p2), cap, d_n, it0,
                            it1, st, Fm, nmodels, thr, counts);
-        hipLaunchKernelGGL(fr_select_kernel, dim3(1), dim3(64), 0, ctx->stream, st, ph == 0 ? 1 : 0, it1, max_iters,
+        hipLaunchKernelGGL(ransac_select_kernel<3>, dim3(1), dim3(64), 0, ctx->stream, st, ph == 0 ? 1 : 0, it1, max_iters,
                            cap, d_n, confidence, nmodels, counts, M);
     }
     hipLaunchKernelGGL(fr_mask_kernel, dim3((cap + 255) / 256), dim3(256), 0, ctx->stream,

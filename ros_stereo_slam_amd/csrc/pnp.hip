@@ -1,0 +1,1182 @@
+// pnp.hip -- 3D-2D PnP-RANSAC for gfx950.
+//
+// Replaces cv::solvePnPRansac(obj, img, K, 0, rvec, tvec, false, 100, thr, conf, inliers)
+// as the reference calls it at src/keyFrameManagement.cpp:84 (100, 1.0, 0.99) and :88
+// (100, 8.0, 0.98): RANSAC over 5-point samples solved by EPnP, squared reprojection error
+// (float) against thr^2, adaptive iteration bound, then an iterative refinement of the best
+// hypothesis over its inliers.
+//
+//   solve   one WAVEFRONT per hypothesis.  The sample's 10x12 system, M^T M and the 12x12
+//           symmetric eigenproblem live in LDS; the Jacobi sweeps run wave-parallel (each
+//           round-robin round holds 6 disjoint rotations: 6 lanes compute them, then all
+//           lanes apply the 72 column / row / eigenvector updates).  The three beta
+//           linearisations (N = 1, 2, 3) + Gauss-Newton + rigid alignment run on lanes
+//           0..2 side by side, entirely in registers.
+//   score   one WAVEFRONT per hypothesis, N correspondences strided over the lanes.
+//   select  sequential-semantics replay (ransac_common.cuh).
+//   refine  one workgroup: Levenberg-Marquardt on (R, t), 6x6 normal equations reduced
+//           with a fixed-order tree (deterministic), solved by one lane.
+#include <cfloat>
+
+#include "ransac_common.cuh"
+#include "svo_internal.h"
+
+using namespace svo;
+
+namespace {
+
+constexpr int MP = 5;  // model points
+
+struct K4 {
+    double fx, fy, cx, cy;
+};
+
+// ---- small dense helpers (registers, static indexing) --------------------------------------
+template <int N>
+__device__ __forceinline__ void lstsq6(const double (&A)[6][N], const double (&b)[6], double (&x)[N])
+{
+    // normal equations, Tikhonov-damped by 1e-14 of the mean diagonal, Cholesky
+    double Nm[N][N], rhs[N], L[N][N], y[N];
+    double tr = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            double s = 0;
+#pragma unroll
+            for (int k = 0; k < 6; k++)
+                s += A[k][i] * A[k][j];
+            Nm[i][j] = s;
+        }
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++)
+            s += A[k][i] * b[k];
+        rhs[i] = s;
+        tr += Nm[i][i];
+    }
+    const double damp = 1e-14 * tr / N;
+#pragma unroll
+    for (int i = 0; i < N; i++)
+        x[i] = 0;
+    bool ok = true;
+#pragma unroll
+    for (int i = 0; i < N; i++)
+#pragma unroll
+        for (int j = 0; j <= i; j++) {
+            double s = Nm[i][j] + (i == j ? damp : 0.);
+#pragma unroll
+            for (int k = 0; k < j; k++)
+                s -= L[i][k] * L[j][k];
+            if (i == j) {
+                if (!(s > 0))
+                    ok = false;
+                L[i][i] = sqrt(s);
+            } else
+                L[i][j] = s / L[j][j];
+        }
+    if (!ok)
+        return;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        double s = rhs[i];
+#pragma unroll
+        for (int k = 0; k < i; k++)
+            s -= L[i][k] * y[k];
+        y[i] = s / L[i][i];
+    }
+#pragma unroll
+    for (int i = N - 1; i >= 0; i--) {
+        double s = y[i];
+#pragma unroll
+        for (int k = i + 1; k < N; k++)
+            s -= L[k][i] * x[k];
+        x[i] = s / L[i][i];
+    }
+}
+
+// SVD of a 3x3 matrix by one-sided Jacobi; returns U and V (columns = singular vectors,
+// decreasing singular value, U completed to a basis when the last one vanishes)
+__device__ void svd3(const double (&Ain)[9], double (&U)[9], double (&Vout)[9])
+{
+    double A[3][3], V[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            A[i][j] = Ain[3 * i + j];
+            V[i][j] = i == j ? 1. : 0.;
+        }
+    for (int sweep = 0; sweep < 30; sweep++) {
+        bool rotated = false;
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+            constexpr int P[3] = {0, 0, 1}, Q[3] = {1, 2, 2};
+            const int p = P[e], q = Q[e];
+            double al = 0, be = 0, ga = 0;
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                al += A[i][p] * A[i][p];
+                be += A[i][q] * A[i][q];
+                ga += A[i][p] * A[i][q];
+            }
+            if (ga == 0 || fabs(ga) <= DBL_EPSILON * sqrt(al * be))
+                continue;
+            rotated = true;
+            const double zeta = (be - al) / (2. * ga);
+            const double t = (zeta >= 0 ? 1. : -1.) / (fabs(zeta) + sqrt(1. + zeta * zeta));
+            const double c = 1. / sqrt(1. + t * t), s = c * t;
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                const double ap = A[i][p], aq = A[i][q];
+                A[i][p] = c * ap - s * aq;
+                A[i][q] = s * ap + c * aq;
+                const double vp = V[i][p], vq = V[i][q];
+                V[i][p] = c * vp - s * vq;
+                V[i][q] = s * vp + c * vq;
+            }
+        }
+        if (!rotated)
+            break;
+    }
+    double nrm[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+        nrm[j] = sqrt(A[0][j] * A[0][j] + A[1][j] * A[1][j] + A[2][j] * A[2][j]);
+    // order by decreasing norm (same comparison network as the oracle's insertion loops)
+    int o0 = 0, o1 = 1, o2 = 2;
+    if (nrm[o1] > nrm[o0]) {
+        int t = o0;
+        o0 = o1;
+        o1 = t;
+    }
+    if (nrm[o2] > nrm[o0]) {
+        int t = o0;
+        o0 = o2;
+        o2 = t;
+    }
+    if (nrm[o2] > nrm[o1]) {
+        int t = o1;
+        o1 = o2;
+        o2 = t;
+    }
+    const int ord[3] = {o0, o1, o2};
+    double Uc[3][3], Vc[3][3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int j = ord[k];
+        const double nj = j == 0 ? nrm[0] : (j == 1 ? nrm[1] : nrm[2]);
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const double vij = j == 0 ? V[i][0] : (j == 1 ? V[i][1] : V[i][2]);
+            const double aij = j == 0 ? A[i][0] : (j == 1 ? A[i][1] : A[i][2]);
+            Vc[k][i] = vij;
+            Uc[k][i] = nj > 0 ? aij / nj : 0.;
+        }
+    }
+    const double n0 = o0 == 0 ? nrm[0] : (o0 == 1 ? nrm[1] : nrm[2]);
+    const double n2 = o2 == 0 ? nrm[0] : (o2 == 1 ? nrm[1] : nrm[2]);
+    if (!(n2 > 1e-12 * n0)) {
+        Uc[2][0] = Uc[0][1] * Uc[1][2] - Uc[0][2] * Uc[1][1];
+        Uc[2][1] = Uc[0][2] * Uc[1][0] - Uc[0][0] * Uc[1][2];
+        Uc[2][2] = Uc[0][0] * Uc[1][1] - Uc[0][1] * Uc[1][0];
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            U[3 * i + k] = Uc[k][i];
+            Vout[3 * i + k] = Vc[k][i];
+        }
+}
+
+// ---- wave-parallel cyclic Jacobi for a symmetric n x n matrix in LDS -------------------------
+// Round-robin pair schedule (n-1 rounds of n/2 disjoint pairs, odd n padded with an idle
+// player).  Per round: lanes < m/2 compute their rotation, then all lanes apply the column
+// updates, then the row updates, then the eigenvector updates -- the exact order the CPU
+// oracle uses, so the two round identically.  A, V: row-major n x n; cs: 2*8 doubles; pq: 16 ints.
+__device__ void wave_jacobi_eigen_sym(int n, double *A, double *V, double *cs, int *pq, int sweeps, int lane)
+{
+    for (int i = lane; i < n * n; i += 64)
+        V[i] = (i / n) == (i % n) ? 1. : 0.;
+    wave_lds_fence();
+    const int m = n + (n & 1), half = m / 2;
+    for (int s = 0; s < sweeps; s++)
+        for (int r = 0; r < m - 1; r++) {
+            if (lane < half) {
+                const int k = lane;
+                const int a = k == 0 ? m - 1 : (r + k) % (m - 1);
+                const int b = k == 0 ? r % (m - 1) : (r - k + (m - 1)) % (m - 1);
+                int p = a < b ? a : b, q = a < b ? b : a;
+                double c = 1., sn = 0.;
+                if (a >= n || b >= n) {
+                    p = -1;
+                    q = -1;
+                } else {
+                    const double apq = A[p * n + q];
+                    if (apq != 0.) {
+                        const double app = A[p * n + p], aqq = A[q * n + q];
+                        const double theta = (aqq - app) / (2. * apq);
+                        const double t = (theta >= 0 ? 1. : -1.) / (fabs(theta) + sqrt(theta * theta + 1.));
+                        c = 1. / sqrt(t * t + 1.);
+                        sn = t * c;
+                    }
+                }
+                cs[2 * k] = c;
+                cs[2 * k + 1] = sn;
+                pq[2 * k] = p;
+                pq[2 * k + 1] = q;
+            }
+            wave_lds_fence();
+            for (int i = lane; i < half * n; i += 64) {  // columns p,q:  A <- A J
+                const int e = i / n, k = i - e * n;
+                const int p = pq[2 * e], q = pq[2 * e + 1];
+                if (p >= 0) {
+                    const double c = cs[2 * e], sn = cs[2 * e + 1];
+                    const double akp = A[k * n + p], akq = A[k * n + q];
+                    A[k * n + p] = c * akp - sn * akq;
+                    A[k * n + q] = sn * akp + c * akq;
+                }
+            }
+            wave_lds_fence();
+            for (int i = lane; i < half * n; i += 64) {  // rows p,q:  A <- J^T A ;  V <- V J
+                const int e = i / n, k = i - e * n;
+                const int p = pq[2 * e], q = pq[2 * e + 1];
+                if (p >= 0) {
+                    const double c = cs[2 * e], sn = cs[2 * e + 1];
+                    const double apk = A[p * n + k], aqk = A[q * n + k];
+                    A[p * n + k] = c * apk - sn * aqk;
+                    A[q * n + k] = sn * apk + c * aqk;
+                    const double vkp = V[k * n + p], vkq = V[k * n + q];
+                    V[k * n + p] = c * vkp - sn * vkq;
+                    V[k * n + q] = sn * vkp + c * vkq;
+                }
+            }
+            wave_lds_fence();
+        }
+}
+
+__device__ __forceinline__ double dot3(const double *a, const double *b)
+{
+    return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+}
+
+// per-wave LDS layout (doubles)
+struct WaveLds {
+    double A[144];
+    double V[144];
+    double M[120];
+    double vsel[48];
+    double L[60];
+    double rho[8];
+    double alphas[20];
+    double pws[16];
+    double us[10];
+    double A3[9];
+    double V3[9];
+    double cs[16];
+    int pq[16];
+};
+
+__global__ __launch_bounds__(256) void pnp_solve_kernel(const float *__restrict__ obj, const float *__restrict__ img,
+                                                        int n_host, const int *__restrict__ d_n, K4 K,
+                                                        uint64_t seed, int it0, int it1,
+                                                        const RansacState *__restrict__ st,
+                                                        double *__restrict__ hyp, int *__restrict__ nmodels)
+{
+    __shared__ WaveLds s_lds[4];
+    const int lane = threadIdx.x & 63;
+    const int it = __builtin_amdgcn_readfirstlane(it0 + blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (it >= it1)
+        return;
+    if (it0 > 0 && st->done)
+        return;
+    WaveLds &S = s_lds[threadIdx.x >> 6];
+    const int n = d_n ? *d_n : n_host;
+    if (n < MP) {
+        if (lane == 0)
+            nmodels[it] = -1;
+        return;
+    }
+    // ---- sample (every lane draws the same indices) ----
+    int idx[MP];
+    bool filled = true;
+    {
+        uint32_t draw = 0;
+        int guard = 0;
+#pragma unroll
+        for (int slot = 0; slot < MP; slot++) {
+            int v = 0;
+            bool got = false;
+            while (!got && guard < kMaxDraws) {
+                v = (int)(rng_u32(seed, (uint32_t)it, draw++) % (uint32_t)n);
+                guard++;
+                bool dup = false;
+#pragma unroll
+                for (int j = 0; j < MP; j++)
+                    if (j < slot && idx[j] == v)
+                        dup = true;
+                got = !dup;
+            }
+            if (!got)
+                filled = false;
+            idx[slot] = v;
+        }
+    }
+    if (!filled) {
+        if (lane == 0)
+            nmodels[it] = -1;
+        return;
+    }
+    if (lane < MP) {
+        const int i = lane == 0 ? idx[0] : lane == 1 ? idx[1] : lane == 2 ? idx[2] : lane == 3 ? idx[3] : idx[4];
+        S.pws[3 * lane] = obj[3 * i];
+        S.pws[3 * lane + 1] = obj[3 * i + 1];
+        S.pws[3 * lane + 2] = obj[3 * i + 2];
+        S.us[2 * lane] = img[2 * i];
+        S.us[2 * lane + 1] = img[2 * i + 1];
+    }
+    wave_lds_fence();
+    // ---- control points: centroid + PCA (every lane, same values) ----
+    double cws[4][3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        double s = 0;
+#pragma unroll
+        for (int i = 0; i < MP; i++)
+            s += S.pws[3 * i + k];
+        cws[0][k] = s / MP;
+    }
+    if (lane < 9) {
+        const int a = lane / 3, b = lane % 3;
+        double s = 0;
+        for (int i = 0; i < MP; i++)
+            s += (S.pws[3 * i + a] - cws[0][a == 0 ? 0 : a == 1 ? 1 : 2]) *
+                 (S.pws[3 * i + b] - cws[0][b == 0 ? 0 : b == 1 ? 1 : 2]);
+        S.A3[lane] = s;
+    }
+    wave_lds_fence();
+    wave_jacobi_eigen_sym(3, S.A3, S.V3, S.cs, S.pq, 10, lane);
+    {
+        const double wc[3] = {S.A3[0], S.A3[4], S.A3[8]};
+        int o0 = 0, o1 = 1, o2 = 2;  // descending eigenvalue, same comparison order as the oracle
+        if (wc[o1] > wc[o0]) {
+            int t = o0;
+            o0 = o1;
+            o1 = t;
+        }
+        if (wc[o2] > wc[o0]) {
+            int t = o0;
+            o0 = o2;
+            o2 = t;
+        }
+        if (wc[o2] > wc[o1]) {
+            int t = o1;
+            o1 = o2;
+            o2 = t;
+        }
+        const int ord[3] = {o0, o1, o2};
+#pragma unroll
+        for (int i = 1; i < 4; i++) {
+            const int e = ord[i - 1];
+            const double lam = S.A3[4 * e];
+            const double k = sqrt((lam > 0 ? lam : 0) / MP);
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+                cws[i][j] = cws[0][j] + k * S.V3[3 * j + e];
+        }
+    }
+    // ---- barycentric coordinates ----
+    double CC[9], CCi[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 1; j < 4; j++)
+            CC[3 * i + j - 1] = cws[j][i] - cws[0][i];
+    const double det = CC[0] * (CC[4] * CC[8] - CC[5] * CC[7]) - CC[1] * (CC[3] * CC[8] - CC[5] * CC[6]) +
+                       CC[2] * (CC[3] * CC[7] - CC[4] * CC[6]);
+    const double scale = fabs(CC[0]) + fabs(CC[4]) + fabs(CC[8]) + fabs(CC[1]) + fabs(CC[2]) + fabs(CC[3]) +
+                         fabs(CC[5]) + fabs(CC[6]) + fabs(CC[7]);
+    if (!(fabs(det) > 1e-18 * scale * scale * scale) || !isfinite(det)) {
+        if (lane == 0)
+            nmodels[it] = 0;  // coplanar / coincident sample: no model, the loop continues
+        return;
+    }
+    const double id = 1. / det;
+    CCi[0] = (CC[4] * CC[8] - CC[5] * CC[7]) * id;
+    CCi[1] = (CC[2] * CC[7] - CC[1] * CC[8]) * id;
+    CCi[2] = (CC[1] * CC[5] - CC[2] * CC[4]) * id;
+    CCi[3] = (CC[5] * CC[6] - CC[3] * CC[8]) * id;
+    CCi[4] = (CC[0] * CC[8] - CC[2] * CC[6]) * id;
+    CCi[5] = (CC[2] * CC[3] - CC[0] * CC[5]) * id;
+    CCi[6] = (CC[3] * CC[7] - CC[4] * CC[6]) * id;
+    CCi[7] = (CC[1] * CC[6] - CC[0] * CC[7]) * id;
+    CCi[8] = (CC[0] * CC[4] - CC[1] * CC[3]) * id;
+    if (lane < MP) {
+        const double d0 = S.pws[3 * lane] - cws[0][0], d1 = S.pws[3 * lane + 1] - cws[0][1],
+                     d2 = S.pws[3 * lane + 2] - cws[0][2];
+        double a[4];
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            a[1 + j] = CCi[3 * j] * d0 + CCi[3 * j + 1] * d1 + CCi[3 * j + 2] * d2;
+        a[0] = 1.0 - a[1] - a[2] - a[3];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            S.alphas[4 * lane + j] = a[j];
+    }
+    wave_lds_fence();
+    // ---- M (10 x 12) and M^T M ----
+    for (int e = lane; e < 120; e += 64) {
+        const int r = e / 12, c = e - r * 12;
+        const int i = r >> 1, j = c / 3, comp = c - 3 * j;
+        const double al = S.alphas[4 * i + j];
+        double v;
+        if ((r & 1) == 0)
+            v = comp == 0 ? al * K.fx : (comp == 1 ? 0. : al * (K.cx - S.us[2 * i]));
+        else
+            v = comp == 0 ? 0. : (comp == 1 ? al * K.fy : al * (K.cy - S.us[2 * i + 1]));
+        S.M[e] = v;
+    }
+    wave_lds_fence();
+    for (int e = lane; e < 144; e += 64) {
+        const int a = e / 12, b = e - a * 12;
+        double s = 0;
+        for (int r = 0; r < 2 * MP; r++)
+            s += S.M[r * 12 + a] * S.M[r * 12 + b];
+        S.A[e] = s;
+    }
+    wave_lds_fence();
+    wave_jacobi_eigen_sym(12, S.A, S.V, S.cs, S.pq, 12, lane);
+    // ---- the four smallest eigenvalues, ascending (ties: lower index first) ----
+    {
+        int sel[4];
+        unsigned used = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int best = -1;
+            double wb = 0;
+            for (int e = 0; e < 12; e++) {
+                const double we = S.A[13 * e];
+                if (!((used >> e) & 1u) && (best < 0 || we < wb)) {
+                    best = e;
+                    wb = we;
+                }
+            }
+            used |= 1u << best;
+            sel[k] = best;
+        }
+        if (lane < 48) {
+            const int k = lane / 12, i = lane - 12 * k;
+            const int sk = k == 0 ? sel[0] : k == 1 ? sel[1] : k == 2 ? sel[2] : sel[3];
+            S.vsel[lane] = S.V[12 * i + sk];
+        }
+    }
+    wave_lds_fence();
+    // ---- L (6 x 10) and rho: lane i < 6 builds row i ----
+    if (lane < 6) {
+        constexpr int PA[6] = {0, 0, 0, 1, 1, 2}, PB[6] = {1, 2, 3, 2, 3, 3};
+        int pa = 0, pb = 1;
+#pragma unroll
+        for (int e = 0; e < 6; e++)
+            if (lane == e) {
+                pa = PA[e];
+                pb = PB[e];
+            }
+        double dv[4][3];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                dv[i][k] = S.vsel[12 * i + 3 * pa + k] - S.vsel[12 * i + 3 * pb + k];
+        double *Lr = S.L + 10 * lane;
+        Lr[0] = dot3(dv[0], dv[0]);
+        Lr[1] = 2. * dot3(dv[0], dv[1]);
+        Lr[2] = dot3(dv[1], dv[1]);
+        Lr[3] = 2. * dot3(dv[0], dv[2]);
+        Lr[4] = 2. * dot3(dv[1], dv[2]);
+        Lr[5] = dot3(dv[2], dv[2]);
+        Lr[6] = 2. * dot3(dv[0], dv[3]);
+        Lr[7] = 2. * dot3(dv[1], dv[3]);
+        Lr[8] = 2. * dot3(dv[2], dv[3]);
+        Lr[9] = dot3(dv[3], dv[3]);
+        double ca[3], cb[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            ca[k] = pa == 0 ? cws[0][k] : pa == 1 ? cws[1][k] : pa == 2 ? cws[2][k] : cws[3][k];
+            cb[k] = pb == 0 ? cws[0][k] : pb == 1 ? cws[1][k] : pb == 2 ? cws[2][k] : cws[3][k];
+        }
+        const double d[3] = {ca[0] - cb[0], ca[1] - cb[1], ca[2] - cb[2]};
+        S.rho[lane] = dot3(d, d);
+    }
+    wave_lds_fence();
+    // ---- lanes 0..2: beta linearisation N = lane+1, Gauss-Newton, rigid alignment ----
+    double R[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, t[3] = {0, 0, 0};
+    double err = 1e300;
+    bool good = false;
+    if (lane < 3) {
+        double L[6][10], rho[6], b[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+#pragma unroll
+            for (int k = 0; k < 10; k++)
+                L[i][k] = S.L[10 * i + k];
+            rho[i] = S.rho[i];
+        }
+        if (lane == 0) {  // [B11 B12 B13 B14]
+            double A[6][4], x[4];
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                A[i][0] = L[i][0];
+                A[i][1] = L[i][1];
+                A[i][2] = L[i][3];
+                A[i][3] = L[i][6];
+            }
+            lstsq6<4>(A, rho, x);
+            if (x[0] < 0) {
+                b[0] = sqrt(-x[0]);
+                b[1] = -x[1] / b[0];
+                b[2] = -x[2] / b[0];
+                b[3] = -x[3] / b[0];
+            } else {
+                b[0] = sqrt(x[0]);
+                b[1] = x[1] / b[0];
+                b[2] = x[2] / b[0];
+                b[3] = x[3] / b[0];
+            }
+        } else if (lane == 1) {  // [B11 B12 B22]
+            double A[6][3], x[3];
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                A[i][0] = L[i][0];
+                A[i][1] = L[i][1];
+                A[i][2] = L[i][2];
+            }
+            lstsq6<3>(A, rho, x);
+            if (x[0] < 0) {
+                b[0] = sqrt(-x[0]);
+                b[1] = x[2] < 0 ? sqrt(-x[2]) : 0.;
+            } else {
+                b[0] = sqrt(x[0]);
+                b[1] = x[2] > 0 ? sqrt(x[2]) : 0.;
+            }
+            if (x[1] < 0)
+                b[0] = -b[0];
+        } else {  // [B11 B12 B22 B13 B23]
+            double A[6][5], x[5];
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int k = 0; k < 5; k++)
+                    A[i][k] = L[i][k];
+            lstsq6<5>(A, rho, x);
+            if (x[0] < 0) {
+                b[0] = sqrt(-x[0]);
+                b[1] = x[2] < 0 ? sqrt(-x[2]) : 0.;
+            } else {
+                b[0] = sqrt(x[0]);
+                b[1] = x[2] > 0 ? sqrt(x[2]) : 0.;
+            }
+            if (x[1] < 0)
+                b[0] = -b[0];
+            b[2] = x[3] / b[0];
+        }
+        for (int gn = 0; gn < 5; gn++) {  // Gauss-Newton on the six control-point distances
+            double A[6][4], r[6], x[4];
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                const double *l = L[i];
+                A[i][0] = 2 * l[0] * b[0] + l[1] * b[1] + l[3] * b[2] + l[6] * b[3];
+                A[i][1] = l[1] * b[0] + 2 * l[2] * b[1] + l[4] * b[2] + l[7] * b[3];
+                A[i][2] = l[3] * b[0] + l[4] * b[1] + 2 * l[5] * b[2] + l[8] * b[3];
+                A[i][3] = l[6] * b[0] + l[7] * b[1] + l[8] * b[2] + 2 * l[9] * b[3];
+                r[i] = rho[i] - (l[0] * b[0] * b[0] + l[1] * b[0] * b[1] + l[2] * b[1] * b[1] + l[3] * b[0] * b[2] +
+                                 l[4] * b[1] * b[2] + l[5] * b[2] * b[2] + l[6] * b[0] * b[3] + l[7] * b[1] * b[3] +
+                                 l[8] * b[2] * b[3] + l[9] * b[3] * b[3]);
+            }
+            lstsq6<4>(A, r, x);
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                b[k] += x[k];
+        }
+        // control points in the camera frame, sample points in the camera frame
+        double ccs[4][3], pcs[MP][3];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                ccs[j][k] = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int k = 0; k < 3; k++)
+                    ccs[j][k] += b[i] * S.vsel[12 * i + 3 * j + k];
+#pragma unroll
+        for (int i = 0; i < MP; i++)
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                pcs[i][k] = S.alphas[4 * i] * ccs[0][k] + S.alphas[4 * i + 1] * ccs[1][k] +
+                            S.alphas[4 * i + 2] * ccs[2][k] + S.alphas[4 * i + 3] * ccs[3][k];
+        if (pcs[0][2] < 0.) {
+#pragma unroll
+            for (int i = 0; i < MP; i++)
+#pragma unroll
+                for (int k = 0; k < 3; k++)
+                    pcs[i][k] = -pcs[i][k];
+        }
+        double pc0[3] = {0, 0, 0}, pw0[3] = {0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < MP; i++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                pc0[k] += pcs[i][k];
+                pw0[k] += S.pws[3 * i + k];
+            }
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            pc0[k] /= MP;
+            pw0[k] /= MP;
+        }
+        double ABt[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, U[9], V[9];
+#pragma unroll
+        for (int i = 0; i < MP; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+#pragma unroll
+                for (int k = 0; k < 3; k++)
+                    ABt[3 * j + k] += (pcs[i][j] - pc0[j]) * (S.pws[3 * i + k] - pw0[k]);
+        svd3(ABt, U, V);
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+                R[3 * i + j] = U[3 * i] * V[3 * j] + U[3 * i + 1] * V[3 * j + 1] + U[3 * i + 2] * V[3 * j + 2];
+        const double dR = R[0] * (R[4] * R[8] - R[5] * R[7]) - R[1] * (R[3] * R[8] - R[5] * R[6]) +
+                          R[2] * (R[3] * R[7] - R[4] * R[6]);
+        if (dR < 0) {
+            R[6] = -R[6];
+            R[7] = -R[7];
+            R[8] = -R[8];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+            t[i] = pc0[i] - (R[3 * i] * pw0[0] + R[3 * i + 1] * pw0[1] + R[3 * i + 2] * pw0[2]);
+        double sum = 0;
+#pragma unroll
+        for (int i = 0; i < MP; i++) {
+            const double *pw = S.pws + 3 * i;
+            const double Xc = dot3(R, pw) + t[0], Yc = dot3(R + 3, pw) + t[1];
+            const double inv_Zc = 1.0 / (dot3(R + 6, pw) + t[2]);
+            const double ue = K.cx + K.fx * Xc * inv_Zc, ve = K.cy + K.fy * Yc * inv_Zc;
+            const double du = S.us[2 * i] - ue, dv = S.us[2 * i + 1] - ve;
+            sum += sqrt(du * du + dv * dv);
+        }
+        err = sum / MP;
+        good = isfinite(err);
+#pragma unroll
+        for (int i = 0; i < 9; i++)
+            good = good && isfinite(R[i]);
+        if (!good)
+            err = 1e300;
+    }
+    // ---- best of the three (lowest error, ties to the lower N like the oracle's scan) ----
+    const double e0 = __shfl(err, 0), e1 = __shfl(err, 1), e2 = __shfl(err, 2);
+    int best = -1;
+    double eb = 1e300;
+    if (e0 < 1e300) {
+        best = 0;
+        eb = e0;
+    }
+    if (e1 < 1e300 && (best < 0 || e1 < eb)) {
+        best = 1;
+        eb = e1;
+    }
+    if (e2 < 1e300 && (best < 0 || e2 < eb)) {
+        best = 2;
+        eb = e2;
+    }
+    if (best < 0) {
+        if (lane == 0)
+            nmodels[it] = 0;
+        return;
+    }
+    if (lane == best) {
+        double *dst = hyp + (size_t)it * 12;
+#pragma unroll
+        for (int i = 0; i < 9; i++)
+            dst[i] = R[i];
+        dst[9] = t[0];
+        dst[10] = t[1];
+        dst[11] = t[2];
+        nmodels[it] = 1;
+    }
+}
+
+// PnPRansacCallback::computeError for one correspondence
+__device__ __forceinline__ float reproj_err_sq(const double (&P)[12], const K4 &K, float X, float Y, float Z,
+                                               float u, float v)
+{
+    const double Xc = P[0] * X + P[1] * Y + P[2] * Z + P[9];
+    const double Yc = P[3] * X + P[4] * Y + P[5] * Z + P[10];
+    const double Zc = P[6] * X + P[7] * Y + P[8] * Z + P[11];
+    const double z = Zc != 0 ? 1. / Zc : 1.;
+    const float px = (float)(Xc * z * K.fx + K.cx), py = (float)(Yc * z * K.fy + K.cy);
+    const float dx = u - px, dy = v - py;
+    return (float)((double)dx * dx + (double)dy * dy);
+}
+
+__global__ __launch_bounds__(256) void pnp_score_kernel(const float *__restrict__ obj, const float2 *__restrict__ img,
+                                                        int n_host, const int *__restrict__ d_n, K4 K, int it0,
+                                                        int it1, const RansacState *__restrict__ st,
+                                                        const double *__restrict__ hyp,
+                                                        const int *__restrict__ nmodels, float thr,
+                                                        int *__restrict__ counts)
+{
+    const int lane = threadIdx.x & 63;
+    const int it = __builtin_amdgcn_readfirstlane(it0 + blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (it >= it1)
+        return;
+    if (it0 > 0 && st->done)
+        return;
+    if (nmodels[it] <= 0) {
+        if (lane == 0)
+            counts[it] = 0;
+        return;
+    }
+    const int n = d_n ? *d_n : n_host;
+    double P[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++)
+        P[i] = hyp[(size_t)it * 12 + i];
+    int cnt = 0;
+    for (int i = lane; i < n; i += 64) {
+        const float2 u = img[i];
+        cnt += reproj_err_sq(P, K, obj[3 * i], obj[3 * i + 1], obj[3 * i + 2], u.x, u.y) <= thr ? 1 : 0;
+    }
+    cnt = wave_sum_small(cnt);
+    if (lane == 0)
+        counts[it] = cnt;
+}
+
+__global__ __launch_bounds__(256) void pnp_mask_kernel(const float *__restrict__ obj, const float2 *__restrict__ img,
+                                                       int n_host, const int *__restrict__ d_n, K4 K,
+                                                       const RansacState *__restrict__ st,
+                                                       const double *__restrict__ hyp, float thr,
+                                                       uint8_t *__restrict__ mask)
+{
+    const int n = d_n ? *d_n : n_host;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_host)
+        return;
+    const RansacState s = *st;
+    uint8_t m = 0;
+    if (s.best_iter >= 0 && s.best_count > 0 && i < n) {
+        double P[12];
+#pragma unroll
+        for (int k = 0; k < 12; k++)
+            P[k] = hyp[(size_t)s.best_iter * 12 + k];
+        const float2 u = img[i];
+        m = reproj_err_sq(P, K, obj[3 * i], obj[3 * i + 1], obj[3 * i + 2], u.x, u.y) <= thr ? 1 : 0;
+    }
+    mask[i] = m;
+}
+
+// order-preserving list of the indices with mask == 1 (the `inliers` vector of solvePnPRansac)
+__global__ __launch_bounds__(1024) void mask_to_index_kernel(const uint8_t *__restrict__ mask, int n_host,
+                                                             const int *__restrict__ d_n, int *__restrict__ out_idx,
+                                                             int *__restrict__ d_count)
+{
+    __shared__ int s_sum[1024];
+    const int n = d_n ? *d_n : n_host;
+    const int t = threadIdx.x;
+    const int per = (n + 1023) / 1024;
+    const int b = t * per, e = min(b + per, n);
+    int cnt = 0;
+    for (int i = b; i < e; i++)
+        cnt += mask[i] == 1;
+    s_sum[t] = cnt;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        int v = t >= off ? s_sum[t - off] : 0;
+        __syncthreads();
+        s_sum[t] += v;
+        __syncthreads();
+    }
+    int pos = s_sum[t] - cnt;
+    if (t == 1023)
+        *d_count = s_sum[1023];
+    for (int i = b; i < e; i++)
+        if (mask[i] == 1)
+            out_idx[pos++] = i;
+}
+
+// ---- Levenberg-Marquardt refinement over the inlier list -------------------------------------
+__device__ void rodrigues_dev(const double *r, double *R)
+{
+    const double th = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    if (th < DBL_EPSILON) {
+        for (int i = 0; i < 9; i++)
+            R[i] = (i % 4) == 0 ? 1. : 0.;
+        return;
+    }
+    const double c = cos(th), s = sin(th), c1 = 1. - c, it = 1. / th;
+    const double x = r[0] * it, y = r[1] * it, z = r[2] * it;
+    R[0] = c + c1 * x * x;
+    R[1] = c1 * x * y - s * z;
+    R[2] = c1 * x * z + s * y;
+    R[3] = c1 * x * y + s * z;
+    R[4] = c + c1 * y * y;
+    R[5] = c1 * y * z - s * x;
+    R[6] = c1 * x * z - s * y;
+    R[7] = c1 * y * z + s * x;
+    R[8] = c + c1 * z * z;
+}
+
+__device__ void rodrigues_inv_dev(const double *R, double *r)
+{
+    double rx = R[7] - R[5], ry = R[2] - R[6], rz = R[3] - R[1];
+    const double s = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
+    double c = (R[0] + R[4] + R[8] - 1) * 0.5;
+    c = c > 1. ? 1. : (c < -1. ? -1. : c);
+    double theta = acos(c);
+    if (s < 1e-5) {
+        if (c > 0) {
+            r[0] = r[1] = r[2] = 0;
+        } else {
+            double t;
+            t = (R[0] + 1) * 0.5;
+            rx = sqrt(t > 0 ? t : 0);
+            t = (R[4] + 1) * 0.5;
+            ry = sqrt(t > 0 ? t : 0) * (R[1] < 0 ? -1. : 1.);
+            t = (R[8] + 1) * 0.5;
+            rz = sqrt(t > 0 ? t : 0) * (R[2] < 0 ? -1. : 1.);
+            if (fabs(rx) < fabs(ry) && fabs(rx) < fabs(rz) && (R[5] > 0) != (ry * rz > 0))
+                rz = -rz;
+            theta /= sqrt(rx * rx + ry * ry + rz * rz);
+            r[0] = rx * theta;
+            r[1] = ry * theta;
+            r[2] = rz * theta;
+        }
+    } else {
+        const double vth = 1 / (2 * s) * theta;
+        r[0] = rx * vth;
+        r[1] = ry * vth;
+        r[2] = rz * vth;
+    }
+}
+
+__device__ bool chol6_solve(const double *Ain, const double *b, double *x)
+{
+    double L[36];
+    for (int i = 0; i < 36; i++)
+        L[i] = 0;
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j <= i; j++) {
+            double s = Ain[6 * i + j];
+            for (int k = 0; k < j; k++)
+                s -= L[6 * i + k] * L[6 * j + k];
+            if (i == j) {
+                if (!(s > 0))
+                    return false;
+                L[6 * i + i] = sqrt(s);
+            } else
+                L[6 * i + j] = s / L[6 * j + j];
+        }
+    double y[6];
+    for (int i = 0; i < 6; i++) {
+        double s = b[i];
+        for (int k = 0; k < i; k++)
+            s -= L[6 * i + k] * y[k];
+        y[i] = s / L[6 * i + i];
+    }
+    for (int i = 5; i >= 0; i--) {
+        double s = y[i];
+        for (int k = i + 1; k < 6; k++)
+            s -= L[6 * k + i] * x[k];
+        x[i] = s / L[6 * i + i];
+    }
+    return true;
+}
+
+constexpr int NACC = 28;  // 21 upper-triangular J^T J + 6 J^T r + 1 squared error
+
+// Fixed-order block reduction of NV doubles per thread (256 threads): shuffle tree inside
+// each wave, then lane 0 of every wave to LDS, then thread 0 adds the four partials.
+template <int NV> __device__ void block_reduce(double (&v)[NV], double *s_part /*4*NV*/, double *s_out /*NV*/)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        double x = v[k];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1)
+            x += __shfl_down(x, off);
+        if (lane == 0)
+            s_part[wave * NV + k] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        const int k = threadIdx.x;
+        s_out[k] = ((s_part[k] + s_part[NV + k]) + s_part[2 * NV + k]) + s_part[3 * NV + k];
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void pnp_point_terms(const float *__restrict__ obj, const float2 *__restrict__ img, int i,
+                                                const K4 &K, const double *R, const double *t, bool with_jac,
+                                                double (&acc)[NACC])
+{
+    const double X = obj[3 * i], Y = obj[3 * i + 1], Z = obj[3 * i + 2];
+    const double rx = R[0] * X + R[1] * Y + R[2] * Z;
+    const double ry = R[3] * X + R[4] * Y + R[5] * Z;
+    const double rz = R[6] * X + R[7] * Y + R[8] * Z;
+    const double Xc = rx + t[0], Yc = ry + t[1], Zc = rz + t[2];
+    const double iz = 1. / Zc;
+    const double u = K.fx * Xc * iz + K.cx, v = K.fy * Yc * iz + K.cy;
+    const float2 o = img[i];
+    const double ru = u - o.x, rv = v - o.y;
+    acc[27] += ru * ru + rv * rv;
+    if (!with_jac)
+        return;
+    const double a0 = K.fx * iz, a2 = -K.fx * Xc * iz * iz;
+    const double b1 = K.fy * iz, b2 = -K.fy * Yc * iz * iz;
+    const double Ju[6] = {a2 * ry, a0 * rz - a2 * rx, -a0 * ry, a0, 0, a2};
+    const double Jv[6] = {-b1 * rz + b2 * ry, -b2 * rx, b1 * rx, 0, b1, b2};
+    int k = 0;
+#pragma unroll
+    for (int p = 0; p < 6; p++) {
+#pragma unroll
+        for (int q = p; q < 6; q++)
+            acc[k++] += Ju[p] * Ju[q] + Jv[p] * Jv[q];
+    }
+#pragma unroll
+    for (int p = 0; p < 6; p++)
+        acc[21 + p] += Ju[p] * ru + Jv[p] * rv;
+}
+
+struct PnpResult {      // what the host reads back after a localisation
+    double rvec[3], tvec[3];
+    double R[9];        // Rodrigues(rvec)
+    double rms;
+    int n_inliers, iters_run;
+};
+
+__global__ __launch_bounds__(256) void pnp_refine_kernel(const float *__restrict__ obj, const float2 *__restrict__ img,
+                                                         const int *__restrict__ inl, const int *__restrict__ d_m,
+                                                         K4 K, const RansacState *__restrict__ st,
+                                                         const double *__restrict__ hyp, int max_iters,
+                                                         PnpResult *__restrict__ out)
+{
+    __shared__ double s_part[4 * NACC], s_sum[NACC], s_pose[12], s_trial[12];
+    __shared__ int s_flag;
+    const int tid = threadIdx.x;
+    const RansacState s = *st;
+    const int m = *d_m;
+    if (s.best_iter < 0 || s.best_count <= 0 || m <= 0) {
+        if (tid == 0) {
+            PnpResult r;
+            memset(&r, 0, sizeof(r));
+            r.iters_run = s.iters_run;
+            *out = r;
+        }
+        return;
+    }
+    if (tid < 12)
+        s_pose[tid] = hyp[(size_t)s.best_iter * 12 + tid];
+    __syncthreads();
+    double acc[NACC];
+    auto accumulate = [&](const double *pose, bool jac) {
+#pragma unroll
+        for (int k = 0; k < NACC; k++)
+            acc[k] = 0;
+        for (int e = tid; e < m; e += 256)
+            pnp_point_terms(obj, img, inl[e], K, pose, pose + 9, jac, acc);
+        block_reduce<NACC>(acc, s_part, s_sum);
+    };
+    accumulate(s_pose, true);
+    double err = s_sum[27], lambda = 1e-3;
+    double JtJ[36], Jtr[6];
+    auto unpack = [&]() {
+        int k = 0;
+        for (int p = 0; p < 6; p++)
+            for (int q = p; q < 6; q++) {
+                JtJ[6 * p + q] = s_sum[k];
+                JtJ[6 * q + p] = s_sum[k];
+                k++;
+            }
+        for (int p = 0; p < 6; p++)
+            Jtr[p] = s_sum[21 + p];
+    };
+    unpack();
+    for (int it = 0; it < max_iters; it++) {
+        // thread 0 proposes a step; flag: 0 = trial pose ready, 1 = solve failed (raise lambda), 2 = stop
+        if (tid == 0) {
+            double A[36], nb[6], d[6];
+            for (int k = 0; k < 36; k++)
+                A[k] = JtJ[k];
+            for (int k = 0; k < 6; k++) {
+                A[7 * k] += lambda * JtJ[7 * k] + 1e-300;
+                nb[k] = -Jtr[k];
+            }
+            int flag = 0;
+            if (!chol6_solve(A, nb, d)) {
+                flag = lambda * 10 > 1e12 ? 2 : 1;
+            } else {
+                double dR[9];
+                rodrigues_dev(d, dR);
+                for (int i = 0; i < 3; i++)
+                    for (int j = 0; j < 3; j++)
+                        s_trial[3 * i + j] =
+                            dR[3 * i] * s_pose[j] + dR[3 * i + 1] * s_pose[3 + j] + dR[3 * i + 2] * s_pose[6 + j];
+                for (int k = 0; k < 3; k++)
+                    s_trial[9 + k] = s_pose[9 + k] + d[3 + k];
+                s_part[0] = d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3] + d[4] * d[4] + d[5] * d[5];
+            }
+            s_flag = flag;
+        }
+        __syncthreads();
+        const int flag = s_flag;
+        if (flag == 2)
+            break;
+        if (flag == 1) {
+            lambda *= 10;
+            __syncthreads();
+            continue;
+        }
+        const double step = s_part[0];
+        __syncthreads();
+        accumulate(s_trial, false);
+        const double e2 = s_sum[27];
+        if (e2 < err || !(err == err)) {
+            __syncthreads();
+            if (tid < 12)
+                s_pose[tid] = s_trial[tid];
+            __syncthreads();
+            const double prev = err;
+            accumulate(s_pose, true);
+            err = s_sum[27];
+            unpack();
+            lambda *= 0.1;
+            if (lambda < 1e-12)
+                lambda = 1e-12;
+            const double scale = 1. + s_pose[9] * s_pose[9] + s_pose[10] * s_pose[10] + s_pose[11] * s_pose[11];
+            if (step <= 1e-20 * scale || prev - err <= 1e-14 * prev)
+                break;
+        } else {
+            lambda *= 10;
+            if (lambda > 1e12)
+                break;
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (tid == 0) {
+        PnpResult r;
+        for (int k = 0; k < 9; k++)
+            r.R[k] = s_pose[k];
+        rodrigues_inv_dev(s_pose, r.rvec);
+        r.tvec[0] = s_pose[9];
+        r.tvec[1] = s_pose[10];
+        r.tvec[2] = s_pose[11];
+        r.rms = sqrt(err / m);
+        r.n_inliers = m;
+        r.iters_run = s.iters_run;
+        *out = r;
+    }
+}
+
+}  // namespace
+
+static_assert(sizeof(PnpResult) == 17 * 8, "PnpResult layout");
+
+// Device-pointer form.  inliers: cap ints; d_result: one PnpResult (136 bytes):
+// rvec[3] tvec[3] R[9] rms (doubles) n_inliers iters_run (ints).
+int svo_launch_pnp_ransac(svo_ctx *ctx, const float *obj, const float *img, int cap, const int *d_n,
+                          const double *K4h, int iterations, double reproj_err, double confidence, uint64_t seed,
+                          int refine_iters, int *inliers, uint8_t *mask, void *d_result)
+{
+    if (cap <= 0)
+        return SVO_OK;
+    if (iterations < 1)
+        iterations = 1;
+    int rc;
+    const size_t h_bytes = (size_t)iterations * 12 * sizeof(double);
+    const size_t i_bytes = (size_t)iterations * 2 * sizeof(int) + 128;
+    if ((rc = ctx->w_c.ensure(h_bytes)) || (rc = ctx->w_d.ensure(i_bytes)) ||
+        (rc = ctx->w_e.ensure((size_t)cap + 64)))
+        return rc;
+    double *hyp = ctx->w_c.as<double>();
+    RansacState *st = reinterpret_cast<RansacState *>(ctx->w_d.p);
+    int *d_m = ctx->w_d.as<int>() + 8;  // inlier count of the winning hypothesis
+    int *nmodels = ctx->w_d.as<int>() + 16;
+    int *counts = nmodels + iterations;
+    uint8_t *d_mask = mask ? mask : ctx->w_e.as<uint8_t>();
+    const K4 K = {K4h[0], K4h[1], K4h[2], K4h[3]};
+    const float thr = (float)(reproj_err * reproj_err);
+    const float2 *img2 = reinterpret_cast<const float2 *>(img);
+    ScopedKernelTime tm(ctx, SVO_K_PNP);
+    const int nblk = (iterations + 3) / 4;
+    hipLaunchKernelGGL(pnp_solve_kernel, dim3(nblk), dim3(256), 0, ctx->stream, obj, img, cap, d_n, K, seed, 0,
+                       iterations, st, hyp, nmodels);
+    hipLaunchKernelGGL(pnp_score_kernel, dim3(nblk), dim3(256), 0, ctx->stream, obj, img2, cap, d_n, K, 0, iterations,
+                       st, hyp, nmodels, thr, counts);
+    hipLaunchKernelGGL(ransac_select_kernel<1>, dim3(1), dim3(64), 0, ctx->stream, st, 1, iterations, iterations, cap,
+                       d_n, confidence, nmodels, counts, MP);
+    hipLaunchKernelGGL(pnp_mask_kernel, dim3((cap + 255) / 256), dim3(256), 0, ctx->stream, obj, img2, cap, d_n, K, st,
+                       hyp, thr, d_mask);
+    hipLaunchKernelGGL(mask_to_index_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_mask, cap, d_n, inliers, d_m);
+    hipLaunchKernelGGL(pnp_refine_kernel, dim3(1), dim3(256), 0, ctx->stream, obj, img2, inliers, d_m, K, st, hyp,
+                       refine_iters > 0 ? refine_iters : 20, reinterpret_cast<PnpResult *>(d_result));
+    SVO_HIP(hipGetLastError());
+    return SVO_OK;
+}
+
+extern "C" int svo_pnp_ransac(svo_ctx *ctx, const float *obj, const float *img, int n, const double *K4h,
+                              int iterations, double reproj_err, double confidence, uint64_t seed, double *rvec,
+                              double *tvec, int *inliers, int *n_inliers, int *iters_run, int mem)
+{
+    SVO_CHECK_ARG(ctx && K4h && n >= 0 && iterations > 0 && reproj_err > 0);
+    SVO_CHECK_ARG(mem == SVO_MEM_HOST || mem == SVO_MEM_DEVICE);
+    if (n_inliers)
+        *n_inliers = 0;
+    if (iters_run)
+        *iters_run = 0;
+    if (n == 0)
+        return SVO_OK;
+    SVO_CHECK_ARG(obj && img && inliers && rvec && tvec);
+    int rc;
+    if ((rc = ctx->s_d.ensure(sizeof(PnpResult) + 64)))
+        return rc;
+    const float *dobj = obj, *dimg = img;
+    int *dinl = inliers;
+    if (mem == SVO_MEM_HOST) {
+        if ((rc = ctx->s_a.ensure((size_t)n * 12)) || (rc = ctx->s_b.ensure((size_t)n * 8)) ||
+            (rc = ctx->s_c.ensure((size_t)n * 4)))
+            return rc;
+        SVO_HIP(hipMemcpyAsync(ctx->s_a.p, obj, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
+        SVO_HIP(hipMemcpyAsync(ctx->s_b.p, img, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+        dobj = ctx->s_a.as<float>();
+        dimg = ctx->s_b.as<float>();
+        dinl = ctx->s_c.as<int>();
+    }
+    rc = svo_launch_pnp_ransac(ctx, dobj, dimg, n, nullptr, K4h, iterations, reproj_err, confidence, seed, 20, dinl,
+                               nullptr, ctx->s_d.p);
+    if (rc)
+        return rc;
+    // rvec / tvec / counts are host outputs in both modes (the caller decides on them)
+    SVO_HIP(hipMemcpyAsync(ctx->pinned, ctx->s_d.p, sizeof(PnpResult), hipMemcpyDeviceToHost, ctx->stream));
+    SVO_HIP(hipStreamSynchronize(ctx->stream));
+    const PnpResult *r = reinterpret_cast<const PnpResult *>(ctx->pinned);
+    memcpy(rvec, r->rvec, sizeof(r->rvec));
+    memcpy(tvec, r->tvec, sizeof(r->tvec));
+    if (n_inliers)
+        *n_inliers = r->n_inliers;
+    if (iters_run)
+        *iters_run = r->iters_run;
+    if (mem == SVO_MEM_HOST && r->n_inliers > 0) {
+        SVO_HIP(hipMemcpyAsync(inliers, dinl, (size_t)r->n_inliers * 4, hipMemcpyDeviceToHost, ctx->stream));
+        SVO_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return SVO_OK;
+}

@@ -61,4 +61,74 @@ __device__ __forceinline__ int wave_sum_small(int v)
            __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
 }
 
+// Replays the SEQUENTIAL RANSAC loop over iterations [st->next_iter, it_end): first-best-wins,
+// adaptive iteration bound, stop at a failed sample -- so that evaluating all hypotheses
+// concurrently gives exactly the serial algorithm's answer.  MPI = models per iteration slot
+// (nmodels[it] in -1 (sampling failed) .. MPI, counts[it * MPI + k]).
+template <int MPI>
+__global__ void ransac_select_kernel(RansacState *st, int first, int it_end, int max_iters, int n_host,
+                                     const int *__restrict__ d_n, double confidence,
+                                     const int *__restrict__ nmodels, const int *__restrict__ counts,
+                                     int model_points)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0)
+        return;
+    RansacState s;
+    if (first) {
+        s.niters = max_iters;
+        s.next_iter = 0;
+        s.best_iter = -1;
+        s.best_model = 0;
+        s.best_count = 0;
+        s.done = 0;
+        s.iters_run = 0;
+        s.pad = 0;
+    } else {
+        s = *st;
+        if (s.done)
+            return;
+    }
+    const int n = d_n ? *d_n : n_host;
+    int it = s.next_iter;
+    if (n < model_points) {
+        s.done = 1;
+    } else {
+        for (; it < it_end; it++) {
+            if (it >= s.niters) {
+                s.done = 1;
+                break;
+            }
+            const int nm = nmodels[it];
+            if (nm < 0) {
+                s.done = 1;
+                break;
+            }
+            for (int k = 0; k < nm; k++) {
+                const int c = counts[it * MPI + k];
+                const int floor_cnt = s.best_count > model_points - 1 ? s.best_count : model_points - 1;
+                if (c > floor_cnt) {
+                    s.best_count = c;
+                    s.best_iter = it;
+                    s.best_model = k;
+                    s.niters = update_num_iters(confidence, (double)(n - c) / n, model_points, s.niters);
+                }
+            }
+        }
+        if (it >= s.niters || it >= max_iters)
+            s.done = 1;
+    }
+    s.next_iter = it;
+    s.iters_run = it;
+    *st = s;
+}
+
+// hand-off of LDS data between lanes of ONE wave (LDS ops of a wave execute in order; this
+// only pins the compiler)
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 }  // namespace svo

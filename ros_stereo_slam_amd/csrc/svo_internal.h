@@ -118,3 +118,9 @@ int svo_launch_colors(svo_ctx *ctx, const svo_pyramid *pyr, const float *xy, int
 int svo_launch_compact(svo_ctx *ctx, const uint8_t *mask, int cap, const int *d_n, const float *in_a, int stride_a,
                        float *out_a, const float *in_b, int stride_b, float *out_b, const float *in_c, int stride_c,
                        float *out_c, int *d_count);
+// pnp.hip
+int svo_launch_pnp_ransac(svo_ctx *ctx, const float *obj, const float *img, int cap, const int *d_n,
+                          const double *K4h, int iterations, double reproj_err, double confidence, uint64_t seed,
+                          int refine_iters, int *inliers, uint8_t *mask, void *d_result);
+// anms.hip
+int svo_launch_anms(svo_ctx *ctx, const float *xy, const float *resp, int n, int keep, int *out_idx, int *d_count);
