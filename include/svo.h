@@ -61,6 +61,7 @@ enum {
 
 typedef struct svo_ctx svo_ctx;
 typedef struct svo_pyramid svo_pyramid;
+typedef struct svo_vo svo_vo;
 
 int svo_version(void);
 const char *svo_last_error(void);
@@ -151,6 +152,41 @@ int svo_anms(svo_ctx *ctx, const float *xy, const float *response, int n, int nu
 int svo_pnp_ransac(svo_ctx *ctx, const float *obj, const float *img, int n, const double *K4,
                    int iterations, double reproj_err, double confidence, uint64_t seed, double *rvec,
                    double *tvec, int *inliers, int *n_inliers, int *iters_run, int mem);
+
+/* ---- the front-end frame loop: visualSLAM::initSequence, src/VisualSLAM.cpp:11-169 ----------- */
+typedef struct svo_vo_params {
+    double fx, fy, cx, cy;    /* include/visualSLAM.h:82-87 (KITTI 00-02)                      */
+    double baseline;          /* include/visualSLAM.h:68, 0.54 m                               */
+    int grid_step;            /* src/triangulation.cpp:89, 30 px                               */
+    int anms_keep;            /* 0 = no ANMS (reference); else keep this many grid keypoints   */
+    int keyframe_min_inliers; /* src/VisualSLAM.cpp:120, 200                                   */
+    double f_thr_stereo;      /* src/tracking.cpp:34, 3.0 px                                   */
+    double f_thr_temporal;    /* src/tracking.cpp:75, 1.0 px                                   */
+    uint64_t seed;            /* RANSAC sampling seed; stage seeds are seed + 8*frame + stage  */
+} svo_vo_params;
+void svo_vo_default_params(svo_vo_params *p);
+
+int svo_vo_create(svo_ctx *ctx, const svo_vo_params *params, int width, int height, int channels,
+                  svo_vo **out);
+int svo_vo_destroy(svo_vo *vo);
+/* frame 0: stereoTriangulate(imL, imR), identity pose (src/VisualSLAM.cpp:22-41) */
+int svo_vo_init(svo_vo *vo, const uint8_t *left, const uint8_t *right, int mem, int *n_points);
+/* PerspectiveNpointEstimation + pose composition (src/VisualSLAM.cpp:64-74,
+ * src/keyFrameManagement.cpp:73-94).  R9 (row-major) / t3: camera pose in the world.
+ * Returns SVO_ERR_TRACKING_LOST where the reference sets SHUTDOWN_FLAG.                      */
+int svo_vo_localize(svo_vo *vo, const uint8_t *left, int mem, double *R9, double *t3, int *n_inliers,
+                    int *n_tracked);
+/* keyframe rule and reference hand-over (src/VisualSLAM.cpp:93-152) with the pose the caller
+ * settled on; force_keyframe is the reference's LC_FLAG.  `right` may be NULL when no
+ * keyframe can be due.                                                                        */
+int svo_vo_update(svo_vo *vo, const uint8_t *right, int mem, const double *R9, const double *t3,
+                  int n_inliers, int force_keyframe, int *was_keyframe);
+/* localize + update */
+int svo_vo_track(svo_vo *vo, const uint8_t *left, const uint8_t *right, int mem, int force_keyframe,
+                 double *R9, double *t3, int *n_inliers, int *was_keyframe, int *n_tracked);
+/* the current reference point set (2-D in the reference image, 3-D world) */
+int svo_vo_get_reference(svo_vo *vo, float *ref2d, float *ref3d, int cap, int *n, int mem);
+int svo_vo_capacity(const svo_vo *vo);
 
 #ifdef __cplusplus
 }

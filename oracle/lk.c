@@ -355,7 +355,9 @@ int orc_lk_track(const uint8_t *prev, const uint8_t *next, int w, int h, int c,
                 pdx = dx;
                 pdy = dy;
             }
-            if (status[p] && err && level == 0) {
+            /* the reference always asks for err (src/tracking.cpp:17,50), so the final
+             * out-of-image check below always runs; err itself is optional here */
+            if (status[p] && level == 0) {
                 float qx = next_pts[2 * p] - half, qy = next_pts[2 * p + 1] - half;
                 int iqx = cv_floor_f(qx), iqy = cv_floor_f(qy);
                 if (iqx < -win || iqx >= lw || iqy < -win || iqy >= lh) {
@@ -381,7 +383,8 @@ int orc_lk_track(const uint8_t *prev, const uint8_t *next, int w, int h, int c,
                                        Iw[e];
                             sabs += diff < 0 ? -diff : diff;
                         }
-                err[p] = (float)sabs / (float)(32 * win * c * win);
+                if (err)
+                    err[p] = (float)sabs / (float)(32 * win * c * win);
             }
         }
     }

@@ -10,6 +10,7 @@ import ctypes as C
 import os
 import pathlib
 import re
+import weakref
 
 import numpy as np
 
@@ -78,6 +79,7 @@ class Pyramid:
         self.ctx, self.w, self.h, self.c, self.levels = ctx, w, h, c, levels
         self._h = C.c_void_p()
         _check(ctx.lib.svo_pyramid_create(ctx._h, w, h, c, levels, C.byref(self._h)))
+        ctx._children.add(self)
 
     def build(self, image, mem: int = MEM_HOST):
         if isinstance(image, np.ndarray):
@@ -95,9 +97,9 @@ class Pyramid:
         return out
 
     def close(self):
-        if self._h:
+        if self._h and self.ctx._h:
             self.ctx.lib.svo_pyramid_destroy(self.ctx._h, self._h)
-            self._h = C.c_void_p()
+        self._h = C.c_void_p()
 
     def __del__(self):
         try:
@@ -112,11 +114,14 @@ class Context:
     def __init__(self, device: int = 0):
         self.lib = load()
         self._h = C.c_void_p()
+        self._children = weakref.WeakSet()  # pyramids / front-ends that must go before the context
         _check(self.lib.svo_ctx_create(device, C.byref(self._h)))
         self.device = device
 
     def close(self):
         if self._h:
+            for child in list(self._children):
+                child.close()
             self.lib.svo_ctx_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -272,3 +277,81 @@ def pnp_ransac(self, obj, img, K4, iterations=100, reproj_err=1.0, confidence=0.
                                    iterations, C.c_double(reproj_err), C.c_double(confidence), C.c_uint64(seed),
                                    _ptr(rvec), _ptr(tvec), _ptr(inl), C.byref(cnt), C.byref(iters), MEM_HOST))
     return cnt.value, rvec, tvec, inl[:cnt.value].copy(), iters.value
+
+
+class VoParams(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("baseline", C.c_double), ("grid_step", C.c_int), ("anms_keep", C.c_int),
+                ("keyframe_min_inliers", C.c_int), ("f_thr_stereo", C.c_double),
+                ("f_thr_temporal", C.c_double), ("seed", C.c_uint64)]
+
+
+class VisualOdometry:
+    """The front-end frame loop on one GPU (``svo_vo``), mirroring visualSLAM::initSequence
+    (src/VisualSLAM.cpp:11-169).  Images: numpy (H, W, C) uint8 or device tensors."""
+
+    def __init__(self, ctx: Context, w, h, c, grid_step=30, anms_keep=0, keyframe_min_inliers=200, seed=0,
+                 K4=None, baseline=None):
+        self.ctx = ctx
+        self.prm = VoParams()
+        ctx.lib.svo_vo_default_params(C.byref(self.prm))
+        self.prm.grid_step, self.prm.anms_keep = grid_step, anms_keep
+        self.prm.keyframe_min_inliers, self.prm.seed = keyframe_min_inliers, seed
+        if K4 is not None:
+            self.prm.fx, self.prm.fy, self.prm.cx, self.prm.cy = K4
+        if baseline is not None:
+            self.prm.baseline = baseline
+        self._h = C.c_void_p()
+        _check(ctx.lib.svo_vo_create(ctx._h, C.byref(self.prm), w, h, c, C.byref(self._h)))
+        ctx._children.add(self)
+
+    @staticmethod
+    def _mem(img):
+        return MEM_HOST if isinstance(img, np.ndarray) else MEM_DEVICE
+
+    def init(self, left, right):
+        n = C.c_int()
+        _check(self.ctx.lib.svo_vo_init(self._h, _ptr(left), _ptr(right), self._mem(left), C.byref(n)))
+        return n.value
+
+    def localize(self, left):
+        R, t = np.zeros((3, 3)), np.zeros(3)
+        ninl, ntrk = C.c_int(), C.c_int()
+        rc = self.ctx.lib.svo_vo_localize(self._h, _ptr(left), self._mem(left), _ptr(R), _ptr(t), C.byref(ninl),
+                                          C.byref(ntrk))
+        if rc not in (SVO_OK, SVO_ERR_TRACKING_LOST):
+            _check(rc)
+        return rc, R, t, ninl.value, ntrk.value
+
+    def update(self, right, R, t, n_inliers, force_keyframe=False):
+        kf = C.c_int()
+        mem = MEM_HOST if right is None else self._mem(right)
+        _check(self.ctx.lib.svo_vo_update(self._h, _ptr(right), mem, _ptr(np.ascontiguousarray(R, np.float64)),
+                                          _ptr(np.ascontiguousarray(t, np.float64)), n_inliers,
+                                          int(force_keyframe), C.byref(kf)))
+        return bool(kf.value)
+
+    def track(self, left, right, force_keyframe=False):
+        rc, R, t, ninl, ntrk = self.localize(left)
+        if rc:
+            return rc, R, t, ninl, False, ntrk
+        kf = self.update(right, R, t, ninl, force_keyframe)
+        return rc, R, t, ninl, kf, ntrk
+
+    def reference(self):
+        cap = self.ctx.lib.svo_vo_capacity(self._h)
+        a, b = np.zeros((cap, 2), np.float32), np.zeros((cap, 3), np.float32)
+        n = C.c_int()
+        _check(self.ctx.lib.svo_vo_get_reference(self._h, _ptr(a), _ptr(b), cap, C.byref(n), MEM_HOST))
+        return a[:n.value], b[:n.value]
+
+    def close(self):
+        if self._h and self.ctx._h:
+            self.ctx.lib.svo_vo_destroy(self._h)
+        self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

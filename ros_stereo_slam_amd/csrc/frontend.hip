@@ -1,0 +1,386 @@
+// frontend.hip -- the stereo-VO front-end frame loop on one GPU (svo_vo).
+//
+// Host-side mirror of visualSLAM::initSequence's per-frame body
+// (src/VisualSLAM.cpp:11-169) with every data-parallel stage on the device:
+//   svo_vo_init      stereoTriangulate of frame 0            VisualSLAM.cpp:22-41
+//   svo_vo_localize  PerspectiveNpointEstimation + pose      VisualSLAM.cpp:64-74,
+//                    composition                              keyFrameManagement.cpp:73-94
+//   svo_vo_update    keyframe rule + reference hand-over     VisualSLAM.cpp:93-152,
+//                                                             keyFrameManagement.cpp:9-31
+// The split lets the caller run the pose graph between the two (VisualSLAM.cpp:76-89
+// re-anchors t after a loop closure before the keyframe is inserted).
+//
+// Device residency: the reference image pyramid, the current pyramid, the reference point
+// sets (2-D, 3-D world) and every intermediate live in HBM.  A localisation enqueues
+// pyramid -> LK -> compaction -> F-RANSAC -> compaction -> PnP-RANSAC (+refine) on the
+// context's stream with device-side counts chained between stages, and reads back ONE
+// 144-byte record (pose, inlier count, tracked count) -- the values the reference's host
+// policy branches on (inliers < 10: retry / shutdown; inliers < 200: keyframe).
+#include <cmath>
+
+#include "svo_internal.h"
+
+struct PnpRecord {  // layout of pnp.hip's PnpResult + the tracked-point count behind it
+    double rvec[3], tvec[3], R[9], rms;
+    int n_inliers, iters_run;
+    int n_tracked, pad;
+};
+
+struct svo_vo {
+    svo_ctx *ctx = nullptr;
+    svo_vo_params prm;
+    int w = 0, h = 0, c = 0, cap = 0;
+    svo_pyramid *pyr_ref = nullptr, *pyr_cur = nullptr, *pyr_right = nullptr;
+    // point sets (device)
+    float *ref2d = nullptr, *ref3d = nullptr, *trk2d = nullptr, *trk3d = nullptr;
+    float *a2 = nullptr, *b2 = nullptr, *c2 = nullptr, *d2 = nullptr, *a3 = nullptr, *b3 = nullptr, *resp = nullptr;
+    uint8_t *status = nullptr, *mask = nullptr, *st2 = nullptr;
+    int *idx = nullptr, *d_cnt = nullptr;  // d_cnt[0..7]: stage counts
+    PnpRecord *d_rec = nullptr;
+    uint8_t *d_img = nullptr;  // staging for host images
+    int nref = 0, ntrk = 0, frame = 0;
+    double R[9], t[3];
+    bool has_cur = false;
+};
+
+namespace {
+
+template <class T> int dev_alloc(T **p, size_t count)
+{
+    hipError_t e = hipMalloc((void **)p, count * sizeof(T));
+    if (e != hipSuccess) {
+        svo_set_error("hipMalloc(%zu) -> %s", count * sizeof(T), hipGetErrorString(e));
+        return SVO_ERR_HIP;
+    }
+    return SVO_OK;
+}
+
+int grid_axis(int dim, int step)
+{
+    int k = 0;
+    for (int v = step; v < dim - step; v += step)
+        k++;
+    return k;
+}
+
+uint64_t stage_seed(const svo_vo *v, int stage) { return v->prm.seed + 8ull * (uint64_t)v->frame + stage; }
+
+__global__ void gather_kernel(const int *__restrict__ idx, const int *__restrict__ d_count, int cap,
+                              const float2 *__restrict__ in_a, float2 *__restrict__ out_a,
+                              const float2 *__restrict__ in_b, float2 *__restrict__ out_b,
+                              const uint8_t *__restrict__ in_s, uint8_t *__restrict__ out_s)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap || i >= *d_count)
+        return;
+    const int j = idx[i];
+    out_a[i] = in_a[j];
+    out_b[i] = in_b[j];
+    out_s[i] = in_s[j];
+}
+
+__global__ void store_count_kernel(const int *__restrict__ src, int *__restrict__ dst) { *dst = *src; }
+
+const uint8_t *stage_image(svo_vo *v, const uint8_t *img, int mem, int *rc)
+{
+    *rc = SVO_OK;
+    if (mem == SVO_MEM_DEVICE)
+        return img;
+    hipError_t e =
+        hipMemcpyAsync(v->d_img, img, (size_t)v->w * v->h * v->c, hipMemcpyHostToDevice, v->ctx->stream);
+    if (e != hipSuccess) {
+        svo_set_error("image upload -> %s", hipGetErrorString(e));
+        *rc = SVO_ERR_HIP;
+    }
+    return v->d_img;
+}
+
+// visualSLAM::stereoTriangulate, dense branch (src/triangulation.cpp:87-103,137-165), with
+// the optional ANMS stage.  Leaves x1 in out2d, camera-frame points in v->b3 and, when Rt is
+// given, world points in out3d (else the camera-frame points).  Count -> d_cnt[4] and host.
+int stereo_triangulate(svo_vo *v, const svo_pyramid *left, const svo_pyramid *right, const double *Rt,
+                       float *out2d, float *out3d, int *n_out)
+{
+    svo_ctx *ctx = v->ctx;
+    int rc;
+    int n = grid_axis(v->w, v->prm.grid_step) * grid_axis(v->h, v->prm.grid_step);
+    if ((rc = svo_launch_grid(ctx, v->h, v->w, v->prm.grid_step, v->a2, n)))
+        return rc;
+    // denseLKtracking: LK left -> right (src/tracking.cpp:18); min-eig is the ANMS response
+    if ((rc = svo_launch_lk(ctx, left->dev, right->dev, v->a2, n, v->b2, v->status, nullptr, v->resp)))
+        return rc;
+    const float *pts = v->a2, *trk = v->b2;
+    const uint8_t *st = v->status;
+    const int *d_n = nullptr;
+    if (v->prm.anms_keep > 0) {
+        if ((rc = svo_launch_anms(ctx, v->a2, v->resp, n, v->prm.anms_keep, v->idx, v->d_cnt + 2)))
+            return rc;
+        hipLaunchKernelGGL(gather_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, v->idx, v->d_cnt + 2, n,
+                           reinterpret_cast<const float2 *>(v->a2), reinterpret_cast<float2 *>(v->c2),
+                           reinterpret_cast<const float2 *>(v->b2), reinterpret_cast<float2 *>(v->d2), v->status,
+                           v->st2);
+        pts = v->c2;
+        trk = v->d2;
+        st = v->st2;
+        d_n = v->d_cnt + 2;
+    }
+    // status compaction (src/tracking.cpp:20-27); ping-pong between the (a2,b2) and (c2,d2) pairs
+    float *o1 = pts == v->a2 ? v->c2 : v->a2, *o2 = pts == v->a2 ? v->d2 : v->b2;
+    if ((rc = svo_launch_compact(ctx, st, n, d_n, pts, 2, o1, trk, 2, o2, nullptr, 0, nullptr, v->d_cnt + 3)))
+        return rc;
+    // FmatThresholding (src/tracking.cpp:30-43): 3 px, 0.99
+    if ((rc = svo_launch_fransac(ctx, o1, o2, n, v->d_cnt + 3, v->prm.f_thr_stereo, 0.99, 1000, stage_seed(v, 3),
+                                 v->mask, nullptr, nullptr, nullptr)))
+        return rc;
+    float *x1 = out2d, *x2 = o1 == v->a2 ? v->c2 : v->a2;
+    if ((rc = svo_launch_compact(ctx, v->mask, n, v->d_cnt + 3, o1, 2, x1, o2, 2, x2, nullptr, 0, nullptr,
+                                 v->d_cnt + 4)))
+        return rc;
+    double P1[12], P2[12];
+    svo_stereo_projections(v->prm.fx, v->prm.fy, v->prm.cx, v->prm.cy, v->prm.baseline, P1, P2);
+    if ((rc = svo_launch_triangulate(ctx, P1, P2, x1, x2, n, v->d_cnt + 4, Rt ? v->b3 : out3d, nullptr, Rt,
+                                     Rt ? out3d : nullptr)))
+        return rc;
+    SVO_HIP(hipMemcpyAsync(ctx->pinned, v->d_cnt + 4, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    SVO_HIP(hipStreamSynchronize(ctx->stream));
+    *n_out = *reinterpret_cast<int *>(ctx->pinned);
+    return SVO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void svo_vo_default_params(svo_vo_params *p)
+{
+    if (!p)
+        return;
+    p->fx = 7.188560000000e+02;  // include/visualSLAM.h:82-87
+    p->fy = 7.188560000000e+02;
+    p->cx = 6.071928000000e+02;
+    p->cy = 1.852157000000e+02;
+    p->baseline = 0.54;  // include/visualSLAM.h:68
+    p->grid_step = 30;   // src/triangulation.cpp:89
+    p->anms_keep = 0;
+    p->keyframe_min_inliers = 200;  // src/VisualSLAM.cpp:120
+    p->f_thr_stereo = 3.0;          // src/tracking.cpp:34
+    p->f_thr_temporal = 1.0;        // src/tracking.cpp:75
+    p->seed = 0;
+}
+
+int svo_vo_create(svo_ctx *ctx, const svo_vo_params *params, int width, int height, int channels, svo_vo **out)
+{
+    SVO_CHECK_ARG(ctx && params && out);
+    SVO_CHECK_ARG(channels == 1 || channels == 3);
+    SVO_CHECK_ARG(params->grid_step > 0 && params->keyframe_min_inliers >= 0);
+    *out = nullptr;
+    SVO_HIP(hipSetDevice(ctx->device));
+    svo_vo *v = new svo_vo();
+    v->ctx = ctx;
+    v->prm = *params;
+    v->w = width;
+    v->h = height;
+    v->c = channels;
+    v->cap = grid_axis(width, params->grid_step) * grid_axis(height, params->grid_step);
+    if (v->cap < 16)
+        v->cap = 16;
+    int rc = SVO_OK;
+    const size_t n = (size_t)v->cap;
+    if ((rc = svo_pyramid_create(ctx, width, height, channels, SVO_MAX_LEVELS, &v->pyr_ref)) ||
+        (rc = svo_pyramid_create(ctx, width, height, channels, SVO_MAX_LEVELS, &v->pyr_cur)) ||
+        (rc = svo_pyramid_create(ctx, width, height, channels, SVO_MAX_LEVELS, &v->pyr_right)) ||
+        (rc = dev_alloc(&v->ref2d, n * 2)) || (rc = dev_alloc(&v->ref3d, n * 3)) ||
+        (rc = dev_alloc(&v->trk2d, n * 2)) || (rc = dev_alloc(&v->trk3d, n * 3)) ||
+        (rc = dev_alloc(&v->a2, n * 2)) || (rc = dev_alloc(&v->b2, n * 2)) || (rc = dev_alloc(&v->c2, n * 2)) ||
+        (rc = dev_alloc(&v->d2, n * 2)) || (rc = dev_alloc(&v->a3, n * 3)) || (rc = dev_alloc(&v->b3, n * 3)) ||
+        (rc = dev_alloc(&v->resp, n)) || (rc = dev_alloc(&v->status, n)) || (rc = dev_alloc(&v->mask, n)) ||
+        (rc = dev_alloc(&v->st2, n)) || (rc = dev_alloc(&v->idx, n)) || (rc = dev_alloc(&v->d_cnt, 16)) ||
+        (rc = dev_alloc(&v->d_rec, 1)) || (rc = dev_alloc(&v->d_img, (size_t)width * height * channels))) {
+        svo_vo_destroy(v);
+        return rc;
+    }
+    for (int i = 0; i < 9; i++)
+        v->R[i] = (i % 4) == 0;
+    v->t[0] = v->t[1] = v->t[2] = 0;
+    *out = v;
+    return SVO_OK;
+}
+
+int svo_vo_destroy(svo_vo *v)
+{
+    if (!v)
+        return SVO_OK;
+    (void)hipSetDevice(v->ctx->device);
+    (void)hipStreamSynchronize(v->ctx->stream);
+    svo_pyramid_destroy(v->ctx, v->pyr_ref);
+    svo_pyramid_destroy(v->ctx, v->pyr_cur);
+    svo_pyramid_destroy(v->ctx, v->pyr_right);
+    void *bufs[] = {v->ref2d, v->ref3d, v->trk2d, v->trk3d, v->a2,   v->b2,    v->c2,    v->d2,   v->a3,
+                    v->b3,    v->resp,  v->status, v->mask, v->st2, v->idx,   v->d_cnt, v->d_rec, v->d_img};
+    for (void *b : bufs)
+        if (b)
+            (void)hipFree(b);
+    delete v;
+    return SVO_OK;
+}
+
+int svo_vo_init(svo_vo *v, const uint8_t *left, const uint8_t *right, int mem, int *n_points)
+{
+    SVO_CHECK_ARG(v && left && right);
+    SVO_CHECK_ARG(mem == SVO_MEM_HOST || mem == SVO_MEM_DEVICE);
+    int rc;
+    v->frame = 0;
+    for (int i = 0; i < 9; i++)
+        v->R[i] = (i % 4) == 0;
+    v->t[0] = v->t[1] = v->t[2] = 0;
+    const uint8_t *d = stage_image(v, left, mem, &rc);
+    if (rc || (rc = svo_build_pyramid_from_device(v->ctx, v->pyr_ref, d)))
+        return rc;
+    d = stage_image(v, right, mem, &rc);
+    if (rc || (rc = svo_build_pyramid_from_device(v->ctx, v->pyr_right, d)))
+        return rc;
+    if ((rc = stereo_triangulate(v, v->pyr_ref, v->pyr_right, nullptr, v->ref2d, v->ref3d, &v->nref)))
+        return rc;
+    v->has_cur = false;
+    if (n_points)
+        *n_points = v->nref;
+    return SVO_OK;
+}
+
+int svo_vo_localize(svo_vo *v, const uint8_t *left, int mem, double *R9, double *t3, int *n_inliers,
+                    int *n_tracked)
+{
+    SVO_CHECK_ARG(v && left && R9 && t3);
+    SVO_CHECK_ARG(mem == SVO_MEM_HOST || mem == SVO_MEM_DEVICE);
+    svo_ctx *ctx = v->ctx;
+    int rc;
+    v->frame++;
+    const int n = v->nref;
+    if (n_inliers)
+        *n_inliers = 0;
+    if (n_tracked)
+        *n_tracked = 0;
+    const uint8_t *d = stage_image(v, left, mem, &rc);
+    if (rc || (rc = svo_build_pyramid_from_device(ctx, v->pyr_cur, d)))
+        return rc;
+    v->has_cur = true;
+    if (n < 5) {
+        svo_set_error("tracking lost: %d reference points", n);
+        return SVO_ERR_TRACKING_LOST;
+    }
+    // PyrLKtrackFrame2Frame (src/tracking.cpp:46-91)
+    if ((rc = svo_launch_lk(ctx, v->pyr_ref->dev, v->pyr_cur->dev, v->ref2d, n, v->a2, v->status, nullptr, nullptr)))
+        return rc;
+    if ((rc = svo_launch_compact(ctx, v->status, n, nullptr, v->ref2d, 2, v->b2, v->a2, 2, v->c2, v->ref3d, 3, v->a3,
+                                 v->d_cnt)))
+        return rc;
+    if ((rc = svo_launch_fransac(ctx, v->b2, v->c2, n, v->d_cnt, v->prm.f_thr_temporal, 0.99, 1000, stage_seed(v, 0),
+                                 v->mask, nullptr, nullptr, nullptr)))
+        return rc;
+    if ((rc = svo_launch_compact(ctx, v->mask, n, v->d_cnt, v->c2, 2, v->trk2d, v->a3, 3, v->trk3d, nullptr, 0,
+                                 nullptr, v->d_cnt + 1)))
+        return rc;
+    // solvePnPRansac (src/keyFrameManagement.cpp:84), retry (:85-92)
+    const double K4[4] = {v->prm.fx, v->prm.fy, v->prm.cx, v->prm.cy};
+    const PnpRecord *rec = reinterpret_cast<const PnpRecord *>(ctx->pinned);
+    for (int attempt = 0; attempt < 2; attempt++) {
+        if ((rc = svo_launch_pnp_ransac(ctx, v->trk3d, v->trk2d, n, v->d_cnt + 1, K4, 100, attempt ? 8.0 : 1.0,
+                                        attempt ? 0.98 : 0.99, stage_seed(v, attempt ? 2 : 1), 20, v->idx, nullptr,
+                                        v->d_rec)))
+            return rc;
+        hipLaunchKernelGGL(store_count_kernel, dim3(1), dim3(1), 0, ctx->stream, v->d_cnt + 1, &v->d_rec->n_tracked);
+        SVO_HIP(hipMemcpyAsync(ctx->pinned, v->d_rec, sizeof(PnpRecord), hipMemcpyDeviceToHost, ctx->stream));
+        SVO_HIP(hipStreamSynchronize(ctx->stream));
+        if (rec->n_inliers >= 10)
+            break;
+    }
+    v->ntrk = rec->n_tracked;
+    if (n_inliers)
+        *n_inliers = rec->n_inliers;
+    if (n_tracked)
+        *n_tracked = rec->n_tracked;
+    if (rec->n_inliers < 10) {
+        svo_set_error("tracking lost at frame %d: %d PnP inliers", v->frame, rec->n_inliers);
+        return SVO_ERR_TRACKING_LOST;
+    }
+    // Rodrigues; R = R^T; t = -R * tvec (src/VisualSLAM.cpp:70-74)
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            R9[3 * i + j] = rec->R[3 * j + i];
+    for (int i = 0; i < 3; i++)
+        t3[i] = -(R9[3 * i] * rec->tvec[0] + R9[3 * i + 1] * rec->tvec[1] + R9[3 * i + 2] * rec->tvec[2]);
+    return SVO_OK;
+}
+
+int svo_vo_update(svo_vo *v, const uint8_t *right, int mem, const double *R9, const double *t3, int n_inliers,
+                  int force_keyframe, int *was_keyframe)
+{
+    SVO_CHECK_ARG(v && R9 && t3);
+    SVO_CHECK_ARG(mem == SVO_MEM_HOST || mem == SVO_MEM_DEVICE);
+    if (!v->has_cur) {
+        svo_set_error("svo_vo_update without a preceding svo_vo_localize");
+        return SVO_ERR_STATE;
+    }
+    memcpy(v->R, R9, sizeof(v->R));
+    memcpy(v->t, t3, sizeof(v->t));
+    const bool kf = n_inliers < v->prm.keyframe_min_inliers || force_keyframe;  // src/VisualSLAM.cpp:120
+    if (kf) {
+        SVO_CHECK_ARG(right != nullptr);
+        int rc;
+        const uint8_t *d = stage_image(v, right, mem, &rc);
+        if (rc || (rc = svo_build_pyramid_from_device(v->ctx, v->pyr_right, d)))
+            return rc;
+        double Rt[12];
+        for (int i = 0; i < 3; i++) {
+            Rt[4 * i] = R9[3 * i];
+            Rt[4 * i + 1] = R9[3 * i + 1];
+            Rt[4 * i + 2] = R9[3 * i + 2];
+            Rt[4 * i + 3] = t3[i];
+        }
+        // insertKeyFrames (src/keyFrameManagement.cpp:9-31): re-triangulate at the current frame
+        if ((rc = stereo_triangulate(v, v->pyr_cur, v->pyr_right, Rt, v->ref2d, v->ref3d, &v->nref)))
+            return rc;
+    } else {  // src/VisualSLAM.cpp:143-146: carry the tracked sets forward
+        std::swap(v->ref2d, v->trk2d);
+        std::swap(v->ref3d, v->trk3d);
+        v->nref = v->ntrk;
+    }
+    std::swap(v->pyr_ref, v->pyr_cur);  // referenceImg = currentImage (src/VisualSLAM.cpp:151)
+    v->has_cur = false;
+    if (was_keyframe)
+        *was_keyframe = kf ? 1 : 0;
+    return SVO_OK;
+}
+
+int svo_vo_track(svo_vo *v, const uint8_t *left, const uint8_t *right, int mem, int force_keyframe, double *R9,
+                 double *t3, int *n_inliers, int *was_keyframe, int *n_tracked)
+{
+    int ninl = 0;
+    int rc = svo_vo_localize(v, left, mem, R9, t3, &ninl, n_tracked);
+    if (n_inliers)
+        *n_inliers = ninl;
+    if (rc)
+        return rc;
+    return svo_vo_update(v, right, mem, R9, t3, ninl, force_keyframe, was_keyframe);
+}
+
+int svo_vo_get_reference(svo_vo *v, float *ref2d, float *ref3d, int cap, int *n, int mem)
+{
+    SVO_CHECK_ARG(v && n);
+    *n = v->nref;
+    if (cap < v->nref) {
+        svo_set_error("reference set has %d points, capacity %d", v->nref, cap);
+        return SVO_ERR_CAPACITY;
+    }
+    const hipMemcpyKind kind = mem == SVO_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    if (ref2d)
+        SVO_HIP(hipMemcpyAsync(ref2d, v->ref2d, (size_t)v->nref * 8, kind, v->ctx->stream));
+    if (ref3d)
+        SVO_HIP(hipMemcpyAsync(ref3d, v->ref3d, (size_t)v->nref * 12, kind, v->ctx->stream));
+    SVO_HIP(hipStreamSynchronize(v->ctx->stream));
+    return SVO_OK;
+}
+
+int svo_vo_capacity(const svo_vo *v) { return v ? v->cap : 0; }
+
+}  // extern "C"

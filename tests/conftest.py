@@ -25,6 +25,11 @@ def orc():
 @pytest.fixture(scope="session")
 def ctx():
     """A libsvo_hip context on device 0.  GPU tests only; fails loudly without the library."""
+    # torch ships its own HIP runtime: let it load first (as bench.py does) so that one copy
+    # serves both torch and libsvo_hip in this process
+    import torch
+
+    torch.cuda.is_available()
     from ros_stereo_slam_amd import capi
 
     c = capi.Context(0)
