@@ -2,12 +2,17 @@
 """bench.py -- stereo frames/s of the MI355X front-end on a synthetic 1241x376 stream.
 
 Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` prints ONE JSON line on
-rank 0.  A step is one pass of the hot path over one frame (inputs already resident in
-HBM): pyramid of the new left image + pyramidal LK of 4096 keypoints from the previous
-frame (+ the stages the front-end has grown, see ``config.stages``).  For N > 1 the driver
-launches one rank per GPU (torch.distributed, backend nccl == RCCL); every rank processes
-its own contiguous chunk of the stream (weak scaling, no data-path collective; the only
-exchange is the all-gather of chunk-boundary poses).
+rank 0.  A step is one pass of the hot path over one stereo frame whose images are already
+resident in HBM: pyramid of the new left image, pyramidal LK of the reference keypoints,
+F-matrix RANSAC, PnP-RANSAC + refinement, pose composition, keyframe rule and -- when the
+rule fires -- the stereo keyframe path (right pyramid, grid + ANMS to 4096 keypoints, LK
+left->right, F-RANSAC, DLT triangulation, rigid transform).  That is BASELINE.json
+configs[1] ("front-end only, pose-graph off") on the synthetic stream of SURVEY.md 8d.
+
+For N > 1 the driver launches one rank per GPU (torch.distributed, backend nccl == RCCL).
+Every rank runs the front-end on its own contiguous chunk of the stream (weak scaling, no
+data-path collective); the one exchange step of the path is the all-gather of the
+chunk-boundary poses (12 doubles per rank) at the end of the timed region.
 """
 from __future__ import annotations
 
@@ -24,17 +29,26 @@ sys.path.insert(0, ROOT)
 
 W, H, C = 1241, 376, 3
 N_KPTS = 4096
-PYR_BYTES = 619930 * C  # sum of the 4 level sizes
+GRID_STEP = 10            # 4428 lattice points -> ANMS keeps 4096
+KF_MIN_INLIERS = 2000     # the reference's 200-of-440 rule scaled to 4096 keypoints
+PYR_BYTES = 619930 * C    # sum of the 4 level sizes
 
 
 def lk_algorithmic_bytes(n_pts: int) -> int:
-    """HBM bytes the LK kernel must move per launch: both pyramids once + 8 B in / 13 B out
-    per point (its share of SURVEY 8d's B_track = 3*pyr + 71*N)."""
+    """HBM bytes one LK launch must move: both pyramids once + 8 B in / 13 B out per point
+    (the LK share of SURVEY 8d's B_track = 3*pyr + 71*N)."""
     return 2 * PYR_BYTES + 21 * n_pts
 
 
-def frame_algorithmic_bytes(n_pts: int) -> int:
-    return 3 * PYR_BYTES + 71 * n_pts
+def frame_algorithmic_bytes(n_pts: int, keyframe_rate: float) -> float:
+    return 3 * PYR_BYTES + 71 * n_pts + keyframe_rate * (3 * PYR_BYTES + 102 * n_pts)
+
+
+def pingpong(i: int, n: int) -> int:
+    """0,1,..,n-1,n-2,..,1,0,1,.. : a temporally continuous walk over n resident frames."""
+    p = 2 * (n - 1)
+    k = i % p
+    return k if k < n else p - k
 
 
 def main():
@@ -42,9 +56,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--frames", type=int, default=6, help="distinct synthetic frames kept in HBM")
+    ap.add_argument("--frames", type=int, default=6, help="distinct synthetic stereo frames kept in HBM per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=12)
+    ap.add_argument("--cpu-frames", type=int, default=24)
     args = ap.parse_args()
 
     import torch
@@ -66,30 +80,32 @@ def main():
 
     ctx = capi.Context(local_rank)
     scene = synth.Scene()
-    # every rank renders its own chunk of the stream (contiguous frames, offset by rank)
+    # every rank renders its own contiguous chunk of the stream
     poses = synth.corridor_trajectory(args.frames * world)[rank * args.frames:(rank + 1) * args.frames]
-    host_frames = [scene.render(R, t)[0] for (R, t) in poses]
-    dev_frames = [torch.from_numpy(f).cuda() for f in host_frames]
-
-    grid = ctx.grid_keypoints(H, W, 10)  # 4428 lattice points
-    pts_host = np.ascontiguousarray(grid[:N_KPTS])
-    n = pts_host.shape[0]
-    d_pts = torch.from_numpy(pts_host).cuda()
-    d_out = torch.empty_like(d_pts)
-    d_status = torch.empty(n, dtype=torch.uint8, device="cuda")
-    d_err = torch.empty(n, dtype=torch.float32, device="cuda")
-    pyr = [ctx.pyramid(W, H, C), ctx.pyramid(W, H, C)]
-    pyr[0].build(dev_frames[0], capi.MEM_DEVICE)
+    host_frames = [scene.stereo(R, t)[:2] for (R, t) in poses]
+    dev_frames = [(torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()) for l, r in host_frames]
     torch.cuda.synchronize()
-    ctx.sync()
 
-    def step(i: int):
-        cur, prev = pyr[(i + 1) & 1], pyr[i & 1]
-        cur.build(dev_frames[(i + 1) % args.frames], capi.MEM_DEVICE)
-        ctx.lk_track_device(prev, cur, d_pts, n, d_out, d_status, d_err)
+    vo = capi.VisualOdometry(ctx, W, H, C, grid_step=GRID_STEP, anms_keep=N_KPTS,
+                             keyframe_min_inliers=KF_MIN_INLIERS, seed=20261003)
+    n0 = vo.init(*dev_frames[0])
+
+    stats = {"keyframes": 0, "inliers": 0, "tracked": 0, "lost": 0}
+
+    def step(i: int, record: bool):
+        l, r = dev_frames[pingpong(i + 1, args.frames)]
+        rc, R, t, ninl, kf, ntrk = vo.track(l, r)
+        if rc:
+            stats["lost"] += 1
+            vo.init(l, r)  # re-seed (the reference would shut down; a throughput run carries on)
+        if record:
+            stats["keyframes"] += int(kf)
+            stats["inliers"] += ninl
+            stats["tracked"] += ntrk
+        return R, t
 
     for i in range(args.warmup):
-        step(i)
+        step(i, False)
     ctx.sync()
     ctx.enable_kernel_timing(True)
     ctx.reset_kernel_time()
@@ -98,15 +114,23 @@ def main():
     torch.cuda.synchronize()
     ctx.sync()
     t0 = time.perf_counter()
+    R = t = None
     for i in range(args.steps):
-        step(args.warmup + i)
+        R, t = step(args.warmup + i, True)
+    if dist is not None:
+        # the path's one exchange: chunk-boundary poses, 12 doubles per rank, over RCCL
+        mine = torch.tensor(np.r_[R.ravel(), t], dtype=torch.float64, device="cuda")
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
     ctx.sync()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    lk_ms, lk_launches = ctx.kernel_time(capi.K_LK)
+    times = {name: ctx.kernel_time(kid) for name, kid in
+             (("pyramid", capi.K_PYRAMID), ("lk", capi.K_LK), ("fransac", capi.K_FRANSAC),
+              ("triangulate", capi.K_TRIANGULATE), ("pnp", capi.K_PNP), ("anms", capi.K_ANMS))}
     ctx.enable_kernel_timing(False)
 
     if dist is not None:
@@ -114,12 +138,12 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    tracked = int(d_status.sum().item())
-    result = None
     if rank == 0:
         fps = world * args.steps / elapsed
+        lk_ms, lk_launches = times["lk"]
         lk_avg_s = lk_ms / max(lk_launches, 1) * 1e-3
-        achieved = lk_algorithmic_bytes(n) / lk_avg_s / 1e9 if lk_avg_s > 0 else 0.0
+        achieved = lk_algorithmic_bytes(N_KPTS) / lk_avg_s / 1e9 if lk_avg_s > 0 else 0.0
+        kf_rate = stats["keyframes"] / args.steps
         result = {
             "metric": "stereo frames/sec @1241x376, 4096 kpts",
             "value": fps,
@@ -131,14 +155,20 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u8/i32 fixed-point + f32",
+            "dtype": "u8/i32 fixed-point (LK) + f32/f64 (geometry)",
             "data": "synthetic",
             "config": {
-                "workload": "synthetic corridor 1241x376x3 stream, 4096 grid keypoints/frame, front-end "
-                            "(BASELINE configs[1] shape)",
-                "stages": ["pyramid", "lk_t-1_to_t"],
-                "parallelism": f"chunk-per-gpu x{world}",
-                "tracked_last_frame": tracked,
+                "workload": "synthetic corridor 1241x376x3 stereo stream, grid step 10 -> ANMS 4096 keypoints, "
+                            "front-end only (BASELINE configs[1]): pyramid + LK + F-RANSAC + PnP-RANSAC + "
+                            "keyframe path (LK L->R, F-RANSAC, DLT triangulation)",
+                "keyframe_min_inliers": KF_MIN_INLIERS,
+                "parallelism": f"one contiguous chunk per GPU x{world}, all-gather of chunk-boundary poses",
+                "keyframe_rate": kf_rate,
+                "mean_tracked": stats["tracked"] / args.steps,
+                "mean_pnp_inliers": stats["inliers"] / args.steps,
+                "tracking_lost": stats["lost"],
+                "init_points": n0,
+                "stage_ms_per_step": {k: v[0] / args.steps for k, v in times.items()},
             },
             "roofline": {
                 "kernel": "lk_track_kernel<3>",
@@ -149,27 +179,36 @@ def main():
                 "frac": achieved / 8000.0,
                 "traffic": None,
                 "avg_launch_us": lk_avg_s * 1e6,
-                "algorithmic_bytes_per_launch": lk_algorithmic_bytes(n),
-                "frame_hbm_frac": frame_algorithmic_bytes(n) / (elapsed / args.steps) / 8e12,
+                "launches_per_step": lk_launches / args.steps,
+                "algorithmic_bytes_per_launch": lk_algorithmic_bytes(N_KPTS),
+                "frame_hbm_frac": frame_algorithmic_bytes(N_KPTS, kf_rate) / (elapsed / args.steps) / 8e12,
             },
         }
         if not args.no_cpu_baseline and world == 1:
             from oracle import orc  # the checker, timed as the CPU baseline ("port")
 
-            t0 = time.perf_counter()
+            o = orc.VO(W, H, C, grid_step=GRID_STEP, anms_keep=N_KPTS, keyframe_min_inliers=KF_MIN_INLIERS,
+                       seed=20261003)
+            o.init(*host_frames[0])
+            c0 = time.perf_counter()
             for i in range(args.cpu_frames):
-                orc.lk_track(host_frames[i % args.frames], host_frames[(i + 1) % args.frames], pts_host)
-            dt = time.perf_counter() - t0
+                l, r = host_frames[pingpong(i + 1, args.frames)]
+                rc = o.track(l, r)[0]
+                if rc:
+                    o.init(l, r)
+            dt = time.perf_counter() - c0
             result["cpu_baseline"] = {
                 "value": args.cpu_frames / dt,
                 "unit": "frames/s",
                 "cores": 1,
                 "kind": "port",
-                "sample": f"{args.cpu_frames} frames of the same stream, same stages, oracle C -O2, 1 thread",
+                "sample": f"{args.cpu_frames} frames of the same stream and stages, oracle C (-O2), 1 thread",
             }
         print(json.dumps(result))
     if dist is not None:
         dist.destroy_process_group()
+    vo.close()
+    ctx.close()
 
 
 if __name__ == "__main__":

@@ -6,9 +6,8 @@
 // largest radius, in response order.  The reference's grid keypoints carry response 0
 // (src/tracking.cpp:8), so the caller supplies one (the level-0 LK minimum eigenvalue).
 //
-// N is a few thousand: every step is an all-pairs pass with the compared array staged in
-// LDS (a rank-by-counting sort, the radius scan, a rank-by-counting selection), one thread
-// per keypoint.  Ties in response keep input order (std::sort is unstable upstream);
+// N is a few thousand: every step is an all-pairs pass (a rank-by-counting sort, the radius
+// scan, a rank-by-counting selection), one WAVEFRONT per keypoint.  Ties in response keep input order (std::sort is unstable upstream);
 // N <= numToKeep returns everything (the reference reads out of bounds at N == numToKeep).
 #include <cfloat>
 
@@ -16,96 +15,100 @@
 
 namespace {
 
-constexpr int CHUNK = 2048;  // keypoints staged in LDS per pass
-
-// rank[i] = number of keypoints that sort before i (response descending, index ascending)
-__global__ __launch_bounds__(256) void anms_rank_kernel(const float *__restrict__ resp, int n, int *__restrict__ order)
+// exact wave-wide integer sum (per-lane values < 2^24)
+__device__ __forceinline__ int wave_sum_int(int v)
 {
-    __shared__ float s_r[CHUNK];
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const float ri = i < n ? resp[i] : 0.f;
-    int rank = 0;
-    for (int base = 0; base < n; base += CHUNK) {
-        const int cnt = min(CHUNK, n - base);
-        __syncthreads();
-        for (int k = threadIdx.x; k < cnt; k += 256)
-            s_r[k] = resp[base + k];
-        __syncthreads();
-        if (i < n)
-            for (int k = 0; k < cnt; k++) {
-                const float rj = s_r[k];
-                const int j = base + k;
-                rank += (rj > ri || (rj == ri && j < i)) ? 1 : 0;
-            }
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);  // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);  // row_mirror
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) +
+           __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+}
+
+// One WAVEFRONT per keypoint in every all-pairs pass: the 64 lanes stride over the other
+// keypoints (coalesced reads of a 17-50 KB array that stays in L2) and the per-lane partials
+// are combined with DPP / shuffles.  N waves instead of N/64 keep all 256 CUs busy.
+
+// order[rank] = i, rank = #keypoints sorting before i (response descending, index ascending);
+// also emits the sorted (x, y, response) triples the radius pass streams through.
+__global__ __launch_bounds__(256) void anms_rank_kernel(const float2 *__restrict__ xy, const float *__restrict__ resp,
+                                                        int n, int *__restrict__ order, float4 *__restrict__ sorted)
+{
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n)
+        return;
+    const float ri = resp[i];
+    int cnt = 0;
+    for (int j = lane; j < n; j += 64) {
+        const float rj = resp[j];
+        cnt += (rj > ri || (rj == ri && j < i)) ? 1 : 0;
     }
-    if (i < n)
-        order[rank] = i;  // order[s] = input index of the s-th keypoint in sorted order
+    const int rank = wave_sum_int(cnt);
+    if (lane == 0) {
+        order[rank] = i;
+        const float2 p = xy[i];
+        sorted[rank] = make_float4(p.x, p.y, ri, 0.f);
+    }
 }
 
 // squared suppression radius of the s-th sorted keypoint (DBL_MAX when nothing dominates it)
-__global__ __launch_bounds__(256) void anms_radius_kernel(const float2 *__restrict__ xy, const float *__restrict__ resp,
-                                                          const int *__restrict__ order, int n,
+__global__ __launch_bounds__(256) void anms_radius_kernel(const float4 *__restrict__ sorted, int n,
                                                           double *__restrict__ radius_sq)
 {
-    __shared__ float s_x[CHUNK], s_y[CHUNK], s_r[CHUNK];
-    const int s = blockIdx.x * 256 + threadIdx.x;
-    float xi = 0, yi = 0, thr = 0;
-    if (s < n) {
-        const int i = order[s];
-        xi = xy[i].x;
-        yi = xy[i].y;
-        thr = resp[i] * 1.11f;
-    }
+    const int lane = threadIdx.x & 63;
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= n)
+        return;
+    const float4 me = sorted[s];
+    const float thr = me.z * 1.11f;
     double best = DBL_MAX;
-    // only sorted positions j < s can dominate; blocks never need chunks past their last s
-    const int limit = min(n, (int)(blockIdx.x * 256 + 256));
-    for (int base = 0; base < limit; base += CHUNK) {
-        const int cnt = min(CHUNK, limit - base);
-        __syncthreads();
-        for (int k = threadIdx.x; k < cnt; k += 256) {
-            const int j = order[base + k];
-            s_x[k] = xy[j].x;
-            s_y[k] = xy[j].y;
-            s_r[k] = resp[j];
-        }
-        __syncthreads();
-        if (s < n)
-            for (int k = 0; k < cnt && base + k < s; k++) {
-                if (!(s_r[k] > thr))
-                    break;  // sorted by response: nothing later dominates either
-                const float dx = xi - s_x[k], dy = yi - s_y[k];
+    for (int j0 = 0; j0 < s; j0 += 64) {
+        const int j = j0 + lane;
+        bool dom = false;
+        if (j < s) {
+            const float4 o = sorted[j];
+            dom = o.z > thr;
+            if (dom) {
+                const float dx = me.x - o.x, dy = me.y - o.y;
                 const double d = (double)dx * dx + (double)dy * dy;
                 best = d < best ? d : best;
             }
+        }
+        // sorted by response: once a whole stripe fails, nothing later dominates either
+        if (!__any(dom))
+            break;
     }
-    if (s < n)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double o = __shfl_xor(best, off);
+        best = o < best ? o : best;
+    }
+    if (lane == 0)
         radius_sq[s] = best;
 }
 
-// decision radius = the (keep+1)-th largest radius; flags[s] = radius[s] >= decision
+// decision radius = the (keep+1)-th largest radius
 __global__ __launch_bounds__(256) void anms_decide_kernel(const double *__restrict__ radius_sq, int n, int keep,
-                                                          uint8_t *__restrict__ flags, double *__restrict__ decision)
+                                                          double *__restrict__ decision)
 {
-    __shared__ double s_v[CHUNK];
-    const int s = blockIdx.x * 256 + threadIdx.x;
-    const double ri = s < n ? radius_sq[s] : 0.;
+    const int lane = threadIdx.x & 63;
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (s >= n)
+        return;
+    const double ri = radius_sq[s];
     int gt = 0, ge = 0;
-    for (int base = 0; base < n; base += CHUNK) {
-        const int cnt = min(CHUNK, n - base);
-        __syncthreads();
-        for (int k = threadIdx.x; k < cnt; k += 256)
-            s_v[k] = radius_sq[base + k];
-        __syncthreads();
-        if (s < n)
-            for (int k = 0; k < cnt; k++) {
-                gt += s_v[k] > ri ? 1 : 0;
-                ge += s_v[k] >= ri ? 1 : 0;
-            }
+    for (int j = lane; j < n; j += 64) {
+        const double rj = radius_sq[j];
+        gt += rj > ri ? 1 : 0;
+        ge += rj >= ri ? 1 : 0;
     }
+    gt = wave_sum_int(gt);
+    ge = wave_sum_int(ge);
     // radiiSorted[keep] (descending, 0-based) == ri  <=>  gt <= keep < ge
-    if (s < n && gt <= keep && keep < ge)
-        *decision = ri;  // every thread that qualifies writes the same value
-    (void)flags;
+    if (lane == 0 && gt <= keep && keep < ge)
+        *decision = ri;  // every wave that qualifies writes the same value
 }
 
 __global__ __launch_bounds__(256) void anms_flag_kernel(const double *__restrict__ radius_sq, int n,
@@ -150,7 +153,7 @@ __global__ void set_int_kernel(int *p, int v) { *p = v; }
 }  // namespace
 
 // Device form.  out_idx: n ints (input indices of the kept keypoints, response order);
-// d_count: device int.  Uses ctx->w_a..w_c as scratch.
+// d_count: device int.  Uses ctx->w_a..w_d as scratch.
 int svo_launch_anms(svo_ctx *ctx, const float *xy, const float *resp, int n, int keep, int *out_idx, int *d_count)
 {
     if (n <= 0)
@@ -158,14 +161,16 @@ int svo_launch_anms(svo_ctx *ctx, const float *xy, const float *resp, int n, int
     ScopedKernelTime tm(ctx, SVO_K_ANMS);
     int rc;
     if ((rc = ctx->w_a.ensure((size_t)n * 4)) || (rc = ctx->w_b.ensure((size_t)n * 8 + 64)) ||
-        (rc = ctx->w_c.ensure((size_t)n)))
+        (rc = ctx->w_c.ensure((size_t)n)) || (rc = ctx->w_d.ensure((size_t)n * 16)))
         return rc;
     int *order = ctx->w_a.as<int>();
     double *radius = ctx->w_b.as<double>();
     double *decision = radius + n;
     uint8_t *flags = ctx->w_c.as<uint8_t>();
-    const dim3 grid((n + 255) / 256), block(256);
-    hipLaunchKernelGGL(anms_rank_kernel, grid, block, 0, ctx->stream, resp, n, order);
+    float4 *sorted = ctx->w_d.as<float4>();
+    const dim3 wgrid((n + 3) / 4), tgrid((n + 255) / 256), block(256);
+    hipLaunchKernelGGL(anms_rank_kernel, wgrid, block, 0, ctx->stream, reinterpret_cast<const float2 *>(xy), resp, n,
+                       order, sorted);
     if (n <= keep) {
         // everything is kept, in sorted order
         SVO_HIP(hipMemcpyAsync(out_idx, order, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
@@ -173,10 +178,9 @@ int svo_launch_anms(svo_ctx *ctx, const float *xy, const float *resp, int n, int
         SVO_HIP(hipGetLastError());
         return SVO_OK;
     }
-    hipLaunchKernelGGL(anms_radius_kernel, grid, block, 0, ctx->stream, reinterpret_cast<const float2 *>(xy), resp,
-                       order, n, radius);
-    hipLaunchKernelGGL(anms_decide_kernel, grid, block, 0, ctx->stream, radius, n, keep, flags, decision);
-    hipLaunchKernelGGL(anms_flag_kernel, grid, block, 0, ctx->stream, radius, n, decision, flags);
+    hipLaunchKernelGGL(anms_radius_kernel, wgrid, block, 0, ctx->stream, sorted, n, radius);
+    hipLaunchKernelGGL(anms_decide_kernel, wgrid, block, 0, ctx->stream, radius, n, keep, decision);
+    hipLaunchKernelGGL(anms_flag_kernel, tgrid, block, 0, ctx->stream, radius, n, decision, flags);
     hipLaunchKernelGGL(anms_gather_kernel, dim3(1), dim3(1024), 0, ctx->stream, flags, order, n, out_idx, d_count);
     SVO_HIP(hipGetLastError());
     return SVO_OK;

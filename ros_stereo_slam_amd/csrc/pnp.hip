@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256) void pnp_solve_kernel(const float *__restrict_
         S.A3[lane] = s;
     }
     wave_lds_fence();
-    wave_jacobi_eigen_sym(3, S.A3, S.V3, S.cs, S.pq, 10, lane);
+    wave_jacobi_eigen_sym(3, S.A3, S.V3, S.cs, S.pq, 6, lane);
     {
         const double wc[3] = {S.A3[0], S.A3[4], S.A3[8]};
         int o0 = 0, o1 = 1, o2 = 2;  // descending eigenvalue, same comparison order as the oracle
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(256) void pnp_solve_kernel(const float *__restrict_
         S.A[e] = s;
     }
     wave_lds_fence();
-    wave_jacobi_eigen_sym(12, S.A, S.V, S.cs, S.pq, 12, lane);
+    wave_jacobi_eigen_sym(12, S.A, S.V, S.cs, S.pq, 8, lane);  // quadratic convergence: 8 sweeps reach 1e-16
     // ---- the four smallest eigenvalues, ascending (ties: lower index first) ----
     {
         int sel[4];
@@ -899,27 +899,32 @@ __device__ bool chol6_solve(const double *Ain, const double *b, double *x)
     return true;
 }
 
-constexpr int NACC = 28;  // 21 upper-triangular J^T J + 6 J^T r + 1 squared error
+constexpr int NACC = 28;  // [0] squared error, [1..21] upper-triangular J^T J, [22..27] J^T r
 
-// Fixed-order block reduction of NV doubles per thread (256 threads): shuffle tree inside
-// each wave, then lane 0 of every wave to LDS, then thread 0 adds the four partials.
-template <int NV> __device__ void block_reduce(double (&v)[NV], double *s_part /*4*NV*/, double *s_out /*NV*/)
+// Fixed-order block reduction of the first NV of a thread's accumulators (256 threads):
+// every thread parks its partials in LDS ([value][thread], rows padded against bank
+// conflicts), thread (w*NV + k) adds the 64 partials of wave w for value k in lane order, and
+// thread k adds the four wave totals.  The order never changes, so results are reproducible.
+constexpr int RED_STRIDE = 257;
+template <int NV> __device__ void block_reduce(const double *v, double *s_all /*NACC*RED_STRIDE*/,
+                                               double *s_part /*4*NACC*/, double *s_out /*NACC*/)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tid = threadIdx.x;
 #pragma unroll
-    for (int k = 0; k < NV; k++) {
-        double x = v[k];
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1)
-            x += __shfl_down(x, off);
-        if (lane == 0)
-            s_part[wave * NV + k] = x;
+    for (int k = 0; k < NV; k++)
+        s_all[k * RED_STRIDE + tid] = v[k];
+    __syncthreads();
+    if (tid < 4 * NV) {
+        const int w = tid / NV, k = tid - w * NV;
+        const double *src = s_all + k * RED_STRIDE + w * 64;
+        double x = 0;
+        for (int j = 0; j < 64; j++)
+            x += src[j];
+        s_part[w * NV + k] = x;
     }
     __syncthreads();
-    if (threadIdx.x < NV) {
-        const int k = threadIdx.x;
-        s_out[k] = ((s_part[k] + s_part[NV + k]) + s_part[2 * NV + k]) + s_part[3 * NV + k];
-    }
+    if (tid < NV)
+        s_out[tid] = ((s_part[tid] + s_part[NV + tid]) + s_part[2 * NV + tid]) + s_part[3 * NV + tid];
     __syncthreads();
 }
 
@@ -936,14 +941,14 @@ __device__ __forceinline__ void pnp_point_terms(const float *__restrict__ obj, c
     const double u = K.fx * Xc * iz + K.cx, v = K.fy * Yc * iz + K.cy;
     const float2 o = img[i];
     const double ru = u - o.x, rv = v - o.y;
-    acc[27] += ru * ru + rv * rv;
+    acc[0] += ru * ru + rv * rv;
     if (!with_jac)
         return;
     const double a0 = K.fx * iz, a2 = -K.fx * Xc * iz * iz;
     const double b1 = K.fy * iz, b2 = -K.fy * Yc * iz * iz;
     const double Ju[6] = {a2 * ry, a0 * rz - a2 * rx, -a0 * ry, a0, 0, a2};
     const double Jv[6] = {-b1 * rz + b2 * ry, -b2 * rx, b1 * rx, 0, b1, b2};
-    int k = 0;
+    int k = 1;
 #pragma unroll
     for (int p = 0; p < 6; p++) {
 #pragma unroll
@@ -952,7 +957,7 @@ __device__ __forceinline__ void pnp_point_terms(const float *__restrict__ obj, c
     }
 #pragma unroll
     for (int p = 0; p < 6; p++)
-        acc[21 + p] += Ju[p] * ru + Jv[p] * rv;
+        acc[22 + p] += Ju[p] * ru + Jv[p] * rv;
 }
 
 struct PnpResult {      // what the host reads back after a localisation
@@ -968,7 +973,7 @@ __global__ __launch_bounds__(256) void pnp_refine_kernel(const float *__restrict
                                                          const double *__restrict__ hyp, int max_iters,
                                                          PnpResult *__restrict__ out)
 {
-    __shared__ double s_part[4 * NACC], s_sum[NACC], s_pose[12], s_trial[12];
+    __shared__ double s_all[NACC * RED_STRIDE], s_part[4 * NACC], s_sum[NACC], s_pose[12], s_trial[12];
     __shared__ int s_flag;
     const int tid = threadIdx.x;
     const RansacState s = *st;
@@ -992,13 +997,16 @@ __global__ __launch_bounds__(256) void pnp_refine_kernel(const float *__restrict
             acc[k] = 0;
         for (int e = tid; e < m; e += 256)
             pnp_point_terms(obj, img, inl[e], K, pose, pose + 9, jac, acc);
-        block_reduce<NACC>(acc, s_part, s_sum);
+        if (jac)
+            block_reduce<NACC>(acc, s_all, s_part, s_sum);
+        else
+            block_reduce<1>(acc, s_all, s_part, s_sum);  // the trial pass only needs the error
     };
     accumulate(s_pose, true);
-    double err = s_sum[27], lambda = 1e-3;
+    double err = s_sum[0], lambda = 1e-3;
     double JtJ[36], Jtr[6];
     auto unpack = [&]() {
-        int k = 0;
+        int k = 1;
         for (int p = 0; p < 6; p++)
             for (int q = p; q < 6; q++) {
                 JtJ[6 * p + q] = s_sum[k];
@@ -1006,7 +1014,7 @@ __global__ __launch_bounds__(256) void pnp_refine_kernel(const float *__restrict
                 k++;
             }
         for (int p = 0; p < 6; p++)
-            Jtr[p] = s_sum[21 + p];
+            Jtr[p] = s_sum[22 + p];
     };
     unpack();
     for (int it = 0; it < max_iters; it++) {
@@ -1047,7 +1055,7 @@ __global__ __launch_bounds__(256) void pnp_refine_kernel(const float *__restrict
         const double step = s_part[0];
         __syncthreads();
         accumulate(s_trial, false);
-        const double e2 = s_sum[27];
+        const double e2 = s_sum[0];
         if (e2 < err || !(err == err)) {
             __syncthreads();
             if (tid < 12)
@@ -1055,7 +1063,7 @@ __global__ __launch_bounds__(256) void pnp_refine_kernel(const float *__restrict
             __syncthreads();
             const double prev = err;
             accumulate(s_pose, true);
-            err = s_sum[27];
+            err = s_sum[0];
             unpack();
             lambda *= 0.1;
             if (lambda < 1e-12)
