@@ -62,6 +62,7 @@ enum {
 typedef struct svo_ctx svo_ctx;
 typedef struct svo_pyramid svo_pyramid;
 typedef struct svo_vo svo_vo;
+typedef struct svo_posegraph svo_posegraph;
 
 int svo_version(void);
 const char *svo_last_error(void);
@@ -187,6 +188,31 @@ int svo_vo_track(svo_vo *vo, const uint8_t *left, const uint8_t *right, int mem,
 /* the current reference point set (2-D in the reference image, 3-D world) */
 int svo_vo_get_reference(svo_vo *vo, float *ref2d, float *ref3d, int cap, int *n, int mem);
 int svo_vo_capacity(const svo_vo *vo);
+
+/* ---- SE3 pose graph: globalPoseGraph, include/poseGraph.h:36-179 ------------------------------ */
+/* Poses are 7 doubles: tx ty tz qx qy qz qw (the VERTEX_SE3:QUAT order of g2o).  All pose and
+ * chi2 arrays of this group are HOST memory: the graph is built on the host one vertex per frame
+ * (src/optimizationStuff.cpp:3-15) and optimised on the device.                                */
+int svo_pg_create(svo_ctx *ctx, svo_posegraph **out); /* includes initializeGraph()             */
+int svo_pg_destroy(svo_posegraph *pg);
+/* initializeGraph, poseGraph.h:69-84: vertex 0 = identity, fixed */
+int svo_pg_initialize(svo_posegraph *pg);
+/* augmentNode(localT, globalT), poseGraph.h:87-111: new vertex with estimate globalT and an edge
+ * from the previous vertex whose measurement is prev^-1 * cur of the CURRENT estimates (localT is
+ * never read by the reference and is not a parameter here) */
+int svo_pg_augment_node(svo_posegraph *pg, const double *pose7);
+/* addLoopClosure(T, fromID), poseGraph.h:113-126: edge(previous vertex -> vertex fromID) with
+ * IDENTITY measurement (T is unused by the reference) */
+int svo_pg_add_loop_closure(svo_posegraph *pg, int from_id);
+/* globalOptimize, poseGraph.h:128-138: `iters` Gauss-Newton iterations (the reference: 10).
+ * chi2 (optional, iters+1 doubles): the error before each iteration and after the last.        */
+int svo_pg_optimize(svo_posegraph *pg, int iters, double *chi2);
+int svo_pg_num_vertices(const svo_posegraph *pg);
+int svo_pg_num_edges(const svo_posegraph *pg);
+int svo_pg_get_estimates(const svo_posegraph *pg, double *pose7_out);
+int svo_pg_get_edge(const svo_posegraph *pg, int e, int *from, int *to, double *meas7);
+/* saveStructure, poseGraph.h:140-179: VERTEX_SE3:QUAT / EDGE_SE3:QUAT text */
+int svo_pg_write_g2o(const svo_posegraph *pg, const char *path);
 
 #ifdef __cplusplus
 }

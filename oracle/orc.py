@@ -309,3 +309,72 @@ class VO:
             self.close()
         except Exception:
             pass
+
+
+# ---- SE3 pose graph (include/poseGraph.h) -------------------------------------------------------
+def se3_edge_error(Xi, Xj, Z):
+    Xi, Xj, Z = (np.ascontiguousarray(a, np.float64) for a in (Xi, Xj, Z))
+    e, Ji, Jj = np.zeros(6), np.zeros((6, 6)), np.zeros((6, 6))
+    load().orc_se3_edge_error(_p(Xi), _p(Xj), _p(Z), _p(e), _p(Ji), _p(Jj))
+    return e, Ji, Jj
+
+
+def se3_oplus(X, v):
+    out = np.zeros(7)
+    load().orc_se3_oplus(_p(np.ascontiguousarray(X, np.float64)), _p(np.ascontiguousarray(v, np.float64)), _p(out))
+    return out
+
+
+class PoseGraph:
+    def __init__(self):
+        lib = load()
+        lib.orc_pg_create.restype = C.c_void_p
+        self.lib = lib
+        self._h = C.c_void_p(lib.orc_pg_create())
+        lib.orc_pg_initialize(self._h)
+
+    def augment_node(self, pose7):
+        self.lib.orc_pg_augment_node(self._h, _p(np.ascontiguousarray(pose7, np.float64)))
+
+    def add_loop_closure(self, from_id):
+        self.lib.orc_pg_add_loop_closure(self._h, int(from_id))
+
+    def optimize(self, iters=10):
+        chi2 = np.zeros(iters + 1)
+        self.lib.orc_pg_optimize(self._h, iters, _p(chi2))
+        return chi2
+
+    @property
+    def num_vertices(self):
+        return self.lib.orc_pg_num_vertices(self._h)
+
+    @property
+    def num_edges(self):
+        return self.lib.orc_pg_num_edges(self._h)
+
+    def estimates(self):
+        out = np.zeros((self.num_vertices, 7))
+        self.lib.orc_pg_get_estimates(self._h, _p(out))
+        return out
+
+    def edges(self):
+        res = []
+        for e in range(self.num_edges):
+            a, b, z = C.c_int(), C.c_int(), np.zeros(7)
+            self.lib.orc_pg_get_edge(self._h, e, C.byref(a), C.byref(b), _p(z))
+            res.append((a.value, b.value, z))
+        return res
+
+    def write_g2o(self, path):
+        return self.lib.orc_pg_write_g2o(self._h, os.fspath(path).encode())
+
+    def close(self):
+        if self._h:
+            self.lib.orc_pg_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -355,3 +355,60 @@ class VisualOdometry:
             self.close()
         except Exception:
             pass
+
+
+class PoseGraph:
+    """SE3 pose graph on the GPU (``svo_posegraph``), mirroring globalPoseGraph
+    (include/poseGraph.h:36-179).  Poses: tx ty tz qx qy qz qw."""
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        self._h = C.c_void_p()
+        _check(ctx.lib.svo_pg_create(ctx._h, C.byref(self._h)))
+        ctx._children.add(self)
+
+    def augment_node(self, pose7):
+        _check(self.ctx.lib.svo_pg_augment_node(self._h, _ptr(np.ascontiguousarray(pose7, np.float64))))
+
+    def add_loop_closure(self, from_id: int):
+        _check(self.ctx.lib.svo_pg_add_loop_closure(self._h, int(from_id)))
+
+    def optimize(self, iters: int = 10) -> np.ndarray:
+        chi2 = np.zeros(iters + 1)
+        _check(self.ctx.lib.svo_pg_optimize(self._h, iters, _ptr(chi2)))
+        return chi2
+
+    @property
+    def num_vertices(self) -> int:
+        return self.ctx.lib.svo_pg_num_vertices(self._h)
+
+    @property
+    def num_edges(self) -> int:
+        return self.ctx.lib.svo_pg_num_edges(self._h)
+
+    def estimates(self) -> np.ndarray:
+        out = np.zeros((self.num_vertices, 7))
+        _check(self.ctx.lib.svo_pg_get_estimates(self._h, _ptr(out)))
+        return out
+
+    def edges(self):
+        res = []
+        for e in range(self.num_edges):
+            a, b, z = C.c_int(), C.c_int(), np.zeros(7)
+            _check(self.ctx.lib.svo_pg_get_edge(self._h, e, C.byref(a), C.byref(b), _ptr(z)))
+            res.append((a.value, b.value, z))
+        return res
+
+    def write_g2o(self, path):
+        _check(self.ctx.lib.svo_pg_write_g2o(self._h, os.fspath(path).encode()))
+
+    def close(self):
+        if self._h and self.ctx._h:
+            self.ctx.lib.svo_pg_destroy(self._h)
+        self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
