@@ -119,9 +119,11 @@ def main():
         R, t = step(args.warmup + i, True)
     if dist is not None:
         # the path's one exchange: chunk-boundary poses, 12 doubles per rank, over RCCL
-        mine = torch.tensor(np.r_[R.ravel(), t], dtype=torch.float64, device="cuda")
-        gathered = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(gathered, mine)
+        from ros_stereo_slam_amd import chunked
+
+        boundaries = chunked.all_gather_boundaries(dist, R, t, device="cuda")
+        starts = chunked.prefix_transforms(boundaries)  # global pose of every chunk's first frame
+        assert len(starts) == world
     ctx.sync()
     torch.cuda.synchronize()
     if dist is not None:

@@ -1,0 +1,368 @@
+// svo_compat/visualSLAM.hpp -- the hot-path member surface of the reference's visualSLAM
+// class (include/visualSLAM.h:152-178) on top of the svo_* C ABI.
+//
+// Two levels, same results:
+//  * stage methods with the reference's names and argument meaning (denseKeypointExtractor,
+//    denseLKtracking, FmatThresholding, stereoTriangulate, PyrLKtrackFrame2Frame,
+//    insertKeyFrames, update3dtransformation, PerspectiveNpointEstimation, stageForPGO,
+//    updateOdometry).  Containers are the caller's, outputs are cleared and refilled through
+//    references, the side-channel members (colors, untransformed, inlierReferencePyrLKPts,
+//    refDrawPts, trackedDrawPts, referenceImg, currentImage, LC_FLAG, LCidx, cooldownTimer,
+//    SHUTDOWN_FLAG) behave as in the reference.  Each call stages its host containers
+//    through the device (like the reference, it rebuilds image pyramids per call).
+//  * processFrame(): the body of initSequence's loop (src/VisualSLAM.cpp:54-169) on the
+//    fused, device-resident front-end (svo_vo) + the device pose graph -- the fast path.
+// Not here (out of the hot path): ROS publishing, Pangolin viewer, PCL outlier removal,
+// DBoW2 loop detection (checkLoopDetectorStatus) -- their outputs (LC_FLAG, LCidx) are inputs.
+#pragma once
+
+#include <cstdio>
+
+#include "poseGraph.hpp"
+#include "types.hpp"
+
+namespace svo_compat {
+
+struct keyFrame {  // include/visualSLAM.h:47-54
+    int idx = -1;
+    bool retrack = false;
+    Mat33d R;
+    Vec3d t;
+    std::vector<Point3f> ref3dCoords;
+};
+
+class visualSLAM {
+  public:
+    // ---- public state of the reference (include/visualSLAM.h:66-113) ----
+    double baseline = 0.54;
+    int LCidx = 0;
+    int cooldownTimer = 0;
+    bool LC_FLAG = false;
+    bool SHUTDOWN_FLAG = false;
+    bool DENSE_FLAG = true;
+    double focal_x = 7.188560000000e+02, cx = 6.071928000000e+02;
+    double focal_y = 7.188560000000e+02, cy = 1.852157000000e+02;
+    int gridStep = 30;              // src/triangulation.cpp:89
+    int keyframeMinInliers = 200;   // src/VisualSLAM.cpp:120
+    uint64_t ransacSeed = 0;
+    Mat referenceImg, currentImage;
+    std::vector<Point3f> untransformed, colors;
+    std::vector<Point2f> refDrawPts, trackedDrawPts, inlierReferencePyrLKPts;
+    std::vector<std::vector<Point3f>> mapHistory, colorHistory;
+    std::vector<Vec3d> trajectory;
+    std::vector<keyFrame> keyFrameHistory;
+    std::vector<Isometry3d> isoVector;
+    globalPoseGraph poseGraph;
+
+    explicit visualSLAM(svo_ctx *ctx = nullptr) : poseGraph(ctx ? ctx : shared_context()), ctx_(ctx ? ctx : shared_context()) {}
+    ~visualSLAM()
+    {
+        if (vo_)
+            svo_vo_destroy(vo_);
+    }
+    visualSLAM(const visualSLAM &) = delete;
+    visualSLAM &operator=(const visualSLAM &) = delete;
+
+    // ---- src/tracking.cpp:4-12 ----
+    std::vector<KeyPoint> denseKeypointExtractor(const Mat &img, int stepSize)
+    {
+        int n = 0;
+        check(svo_grid_keypoints(ctx_, mat_rows(img), mat_cols(img), stepSize, nullptr, 0, SVO_MEM_HOST, &n));
+        std::vector<float> xy((size_t)n * 2);
+        check(svo_grid_keypoints(ctx_, mat_rows(img), mat_cols(img), stepSize, xy.data(), n, SVO_MEM_HOST, &n));
+        std::vector<KeyPoint> out;
+        out.reserve(n);
+        for (int i = 0; i < n; i++)
+            out.emplace_back(xy[2 * i], xy[2 * i + 1], (float)stepSize);
+        return out;
+    }
+
+    // ---- src/tracking.cpp:14-28 ----
+    void denseLKtracking(const Mat &refImg, const Mat &curImg, std::vector<Point2f> &refPts,
+                         std::vector<Point2f> &trackPts)
+    {
+        std::vector<Point2f> trk(refPts.size());
+        std::vector<uint8_t> status(refPts.size());
+        lk(refImg, curImg, refPts, trk, status);
+        compact2(status, refPts, trk);
+        trackPts = trk;
+    }
+
+    // ---- src/tracking.cpp:30-43: findFundamentalMat(..., CV_RANSAC, 3.0, 0.99, mask) ----
+    void FmatThresholding(std::vector<Point2f> &refPts, std::vector<Point2f> &trkPts)
+    {
+        std::vector<uint8_t> mask(refPts.size());
+        int cnt = 0;
+        check(svo_fransac(ctx_, f(refPts), f(trkPts), (int)refPts.size(), 3.0, 0.99, 1000, ransacSeed + 3, mask.data(),
+                          nullptr, &cnt, nullptr, SVO_MEM_HOST));
+        compact2(mask, refPts, trkPts);
+    }
+
+    // ---- src/triangulation.cpp:73-166 (dense branch) ----
+    void stereoTriangulate(const Mat &im1, const Mat &im2, std::vector<Point3f> &ref3dPts,
+                           std::vector<Point2f> &ref2dPts)
+    {
+        if (mat_data(im1) == nullptr || mat_data(im2) == nullptr) {
+            std::printf("NULL IMG\n");  // src/triangulation.cpp:81-84
+            return;
+        }
+        std::vector<KeyPoint> dkps = denseKeypointExtractor(im1, gridStep);
+        std::vector<Point2f> refPts, trkPts;
+        for (const KeyPoint &k : dkps)
+            refPts.emplace_back(k.pt);
+        denseLKtracking(im1, im2, refPts, trkPts);
+        FmatThresholding(refPts, trkPts);
+        // getColors (include/monoUtils.h:180-193)
+        svo_pyramid *p = nullptr;
+        check(svo_pyramid_create(ctx_, mat_cols(im1), mat_rows(im1), mat_channels(im1), 1, &p));
+        colors.assign(refPts.size(), Point3f());
+        int rc = svo_pyramid_build(ctx_, p, mat_data(im1), SVO_MEM_HOST);
+        if (rc == SVO_OK)
+            rc = svo_get_colors(ctx_, p, f(refPts), (int)refPts.size(), f3(colors), SVO_MEM_HOST);
+        svo_pyramid_destroy(ctx_, p);
+        check(rc);
+        double P1[12], P2[12];
+        check(svo_stereo_projections(focal_x, focal_y, cx, cy, baseline, P1, P2));
+        std::vector<Point3f> xyz(refPts.size());
+        check(svo_triangulate(ctx_, P1, P2, f(refPts), f(trkPts), (int)refPts.size(), f3(xyz), nullptr, SVO_MEM_HOST));
+        ref3dPts = xyz;
+        ref2dPts = refPts;
+    }
+
+    // ---- src/tracking.cpp:46-91 (refPts / ref3dpts by value, as upstream) ----
+    void PyrLKtrackFrame2Frame(const Mat &refimg, const Mat &curImg, std::vector<Point2f> refPts,
+                               std::vector<Point3f> ref3dpts, std::vector<Point2f> &refRetpts,
+                               std::vector<Point3f> &ref3dretPts)
+    {
+        std::vector<Point2f> trackPts(refPts.size());
+        std::vector<uint8_t> status(refPts.size());
+        lk(refimg, curImg, refPts, trackPts, status);
+        std::vector<Point2f> inlierRefPts, inlierTracked, finalInlierRef;
+        std::vector<Point3f> inlierRef3dPts;
+        for (size_t j = 0; j < refPts.size(); j++)
+            if (status[j] == 1) {
+                inlierRefPts.push_back(refPts[j]);
+                inlierRef3dPts.push_back(ref3dpts[j]);
+                inlierTracked.push_back(trackPts[j]);
+            }
+        std::vector<uint8_t> inIdx(inlierRefPts.size());
+        int cnt = 0;
+        check(svo_fransac(ctx_, f(inlierRefPts), f(inlierTracked), (int)inlierRefPts.size(), 1.0, 0.99, 1000,
+                          ransacSeed + 0, inIdx.data(), nullptr, &cnt, nullptr, SVO_MEM_HOST));
+        // the reference loops to refPts.size() here and reads past the compacted arrays
+        // (src/tracking.cpp:78); the mask length is what was meant
+        for (size_t j = 0; j < inIdx.size(); j++)
+            if (inIdx[j] == 1) {
+                finalInlierRef.push_back(inlierRefPts[j]);
+                ref3dretPts.push_back(inlierRef3dPts[j]);
+                refRetpts.push_back(inlierTracked[j]);
+            }
+        refDrawPts = finalInlierRef;
+        trackedDrawPts = refRetpts;
+        inlierReferencePyrLKPts = finalInlierRef;
+    }
+
+    // ---- src/keyFrameManagement.cpp:33-46 ----
+    std::vector<Point3f> update3dtransformation(std::vector<Point3f> &pt3d, const Mat34d &pose4dTransform)
+    {
+        std::vector<Point3f> out(pt3d.size());
+        check(svo_transform_points(ctx_, pose4dTransform.m, f3(pt3d), (int)pt3d.size(), f3(out), SVO_MEM_HOST));
+        return out;
+    }
+
+    // ---- src/keyFrameManagement.cpp:9-31 ----
+    void insertKeyFrames(int /*start*/, const Mat &imL, const Mat &imR, const Mat34d &pose4dTransform,
+                         std::vector<Point2f> &ftrPts, std::vector<Point3f> &ref3dCoords)
+    {
+        std::vector<Point2f> new2d;
+        std::vector<Point3f> new3d;
+        ftrPts.clear();
+        ref3dCoords.clear();
+        stereoTriangulate(imL, imR, new3d, new2d);
+        untransformed = new3d;
+        ref3dCoords = update3dtransformation(new3d, pose4dTransform);
+        ftrPts = new2d;
+    }
+
+    // ---- src/keyFrameManagement.cpp:73-94 (uses the members referenceImg / currentImage) ----
+    void PerspectiveNpointEstimation(Mat & /*prevImg*/, Mat & /*curImg*/, std::vector<Point2f> &ref2dPoints,
+                                     std::vector<Point3f> &ref3dPoints, std::vector<Point2f> &tracked2dPoints,
+                                     std::vector<Point3f> &tracked3dPoints, Vec3d &rvec, Vec3d &tvec,
+                                     std::vector<int> &inliers)
+    {
+        PyrLKtrackFrame2Frame(referenceImg, currentImage, ref2dPoints, ref3dPoints, tracked2dPoints, tracked3dPoints);
+        const double K4[4] = {focal_x, focal_y, cx, cy};
+        const int n = (int)tracked3dPoints.size();
+        int ninl = 0;
+        inliers.assign((size_t)(n > 0 ? n : 1), 0);
+        check(svo_pnp_ransac(ctx_, f3(tracked3dPoints), f(tracked2dPoints), n, K4, 100, 1.0, 0.99, ransacSeed + 1,
+                             rvec.v, tvec.v, inliers.data(), &ninl, nullptr, SVO_MEM_HOST));
+        if (ninl < 10) {
+            std::printf("Low inlier count at %d, trying again with increased reprojection Threshold \n", ninl);
+            check(svo_pnp_ransac(ctx_, f3(tracked3dPoints), f(tracked2dPoints), n, K4, 100, 8.0, 0.98, ransacSeed + 2,
+                                 rvec.v, tvec.v, inliers.data(), &ninl, nullptr, SVO_MEM_HOST));
+            if (ninl < 10)
+                SHUTDOWN_FLAG = true;  // src/keyFrameManagement.cpp:89-92
+        }
+        inliers.resize((size_t)ninl);
+    }
+
+    // ---- src/optimizationStuff.cpp:3-15 ----
+    void stageForPGO(const Mat33d & /*Rl*/, const Vec3d & /*tl*/, const Mat33d &Rg, const Vec3d &tg, bool loopClose)
+    {
+        const Isometry3d globalT = Isometry3d_from(Rg, tg);
+        if (loopClose) {
+            LC_FLAG = true;
+            poseGraph.addLoopClosure(globalT, LCidx);
+        } else {
+            poseGraph.augmentNode(globalT, globalT);
+        }
+    }
+
+    // ---- src/optimizationStuff.cpp:17-47 ----
+    void updateOdometry(std::vector<Isometry3d> &T)
+    {
+        trajectory.clear();
+        trajectory.reserve(T.size());
+        for (const Isometry3d &iso : T)
+            trajectory.push_back(translation_of(iso));
+        mapHistory.clear();
+        for (size_t j = 0; j < keyFrameHistory.size() && j < trajectory.size(); j++) {
+            keyFrame &kf = keyFrameHistory[j];
+            kf.t = trajectory[j];  // R keeps its un-optimised value, as upstream (:29-32)
+            Mat34d P = Mat34d::from(kf.R, kf.t);
+            std::vector<Point3f> upd = update3dtransformation(kf.ref3dCoords, P);
+            if (kf.retrack)
+                mapHistory.emplace_back(upd);
+        }
+    }
+
+    // ---- the loop body of initSequence (src/VisualSLAM.cpp:54-169) on the fused front-end ----
+    // First call = frame 0 (stereo init, src/VisualSLAM.cpp:22-41).  loopMatch >= 0 plays the role
+    // of DLoopDetector's result.match for this frame (src/optimizationStuff.cpp:59-63).
+    // Returns false when tracking is lost (SHUTDOWN_FLAG).
+    bool processFrame(const Mat &left, const Mat &right, int loopMatch, Mat33d &R, Vec3d &t)
+    {
+        if (!vo_) {
+            svo_vo_params p;
+            svo_vo_default_params(&p);
+            p.fx = focal_x;
+            p.fy = focal_y;
+            p.cx = cx;
+            p.cy = cy;
+            p.baseline = baseline;
+            p.grid_step = gridStep;
+            p.keyframe_min_inliers = keyframeMinInliers;
+            p.seed = ransacSeed;
+            check(svo_vo_create(ctx_, &p, mat_cols(left), mat_rows(left), mat_channels(left), &vo_));
+            int n = 0;
+            check(svo_vo_init(vo_, mat_data(left), mat_data(right), SVO_MEM_HOST, &n));
+            poseGraph.initializeGraph();
+            R = Mat33d();
+            t = Vec3d();
+            keyFrame kf;
+            kf.idx = 0;
+            keyFrameHistory.push_back(kf);
+            isoVector.push_back(Isometry3d_from(R, t));
+            frame_ = 0;
+            return true;
+        }
+        frame_++;
+        int ninl = 0, ntrk = 0;
+        int rc = svo_vo_localize(vo_, mat_data(left), SVO_MEM_HOST, R.m, t.v, &ninl, &ntrk);
+        if (rc == SVO_ERR_TRACKING_LOST) {
+            SHUTDOWN_FLAG = true;
+            return false;
+        }
+        check(rc);
+        // checkLoopDetectorStatus (src/optimizationStuff.cpp:59-63) with the supplied match
+        if (loopMatch >= 0 && (frame_ - loopMatch > 100) && cooldownTimer == 0) {
+            LC_FLAG = true;
+            LCidx = loopMatch - 1;
+            cooldownTimer = 100;
+        }
+        if (LC_FLAG) {  // src/VisualSLAM.cpp:76-86
+            stageForPGO(R, t, R, t, true);
+            stageForPGO(R, t, R, t, false);
+            std::vector<Isometry3d> trans = poseGraph.globalOptimize();
+            isoVector = trans;
+            t = translation_of(trans.back());  // only t is re-anchored, R keeps its value (:81-82)
+            updateOdometry(trans);
+        } else {
+            stageForPGO(R, t, R, t, false);
+        }
+        int kf = 0;
+        check(svo_vo_update(vo_, mat_data(right), SVO_MEM_HOST, R.m, t.v, ninl, LC_FLAG ? 1 : 0, &kf));
+        if (kf) {
+            isoVector.push_back(Isometry3d_from(R, t));
+            trajectory.push_back(t);
+        }
+        if (cooldownTimer != 0)
+            cooldownTimer--;
+        LC_FLAG = false;
+        keyFrame k;
+        k.idx = frame_;
+        k.R = R;
+        k.t = t;
+        k.retrack = kf != 0;
+        keyFrameHistory.push_back(k);
+        return true;
+    }
+
+  private:
+    static const float *f(const std::vector<Point2f> &v) { return reinterpret_cast<const float *>(v.data()); }
+    static float *f(std::vector<Point2f> &v) { return reinterpret_cast<float *>(v.data()); }
+    static const float *f3(const std::vector<Point3f> &v) { return reinterpret_cast<const float *>(v.data()); }
+    static float *f3(std::vector<Point3f> &v) { return reinterpret_cast<float *>(v.data()); }
+    static Isometry3d Isometry3d_from(const Mat33d &R, const Vec3d &t)
+    {
+        Isometry3d T = Isometry3d::Identity();
+        for (int i = 0; i < 3; i++) {
+            for (int j = 0; j < 3; j++)
+                T(i, j) = R(i, j);
+            T(i, 3) = t(i);
+        }
+        return T;
+    }
+    static Vec3d translation_of(const Isometry3d &T)
+    {
+        Vec3d t;
+        for (int i = 0; i < 3; i++)
+            t(i) = T(i, 3);
+        return t;
+    }
+    void lk(const Mat &a, const Mat &b, const std::vector<Point2f> &pts, std::vector<Point2f> &out,
+            std::vector<uint8_t> &status)
+    {
+        svo_pyramid *pa = nullptr, *pb = nullptr;
+        check(svo_pyramid_create(ctx_, mat_cols(a), mat_rows(a), mat_channels(a), 4, &pa));
+        int rc = svo_pyramid_create(ctx_, mat_cols(b), mat_rows(b), mat_channels(b), 4, &pb);
+        if (rc == SVO_OK)
+            rc = svo_pyramid_build(ctx_, pa, mat_data(a), SVO_MEM_HOST);
+        if (rc == SVO_OK)
+            rc = svo_pyramid_build(ctx_, pb, mat_data(b), SVO_MEM_HOST);
+        if (rc == SVO_OK)
+            rc = svo_lk_track(ctx_, pa, pb, f(pts), (int)pts.size(), f(out), status.data(), nullptr, nullptr,
+                              SVO_MEM_HOST);
+        svo_pyramid_destroy(ctx_, pa);
+        svo_pyramid_destroy(ctx_, pb);
+        check(rc);
+    }
+    void compact2(const std::vector<uint8_t> &mask, std::vector<Point2f> &a, std::vector<Point2f> &b)
+    {
+        std::vector<Point2f> oa(a.size()), ob(b.size());
+        int cnt = 0;
+        check(svo_compact(ctx_, mask.data(), (int)mask.size(), f(a), 2, f(oa), f(b), 2, f(ob), nullptr, 0, nullptr, &cnt,
+                          SVO_MEM_HOST));
+        oa.resize((size_t)cnt);
+        ob.resize((size_t)cnt);
+        a.swap(oa);
+        b.swap(ob);
+    }
+
+    svo_ctx *ctx_;
+    svo_vo *vo_ = nullptr;
+    int frame_ = 0;
+};
+
+}  // namespace svo_compat
