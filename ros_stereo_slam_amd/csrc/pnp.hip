@@ -107,7 +107,7 @@ __device__ void svd3(const double (&Ain)[9], double (&U)[9], double (&Vout)[9])
             A[i][j] = Ain[3 * i + j];
             V[i][j] = i == j ? 1. : 0.;
         }
-    for (int sweep = 0; sweep < 30; sweep++) {
+    for (int sweep = 0; sweep < 12; sweep++) {
         bool rotated = false;
 #pragma unroll
         for (int e = 0; e < 3; e++) {
@@ -195,12 +195,18 @@ __device__ void svd3(const double (&Ain)[9], double (&U)[9], double (&Vout)[9])
 // player).  Per round: lanes < m/2 compute their rotation, then all lanes apply the column
 // updates, then the row updates, then the eigenvector updates -- the exact order the CPU
 // oracle uses, so the two round identically.  A, V: row-major n x n; cs: 2*8 doubles; pq: 16 ints.
-__device__ void wave_jacobi_eigen_sym(int n, double *A, double *V, double *cs, int *pq, int sweeps, int lane)
+// n is a template parameter so the item -> (pair, index) maps divide by constants.
+template <int n>
+__device__ void wave_jacobi_eigen_sym(double *A, double *V, double *cs, int *pq, int sweeps, int lane)
 {
+    constexpr int m = n + (n & 1), half = m / 2, items = half * n;
     for (int i = lane; i < n * n; i += 64)
         V[i] = (i / n) == (i % n) ? 1. : 0.;
     wave_lds_fence();
-    const int m = n + (n & 1), half = m / 2;
+    // the (pair, index) items of this lane: item = lane (+64); constant divisors
+    const int e0 = lane / n, k0 = lane - e0 * n;
+    const int e1 = (lane + 64) / n, k1 = (lane + 64) - e1 * n;
+    const bool has0 = lane < items, has1 = lane + 64 < items;
     for (int s = 0; s < sweeps; s++)
         for (int r = 0; r < m - 1; r++) {
             if (lane < half) {
@@ -228,29 +234,38 @@ __device__ void wave_jacobi_eigen_sym(int n, double *A, double *V, double *cs, i
                 pq[2 * k + 1] = q;
             }
             wave_lds_fence();
-            for (int i = lane; i < half * n; i += 64) {  // columns p,q:  A <- A J
-                const int e = i / n, k = i - e * n;
-                const int p = pq[2 * e], q = pq[2 * e + 1];
-                if (p >= 0) {
-                    const double c = cs[2 * e], sn = cs[2 * e + 1];
-                    const double akp = A[k * n + p], akq = A[k * n + q];
-                    A[k * n + p] = c * akp - sn * akq;
-                    A[k * n + q] = sn * akp + c * akq;
-                }
+            const int p0 = has0 ? pq[2 * e0] : -1, q0 = has0 ? pq[2 * e0 + 1] : -1;
+            const int p1 = has1 ? pq[2 * e1] : -1, q1 = has1 ? pq[2 * e1 + 1] : -1;
+            const double c0 = has0 ? cs[2 * e0] : 1., s0 = has0 ? cs[2 * e0 + 1] : 0.;
+            const double c1 = has1 ? cs[2 * e1] : 1., s1 = has1 ? cs[2 * e1 + 1] : 0.;
+            // columns p,q:  A <- A J
+            if (p0 >= 0) {
+                const double akp = A[k0 * n + p0], akq = A[k0 * n + q0];
+                A[k0 * n + p0] = c0 * akp - s0 * akq;
+                A[k0 * n + q0] = s0 * akp + c0 * akq;
+            }
+            if (p1 >= 0) {
+                const double akp = A[k1 * n + p1], akq = A[k1 * n + q1];
+                A[k1 * n + p1] = c1 * akp - s1 * akq;
+                A[k1 * n + q1] = s1 * akp + c1 * akq;
             }
             wave_lds_fence();
-            for (int i = lane; i < half * n; i += 64) {  // rows p,q:  A <- J^T A ;  V <- V J
-                const int e = i / n, k = i - e * n;
-                const int p = pq[2 * e], q = pq[2 * e + 1];
-                if (p >= 0) {
-                    const double c = cs[2 * e], sn = cs[2 * e + 1];
-                    const double apk = A[p * n + k], aqk = A[q * n + k];
-                    A[p * n + k] = c * apk - sn * aqk;
-                    A[q * n + k] = sn * apk + c * aqk;
-                    const double vkp = V[k * n + p], vkq = V[k * n + q];
-                    V[k * n + p] = c * vkp - sn * vkq;
-                    V[k * n + q] = sn * vkp + c * vkq;
-                }
+            // rows p,q:  A <- J^T A ;  V <- V J
+            if (p0 >= 0) {
+                const double apk = A[p0 * n + k0], aqk = A[q0 * n + k0];
+                A[p0 * n + k0] = c0 * apk - s0 * aqk;
+                A[q0 * n + k0] = s0 * apk + c0 * aqk;
+                const double vkp = V[k0 * n + p0], vkq = V[k0 * n + q0];
+                V[k0 * n + p0] = c0 * vkp - s0 * vkq;
+                V[k0 * n + q0] = s0 * vkp + c0 * vkq;
+            }
+            if (p1 >= 0) {
+                const double apk = A[p1 * n + k1], aqk = A[q1 * n + k1];
+                A[p1 * n + k1] = c1 * apk - s1 * aqk;
+                A[q1 * n + k1] = s1 * apk + c1 * aqk;
+                const double vkp = V[k1 * n + p1], vkq = V[k1 * n + q1];
+                V[k1 * n + p1] = c1 * vkp - s1 * vkq;
+                V[k1 * n + q1] = s1 * vkp + c1 * vkq;
             }
             wave_lds_fence();
         }
@@ -356,7 +371,7 @@ __global__ __launch_bounds__(256) void pnp_solve_kernel(const float *__restrict_
         S.A3[lane] = s;
     }
     wave_lds_fence();
-    wave_jacobi_eigen_sym(3, S.A3, S.V3, S.cs, S.pq, 6, lane);
+    wave_jacobi_eigen_sym<3>(S.A3, S.V3, S.cs, S.pq, 5, lane);
     {
         const double wc[3] = {S.A3[0], S.A3[4], S.A3[8]};
         int o0 = 0, o1 = 1, o2 = 2;  // descending eigenvalue, same comparison order as the oracle
@@ -446,7 +461,7 @@ __global__ __launch_bounds__(256) void pnp_solve_kernel(const float *__restrict_
         S.A[e] = s;
     }
     wave_lds_fence();
-    wave_jacobi_eigen_sym(12, S.A, S.V, S.cs, S.pq, 8, lane);  // quadratic convergence: 8 sweeps reach 1e-16
+    wave_jacobi_eigen_sym<12>(S.A, S.V, S.cs, S.pq, 6, lane);  // quadratic convergence: off-diagonals < 1e-12 after 6
     // ---- the four smallest eigenvalues, ascending (ties: lower index first) ----
     {
         int sel[4];
