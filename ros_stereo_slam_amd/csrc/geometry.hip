@@ -160,28 +160,34 @@ __global__ __launch_bounds__(1024) void compact_kernel(const uint8_t *__restrict
                                                        const int *__restrict__ d_n, CompactArgs args,
                                                        int *__restrict__ d_count)
 {
-    __shared__ int s_sum[1024];
+    // One workgroup of 16 waves walks the array in 1024-element strips.  Inside a wave the
+    // position of a kept element is a popcount of the ballot below its lane; wave totals are
+    // combined through 16 LDS words; the running base carries from strip to strip.
+    __shared__ int s_wave[16];
+    __shared__ int s_base;
     const int n = d_n ? *d_n : n_host;
-    const int t = threadIdx.x;
-    const int per = (n + 1023) / 1024;
-    const int b = t * per, e = min(b + per, n);
-    int cnt = 0;
-    for (int i = b; i < e; i++)
-        cnt += mask[i] == 1;
-    s_sum[t] = cnt;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t == 0)
+        s_base = 0;
     __syncthreads();
-    // inclusive scan over 1024 partials (Hillis-Steele)
-    for (int off = 1; off < 1024; off <<= 1) {
-        int v = t >= off ? s_sum[t - off] : 0;
+    for (int start = 0; start < n; start += 1024) {
+        const int i = start + t;
+        const bool keep = i < n && mask[i] == 1;
+        const unsigned long long bal = __ballot(keep);
+        const int below = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0)
+            s_wave[wave] = __popcll(bal);
         __syncthreads();
-        s_sum[t] += v;
-        __syncthreads();
-    }
-    int pos = s_sum[t] - cnt;
-    if (t == 1023 && d_count)
-        *d_count = s_sum[1023];
-    for (int i = b; i < e; i++)
-        if (mask[i] == 1) {
+        int wbase = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) {
+            const int c = s_wave[w];
+            wbase += w < wave ? c : 0;
+            total += c;
+        }
+        const int base = s_base;
+        if (keep) {
+            const int pos = base + wbase + below;
 #pragma unroll
             for (int a = 0; a < 3; a++)
                 if (args.in[a]) {
@@ -189,8 +195,14 @@ __global__ __launch_bounds__(1024) void compact_kernel(const uint8_t *__restrict
                     for (int k = 0; k < st; k++)
                         args.out[a][(size_t)pos * st + k] = args.in[a][(size_t)i * st + k];
                 }
-            pos++;
         }
+        __syncthreads();
+        if (t == 0)
+            s_base = base + total;
+        __syncthreads();
+    }
+    if (t == 0 && d_count)
+        *d_count = s_base;
 }
 
 Mat34 to_mat34(const double *p)

@@ -802,28 +802,38 @@ __global__ __launch_bounds__(1024) void mask_to_index_kernel(const uint8_t *__re
                                                              const int *__restrict__ d_n, int *__restrict__ out_idx,
                                                              int *__restrict__ d_count)
 {
-    __shared__ int s_sum[1024];
+    __shared__ int s_wave[16];
+    __shared__ int s_base;
     const int n = d_n ? *d_n : n_host;
-    const int t = threadIdx.x;
-    const int per = (n + 1023) / 1024;
-    const int b = t * per, e = min(b + per, n);
-    int cnt = 0;
-    for (int i = b; i < e; i++)
-        cnt += mask[i] == 1;
-    s_sum[t] = cnt;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t == 0)
+        s_base = 0;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        int v = t >= off ? s_sum[t - off] : 0;
+    for (int start = 0; start < n; start += 1024) {
+        const int i = start + t;
+        const bool keep = i < n && mask[i] == 1;
+        const unsigned long long bal = __ballot(keep);
+        const int below = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0)
+            s_wave[wave] = __popcll(bal);
         __syncthreads();
-        s_sum[t] += v;
+        int wbase = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) {
+            const int c = s_wave[w];
+            wbase += w < wave ? c : 0;
+            total += c;
+        }
+        const int base = s_base;
+        if (keep)
+            out_idx[base + wbase + below] = i;
+        __syncthreads();
+        if (t == 0)
+            s_base = base + total;
         __syncthreads();
     }
-    int pos = s_sum[t] - cnt;
-    if (t == 1023)
-        *d_count = s_sum[1023];
-    for (int i = b; i < e; i++)
-        if (mask[i] == 1)
-            out_idx[pos++] = i;
+    if (t == 0)
+        *d_count = s_base;
 }
 
 // ---- Levenberg-Marquardt refinement over the inlier list -------------------------------------
@@ -1069,20 +1079,19 @@ __global__ __launch_bounds__(256) void pnp_refine_kernel(const float *__restrict
         }
         const double step = s_part[0];
         __syncthreads();
-        accumulate(s_trial, false);
+        // one pass gives the trial error AND, if the step is accepted, the normal equations there
+        accumulate(s_trial, true);
         const double e2 = s_sum[0];
         if (e2 < err || !(err == err)) {
-            __syncthreads();
             if (tid < 12)
                 s_pose[tid] = s_trial[tid];
-            __syncthreads();
             const double prev = err;
-            accumulate(s_pose, true);
-            err = s_sum[0];
+            err = e2;
             unpack();
             lambda *= 0.1;
             if (lambda < 1e-12)
                 lambda = 1e-12;
+            __syncthreads();
             const double scale = 1. + s_pose[9] * s_pose[9] + s_pose[10] * s_pose[10] + s_pose[11] * s_pose[11];
             if (step <= 1e-20 * scale || prev - err <= 1e-14 * prev)
                 break;
