@@ -278,7 +278,7 @@ class visualSLAM {
         // checkLoopDetectorStatus (src/optimizationStuff.cpp:59-63) with the supplied match
         if (loopMatch >= 0 && (frame_ - loopMatch > 100) && cooldownTimer == 0) {
             LC_FLAG = true;
-            LCidx = loopMatch - 1;
+            LCidx = loopMatch > 0 ? loopMatch - 1 : 0;  // the reference indexes vertices[-1] when match == 0
             cooldownTimer = 100;
         }
         if (LC_FLAG) {  // src/VisualSLAM.cpp:76-86

@@ -274,12 +274,14 @@ class VO:
     def localize(self, left):
         R, t = np.zeros((3, 3)), np.zeros(3)
         ninl, ntrk = C.c_int(), C.c_int()
-        rc = self.lib.orc_vo_localize(self._h, _p(np.ascontiguousarray(left)), _p(R), _p(t), C.byref(ninl),
-                                      C.byref(ntrk))
+        self._left = np.ascontiguousarray(left)  # update() hands it over as the new reference image
+        rc = self.lib.orc_vo_localize(self._h, _p(self._left), _p(R), _p(t), C.byref(ninl), C.byref(ntrk))
         return rc, R, t, ninl.value, ntrk.value
 
-    def update(self, left, right, R, t, n_inliers, force_keyframe=False):
+    def update(self, right, R, t, n_inliers, force_keyframe=False):
+        """Same signature as capi.VisualOdometry.update (the left image is the one localize() saw)."""
         kf = C.c_int()
+        left = self._left
         rc = self.lib.orc_vo_update(self._h, _p(np.ascontiguousarray(left)),
                                     _p(np.ascontiguousarray(right)) if right is not None else None,
                                     _p(np.ascontiguousarray(R, np.float64)), _p(np.ascontiguousarray(t, np.float64)),
@@ -290,7 +292,7 @@ class VO:
         rc, R, t, ninl, ntrk = self.localize(left)
         if rc:
             return rc, R, t, ninl, False, ntrk
-        rc, kf = self.update(left, right, R, t, ninl, force_keyframe)
+        rc, kf = self.update(right, R, t, ninl, force_keyframe)
         return rc, R, t, ninl, kf, ntrk
 
     def ref(self):

@@ -210,3 +210,20 @@ def textured_pair(w: int, h: int, c: int, shift=(0.0, 0.0), seed: int = 1, wavel
     a = np.ascontiguousarray(np.repeat(a[..., None], c, 2))
     b = np.ascontiguousarray(np.repeat(b[..., None], c, 2))
     return a, b
+
+
+def loop_closures(poses, max_dist: float = 2.0, max_angle_deg: float = 10.0, min_gap: int = 100):
+    """Stand-in for the reference's DBoW2 loop detector (vocabularies are not in the checkout):
+    for every frame the earliest frame at least ``min_gap`` frames back whose pose lies within
+    ``max_dist`` metres and ``max_angle_deg`` degrees, else -1."""
+    out = []
+    cosmax = np.cos(np.radians(max_angle_deg))
+    for i, (Ri, ti) in enumerate(poses):
+        match = -1
+        for j in range(0, i - min_gap):
+            Rj, tj = poses[j]
+            if np.linalg.norm(ti - tj) <= max_dist and (np.trace(Ri.T @ Rj) - 1) / 2 >= cosmax:
+                match = j
+                break
+        out.append(match)
+    return out

@@ -1,0 +1,119 @@
+"""The frame loop with the pose graph in it (src/VisualSLAM.cpp:54-169): policy tests with fake
+back-ends on CPU, and on the GPU a loop sequence with a generator-supplied closure run through
+the device front-end + device pose graph against the same loop over the CPU oracle."""
+import numpy as np
+import pytest
+
+from ros_stereo_slam_amd import chunked, synth
+from ros_stereo_slam_amd.slam import StereoSlam
+
+
+class _FakeVO:
+    def __init__(self, poses, inliers=300):
+        self.poses, self.i, self.inliers, self.updates = poses, 0, inliers, []
+
+    def init(self, l, r):
+        self.i = 0
+        return 100
+
+    def localize(self, left):
+        self.i += 1
+        R, t = self.poses[self.i]
+        return 0, R.copy(), t.copy(), self.inliers, 250
+
+    def update(self, right, R, t, n_inl, force):
+        self.updates.append((self.i, np.array(t), bool(force)))
+        return bool(force or n_inl < 200)
+
+
+class _FakePG:
+    def __init__(self):
+        self.nodes, self.loops, self.opt = [np.array([0, 0, 0, 0, 0, 0, 1.0])], [], 0
+
+    def augment_node(self, p):
+        self.nodes.append(np.array(p))
+
+    def add_loop_closure(self, idx):
+        self.loops.append((len(self.nodes) - 1, idx))
+
+    def optimize(self, iters):
+        self.opt += 1
+        return np.zeros(iters + 1)
+
+    def estimates(self):
+        e = np.array(self.nodes)
+        e[-1, :3] += 0.5  # pretend the optimiser moved the last vertex
+        return e
+
+
+def test_loop_closure_gating_and_reanchoring():
+    poses = [(np.eye(3), np.array([0.0, 0, 0.1 * i])) for i in range(260)]
+    vo, pg = _FakeVO(poses), _FakePG()
+    s = StereoSlam(vo, pg)
+    s.start(None, None)
+    events = []
+    for f in range(1, 250):
+        match = 5 if f in (50, 120, 121, 130, 230) else -1
+        ok, R, t, info = s.step(None, None, match)
+        if info["loop_closure"]:
+            events.append(f)
+    # frame 50: gap 45 <= 100 rejected; 120 accepted (LCidx 4, cooldown 100); 121/130 in cooldown;
+    # 230: cooldown expired -> accepted
+    assert events == [120, 230]
+    assert pg.loops == [(119, 4), (229, 4)]          # edge from the PREVIOUS vertex to vertices[match-1]
+    assert pg.opt == 2
+    upd = {i: (t, f) for i, t, f in vo.updates}
+    assert upd[120][1] and not upd[119][1]           # closure frames are forced keyframes
+    assert np.allclose(upd[120][0], poses[120][1] + 0.5)   # only t re-anchored, from the optimised last vertex
+    assert len(pg.nodes) == 250 and len(s.trajectory) == 250 and 120 in s.keyframes
+
+
+def test_loop_closure_generator():
+    poses = synth.loop_trajectory(150, half_x=6, half_z=10, radius=4, step=0.5)
+    lc = synth.loop_closures(poses, min_gap=100)
+    first = next(i for i, m in enumerate(lc) if m >= 0)
+    assert 100 < first < 125 and lc[first] < 10
+    assert all(m == -1 for m in lc[:100])
+
+
+SIZE, K4 = (480, 160), (270.0, 270.0, 240.0, 80.0)
+
+
+def _loop_frames(n):
+    poses = synth.loop_trajectory(n, half_x=6, half_z=10, radius=4, step=0.5)
+    sc = synth.Scene(wall_x=14, z_min=-18, z_max=18)
+    frames = [sc.stereo(R, t, K=K4, size=SIZE)[:2] for R, t in poses]
+    # poses relative to frame 0, as the VO reports them
+    R0, t0 = poses[0]
+    rel = [(R0.T @ R, R0.T @ (t - t0)) for R, t in poses]
+    return rel, frames, synth.loop_closures(poses, min_gap=100)
+
+
+@pytest.mark.gpu
+def test_slam_loop_with_closure_matches_oracle(ctx, orc):
+    from ros_stereo_slam_amd import capi
+
+    n = 124
+    gt, frames, lc = _loop_frames(n)
+    assert any(m >= 0 for m in lc)
+    kw = dict(grid_step=12, keyframe_min_inliers=90, seed=3, K4=K4)
+    g = StereoSlam(capi.VisualOdometry(ctx, SIZE[0], SIZE[1], 3, **kw), capi.PoseGraph(ctx))
+    o = StereoSlam(orc.VO(SIZE[0], SIZE[1], 3, **kw), orc.PoseGraph())
+    assert g.start(*frames[0]) == o.start(*frames[0])
+    for i in range(1, n):
+        okg, Rg, tg, ig = g.step(*frames[i], lc[i])
+        oko, Ro, to, io = o.step(*frames[i], lc[i])
+        assert okg and oko, f"frame {i}"
+        assert ig["keyframe"] == io["keyframe"] and ig["loop_closure"] == io["loop_closure"], f"frame {i}"
+        assert ig["tracked"] == io["tracked"], f"frame {i}"
+        assert np.linalg.norm(tg - to) < 2e-3, f"frame {i}: {np.linalg.norm(tg - to)}"
+    assert len(g.closures) == 1 and g.closures == o.closures
+    # the closure pulled the graph together, identically on both sides
+    assert np.allclose(g.chi2[0], o.chi2[0], rtol=1e-6)
+    assert g.chi2[0][-1] < 0.05 * g.chi2[0][0]
+    eg, eo = g.optimized_translations(), o.optimized_translations()
+    assert np.abs(eg - eo).max() < 5e-3
+    gt_t = np.array([t for _, t in gt])
+    ate_raw = chunked.ate_rmse([t for _, t in g.trajectory], gt_t)
+    print(f"ATE vs generator ground truth: {ate_raw:.3f} m over {n} frames; closure at {g.closures}")
+    assert ate_raw < 1.0
