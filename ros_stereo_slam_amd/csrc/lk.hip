@@ -21,6 +21,8 @@
 //
 // Roofline: the kernel's algorithmic HBM traffic is both pyramids once plus 21 B/point
 // (SURVEY.md section 8d); its time is VALU/LDS work, see DESIGN.md.
+#include <type_traits>
+
 #include "svo_internal.h"
 
 namespace {
@@ -131,97 +133,93 @@ __device__ __forceinline__ int stage_tile(uint8_t *tile, const uint8_t *__restri
     return shift;
 }
 
-// d = a * b + c with 24-bit signed operands (full-rate v_mad_i32_i24).  hipcc has no builtin
-// for it and lowers __mul24 to sign-extension + quarter-rate v_mul_lo_u32 when it cannot
-// prove the operand ranges, so it is spelled out.  Exact here: |a|,|b| < 2^23 by construction.
-__device__ __forceinline__ int mad24(int a, int b, int c)
-{
-    int d;
-    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
-
-// Read (SEG+1)*C consecutive LDS bytes into registers as individual ds_read_u8.  Left to the
-// compiler these byte loads are merged into b64/b128 reads that are misaligned (tile shift +
-// 3-byte pixels) and replay at 64 cycles each.  No wait inside: the caller issues
-// lds_wait_all() before the first use (cdna_hip_programming.md section 5.7).
-template <int C> __device__ __forceinline__ void lds_read_row_bytes(unsigned addr, int (&r)[(SEG + 1) * C]);
-template <> __device__ __forceinline__ void lds_read_row_bytes<1>(unsigned addr, int (&r)[8])
-{
-    asm volatile("ds_read_u8 %0, %8 offset:0\n\tds_read_u8 %1, %8 offset:1\n\tds_read_u8 %2, %8 offset:2\n\t"
-                 "ds_read_u8 %3, %8 offset:3\n\tds_read_u8 %4, %8 offset:4\n\tds_read_u8 %5, %8 offset:5\n\t"
-                 "ds_read_u8 %6, %8 offset:6\n\tds_read_u8 %7, %8 offset:7"
-                 : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]),
-                   "=&v"(r[7])
-                 : "v"(addr));
-}
-template <> __device__ __forceinline__ void lds_read_row_bytes<3>(unsigned addr, int (&r)[24])
-{
-    asm volatile("ds_read_u8 %0, %24 offset:0\n\tds_read_u8 %1, %24 offset:1\n\tds_read_u8 %2, %24 offset:2\n\t"
-                 "ds_read_u8 %3, %24 offset:3\n\tds_read_u8 %4, %24 offset:4\n\tds_read_u8 %5, %24 offset:5\n\t"
-                 "ds_read_u8 %6, %24 offset:6\n\tds_read_u8 %7, %24 offset:7\n\tds_read_u8 %8, %24 offset:8\n\t"
-                 "ds_read_u8 %9, %24 offset:9\n\tds_read_u8 %10, %24 offset:10\n\tds_read_u8 %11, %24 offset:11\n\t"
-                 "ds_read_u8 %12, %24 offset:12\n\tds_read_u8 %13, %24 offset:13\n\tds_read_u8 %14, %24 offset:14\n\t"
-                 "ds_read_u8 %15, %24 offset:15\n\tds_read_u8 %16, %24 offset:16\n\tds_read_u8 %17, %24 offset:17\n\t"
-                 "ds_read_u8 %18, %24 offset:18\n\tds_read_u8 %19, %24 offset:19\n\tds_read_u8 %20, %24 offset:20\n\t"
-                 "ds_read_u8 %21, %24 offset:21\n\tds_read_u8 %22, %24 offset:22\n\tds_read_u8 %23, %24 offset:23"
-                 : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]),
-                   "=&v"(r[7]), "=&v"(r[8]), "=&v"(r[9]), "=&v"(r[10]), "=&v"(r[11]), "=&v"(r[12]), "=&v"(r[13]),
-                   "=&v"(r[14]), "=&v"(r[15]), "=&v"(r[16]), "=&v"(r[17]), "=&v"(r[18]), "=&v"(r[19]),
-                   "=&v"(r[20]), "=&v"(r[21]), "=&v"(r[22]), "=&v"(r[23])
-                 : "v"(addr));
-}
-__device__ __forceinline__ void lds_wait_all()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);  // nothing may be hoisted above the wait
-}
-// LDS byte offset of a pointer into the dynamic shared segment
-__device__ __forceinline__ unsigned lds_offset(const void *p)
-{
-    return (unsigned)(uintptr_t)p;  // the low 32 bits of a generic LDS address are the LDS offset
-}
-
 typedef short short2v __attribute__((ext_vector_type(2)));
 constexpr int npairs(int c) { return (SEG * c + 1) / 2; }
+constexpr int ndwords(int c) { return ((SEG + 1) * c + 3) / 4; }  // packed dwords of one (SEG+1)-pixel row run
+
+__device__ __forceinline__ int sdot2(int a, int b, int c)
+{
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b), c, false);
+}
+
+// The (SEG+1)*C bytes of a row run starting at LDS byte offset `off` (any alignment), as
+// packed dwords: aligned ds_read_b32 (never the misaligned b64/b128 the compiler would form
+// from byte loads, which replay at 64 cycles) + one v_alignbyte_b32 per dword.
+template <int C>
+__device__ __forceinline__ void load_row_packed(const uint8_t *lds, int off, unsigned (&d)[ndwords(C)])
+{
+    const unsigned sh = (unsigned)off & 3u;
+    const unsigned *base = reinterpret_cast<const unsigned *>(lds + (off & ~3));
+    unsigned raw[ndwords(C) + 1];
+#pragma unroll
+    for (int i = 0; i <= ndwords(C); i++)
+        raw[i] = base[i];
+#pragma unroll
+    for (int i = 0; i < ndwords(C); i++)
+        d[i] = __builtin_amdgcn_alignbyte(raw[i + 1], raw[i], sh);
+}
+
+// (byte k) | (byte k+C) << 16 of a packed row run: the two horizontal bilinear neighbours of
+// element k as an int16 pair, one v_perm_b32 (selector bytes 0-3 pick from the second source,
+// 4-7 from the first, 0x0c is a zero byte).
+template <int C, int K> __device__ __forceinline__ int pixel_pair(const unsigned (&d)[ndwords(C)])
+{
+    constexpr int a = K >> 2, b = (K + C) >> 2;
+    constexpr unsigned sel = (unsigned)(K & 3) | (0x0cu << 8) | ((4u + (unsigned)((K + C) & 3)) << 16) | (0x0cu << 24);
+    return (int)__builtin_amdgcn_perm(d[b], d[a], sel);
+}
+
+// low (HI = false) or high (HI = true) int16 halves of two dwords as a pair: (x.half, y.half)
+template <bool HI> __device__ __forceinline__ int half_pair(int x, int y)
+{
+    constexpr unsigned sel = HI ? 0x07060302u : 0x05040100u;
+    return (int)__builtin_amdgcn_perm((unsigned)y, (unsigned)x, sel);
+}
+
+template <int C, int K> struct ForEachElem {
+    template <class F> static __device__ __forceinline__ void run(F &&f)
+    {
+        ForEachElem<C, K - 1>::run(f);
+        f(std::integral_constant<int, K - 1>());
+    }
+};
+template <int C> struct ForEachElem<C, 0> {
+    template <class F> static __device__ __forceinline__ void run(F &&) {}
+};
 
 // One lane's share of  sum (J - I) * {Ix, Iy}  (or sum |J - I| when ABS) over its 7*C patch
-// elements.  Patch registers hold element PAIRS as packed int16 (I is 14 bits, derivatives
-// 13 bits): the bilinear samples of two elements are packed, subtracted with one
-// v_pk_sub_i16 and fed to v_dot2_i32_i16 against the packed derivatives.
+// elements.  Per element: two v_perm_b32 build the neighbour pairs of both rows, two
+// v_dot2_i32_i16 apply the four 14-bit weights (pixel <= 255, -1 <= weight <= 2^14: exact);
+// per element PAIR: pack, one v_pk_sub_i16 against the packed template, two v_dot2_i32_i16
+// against the packed derivatives.
 template <int C, bool ABS>
-__device__ __forceinline__ void lane_residual(const uint8_t *tj, int tx, int ty, int w00, int w01, int w10,
-                                              int w11, const int (&Ivp)[npairs(C)],
-                                              const int (&Ixp)[npairs(C)], const int (&Iyp)[npairs(C)],
-                                              int &s1, int &s2)
+__device__ __forceinline__ void lane_residual(const uint8_t *lds, int off, int wp0, int wp1,
+                                              const int (&Ivp)[npairs(C)], const int (&Ixp)[npairs(C)],
+                                              const int (&Iyp)[npairs(C)], int &s1, int &s2)
 {
-    const unsigned q0 = lds_offset(tj) + ty * Tile<C, TS>::ROW + tx * C;  // tj includes the tile shift
-    int r0[(SEG + 1) * C], r1[(SEG + 1) * C];
-    lds_read_row_bytes<C>(q0, r0);
-    lds_read_row_bytes<C>(q0 + Tile<C, TS>::ROW, r1);
-    lds_wait_all();
+    constexpr int NE = SEG * C;
+    constexpr int RND = 1 << (W_BITS - 5 - 1);
+    unsigned r0[ndwords(C)], r1[ndwords(C)];
+    load_row_packed<C>(lds, off, r0);
+    load_row_packed<C>(lds, off + Tile<C, TS>::ROW, r1);
+    int v[NE + 1];
+    v[NE] = 0;
+    ForEachElem<C, NE>::run([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        v[k] = sdot2(pixel_pair<C, k>(r1), wp1, sdot2(pixel_pair<C, k>(r0), wp0, RND)) >> (W_BITS - 5);
+    });
     s1 = 0;
     s2 = 0;
-    constexpr int RND = 1 << (W_BITS - 5 - 1);
 #pragma unroll
     for (int j = 0; j < npairs(C); j++) {
-        const int k0 = 2 * j, k1 = 2 * j + 1;
-        // pixel <= 255, -1 <= weight <= 2^14 (the fourth weight, 2^14 minus three rounded
-        // ones, can be -1): signed 24-bit multiply-adds are exact and full rate; the sum
-        // plus the rounding constant is never negative.
-        int v0 = mad24(r0[k0], w00, mad24(r0[k0 + C], w01, mad24(r1[k0], w10, mad24(r1[k0 + C], w11, RND)))) >>
-                 (W_BITS - 5);
-        int v1 = 0;
-        if (k1 < SEG * C)
-            v1 = mad24(r0[k1], w00, mad24(r0[k1 + C], w01, mad24(r1[k1], w10, mad24(r1[k1 + C], w11, RND)))) >>
-                 (W_BITS - 5);
-        const short2v d = __builtin_bit_cast(short2v, v0 | (v1 << 16)) - __builtin_bit_cast(short2v, Ivp[j]);
+        const int k0 = 2 * j, k1 = 2 * j + 1 < NE ? 2 * j + 1 : NE;  // v[NE] == 0 pads an odd count
+        const short2v d = __builtin_bit_cast(short2v, v[k0] | (v[k1] << 16)) - __builtin_bit_cast(short2v, Ivp[j]);
         if (ABS) {
             int d0 = d.x, d1 = d.y;
-            s1 += (d0 < 0 ? -d0 : d0) + (k1 < SEG * C ? (d1 < 0 ? -d1 : d1) : 0);
+            s1 += (d0 < 0 ? -d0 : d0) + (2 * j + 1 < NE ? (d1 < 0 ? -d1 : d1) : 0);
         } else {
-            s1 = __builtin_amdgcn_sdot2(d, __builtin_bit_cast(short2v, Ixp[j]), s1, false);
-            s2 = __builtin_amdgcn_sdot2(d, __builtin_bit_cast(short2v, Iyp[j]), s2, false);
+            s1 = sdot2(__builtin_bit_cast(int, d), Ixp[j], s1);
+            s2 = sdot2(__builtin_bit_cast(int, d), Iyp[j], s2);
         }
     }
 }
@@ -311,40 +309,35 @@ __global__ __launch_bounds__(64 * WAVES, 3) void lk_track_kernel(
         int Ivp[npairs(C)], Ixp[npairs(C)], Iyp[npairs(C)];  // packed int16 pairs (low = even element)
         int a11 = 0, a12 = 0, a22 = 0;
         {
-            int t0[(SEG + 1) * C], t1[(SEG + 1) * C];
-            {
-                const unsigned ta = lds_offset(Ts) + (wy + 1) * TROW + (wx + 1) * C;
-                lds_read_row_bytes<C>(ta, t0);
-                lds_read_row_bytes<C>(ta + TROW, t1);
-                lds_wait_all();
-            }
+            const int wp0 = (w00 & 0xffff) | (w01 << 16), wp1 = (w10 & 0xffff) | (w11 << 16);
+            constexpr int NE = SEG * C;
+            unsigned t0[ndwords(C)], t1[ndwords(C)];
+            const int toff = (int)(Ts - lds) + (wy + 1) * TROW + (wx + 1) * C;
+            load_row_packed<C>(lds, toff, t0);
+            load_row_packed<C>(lds, toff + TROW, t1);
             const int *d0 = D + (wy * DT + wx) * C;
             const int *d1 = d0 + DT * C;
+            int iv[NE + 1], ix[NE + 1], iy[NE + 1];
+            iv[NE] = ix[NE] = iy[NE] = 0;
+            ForEachElem<C, NE>::run([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                iv[k] = sdot2(pixel_pair<C, k>(t1), wp1, sdot2(pixel_pair<C, k>(t0), wp0, 1 << (W_BITS - 5 - 1))) >>
+                        (W_BITS - 5);
+                // derivative tile entries are (dx | dy << 16); |derivative| <= 4080: exact in int16 pairs
+                const int p00 = d0[k], p01 = d0[k + C], p10 = d1[k], p11 = d1[k + C];
+                constexpr int RD = 1 << (W_BITS - 1);
+                ix[k] = sdot2(half_pair<false>(p10, p11), wp1, sdot2(half_pair<false>(p00, p01), wp0, RD)) >> W_BITS;
+                iy[k] = sdot2(half_pair<true>(p10, p11), wp1, sdot2(half_pair<true>(p00, p01), wp0, RD)) >> W_BITS;
+            });
 #pragma unroll
             for (int j = 0; j < npairs(C); j++) {
-                int iv[2] = {0, 0}, ix[2] = {0, 0}, iy[2] = {0, 0};
-#pragma unroll
-                for (int e = 0; e < 2; e++) {
-                    const int k = 2 * j + e;
-                    if (k < SEG * C) {
-                        iv[e] = mad24(t0[k], w00, mad24(t0[k + C], w01, mad24(t1[k], w10,
-                                      mad24(t1[k + C], w11, 1 << (W_BITS - 5 - 1))))) >> (W_BITS - 5);
-                        int p00 = d0[k], p01 = d0[k + C], p10 = d1[k], p11 = d1[k + C];
-                        // |derivative| <= 4080 < 2^12, weight <= 2^14: signed 24-bit multiplies are exact
-                        constexpr int RD = 1 << (W_BITS - 1);
-                        int gx = mad24((int)(short)(p00 & 0xffff), w00, mad24((int)(short)(p01 & 0xffff), w01,
-                                 mad24((int)(short)(p10 & 0xffff), w10, mad24((int)(short)(p11 & 0xffff), w11, RD))));
-                        int gy = mad24(p00 >> 16, w00, mad24(p01 >> 16, w01, mad24(p10 >> 16, w10, mad24(p11 >> 16, w11, RD))));
-                        ix[e] = gx >> W_BITS;
-                        iy[e] = gy >> W_BITS;
-                        a11 = mad24(ix[e], ix[e], a11);
-                        a12 = mad24(ix[e], iy[e], a12);
-                        a22 = mad24(iy[e], iy[e], a22);
-                    }
-                }
-                Ivp[j] = iv[0] | (iv[1] << 16);
-                Ixp[j] = (ix[0] & 0xffff) | (ix[1] << 16);
-                Iyp[j] = (iy[0] & 0xffff) | (iy[1] << 16);
+                const int k0 = 2 * j, k1 = 2 * j + 1 < NE ? 2 * j + 1 : NE;
+                Ivp[j] = iv[k0] | (iv[k1] << 16);
+                Ixp[j] = (ix[k0] & 0xffff) | (ix[k1] << 16);
+                Iyp[j] = (iy[k0] & 0xffff) | (iy[k1] << 16);
+                a11 = sdot2(Ixp[j], Ixp[j], a11);  // sums of squares of int16 pairs, exact
+                a12 = sdot2(Ixp[j], Iyp[j], a12);
+                a22 = sdot2(Iyp[j], Iyp[j], a22);
             }
         }
         if (!active) {
@@ -392,8 +385,9 @@ __global__ __launch_bounds__(64 * WAVES, 3) void lk_track_kernel(
             }
             bilinear_weights(nxp - (float)inx, nyp - (float)iny, w00, w01, w10, w11);
             int s1, s2;
-            lane_residual<C, false>(TJs, inx - ox + wx, iny - oy + wy, w00, w01, w10, w11, Ivp, Ixp, Iyp,
-                                    s1, s2);
+            lane_residual<C, false>(lds, (int)(TJs - lds) + (iny - oy + wy) * Tile<C, TS>::ROW + (inx - ox + wx) * C,
+                                    (w00 & 0xffff) | (w01 << 16), (w10 & 0xffff) | (w11 << 16), Ivp, Ixp, Iyp, s1,
+                                    s2);
             if (!active) {
                 s1 = 0;
                 s2 = 0;
@@ -436,7 +430,8 @@ __global__ __launch_bounds__(64 * WAVES, 3) void lk_track_kernel(
             }
             bilinear_weights(qx - (float)iqx, qy - (float)iqy, w00, w01, w10, w11);
             int s1, s2;
-            lane_residual<C, true>(TJs, iqx - ox + wx, iqy - oy + wy, w00, w01, w10, w11, Ivp, Ixp, Iyp, s1,
+            lane_residual<C, true>(lds, (int)(TJs - lds) + (iqy - oy + wy) * Tile<C, TS>::ROW + (iqx - ox + wx) * C,
+                                   (w00 & 0xffff) | (w01 << 16), (w10 & 0xffff) | (w11 << 16), Ivp, Ixp, Iyp, s1,
                                    s2);
             if (!active)
                 s1 = 0;
