@@ -83,6 +83,20 @@ int svo_resolve_timers(svo_ctx *ctx)
     return SVO_OK;
 }
 
+int svo_wait(svo_ctx *ctx)
+{
+    SVO_HIP(hipEventRecord(ctx->wait_ev, ctx->stream));
+    for (;;) {
+        hipError_t e = hipEventQuery(ctx->wait_ev);
+        if (e == hipSuccess)
+            return SVO_OK;
+        if (e != hipErrorNotReady) {
+            svo_set_error("hipEventQuery -> %s", hipGetErrorString(e));
+            return SVO_ERR_HIP;
+        }
+    }
+}
+
 extern "C" {
 
 int svo_version(void) { return SVO_VERSION; }
@@ -124,6 +138,14 @@ int svo_ctx_create(int device, svo_ctx **out)
         svo_set_error("hipHostMalloc -> %s", hipGetErrorString(e));
         return SVO_ERR_HIP;
     }
+    e = hipEventCreateWithFlags(&ctx->wait_ev, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        (void)hipHostFree(ctx->pinned);
+        (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        svo_set_error("hipEventCreate -> %s", hipGetErrorString(e));
+        return SVO_ERR_HIP;
+    }
     *out = ctx;
     return SVO_OK;
 }
@@ -147,6 +169,8 @@ int svo_ctx_destroy(svo_ctx *ctx)
         b->release();
     if (ctx->pinned)
         (void)hipHostFree(ctx->pinned);
+    if (ctx->wait_ev)
+        (void)hipEventDestroy(ctx->wait_ev);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return SVO_OK;

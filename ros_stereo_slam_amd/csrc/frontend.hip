@@ -142,7 +142,8 @@ int stereo_triangulate(svo_vo *v, const svo_pyramid *left, const svo_pyramid *ri
                                      Rt ? out3d : nullptr)))
         return rc;
     SVO_HIP(hipMemcpyAsync(ctx->pinned, v->d_cnt + 4, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    SVO_HIP(hipStreamSynchronize(ctx->stream));
+    if ((rc = svo_wait(ctx)))
+        return rc;
     *n_out = *reinterpret_cast<int *>(ctx->pinned);
     return SVO_OK;
 }
@@ -290,7 +291,8 @@ int svo_vo_localize(svo_vo *v, const uint8_t *left, int mem, double *R9, double 
             return rc;
         hipLaunchKernelGGL(store_count_kernel, dim3(1), dim3(1), 0, ctx->stream, v->d_cnt + 1, &v->d_rec->n_tracked);
         SVO_HIP(hipMemcpyAsync(ctx->pinned, v->d_rec, sizeof(PnpRecord), hipMemcpyDeviceToHost, ctx->stream));
-        SVO_HIP(hipStreamSynchronize(ctx->stream));
+        if ((rc = svo_wait(ctx)))
+            return rc;
         if (rec->n_inliers >= 10)
             break;
     }

@@ -86,7 +86,12 @@ struct svo_ctx {
     DevBuf w_a, w_b, w_c, w_d, w_e;
     void *pinned = nullptr;  // small pinned host block for scalar read-backs
     size_t pinned_bytes = 0;
+    hipEvent_t wait_ev = nullptr;  // svo_wait(): event polled by the host
 };
+
+// Low-latency host wait for everything queued on the context's stream: records an event and
+// polls it (hipStreamSynchronize parks the thread and costs tens of microseconds to wake).
+int svo_wait(svo_ctx *ctx);
 
 // scoped timer: records events around a kernel when ctx->timing is on
 struct ScopedKernelTime {
