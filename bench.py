@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--frames", type=int, default=6, help="distinct synthetic stereo frames kept in HBM per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="run the frames strictly serially on one stream")
     ap.add_argument("--cpu-frames", type=int, default=24)
     args = ap.parse_args()
 
@@ -92,20 +93,29 @@ def main():
 
     stats = {"keyframes": 0, "inliers": 0, "tracked": 0, "lost": 0}
 
-    def step(i: int, record: bool):
-        l, r = dev_frames[pingpong(i + 1, args.frames)]
-        rc, R, t, ninl, kf, ntrk = vo.track(l, r)
-        if rc:
-            stats["lost"] += 1
-            vo.init(l, r)  # re-seed (the reference would shut down; a throughput run carries on)
-        if record:
-            stats["keyframes"] += int(kf)
-            stats["inliers"] += ninl
-            stats["tracked"] += ntrk
+    def run(first: int, count: int, record: bool):
+        """Frames first+1 .. first+count of the ping-pong walk through the chunk runner (one C
+        call, no Python between frames; PnP of frame t overlaps pyramid + LK of frame t+1)."""
+        R = t = None
+        done_total = 0
+        while done_total < count:
+            idx = [pingpong(first + done_total + k + 1, args.frames) for k in range(count - done_total)]
+            rc, done, Rs, ts, inl, trk, kf = vo.run_chunk([dev_frames[i][0] for i in idx],
+                                                          [dev_frames[i][1] for i in idx], pipeline=not args.no_pipeline)
+            if record:
+                stats["keyframes"] += int(kf[:done].sum())
+                stats["inliers"] += int(inl[:done].sum())
+                stats["tracked"] += int(trk[:done].sum())
+            if done:
+                R, t = Rs[done - 1], ts[done - 1]
+            done_total += done
+            if rc:  # tracking lost: re-seed on that frame (the reference would shut down)
+                stats["lost"] += 1
+                vo.init(*dev_frames[idx[done]])
+                done_total += 1
         return R, t
 
-    for i in range(args.warmup):
-        step(i, False)
+    run(0, args.warmup, False)
     ctx.sync()
     ctx.enable_kernel_timing(True)
     ctx.reset_kernel_time()
@@ -114,9 +124,7 @@ def main():
     torch.cuda.synchronize()
     ctx.sync()
     t0 = time.perf_counter()
-    R = t = None
-    for i in range(args.steps):
-        R, t = step(args.warmup + i, True)
+    R, t = run(args.warmup, args.steps, True)
     if dist is not None:
         # the path's one exchange: chunk-boundary poses, 12 doubles per rank, over RCCL
         from ros_stereo_slam_amd import chunked
@@ -165,6 +173,7 @@ def main():
                             "keyframe path (LK L->R, F-RANSAC, DLT triangulation)",
                 "keyframe_min_inliers": KF_MIN_INLIERS,
                 "parallelism": f"one contiguous chunk per GPU x{world}, all-gather of chunk-boundary poses",
+                "pipeline": "serial" if args.no_pipeline else "two HIP streams: PnP(t) beside pyramid+LK(t+1)",
                 "keyframe_rate": kf_rate,
                 "mean_tracked": stats["tracked"] / args.steps,
                 "mean_pnp_inliers": stats["inliers"] / args.steps,

@@ -185,6 +185,16 @@ int svo_vo_update(svo_vo *vo, const uint8_t *right, int mem, const double *R9, c
 /* localize + update */
 int svo_vo_track(svo_vo *vo, const uint8_t *left, const uint8_t *right, int mem, int force_keyframe,
                  double *R9, double *t3, int *n_inliers, int *was_keyframe, int *n_tracked);
+/* The chunk runner: n_frames consecutive frames (lefts[i], rights[i]: one image pointer each,
+ * all HOST or all DEVICE per `mem`) through the front-end without returning to the caller in
+ * between -- exactly the result of n_frames calls of svo_vo_track(force_keyframe = 0).
+ * Outputs per frame (host arrays, any may be NULL except R_out/t_out): R_out n*9, t_out n*3,
+ * inliers_out, tracked_out, keyframe_out.  pipeline != 0 (device images only) overlaps the
+ * PnP-RANSAC of frame t with the pyramid + LK of frame t+1 on a second HIP stream; results
+ * are identical.  Stops at tracking loss (SVO_ERR_TRACKING_LOST, *n_done frames completed).    */
+int svo_vo_run_chunk(svo_vo *vo, const uint8_t *const *lefts, const uint8_t *const *rights, int n_frames,
+                     int mem, int pipeline, double *R_out, double *t_out, int *inliers_out,
+                     int *tracked_out, uint8_t *keyframe_out, int *n_done);
 /* the current reference point set (2-D in the reference image, 3-D world) */
 int svo_vo_get_reference(svo_vo *vo, float *ref2d, float *ref3d, int cap, int *n, int mem);
 int svo_vo_capacity(const svo_vo *vo);

@@ -338,6 +338,24 @@ class VisualOdometry:
         kf = self.update(right, R, t, ninl, force_keyframe)
         return rc, R, t, ninl, kf, ntrk
 
+    def run_chunk(self, lefts, rights, pipeline: bool = True):
+        """Consecutive frames without returning to Python in between (``svo_vo_run_chunk``).
+        Returns (rc, n_done, R[n,3,3], t[n,3], inliers[n], tracked[n], keyframe[n])."""
+        n = len(lefts)
+        mem = self._mem(lefts[0])
+        PtrArr = C.c_void_p * n
+        la = PtrArr(*[_ptr(x).value for x in lefts])
+        ra = PtrArr(*[_ptr(x).value for x in rights])
+        R, t = np.zeros((n, 3, 3)), np.zeros((n, 3))
+        inl, trk = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        kf = np.zeros(n, np.uint8)
+        done = C.c_int()
+        rc = self.ctx.lib.svo_vo_run_chunk(self._h, la, ra, n, mem, int(bool(pipeline)), _ptr(R), _ptr(t), _ptr(inl),
+                                           _ptr(trk), _ptr(kf), C.byref(done))
+        if rc not in (SVO_OK, SVO_ERR_TRACKING_LOST):
+            _check(rc)
+        return rc, done.value, R, t, inl, trk, kf.astype(bool)
+
     def reference(self):
         cap = self.ctx.lib.svo_vo_capacity(self._h)
         a, b = np.zeros((cap, 2), np.float32), np.zeros((cap, 3), np.float32)

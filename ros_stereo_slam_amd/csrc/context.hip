@@ -83,9 +83,11 @@ int svo_resolve_timers(svo_ctx *ctx)
     return SVO_OK;
 }
 
-int svo_wait(svo_ctx *ctx)
+int svo_wait(svo_ctx *ctx) { return svo_wait_stream(ctx, ctx->stream); }
+
+int svo_wait_stream(svo_ctx *ctx, hipStream_t stream)
 {
-    SVO_HIP(hipEventRecord(ctx->wait_ev, ctx->stream));
+    SVO_HIP(hipEventRecord(ctx->wait_ev, stream));
     for (;;) {
         hipError_t e = hipEventQuery(ctx->wait_ev);
         if (e == hipSuccess)

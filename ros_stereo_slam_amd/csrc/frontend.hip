@@ -30,7 +30,11 @@ struct svo_vo {
     svo_ctx *ctx = nullptr;
     svo_vo_params prm;
     int w = 0, h = 0, c = 0, cap = 0;
-    svo_pyramid *pyr_ref = nullptr, *pyr_cur = nullptr, *pyr_right = nullptr;
+    svo_pyramid *pyr_ref = nullptr, *pyr_cur = nullptr, *pyr_right = nullptr, *pyr_next = nullptr;
+    hipStream_t stream_b = nullptr;          // second stream: PnP of frame t beside pyramid + LK of frame t+1
+    hipEvent_t ev_a = nullptr;               // "tracked sets of frame t are ready" (stream A -> B)
+    float *sa2 = nullptr;                    // speculative LK output for frame t+1
+    uint8_t *sstatus = nullptr;
     // point sets (device)
     float *ref2d = nullptr, *ref3d = nullptr, *trk2d = nullptr, *trk3d = nullptr;
     float *a2 = nullptr, *b2 = nullptr, *c2 = nullptr, *d2 = nullptr, *a3 = nullptr, *b3 = nullptr, *resp = nullptr;
@@ -190,6 +194,8 @@ int svo_vo_create(svo_ctx *ctx, const svo_vo_params *params, int width, int heig
     if ((rc = svo_pyramid_create(ctx, width, height, channels, SVO_MAX_LEVELS, &v->pyr_ref)) ||
         (rc = svo_pyramid_create(ctx, width, height, channels, SVO_MAX_LEVELS, &v->pyr_cur)) ||
         (rc = svo_pyramid_create(ctx, width, height, channels, SVO_MAX_LEVELS, &v->pyr_right)) ||
+        (rc = svo_pyramid_create(ctx, width, height, channels, SVO_MAX_LEVELS, &v->pyr_next)) ||
+        (rc = dev_alloc(&v->sa2, n * 2)) || (rc = dev_alloc(&v->sstatus, n)) ||
         (rc = dev_alloc(&v->ref2d, n * 2)) || (rc = dev_alloc(&v->ref3d, n * 3)) ||
         (rc = dev_alloc(&v->trk2d, n * 2)) || (rc = dev_alloc(&v->trk3d, n * 3)) ||
         (rc = dev_alloc(&v->a2, n * 2)) || (rc = dev_alloc(&v->b2, n * 2)) || (rc = dev_alloc(&v->c2, n * 2)) ||
@@ -199,6 +205,12 @@ int svo_vo_create(svo_ctx *ctx, const svo_vo_params *params, int width, int heig
         (rc = dev_alloc(&v->d_rec, 1)) || (rc = dev_alloc(&v->d_img, (size_t)width * height * channels))) {
         svo_vo_destroy(v);
         return rc;
+    }
+    if (hipStreamCreateWithFlags(&v->stream_b, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&v->ev_a, hipEventDisableTiming) != hipSuccess) {
+        svo_set_error("front-end: cannot create the second stream / event");
+        svo_vo_destroy(v);
+        return SVO_ERR_HIP;
     }
     for (int i = 0; i < 9; i++)
         v->R[i] = (i % 4) == 0;
@@ -216,6 +228,17 @@ int svo_vo_destroy(svo_vo *v)
     svo_pyramid_destroy(v->ctx, v->pyr_ref);
     svo_pyramid_destroy(v->ctx, v->pyr_cur);
     svo_pyramid_destroy(v->ctx, v->pyr_right);
+    svo_pyramid_destroy(v->ctx, v->pyr_next);
+    if (v->stream_b) {
+        (void)hipStreamSynchronize(v->stream_b);
+        (void)hipStreamDestroy(v->stream_b);
+    }
+    if (v->ev_a)
+        (void)hipEventDestroy(v->ev_a);
+    if (v->sa2)
+        (void)hipFree(v->sa2);
+    if (v->sstatus)
+        (void)hipFree(v->sstatus);
     void *bufs[] = {v->ref2d, v->ref3d, v->trk2d, v->trk3d, v->a2,   v->b2,    v->c2,    v->d2,   v->a3,
                     v->b3,    v->resp,  v->status, v->mask, v->st2, v->idx,   v->d_cnt, v->d_rec, v->d_img};
     for (void *b : bufs)
@@ -364,6 +387,158 @@ int svo_vo_track(svo_vo *v, const uint8_t *left, const uint8_t *right, int mem, 
     if (rc)
         return rc;
     return svo_vo_update(v, right, mem, R9, t3, ninl, force_keyframe, was_keyframe);
+}
+
+// A run of consecutive frames through the front-end without returning to the caller between
+// frames (the "chunk runner" of SURVEY.md 8b/8e): exactly the result of n_frames calls of
+// svo_vo_track(..., force_keyframe = 0), frame by frame.
+//
+// With pipeline != 0 the loop overlaps work on two HIP streams.  Stream A carries a frame's
+// pyramid, LK, filters and the keyframe path; the PnP-RANSAC of frame t (a handful of
+// wavefronts of f64 latency) runs on stream B while stream A already builds the pyramid of
+// frame t+1 and tracks into it from the points frame t kept -- which is what frame t+1 will do
+// unless frame t turns out to be a keyframe (fewer PnP inliers than the threshold).  In that
+// case the speculative tracking is discarded and redone from the new keyframe's points; the
+// pyramid is kept.  Scheduling only: every stage sees the same inputs as in the serial order,
+// so results are identical (tests/test_gpu_frontend.py::test_run_chunk_*).
+int svo_vo_run_chunk(svo_vo *v, const uint8_t *const *lefts, const uint8_t *const *rights, int n_frames, int mem,
+                     int pipeline, double *R_out, double *t_out, int *inliers_out, int *tracked_out,
+                     uint8_t *keyframe_out, int *n_done)
+{
+    SVO_CHECK_ARG(v && lefts && rights && n_frames >= 0 && R_out && t_out);
+    SVO_CHECK_ARG(mem == SVO_MEM_HOST || mem == SVO_MEM_DEVICE);
+    svo_ctx *ctx = v->ctx;
+    hipStream_t sA = ctx->stream, sB = v->stream_b;
+    if (n_done)
+        *n_done = 0;
+    if (mem == SVO_MEM_HOST)
+        pipeline = 0;  // host images go through one staging buffer; keep them strictly in order
+    const double K4[4] = {v->prm.fx, v->prm.fy, v->prm.cx, v->prm.cy};
+    const PnpRecord *rec = reinterpret_cast<const PnpRecord *>(ctx->pinned);
+    bool spec = false, next_built = false;
+    int rc;
+    for (int f = 0; f < n_frames; f++) {
+        v->frame++;
+        const int n = v->nref;
+        if (n < 5) {
+            svo_set_error("tracking lost: %d reference points", n);
+            return SVO_ERR_TRACKING_LOST;
+        }
+        if (spec) {  // frame f was tracked speculatively during frame f-1's PnP
+            std::swap(v->pyr_cur, v->pyr_next);
+            std::swap(v->a2, v->sa2);
+            std::swap(v->status, v->sstatus);
+        } else {
+            if (next_built) {
+                std::swap(v->pyr_cur, v->pyr_next);
+            } else {
+                const uint8_t *d = stage_image(v, lefts[f], mem, &rc);
+                if (rc || (rc = svo_build_pyramid_from_device(ctx, v->pyr_cur, d)))
+                    return rc;
+            }
+            if ((rc = svo_launch_lk(ctx, v->pyr_ref->dev, v->pyr_cur->dev, v->ref2d, n, v->a2, v->status, nullptr,
+                                    nullptr)))
+                return rc;
+        }
+        spec = next_built = false;
+        if ((rc = svo_launch_compact(ctx, v->status, n, nullptr, v->ref2d, 2, v->b2, v->a2, 2, v->c2, v->ref3d, 3,
+                                     v->a3, v->d_cnt)) ||
+            (rc = svo_launch_fransac(ctx, v->b2, v->c2, n, v->d_cnt, v->prm.f_thr_temporal, 0.99, 1000,
+                                     stage_seed(v, 0), v->mask, nullptr, nullptr, nullptr)) ||
+            (rc = svo_launch_compact(ctx, v->mask, n, v->d_cnt, v->c2, 2, v->trk2d, v->a3, 3, v->trk3d, nullptr, 0,
+                                     nullptr, v->d_cnt + 1)))
+            return rc;
+        // ---- PnP of this frame: stream B when pipelining ----
+        hipStream_t sP = pipeline ? sB : sA;
+        if (pipeline) {
+            SVO_HIP(hipEventRecord(v->ev_a, sA));
+            SVO_HIP(hipStreamWaitEvent(sB, v->ev_a, 0));
+        }
+        ctx->stream = sP;
+        rc = svo_launch_pnp_ransac(ctx, v->trk3d, v->trk2d, n, v->d_cnt + 1, K4, 100, 1.0, 0.99, stage_seed(v, 1), 20,
+                                   v->idx, nullptr, v->d_rec);
+        ctx->stream = sA;
+        if (rc)
+            return rc;
+        hipLaunchKernelGGL(store_count_kernel, dim3(1), dim3(1), 0, sP, v->d_cnt + 1, &v->d_rec->n_tracked);
+        SVO_HIP(hipMemcpyAsync(ctx->pinned, v->d_rec, sizeof(PnpRecord), hipMemcpyDeviceToHost, sP));
+        // ---- speculation for the next frame on stream A ----
+        bool speculated = false;
+        if (pipeline && f + 1 < n_frames) {
+            const uint8_t *d = stage_image(v, lefts[f + 1], mem, &rc);
+            if (rc || (rc = svo_build_pyramid_from_device(ctx, v->pyr_next, d)))
+                return rc;
+            // next frame's reference = this frame's tracked set (count lives in d_cnt[1])
+            if ((rc = svo_launch_lk(ctx, v->pyr_cur->dev, v->pyr_next->dev, v->trk2d, n, v->sa2, v->sstatus, nullptr,
+                                    nullptr, v->d_cnt + 1)))
+                return rc;
+            speculated = true;
+        }
+        if ((rc = svo_wait_stream(ctx, sP)))
+            return rc;
+        if (rec->n_inliers < 10) {  // retry at 8 px / 0.98 (src/keyFrameManagement.cpp:85-92)
+            ctx->stream = sP;
+            rc = svo_launch_pnp_ransac(ctx, v->trk3d, v->trk2d, n, v->d_cnt + 1, K4, 100, 8.0, 0.98, stage_seed(v, 2),
+                                       20, v->idx, nullptr, v->d_rec);
+            ctx->stream = sA;
+            if (rc)
+                return rc;
+            hipLaunchKernelGGL(store_count_kernel, dim3(1), dim3(1), 0, sP, v->d_cnt + 1, &v->d_rec->n_tracked);
+            SVO_HIP(hipMemcpyAsync(ctx->pinned, v->d_rec, sizeof(PnpRecord), hipMemcpyDeviceToHost, sP));
+            if ((rc = svo_wait_stream(ctx, sP)))
+                return rc;
+        }
+        v->ntrk = rec->n_tracked;
+        const int ninl = rec->n_inliers;
+        if (inliers_out)
+            inliers_out[f] = ninl;
+        if (tracked_out)
+            tracked_out[f] = rec->n_tracked;
+        if (ninl < 10) {
+            if (speculated)
+                (void)hipStreamSynchronize(sA);
+            svo_set_error("tracking lost at frame %d: %d PnP inliers", v->frame, ninl);
+            return SVO_ERR_TRACKING_LOST;
+        }
+        double *R9 = R_out + 9 * (size_t)f, *t3 = t_out + 3 * (size_t)f;
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++)
+                R9[3 * i + j] = rec->R[3 * j + i];
+        for (int i = 0; i < 3; i++)
+            t3[i] = -(R9[3 * i] * rec->tvec[0] + R9[3 * i + 1] * rec->tvec[1] + R9[3 * i + 2] * rec->tvec[2]);
+        memcpy(v->R, R9, sizeof(v->R));
+        memcpy(v->t, t3, sizeof(v->t));
+        const bool kf = ninl < v->prm.keyframe_min_inliers;  // src/VisualSLAM.cpp:120
+        if (kf) {
+            const uint8_t *d = stage_image(v, rights[f], mem, &rc);
+            if (rc || (rc = svo_build_pyramid_from_device(ctx, v->pyr_right, d)))
+                return rc;
+            double Rt[12];
+            for (int i = 0; i < 3; i++) {
+                Rt[4 * i] = R9[3 * i];
+                Rt[4 * i + 1] = R9[3 * i + 1];
+                Rt[4 * i + 2] = R9[3 * i + 2];
+                Rt[4 * i + 3] = t3[i];
+            }
+            if ((rc = stereo_triangulate(v, v->pyr_cur, v->pyr_right, Rt, v->ref2d, v->ref3d, &v->nref)))
+                return rc;
+            next_built = speculated;  // the speculative tracking is void, the next pyramid is not
+        } else {
+            std::swap(v->ref2d, v->trk2d);
+            std::swap(v->ref3d, v->trk3d);
+            v->nref = v->ntrk;
+            spec = speculated;
+        }
+        std::swap(v->pyr_ref, v->pyr_cur);
+        if (keyframe_out)
+            keyframe_out[f] = kf ? 1 : 0;
+        if (n_done)
+            *n_done = f + 1;
+    }
+    if (spec || next_built)  // cannot happen (speculation stops at the last frame), kept for safety
+        (void)hipStreamSynchronize(sA);
+    v->has_cur = false;
+    return SVO_OK;
 }
 
 int svo_vo_get_reference(svo_vo *v, float *ref2d, float *ref3d, int cap, int *n, int mem)

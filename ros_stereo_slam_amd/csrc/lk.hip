@@ -226,10 +226,11 @@ __device__ __forceinline__ void lane_residual(const uint8_t *lds, int off, int w
 
 template <int C>
 __global__ __launch_bounds__(64 * WAVES, 3) void lk_track_kernel(
-    PyrDev prev, PyrDev next, const float *__restrict__ prev_pts, int n,
+    PyrDev prev, PyrDev next, const float *__restrict__ prev_pts, int n_cap, const int *__restrict__ d_n,
     float *__restrict__ next_pts, uint8_t *__restrict__ status, float *__restrict__ err,
     float *__restrict__ min_eig_out, LkParams prm)
 {
+    const int n = d_n ? min(*d_n, n_cap) : n_cap;  // live count may sit in HBM (chained stages)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int p = blockIdx.x * WAVES + wave;
@@ -465,7 +466,7 @@ __global__ void grid_keypoints_kernel(int rows, int cols, int step, int nx, int 
 }  // namespace
 
 int svo_launch_lk(svo_ctx *ctx, const PyrDev &prev, const PyrDev &next, const float *prev_pts, int n,
-                  float *next_pts, uint8_t *status, float *err, float *min_eig)
+                  float *next_pts, uint8_t *status, float *err, float *min_eig, const int *d_n)
 {
     if (n == 0)
         return SVO_OK;
@@ -479,11 +480,11 @@ int svo_launch_lk(svo_ctx *ctx, const PyrDev &prev, const PyrDev &next, const fl
     switch (prev.c) {
     case 1:
         hipLaunchKernelGGL(lk_track_kernel<1>, grid, block, WAVES * Lds<1>::WAVE_BYTES, ctx->stream, prev,
-                           next, prev_pts, n, next_pts, status, err, min_eig, prm);
+                           next, prev_pts, n, d_n, next_pts, status, err, min_eig, prm);
         break;
     case 3:
         hipLaunchKernelGGL(lk_track_kernel<3>, grid, block, WAVES * Lds<3>::WAVE_BYTES, ctx->stream, prev,
-                           next, prev_pts, n, next_pts, status, err, min_eig, prm);
+                           next, prev_pts, n, d_n, next_pts, status, err, min_eig, prm);
         break;
     default:
         svo_set_error("lk: unsupported channel count %d (1 or 3)", prev.c);
@@ -561,7 +562,7 @@ int svo_lk_track(svo_ctx *ctx, const svo_pyramid *prev, const svo_pyramid *next,
         return SVO_OK;
     SVO_CHECK_ARG(prev_pts && next_pts && status);
     if (mem == SVO_MEM_DEVICE)
-        return svo_launch_lk(ctx, prev->dev, next->dev, prev_pts, n, next_pts, status, err, min_eig);
+        return svo_launch_lk(ctx, prev->dev, next->dev, prev_pts, n, next_pts, status, err, min_eig, nullptr);
 
     int rc;
     if ((rc = ctx->s_a.ensure((size_t)n * 8)) || (rc = ctx->s_b.ensure((size_t)n * 8)) ||
@@ -570,7 +571,7 @@ int svo_lk_track(svo_ctx *ctx, const svo_pyramid *prev, const svo_pyramid *next,
         return rc;
     SVO_HIP(hipMemcpyAsync(ctx->s_a.p, prev_pts, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
     rc = svo_launch_lk(ctx, prev->dev, next->dev, ctx->s_a.as<float>(), n, ctx->s_b.as<float>(),
-                       ctx->s_c.as<uint8_t>(), ctx->s_d.as<float>(), ctx->s_e.as<float>());
+                       ctx->s_c.as<uint8_t>(), ctx->s_d.as<float>(), ctx->s_e.as<float>(), nullptr);
     if (rc)
         return rc;
     SVO_HIP(hipMemcpyAsync(next_pts, ctx->s_b.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));

@@ -92,6 +92,7 @@ struct svo_ctx {
 // Low-latency host wait for everything queued on the context's stream: records an event and
 // polls it (hipStreamSynchronize parks the thread and costs tens of microseconds to wake).
 int svo_wait(svo_ctx *ctx);
+int svo_wait_stream(svo_ctx *ctx, hipStream_t stream);
 
 // scoped timer: records events around a kernel when ctx->timing is on
 struct ScopedKernelTime {
@@ -107,7 +108,8 @@ int svo_resolve_timers(svo_ctx *ctx);
 int svo_build_pyramid_from_device(svo_ctx *ctx, svo_pyramid *pyr, const uint8_t *d_image);
 // lk.hip
 int svo_launch_lk(svo_ctx *ctx, const PyrDev &prev, const PyrDev &next, const float *prev_pts,
-                  int n, float *next_pts, uint8_t *status, float *err, float *min_eig);
+                  int n, float *next_pts, uint8_t *status, float *err, float *min_eig,
+                  const int *d_n = nullptr);
 int svo_launch_grid(svo_ctx *ctx, int rows, int cols, int step, float *out_xy, int cap);
 
 // fransac.hip

@@ -84,3 +84,30 @@ def test_frontend_tracking_lost(ctx):
     rc, *_ = g.localize(junk)
     assert rc == capi.SVO_ERR_TRACKING_LOST
     g.close()
+
+
+@pytest.mark.parametrize("pipeline", [False, True])
+def test_run_chunk_equals_frame_by_frame(ctx, pipeline):
+    """The chunk runner (optionally with the two-stream PnP / LK overlap and its speculative
+    tracking) must reproduce frame-by-frame svo_vo_track exactly: poses bit for bit, the same
+    keyframes, the same reference set at the end."""
+    import torch
+    poses, frames = _frames(9)
+    dev = [(torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()) for l, r in frames]
+    torch.cuda.synchronize()
+    kw = dict(grid_step=30, keyframe_min_inliers=200, seed=11)
+    a = capi.VisualOdometry(ctx, 1241, 376, 3, **kw)
+    b = capi.VisualOdometry(ctx, 1241, 376, 3, **kw)
+    assert a.init(*dev[0]) == b.init(*dev[0])
+    ref = [a.track(*dev[i]) for i in range(1, 9)]
+    rc, done, R, t, inl, trk, kf = b.run_chunk([d[0] for d in dev[1:]], [d[1] for d in dev[1:]], pipeline=pipeline)
+    assert rc == 0 and done == 8
+    assert kf.any() and not kf.all()        # both the speculation-hit and the discard path ran
+    for i, (rc_i, R_i, t_i, inl_i, kf_i, trk_i) in enumerate(ref):
+        assert np.array_equal(R[i], R_i) and np.array_equal(t[i], t_i), f"frame {i + 1}"
+        assert inl[i] == inl_i and trk[i] == trk_i and bool(kf[i]) == kf_i
+    a2, a3 = a.reference()
+    b2, b3 = b.reference()
+    assert np.array_equal(a2, b2) and np.array_equal(a3, b3)
+    a.close()
+    b.close()
