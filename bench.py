@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--frames", type=int, default=6, help="distinct synthetic stereo frames kept in HBM per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="run the frames strictly serially on one stream")
+    ap.add_argument("--chunks-per-gpu", type=int, default=int(os.environ.get("SVO_CHUNKS_PER_GPU", "1")),
+                    help="independent chunks of the stream run concurrently on each GPU (svo_vo_run_chunks)")
     ap.add_argument("--cpu-frames", type=int, default=24)
     args = ap.parse_args()
 
@@ -79,69 +81,93 @@ def main():
 
     from ros_stereo_slam_amd import capi, synth
 
-    ctx = capi.Context(local_rank)
+    M = max(1, args.chunks_per_gpu)
     scene = synth.Scene()
-    # every rank renders its own contiguous chunk of the stream
-    poses = synth.corridor_trajectory(args.frames * world)[rank * args.frames:(rank + 1) * args.frames]
-    host_frames = [scene.stereo(R, t)[:2] for (R, t) in poses]
-    dev_frames = [(torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()) for l, r in host_frames]
+    # every rank renders its own contiguous chunks of the stream (M per GPU, one context each)
+    all_poses = synth.corridor_trajectory(args.frames * world * M)
+    ctxs, vos, host_frames, dev_frames = [], [], [], []
+    for m in range(M):
+        c0 = (rank * M + m) * args.frames
+        hf = [scene.stereo(R, t)[:2] for (R, t) in all_poses[c0:c0 + args.frames]]
+        host_frames.append(hf)
+        dev_frames.append([(torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()) for l, r in hf])
+        ctxs.append(capi.Context(local_rank))
+        vos.append(capi.VisualOdometry(ctxs[m], W, H, C, grid_step=GRID_STEP, anms_keep=N_KPTS,
+                                       keyframe_min_inliers=KF_MIN_INLIERS, seed=20261003 + m))
     torch.cuda.synchronize()
-
-    vo = capi.VisualOdometry(ctx, W, H, C, grid_step=GRID_STEP, anms_keep=N_KPTS,
-                             keyframe_min_inliers=KF_MIN_INLIERS, seed=20261003)
-    n0 = vo.init(*dev_frames[0])
+    n0 = [vos[m].init(*dev_frames[m][0]) for m in range(M)][0]
 
     stats = {"keyframes": 0, "inliers": 0, "tracked": 0, "lost": 0}
 
-    def run(first: int, count: int, record: bool):
-        """Frames first+1 .. first+count of the ping-pong walk through the chunk runner (one C
-        call, no Python between frames; PnP of frame t overlaps pyramid + LK of frame t+1)."""
-        R = t = None
-        done_total = 0
-        while done_total < count:
-            idx = [pingpong(first + done_total + k + 1, args.frames) for k in range(count - done_total)]
-            rc, done, Rs, ts, inl, trk, kf = vo.run_chunk([dev_frames[i][0] for i in idx],
-                                                          [dev_frames[i][1] for i in idx], pipeline=not args.no_pipeline)
-            if record:
-                stats["keyframes"] += int(kf[:done].sum())
-                stats["inliers"] += int(inl[:done].sum())
-                stats["tracked"] += int(trk[:done].sum())
-            if done:
-                R, t = Rs[done - 1], ts[done - 1]
-            done_total += done
-            if rc:  # tracking lost: re-seed on that frame (the reference would shut down)
-                stats["lost"] += 1
-                vo.init(*dev_frames[idx[done]])
-                done_total += 1
-        return R, t
+    def run(first: int, counts, record: bool):
+        """Frames first+1 .. first+counts[m] of chunk m's ping-pong walk through the chunk runner
+        (one C call, no Python between frames; PnP of frame t overlaps pyramid + LK of frame t+1;
+        the M chunks of this GPU run side by side on their own contexts)."""
+        last = [None] * M
+        done_total = [0] * M
+        while any(done_total[m] < counts[m] for m in range(M)):
+            active = [m for m in range(M) if done_total[m] < counts[m]]
+            idx = {m: [pingpong(first + done_total[m] + k + 1, args.frames) for k in range(counts[m] - done_total[m])]
+                   for m in active}
+            jobs = [(vos[m], [dev_frames[m][i][0] for i in idx[m]], [dev_frames[m][i][1] for i in idx[m]])
+                    for m in active]
+            if M == 1:
+                res = [vos[0].run_chunk(jobs[0][1], jobs[0][2], pipeline=not args.no_pipeline)]
+            else:
+                res = capi.run_chunks(jobs, pipeline=not args.no_pipeline)
+            for m, (rc, done, Rs, ts, inl, trk, kf) in zip(active, res):
+                if record:
+                    stats["keyframes"] += int(kf[:done].sum())
+                    stats["inliers"] += int(inl[:done].sum())
+                    stats["tracked"] += int(trk[:done].sum())
+                if done:
+                    last[m] = (Rs[done - 1], ts[done - 1])
+                done_total[m] += done
+                if rc:  # tracking lost: re-seed on that frame (the reference would shut down)
+                    stats["lost"] += 1
+                    vos[m].init(*dev_frames[m][idx[m][done]])
+                    done_total[m] += 1
+        return last
 
-    run(0, args.warmup, False)
-    ctx.sync()
-    ctx.enable_kernel_timing(True)
-    ctx.reset_kernel_time()
+    def split(total):
+        return [total // M + (1 if m < total % M else 0) for m in range(M)]
+
+    def sync_all():
+        for c in ctxs:
+            c.sync()
+
+    run(0, split(args.warmup * M), False)
+    sync_all()
+    for c in ctxs:
+        c.enable_kernel_timing(True)
+        c.reset_kernel_time()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    ctx.sync()
+    sync_all()
     t0 = time.perf_counter()
-    R, t = run(args.warmup, args.steps, True)
+    last = run(args.warmup, split(args.steps), True)  # EXACTLY --steps frames on this GPU
     if dist is not None:
         # the path's one exchange: chunk-boundary poses, 12 doubles per rank, over RCCL
         from ros_stereo_slam_amd import chunked
 
+        R, t = last[M - 1] if last[M - 1] is not None else (np.eye(3), np.zeros(3))
         boundaries = chunked.all_gather_boundaries(dist, R, t, device="cuda")
         starts = chunked.prefix_transforms(boundaries)  # global pose of every chunk's first frame
         assert len(starts) == world
-    ctx.sync()
+    sync_all()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    times = {name: ctx.kernel_time(kid) for name, kid in
-             (("pyramid", capi.K_PYRAMID), ("lk", capi.K_LK), ("fransac", capi.K_FRANSAC),
-              ("triangulate", capi.K_TRIANGULATE), ("pnp", capi.K_PNP), ("anms", capi.K_ANMS))}
-    ctx.enable_kernel_timing(False)
+    times = {}
+    for name, kid in (("pyramid", capi.K_PYRAMID), ("lk", capi.K_LK), ("fransac", capi.K_FRANSAC),
+                      ("triangulate", capi.K_TRIANGULATE), ("pnp", capi.K_PNP), ("anms", capi.K_ANMS)):
+        per = [c.kernel_time(kid) for c in ctxs]
+        times[name] = (sum(p[0] for p in per), sum(p[1] for p in per))
+    for c in ctxs:
+        c.enable_kernel_timing(False)
 
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -172,7 +198,8 @@ def main():
                             "front-end only (BASELINE configs[1]): pyramid + LK + F-RANSAC + PnP-RANSAC + "
                             "keyframe path (LK L->R, F-RANSAC, DLT triangulation)",
                 "keyframe_min_inliers": KF_MIN_INLIERS,
-                "parallelism": f"one contiguous chunk per GPU x{world}, all-gather of chunk-boundary poses",
+                "parallelism": f"{M} contiguous chunk(s) per GPU x{world} GPU(s), all-gather of chunk-boundary poses",
+                "chunks_per_gpu": M,
                 "pipeline": "serial" if args.no_pipeline else "two HIP streams: PnP(t) beside pyramid+LK(t+1)",
                 "keyframe_rate": kf_rate,
                 "mean_tracked": stats["tracked"] / args.steps,
@@ -200,10 +227,10 @@ def main():
 
             o = orc.VO(W, H, C, grid_step=GRID_STEP, anms_keep=N_KPTS, keyframe_min_inliers=KF_MIN_INLIERS,
                        seed=20261003)
-            o.init(*host_frames[0])
+            o.init(*host_frames[0][0])
             c0 = time.perf_counter()
             for i in range(args.cpu_frames):
-                l, r = host_frames[pingpong(i + 1, args.frames)]
+                l, r = host_frames[0][pingpong(i + 1, args.frames)]
                 rc = o.track(l, r)[0]
                 if rc:
                     o.init(l, r)
@@ -218,8 +245,10 @@ def main():
         print(json.dumps(result))
     if dist is not None:
         dist.destroy_process_group()
-    vo.close()
-    ctx.close()
+    for v in vos:
+        v.close()
+    for c in ctxs:
+        c.close()
 
 
 if __name__ == "__main__":

@@ -195,6 +195,23 @@ int svo_vo_track(svo_vo *vo, const uint8_t *left, const uint8_t *right, int mem,
 int svo_vo_run_chunk(svo_vo *vo, const uint8_t *const *lefts, const uint8_t *const *rights, int n_frames,
                      int mem, int pipeline, double *R_out, double *t_out, int *inliers_out,
                      int *tracked_out, uint8_t *keyframe_out, int *n_done);
+/* Several independent chunks of a stream at once on ONE GPU (the per-GPU form of SURVEY.md 8e's
+ * chunk sharding): every job is one svo_vo_run_chunk() call on its own host thread.  The
+ * front-end's kernels are latency-bound (one wave per keypoint / hypothesis, a few hundred to a
+ * few thousand waves per launch), so chunks on separate contexts interleave on the chip.  Each
+ * job's svo_vo must live on its own svo_ctx.  rc / n_done are filled per job; the return value is
+ * the first failing job's code other than SVO_ERR_TRACKING_LOST, else SVO_OK.                   */
+typedef struct svo_chunk_job {
+    svo_vo *vo;
+    const uint8_t *const *lefts;
+    const uint8_t *const *rights;
+    int n_frames, mem, pipeline;
+    double *R_out, *t_out;
+    int *inliers_out, *tracked_out;
+    uint8_t *keyframe_out;
+    int n_done, rc;
+} svo_chunk_job;
+int svo_vo_run_chunks(svo_chunk_job *jobs, int n_jobs);
 /* the current reference point set (2-D in the reference image, 3-D world) */
 int svo_vo_get_reference(svo_vo *vo, float *ref2d, float *ref3d, int cap, int *n, int mem);
 int svo_vo_capacity(const svo_vo *vo);

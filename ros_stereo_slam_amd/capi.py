@@ -375,6 +375,37 @@ class VisualOdometry:
             pass
 
 
+class _ChunkJob(C.Structure):
+    _fields_ = [("vo", C.c_void_p), ("lefts", C.c_void_p), ("rights", C.c_void_p), ("n_frames", C.c_int),
+                ("mem", C.c_int), ("pipeline", C.c_int), ("R_out", C.c_void_p), ("t_out", C.c_void_p),
+                ("inliers_out", C.c_void_p), ("tracked_out", C.c_void_p), ("keyframe_out", C.c_void_p),
+                ("n_done", C.c_int), ("rc", C.c_int)]
+
+
+def run_chunks(jobs, pipeline: bool = True):
+    """``svo_vo_run_chunks``: jobs = [(vo, lefts, rights), ...], one VisualOdometry per Context.
+    Returns one (rc, n_done, R, t, inliers, tracked, keyframe) tuple per job."""
+    arr = (_ChunkJob * len(jobs))()
+    keep, outs = [], []
+    for k, (vo, lefts, rights) in enumerate(jobs):
+        n = len(lefts)
+        PtrArr = C.c_void_p * max(n, 1)
+        la = PtrArr(*[_ptr(x).value for x in lefts])
+        ra = PtrArr(*[_ptr(x).value for x in rights])
+        R, t = np.zeros((n, 3, 3)), np.zeros((n, 3))
+        inl, trk = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        kf = np.zeros(n, np.uint8)
+        keep.append((la, ra))
+        outs.append((R, t, inl, trk, kf))
+        j = arr[k]
+        j.vo, j.lefts, j.rights = vo._h, C.addressof(la), C.addressof(ra)
+        j.n_frames, j.mem, j.pipeline = n, (vo._mem(lefts[0]) if n else MEM_DEVICE), int(bool(pipeline))
+        j.R_out, j.t_out, j.inliers_out = _ptr(R), _ptr(t), _ptr(inl)
+        j.tracked_out, j.keyframe_out = _ptr(trk), _ptr(kf)
+    _check(jobs[0][0].ctx.lib.svo_vo_run_chunks(arr, len(jobs)))
+    return [(arr[k].rc, arr[k].n_done, *outs[k][:4], outs[k][4].astype(bool)) for k in range(len(jobs))]
+
+
 class PoseGraph:
     """SE3 pose graph on the GPU (``svo_posegraph``), mirroring globalPoseGraph
     (include/poseGraph.h:36-179).  Poses: tx ty tz qx qy qz qw."""

@@ -16,6 +16,9 @@
 // context's stream with device-side counts chained between stages, and reads back ONE
 // 144-byte record (pose, inlier count, tracked count) -- the values the reference's host
 // policy branches on (inliers < 10: retry / shutdown; inliers < 200: keyframe).
+#include <string>
+#include <thread>
+#include <vector>
 #include <cmath>
 
 #include "svo_internal.h"
@@ -33,6 +36,8 @@ struct svo_vo {
     svo_pyramid *pyr_ref = nullptr, *pyr_cur = nullptr, *pyr_right = nullptr, *pyr_next = nullptr;
     hipStream_t stream_b = nullptr;          // second stream: PnP of frame t beside pyramid + LK of frame t+1
     hipEvent_t ev_a = nullptr;               // "tracked sets of frame t are ready" (stream A -> B)
+    hipEvent_t ev_early = nullptr;           // PnP inlier count of frame t is on the host
+    hipEvent_t ev_pose[2] = {nullptr, nullptr};  // refined pose record of frame t (slot t & 1) is on the host
     float *sa2 = nullptr;                    // speculative LK output for frame t+1
     uint8_t *sstatus = nullptr;
     // point sets (device)
@@ -202,12 +207,15 @@ int svo_vo_create(svo_ctx *ctx, const svo_vo_params *params, int width, int heig
         (rc = dev_alloc(&v->d2, n * 2)) || (rc = dev_alloc(&v->a3, n * 3)) || (rc = dev_alloc(&v->b3, n * 3)) ||
         (rc = dev_alloc(&v->resp, n)) || (rc = dev_alloc(&v->status, n)) || (rc = dev_alloc(&v->mask, n)) ||
         (rc = dev_alloc(&v->st2, n)) || (rc = dev_alloc(&v->idx, n)) || (rc = dev_alloc(&v->d_cnt, 16)) ||
-        (rc = dev_alloc(&v->d_rec, 1)) || (rc = dev_alloc(&v->d_img, (size_t)width * height * channels))) {
+        (rc = dev_alloc(&v->d_rec, 2)) || (rc = dev_alloc(&v->d_img, (size_t)width * height * channels))) {
         svo_vo_destroy(v);
         return rc;
     }
     if (hipStreamCreateWithFlags(&v->stream_b, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&v->ev_a, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&v->ev_a, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&v->ev_early, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&v->ev_pose[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&v->ev_pose[1], hipEventDisableTiming) != hipSuccess) {
         svo_set_error("front-end: cannot create the second stream / event");
         svo_vo_destroy(v);
         return SVO_ERR_HIP;
@@ -235,6 +243,11 @@ int svo_vo_destroy(svo_vo *v)
     }
     if (v->ev_a)
         (void)hipEventDestroy(v->ev_a);
+    if (v->ev_early)
+        (void)hipEventDestroy(v->ev_early);
+    for (hipEvent_t e : v->ev_pose)
+        if (e)
+            (void)hipEventDestroy(e);
     if (v->sa2)
         (void)hipFree(v->sa2);
     if (v->sstatus)
@@ -414,13 +427,40 @@ int svo_vo_run_chunk(svo_vo *v, const uint8_t *const *lefts, const uint8_t *cons
     if (mem == SVO_MEM_HOST)
         pipeline = 0;  // host images go through one staging buffer; keep them strictly in order
     const double K4[4] = {v->prm.fx, v->prm.fy, v->prm.cx, v->prm.cy};
-    const PnpRecord *rec = reinterpret_cast<const PnpRecord *>(ctx->pinned);
+    // pinned layout: pose records of even / odd frames at 0 / 256, the early (count, tracked) pair at 512
+    uint8_t *pin = reinterpret_cast<uint8_t *>(ctx->pinned);
+    int *h_early = reinterpret_cast<int *>(pin + 512);
     bool spec = false, next_built = false;
+    int pending = -1;  // frame whose refined pose has not been collected yet
     int rc;
+    auto wait_event = [&](hipEvent_t ev) -> int {
+        for (;;) {
+            hipError_t e = hipEventQuery(ev);
+            if (e == hipSuccess)
+                return SVO_OK;
+            if (e != hipErrorNotReady) {
+                svo_set_error("hipEventQuery -> %s", hipGetErrorString(e));
+                return SVO_ERR_HIP;
+            }
+        }
+    };
+    auto harvest = [&](int f) {  // record of frame f is on the host: pose composition (src/VisualSLAM.cpp:70-74)
+        const PnpRecord *rec = reinterpret_cast<const PnpRecord *>(pin + 256 * (f & 1));
+        double *R9 = R_out + 9 * (size_t)f, *t3 = t_out + 3 * (size_t)f;
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++)
+                R9[3 * i + j] = rec->R[3 * j + i];
+        for (int i = 0; i < 3; i++)
+            t3[i] = -(R9[3 * i] * rec->tvec[0] + R9[3 * i + 1] * rec->tvec[1] + R9[3 * i + 2] * rec->tvec[2]);
+        memcpy(v->R, R9, sizeof(v->R));
+        memcpy(v->t, t3, sizeof(v->t));
+    };
     for (int f = 0; f < n_frames; f++) {
         v->frame++;
         const int n = v->nref;
         if (n < 5) {
+            if (pending >= 0 && wait_event(v->ev_pose[pending & 1]) == SVO_OK)
+                harvest(pending);
             svo_set_error("tracking lost: %d reference points", n);
             return SVO_ERR_TRACKING_LOST;
         }
@@ -441,12 +481,16 @@ int svo_vo_run_chunk(svo_vo *v, const uint8_t *const *lefts, const uint8_t *cons
                 return rc;
         }
         spec = next_built = false;
+        // the tracked-point count alternates between two device slots: the refinement of frame
+        // f-1 (stream B) may still read its slot while this frame's filters (stream A) write theirs
+        int *cnt_trk = v->d_cnt + ((f & 1) ? 9 : 1);
+        PnpRecord *d_rec = v->d_rec + (f & 1);
         if ((rc = svo_launch_compact(ctx, v->status, n, nullptr, v->ref2d, 2, v->b2, v->a2, 2, v->c2, v->ref3d, 3,
                                      v->a3, v->d_cnt)) ||
             (rc = svo_launch_fransac(ctx, v->b2, v->c2, n, v->d_cnt, v->prm.f_thr_temporal, 0.99, 1000,
                                      stage_seed(v, 0), v->mask, nullptr, nullptr, nullptr)) ||
             (rc = svo_launch_compact(ctx, v->mask, n, v->d_cnt, v->c2, 2, v->trk2d, v->a3, 3, v->trk3d, nullptr, 0,
-                                     nullptr, v->d_cnt + 1)))
+                                     nullptr, cnt_trk)))
             return rc;
         // ---- PnP of this frame: stream B when pipelining ----
         hipStream_t sP = pipeline ? sB : sA;
@@ -454,65 +498,68 @@ int svo_vo_run_chunk(svo_vo *v, const uint8_t *const *lefts, const uint8_t *cons
             SVO_HIP(hipEventRecord(v->ev_a, sA));
             SVO_HIP(hipStreamWaitEvent(sB, v->ev_a, 0));
         }
-        ctx->stream = sP;
-        rc = svo_launch_pnp_ransac(ctx, v->trk3d, v->trk2d, n, v->d_cnt + 1, K4, 100, 1.0, 0.99, stage_seed(v, 1), 20,
-                                   v->idx, nullptr, v->d_rec);
-        ctx->stream = sA;
-        if (rc)
+        auto launch_pnp = [&](double thr, double conf, int stage) -> int {
+            ctx->stream = sP;
+            int r = svo_launch_pnp_ransac(ctx, v->trk3d, v->trk2d, n, cnt_trk, K4, 100, thr, conf, stage_seed(v, stage),
+                                          20, v->idx, nullptr, d_rec, h_early, v->ev_early);
+            ctx->stream = sA;
+            if (r)
+                return r;
+            hipLaunchKernelGGL(store_count_kernel, dim3(1), dim3(1), 0, sP, cnt_trk, &d_rec->n_tracked);
+            SVO_HIP(hipMemcpyAsync(pin + 256 * (f & 1), d_rec, sizeof(PnpRecord), hipMemcpyDeviceToHost, sP));
+            SVO_HIP(hipEventRecord(v->ev_pose[f & 1], sP));
+            return SVO_OK;
+        };
+        if ((rc = launch_pnp(1.0, 0.99, 1)))
             return rc;
-        hipLaunchKernelGGL(store_count_kernel, dim3(1), dim3(1), 0, sP, v->d_cnt + 1, &v->d_rec->n_tracked);
-        SVO_HIP(hipMemcpyAsync(ctx->pinned, v->d_rec, sizeof(PnpRecord), hipMemcpyDeviceToHost, sP));
         // ---- speculation for the next frame on stream A ----
         bool speculated = false;
         if (pipeline && f + 1 < n_frames) {
             const uint8_t *d = stage_image(v, lefts[f + 1], mem, &rc);
             if (rc || (rc = svo_build_pyramid_from_device(ctx, v->pyr_next, d)))
                 return rc;
-            // next frame's reference = this frame's tracked set (count lives in d_cnt[1])
+            // next frame's reference = this frame's tracked set (its count lives in cnt_trk)
             if ((rc = svo_launch_lk(ctx, v->pyr_cur->dev, v->pyr_next->dev, v->trk2d, n, v->sa2, v->sstatus, nullptr,
-                                    nullptr, v->d_cnt + 1)))
+                                    nullptr, cnt_trk)))
                 return rc;
             speculated = true;
         }
-        if ((rc = svo_wait_stream(ctx, sP)))
+        // ---- the policy needs only the RANSAC inlier count: known before mask / refinement end ----
+        if ((rc = wait_event(v->ev_early)))
             return rc;
-        if (rec->n_inliers < 10) {  // retry at 8 px / 0.98 (src/keyFrameManagement.cpp:85-92)
-            ctx->stream = sP;
-            rc = svo_launch_pnp_ransac(ctx, v->trk3d, v->trk2d, n, v->d_cnt + 1, K4, 100, 8.0, 0.98, stage_seed(v, 2),
-                                       20, v->idx, nullptr, v->d_rec);
-            ctx->stream = sA;
-            if (rc)
-                return rc;
-            hipLaunchKernelGGL(store_count_kernel, dim3(1), dim3(1), 0, sP, v->d_cnt + 1, &v->d_rec->n_tracked);
-            SVO_HIP(hipMemcpyAsync(ctx->pinned, v->d_rec, sizeof(PnpRecord), hipMemcpyDeviceToHost, sP));
-            if ((rc = svo_wait_stream(ctx, sP)))
-                return rc;
+        if (pending >= 0) {  // stream B runs in order: frame f-1's record landed before this count
+            harvest(pending);
+            pending = -1;
         }
-        v->ntrk = rec->n_tracked;
-        const int ninl = rec->n_inliers;
+        int ninl = h_early[0];
+        if (ninl < 10) {  // retry at 8 px / 0.98 (src/keyFrameManagement.cpp:85-92)
+            if ((rc = wait_event(v->ev_pose[f & 1])) || (rc = launch_pnp(8.0, 0.98, 2)) ||
+                (rc = wait_event(v->ev_early)))
+                return rc;
+            ninl = h_early[0];
+        }
+        v->ntrk = h_early[1];
         if (inliers_out)
             inliers_out[f] = ninl;
         if (tracked_out)
-            tracked_out[f] = rec->n_tracked;
+            tracked_out[f] = v->ntrk;
         if (ninl < 10) {
+            (void)hipStreamSynchronize(sP);
             if (speculated)
                 (void)hipStreamSynchronize(sA);
             svo_set_error("tracking lost at frame %d: %d PnP inliers", v->frame, ninl);
             return SVO_ERR_TRACKING_LOST;
         }
-        double *R9 = R_out + 9 * (size_t)f, *t3 = t_out + 3 * (size_t)f;
-        for (int i = 0; i < 3; i++)
-            for (int j = 0; j < 3; j++)
-                R9[3 * i + j] = rec->R[3 * j + i];
-        for (int i = 0; i < 3; i++)
-            t3[i] = -(R9[3 * i] * rec->tvec[0] + R9[3 * i + 1] * rec->tvec[1] + R9[3 * i + 2] * rec->tvec[2]);
-        memcpy(v->R, R9, sizeof(v->R));
-        memcpy(v->t, t3, sizeof(v->t));
         const bool kf = ninl < v->prm.keyframe_min_inliers;  // src/VisualSLAM.cpp:120
         if (kf) {
+            // the keyframe's points are placed with the refined pose: wait for it
+            if ((rc = wait_event(v->ev_pose[f & 1])))
+                return rc;
+            harvest(f);
             const uint8_t *d = stage_image(v, rights[f], mem, &rc);
             if (rc || (rc = svo_build_pyramid_from_device(ctx, v->pyr_right, d)))
                 return rc;
+            const double *R9 = R_out + 9 * (size_t)f, *t3 = t_out + 3 * (size_t)f;
             double Rt[12];
             for (int i = 0; i < 3; i++) {
                 Rt[4 * i] = R9[3 * i];
@@ -524,6 +571,7 @@ int svo_vo_run_chunk(svo_vo *v, const uint8_t *const *lefts, const uint8_t *cons
                 return rc;
             next_built = speculated;  // the speculative tracking is void, the next pyramid is not
         } else {
+            pending = f;  // its refinement may still be running beside the next frame's filters
             std::swap(v->ref2d, v->trk2d);
             std::swap(v->ref3d, v->trk3d);
             v->nref = v->ntrk;
@@ -535,10 +583,55 @@ int svo_vo_run_chunk(svo_vo *v, const uint8_t *const *lefts, const uint8_t *cons
         if (n_done)
             *n_done = f + 1;
     }
-    if (spec || next_built)  // cannot happen (speculation stops at the last frame), kept for safety
-        (void)hipStreamSynchronize(sA);
+    if (pending >= 0) {
+        if ((rc = wait_event(v->ev_pose[pending & 1])))
+            return rc;
+        harvest(pending);
+    }
     v->has_cur = false;
     return SVO_OK;
+}
+
+int svo_vo_run_chunks(svo_chunk_job *jobs, int n_jobs)
+{
+    SVO_CHECK_ARG(jobs && n_jobs >= 1);
+    for (int a = 0; a < n_jobs; a++) {
+        SVO_CHECK_ARG(jobs[a].vo != nullptr);
+        for (int b = 0; b < a; b++)
+            if (jobs[a].vo->ctx == jobs[b].vo->ctx) {
+                svo_set_error("svo_vo_run_chunks: jobs %d and %d share a context", b, a);
+                return SVO_ERR_ARG;
+            }
+    }
+    std::vector<std::string> errs(n_jobs);
+    auto body = [&](int a) {
+        svo_chunk_job &j = jobs[a];
+        j.n_done = 0;
+        if (hipSetDevice(j.vo->ctx->device) != hipSuccess) {  // the current device is per host thread
+            j.rc = SVO_ERR_HIP;
+            errs[a] = "hipSetDevice failed";
+            return;
+        }
+        j.rc = svo_vo_run_chunk(j.vo, j.lefts, j.rights, j.n_frames, j.mem, j.pipeline, j.R_out, j.t_out,
+                                j.inliers_out, j.tracked_out, j.keyframe_out, &j.n_done);
+        if (j.rc)
+            errs[a] = svo_last_error();  // the error text is thread-local
+    };
+    std::vector<std::thread> th;
+    for (int a = 1; a < n_jobs; a++)
+        th.emplace_back(body, a);
+    body(0);
+    for (auto &t : th)
+        t.join();
+    int rc = SVO_OK;
+    for (int a = 0; a < n_jobs; a++)
+        if (jobs[a].rc) {
+            if (rc == SVO_OK || (rc == SVO_ERR_TRACKING_LOST && jobs[a].rc != SVO_ERR_TRACKING_LOST)) {
+                rc = jobs[a].rc;
+                svo_set_error("chunk %d: %s", a, errs[a].c_str());
+            }
+        }
+    return rc == SVO_ERR_TRACKING_LOST ? SVO_OK : rc;
 }
 
 int svo_vo_get_reference(svo_vo *v, float *ref2d, float *ref3d, int cap, int *n, int mem)

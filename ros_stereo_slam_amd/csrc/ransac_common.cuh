@@ -69,7 +69,7 @@ template <int MPI>
 __global__ void ransac_select_kernel(RansacState *st, int first, int it_end, int max_iters, int n_host,
                                      const int *__restrict__ d_n, double confidence,
                                      const int *__restrict__ nmodels, const int *__restrict__ counts,
-                                     int model_points)
+                                     int model_points, int *__restrict__ early_out = nullptr)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0)
         return;
@@ -120,6 +120,10 @@ __global__ void ransac_select_kernel(RansacState *st, int first, int it_end, int
     s.next_iter = it;
     s.iters_run = it;
     *st = s;
+    if (early_out) {  // what the host policy branches on, available before the refinement runs
+        early_out[0] = s.best_iter >= 0 ? s.best_count : 0;
+        early_out[1] = n;
+    }
 }
 
 // hand-off of LDS data between lanes of ONE wave (LDS ops of a wave execute in order; this

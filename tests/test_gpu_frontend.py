@@ -111,3 +111,34 @@ def test_run_chunk_equals_frame_by_frame(ctx, pipeline):
     assert np.array_equal(a2, b2) and np.array_equal(a3, b3)
     a.close()
     b.close()
+
+
+def test_run_chunks_side_by_side_equals_one_by_one(ctx):
+    """svo_vo_run_chunks (several chunks of the stream at once on one GPU, one context and one
+    host thread each) must give every chunk exactly what svo_vo_run_chunk gives it alone."""
+    import torch
+    poses, frames = _frames(12)
+    dev = [(torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()) for l, r in frames]
+    torch.cuda.synchronize()
+    kw = dict(grid_step=30, keyframe_min_inliers=200)
+    chunks = [dev[0:4], dev[4:8], dev[8:12]]
+    alone = []
+    for k, ch in enumerate(chunks):
+        v = capi.VisualOdometry(ctx, 1241, 376, 3, seed=5 + k, **kw)
+        v.init(*ch[0])
+        alone.append(v.run_chunk([d[0] for d in ch[1:]], [d[1] for d in ch[1:]]))
+        v.close()
+    ctxs = [capi.Context(0) for _ in chunks]
+    vos = [capi.VisualOdometry(c, 1241, 376, 3, seed=5 + k, **kw) for k, c in enumerate(ctxs)]
+    for v, ch in zip(vos, chunks):
+        v.init(*ch[0])
+    res = capi.run_chunks([(v, [d[0] for d in ch[1:]], [d[1] for d in ch[1:]]) for v, ch in zip(vos, chunks)])
+    for one, par in zip(alone, res):
+        assert one[0] == par[0] == 0 and one[1] == par[1] == 3
+        for x, y in zip(one[2:], par[2:]):
+            assert np.array_equal(x, y)
+    with pytest.raises(capi.SvoError):  # two jobs on one context are refused
+        w = capi.VisualOdometry(ctxs[0], 1241, 376, 3, **kw)
+        capi.run_chunks([(vos[0], [], []), (w, [], [])])
+    for c in ctxs:
+        c.close()
