@@ -58,10 +58,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--frames", type=int, default=6, help="distinct synthetic stereo frames kept in HBM per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-pipeline", action="store_true", help="run the frames strictly serially on one stream")
-    ap.add_argument("--chunks-per-gpu", type=int, default=int(os.environ.get("SVO_CHUNKS_PER_GPU", "1")),
-                    help="independent chunks of the stream run concurrently on each GPU (svo_vo_run_chunks)")
+    ap.add_argument("--pipeline", choices=("auto", "on", "off"), default="auto",
+                    help="two-stream overlap of PnP(t) with pyramid + LK(t+1) inside a chunk; auto = on for one "
+                         "chunk per GPU, off when several chunks already fill the hardware queues")
+    ap.add_argument("--chunks-per-gpu", type=int, default=int(os.environ.get("SVO_CHUNKS_PER_GPU", "4")),
+                    help="independent chunks of the stream run side by side on each GPU (svo_vo_run_chunks); "
+                         "4 = one in-order stream per default HIP hardware queue")
     ap.add_argument("--cpu-frames", type=int, default=24)
+    ap.add_argument("--no-kernel-timing", action="store_true",
+                    help="diagnostic: no HIP events around the kernels (the roofline object is then empty)")
     args = ap.parse_args()
 
     import torch
@@ -82,6 +87,7 @@ def main():
     from ros_stereo_slam_amd import capi, synth
 
     M = max(1, args.chunks_per_gpu)
+    pipeline = args.pipeline == "on" or (args.pipeline == "auto" and M == 1)
     scene = synth.Scene()
     # every rank renders its own contiguous chunks of the stream (M per GPU, one context each)
     all_poses = synth.corridor_trajectory(args.frames * world * M)
@@ -112,9 +118,9 @@ def main():
             jobs = [(vos[m], [dev_frames[m][i][0] for i in idx[m]], [dev_frames[m][i][1] for i in idx[m]])
                     for m in active]
             if M == 1:
-                res = [vos[0].run_chunk(jobs[0][1], jobs[0][2], pipeline=not args.no_pipeline)]
+                res = [vos[0].run_chunk(jobs[0][1], jobs[0][2], pipeline=pipeline)]
             else:
-                res = capi.run_chunks(jobs, pipeline=not args.no_pipeline)
+                res = capi.run_chunks(jobs, pipeline=pipeline)
             for m, (rc, done, Rs, ts, inl, trk, kf) in zip(active, res):
                 if record:
                     stats["keyframes"] += int(kf[:done].sum())
@@ -139,7 +145,7 @@ def main():
     run(0, split(args.warmup * M), False)
     sync_all()
     for c in ctxs:
-        c.enable_kernel_timing(True)
+        c.enable_kernel_timing(not args.no_kernel_timing)
         c.reset_kernel_time()
     if dist is not None:
         dist.barrier()
@@ -151,10 +157,10 @@ def main():
         # the path's one exchange: chunk-boundary poses, 12 doubles per rank, over RCCL
         from ros_stereo_slam_amd import chunked
 
-        R, t = last[M - 1] if last[M - 1] is not None else (np.eye(3), np.zeros(3))
-        boundaries = chunked.all_gather_boundaries(dist, R, t, device="cuda")
+        pairs = [p if p is not None else (np.eye(3), np.zeros(3)) for p in last]
+        boundaries = chunked.all_gather_chunk_boundaries(dist, pairs, device="cuda")
         starts = chunked.prefix_transforms(boundaries)  # global pose of every chunk's first frame
-        assert len(starts) == world
+        assert len(starts) == world * M
     sync_all()
     torch.cuda.synchronize()
     if dist is not None:
@@ -168,6 +174,19 @@ def main():
         times[name] = (sum(p[0] for p in per), sum(p[1] for p in per))
     for c in ctxs:
         c.enable_kernel_timing(False)
+
+    # beside the throughput figure: ONE chunk alone with the two-stream pipeline (what a single
+    # live stream gets); reported in config, not part of the timed K steps above
+    single_fps = None
+    if M > 1 and rank == 0:
+        first = args.warmup + split(args.steps)[0]
+        idx = [pingpong(first + k + 1, args.frames) for k in range(args.steps)]
+        s0 = time.perf_counter()
+        rc1, done1, *_ = vos[0].run_chunk([dev_frames[0][i][0] for i in idx], [dev_frames[0][i][1] for i in idx],
+                                          pipeline=True)
+        ctxs[0].sync()
+        if rc1 == 0:
+            single_fps = done1 / (time.perf_counter() - s0)
 
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -200,7 +219,9 @@ def main():
                 "keyframe_min_inliers": KF_MIN_INLIERS,
                 "parallelism": f"{M} contiguous chunk(s) per GPU x{world} GPU(s), all-gather of chunk-boundary poses",
                 "chunks_per_gpu": M,
-                "pipeline": "serial" if args.no_pipeline else "two HIP streams: PnP(t) beside pyramid+LK(t+1)",
+                "single_chunk_pipelined_frames_per_s": single_fps,
+                "pipeline": "two HIP streams per chunk: PnP(t) beside pyramid+LK(t+1)" if pipeline
+                            else "one in-order HIP stream per chunk",
                 "keyframe_rate": kf_rate,
                 "mean_tracked": stats["tracked"] / args.steps,
                 "mean_pnp_inliers": stats["inliers"] / args.steps,

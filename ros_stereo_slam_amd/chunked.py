@@ -73,6 +73,26 @@ def all_gather_boundaries(dist, R, t, device=None):
     return res
 
 
+def all_gather_chunk_boundaries(dist, pairs, device=None):
+    """As :func:`all_gather_boundaries` when every rank runs several chunks side by side
+    (``svo_vo_run_chunks``): ``pairs`` = this rank's chunk-boundary poses in chunk order, the
+    same number on every rank.  Still ONE all-gather (12 doubles per chunk); returns the
+    boundaries of all chunks in global chunk order (rank-major)."""
+    import torch
+
+    dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
+    flat = np.concatenate([np.r_[np.asarray(R, np.float64).ravel(), np.asarray(t, np.float64).ravel()]
+                           for R, t in pairs])
+    mine = torch.tensor(flat, dtype=torch.float64, device=dev)
+    got = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(got, mine)
+    res = []
+    for g in got:
+        a = g.cpu().numpy().reshape(-1, 12)
+        res.extend((row[:9].reshape(3, 3).copy(), row[9:].copy()) for row in a)
+    return res
+
+
 def gather_trajectories(dist, poses, device=None):
     """All ranks receive every rank's (rebased) pose list; used to build the global pose graph.
     Chunks may differ in length by one frame, so lists are padded to the longest."""

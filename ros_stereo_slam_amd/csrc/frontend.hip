@@ -29,15 +29,24 @@ struct PnpRecord {  // layout of pnp.hip's PnpResult + the tracked-point count b
     int n_tracked, pad;
 };
 
+// Pinned, fine-grained host memory the chunk runner's kernels publish into; the host spins on the
+// tags instead of asking the runtime about events (no copy engine, no runtime lock on the way).
+struct Mailbox {
+    int early[4];     // tag, RANSAC inlier count, tracked points
+    int pose_tag[2];  // per record slot
+    int pad[2];
+    PnpRecord rec[2];
+};
+
 struct svo_vo {
     svo_ctx *ctx = nullptr;
+    Mailbox *mbox = nullptr;
+    int tag = 0;
     svo_vo_params prm;
     int w = 0, h = 0, c = 0, cap = 0;
     svo_pyramid *pyr_ref = nullptr, *pyr_cur = nullptr, *pyr_right = nullptr, *pyr_next = nullptr;
     hipStream_t stream_b = nullptr;          // second stream: PnP of frame t beside pyramid + LK of frame t+1
     hipEvent_t ev_a = nullptr;               // "tracked sets of frame t are ready" (stream A -> B)
-    hipEvent_t ev_early = nullptr;           // PnP inlier count of frame t is on the host
-    hipEvent_t ev_pose[2] = {nullptr, nullptr};  // refined pose record of frame t (slot t & 1) is on the host
     float *sa2 = nullptr;                    // speculative LK output for frame t+1
     uint8_t *sstatus = nullptr;
     // point sets (device)
@@ -89,6 +98,25 @@ __global__ void gather_kernel(const int *__restrict__ idx, const int *__restrict
 }
 
 __global__ void store_count_kernel(const int *__restrict__ src, int *__restrict__ dst) { *dst = *src; }
+
+// One wave: completes the pose record with the tracked-point count and publishes it into the
+// pinned mailbox slot, then releases the slot's tag at system scope.
+__global__ void publish_record_kernel(PnpRecord *__restrict__ d_rec, const int *__restrict__ cnt, PnpRecord *h_rec,
+                                      int *h_tag, int tag)
+{
+    constexpr int WORDS = sizeof(PnpRecord) / 4, TRACKED = offsetof(PnpRecord, n_tracked) / 4;
+    const int l = threadIdx.x;
+    if (l < WORDS) {
+        int w = l == TRACKED ? *cnt : reinterpret_cast<const int *>(d_rec)[l];
+        if (l == TRACKED)
+            d_rec->n_tracked = w;
+        reinterpret_cast<int *>(h_rec)[l] = w;
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (l == 0)
+        __hip_atomic_store(h_tag, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 const uint8_t *stage_image(svo_vo *v, const uint8_t *img, int mem, int *rc)
 {
@@ -213,9 +241,8 @@ int svo_vo_create(svo_ctx *ctx, const svo_vo_params *params, int width, int heig
     }
     if (hipStreamCreateWithFlags(&v->stream_b, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&v->ev_a, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&v->ev_early, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&v->ev_pose[0], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&v->ev_pose[1], hipEventDisableTiming) != hipSuccess) {
+        hipHostMalloc(reinterpret_cast<void **>(&v->mbox), sizeof(Mailbox),
+                      hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
         svo_set_error("front-end: cannot create the second stream / event");
         svo_vo_destroy(v);
         return SVO_ERR_HIP;
@@ -243,11 +270,8 @@ int svo_vo_destroy(svo_vo *v)
     }
     if (v->ev_a)
         (void)hipEventDestroy(v->ev_a);
-    if (v->ev_early)
-        (void)hipEventDestroy(v->ev_early);
-    for (hipEvent_t e : v->ev_pose)
-        if (e)
-            (void)hipEventDestroy(e);
+    if (v->mbox)
+        (void)hipHostFree(v->mbox);
     if (v->sa2)
         (void)hipFree(v->sa2);
     if (v->sstatus)
@@ -427,25 +451,29 @@ int svo_vo_run_chunk(svo_vo *v, const uint8_t *const *lefts, const uint8_t *cons
     if (mem == SVO_MEM_HOST)
         pipeline = 0;  // host images go through one staging buffer; keep them strictly in order
     const double K4[4] = {v->prm.fx, v->prm.fy, v->prm.cx, v->prm.cy};
-    // pinned layout: pose records of even / odd frames at 0 / 256, the early (count, tracked) pair at 512
-    uint8_t *pin = reinterpret_cast<uint8_t *>(ctx->pinned);
-    int *h_early = reinterpret_cast<int *>(pin + 512);
+    Mailbox *mb = v->mbox;
+    int early_tag = 0, pose_tag[2] = {0, 0};
     bool spec = false, next_built = false;
     int pending = -1;  // frame whose refined pose has not been collected yet
     int rc;
-    auto wait_event = [&](hipEvent_t ev) -> int {
-        for (;;) {
-            hipError_t e = hipEventQuery(ev);
-            if (e == hipSuccess)
+    // spin on a tag a kernel releases into the mailbox; now and then make sure the stream is alive
+    auto wait_tag = [&](const int *slot, int tag, hipStream_t stream) -> int {
+        for (unsigned spins = 1;; spins++) {
+            if (__atomic_load_n(slot, __ATOMIC_ACQUIRE) == tag)
                 return SVO_OK;
-            if (e != hipErrorNotReady) {
-                svo_set_error("hipEventQuery -> %s", hipGetErrorString(e));
-                return SVO_ERR_HIP;
+            if ((spins & 0x3FFFF) == 0) {
+                hipError_t e = hipStreamQuery(stream);
+                if (e == hipSuccess && __atomic_load_n(slot, __ATOMIC_ACQUIRE) != tag)
+                    e = hipErrorUnknown;  // drained without publishing
+                if (e != hipSuccess && e != hipErrorNotReady) {
+                    svo_set_error("waiting for the PnP mailbox -> %s", hipGetErrorString(e));
+                    return SVO_ERR_HIP;
+                }
             }
         }
     };
     auto harvest = [&](int f) {  // record of frame f is on the host: pose composition (src/VisualSLAM.cpp:70-74)
-        const PnpRecord *rec = reinterpret_cast<const PnpRecord *>(pin + 256 * (f & 1));
+        const PnpRecord *rec = &mb->rec[f & 1];
         double *R9 = R_out + 9 * (size_t)f, *t3 = t_out + 3 * (size_t)f;
         for (int i = 0; i < 3; i++)
             for (int j = 0; j < 3; j++)
@@ -459,7 +487,7 @@ int svo_vo_run_chunk(svo_vo *v, const uint8_t *const *lefts, const uint8_t *cons
         v->frame++;
         const int n = v->nref;
         if (n < 5) {
-            if (pending >= 0 && wait_event(v->ev_pose[pending & 1]) == SVO_OK)
+            if (pending >= 0 && wait_tag(&mb->pose_tag[pending & 1], pose_tag[pending & 1], pipeline ? sB : sA) == SVO_OK)
                 harvest(pending);
             svo_set_error("tracking lost: %d reference points", n);
             return SVO_ERR_TRACKING_LOST;
@@ -499,15 +527,16 @@ int svo_vo_run_chunk(svo_vo *v, const uint8_t *const *lefts, const uint8_t *cons
             SVO_HIP(hipStreamWaitEvent(sB, v->ev_a, 0));
         }
         auto launch_pnp = [&](double thr, double conf, int stage) -> int {
+            early_tag = ++v->tag;
+            pose_tag[f & 1] = ++v->tag;
             ctx->stream = sP;
             int r = svo_launch_pnp_ransac(ctx, v->trk3d, v->trk2d, n, cnt_trk, K4, 100, thr, conf, stage_seed(v, stage),
-                                          20, v->idx, nullptr, d_rec, h_early, v->ev_early);
+                                          20, v->idx, nullptr, d_rec, mb->early, early_tag);
             ctx->stream = sA;
             if (r)
                 return r;
-            hipLaunchKernelGGL(store_count_kernel, dim3(1), dim3(1), 0, sP, cnt_trk, &d_rec->n_tracked);
-            SVO_HIP(hipMemcpyAsync(pin + 256 * (f & 1), d_rec, sizeof(PnpRecord), hipMemcpyDeviceToHost, sP));
-            SVO_HIP(hipEventRecord(v->ev_pose[f & 1], sP));
+            hipLaunchKernelGGL(publish_record_kernel, dim3(1), dim3(64), 0, sP, d_rec, cnt_trk, &mb->rec[f & 1],
+                               &mb->pose_tag[f & 1], pose_tag[f & 1]);
             return SVO_OK;
         };
         if ((rc = launch_pnp(1.0, 0.99, 1)))
@@ -525,20 +554,22 @@ int svo_vo_run_chunk(svo_vo *v, const uint8_t *const *lefts, const uint8_t *cons
             speculated = true;
         }
         // ---- the policy needs only the RANSAC inlier count: known before mask / refinement end ----
-        if ((rc = wait_event(v->ev_early)))
+        if ((rc = wait_tag(&mb->early[0], early_tag, sP)))
             return rc;
         if (pending >= 0) {  // stream B runs in order: frame f-1's record landed before this count
+            if ((rc = wait_tag(&mb->pose_tag[pending & 1], pose_tag[pending & 1], sP)))
+                return rc;
             harvest(pending);
             pending = -1;
         }
-        int ninl = h_early[0];
+        int ninl = mb->early[1];
         if (ninl < 10) {  // retry at 8 px / 0.98 (src/keyFrameManagement.cpp:85-92)
-            if ((rc = wait_event(v->ev_pose[f & 1])) || (rc = launch_pnp(8.0, 0.98, 2)) ||
-                (rc = wait_event(v->ev_early)))
+            if ((rc = wait_tag(&mb->pose_tag[f & 1], pose_tag[f & 1], sP)) || (rc = launch_pnp(8.0, 0.98, 2)) ||
+                (rc = wait_tag(&mb->early[0], early_tag, sP)))
                 return rc;
-            ninl = h_early[0];
+            ninl = mb->early[1];
         }
-        v->ntrk = h_early[1];
+        v->ntrk = mb->early[2];
         if (inliers_out)
             inliers_out[f] = ninl;
         if (tracked_out)
@@ -553,7 +584,7 @@ int svo_vo_run_chunk(svo_vo *v, const uint8_t *const *lefts, const uint8_t *cons
         const bool kf = ninl < v->prm.keyframe_min_inliers;  // src/VisualSLAM.cpp:120
         if (kf) {
             // the keyframe's points are placed with the refined pose: wait for it
-            if ((rc = wait_event(v->ev_pose[f & 1])))
+            if ((rc = wait_tag(&mb->pose_tag[f & 1], pose_tag[f & 1], sP)))
                 return rc;
             harvest(f);
             const uint8_t *d = stage_image(v, rights[f], mem, &rc);
@@ -584,7 +615,7 @@ int svo_vo_run_chunk(svo_vo *v, const uint8_t *const *lefts, const uint8_t *cons
             *n_done = f + 1;
     }
     if (pending >= 0) {
-        if ((rc = wait_event(v->ev_pose[pending & 1])))
+        if ((rc = wait_tag(&mb->pose_tag[pending & 1], pose_tag[pending & 1], pipeline ? sB : sA)))
             return rc;
         harvest(pending);
     }

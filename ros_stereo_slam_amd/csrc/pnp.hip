@@ -1126,8 +1126,8 @@ static_assert(sizeof(PnpResult) == 17 * 8, "PnpResult layout");
 // rvec[3] tvec[3] R[9] rms (doubles) n_inliers iters_run (ints).
 int svo_launch_pnp_ransac(svo_ctx *ctx, const float *obj, const float *img, int cap, const int *d_n,
                           const double *K4h, int iterations, double reproj_err, double confidence, uint64_t seed,
-                          int refine_iters, int *inliers, uint8_t *mask, void *d_result, int *h_early,
-                          hipEvent_t ev_early)
+                          int refine_iters, int *inliers, uint8_t *mask, void *d_result, int *early_mbox,
+                          int early_tag)
 {
     if (cap <= 0)
         return SVO_OK;
@@ -1154,16 +1154,8 @@ int svo_launch_pnp_ransac(svo_ctx *ctx, const float *obj, const float *img, int 
                        iterations, st, hyp, nmodels);
     hipLaunchKernelGGL(pnp_score_kernel, dim3(nblk), dim3(256), 0, ctx->stream, obj, img2, cap, d_n, K, 0, iterations,
                        st, hyp, nmodels, thr, counts);
-    int *d_early = ctx->w_d.as<int>() + 12;
     hipLaunchKernelGGL(ransac_select_kernel<1>, dim3(1), dim3(64), 0, ctx->stream, st, 1, iterations, iterations, cap,
-                       d_n, confidence, nmodels, counts, MP, h_early ? d_early : nullptr);
-    if (h_early) {
-        // inlier count of the winning hypothesis + number of tracked points: all the keyframe /
-        // retry / shutdown policy needs, readable while mask, index list and refinement still run
-        SVO_HIP(hipMemcpyAsync(h_early, d_early, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        if (ev_early)
-            SVO_HIP(hipEventRecord(ev_early, ctx->stream));
-    }
+                       d_n, confidence, nmodels, counts, MP, early_mbox, early_tag);
     hipLaunchKernelGGL(pnp_mask_kernel, dim3((cap + 255) / 256), dim3(256), 0, ctx->stream, obj, img2, cap, d_n, K, st,
                        hyp, thr, d_mask);
     hipLaunchKernelGGL(mask_to_index_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_mask, cap, d_n, inliers, d_m);
@@ -1202,7 +1194,7 @@ extern "C" int svo_pnp_ransac(svo_ctx *ctx, const float *obj, const float *img, 
         dinl = ctx->s_c.as<int>();
     }
     rc = svo_launch_pnp_ransac(ctx, dobj, dimg, n, nullptr, K4h, iterations, reproj_err, confidence, seed, 20, dinl,
-                               nullptr, ctx->s_d.p, nullptr, nullptr);
+                               nullptr, ctx->s_d.p, nullptr, 0);
     if (rc)
         return rc;
     // rvec / tvec / counts are host outputs in both modes (the caller decides on them)

@@ -69,7 +69,7 @@ template <int MPI>
 __global__ void ransac_select_kernel(RansacState *st, int first, int it_end, int max_iters, int n_host,
                                      const int *__restrict__ d_n, double confidence,
                                      const int *__restrict__ nmodels, const int *__restrict__ counts,
-                                     int model_points, int *__restrict__ early_out = nullptr)
+                                     int model_points, int *early_out = nullptr, int early_tag = 0)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0)
         return;
@@ -120,9 +120,13 @@ __global__ void ransac_select_kernel(RansacState *st, int first, int it_end, int
     s.next_iter = it;
     s.iters_run = it;
     *st = s;
-    if (early_out) {  // what the host policy branches on, available before the refinement runs
-        early_out[0] = s.best_iter >= 0 ? s.best_count : 0;
-        early_out[1] = n;
+    if (early_out) {
+        // what the host policy branches on, published straight into pinned host memory (the host
+        // spins on the tag) while mask, index list and refinement still run
+        early_out[1] = s.best_iter >= 0 ? s.best_count : 0;
+        early_out[2] = n;
+        __threadfence_system();
+        __hip_atomic_store(&early_out[0], early_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 

@@ -128,7 +128,7 @@ int svo_launch_compact(svo_ctx *ctx, const uint8_t *mask, int cap, const int *d_
 // pnp.hip
 int svo_launch_pnp_ransac(svo_ctx *ctx, const float *obj, const float *img, int cap, const int *d_n,
                           const double *K4h, int iterations, double reproj_err, double confidence, uint64_t seed,
-                          int refine_iters, int *inliers, uint8_t *mask, void *d_result, int *h_early = nullptr,
-                          hipEvent_t ev_early = nullptr);
+                          int refine_iters, int *inliers, uint8_t *mask, void *d_result, int *early_mbox = nullptr,
+                          int early_tag = 0);
 // anms.hip
 int svo_launch_anms(svo_ctx *ctx, const float *xy, const float *resp, int n, int keep, int *out_idx, int *d_count);

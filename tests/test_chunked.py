@@ -96,3 +96,49 @@ def test_stitch_over_gloo(world):
     for rank, ntraj, e_mine, e_traj in res:
         assert ntraj == n                      # overlap frames are not duplicated
         assert e_mine < 1e-10 and e_traj < 1e-10
+
+
+def _worker_multi(rank, world, port, n, m, q):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        gt = _trajectory(n)
+        bounds = chunked.chunk_bounds(n, world * m)[rank * m:(rank + 1) * m]  # this rank's m chunks
+        local = []
+        for s, e in bounds:
+            R0, t0 = gt[s]
+            local.append([(R0.T @ R, R0.T @ (t - t0)) for R, t in gt[s:e + 1]])
+        boundaries = chunked.all_gather_chunk_boundaries(dist, [loc[-1] for loc in local])
+        starts = chunked.prefix_transforms(boundaries)
+        err = 0.0
+        for k, ((s, e), loc) in enumerate(zip(bounds, local)):
+            for (R, t), (Rg, tg) in zip(chunked.rebase(loc, *starts[rank * m + k]), gt[s:e + 1]):
+                err = max(err, np.abs(R - Rg).max() + np.abs(t - tg).max())
+        q.put((rank, len(boundaries), err))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_several_chunks_per_rank_over_gloo():
+    """svo_vo_run_chunks layout: every rank owns m chunks; one all-gather carries all m
+    boundary poses of every rank and the global chunk order is rank-major."""
+    import torch.multiprocessing as mp
+
+    world, m, n = 2, 3, 37
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_multi, args=(r, world, port, n, m, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, nb, err in res:
+        assert nb == world * m and err < 1e-10
