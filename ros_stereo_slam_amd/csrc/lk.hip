@@ -233,8 +233,12 @@ __global__ __launch_bounds__(64 * WAVES, 3) void lk_track_kernel(
     const int n = d_n ? min(*d_n, n_cap) : n_cap;  // live count may sit in HBM (chained stages)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int p = blockIdx.x * WAVES + wave;
-    if (p >= n)
+    // XCD-aware point order: workgroups go to the 8 XCDs round-robin, keypoints arrive in raster
+    // order, so XCD x is given the x-th contiguous eighth of the list -- one band of the image.
+    // Each XCD's L2 then fetches its band of both pyramids once instead of all of them.
+    const int slot = blockIdx.x * WAVES + wave, band = (n + 7) >> 3;
+    const int p = (slot & 7) * band + (slot >> 3);
+    if ((slot >> 3) >= band || p >= n)
         return;  // whole wave leaves; no workgroup barrier is used below
     uint8_t *lds = smem + wave * Lds<C>::WAVE_BYTES;
     uint8_t *T = lds;                                           // PT x PT x C bytes
@@ -475,7 +479,7 @@ int svo_launch_lk(svo_ctx *ctx, const PyrDev &prev, const PyrDev &next, const fl
     prm.max_count = 30;
     prm.eps_sq = 0.01 * 0.01;
     prm.min_eig_thr = (float)1e-4;
-    dim3 grid((n + WAVES - 1) / WAVES), block(64 * WAVES);
+    dim3 grid(((n + 7) / 8) * 8), block(64 * WAVES);  // a multiple of 8: every XCD band has all its slots
     ScopedKernelTime t(ctx, SVO_K_LK);
     switch (prev.c) {
     case 1:
