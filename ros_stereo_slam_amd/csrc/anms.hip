@@ -35,6 +35,7 @@ __device__ __forceinline__ int wave_sum_int(int v)
 __global__ __launch_bounds__(256) void anms_rank_kernel(const float2 *__restrict__ xy, const float *__restrict__ resp,
                                                         int n, int *__restrict__ order, float4 *__restrict__ sorted)
 {
+    __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n)
@@ -57,6 +58,7 @@ __global__ __launch_bounds__(256) void anms_rank_kernel(const float2 *__restrict
 __global__ __launch_bounds__(256) void anms_radius_kernel(const float4 *__restrict__ sorted, int n,
                                                           double *__restrict__ radius_sq)
 {
+    __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     const int lane = threadIdx.x & 63;
     const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (s >= n)
@@ -93,6 +95,7 @@ __global__ __launch_bounds__(256) void anms_radius_kernel(const float4 *__restri
 __global__ __launch_bounds__(256) void anms_decide_kernel(const double *__restrict__ radius_sq, int n, int keep,
                                                           double *__restrict__ decision)
 {
+    __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     const int lane = threadIdx.x & 63;
     const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (s >= n)
@@ -115,6 +118,7 @@ __global__ __launch_bounds__(256) void anms_flag_kernel(const double *__restrict
                                                         const double *__restrict__ decision,
                                                         uint8_t *__restrict__ flags)
 {
+    __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     const int s = blockIdx.x * 256 + threadIdx.x;
     if (s < n)
         flags[s] = radius_sq[s] >= *decision ? 1 : 0;
@@ -125,6 +129,7 @@ __global__ __launch_bounds__(1024) void anms_gather_kernel(const uint8_t *__rest
                                                            const int *__restrict__ order, int n,
                                                            int *__restrict__ out_idx, int *__restrict__ d_count)
 {
+    __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     __shared__ int s_sum[1024];
     const int t = threadIdx.x;
     const int per = (n + 1023) / 1024;

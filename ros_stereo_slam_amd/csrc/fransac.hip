@@ -120,6 +120,7 @@ __global__ __launch_bounds__(SOLVE_T) void fr_solve_kernel(const float *__restri
                                                            int it1, const RansacState *__restrict__ st,
                                                            double *__restrict__ Fout, int *__restrict__ nmodels)
 {
+    __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     __shared__ double sA[63][SOLVE_T];
     __shared__ double sV[18][SOLVE_T];
     __shared__ int sPerm[9][SOLVE_T];
@@ -317,6 +318,7 @@ __global__ __launch_bounds__(256) void fr_score_kernel(const float2 *__restrict_
                                                        const int *__restrict__ nmodels, float thr,
                                                        int *__restrict__ counts)
 {
+    __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     const int it = it0 + w / 3, k = w - (w / 3) * 3;
@@ -353,6 +355,7 @@ __global__ __launch_bounds__(256) void fr_mask_kernel(const float2 *__restrict__
                                                       uint8_t *__restrict__ mask, double *__restrict__ Fbest,
                                                       int *__restrict__ out_count, int *__restrict__ out_iters)
 {
+    __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     const int n = d_n ? *d_n : n_host;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const RansacState s = *st;

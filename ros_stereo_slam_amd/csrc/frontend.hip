@@ -88,6 +88,7 @@ __global__ void gather_kernel(const int *__restrict__ idx, const int *__restrict
                               const float2 *__restrict__ in_b, float2 *__restrict__ out_b,
                               const uint8_t *__restrict__ in_s, uint8_t *__restrict__ out_s)
 {
+    __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= cap || i >= *d_count)
         return;
@@ -104,6 +105,7 @@ __global__ void store_count_kernel(const int *__restrict__ src, int *__restrict_
 __global__ void publish_record_kernel(PnpRecord *__restrict__ d_rec, const int *__restrict__ cnt, PnpRecord *h_rec,
                                       int *h_tag, int tag)
 {
+    __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     constexpr int WORDS = sizeof(PnpRecord) / 4, TRACKED = offsetof(PnpRecord, n_tracked) / 4;
     const int l = threadIdx.x;
     if (l < WORDS) {

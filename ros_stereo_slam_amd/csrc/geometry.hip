@@ -84,6 +84,7 @@ __global__ __launch_bounds__(128) void triangulate_kernel(Mat34 P1, Mat34 P2, co
                                                           float *__restrict__ out_h, Mat34 Rt, int apply_rt,
                                                           float *__restrict__ out_world)
 {
+    __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     const int n = d_n ? *d_n : n_host;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n)
@@ -120,6 +121,7 @@ __global__ __launch_bounds__(128) void triangulate_kernel(Mat34 P1, Mat34 P2, co
 __global__ __launch_bounds__(256) void transform_kernel(Mat34 Rt, const float *__restrict__ in, int n_host,
                                                         const int *__restrict__ d_n, float *__restrict__ out)
 {
+    __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     const int n = d_n ? *d_n : n_host;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n)
@@ -134,6 +136,7 @@ __global__ __launch_bounds__(256) void colors_kernel(const uint8_t *__restrict__
                                                      int c, const float2 *__restrict__ xy, int n_host,
                                                      const int *__restrict__ d_n, float *__restrict__ out)
 {
+    __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     const int n = d_n ? *d_n : n_host;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n)
@@ -160,6 +163,7 @@ __global__ __launch_bounds__(1024) void compact_kernel(const uint8_t *__restrict
                                                        const int *__restrict__ d_n, CompactArgs args,
                                                        int *__restrict__ d_count)
 {
+    __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     // One workgroup of 16 waves walks the array in 1024-element strips.  Inside a wave the
     // position of a kept element is a popcount of the ballot below its lane; wave totals are
     // combined through 16 LDS words; the running base carries from strip to strip.

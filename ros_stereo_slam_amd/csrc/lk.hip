@@ -459,6 +459,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void lk_track_kernel(
 __global__ void grid_keypoints_kernel(int rows, int cols, int step, int nx, int total,
                                       float *__restrict__ out_xy)
 {
+    __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total)
         return;

@@ -299,6 +299,7 @@ __global__ __launch_bounds__(256) void pnp_solve_kernel(const float *__restrict_
                                                         const RansacState *__restrict__ st,
                                                         double *__restrict__ hyp, int *__restrict__ nmodels)
 {
+    __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     __shared__ WaveLds s_lds[4];
     const int lane = threadIdx.x & 63;
     const int it = __builtin_amdgcn_readfirstlane(it0 + blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -748,6 +749,7 @@ __global__ __launch_bounds__(256) void pnp_score_kernel(const float *__restrict_
                                                         const int *__restrict__ nmodels, float thr,
                                                         int *__restrict__ counts)
 {
+    __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     const int lane = threadIdx.x & 63;
     const int it = __builtin_amdgcn_readfirstlane(it0 + blockIdx.x * 4 + (threadIdx.x >> 6));
     if (it >= it1)
@@ -772,68 +774,6 @@ __global__ __launch_bounds__(256) void pnp_score_kernel(const float *__restrict_
     cnt = wave_sum_small(cnt);
     if (lane == 0)
         counts[it] = cnt;
-}
-
-__global__ __launch_bounds__(256) void pnp_mask_kernel(const float *__restrict__ obj, const float2 *__restrict__ img,
-                                                       int n_host, const int *__restrict__ d_n, K4 K,
-                                                       const RansacState *__restrict__ st,
-                                                       const double *__restrict__ hyp, float thr,
-                                                       uint8_t *__restrict__ mask)
-{
-    const int n = d_n ? *d_n : n_host;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_host)
-        return;
-    const RansacState s = *st;
-    uint8_t m = 0;
-    if (s.best_iter >= 0 && s.best_count > 0 && i < n) {
-        double P[12];
-#pragma unroll
-        for (int k = 0; k < 12; k++)
-            P[k] = hyp[(size_t)s.best_iter * 12 + k];
-        const float2 u = img[i];
-        m = reproj_err_sq(P, K, obj[3 * i], obj[3 * i + 1], obj[3 * i + 2], u.x, u.y) <= thr ? 1 : 0;
-    }
-    mask[i] = m;
-}
-
-// order-preserving list of the indices with mask == 1 (the `inliers` vector of solvePnPRansac)
-__global__ __launch_bounds__(1024) void mask_to_index_kernel(const uint8_t *__restrict__ mask, int n_host,
-                                                             const int *__restrict__ d_n, int *__restrict__ out_idx,
-                                                             int *__restrict__ d_count)
-{
-    __shared__ int s_wave[16];
-    __shared__ int s_base;
-    const int n = d_n ? *d_n : n_host;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    if (t == 0)
-        s_base = 0;
-    __syncthreads();
-    for (int start = 0; start < n; start += 1024) {
-        const int i = start + t;
-        const bool keep = i < n && mask[i] == 1;
-        const unsigned long long bal = __ballot(keep);
-        const int below = __popcll(bal & ((1ull << lane) - 1ull));
-        if (lane == 0)
-            s_wave[wave] = __popcll(bal);
-        __syncthreads();
-        int wbase = 0, total = 0;
-#pragma unroll
-        for (int w = 0; w < 16; w++) {
-            const int c = s_wave[w];
-            wbase += w < wave ? c : 0;
-            total += c;
-        }
-        const int base = s_base;
-        if (keep)
-            out_idx[base + wbase + below] = i;
-        __syncthreads();
-        if (t == 0)
-            s_base = base + total;
-        __syncthreads();
-    }
-    if (t == 0)
-        *d_count = s_base;
 }
 
 // ---- Levenberg-Marquardt refinement over the inlier list -------------------------------------
@@ -992,18 +932,77 @@ struct PnpResult {      // what the host reads back after a localisation
     int n_inliers, iters_run;
 };
 
-__global__ __launch_bounds__(256) void pnp_refine_kernel(const float *__restrict__ obj, const float2 *__restrict__ img,
-                                                         const int *__restrict__ inl, const int *__restrict__ d_m,
-                                                         K4 K, const RansacState *__restrict__ st,
-                                                         const double *__restrict__ hyp, int max_iters,
-                                                         PnpResult *__restrict__ out)
+// The tail of solvePnPRansac in ONE single-workgroup launch: (1) thread 0 replays the sequential
+// RANSAC loop over the scored hypotheses and publishes the inlier count for the host policy;
+// (2) the workgroup evaluates the winning hypothesis on every point, writes the mask and the
+// order-preserving inlier index list (ballot scan); (3) Levenberg-Marquardt refinement over the
+// inlier list.
+__global__ __launch_bounds__(256) void pnp_finish_kernel(const float *__restrict__ obj, const float2 *__restrict__ img,
+                                                         int n_host, const int *__restrict__ d_n, K4 K,
+                                                         RansacState *__restrict__ st, int iterations,
+                                                         double confidence, const int *__restrict__ nmodels,
+                                                         const int *__restrict__ counts,
+                                                         const double *__restrict__ hyp, float thr,
+                                                         uint8_t *__restrict__ mask, int *__restrict__ inl,
+                                                         int *__restrict__ d_m, int max_iters,
+                                                         PnpResult *__restrict__ out, int *early_out, int early_tag)
 {
+    __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     __shared__ double s_all[NACC * RED_STRIDE], s_part[4 * NACC], s_sum[NACC], s_pose[12], s_trial[12];
-    __shared__ int s_flag;
-    const int tid = threadIdx.x;
-    const RansacState s = *st;
-    const int m = *d_m;
-    if (s.best_iter < 0 || s.best_count <= 0 || m <= 0) {
+    __shared__ int s_flag, s_wave[4], s_base;
+    __shared__ RansacState s_state;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = d_n ? min(*d_n, n_host) : n_host;
+    if (tid == 0) {
+        const RansacState r = ransac_replay<1>(nullptr, 1, iterations, iterations, n, confidence, nmodels, counts, MP);
+        *st = r;
+        s_state = r;
+        s_base = 0;
+        if (early_out)
+            publish_early(early_out, early_tag, r, n);
+    }
+    __syncthreads();
+    const RansacState s = s_state;
+    const bool have_model = s.best_iter >= 0 && s.best_count > 0;
+    {
+        double P[12];
+#pragma unroll
+        for (int k = 0; k < 12; k++)
+            P[k] = have_model ? hyp[(size_t)s.best_iter * 12 + k] : 0.;
+        for (int start = 0; start < n_host; start += 256) {
+            const int i = start + tid;
+            bool keep = false;
+            if (have_model && i < n) {
+                const float2 u = img[i];
+                keep = reproj_err_sq(P, K, obj[3 * i], obj[3 * i + 1], obj[3 * i + 2], u.x, u.y) <= thr;
+            }
+            if (mask && i < n_host)
+                mask[i] = keep ? 1 : 0;
+            const unsigned long long bal = __ballot(keep);
+            const int below = __popcll(bal & ((1ull << lane) - 1ull));
+            if (lane == 0)
+                s_wave[wave] = __popcll(bal);
+            __syncthreads();
+            int wbase = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const int c = s_wave[w];
+                wbase += w < wave ? c : 0;
+                total += c;
+            }
+            const int base = s_base;
+            if (keep)
+                inl[base + wbase + below] = i;
+            __syncthreads();
+            if (tid == 0)
+                s_base = base + total;
+            __syncthreads();
+        }
+    }
+    const int m = s_base;
+    if (tid == 0)
+        *d_m = m;
+    if (!have_model || m <= 0) {
         if (tid == 0) {
             PnpResult r;
             memset(&r, 0, sizeof(r));
@@ -1012,6 +1011,7 @@ __global__ __launch_bounds__(256) void pnp_refine_kernel(const float *__restrict
         }
         return;
     }
+    __syncthreads();  // the index list written above is read by other threads below
     if (tid < 12)
         s_pose[tid] = hyp[(size_t)s.best_iter * 12 + tid];
     __syncthreads();
@@ -1136,15 +1136,13 @@ int svo_launch_pnp_ransac(svo_ctx *ctx, const float *obj, const float *img, int 
     int rc;
     const size_t h_bytes = (size_t)iterations * 12 * sizeof(double);
     const size_t i_bytes = (size_t)iterations * 2 * sizeof(int) + 128;
-    if ((rc = ctx->w_c.ensure(h_bytes)) || (rc = ctx->w_d.ensure(i_bytes)) ||
-        (rc = ctx->w_e.ensure((size_t)cap + 64)))
+    if ((rc = ctx->w_c.ensure(h_bytes)) || (rc = ctx->w_d.ensure(i_bytes)))
         return rc;
     double *hyp = ctx->w_c.as<double>();
     RansacState *st = reinterpret_cast<RansacState *>(ctx->w_d.p);
     int *d_m = ctx->w_d.as<int>() + 8;  // inlier count of the winning hypothesis
     int *nmodels = ctx->w_d.as<int>() + 16;
     int *counts = nmodels + iterations;
-    uint8_t *d_mask = mask ? mask : ctx->w_e.as<uint8_t>();
     const K4 K = {K4h[0], K4h[1], K4h[2], K4h[3]};
     const float thr = (float)(reproj_err * reproj_err);
     const float2 *img2 = reinterpret_cast<const float2 *>(img);
@@ -1154,13 +1152,9 @@ int svo_launch_pnp_ransac(svo_ctx *ctx, const float *obj, const float *img, int 
                        iterations, st, hyp, nmodels);
     hipLaunchKernelGGL(pnp_score_kernel, dim3(nblk), dim3(256), 0, ctx->stream, obj, img2, cap, d_n, K, 0, iterations,
                        st, hyp, nmodels, thr, counts);
-    hipLaunchKernelGGL(ransac_select_kernel<1>, dim3(1), dim3(64), 0, ctx->stream, st, 1, iterations, iterations, cap,
-                       d_n, confidence, nmodels, counts, MP, early_mbox, early_tag);
-    hipLaunchKernelGGL(pnp_mask_kernel, dim3((cap + 255) / 256), dim3(256), 0, ctx->stream, obj, img2, cap, d_n, K, st,
-                       hyp, thr, d_mask);
-    hipLaunchKernelGGL(mask_to_index_kernel, dim3(1), dim3(1024), 0, ctx->stream, d_mask, cap, d_n, inliers, d_m);
-    hipLaunchKernelGGL(pnp_refine_kernel, dim3(1), dim3(256), 0, ctx->stream, obj, img2, inliers, d_m, K, st, hyp,
-                       refine_iters > 0 ? refine_iters : 20, reinterpret_cast<PnpResult *>(d_result));
+    hipLaunchKernelGGL(pnp_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, obj, img2, cap, d_n, K, st, iterations,
+                       confidence, nmodels, counts, hyp, thr, mask, inliers, d_m, refine_iters > 0 ? refine_iters : 20,
+                       reinterpret_cast<PnpResult *>(d_result), early_mbox, early_tag);
     SVO_HIP(hipGetLastError());
     return SVO_OK;
 }

@@ -31,6 +31,7 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const uint8_t *__restrict
                                                        int w, int h, uint8_t *__restrict__ dst,
                                                        int dpitch, int dw, int dh)
 {
+    __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     constexpr int SROW = ((SW * C + 3) / 4) * 4;
     __shared__ uint8_t s_src[SH * SROW];
     __shared__ uint16_t s_h[SH][TW * C];
@@ -69,6 +70,7 @@ template <int C>
 __global__ __launch_bounds__(256) void pad_copy_kernel(const uint8_t *__restrict__ src, int w, int h,
                                                        uint8_t *__restrict__ padded, int pitch)
 {
+    __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     const int dwords_per_row = pitch >> 2;
     const int row = blockIdx.y;  // 0 .. h + 2*PAD - 1
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
@@ -98,6 +100,7 @@ struct BorderJob {
 template <int C>
 __global__ __launch_bounds__(256) void fill_border_kernel(BorderJob job)
 {
+    __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     const int l = blockIdx.z + 1;
     const int w = job.w[l], h = job.h[l], pitch = job.pitch[l];
     const int row = blockIdx.y;

@@ -66,13 +66,10 @@ __device__ __forceinline__ int wave_sum_small(int v)
 // concurrently gives exactly the serial algorithm's answer.  MPI = models per iteration slot
 // (nmodels[it] in -1 (sampling failed) .. MPI, counts[it * MPI + k]).
 template <int MPI>
-__global__ void ransac_select_kernel(RansacState *st, int first, int it_end, int max_iters, int n_host,
-                                     const int *__restrict__ d_n, double confidence,
-                                     const int *__restrict__ nmodels, const int *__restrict__ counts,
-                                     int model_points, int *early_out = nullptr, int early_tag = 0)
+__device__ inline RansacState ransac_replay(const RansacState *st_in, int first, int it_end, int max_iters, int n,
+                                            double confidence, const int *__restrict__ nmodels,
+                                            const int *__restrict__ counts, int model_points)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0)
-        return;
     RansacState s;
     if (first) {
         s.niters = max_iters;
@@ -84,11 +81,10 @@ __global__ void ransac_select_kernel(RansacState *st, int first, int it_end, int
         s.iters_run = 0;
         s.pad = 0;
     } else {
-        s = *st;
+        s = *st_in;
         if (s.done)
-            return;
+            return s;
     }
-    const int n = d_n ? *d_n : n_host;
     int it = s.next_iter;
     if (n < model_points) {
         s.done = 1;
@@ -119,15 +115,32 @@ __global__ void ransac_select_kernel(RansacState *st, int first, int it_end, int
     }
     s.next_iter = it;
     s.iters_run = it;
-    *st = s;
-    if (early_out) {
-        // what the host policy branches on, published straight into pinned host memory (the host
-        // spins on the tag) while mask, index list and refinement still run
-        early_out[1] = s.best_iter >= 0 ? s.best_count : 0;
-        early_out[2] = n;
-        __threadfence_system();
-        __hip_atomic_store(&early_out[0], early_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    return s;
+}
+
+// What the host policy branches on -- RANSAC inlier count and tracked-point count -- published
+// straight into pinned host memory (the host spins on the tag) while the rest of the stage runs.
+__device__ inline void publish_early(int *early_out, int early_tag, const RansacState &s, int n)
+{
+    early_out[1] = s.best_iter >= 0 ? s.best_count : 0;
+    early_out[2] = n;
+    __threadfence_system();
+    __hip_atomic_store(&early_out[0], early_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+template <int MPI>
+__global__ void ransac_select_kernel(RansacState *st, int first, int it_end, int max_iters, int n_host,
+                                     const int *__restrict__ d_n, double confidence,
+                                     const int *__restrict__ nmodels, const int *__restrict__ counts,
+                                     int model_points)
+{
+    __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
+    if (threadIdx.x != 0 || blockIdx.x != 0)
+        return;
+    if (!first && st->done)
+        return;
+    *st = ransac_replay<MPI>(st, first, it_end, max_iters, d_n ? *d_n : n_host, confidence, nmodels, counts,
+                             model_points);
 }
 
 // hand-off of LDS data between lanes of ONE wave (LDS ops of a wave execute in order; this
