@@ -241,7 +241,13 @@ int svo_vo_create(svo_ctx *ctx, const svo_vo_params *params, int width, int heig
         svo_vo_destroy(v);
         return rc;
     }
-    if (hipStreamCreateWithFlags(&v->stream_b, hipStreamNonBlocking) != hipSuccess ||
+    // The PnP stream is created in the high-priority class: HIP keeps a separate pool of hardware
+    // queues per priority class, so the two streams of a chunk never land on one queue (with both
+    // in the default class the runtime was seen to put them on the same queue, which serialises
+    // the overlap away), and PnP -- the stage the host waits for -- is dispatched first.
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (hipStreamCreateWithPriority(&v->stream_b, hipStreamNonBlocking, prio_hi) != hipSuccess ||
         hipEventCreateWithFlags(&v->ev_a, hipEventDisableTiming) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void **>(&v->mbox), sizeof(Mailbox),
                       hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
