@@ -5,21 +5,19 @@
 //   globalOptimize :128-138 (Gauss-Newton, 10 iterations, BlockSolver<6,6> + sparse
 //   Cholesky, identity information), saveStructure :140-179.
 //
-// One Gauss-Newton iteration is four launches on the context's stream (f64 throughout):
+// One Gauss-Newton iteration on the context's stream (f64 throughout):
 //   linearize  one thread per edge: error e = toVectorMQT(Z^-1 Xi^-1 Xj), analytic 6x6
 //              Jacobians, and the edge's blocks Ji^T Ji, Ji^T Jj, Jj^T Jj, Ji^T e, Jj^T e
 //              written to per-edge slots (the "per-edge 6x6 Jacobian blocks");
-//   assemble   one thread per vertex: its diagonal block and gradient are summed from its
-//              incident edges in edge order, its off-diagonal blocks are dropped into a
-//              block-skyline store -- a gather, so the sum order is fixed and the result
-//              reproducible (no float atomics);
-//   solve      H dx = -b by a block-skyline Cholesky in vertex order.  The graph is a chain
-//              (block tridiagonal) plus one long row per loop closure; eliminating in time
-//              order keeps all fill inside those rows.  The recurrence along the chain is
-//              inherently serial (latency-, not bandwidth-bound: ~3 MB per iteration), so one
-//              wavefront walks it with the 36 lanes of a 6x6 block working in parallel;
+//   assemble   one thread per vertex: its diagonal block, gradient and chain block are summed
+//              from its incident edges in edge order -- a gather, so the sum order is fixed and
+//              the result reproducible (no float atomics);
+//   solve      H dx = -b by a Cholesky factorisation in nested-dissection order: chain segments
+//              in parallel (one wavefront each), a dense Schur complement on the separators
+//              (loop-closure endpoints + every 128th vertex), back-substitution -- see below;
 //   update     one thread per vertex: X <- X * fromVectorMQT(dx).
 #include <cmath>
+#include <map>
 #include <vector>
 
 #include "svo_internal.h"
@@ -187,27 +185,59 @@ __global__ __launch_bounds__(128) void pg_linearize_kernel(const double *__restr
     }
 }
 
-// Block-skyline store.  Unknown block b = vertex b+1 (vertex 0 is fixed).  Row b keeps its
-// off-diagonal blocks for columns benv[b] .. b-1 at Ls[(rowptr[b] + c - benv[b]) * 36], the
-// diagonal blocks live in Ld, the gradient in rhs.
+// ---- the linear solve  H dx = -b --------------------------------------------------------------
 //
-// assemble: incident edges of vertex v are inc[incptr[v] .. incptr[v+1]) = edge*2 + role
-// (role 0: v is the edge's `from`, 1: `to`), ascending in edge index.
+// Unknown block b = vertex b+1 (vertex 0 is fixed).  H is block tridiagonal along the odometry
+// chain plus one block pair per loop-closure edge ("chord").  A Cholesky factorisation in time
+// order is one serial chain of nb block steps with the fill of every chord on top; instead the
+// rows are ordered by ONE level of nested dissection:
+//   separators  = the endpoints of all chords + every SEG_L-th row;
+//   segments    = the runs of rows between consecutive separators: independent block-tridiagonal
+//                 systems, factorised and solved by one wavefront each, all in parallel;
+//   reduced system = the Schur complement on the separators (block tridiagonal in separator
+//                 order + the chord blocks), assembled by gathers in a fixed order and solved by a
+//                 blocked dense Cholesky (48-wide tiles, many workgroups per step);
+//   back-substitution of the segment interiors, one thread per unknown.
+// This is still a Cholesky factorisation of H (under a symmetric block permutation), so it is as
+// stable as the time-ordered one, and every sum has a fixed order (no float atomics).
+//
+// Segment rows a..z with left separator l = a-1 and right separator r = z+1 (either may be
+// missing at the ends of the chain).  With C_b = H[b+1][b]:
+//   T x_seg + E_a C_l x_l + E_z C_z^T x_r = r_seg   =>   x_seg = y - Wl x_l - Wr x_r,
+//   y = T^-1 r_seg,  Wl = T^-1 E_a C_l,  Wr = T^-1 E_z C_z^T.
+
+constexpr int SEG_L = 128;  // regular separator spacing (rows)
+constexpr int TB = 48;      // tile of the dense reduced solve (8 block rows)
+
+// hand-off of LDS data between the lanes of the ONE wave a workgroup consists of
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// assemble: one thread per block row.  Incident edges of vertex v are
+// inc[incptr[v] .. incptr[v+1]) = edge*2 + role (role 0: v is the edge's `from`, 1: `to`),
+// ascending in edge index, so every sum has a fixed order.
+//   Dg[b]  = sum of the vertex's diagonal blocks,  rneg[b] = -(sum of its gradients),
+//   Cc[b]  = H[b+1][b], the blocks of the edges between vertices b+1 and b+2.
 __global__ __launch_bounds__(128) void pg_assemble_kernel(int nb, const int *__restrict__ incptr,
                                                           const int *__restrict__ inc, const int *__restrict__ efrom,
                                                           const int *__restrict__ eto, const EdgeOut *__restrict__ eo,
-                                                          const int *__restrict__ benv, const int *__restrict__ rowptr,
-                                                          double *__restrict__ Ld, double *__restrict__ Ls,
-                                                          double *__restrict__ rhs)
+                                                          double *__restrict__ Dg, double *__restrict__ Cc,
+                                                          double *__restrict__ rneg)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb)
         return;
     const int v = b + 1;
-    double D[36], g[6];
+    double D[36], C[36], g[6];
 #pragma unroll
-    for (int k = 0; k < 36; k++)
+    for (int k = 0; k < 36; k++) {
         D[k] = 0;
+        C[k] = 0;
+    }
 #pragma unroll
     for (int k = 0; k < 6; k++)
         g[k] = 0;
@@ -221,184 +251,497 @@ __global__ __launch_bounds__(128) void pg_assemble_kernel(int nb, const int *__r
 #pragma unroll
         for (int k = 0; k < 6; k++)
             g[k] += gd[k];
-        // off-diagonal block (v, other) goes to the row of the larger vertex
         const int other = role ? efrom[e] : eto[e];
-        if (other >= 1 && other < v) {
-            // block(v, other) = J_v^T J_other : role 1 (v = to): (Ji^T Jj)^T ; role 0 (v = from): Ji^T Jj
-            double *dst = Ls + (size_t)(rowptr[b] + (other - 1) - benv[b]) * 36;
+        if (other == v + 1) {
+            // block(v+1, v) = J_{v+1}^T J_v: v = `to` (role 1): Ji^T Jj as stored; v = `from`: its transpose
 #pragma unroll
             for (int p = 0; p < 6; p++)
 #pragma unroll
                 for (int q = 0; q < 6; q++)
-                    dst[6 * p + q] += role ? o.Hij[6 * q + p] : o.Hij[6 * p + q];
+                    C[6 * p + q] += role ? o.Hij[6 * p + q] : o.Hij[6 * q + p];
         }
     }
 #pragma unroll
-    for (int k = 0; k < 36; k++)
-        Ld[(size_t)b * 36 + k] = D[k];
+    for (int k = 0; k < 36; k++) {
+        Dg[(size_t)b * 36 + k] = D[k];
+        Cc[(size_t)b * 36 + k] = C[k];
+    }
 #pragma unroll
     for (int k = 0; k < 6; k++)
-        rhs[(size_t)b * 6 + k] = g[k];
+        rneg[(size_t)b * 6 + k] = -g[k];
 }
 
-// loads / stores of data this kernel itself produces go around the vector L1 (agent scope)
-__device__ __forceinline__ double ldc(const double *p)
+// 6x6 Cholesky S = L L^T and the inverse of L, by the 64 lanes of one wave on LDS arrays
+// (sS is destroyed).  Returns false (wave-uniform) at a non-positive pivot.
+__device__ inline bool wave_chol6_inv(double *sS, double *sL, double *sLi, int lane)
 {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void stc(double *p, double v)
-{
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void wave_sync_mem()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // s_waitcnt vmcnt(0) lgkmcnt(0)
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
-// status[0] = 0 ok, else 1 + the block row whose pivot was not positive
-__global__ __launch_bounds__(64) void pg_solve_kernel(int nb, const int *__restrict__ benv,
-                                                      const int *__restrict__ rowptr, double *Ld, double *Linv,
-                                                      double *Ls, const double *__restrict__ rhs, double *y,
-                                                      int *__restrict__ status)
-{
-    __shared__ double sS[36], sL[36], sLi[36], sv[8], sw[40];
-    const int lane = threadIdx.x;
     const int i = lane / 6, j = lane - 6 * i;
     const bool act = lane < 36;
-    bool failed = false;
-    // ---- factorisation + forward substitution, row by row ----
-    for (int b = 0; b < nb && !failed; b++) {
-        const int env = benv[b], rp = rowptr[b];
-        for (int c = env; c < b; c++) {
-            double acc = act ? ldc(Ls + (size_t)(rp + c - env) * 36 + lane) : 0.;
-            const int envc = benv[c], k0 = env > envc ? env : envc;
-            for (int k = k0; k < c; k++) {
-                if (act) {
-                    const double *Ab = Ls + (size_t)(rp + k - env) * 36 + 6 * i;
-                    const double *Bb = Ls + (size_t)(rowptr[c] + k - envc) * 36 + 6 * j;
+    bool ok = true;
 #pragma unroll
-                    for (int l = 0; l < 6; l++)
-                        acc -= ldc(Ab + l) * ldc(Bb + l);
-                }
-            }
-            if (act)
-                sS[lane] = acc;
-            wave_sync_mem();
-            if (act) {  // L[b][c] = S * Linv[c]^T
-                double x = 0;
-                const double *Li = Linv + (size_t)c * 36 + 6 * j;
+    for (int k = 0; k < 6; k++) {
+        const double piv = sS[7 * k];
+        if (!(piv > 0))
+            ok = false;
+        const double d = sqrt(piv), inv = 1. / d;
+        if (lane < 6) {
+            // column k of L: zero above the diagonal, d on it, scaled entries below
+            sL[6 * lane + k] = lane < k ? 0. : (lane == k ? d : sS[6 * lane + k] * inv);
+        }
+        wave_sync();
+        if (act && j > k && i >= j)
+            sS[6 * i + j] -= sL[6 * i + k] * sL[6 * j + k];
+        wave_sync();
+    }
+    if (lane < 6) {  // column `lane` of L^-1 by forward substitution, kept in registers
+        double x[6];
 #pragma unroll
-                for (int l = 0; l < 6; l++)
-                    x += sS[6 * i + l] * ldc(Li + l);
-                stc(Ls + (size_t)(rp + c - env) * 36 + lane, x);
-            }
-            wave_sync_mem();
-        }
-        // diagonal block: S = H[b][b] - sum_k L[b][k] L[b][k]^T
-        double acc = act ? Ld[(size_t)b * 36 + lane] : 0.;
-        for (int k = env; k < b; k++) {
-            if (act) {
-                const double *Ab = Ls + (size_t)(rp + k - env) * 36;
+        for (int r = 0; r < 6; r++) {
+            double sacc = r == lane ? 1. : 0.;
 #pragma unroll
-                for (int l = 0; l < 6; l++)
-                    acc -= ldc(Ab + 6 * i + l) * ldc(Ab + 6 * j + l);
-            }
+            for (int k = 0; k < 6; k++)
+                if (k < r)
+                    sacc -= sL[6 * r + k] * (k >= lane ? x[k] : 0.);
+            x[r] = r < lane ? 0. : sacc / sL[7 * r];
         }
-        if (act)
-            sS[lane] = acc;
-        wave_sync_mem();
-        if (lane == 0) {  // 6x6 Cholesky and the inverse of its factor, serially (tiny)
-            bool ok = true;
-            for (int r = 0; r < 6; r++)
-                for (int c = 0; c <= r; c++) {
-                    double s = sS[6 * r + c];
-                    for (int k = 0; k < c; k++)
-                        s -= sL[6 * r + k] * sL[6 * c + k];
-                    if (r == c) {
-                        if (!(s > 0))
-                            ok = false;
-                        sL[6 * r + r] = sqrt(s);
-                    } else
-                        sL[6 * r + c] = s / sL[6 * c + c];
-                }
-            for (int r = 0; r < 6; r++)
-                for (int c = r + 1; c < 6; c++)
-                    sL[6 * r + c] = 0.;
-            for (int c = 0; c < 6; c++) {  // column c of L^-1 by forward substitution
-                for (int r = 0; r < 6; r++) {
-                    double s = r == c ? 1. : 0.;
-                    for (int k = c; k < r; k++)
-                        s -= sL[6 * r + k] * sLi[6 * k + c];
-                    sLi[6 * r + c] = r < c ? 0. : s / sL[6 * r + r];
-                }
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+            sLi[6 * r + lane] = x[r];
+    }
+    wave_sync();
+    return ok;
+}
+
+// One wavefront per segment: block-tridiagonal Cholesky of the segment, then y, Wl, Wr for all
+// its rows.  Scratch Li (L_bb^-1), Lsub (L_{b,b-1}) and Z7 (the forward-substituted right-hand
+// sides) are written in the forward sweep and read back by the same wave in the backward sweep.
+// status[0] != 0 marks a non-positive pivot (1 + block row).
+__global__ __launch_bounds__(64) void pg_segment_kernel(int nb, const int *__restrict__ seg_start,
+                                                        const int *__restrict__ seg_len,
+                                                        const double *__restrict__ Dg, const double *__restrict__ Cc,
+                                                        const double *__restrict__ rneg, double *Li, double *Lsub,
+                                                        double *Z7, double *__restrict__ Y, double *__restrict__ Wl,
+                                                        double *__restrict__ Wr, int *__restrict__ status)
+{
+    __shared__ double sS[36], sL[36], sLi[36], sSub[36], sC[36], sT[80], sZ[80], sX[80];
+    const int lane = threadIdx.x;
+    const int a = seg_start[blockIdx.x], n = seg_len[blockIdx.x], z = a + n - 1;
+    const int i = lane / 6, j = lane - 6 * i;
+    const bool act = lane < 36;
+    const bool has_l = a > 0, has_r = z < nb - 1;
+    // ---- forward: factorisation and L^-1 [r | E_a C_l] (7 columns; column layout [6][7]) ----
+    for (int b = a; b <= z; b++) {
+        if (act) {
+            double sv = Dg[(size_t)b * 36 + lane];
+            if (b > a) {
+#pragma unroll
+                for (int t = 0; t < 6; t++)
+                    sv -= sSub[6 * i + t] * sSub[6 * j + t];
             }
-            sv[6] = ok ? 0. : 1.;
+            sS[lane] = sv;
+            sC[lane] = b < z ? Cc[(size_t)b * 36 + lane] : 0.;
         }
-        wave_sync_mem();
-        if (sv[6] != 0.) {
+        // right-hand side block of this row: [rneg_b | C_l (first row only)]
+        if (lane < 42) {
+            const int r = lane / 7, c = lane - 7 * r;
+            double v = c == 0 ? rneg[(size_t)b * 6 + r]
+                              : (b == a && has_l ? Cc[(size_t)(a - 1) * 36 + 6 * r + (c - 1)] : 0.);
+            if (b > a) {
+#pragma unroll
+                for (int t = 0; t < 6; t++)
+                    v -= sSub[6 * r + t] * sZ[7 * t + c];
+            }
+            sT[lane] = v;
+        }
+        wave_sync();
+        if (!wave_chol6_inv(sS, sL, sLi, lane)) {
             if (lane == 0)
-                status[0] = 1 + b;
-            failed = true;
-            break;
+                atomicMax(status, 1 + b);
+            return;
         }
         if (act) {
-            stc(Ld + (size_t)b * 36 + lane, sL[lane]);
-            stc(Linv + (size_t)b * 36 + lane, sLi[lane]);
+            Li[(size_t)b * 36 + lane] = sLi[lane];
+            // L_{b+1,b} = C_b L_bb^-T
+            double v = 0;
+#pragma unroll
+            for (int t = 0; t < 6; t++)
+                v += sC[6 * i + t] * sLi[6 * j + t];
+            if (b < z)
+                Lsub[(size_t)(b + 1) * 36 + lane] = v;
+            sS[lane] = v;  // parked; becomes sSub after the z update below has read the old sSub
         }
-        // forward substitution: y_b = Linv_b * (-rhs_b - sum_c L[b][c] y_c)
-        double part = 0;  // lane (i, l=j): sum over c of L[b][c][i][l] * y_c[l]
-        for (int c = env; c < b; c++)
-            if (act)
-                part += ldc(Ls + (size_t)(rp + c - env) * 36 + lane) * ldc(y + (size_t)c * 6 + j);
+        double zv = 0;
+        if (lane < 42) {
+            const int r = lane / 7, c = lane - 7 * r;
+#pragma unroll
+            for (int t = 0; t < 6; t++)
+                zv += sLi[6 * r + t] * sT[7 * t + c];
+            Z7[(size_t)b * 42 + lane] = zv;
+        }
+        wave_sync();
+        if (lane < 42)
+            sZ[lane] = zv;
         if (act)
-            sw[lane] = part;
-        wave_sync_mem();
-        if (lane < 6) {
-            double s = -rhs[(size_t)b * 6 + lane];
-            for (int l = 0; l < 6; l++)
-                s -= sw[6 * lane + l];
-            sv[lane] = s;
-        }
-        wave_sync_mem();
-        if (lane < 6) {
-            double s = 0;
-            for (int l = 0; l <= lane; l++)
-                s += sLi[6 * lane + l] * sv[l];
-            stc(y + (size_t)b * 6 + lane, s);
-        }
-        wave_sync_mem();
+            sSub[lane] = sS[lane];
+        wave_sync();
     }
-    if (failed)
-        return;
-    if (lane == 0)
-        status[0] = 0;
-    // ---- back substitution: L^T x = y, rows in descending order, in place in y ----
-    for (int b = nb - 1; b >= 0; b--) {
-        const int env = benv[b], rp = rowptr[b];
-        if (lane < 6) {  // x_b = Linv_b^T y_b
-            double s = 0;
-            for (int l = lane; l < 6; l++)
-                s += ldc(Linv + (size_t)b * 36 + 6 * l + lane) * ldc(y + (size_t)b * 6 + l);
-            sv[lane] = s;
+    // the scratch written above is read back below by other lanes of this wave
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    // ---- backward: x = L^-T z for 13 columns [y | Wl (6) | Wr (6)], layout [6][13] in sX ----
+    for (int b = z; b >= a; b--) {
+        if (act) {
+            sLi[lane] = Li[(size_t)b * 36 + lane];
+            if (b < z)
+                sSub[lane] = Lsub[(size_t)(b + 1) * 36 + lane];
         }
-        wave_sync_mem();
-        if (lane < 6)
-            stc(y + (size_t)b * 6 + lane, sv[lane]);
-        // y_c -= L[b][c]^T x_b for the columns of this row; lanes (c-stripe, component)
-        for (int c0 = env; c0 < b; c0 += 10) {
-            const int c = c0 + lane / 6, l = lane - 6 * (lane / 6);
-            if (lane < 60 && c < b) {
-                const double *Lb = Ls + (size_t)(rp + c - env) * 36;
-                double s = 0;
-                for (int r = 0; r < 6; r++)
-                    s += ldc(Lb + 6 * r + l) * sv[r];
-                stc(y + (size_t)c * 6 + l, ldc(y + (size_t)c * 6 + l) - s);
+        wave_sync();
+        for (int e = lane; e < 78; e += 64) {
+            const int r = e / 13, c = e - 13 * r;
+            double v;
+            if (c < 7)
+                v = Z7[(size_t)b * 42 + 7 * r + c];
+            else if (b == z && has_r) {  // z-value of the Wr columns: L_zz^-1 C_z^T, nonzero in the last row only
+                v = 0;
+#pragma unroll
+                for (int t = 0; t < 6; t++)
+                    v += sLi[6 * r + t] * Cc[(size_t)z * 36 + 6 * (c - 7) + t];
+            } else
+                v = 0;
+            if (b < z) {  // - L_{b+1,b}^T x_{b+1}
+#pragma unroll
+                for (int t = 0; t < 6; t++)
+                    v -= sSub[6 * t + r] * sX[13 * t + c];
+            }
+            sT[e] = v;
+        }
+        wave_sync();
+        for (int e = lane; e < 78; e += 64) {
+            const int r = e / 13, c = e - 13 * r;
+            double v = 0;
+#pragma unroll
+            for (int t = 0; t < 6; t++)
+                v += sLi[6 * t + r] * sT[13 * t + c];  // L^-T
+            sZ[e] = v;
+        }
+        wave_sync();
+        for (int e = lane; e < 78; e += 64) {
+            const int r = e / 13, c = e - 13 * r;
+            const double v = sZ[e];
+            sX[e] = v;
+            if (c == 0)
+                Y[(size_t)b * 6 + r] = v;
+            else if (c < 7)
+                Wl[(size_t)b * 36 + 6 * r + (c - 1)] = v;
+            else
+                Wr[(size_t)b * 36 + 6 * r + (c - 7)] = v;
+        }
+        wave_sync();
+    }
+}
+
+// Reduced (separator) system, assembled by gathers.  Block k of the launch owns one nonzero
+// 6x6 block (rb_row >= rb_col, in separator indices) or, for k >= n_blocks, the right-hand side
+// of separator k - n_blocks.  Sources src[ptr[k] .. ptr[k+1]) are added in list order:
+//   kind 0: + Dg[idx]                      kind 1: + Cc[idx]
+//   kind 2: + Hij of edge idx              kind 3: + Hij^T of edge idx
+//   kind 4: - Cc[idx]^T Wl[idx+1]          (segment right of separator row idx, onto the diagonal)
+//   kind 5: - Cc[idx]   Wr[idx]            (segment left of separator row idx+1, onto the diagonal)
+//   kind 6: - Cc[idx]   Wl[idx]            (segment between two separators, sub-diagonal block)
+// right-hand sides: kind 0: + rneg[idx], kind 4: - Cc[idx]^T Y[idx+1], kind 5: - Cc[idx] Y[idx].
+__global__ __launch_bounds__(64) void pg_reduce_kernel(int n_blocks, int m, const int *__restrict__ rb_row,
+                                                       const int *__restrict__ rb_col, const int *__restrict__ ptr,
+                                                       const int2 *__restrict__ src, const double *__restrict__ Dg,
+                                                       const double *__restrict__ Cc, const double *__restrict__ rneg,
+                                                       const EdgeOut *__restrict__ eo, const double *__restrict__ Y,
+                                                       const double *__restrict__ Wl, const double *__restrict__ Wr,
+                                                       double *__restrict__ R, int ldr, double *__restrict__ rR)
+{
+    const int k = blockIdx.x, lane = threadIdx.x;
+    if (k < n_blocks) {
+        if (lane >= 36)
+            return;
+        const int p = lane / 6, q = lane - 6 * p;
+        double acc = 0;
+        for (int t = ptr[k]; t < ptr[k + 1]; t++) {
+            const int kind = src[t].x, idx = src[t].y;
+            const double *C = Cc + (size_t)idx * 36;
+            double v = 0;
+            switch (kind) {
+            case 0: v = Dg[(size_t)idx * 36 + lane]; break;
+            case 1: v = C[lane]; break;
+            case 2: v = eo[idx].Hij[lane]; break;
+            case 3: v = eo[idx].Hij[6 * q + p]; break;
+            case 4:
+                for (int t2 = 0; t2 < 6; t2++)
+                    v -= C[6 * t2 + p] * Wl[(size_t)(idx + 1) * 36 + 6 * t2 + q];
+                break;
+            case 5:
+                for (int t2 = 0; t2 < 6; t2++)
+                    v -= C[6 * p + t2] * Wr[(size_t)idx * 36 + 6 * t2 + q];
+                break;
+            default:
+                for (int t2 = 0; t2 < 6; t2++)
+                    v -= C[6 * p + t2] * Wl[(size_t)idx * 36 + 6 * t2 + q];
+                break;
+            }
+            acc += v;
+        }
+        R[(size_t)(6 * rb_row[k] + p) * ldr + 6 * rb_col[k] + q] = acc;
+    } else {
+        if (lane >= 6)
+            return;
+        const int sidx = k - n_blocks;
+        if (sidx >= m)
+            return;
+        const int kk = n_blocks + sidx;
+        double acc = 0;
+        for (int t = ptr[kk]; t < ptr[kk + 1]; t++) {
+            const int kind = src[t].x, idx = src[t].y;
+            const double *C = Cc + (size_t)idx * 36;
+            double v = 0;
+            if (kind == 0)
+                v = rneg[(size_t)idx * 6 + lane];
+            else if (kind == 4) {
+                for (int t2 = 0; t2 < 6; t2++)
+                    v -= C[6 * t2 + lane] * Y[(size_t)(idx + 1) * 6 + t2];
+            } else {
+                for (int t2 = 0; t2 < 6; t2++)
+                    v -= C[6 * lane + t2] * Y[(size_t)idx * 6 + t2];
+            }
+            acc += v;
+        }
+        rR[6 * sidx + lane] = acc;
+    }
+}
+
+// identity on the padded diagonal of the reduced matrix, zeros elsewhere (runs before the gather)
+__global__ __launch_bounds__(256) void pg_reduce_clear_kernel(double *__restrict__ R, int ldr, int n_used,
+                                                              double *__restrict__ rR)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)ldr * ldr;
+    if (t < total) {
+        const int r = (int)(t / ldr), c = (int)(t - (size_t)r * ldr);
+        R[t] = (r == c && r >= n_used) ? 1. : 0.;
+    }
+    if (t < (size_t)ldr)
+        rR[t] = 0.;
+}
+
+// ---- blocked dense Cholesky of the reduced system (lower triangle, row-major, ld = ldr) ------
+// step kb:  potf2: factor the diagonal tile (kb,kb) -> Lo, and its inverse -> Tinv[kb];
+//           update: every trailing tile (i,j), kb < j <= i: A_ij -= P_i P_j^T with
+//           P_i = A_i,kb * Tinv^T; the tile (i, kb+1) also stores P_i as the factor's block (i,kb).
+// Column kb of A is only read in step kb, the factor goes to a separate array: no races.
+__global__ __launch_bounds__(256) void pg_dense_potf2_kernel(const double *__restrict__ A, double *__restrict__ Lo,
+                                                             double *__restrict__ Tinv, int ldr, int kb,
+                                                             int *__restrict__ status, int status_base)
+{
+    __shared__ double sA[TB * (TB + 1)], sI[TB * (TB + 1)];
+    __shared__ int s_bad;
+    const int tid = threadIdx.x;
+    constexpr int LD = TB + 1;
+    if (tid == 0)
+        s_bad = 0;
+    for (int e = tid; e < TB * TB; e += 256) {
+        const int r = e / TB, c = e - TB * r;
+        sA[r * LD + c] = c <= r ? A[(size_t)(kb * TB + r) * ldr + kb * TB + c] : 0.;
+    }
+    __syncthreads();
+    for (int k = 0; k < TB; k++) {
+        const double piv = sA[k * LD + k];
+        if (!(piv > 0)) {
+            if (tid == 0)
+                s_bad = 1 + k;
+        }
+        const double d = sqrt(piv), inv = 1. / d;
+        __syncthreads();
+        if (tid < TB && tid >= k)
+            sA[tid * LD + k] = tid == k ? d : sA[tid * LD + k] * inv;
+        __syncthreads();
+        // trailing update of the lower triangle: pairs (i, j), k < j <= i
+        const int rem = TB - 1 - k;
+        for (int e = tid; e < rem * rem; e += 256) {
+            const int ii = e / rem, jj = e - rem * ii;
+            if (jj <= ii) {
+                const int i = k + 1 + ii, j = k + 1 + jj;
+                sA[i * LD + j] -= sA[i * LD + k] * sA[j * LD + k];
             }
         }
-        wave_sync_mem();
+        __syncthreads();
     }
+    if (s_bad) {
+        if (tid == 0)
+            atomicMax(status, status_base + kb * TB + s_bad);
+        // keep going with whatever is there: the host reports the failure
+    }
+    if (tid < TB) {  // column tid of the inverse by forward substitution
+        const int c = tid;
+        for (int r = 0; r < TB; r++) {
+            double acc = r == c ? 1. : 0.;
+            for (int k = c; k < r; k++)
+                acc -= sA[r * LD + k] * sI[k * LD + c];
+            sI[r * LD + c] = r < c ? 0. : acc / sA[r * LD + r];
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < TB * TB; e += 256) {
+        const int r = e / TB, c = e - TB * r;
+        Lo[(size_t)(kb * TB + r) * ldr + kb * TB + c] = sA[r * LD + c];
+        Tinv[(size_t)kb * TB * TB + e] = sI[r * LD + c];
+    }
+}
+
+__global__ __launch_bounds__(256) void pg_dense_update_kernel(double *__restrict__ A, double *__restrict__ Lo,
+                                                              const double *__restrict__ Tinv, int ldr, int kb, int T)
+{
+    __shared__ double sI[TB * (TB + 1)], sPi[TB * (TB + 1)], sPj[TB * (TB + 1)], sA[TB * (TB + 1)];
+    constexpr int LD = TB + 1;
+    const int tid = threadIdx.x;
+    // linear tile index -> (i, j) with kb < j <= i < T
+    int t = blockIdx.x, i = kb + 1;
+    while (t >= i - kb) {
+        t -= i - kb;
+        i++;
+    }
+    const int j = kb + 1 + t;
+    (void)T;
+    for (int e = tid; e < TB * TB; e += 256) {
+        const int r = e / TB, c = e - TB * r;
+        sI[r * LD + c] = Tinv[(size_t)kb * TB * TB + e];
+        sA[r * LD + c] = A[(size_t)(i * TB + r) * ldr + kb * TB + c];
+    }
+    __syncthreads();
+    for (int e = tid; e < TB * TB; e += 256) {  // P_i = A_i,kb * Tinv^T
+        const int r = e / TB, c = e - TB * r;
+        double acc = 0;
+        for (int k = 0; k <= c; k++)
+            acc += sA[r * LD + k] * sI[c * LD + k];
+        sPi[r * LD + c] = acc;
+    }
+    __syncthreads();
+    if (i != j) {
+        for (int e = tid; e < TB * TB; e += 256) {
+            const int r = e / TB, c = e - TB * r;
+            sA[r * LD + c] = A[(size_t)(j * TB + r) * ldr + kb * TB + c];
+        }
+        __syncthreads();
+        for (int e = tid; e < TB * TB; e += 256) {
+            const int r = e / TB, c = e - TB * r;
+            double acc = 0;
+            for (int k = 0; k <= c; k++)
+                acc += sA[r * LD + k] * sI[c * LD + k];
+            sPj[r * LD + c] = acc;
+        }
+        __syncthreads();
+    }
+    const double *Pj = i == j ? sPi : sPj;
+    for (int e = tid; e < TB * TB; e += 256) {
+        const int r = e / TB, c = e - TB * r;
+        if (i == j && c > r)
+            continue;
+        double acc = 0;
+        for (int k = 0; k < TB; k++)
+            acc += sPi[r * LD + k] * Pj[c * LD + k];
+        A[(size_t)(i * TB + r) * ldr + j * TB + c] -= acc;
+    }
+    if (j == kb + 1)
+        for (int e = tid; e < TB * TB; e += 256) {
+            const int r = e / TB, c = e - TB * r;
+            Lo[(size_t)(i * TB + r) * ldr + kb * TB + c] = sPi[r * LD + c];
+        }
+}
+
+// L y = b, L^T x = y with the tiles' inverses; one workgroup, the vector lives in LDS
+__global__ __launch_bounds__(256) void pg_dense_solve_kernel(const double *__restrict__ Lo,
+                                                             const double *__restrict__ Tinv, int ldr, int T,
+                                                             const double *__restrict__ rhs, double *__restrict__ x)
+{
+    extern __shared__ double sv[];  // ldr entries + TB * 8 partials + TB
+    double *sp = sv + ldr, *st = sp + TB * 8;
+    const int tid = threadIdx.x;
+    const int r = tid % TB, part = tid / TB;  // 48 rows x 5 column parts (240 threads busy)
+    for (int e = tid; e < ldr; e += 256)
+        sv[e] = rhs[e];
+    __syncthreads();
+    for (int kb = 0; kb < T; kb++) {  // forward
+        double acc = 0;
+        if (part < 5) {
+            const double *row = Lo + (size_t)(kb * TB + r) * ldr;
+            for (int c = part; c < kb * TB; c += 5)
+                acc += row[c] * sv[c];
+            sp[part * TB + r] = acc;
+        }
+        __syncthreads();
+        if (tid < TB)
+            st[tid] = sv[kb * TB + tid] - ((((sp[tid] + sp[TB + tid]) + sp[2 * TB + tid]) + sp[3 * TB + tid]) +
+                                           sp[4 * TB + tid]);
+        __syncthreads();
+        if (tid < TB) {
+            double a2 = 0;
+            const double *ti = Tinv + (size_t)kb * TB * TB + tid * TB;
+            for (int c = 0; c <= tid; c++)
+                a2 += ti[c] * st[c];
+            sv[kb * TB + tid] = a2;
+        }
+        __syncthreads();
+    }
+    for (int kb = T - 1; kb >= 0; kb--) {  // backward: x_kb = Tinv^T (y_kb - sum_{i>kb} L_i,kb^T x_i)
+        double acc = 0;
+        if (part < 5) {
+            for (int rr = (kb + 1) * TB + part; rr < T * TB; rr += 5)
+                acc += Lo[(size_t)rr * ldr + kb * TB + r] * sv[rr];
+            sp[part * TB + r] = acc;
+        }
+        __syncthreads();
+        if (tid < TB)
+            st[tid] = sv[kb * TB + tid] - ((((sp[tid] + sp[TB + tid]) + sp[2 * TB + tid]) + sp[3 * TB + tid]) +
+                                           sp[4 * TB + tid]);
+        __syncthreads();
+        if (tid < TB) {
+            double a2 = 0;
+            const double *ti = Tinv + (size_t)kb * TB * TB;
+            for (int c = tid; c < TB; c++)
+                a2 += ti[c * TB + tid] * st[c];
+            sv[kb * TB + tid] = a2;
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < ldr; e += 256)
+        x[e] = sv[e];
+}
+
+// dx of every block row: separators copy their reduced solution, interior rows combine
+// y - Wl x_l - Wr x_r (lsep / rsep: separator indices of the row's segment, -1 = none)
+__global__ __launch_bounds__(256) void pg_backsub_kernel(int nb, const int *__restrict__ sepidx,
+                                                         const int *__restrict__ lsep, const int *__restrict__ rsep,
+                                                         const double *__restrict__ xR, const double *__restrict__ Y,
+                                                         const double *__restrict__ Wl, const double *__restrict__ Wr,
+                                                         double *__restrict__ dx)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = t / 6, r = t - 6 * b;
+    if (b >= nb)
+        return;
+    const int si = sepidx[b];
+    if (si >= 0) {
+        dx[t] = xR[6 * si + r];
+        return;
+    }
+    double v = Y[t];
+    const int l = lsep[b], rr = rsep[b];
+    if (l >= 0) {
+#pragma unroll
+        for (int c = 0; c < 6; c++)
+            v -= Wl[(size_t)b * 36 + 6 * r + c] * xR[6 * l + c];
+    }
+    if (rr >= 0) {
+#pragma unroll
+        for (int c = 0; c < 6; c++)
+            v -= Wr[(size_t)b * 36 + 6 * r + c] * xR[6 * rr + c];
+    }
+    dx[t] = v;
 }
 
 __global__ __launch_bounds__(128) void pg_update_kernel(int nv, double *__restrict__ pose, const double *__restrict__ dx)
@@ -446,8 +789,8 @@ struct svo_posegraph {
     std::vector<int> efrom, eto;
     std::vector<double> meas;  // 7 per edge
     int prev = -1;
-    DevBuf d_pose, d_from, d_to, d_meas, d_eo, d_incptr, d_inc, d_benv, d_rowptr, d_Ld, d_Linv, d_Ls, d_rhs, d_y,
-        d_misc;
+    DevBuf d_pose, d_from, d_to, d_meas, d_eo, d_incptr, d_inc, d_struct, d_Dg, d_Cc, d_rneg, d_Li, d_Lsub, d_Z7, d_Y,
+        d_Wl, d_Wr, d_R, d_Lo, d_Tinv, d_rR, d_xR, d_dx, d_misc;
     int nv() const { return (int)(pose.size() / 7); }
     int ne() const { return (int)efrom.size(); }
 };
@@ -469,8 +812,9 @@ int svo_pg_destroy(svo_posegraph *g)
         return SVO_OK;
     (void)hipSetDevice(g->ctx->device);
     (void)hipStreamSynchronize(g->ctx->stream);
-    DevBuf *bufs[] = {&g->d_pose, &g->d_from, &g->d_to,   &g->d_meas, &g->d_eo,  &g->d_incptr, &g->d_inc, &g->d_benv,
-                      &g->d_rowptr, &g->d_Ld, &g->d_Linv, &g->d_Ls,   &g->d_rhs, &g->d_y,      &g->d_misc};
+    DevBuf *bufs[] = {&g->d_pose, &g->d_from, &g->d_to, &g->d_meas, &g->d_eo,  &g->d_incptr, &g->d_inc, &g->d_struct,
+                      &g->d_Dg,   &g->d_Cc,   &g->d_rneg, &g->d_Li, &g->d_Lsub, &g->d_Z7, &g->d_Y,     &g->d_Wl,
+                      &g->d_Wr,   &g->d_R,    &g->d_Lo, &g->d_Tinv, &g->d_rR,  &g->d_xR,  &g->d_dx,    &g->d_misc};
     for (DevBuf *b : bufs)
         b->release();
     delete g;
@@ -552,8 +896,8 @@ int svo_pg_optimize(svo_posegraph *g, int iters, double *chi2)
                 chi2[i] = 0;
         return SVO_OK;
     }
-    // ---- structure (host): incidence lists, block envelope, skyline offsets ----
-    std::vector<int> incptr(nv + 1, 0), inc(2 * ne), benv(nb), rowptr(nb + 1);
+    // ---- structure (host): incidence lists, separators, segments, gather lists ----
+    std::vector<int> incptr(nv + 1, 0), inc(2 * ne);
     for (int e = 0; e < ne; e++) {
         incptr[g->efrom[e] + 1]++;
         incptr[g->eto[e] + 1]++;
@@ -567,29 +911,123 @@ int svo_pg_optimize(svo_posegraph *g, int iters, double *chi2)
             inc[fill[g->eto[e]]++] = 2 * e + 1;
         }
     }
-    for (int b = 0; b < nb; b++)
-        benv[b] = b;
+    // separators: both ends of every chord (edge between non-neighbouring unknowns) + every SEG_L-th row
+    std::vector<int> sepidx(nb, -1);
+    std::vector<char> is_sep(nb, 0);
+    for (int b = SEG_L - 1; b < nb - 1; b += SEG_L)
+        is_sep[b] = 1;
     for (int e = 0; e < ne; e++) {
         const int i = g->efrom[e] - 1, j = g->eto[e] - 1;
-        if (i < 0 || j < 0 || i == j)
+        if (i < 0 || j < 0 || i == j || i - j == 1 || j - i == 1)
             continue;
-        const int hi = i > j ? i : j, lo = i > j ? j : i;
-        if (lo < benv[hi])
-            benv[hi] = lo;
+        is_sep[i] = 1;
+        is_sep[j] = 1;
     }
-    rowptr[0] = 0;
+    std::vector<int> seps;
     for (int b = 0; b < nb; b++)
-        rowptr[b + 1] = rowptr[b] + (b - benv[b]);
-    const size_t nblk = (size_t)rowptr[nb];
+        if (is_sep[b]) {
+            sepidx[b] = (int)seps.size();
+            seps.push_back(b);
+        }
+    const int m = (int)seps.size();
+    std::vector<int> seg_start, seg_len, lsep(nb, -1), rsep(nb, -1);
+    for (int b = 0; b < nb;) {
+        if (is_sep[b]) {
+            b++;
+            continue;
+        }
+        int z = b;
+        while (z + 1 < nb && !is_sep[z + 1])
+            z++;
+        seg_start.push_back(b);
+        seg_len.push_back(z - b + 1);
+        for (int r = b; r <= z; r++) {
+            lsep[r] = b > 0 ? sepidx[b - 1] : -1;
+            rsep[r] = z + 1 < nb ? sepidx[z + 1] : -1;
+        }
+        b = z + 1;
+    }
+    const int nseg = (int)seg_start.size();
+    // gather lists of the reduced system: diagonal + sub-diagonal blocks in separator order, chords
+    struct Key {
+        int r, c;
+        bool operator<(const Key &o) const { return r != o.r ? r < o.r : c < o.c; }
+    };
+    std::map<Key, std::vector<int2>> blocks;
+    for (int k = 0; k < m; k++) {
+        const int sr = seps[k];
+        std::vector<int2> &d = blocks[{k, k}];
+        d.push_back(make_int2(0, sr));
+        if (sr + 1 < nb && !is_sep[sr + 1])
+            d.push_back(make_int2(4, sr));  // segment to the right
+        if (sr > 0 && !is_sep[sr - 1])
+            d.push_back(make_int2(5, sr - 1));  // segment to the left
+        if (k > 0) {
+            const int sl = seps[k - 1];
+            if (sl + 1 == sr)
+                blocks[{k, k - 1}].push_back(make_int2(1, sl));
+            else
+                blocks[{k, k - 1}].push_back(make_int2(6, sr - 1));
+        }
+    }
+    for (int e = 0; e < ne; e++) {
+        const int i = g->efrom[e] - 1, j = g->eto[e] - 1;
+        if (i < 0 || j < 0 || i == j || i - j == 1 || j - i == 1)
+            continue;
+        // block(row i, col j) = Ji^T Jj; stored at (hi, lo)
+        if (i > j)
+            blocks[{sepidx[i], sepidx[j]}].push_back(make_int2(2, e));
+        else
+            blocks[{sepidx[j], sepidx[i]}].push_back(make_int2(3, e));
+    }
+    const int n_rblocks = (int)blocks.size();
+    std::vector<int> rb_row, rb_col, rptr(1, 0);
+    std::vector<int2> rsrc;
+    for (auto &kv : blocks) {
+        rb_row.push_back(kv.first.r);
+        rb_col.push_back(kv.first.c);
+        rsrc.insert(rsrc.end(), kv.second.begin(), kv.second.end());
+        rptr.push_back((int)rsrc.size());
+    }
+    for (int k = 0; k < m; k++) {  // right-hand sides
+        const int sr = seps[k];
+        rsrc.push_back(make_int2(0, sr));
+        if (sr + 1 < nb && !is_sep[sr + 1])
+            rsrc.push_back(make_int2(4, sr));
+        if (sr > 0 && !is_sep[sr - 1])
+            rsrc.push_back(make_int2(5, sr - 1));
+        rptr.push_back((int)rsrc.size());
+    }
+    const int T = (6 * m + TB - 1) / TB, ldr = T * TB;
+    // one int buffer for all the structure arrays
+    std::vector<int> hs;
+    auto put = [&](const std::vector<int> &v) {
+        const size_t off = hs.size();
+        hs.insert(hs.end(), v.begin(), v.end());
+        return off;
+    };
+    const size_t o_seg_start = put(seg_start), o_seg_len = put(seg_len), o_sepidx = put(sepidx), o_lsep = put(lsep),
+                 o_rsep = put(rsep), o_rb_row = put(rb_row), o_rb_col = put(rb_col), o_rptr = put(rptr);
+    if (hs.size() & 1)
+        hs.push_back(0);
+    const size_t o_rsrc = hs.size();
+    for (const int2 &v : rsrc) {
+        hs.push_back(v.x);
+        hs.push_back(v.y);
+    }
     int rc;
     if ((rc = g->d_pose.ensure((size_t)nv * 56)) || (rc = g->d_from.ensure((size_t)ne * 4)) ||
         (rc = g->d_to.ensure((size_t)ne * 4)) || (rc = g->d_meas.ensure((size_t)ne * 56)) ||
         (rc = g->d_eo.ensure((size_t)ne * sizeof(EdgeOut))) || (rc = g->d_incptr.ensure((size_t)(nv + 1) * 4)) ||
-        (rc = g->d_inc.ensure((size_t)2 * ne * 4)) || (rc = g->d_benv.ensure((size_t)nb * 4)) ||
-        (rc = g->d_rowptr.ensure((size_t)(nb + 1) * 4)) || (rc = g->d_Ld.ensure((size_t)nb * 288)) ||
-        (rc = g->d_Linv.ensure((size_t)nb * 288)) || (rc = g->d_Ls.ensure((nblk + 1) * 288)) ||
-        (rc = g->d_rhs.ensure((size_t)nb * 48)) || (rc = g->d_y.ensure((size_t)nb * 48)) ||
-        (rc = g->d_misc.ensure(((size_t)iters + 4) * 8 + 64)))
+        (rc = g->d_inc.ensure((size_t)2 * ne * 4)) || (rc = g->d_struct.ensure(hs.size() * 4 + 16)) ||
+        (rc = g->d_Dg.ensure((size_t)nb * 288)) || (rc = g->d_Cc.ensure((size_t)nb * 288)) ||
+        (rc = g->d_rneg.ensure((size_t)nb * 48)) || (rc = g->d_Li.ensure((size_t)nb * 288)) ||
+        (rc = g->d_Lsub.ensure((size_t)(nb + 1) * 288)) || (rc = g->d_Z7.ensure((size_t)nb * 42 * 8)) ||
+        (rc = g->d_Y.ensure((size_t)nb * 48)) || (rc = g->d_Wl.ensure((size_t)nb * 288)) ||
+        (rc = g->d_Wr.ensure((size_t)nb * 288)) || (rc = g->d_R.ensure((size_t)ldr * ldr * 8 + 64)) ||
+        (rc = g->d_Lo.ensure((size_t)ldr * ldr * 8 + 64)) || (rc = g->d_Tinv.ensure((size_t)T * TB * TB * 8 + 64)) ||
+        (rc = g->d_rR.ensure((size_t)ldr * 8 + 64)) || (rc = g->d_xR.ensure((size_t)ldr * 8 + 64)) ||
+        (rc = g->d_dx.ensure((size_t)nb * 48)) || (rc = g->d_misc.ensure(((size_t)iters + 4) * 8 + 64)))
         return rc;
     hipStream_t st = ctx->stream;
     SVO_HIP(hipMemcpyAsync(g->d_pose.p, g->pose.data(), (size_t)nv * 56, hipMemcpyHostToDevice, st));
@@ -598,13 +1036,18 @@ int svo_pg_optimize(svo_posegraph *g, int iters, double *chi2)
     SVO_HIP(hipMemcpyAsync(g->d_meas.p, g->meas.data(), (size_t)ne * 56, hipMemcpyHostToDevice, st));
     SVO_HIP(hipMemcpyAsync(g->d_incptr.p, incptr.data(), (size_t)(nv + 1) * 4, hipMemcpyHostToDevice, st));
     SVO_HIP(hipMemcpyAsync(g->d_inc.p, inc.data(), (size_t)2 * ne * 4, hipMemcpyHostToDevice, st));
-    SVO_HIP(hipMemcpyAsync(g->d_benv.p, benv.data(), (size_t)nb * 4, hipMemcpyHostToDevice, st));
-    SVO_HIP(hipMemcpyAsync(g->d_rowptr.p, rowptr.data(), (size_t)(nb + 1) * 4, hipMemcpyHostToDevice, st));
+    SVO_HIP(hipMemcpyAsync(g->d_struct.p, hs.data(), hs.size() * 4, hipMemcpyHostToDevice, st));
     // the host vectors above must outlive the async copies
     SVO_HIP(hipStreamSynchronize(st));
+    const int *ds = g->d_struct.as<int>();
     double *d_chi = g->d_misc.as<double>();
     int *d_status = reinterpret_cast<int *>(d_chi + iters + 2);
+    SVO_HIP(hipMemsetAsync(d_status, 0, 4, st));
     EdgeOut *eo = reinterpret_cast<EdgeOut *>(g->d_eo.p);
+    double *Dg = g->d_Dg.as<double>(), *Cc = g->d_Cc.as<double>(), *rneg = g->d_rneg.as<double>();
+    double *Y = g->d_Y.as<double>(), *Wl = g->d_Wl.as<double>(), *Wr = g->d_Wr.as<double>();
+    double *R = g->d_R.as<double>(), *Lo = g->d_Lo.as<double>(), *Tinv = g->d_Tinv.as<double>();
+    double *rR = g->d_rR.as<double>(), *xR = g->d_xR.as<double>(), *dx = g->d_dx.as<double>();
     ScopedKernelTime tm(ctx, SVO_K_POSEGRAPH);
     for (int it = 0; it <= iters; it++) {
         hipLaunchKernelGGL(pg_linearize_kernel, dim3((ne + 127) / 128), dim3(128), 0, st, g->d_pose.as<double>(),
@@ -612,15 +1055,33 @@ int svo_pg_optimize(svo_posegraph *g, int iters, double *chi2)
         hipLaunchKernelGGL(pg_chi2_kernel, dim3(1), dim3(256), 0, st, eo, ne, d_chi + it);
         if (it == iters)
             break;
-        SVO_HIP(hipMemsetAsync(g->d_Ls.p, 0, (nblk + 1) * 288, st));
         hipLaunchKernelGGL(pg_assemble_kernel, dim3((nb + 127) / 128), dim3(128), 0, st, nb, g->d_incptr.as<int>(),
-                           g->d_inc.as<int>(), g->d_from.as<int>(), g->d_to.as<int>(), eo, g->d_benv.as<int>(),
-                           g->d_rowptr.as<int>(), g->d_Ld.as<double>(), g->d_Ls.as<double>(), g->d_rhs.as<double>());
-        hipLaunchKernelGGL(pg_solve_kernel, dim3(1), dim3(64), 0, st, nb, g->d_benv.as<int>(), g->d_rowptr.as<int>(),
-                           g->d_Ld.as<double>(), g->d_Linv.as<double>(), g->d_Ls.as<double>(), g->d_rhs.as<double>(),
-                           g->d_y.as<double>(), d_status);
-        hipLaunchKernelGGL(pg_update_kernel, dim3((nv + 127) / 128), dim3(128), 0, st, nv, g->d_pose.as<double>(),
-                           g->d_y.as<double>());
+                           g->d_inc.as<int>(), g->d_from.as<int>(), g->d_to.as<int>(), eo, Dg, Cc, rneg);
+        if (nseg > 0)
+            hipLaunchKernelGGL(pg_segment_kernel, dim3(nseg), dim3(64), 0, st, nb, ds + o_seg_start, ds + o_seg_len, Dg,
+                               Cc, rneg, g->d_Li.as<double>(), g->d_Lsub.as<double>(), g->d_Z7.as<double>(), Y, Wl, Wr,
+                               d_status);
+        if (m > 0) {
+            const size_t tot = (size_t)ldr * ldr;
+            hipLaunchKernelGGL(pg_reduce_clear_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, R, ldr,
+                               6 * m, rR);
+            hipLaunchKernelGGL(pg_reduce_kernel, dim3(n_rblocks + m), dim3(64), 0, st, n_rblocks, m, ds + o_rb_row,
+                               ds + o_rb_col, ds + o_rptr, reinterpret_cast<const int2 *>(ds + o_rsrc), Dg, Cc, rneg, eo,
+                               Y, Wl, Wr, R, ldr, rR);
+            for (int kb = 0; kb < T; kb++) {
+                hipLaunchKernelGGL(pg_dense_potf2_kernel, dim3(1), dim3(256), 0, st, R, Lo, Tinv, ldr, kb, d_status,
+                                   1 << 20);
+                const int nt = T - 1 - kb;
+                if (nt > 0)
+                    hipLaunchKernelGGL(pg_dense_update_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, st, R, Lo, Tinv,
+                                       ldr, kb, T);
+            }
+            hipLaunchKernelGGL(pg_dense_solve_kernel, dim3(1), dim3(256), (size_t)(ldr + TB * 9) * 8, st, Lo, Tinv, ldr,
+                               T, rR, xR);
+        }
+        hipLaunchKernelGGL(pg_backsub_kernel, dim3((nb * 6 + 255) / 256), dim3(256), 0, st, nb, ds + o_sepidx,
+                           ds + o_lsep, ds + o_rsep, xR, Y, Wl, Wr, dx);
+        hipLaunchKernelGGL(pg_update_kernel, dim3((nv + 127) / 128), dim3(128), 0, st, nv, g->d_pose.as<double>(), dx);
     }
     SVO_HIP(hipGetLastError());
     SVO_HIP(hipMemcpyAsync(g->pose.data(), g->d_pose.p, (size_t)nv * 56, hipMemcpyDeviceToHost, st));
@@ -632,7 +1093,11 @@ int svo_pg_optimize(svo_posegraph *g, int iters, double *chi2)
     if (chi2)
         memcpy(chi2, hchi.data(), (size_t)(iters + 1) * 8);
     if (iters > 0 && hstatus != 0) {
-        svo_set_error("pose graph: normal matrix not positive definite at block row %d", hstatus - 1);
+        if (hstatus >= (1 << 20))
+            svo_set_error("pose graph: reduced (separator) system not positive definite at row %d",
+                          hstatus - (1 << 20) - 1);
+        else
+            svo_set_error("pose graph: normal matrix not positive definite at block row %d", hstatus - 1);
         return SVO_ERR_STATE;
     }
     return SVO_OK;
