@@ -58,6 +58,9 @@ int orc_anms(const float *xy, const float *response, int n, int num_to_keep, int
     }
     double *radii = (double *)malloc(sizeof(double) * n), *sorted = (double *)malloc(sizeof(double) * n);
     const float robust = 1.11f;
+    /* every keypoint's suppression radius is independent (a minimum: order-free), so the loop is
+     * shared among OpenMP threads */
+#pragma omp parallel for schedule(dynamic, 64)
     for (int i = 0; i < n; i++) {
         const float r = kp[i].resp * robust;
         double radius = DBL_MAX;

@@ -27,6 +27,15 @@
 #include <stdlib.h>
 #include <string.h>
 
+#ifdef _OPENMP
+#include <omp.h>
+int orc_num_threads(void) { return omp_get_max_threads(); }
+void orc_set_num_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); }
+#else
+int orc_num_threads(void) { return 1; }
+void orc_set_num_threads(int n) { (void)n; }
+#endif
+
 void orc_lk_default_params(orc_lk_params *p)
 {
     p->win = ORC_LK_WIN;
@@ -221,17 +230,23 @@ int orc_lk_track(const uint8_t *prev, const uint8_t *next, int w, int h, int c,
     }
 
     const int wn = win * win * c;
-    int16_t *Iw = (int16_t *)malloc(sizeof(int16_t) * wn);
-    int16_t *dIw = (int16_t *)malloc(sizeof(int16_t) * wn * 2);
     const float half = (win - 1) * 0.5f;
     const float FLT_SCALE = 1.f / (1 << 20);
     const int W_BITS = 14;
 
+    /* Points are independent of each other (only the levels of ONE point depend on each other),
+     * so the point loop is shared among OpenMP threads; every sum is exact integer arithmetic,
+     * the result does not depend on the thread count (OMP_NUM_THREADS=1 gives the scalar port). */
+#pragma omp parallel
+    {
+    int16_t *Iw = (int16_t *)malloc(sizeof(int16_t) * wn);
+    int16_t *dIw = (int16_t *)malloc(sizeof(int16_t) * wn * 2);
     for (int level = P.max_level; level >= 0; level--) {
         const int lw = ws[level], lh = hs[level];
         const uint8_t *I = pl[level].pimg, *J = nx[level].pimg;
         const int16_t *dI = pl[level].deriv;
         const float scale = (float)(1. / (1 << level));
+#pragma omp for schedule(dynamic, 16)
         for (int p = 0; p < n; p++) {
             float px = prev_pts[2 * p] * scale, py = prev_pts[2 * p + 1] * scale;
             float nxp, nyp;
@@ -390,6 +405,7 @@ int orc_lk_track(const uint8_t *prev, const uint8_t *next, int w, int h, int c,
     }
     free(Iw);
     free(dIw);
+    }
     for (int l = 0; l < nl; l++) {
         free(pl[l].img);
         free(nx[l].img);

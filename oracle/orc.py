@@ -168,6 +168,14 @@ def rodrigues_inv(R):
     return r
 
 
+def num_threads() -> int:
+    return int(load().orc_num_threads())
+
+
+def set_num_threads(n: int) -> None:
+    load().orc_set_num_threads(int(n))
+
+
 def compose_camera_pose(rvec, tvec):
     R, t = np.zeros((3, 3)), np.zeros(3)
     load().orc_compose_camera_pose(_p(np.ascontiguousarray(rvec, np.float64)),

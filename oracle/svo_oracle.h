@@ -38,6 +38,9 @@ typedef struct {
     double min_eig_thr; /* 1e-4                                                          */
 } orc_lk_params;
 
+/* OpenMP threads the point-parallel loops (LK, ANMS radii) use; results do not depend on it */
+int orc_num_threads(void);
+void orc_set_num_threads(int n);
 void orc_lk_default_params(orc_lk_params *p);
 
 /* level sizes of the pyramid: ((w+1)/2, (h+1)/2) per level */

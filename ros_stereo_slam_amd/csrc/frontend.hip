@@ -241,14 +241,7 @@ int svo_vo_create(svo_ctx *ctx, const svo_vo_params *params, int width, int heig
         svo_vo_destroy(v);
         return rc;
     }
-    // The PnP stream is created in the high-priority class: HIP keeps a separate pool of hardware
-    // queues per priority class, so the two streams of a chunk never land on one queue (with both
-    // in the default class the runtime was seen to put them on the same queue, which serialises
-    // the overlap away), and PnP -- the stage the host waits for -- is dispatched first.
-    int prio_lo = 0, prio_hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    if (hipStreamCreateWithPriority(&v->stream_b, hipStreamNonBlocking, prio_hi) != hipSuccess ||
-        hipEventCreateWithFlags(&v->ev_a, hipEventDisableTiming) != hipSuccess ||
+    if (hipEventCreateWithFlags(&v->ev_a, hipEventDisableTiming) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void **>(&v->mbox), sizeof(Mailbox),
                       hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
         svo_set_error("front-end: cannot create the second stream / event");
@@ -453,6 +446,16 @@ int svo_vo_run_chunk(svo_vo *v, const uint8_t *const *lefts, const uint8_t *cons
     SVO_CHECK_ARG(v && lefts && rights && n_frames >= 0 && R_out && t_out);
     SVO_CHECK_ARG(mem == SVO_MEM_HOST || mem == SVO_MEM_DEVICE);
     svo_ctx *ctx = v->ctx;
+    if (pipeline && mem == SVO_MEM_DEVICE && !v->stream_b) {
+        // The PnP stream exists only once pipelining is asked for, and in the high-priority class:
+        // HIP keeps a separate pool of hardware queues per priority class, so the two streams of
+        // a chunk never land on one queue (with both in the default class the runtime was seen to
+        // put them on the same queue, which serialises the overlap away), and creating it does not
+        // disturb the stream -> queue assignment of serial chunks running side by side.
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        SVO_HIP(hipStreamCreateWithPriority(&v->stream_b, hipStreamNonBlocking, prio_hi));
+    }
     hipStream_t sA = ctx->stream, sB = v->stream_b;
     if (n_done)
         *n_done = 0;
