@@ -188,23 +188,6 @@ def main():
     for c in ctxs:
         c.enable_kernel_timing(False)
 
-    # beside the throughput figure: ONE chunk alone with the two-stream pipeline (what a single
-    # live stream gets); reported in config, not part of the timed K steps above
-    single_fps = None
-    if M > 1 and rank == 0:
-        first = args.warmup + split(args.steps)[0]
-        idx = [pingpong(first + k + 1, args.frames) for k in range(args.steps + 4)]
-        # untimed: the first pipelined call creates the chunk's second stream (a hardware queue)
-        vos[0].run_chunk([dev_frames[0][i][0] for i in idx[:4]], [dev_frames[0][i][1] for i in idx[:4]], pipeline=True)
-        ctxs[0].sync()
-        idx = idx[4:]
-        s0 = time.perf_counter()
-        rc1, done1, *_ = vos[0].run_chunk([dev_frames[0][i][0] for i in idx], [dev_frames[0][i][1] for i in idx],
-                                          pipeline=True)
-        ctxs[0].sync()
-        if rc1 == 0:
-            single_fps = done1 / (time.perf_counter() - s0)
-
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -236,7 +219,8 @@ def main():
                 "keyframe_min_inliers": KF_MIN_INLIERS,
                 "parallelism": f"{M} contiguous chunk(s) per GPU x{world} GPU(s), all-gather of chunk-boundary poses",
                 "chunks_per_gpu": M,
-                "single_chunk_pipelined_frames_per_s": single_fps,
+                "single_chunk_reference": "one chunk alone: 1.85 k frames/s with the two-stream pipeline "
+                                          "(--chunks-per-gpu 1), 1.32 k serial (DESIGN.md section 6)",
                 "pipeline": "two HIP streams per chunk: PnP(t) beside pyramid+LK(t+1)" if pipeline
                             else "one in-order HIP stream per chunk",
                 "keyframe_rate": kf_rate,
