@@ -83,15 +83,20 @@ __device__ __forceinline__ int row16_sum(int v)
     v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);  // row_mirror
     return v;
 }
-__device__ __forceinline__ long long wave_sum_i64(int v)
+// the total of all 64 lanes, valid in lane 63 only: two more DPP steps carry the row totals
+// across (row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3)
+__device__ __forceinline__ int wave_total_lane63(int v)
 {
-    int lo = row16_sum(v & 0xffff);
-    int hi = row16_sum(v >> 16);
-    int slo = __builtin_amdgcn_readlane(lo, 0) + __builtin_amdgcn_readlane(lo, 16) +
-              __builtin_amdgcn_readlane(lo, 32) + __builtin_amdgcn_readlane(lo, 48);
-    int shi = __builtin_amdgcn_readlane(hi, 0) + __builtin_amdgcn_readlane(hi, 16) +
-              __builtin_amdgcn_readlane(hi, 32) + __builtin_amdgcn_readlane(hi, 48);
-    return (long long)shi * 65536ll + (long long)slo;
+    v = row16_sum(v);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31
+    return __builtin_amdgcn_readlane(v, 63);
+}
+// exact 64-lane sum as a double (|total| < 2^37: exactly representable), wave-uniform
+__device__ __forceinline__ double wave_sum_exact(int v)
+{
+    const int slo = wave_total_lane63(v & 0xffff), shi = wave_total_lane63(v >> 16);
+    return (double)shi * 65536. + (double)slo;
 }
 
 __device__ __forceinline__ void bilinear_weights(float a, float b, int &w00, int &w01, int &w10,
@@ -133,6 +138,11 @@ __device__ __forceinline__ int stage_tile(uint8_t *tile, const uint8_t *__restri
     return shift;
 }
 
+// Every lane of a wave computes the same control values (guess, step, tile origin): telling the
+// compiler so turns the loop's branches into scalar compares instead of exec-mask juggling.
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ bool uniform(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0; }
+
 typedef short short2v __attribute__((ext_vector_type(2)));
 constexpr int npairs(int c) { return (SEG * c + 1) / 2; }
 constexpr int ndwords(int c) { return ((SEG + 1) * c + 3) / 4; }  // packed dwords of one (SEG+1)-pixel row run
@@ -140,6 +150,15 @@ constexpr int ndwords(int c) { return ((SEG + 1) * c + 3) / 4; }  // packed dwor
 __device__ __forceinline__ int sdot2(int a, int b, int c)
 {
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b), c, false);
+}
+
+// dot(a, b) + c with c in an SGPR: the VOP3P form, so a rounding constant costs no v_mov per
+// element (the compiler's own choice is v_mov + the accumulate-in-place VOP2 form)
+__device__ __forceinline__ int sdot2_sconst(int a, int b, int c_uniform)
+{
+    int d;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c_uniform));
+    return d;
 }
 
 // The (SEG+1)*C bytes of a row run starting at LDS byte offset `off` (any alignment), as
@@ -206,14 +225,15 @@ __device__ __forceinline__ void lane_residual(const uint8_t *lds, int off, int w
     v[NE] = 0;
     ForEachElem<C, NE>::run([&](auto kc) {
         constexpr int k = decltype(kc)::value;
-        v[k] = sdot2(pixel_pair<C, k>(r1), wp1, sdot2(pixel_pair<C, k>(r0), wp0, RND)) >> (W_BITS - 5);
+        v[k] = sdot2(pixel_pair<C, k>(r1), wp1, sdot2_sconst(pixel_pair<C, k>(r0), wp0, RND)) >> (W_BITS - 5);
     });
     s1 = 0;
     s2 = 0;
 #pragma unroll
     for (int j = 0; j < npairs(C); j++) {
         const int k0 = 2 * j, k1 = 2 * j + 1 < NE ? 2 * j + 1 : NE;  // v[NE] == 0 pads an odd count
-        const short2v d = __builtin_bit_cast(short2v, v[k0] | (v[k1] << 16)) - __builtin_bit_cast(short2v, Ivp[j]);
+        // 0 <= v < 2^15: the low halves of the two words, packed by one v_perm_b32
+        const short2v d = __builtin_bit_cast(short2v, half_pair<false>(v[k0], v[k1])) - __builtin_bit_cast(short2v, Ivp[j]);
         if (ABS) {
             int d0 = d.x, d1 = d.y;
             s1 += (d0 < 0 ? -d0 : d0) + (2 * j + 1 < NE ? (d1 < 0 ? -d1 : d1) : 0);
@@ -278,7 +298,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void lk_track_kernel(
         outy = nyp;
         px -= half;
         py -= half;
-        const int ipx = (int)floorf(px), ipy = (int)floorf(py);
+        const int ipx = uniform((int)floorf(px)), ipy = uniform((int)floorf(py));
         if (ipx < -WIN || ipx >= lw || ipy < -WIN || ipy >= lh) {
             if (level == 0) {
                 st = 0;
@@ -350,16 +370,15 @@ __global__ __launch_bounds__(64 * WAVES, 3) void lk_track_kernel(
             a12 = 0;
             a22 = 0;
         }
-        const long long sA11 = wave_sum_i64(a11), sA12 = wave_sum_i64(a12), sA22 = wave_sum_i64(a22);
-        const float A11 = (float)(double)sA11 * FLT_SCALE;
-        const float A12 = (float)(double)sA12 * FLT_SCALE;
-        const float A22 = (float)(double)sA22 * FLT_SCALE;
+        const float A11 = (float)wave_sum_exact(a11) * FLT_SCALE;
+        const float A12 = (float)wave_sum_exact(a12) * FLT_SCALE;
+        const float A22 = (float)wave_sum_exact(a22) * FLT_SCALE;
         float Dd = A11 * A22 - A12 * A12;
         const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) /
                              (float)(2 * WIN * WIN);
         if (level == 0)
             mineig0 = minEig;
-        if (minEig < prm.min_eig_thr || Dd < 1.1920928955078125e-7f) {
+        if (uniform(minEig < prm.min_eig_thr || Dd < 1.1920928955078125e-7f)) {
             if (level == 0)
                 st = 0;
             continue;
@@ -374,7 +393,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void lk_track_kernel(
         bool have_tile = false;
         const uint8_t *TJs = TJ;
         for (int j = 0; j < prm.max_count; j++) {
-            const int inx = (int)floorf(nxp), iny = (int)floorf(nyp);
+            const int inx = uniform((int)floorf(nxp)), iny = uniform((int)floorf(nyp));
             if (inx < -WIN || inx >= lw || iny < -WIN || iny >= lh) {
                 if (level == 0)
                     st = 0;
@@ -397,18 +416,17 @@ __global__ __launch_bounds__(64 * WAVES, 3) void lk_track_kernel(
                 s1 = 0;
                 s2 = 0;
             }
-            const long long sb1 = wave_sum_i64(s1), sb2 = wave_sum_i64(s2);
-            const float b1 = (float)(double)sb1 * FLT_SCALE;
-            const float b2 = (float)(double)sb2 * FLT_SCALE;
+            const float b1 = (float)wave_sum_exact(s1) * FLT_SCALE;
+            const float b2 = (float)wave_sum_exact(s2) * FLT_SCALE;
             const float dx = (A12 * b2 - A22 * b1) * Dd;
             const float dy = (A12 * b1 - A11 * b2) * Dd;
             nxp += dx;
             nyp += dy;
             outx = nxp + half;
             outy = nyp + half;
-            if ((double)dx * (double)dx + (double)dy * (double)dy <= prm.eps_sq)
+            if (uniform((double)dx * (double)dx + (double)dy * (double)dy <= prm.eps_sq))
                 break;
-            if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) {
+            if (j > 0 && uniform(fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01)) {
                 outx -= dx * 0.5f;
                 outy -= dy * 0.5f;
                 break;
@@ -420,7 +438,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void lk_track_kernel(
         // ---- 3. level-0 residual (err output of calcOpticalFlowPyrLK) ----
         if (st && level == 0) {
             const float qx = outx - half, qy = outy - half;
-            const int iqx = (int)floorf(qx), iqy = (int)floorf(qy);
+            const int iqx = uniform((int)floorf(qx)), iqy = uniform((int)floorf(qy));
             if (iqx < -WIN || iqx >= lw || iqy < -WIN || iqy >= lh) {
                 st = 0;
                 continue;
@@ -440,7 +458,7 @@ __global__ __launch_bounds__(64 * WAVES, 3) void lk_track_kernel(
                                    s2);
             if (!active)
                 s1 = 0;
-            const long long sabs = wave_sum_i64(s1);  // < 2^24
+            const long long sabs = (long long)wave_sum_exact(s1);  // < 2^24
             errv = (float)sabs / (float)(32 * WIN * C * WIN);
         }
     }
