@@ -136,6 +136,18 @@ int svo_transform_points(svo_ctx *ctx, const double *Rt, const float *in_xyz, in
 /* getColors, include/monoUtils.h:180-193: B,G,R of level 0 at (int(y), int(x)) as floats.      */
 int svo_get_colors(svo_ctx *ctx, const svo_pyramid *pyr, const float *xy, int n, float *out_bgr, int mem);
 
+/* ---- map clean-up: visualSLAM::SORcloud(ref3d, colorMap), src/rosFuncs.cpp:9-39 ------------- */
+/* Drops points with -z > z_limit (500 upstream, :12; <= 0 disables), then the statistical
+ * outlier removal PCL applies at :19-23 (mean_k 200, stddev_mul 0.01): mean distance to the
+ * mean_k nearest other points, keep d <= mean + stddev_mul * stddev.  xyz / color: n x 3 floats
+ * (color may be NULL, then color_out is ignored); outputs compacted in input order, n capacity.
+ * n_out / n_pass_out (points that passed the z filter, optional) are HOST ints in both modes;
+ * mean_dist_out (optional, n floats): the mean neighbour distance of every point that passed the
+ * z filter.  At most 9216 points per call.                                                     */
+int svo_sor_filter(svo_ctx *ctx, const float *xyz, const float *color, int n, int mean_k, double stddev_mul,
+                   float z_limit, float *xyz_out, float *color_out, int *n_out, float *mean_dist_out,
+                   int *n_pass_out, int mem);
+
 /* ---- ANMS: adaptiveNonMaximalSuppresion(keypoints, numToKeep), src/ANMS.cpp:18-67 ------------ */
 /* xy: n*2 floats, response: n floats (the reference's grid keypoints carry response 0; the
  * front-end passes the level-0 LK minimum eigenvalue).  out_idx: n ints capacity, receives the

@@ -12,8 +12,9 @@
 //    through the device (like the reference, it rebuilds image pyramids per call).
 //  * processFrame(): the body of initSequence's loop (src/VisualSLAM.cpp:54-169) on the
 //    fused, device-resident front-end (svo_vo) + the device pose graph -- the fast path.
-// Not here (out of the hot path): ROS publishing, Pangolin viewer, PCL outlier removal,
-// DBoW2 loop detection (checkLoopDetectorStatus) -- their outputs (LC_FLAG, LCidx) are inputs.
+//  * SORcloud(): the map clean-up of src/rosFuncs.cpp:9-39 (PCL StatisticalOutlierRemoval) on the GPU.
+// Not here (out of the hot path): ROS publishing, Pangolin viewer, DBoW2 loop detection
+// (checkLoopDetectorStatus) -- its outputs (LC_FLAG, LCidx) are inputs.
 #pragma once
 
 #include <cstdio>
@@ -168,6 +169,25 @@ class visualSLAM {
         std::vector<Point3f> out(pt3d.size());
         check(svo_transform_points(ctx_, pose4dTransform.m, f3(pt3d), (int)pt3d.size(), f3(out), SVO_MEM_HOST));
         return out;
+    }
+
+    // ---- src/rosFuncs.cpp:9-39: far-point filter (-z > 500) + statistical outlier removal
+    //      (mean_k 200, stddev multiplier 0.01); colorMap is B,G,R per point and is filtered alike ----
+    void SORcloud(std::vector<Point3f> &ref3d, std::vector<Point3f> &colorMap)
+    {
+        const int n = (int)ref3d.size();
+        std::vector<Point3f> p(ref3d.size()), c(colorMap.size());
+        int kept = 0;
+        const bool with_color = colorMap.size() == ref3d.size() && n > 0;
+        check(svo_sor_filter(ctx_, f3(ref3d), with_color ? f3(colorMap) : nullptr, n, 200, 0.01, 500.f, f3(p),
+                             with_color ? f3(c) : nullptr, &kept, nullptr, nullptr, SVO_MEM_HOST));
+        p.resize((size_t)kept);
+        ref3d = p;
+        if (with_color) {
+            c.resize((size_t)kept);
+            colorMap = c;
+        } else
+            colorMap.clear();
     }
 
     // ---- src/keyFrameManagement.cpp:9-31 ----

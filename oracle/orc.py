@@ -250,6 +250,21 @@ def anms(xy, response, num_to_keep):
     return idx[:k].copy(), radii[:n]
 
 
+def sor_filter(xyz, color=None, mean_k=200, stddev_mul=0.01, z_limit=500.0):
+    """visualSLAM::SORcloud (src/rosFuncs.cpp:9-39).  Returns (xyz_kept, color_kept, mean_dist)."""
+    xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+    n = len(xyz)
+    col = None if color is None else np.ascontiguousarray(color, np.float32).reshape(-1, 3)
+    xo, co, md = np.zeros((max(n, 1), 3), np.float32), np.zeros((max(n, 1), 3), np.float32), np.zeros(max(n, 1), np.float32)
+    lib = load()
+    lib.orc_sor_filter.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_float, C.c_void_p,
+                                   C.c_void_p, C.c_void_p]
+    k = lib.orc_sor_filter(_p(xyz), _p(col) if col is not None else None, n, mean_k, stddev_mul, z_limit, _p(xo),
+                           _p(co) if col is not None else None, _p(md))
+    n_pass = n if z_limit <= 0 else int(np.sum(~(-xyz[:, 2] > z_limit)))
+    return xo[:k].copy(), (co[:k].copy() if col is not None else None), md[:n_pass].copy()
+
+
 # ---- front-end frame loop -----------------------------------------------------------------
 class VoParams(C.Structure):
     _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),

@@ -203,6 +203,15 @@ void orc_vo_get_ref(const orc_vo *v, float *ref2d, float *ref3d);
 int orc_vo_track(orc_vo *v, const uint8_t *left, const uint8_t *right, int force_keyframe,
                  double *R, double *t, int *n_inliers, int *was_keyframe, int *n_tracked);
 
+/* ---- statistical outlier removal of the map points -------------------------------------- */
+/* stands in for visualSLAM::SORcloud (src/rosFuncs.cpp:9-39): drop points with -z > z_limit
+ * (500 upstream; <= 0 disables), then pcl::StatisticalOutlierRemoval with mean_k (200) and
+ * stddev_mul (0.01).  xyz / color: n x 3 float32 (color may be NULL); outputs are written
+ * compacted in input order; mean_dist_out (optional): the mean neighbour distance of every point
+ * that passed the z filter.  Returns the number of points kept.                              */
+int orc_sor_filter(const float *xyz, const float *color, int n, int mean_k, double stddev_mul, float z_limit,
+                   float *xyz_out, float *color_out, float *mean_dist_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -266,6 +266,20 @@ def anms(self, xy, response, num_to_keep):
 
 
 @_ctx_method
+def sor_filter(self, xyz, color=None, mean_k=200, stddev_mul=0.01, z_limit=500.0):
+    """visualSLAM::SORcloud (src/rosFuncs.cpp:9-39) -> (xyz_kept, color_kept or None, mean_dist)."""
+    xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+    col = None if color is None else np.ascontiguousarray(color, np.float32).reshape(-1, 3)
+    n = xyz.shape[0]
+    xo, co, md = np.zeros((max(n, 1), 3), np.float32), np.zeros((max(n, 1), 3), np.float32), np.zeros(max(n, 1), np.float32)
+    kept, passed = C.c_int(), C.c_int()
+    _check(self.lib.svo_sor_filter(self._h, _ptr(xyz), _ptr(col), n, int(mean_k), C.c_double(stddev_mul),
+                                   C.c_float(z_limit), _ptr(xo), _ptr(co) if col is not None else _ptr(None),
+                                   C.byref(kept), _ptr(md), C.byref(passed), MEM_HOST))
+    return xo[:kept.value].copy(), (co[:kept.value].copy() if col is not None else None), md[:passed.value].copy()
+
+
+@_ctx_method
 def pnp_ransac(self, obj, img, K4, iterations=100, reproj_err=1.0, confidence=0.99, seed=0):
     obj = np.ascontiguousarray(obj, np.float32).reshape(-1, 3)
     img = np.ascontiguousarray(img, np.float32).reshape(-1, 2)

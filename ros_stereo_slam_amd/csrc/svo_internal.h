@@ -125,6 +125,9 @@ int svo_launch_colors(svo_ctx *ctx, const svo_pyramid *pyr, const float *xy, int
 int svo_launch_compact(svo_ctx *ctx, const uint8_t *mask, int cap, const int *d_n, const float *in_a, int stride_a,
                        float *out_a, const float *in_b, int stride_b, float *out_b, const float *in_c, int stride_c,
                        float *out_c, int *d_count);
+// sor.hip
+int svo_launch_sor(svo_ctx *ctx, const float *xyz, const float *color, int cap, int mean_k, double stddev_mul,
+                   float z_limit, float *xyz_out, float *color_out, int *d_count, float *d_mean_dist, int *d_pass);
 // pnp.hip
 int svo_launch_pnp_ransac(svo_ctx *ctx, const float *obj, const float *img, int cap, const int *d_n,
                           const double *K4h, int iterations, double reproj_err, double confidence, uint64_t seed,

@@ -51,6 +51,43 @@ int main()
         std::printf("FAIL depth: %zu of %zu near %.2f\n", good, p3.size(), z_expect);
         return 1;
     }
+    // SORcloud (src/rosFuncs.cpp:9-39): a far point (-z > 500) and an isolated point go, the wall stays
+    {
+        std::vector<Point3f> cloud, col;
+        for (int i = 0; i < 30; i++)
+            for (int j = 0; j < 30; j++) {
+                Point3f q;
+                q.x = 0.1f * i;
+                q.y = 0.1f * j;
+                q.z = -5.f - 0.001f * ((i * 7 + j * 3) % 11);
+                cloud.push_back(q);
+                Point3f c;
+                c.x = (float)i;
+                c.y = (float)j;
+                c.z = 7.f;
+                col.push_back(c);
+            }
+        Point3f far_pt, lone;
+        far_pt.x = 0.f, far_pt.y = 0.f, far_pt.z = -600.f;
+        lone.x = 40.f, lone.y = -30.f, lone.z = -80.f;
+        cloud.push_back(far_pt);
+        col.push_back(far_pt);
+        cloud.push_back(lone);
+        col.push_back(lone);
+        const size_t before = cloud.size();
+        s.SORcloud(cloud, col);
+        bool bad = cloud.size() != col.size() || cloud.size() >= before - 1 || cloud.size() < 600;
+        for (const Point3f &q : cloud)
+            if (q.z < -50.f)
+                bad = true;
+        for (size_t i = 0; i < cloud.size() && !bad; i++)  // colours follow their points
+            if (std::fabs(col[i].x - 10.f * cloud[i].x) > 1e-3f || col[i].z != 7.f)
+                bad = true;
+        if (bad) {
+            std::printf("FAIL SORcloud: %zu of %zu kept\n", cloud.size(), before);
+            return 1;
+        }
+    }
     // pose graph adaptor: a square loop with drift closes
     globalPoseGraph pg;
     pg.writeResultFile = false;
