@@ -252,6 +252,35 @@ int svo_pg_get_estimates(const svo_posegraph *pg, double *pose7_out);
 int svo_pg_get_edge(const svo_posegraph *pg, int e, int *from, int *to, double *meas7);
 /* saveStructure, poseGraph.h:140-179: VERTEX_SE3:QUAT / EDGE_SE3:QUAT text */
 int svo_pg_write_g2o(const svo_posegraph *pg, const char *path);
+/* the inverse: replace the graph by a .g2o file (VERTEX_SE3:QUAT / EDGE_SE3:QUAT / FIX 0; the
+ * information matrices are ignored -- the reference leaves them at identity, poseGraph.h:102,122) */
+int svo_pg_read_g2o(svo_posegraph *pg, const char *path);
+
+/* ---- data formats either side of the path (host code, no GPU work) -------------------------- */
+/* KITTI odometry pose files: one pose per line, 12 numbers = the 3x4 [R|t]
+ * row-major, camera-to-world.  Rt12: capacity*12 doubles; *n = poses in the file.                */
+int svo_io_read_kitti_poses(const char *path, double *Rt12, int capacity, int *n);
+int svo_io_write_kitti_poses(const char *path, const double *R9s, const double *t3s, int n);
+/* trajectory.csv of the reference (createData / appendData, include/monoUtils.h:23-49): header
+ * "Idx,Xm,Ym,Zm,Xgt,Ygt,Zgt,Const" when create != 0, then rows of 8 floats each followed by ','  */
+int svo_io_trajectory_csv(const char *path, const float *rows8, int n_rows, int create);
+/* absolute trajectory error: RMSE of |t_est - t_gt| (no alignment: both start at the identity)   */
+int svo_eval_ate_rmse(const double *t3_est, const double *t3_gt, int n, double *rmse);
+/* relative pose error over frame pairs (i, i + delta): E = (Qi^-1 Qj)^-1 (Pi^-1 Pj); RMSE of the
+ * translation norm and of the rotation angle (rad).  R9s row-major camera-to-world.              */
+int svo_eval_rpe(const double *R9_est, const double *t3_est, const double *R9_gt, const double *t3_gt, int n,
+                 int delta, double *trans_rmse, double *rot_rmse);
+/* the map / pose messages of rosPublish (src/rosFuncs.cpp:41-98): points with -z > 500 are
+ * skipped, the rest go out as (x, z, -y) * 0.1 with colour (r, g, b) = (c.z, c.y, c.x);
+ * returns the number written.  xyz_out: n*3 floats, rgb_out: n*3 bytes (may be NULL).           */
+int svo_ros_map_points(const float *xyz, const float *bgr, int n, float *xyz_out, uint8_t *rgb_out);
+/* pose message: position (0.1 t0, 0.1 t2, -0.1 t1); orientation from the reference's Rmat2Quat
+ * (include/monoUtils.h:215-227: the Rodrigues vector's components used as X, Y, Z angles) with
+ * the component shuffle of src/rosFuncs.cpp:88-91.  pos3 / quat4 (x, y, z, w).                   */
+int svo_ros_pose(const double *R9, const double *t3, double *pos3, double *quat4);
+/* binary little-endian PLY (x y z float, red green blue uchar), the file SHUTDOWN writes at
+ * src/rosFuncs.cpp:63-67 (PCL's extra camera element is not written)                            */
+int svo_io_write_ply(const char *path, const float *xyz, const uint8_t *rgb, int n);
 
 #ifdef __cplusplus
 }

@@ -389,6 +389,73 @@ class VisualOdometry:
             pass
 
 
+# ---- data formats either side of the path (host code in libsvo_hip.so, no GPU needed) -----------
+def read_kitti_poses(path):
+    """-> (R[n,3,3], t[n,3]) of a KITTI odometry pose file."""
+    lib = load()
+    n = C.c_int()
+    _check(lib.svo_io_read_kitti_poses(str(path).encode(), None, 0, C.byref(n)))
+    buf = np.zeros((max(n.value, 1), 12))
+    _check(lib.svo_io_read_kitti_poses(str(path).encode(), _ptr(buf), n.value, C.byref(n)))
+    Rt = buf[:n.value].reshape(-1, 3, 4)
+    return Rt[:, :, :3].copy(), Rt[:, :, 3].copy()
+
+
+def write_kitti_poses(path, R, t):
+    R = np.ascontiguousarray(R, np.float64).reshape(-1, 9)
+    t = np.ascontiguousarray(t, np.float64).reshape(-1, 3)
+    _check(load().svo_io_write_kitti_poses(str(path).encode(), _ptr(R), _ptr(t), len(R)))
+
+
+def trajectory_csv(path, rows8, create=True):
+    rows8 = np.ascontiguousarray(rows8, np.float32).reshape(-1, 8)
+    _check(load().svo_io_trajectory_csv(str(path).encode(), _ptr(rows8), len(rows8), int(bool(create))))
+
+
+def ate_rmse(t_est, t_gt):
+    a = np.ascontiguousarray(t_est, np.float64).reshape(-1, 3)
+    b = np.ascontiguousarray(t_gt, np.float64).reshape(-1, 3)
+    out = C.c_double()
+    _check(load().svo_eval_ate_rmse(_ptr(a), _ptr(b), len(a), C.byref(out)))
+    return out.value
+
+
+def rpe(R_est, t_est, R_gt, t_gt, delta=1):
+    """-> (translation RMSE, rotation RMSE in rad) over frame pairs (i, i + delta)."""
+    Re = np.ascontiguousarray(R_est, np.float64).reshape(-1, 9)
+    Rg = np.ascontiguousarray(R_gt, np.float64).reshape(-1, 9)
+    te = np.ascontiguousarray(t_est, np.float64).reshape(-1, 3)
+    tg = np.ascontiguousarray(t_gt, np.float64).reshape(-1, 3)
+    a, b = C.c_double(), C.c_double()
+    _check(load().svo_eval_rpe(_ptr(Re), _ptr(te), _ptr(Rg), _ptr(tg), len(Re), int(delta), C.byref(a), C.byref(b)))
+    return a.value, b.value
+
+
+def ros_map_points(xyz, bgr=None):
+    """rosPublish's cloud (src/rosFuncs.cpp:49-62) -> (xyz', rgb uint8 or None)."""
+    xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+    col = None if bgr is None else np.ascontiguousarray(bgr, np.float32).reshape(-1, 3)
+    xo = np.zeros((max(len(xyz), 1), 3), np.float32)
+    co = np.zeros((max(len(xyz), 1), 3), np.uint8)
+    k = load().svo_ros_map_points(_ptr(xyz), _ptr(col), len(xyz), _ptr(xo), _ptr(co) if col is not None else _ptr(None))
+    if k < 0:
+        _check(k)
+    return xo[:k].copy(), (co[:k].copy() if col is not None else None)
+
+
+def ros_pose(R, t):
+    pos, quat = np.zeros(3), np.zeros(4)
+    _check(load().svo_ros_pose(_ptr(np.ascontiguousarray(R, np.float64)), _ptr(np.ascontiguousarray(t, np.float64)),
+                               _ptr(pos), _ptr(quat)))
+    return pos, quat
+
+
+def write_ply(path, xyz, rgb=None):
+    xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+    col = None if rgb is None else np.ascontiguousarray(rgb, np.uint8).reshape(-1, 3)
+    _check(load().svo_io_write_ply(str(path).encode(), _ptr(xyz), _ptr(col), len(xyz)))
+
+
 class _ChunkJob(C.Structure):
     _fields_ = [("vo", C.c_void_p), ("lefts", C.c_void_p), ("rights", C.c_void_p), ("n_frames", C.c_int),
                 ("mem", C.c_int), ("pipeline", C.c_int), ("R_out", C.c_void_p), ("t_out", C.c_void_p),
@@ -461,6 +528,9 @@ class PoseGraph:
             _check(self.ctx.lib.svo_pg_get_edge(self._h, e, C.byref(a), C.byref(b), _ptr(z)))
             res.append((a.value, b.value, z))
         return res
+
+    def read_g2o(self, path):
+        _check(self.ctx.lib.svo_pg_read_g2o(self._h, str(path).encode()))
 
     def write_g2o(self, path):
         _check(self.ctx.lib.svo_pg_write_g2o(self._h, os.fspath(path).encode()))

@@ -17,7 +17,9 @@
 //              (loop-closure endpoints + every 128th vertex), back-substitution -- see below;
 //   update     one thread per vertex: X <- X * fromVectorMQT(dx).
 #include <cmath>
+#include <cstring>
 #include <map>
+#include <utility>
 #include <vector>
 
 #include "svo_internal.h"
@@ -1126,6 +1128,93 @@ int svo_pg_write_g2o(const svo_posegraph *g, const char *path)
         fprintf(f, "\n");
     }
     fclose(f);
+    return SVO_OK;
+}
+
+/* The inverse of svo_pg_write_g2o / saveStructure: replaces the graph by the file's content.
+ * Tags read: VERTEX_SE3:QUAT id x y z qx qy qz qw, EDGE_SE3:QUAT i j x y z qx qy qz qw [21 numbers of
+ * the upper-triangular information matrix, ignored: the reference leaves it at identity,
+ * poseGraph.h:102-104,122], FIX id (only vertex 0 may be fixed, as upstream fixes it, :75).  Vertex
+ * ids must be 0..n-1 (any order in the file); other tags are skipped.                          */
+int svo_pg_read_g2o(svo_posegraph *g, const char *path)
+{
+    SVO_CHECK_ARG(g && path);
+    FILE *f = fopen(path, "r");
+    if (!f) {
+        svo_set_error("cannot open %s", path);
+        return SVO_ERR_ARG;
+    }
+    std::vector<std::pair<int, std::vector<double>>> verts;
+    std::vector<int> ef, et;
+    std::vector<double> em;
+    char line[4096], tag[64];
+    int rc = SVO_OK, lineno = 0;
+    while (fgets(line, sizeof(line), f)) {
+        lineno++;
+        int off = 0;
+        if (sscanf(line, "%63s%n", tag, &off) != 1 || tag[0] == '#')
+            continue;
+        const char *rest = line + off;
+        if (!strcmp(tag, "VERTEX_SE3:QUAT")) {
+            int id;
+            double p[7];
+            if (sscanf(rest, "%d %lf %lf %lf %lf %lf %lf %lf", &id, p, p + 1, p + 2, p + 3, p + 4, p + 5, p + 6) != 8 ||
+                id < 0) {
+                svo_set_error("%s:%d: malformed VERTEX_SE3:QUAT", path, lineno);
+                rc = SVO_ERR_ARG;
+                break;
+            }
+            q_normalize(p + 3);
+            verts.emplace_back(id, std::vector<double>(p, p + 7));
+        } else if (!strcmp(tag, "EDGE_SE3:QUAT")) {
+            int i, j;
+            double z[7];
+            if (sscanf(rest, "%d %d %lf %lf %lf %lf %lf %lf %lf", &i, &j, z, z + 1, z + 2, z + 3, z + 4, z + 5, z + 6) != 9) {
+                svo_set_error("%s:%d: malformed EDGE_SE3:QUAT", path, lineno);
+                rc = SVO_ERR_ARG;
+                break;
+            }
+            q_normalize(z + 3);
+            ef.push_back(i);
+            et.push_back(j);
+            em.insert(em.end(), z, z + 7);
+        } else if (!strcmp(tag, "FIX")) {
+            int id = -1;
+            if (sscanf(rest, "%d", &id) != 1 || id != 0) {
+                svo_set_error("%s:%d: only vertex 0 can be fixed (FIX %d)", path, lineno, id);
+                rc = SVO_ERR_ARG;
+                break;
+            }
+        }
+    }
+    fclose(f);
+    if (rc)
+        return rc;
+    const int n = (int)verts.size();
+    std::vector<double> pose((size_t)n * 7, 0.);
+    std::vector<char> seen(n, 0);
+    for (auto &v : verts) {
+        if (v.first >= n || seen[v.first]) {
+            svo_set_error("%s: vertex ids must be 0..%d without gaps or repeats (id %d)", path, n - 1, v.first);
+            return SVO_ERR_ARG;
+        }
+        seen[v.first] = 1;
+        memcpy(&pose[(size_t)v.first * 7], v.second.data(), 7 * sizeof(double));
+    }
+    for (size_t e = 0; e < ef.size(); e++)
+        if (ef[e] < 0 || ef[e] >= n || et[e] < 0 || et[e] >= n || ef[e] == et[e]) {
+            svo_set_error("%s: edge %zu connects vertices %d -> %d of %d", path, e, ef[e], et[e], n);
+            return SVO_ERR_ARG;
+        }
+    if (n == 0) {
+        svo_set_error("%s: no VERTEX_SE3:QUAT lines", path);
+        return SVO_ERR_ARG;
+    }
+    g->pose = pose;
+    g->efrom = ef;
+    g->eto = et;
+    g->meas = em;
+    g->prev = n - 1;
     return SVO_OK;
 }
 

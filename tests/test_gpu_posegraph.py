@@ -96,3 +96,47 @@ def test_kitti_sized_graph(ctx, orc, tmp_path, n_closures):
     assert sum(l.startswith("VERTEX_SE3:QUAT") for l in lines) == 4541
     assert sum(l.startswith("EDGE_SE3:QUAT") for l in lines) == 4540 + n_closures
     g.close()
+
+
+def test_g2o_round_trip_and_fixture(ctx, orc, tmp_path):
+    """svo_pg_read_g2o is the inverse of saveStructure's writer (poseGraph.h:140-179): a written
+    graph read back optimises to the same chi2; a hand-written .g2o file (tests/golden) loads, its
+    closed square is already consistent, and malformed files are refused."""
+    gt, est = drifting_loop(60, radius=20.0, yaw_drift=2e-3, scale_drift=1.002, laps=1)
+    g = _build(lambda: capi.PoseGraph(ctx), est, [(59, 0)])
+    p = tmp_path / "a.g2o"
+    g.write_g2o(p)
+    h = capi.PoseGraph(ctx)
+    h.read_g2o(p)
+    assert h.num_vertices == g.num_vertices and h.num_edges == g.num_edges
+    assert np.allclose(h.estimates(), g.estimates(), atol=1e-15)
+    cg, ch = g.optimize(5), h.optimize(5)
+    assert np.allclose(cg, ch, rtol=1e-9, atol=1e-18)
+    assert _close(g.estimates(), h.estimates(), 1e-9)
+    # the hand-written fixture: 4 vertices, 4 edges, a consistent square -> chi2 == 0 from the start
+    f = capi.PoseGraph(ctx)
+    f.read_g2o(pathlib.Path(__file__).parent / "golden" / "square4.g2o")
+    assert f.num_vertices == 4 and f.num_edges == 4
+    assert f.edges()[3][:2] == (3, 0)
+    chi = f.optimize(3)
+    assert chi.max() < 1e-24
+    # a perturbed copy of it converges back
+    est4 = f.estimates().copy()
+    est4[2, :3] += [0.05, -0.02, 0.01]
+    pert = tmp_path / "pert.g2o"
+    lines = (pathlib.Path(__file__).parent / "golden" / "square4.g2o").read_text().splitlines()
+    lines = [("VERTEX_SE3:QUAT 2 " + " ".join(repr(float(x)) for x in est4[2])) if l.startswith("VERTEX_SE3:QUAT 2 ") else l
+             for l in lines]
+    pert.write_text("\n".join(lines) + "\n")
+    f.read_g2o(pert)
+    chi = f.optimize(4)
+    assert chi[0] > 1e-4 and chi[-1] < 1e-12 * chi[0] + 1e-20
+    bad = tmp_path / "bad.g2o"
+    bad.write_text("VERTEX_SE3:QUAT 0 0 0 0 0 0 0 1\nVERTEX_SE3:QUAT 2 1 0 0 0 0 0 1\n")   # id gap
+    with pytest.raises(capi.SvoError):
+        f.read_g2o(bad)
+    bad.write_text("VERTEX_SE3:QUAT 0 0 0 0 0 0 0 1\nEDGE_SE3:QUAT 0 5 1 0 0 0 0 0 1\n")      # dangling edge
+    with pytest.raises(capi.SvoError):
+        f.read_g2o(bad)
+    for x in (g, h, f):
+        x.close()
