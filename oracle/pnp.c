@@ -69,17 +69,20 @@ void orc_jacobi_eigen_sym(int n, double *A, double *V, double *w, int sweeps)
             for (int e = 0; e < np; e++) {
                 int p = pairs[e][0], q = pairs[e][1];
                 double apq = A[p * n + q];
-                if (apq == 0.) {
+                double app = A[p * n + p], aqq = A[q * n + q];
+                /* a rotation below the resolution of a double is the identity: skip its arithmetic */
+                if (fabs(apq) <= 1e-19 * (fabs(app) + fabs(aqq))) {
                     cs[e][0] = 1.;
                     cs[e][1] = 0.;
                     continue;
                 }
-                double app = A[p * n + p], aqq = A[q * n + q];
-                double theta = (aqq - app) / (2. * apq);
-                double t = (theta >= 0 ? 1. : -1.) / (fabs(theta) + sqrt(theta * theta + 1.));
-                double c = 1. / sqrt(t * t + 1.);
-                cs[e][0] = c;
-                cs[e][1] = t * c;
+                /* t = tan(phi) = sgn(theta) / (|theta| + sqrt(theta^2 + 1)), theta = a / b, written with
+                 * ONE division: h = |a| + sqrt(a^2 + b^2), c = h / sqrt(h^2 + b^2), s = +-b / sqrt(h^2 + b^2) */
+                double a = aqq - app, b = 2. * apq;
+                double h = fabs(a) + sqrt(a * a + b * b);
+                double inv = 1. / sqrt(h * h + b * b);
+                cs[e][0] = h * inv;
+                cs[e][1] = (a >= 0 ? b : -b) * inv;
             }
             for (int e = 0; e < np; e++) { /* columns p,q:  A <- A J */
                 int p = pairs[e][0], q = pairs[e][1];
@@ -181,9 +184,11 @@ static void svd3(const double *Ain, double *U, double *Vout)
             if (ga == 0 || fabs(ga) <= DBL_EPSILON * sqrt(al * be))
                 continue;
             rotated = 1;
-            double zeta = (be - al) / (2. * ga);
-            double t = (zeta >= 0 ? 1. : -1.) / (fabs(zeta) + sqrt(1. + zeta * zeta));
-            double c = 1. / sqrt(1. + t * t), s = c * t;
+            /* same rotation as in orc_jacobi_eigen_sym, one division */
+            double a = be - al, b = 2. * ga;
+            double h = fabs(a) + sqrt(a * a + b * b);
+            double inv = 1. / sqrt(h * h + b * b);
+            double c = h * inv, s = (a >= 0 ? b : -b) * inv;
             for (int i = 0; i < 3; i++) {
                 double ap = A[3 * i + p], aq = A[3 * i + q];
                 A[3 * i + p] = c * ap - s * aq;

@@ -123,9 +123,10 @@ __device__ void svd3(const double (&Ain)[9], double (&U)[9], double (&Vout)[9])
             if (ga == 0 || fabs(ga) <= DBL_EPSILON * sqrt(al * be))
                 continue;
             rotated = true;
-            const double zeta = (be - al) / (2. * ga);
-            const double t = (zeta >= 0 ? 1. : -1.) / (fabs(zeta) + sqrt(1. + zeta * zeta));
-            const double c = 1. / sqrt(1. + t * t), s = c * t;
+            const double a2 = be - al, b2 = 2. * ga;
+            const double h = fabs(a2) + sqrt(a2 * a2 + b2 * b2);
+            const double inv = 1. / sqrt(h * h + b2 * b2);
+            const double c = h * inv, s = (a2 >= 0 ? b2 : -b2) * inv;
 #pragma unroll
             for (int i = 0; i < 3; i++) {
                 const double ap = A[i][p], aq = A[i][q];
@@ -220,12 +221,15 @@ __device__ void wave_jacobi_eigen_sym(double *A, double *V, double *cs, int *pq,
                     q = -1;
                 } else {
                     const double apq = A[p * n + q];
-                    if (apq != 0.) {
-                        const double app = A[p * n + p], aqq = A[q * n + q];
-                        const double theta = (aqq - app) / (2. * apq);
-                        const double t = (theta >= 0 ? 1. : -1.) / (fabs(theta) + sqrt(theta * theta + 1.));
-                        c = 1. / sqrt(t * t + 1.);
-                        sn = t * c;
+                    const double app = A[p * n + p], aqq = A[q * n + q];
+                    // a rotation below the resolution of a double is the identity (late sweeps skip the
+                    // division and square roots); otherwise tan(phi) with ONE division, as the oracle
+                    if (!(fabs(apq) <= 1e-19 * (fabs(app) + fabs(aqq)))) {
+                        const double a2 = aqq - app, b2 = 2. * apq;
+                        const double h = fabs(a2) + sqrt(a2 * a2 + b2 * b2);
+                        const double inv = 1. / sqrt(h * h + b2 * b2);
+                        c = h * inv;
+                        sn = (a2 >= 0 ? b2 : -b2) * inv;
                     }
                 }
                 cs[2 * k] = c;
