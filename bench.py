@@ -77,6 +77,9 @@ def main():
     ap.add_argument("--chunks-per-gpu", type=int, default=int(os.environ.get("SVO_CHUNKS_PER_GPU", "4")),
                     help="independent chunks of the stream run side by side on each GPU (svo_vo_run_chunks); "
                          "4 = one in-order stream per default HIP hardware queue")
+    ap.add_argument("--kpts", type=int, default=4096, choices=(4096, 8192),
+                    help="keypoints per frame: 4096 = BASELINE's metric (grid step 10), 8192 = configs[4] shape "
+                         "(grid step 7 -> 9152 lattice points -> ANMS 8192, keyframe rule 4000)")
     ap.add_argument("--cpu-frames", type=int, default=24)
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="diagnostic: no HIP events around the kernels (the roofline object is then empty)")
@@ -84,8 +87,17 @@ def main():
 
     import torch
 
+    global N_KPTS, GRID_STEP, KF_MIN_INLIERS
+    if args.kpts == 8192:
+        N_KPTS, GRID_STEP, KF_MIN_INLIERS = 8192, 7, 4000
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal of the N > 1 path on a ONE-GPU box (never used by the driver): all ranks share
+    # device 0 and the collectives run over gloo on host tensors.
+    rehearsal = os.environ.get("SVO_BENCH_REHEARSE_ON_ONE_GPU") == "1"
+    if rehearsal:
+        local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
@@ -95,7 +107,10 @@ def main():
         import torch.distributed as dist_mod
 
         dist = dist_mod
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from ros_stereo_slam_amd import capi, synth
 
@@ -171,7 +186,7 @@ def main():
         from ros_stereo_slam_amd import chunked
 
         pairs = [p if p is not None else (np.eye(3), np.zeros(3)) for p in last]
-        boundaries = chunked.all_gather_chunk_boundaries(dist, pairs, device="cuda")
+        boundaries = chunked.all_gather_chunk_boundaries(dist, pairs, device="cpu" if rehearsal else "cuda")
         starts = chunked.prefix_transforms(boundaries)  # global pose of every chunk's first frame
         assert len(starts) == world * M
     sync_all()
@@ -189,7 +204,7 @@ def main():
         c.enable_kernel_timing(False)
 
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -200,7 +215,7 @@ def main():
         achieved = lk_algorithmic_bytes(N_KPTS) / lk_avg_s / 1e9 if lk_avg_s > 0 else 0.0
         kf_rate = stats["keyframes"] / args.steps
         result = {
-            "metric": "stereo frames/sec @1241x376, 4096 kpts",
+            "metric": f"stereo frames/sec @1241x376, {N_KPTS} kpts",
             "value": fps,
             "unit": "frames/s",
             "n_gpus": world,
@@ -213,7 +228,7 @@ def main():
             "dtype": "u8/i32 fixed-point (LK) + f32/f64 (geometry)",
             "data": "synthetic",
             "config": {
-                "workload": "synthetic corridor 1241x376x3 stereo stream, grid step 10 -> ANMS 4096 keypoints, "
+                "workload": f"synthetic corridor 1241x376x3 stereo stream, grid step {GRID_STEP} -> ANMS {N_KPTS} keypoints, "
                             "front-end only (BASELINE configs[1]): pyramid + LK + F-RANSAC + PnP-RANSAC + "
                             "keyframe path (LK L->R, F-RANSAC, DLT triangulation)",
                 "keyframe_min_inliers": KF_MIN_INLIERS,
