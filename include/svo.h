@@ -148,6 +148,16 @@ int svo_sor_filter(svo_ctx *ctx, const float *xyz, const float *color, int n, in
                    float z_limit, float *xyz_out, float *color_out, int *n_out, float *mean_dist_out,
                    int *n_pass_out, int mem);
 
+/* ---- loop-closure detection: features ---------------------------------------------------------- */
+/* cv::ORB::create()->detectAndCompute(img, Mat(), kp, desc) of visualSLAM::checkLoopDetectorStatus,
+ * src/optimizationStuff.cpp:49-56.  image: h x w x c (BGR or grey).  Up to n_features (500
+ * upstream) oriented-FAST keypoints over 3 octaves with 256-bit steered binary descriptors (the
+ * recipe and its stated differences from cv::ORB: oracle/orb.c).  Outputs, n_features
+ * capacity: xy (level-0 pixels), octave, response, dir (unit orientation vector), desc (8 words
+ * per keypoint); octave / response / dir may be NULL.  *n is a HOST int in both modes.            */
+int svo_orb_extract(svo_ctx *ctx, const uint8_t *image, int w, int h, int c, int n_features, int fast_threshold,
+                    float *xy, int *octave, float *response, float *dir, uint32_t *desc, int *n, int mem);
+
 /* ---- ANMS: adaptiveNonMaximalSuppresion(keypoints, numToKeep), src/ANMS.cpp:18-67 ------------ */
 /* xy: n*2 floats, response: n floats (the reference's grid keypoints carry response 0; the
  * front-end passes the level-0 LK minimum eigenvalue).  out_idx: n ints capacity, receives the

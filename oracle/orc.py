@@ -265,6 +265,53 @@ def sor_filter(xyz, color=None, mean_k=200, stddev_mul=0.01, z_limit=500.0):
     return xo[:k].copy(), (co[:k].copy() if col is not None else None), md[:n_pass].copy()
 
 
+# ---- loop-closure detection: features ------------------------------------------------------
+def orb_pattern():
+    pat = np.zeros((256, 4), np.int8)
+    load().orc_orb_pattern(_p(pat))
+    return pat
+
+
+def bgr_to_gray(img):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape[:2]
+    c = 1 if img.ndim == 2 else img.shape[2]
+    out = np.zeros((h, w), np.uint8)
+    load().orc_bgr_to_gray(_p(img), w, h, c, _p(out))
+    return out
+
+
+def blur5(gray):
+    gray = np.ascontiguousarray(gray, np.uint8)
+    out = np.zeros_like(gray)
+    load().orc_blur5(_p(gray), gray.shape[1], gray.shape[0], _p(out))
+    return out
+
+
+def harris(gray, x, y):
+    lib = load()
+    lib.orc_harris.restype = C.c_float
+    gray = np.ascontiguousarray(gray, np.uint8)
+    return float(lib.orc_harris(_p(gray), gray.shape[1], int(x), int(y)))
+
+
+def fast9(gray, x, y, t=20):
+    gray = np.ascontiguousarray(gray, np.uint8)
+    return bool(load().orc_fast9(_p(gray), gray.shape[1], int(x), int(y), int(t)))
+
+
+def orb_extract(img, n_features=500, fast_t=20):
+    """-> (xy [n,2] float32 level-0 pixels, octave [n], response [n], dir [n,2], desc [n,8] uint32)."""
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape[:2]
+    c = 1 if img.ndim == 2 else img.shape[2]
+    xy, octv = np.zeros((n_features, 2), np.float32), np.zeros(n_features, np.int32)
+    resp, d = np.zeros(n_features, np.float32), np.zeros((n_features, 2), np.float32)
+    desc = np.zeros((n_features, 8), np.uint32)
+    n = load().orc_orb_extract(_p(img), w, h, c, n_features, fast_t, _p(xy), _p(octv), _p(resp), _p(d), _p(desc))
+    return xy[:n].copy(), octv[:n].copy(), resp[:n].copy(), d[:n].copy(), desc[:n].copy()
+
+
 # ---- front-end frame loop -----------------------------------------------------------------
 class VoParams(C.Structure):
     _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),

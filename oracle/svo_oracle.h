@@ -212,6 +212,19 @@ int orc_vo_track(orc_vo *v, const uint8_t *left, const uint8_t *right, int force
 int orc_sor_filter(const float *xyz, const float *color, int n, int mean_k, double stddev_mul, float z_limit,
                    float *xyz_out, float *color_out, float *mean_dist_out);
 
+/* ---- loop-closure detection: features -------------------------------------------------------- */
+/* stand in for cv::ORB::create()->detectAndCompute of visualSLAM::checkLoopDetectorStatus
+ * (src/optimizationStuff.cpp:49-56); see orb.c for the stated recipe.                         */
+void orc_orb_pattern(int8_t *pat /* 256 * 4: x1 y1 x2 y2 */);
+void orc_bgr_to_gray(const uint8_t *img, int w, int h, int c, uint8_t *gray);
+void orc_blur5(const uint8_t *src, int w, int h, uint8_t *dst);
+int orc_fast9(const uint8_t *g, int w, int x, int y, int t);
+float orc_harris(const uint8_t *g, int w, int x, int y);
+int orc_orb_level(const uint8_t *g, const uint8_t *blur, int w, int h, int want, int fast_t, int *xy, float *resp,
+                  float *dir, uint32_t *desc);
+int orc_orb_extract(const uint8_t *img, int w, int h, int c, int n_features, int fast_t, float *xy, int *octave,
+                    float *resp, float *dir, uint32_t *desc);
+
 #ifdef __cplusplus
 }
 #endif

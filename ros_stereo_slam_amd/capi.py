@@ -266,6 +266,23 @@ def anms(self, xy, response, num_to_keep):
 
 
 @_ctx_method
+def orb_extract(self, img, n_features=500, fast_threshold=20):
+    """cv::ORB stand-in of the loop detector (src/optimizationStuff.cpp:49-56) ->
+    (xy [n,2], octave [n], response [n], dir [n,2], desc [n,8] uint32)."""
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape[:2]
+    c = 1 if img.ndim == 2 else img.shape[2]
+    xy, octv = np.zeros((n_features, 2), np.float32), np.zeros(n_features, np.int32)
+    resp, d = np.zeros(n_features, np.float32), np.zeros((n_features, 2), np.float32)
+    desc = np.zeros((n_features, 8), np.uint32)
+    n = C.c_int()
+    _check(self.lib.svo_orb_extract(self._h, _ptr(img), w, h, c, n_features, fast_threshold, _ptr(xy), _ptr(octv),
+                                    _ptr(resp), _ptr(d), _ptr(desc), C.byref(n), MEM_HOST))
+    k = n.value
+    return xy[:k].copy(), octv[:k].copy(), resp[:k].copy(), d[:k].copy(), desc[:k].copy()
+
+
+@_ctx_method
 def sor_filter(self, xyz, color=None, mean_k=200, stddev_mul=0.01, z_limit=500.0):
     """visualSLAM::SORcloud (src/rosFuncs.cpp:9-39) -> (xyz_kept, color_kept or None, mean_dist)."""
     xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)

@@ -125,6 +125,12 @@ int svo_launch_colors(svo_ctx *ctx, const svo_pyramid *pyr, const float *xy, int
 int svo_launch_compact(svo_ctx *ctx, const uint8_t *mask, int cap, const int *d_n, const float *in_a, int stride_a,
                        float *out_a, const float *in_b, int stride_b, float *out_b, const float *in_c, int stride_c,
                        float *out_c, int *d_count);
+// orb.hip -- features of the loop-closure detector
+struct svo_orb;
+int svo_orb_create(svo_ctx *ctx, int w, int h, int c, int n_features, int fast_t, svo_orb **out);
+int svo_orb_destroy(svo_orb *o);
+int svo_orb_launch(svo_orb *o, const uint8_t *d_image, float *d_xy, int *d_oct, float *d_resp, float *d_dir,
+                   uint32_t *d_desc, int *d_n);
 // sor.hip
 int svo_launch_sor(svo_ctx *ctx, const float *xyz, const float *color, int cap, int mean_k, double stddev_mul,
                    float z_limit, float *xyz_out, float *color_out, int *d_count, float *d_mean_dist, int *d_pass);
