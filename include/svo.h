@@ -158,6 +158,48 @@ int svo_sor_filter(svo_ctx *ctx, const float *xyz, const float *color, int n, in
 int svo_orb_extract(svo_ctx *ctx, const uint8_t *image, int w, int h, int c, int n_features, int fast_threshold,
                     float *xy, int *octave, float *response, float *dir, uint32_t *desc, int *n, int mem);
 
+/* ---- loop-closure detection: visualSLAM::checkLoopDetectorStatus, src/optimizationStuff.cpp:49-64 */
+/* = cv::ORB features + DLoopDetector::detectLoop (include/TemplatedLoopDetector.h:696-861).  The
+ * detector keeps every frame's features in HBM; one svo_lc_detect call per frame, in order.
+ * Defaults: Parameters::set(1) (:552-568) overridden as visualSLAM does (include/visualSLAM.h:
+ * 120-127: use_nss, alpha 0.9, k 1).  The bag-of-words score is replaced by a vocabulary-free
+ * descriptor-matching similarity (the vocabulary was stripped from the reference).     */
+typedef struct svo_lc svo_lc;
+typedef struct svo_lc_params {
+    int n_features;               /* 500                                                          */
+    int fast_threshold;           /* 20                                                           */
+    int hamming_threshold;        /* 64: a query descriptor "finds" an entry within this radius   */
+    int max_entries;              /* database capacity in frames (8192)                           */
+    int use_nss;                  /* 1                                                            */
+    float alpha;                  /* 0.9                                                          */
+    int k;                        /* 1: more than k temporally consistent matches                 */
+    int dislocal;                 /* 20                                                           */
+    int max_db_results;           /* 50                                                           */
+    float min_nss_factor;         /* 0.005                                                        */
+    int min_matches_per_group, max_intragroup_gap, max_distance_between_groups,
+        max_distance_between_queries;                                   /* 1, 3, 3, 2             */
+    int min_Fpoints, max_ransac_iterations;                              /* 12, 500               */
+    double ransac_probability, max_reprojection_error, max_neighbor_ratio; /* 0.99, 2.0, 0.6      */
+    uint64_t seed;                /* RANSAC sampling seed of the geometric check                  */
+} svo_lc_params;
+enum { /* DLoopDetector::DetectionStatus, include/TemplatedLoopDetector.h:51-69 */
+    SVO_LC_LOOP_DETECTED = 0,
+    SVO_LC_CLOSE_MATCHES_ONLY = 1,
+    SVO_LC_NO_DB_RESULTS = 2,
+    SVO_LC_LOW_NSS_FACTOR = 3,
+    SVO_LC_LOW_SCORES = 4,
+    SVO_LC_NO_GROUPS = 5,
+    SVO_LC_NO_TEMPORAL_CONSISTENCY = 6,
+    SVO_LC_NO_GEOMETRICAL_CONSISTENCY = 7
+};
+void svo_lc_default_params(svo_lc_params *p);
+int svo_lc_create(svo_ctx *ctx, const svo_lc_params *params, int width, int height, int channels, svo_lc **out);
+int svo_lc_destroy(svo_lc *lc);
+int svo_lc_size(const svo_lc *lc);
+/* detectLoop for the next frame: *status = DetectionStatus, *query = this frame's entry id,
+ * *match = the matched entry (-1 if none); a detection is status == SVO_LC_LOOP_DETECTED.        */
+int svo_lc_detect(svo_lc *lc, const uint8_t *image, int mem, int *status, int *query, int *match);
+
 /* ---- ANMS: adaptiveNonMaximalSuppresion(keypoints, numToKeep), src/ANMS.cpp:18-67 ------------ */
 /* xy: n*2 floats, response: n floats (the reference's grid keypoints carry response 0; the
  * front-end passes the level-0 LK minimum eigenvalue).  out_idx: n ints capacity, receives the

@@ -13,8 +13,9 @@
 //  * processFrame(): the body of initSequence's loop (src/VisualSLAM.cpp:54-169) on the
 //    fused, device-resident front-end (svo_vo) + the device pose graph -- the fast path.
 //  * SORcloud(): the map clean-up of src/rosFuncs.cpp:9-39 (PCL StatisticalOutlierRemoval) on the GPU.
-// Not here (out of the hot path): ROS publishing, Pangolin viewer, DBoW2 loop detection
-// (checkLoopDetectorStatus) -- its outputs (LC_FLAG, LCidx) are inputs.
+//  * checkLoopDetectorStatus(): src/optimizationStuff.cpp:49-64 on the GPU (svo_lc); processFrame
+//    still takes the match as an argument so that a caller may keep its own detector.
+// Not here (out of the hot path): ROS publishing, Pangolin viewer.
 #pragma once
 
 #include <cstdio>
@@ -60,6 +61,8 @@ class visualSLAM {
     {
         if (vo_)
             svo_vo_destroy(vo_);
+        if (lc_)
+            svo_lc_destroy(lc_);
     }
     visualSLAM(const visualSLAM &) = delete;
     visualSLAM &operator=(const visualSLAM &) = delete;
@@ -169,6 +172,29 @@ class visualSLAM {
         std::vector<Point3f> out(pt3d.size());
         check(svo_transform_points(ctx_, pose4dTransform.m, f3(pt3d), (int)pt3d.size(), f3(out), SVO_MEM_HOST));
         return out;
+    }
+
+    // ---- src/optimizationStuff.cpp:49-64: ORB features + DLoopDetector::detectLoop on the GPU.
+    //      One call per frame, in order (the detector stores every frame).  lcParams may be
+    //      edited before the first call; result.match / result.query are kept in lastLoopResult. ----
+    svo_lc_params lcParams = default_lc_params();
+    struct LoopResult {
+        int status = SVO_LC_CLOSE_MATCHES_ONLY, query = -1, match = -1;
+        bool detection() const { return status == SVO_LC_LOOP_DETECTED; }
+    } lastLoopResult;
+    void checkLoopDetectorStatus(const Mat &img, int idx)
+    {
+        if (!lc_)
+            check(svo_lc_create(ctx_, &lcParams, mat_cols(img), mat_rows(img), mat_channels(img), &lc_));
+        LoopResult r;
+        check(svo_lc_detect(lc_, mat_data(img), SVO_MEM_HOST, &r.status, &r.query, &r.match));
+        lastLoopResult = r;
+        if (r.detection() && (r.query - r.match > 100) && cooldownTimer == 0) {  // :58
+            std::fprintf(stderr, "Found Loop Closure between %d and %d\n", idx, r.match);
+            LC_FLAG = true;
+            LCidx = r.match - 1;  // :61 (vertices[-1] when match == 0: callers clamp, see processFrame)
+            cooldownTimer = 100;
+        }
     }
 
     // ---- src/rosFuncs.cpp:9-39: far-point filter (-z > 500) + statistical outlier removal
@@ -382,6 +408,13 @@ class visualSLAM {
 
     svo_ctx *ctx_;
     svo_vo *vo_ = nullptr;
+    svo_lc *lc_ = nullptr;
+    static svo_lc_params default_lc_params()
+    {
+        svo_lc_params p;
+        svo_lc_default_params(&p);
+        return p;
+    }
     int frame_ = 0;
 };
 

@@ -1,0 +1,166 @@
+"""Oracle of the loop-closure detector: DLoopDetector::detectLoop restated in Python on top of the
+oracle's C primitives (features: orb.c, matching: loopdet.c, F-matrix RANSAC: geometry.c).
+
+TEST INFRASTRUCTURE.  Follows include/TemplatedLoopDetector.h of the reference line by line
+(detectLoop :696-861, computeIslands :875-951, updateTemporalWindow :966-1003, the exhaustive
+geometric check :1101-1160 with getMatches_neighratio :1255-1316, removeLowScores :1320-1338) with
+the parameters visualSLAM sets (include/visualSLAM.h:120-127: use_nss, alpha 0.9, k 1, di_levels 2)
+on top of Parameters::set(1) (:552-568).  Stated deviation (loopdet.c): the bag-of-words score is
+replaced by a vocabulary-free descriptor-matching similarity, and GEOM_DI's direct index (which
+needs the vocabulary tree) by the header's own exhaustive neighbour-ratio matching."""
+from __future__ import annotations
+
+import numpy as np
+
+from . import orc
+
+LOOP_DETECTED, CLOSE_MATCHES_ONLY, NO_DB_RESULTS, LOW_NSS_FACTOR, LOW_SCORES, NO_GROUPS, \
+    NO_TEMPORAL_CONSISTENCY, NO_GEOMETRICAL_CONSISTENCY = range(8)
+
+
+class Params:
+    def __init__(self, **kw):
+        self.n_features, self.fast_threshold, self.hamming_threshold = 500, 20, 64
+        self.use_nss, self.alpha, self.k = True, 0.9, 1
+        self.dislocal, self.max_db_results, self.min_nss_factor = 20, 50, 0.005
+        self.min_matches_per_group, self.max_intragroup_gap = 1, 3
+        self.max_distance_between_groups, self.max_distance_between_queries = 3, 2
+        self.min_Fpoints, self.max_ransac_iterations = 12, 500
+        self.ransac_probability, self.max_reprojection_error, self.max_neighbor_ratio = 0.99, 2.0, 0.6
+        self.seed = 0
+        for k, v in kw.items():
+            assert hasattr(self, k), k
+            setattr(self, k, v)
+
+
+class LoopDetector:
+    def __init__(self, params: Params | None = None):
+        self.p = params or Params()
+        self.keys, self.descs = [], []          # m_image_keys / m_image_descriptors
+        self.window = dict(nentries=0, last_island=None, last_query=-1)
+        self.last_desc = None                    # m_last_bowvec's stand-in
+
+    def _scores(self, desc, entries):
+        if len(entries) == 0 or len(desc) == 0:
+            return np.zeros(len(entries))
+        stride = max(max(len(self.descs[e]) for e in entries), 1)
+        db = np.zeros((len(entries), stride, 8), np.uint32)
+        n = np.zeros(len(entries), np.int32)
+        for i, e in enumerate(entries):
+            n[i] = len(self.descs[e])
+            db[i, :n[i]] = self.descs[e]
+        return orc.lc_scores(desc, db, n, self.p.hamming_threshold) / float(len(desc))
+
+    def detect(self, image):
+        xy, octv, resp, d, desc = orc.orb_extract(image, self.p.n_features, self.p.fast_threshold)
+        return self.detect_features(xy, desc)
+
+    def detect_features(self, xy, desc):
+        p = self.p
+        entry_id = len(self.keys)
+        res = dict(query=entry_id, match=-1, status=CLOSE_MATCHES_ONLY)
+        if entry_id > p.dislocal:
+            max_id = entry_id - p.dislocal
+            # m_database->query(bowvec, qret, max_db_results, max_id): ids < max_id, positive score, best first
+            ids = np.arange(max_id)
+            sc = self._scores(desc, list(ids))
+            order = sorted((i for i in ids if sc[i] > 0), key=lambda i: (-sc[i], i))[:p.max_db_results]
+            qret = [(int(i), float(sc[i])) for i in order]
+            if qret:
+                ns = 1.0
+                if p.use_nss:
+                    ns = float(self._scores(desc, [entry_id - 1])[0]) if self.last_desc is not None else 0.0
+                if not p.use_nss or ns >= p.min_nss_factor:
+                    qret = [r for r in qret if r[1] >= p.alpha * ns]          # removeLowScores
+                    if qret:
+                        res["match"] = qret[0][0]
+                        islands = self._islands(qret)
+                        if islands:
+                            best = max(islands, key=lambda t: t["score"])      # first maximum
+                            self._update_window(best, entry_id)
+                            res["match"] = best["best_entry"]
+                            if self.window["nentries"] > p.k:
+                                ok = self._geometric(best["best_entry"], xy, desc)
+                                res["status"] = LOOP_DETECTED if ok else NO_GEOMETRICAL_CONSISTENCY
+                            else:
+                                res["status"] = NO_TEMPORAL_CONSISTENCY
+                        else:
+                            res["status"] = NO_GROUPS
+                    else:
+                        res["status"] = LOW_SCORES
+                else:
+                    res["status"] = LOW_NSS_FACTOR
+            else:
+                res["status"] = NO_DB_RESULTS
+        self.keys.append(np.asarray(xy, np.float32))
+        self.descs.append(np.asarray(desc, np.uint32))
+        if p.use_nss and entry_id + 1 > p.dislocal:
+            self.last_desc = desc
+        return res
+
+    def _islands(self, q):
+        p = self.p
+        if len(q) == 1:
+            return [dict(first=q[0][0], last=q[0][0], score=q[0][1], best_entry=q[0][0], best_score=q[0][1])]
+        q = sorted(q, key=lambda r: r[0])
+        out = []
+        first = last = q[0][0]
+        i_first = i_last = 0
+        best_score, best_entry = q[0][1], q[0][0]
+
+        def close():
+            if last - first + 1 >= p.min_matches_per_group:
+                out.append(dict(first=first, last=last, score=sum(r[1] for r in q[i_first:i_last + 1]),
+                                best_entry=best_entry, best_score=best_score))
+        for idx in range(1, len(q)):
+            eid, s = q[idx]
+            if eid - last < p.max_intragroup_gap:
+                last, i_last = eid, idx
+                if s > best_score:
+                    best_score, best_entry = s, eid
+            else:
+                close()
+                first = last = eid
+                i_first = i_last = idx
+                best_score, best_entry = s, eid
+        close()
+        return out
+
+    def _update_window(self, island, entry_id):
+        w, p = self.window, self.p
+        if w["nentries"] == 0 or entry_id - w["last_query"] > p.max_distance_between_queries:
+            w["nentries"] = 1
+        else:
+            a1, a2 = w["last_island"]["first"], w["last_island"]["last"]
+            b1, b2 = island["first"], island["last"]
+            fit = (b1 <= a1 <= b2) or (a1 <= b1 <= a2)
+            if not fit:
+                gap = max(a1 - b2, b1 - a2)
+                fit = gap <= p.max_distance_between_groups
+            w["nentries"] = w["nentries"] + 1 if fit else 1
+        w["last_island"], w["last_query"] = island, entry_id
+
+    def _geometric(self, old_entry, xy, desc):
+        p = self.p
+        A, B = self.descs[old_entry], desc
+        if len(A) == 0 or len(B) == 0:
+            return False
+        bj, d1, d2 = orc.lc_nearest2(A, B)
+        match_A, match_B = [], []
+        for i in range(len(A)):
+            if float(d1[i]) / float(d2[i]) <= p.max_neighbor_ratio:
+                jb = int(bj[i])
+                if jb not in match_B:
+                    match_B.append(jb)
+                    match_A.append(i)
+                else:
+                    k = match_B.index(jb)
+                    if d1[i] < d1[match_A[k]]:
+                        match_A[k] = i
+        if len(match_A) < p.min_Fpoints:
+            return False
+        old = self.keys[old_entry][match_A]
+        cur = np.asarray(xy, np.float32)[match_B]
+        cnt, mask, F, iters = orc.fransac(old, cur, p.max_reprojection_error, p.ransac_probability,
+                                          p.max_ransac_iterations, p.seed + len(self.keys))
+        return cnt >= p.min_Fpoints

@@ -312,6 +312,25 @@ def orb_extract(img, n_features=500, fast_t=20):
     return xy[:n].copy(), octv[:n].copy(), resp[:n].copy(), d[:n].copy(), desc[:n].copy()
 
 
+def lc_scores(q, db, db_n, hamming_thr):
+    """counts[e] of query descriptors with a neighbour within hamming_thr in entry e (see loopdet.c)."""
+    q = np.ascontiguousarray(q, np.uint32).reshape(-1, 8)
+    db = np.ascontiguousarray(db, np.uint32)
+    assert db.ndim == 3 and db.shape[2] == 8
+    db_n = np.ascontiguousarray(db_n, np.int32)
+    out = np.zeros(max(len(db), 1), np.int32)
+    load().orc_lc_scores(_p(q), len(q), _p(db), _p(db_n), db.shape[1], len(db), int(hamming_thr), _p(out))
+    return out[:len(db)]
+
+
+def lc_nearest2(A, B):
+    A = np.ascontiguousarray(A, np.uint32).reshape(-1, 8)
+    B = np.ascontiguousarray(B, np.uint32).reshape(-1, 8)
+    bj, d1, d2 = (np.zeros(max(len(A), 1), np.int32) for _ in range(3))
+    load().orc_lc_nearest2(_p(A), len(A), _p(B), len(B), _p(bj), _p(d1), _p(d2))
+    return bj[:len(A)], d1[:len(A)], d2[:len(A)]
+
+
 # ---- front-end frame loop -----------------------------------------------------------------
 class VoParams(C.Structure):
     _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),

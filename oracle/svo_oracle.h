@@ -225,6 +225,12 @@ int orc_orb_level(const uint8_t *g, const uint8_t *blur, int w, int h, int want,
 int orc_orb_extract(const uint8_t *img, int w, int h, int c, int n_features, int fast_t, float *xy, int *octave,
                     float *resp, float *dir, uint32_t *desc);
 
+/* ---- loop-closure detection: descriptor matching (see loopdet.c) ----------------------------- */
+int orc_hamming256(const uint32_t *a, const uint32_t *b);
+void orc_lc_scores(const uint32_t *q, int nq, const uint32_t *db, const int *db_n, int stride, int n_entries,
+                   int hamming_thr, int *counts);
+void orc_lc_nearest2(const uint32_t *A, int na, const uint32_t *B, int nb, int *best_j, int *d1, int *d2);
+
 #ifdef __cplusplus
 }
 #endif

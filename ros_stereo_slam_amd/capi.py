@@ -504,6 +504,56 @@ def run_chunks(jobs, pipeline: bool = True):
     return [(arr[k].rc, arr[k].n_done, *outs[k][:4], outs[k][4].astype(bool)) for k in range(len(jobs))]
 
 
+class LcParams(C.Structure):
+    _fields_ = [("n_features", C.c_int), ("fast_threshold", C.c_int), ("hamming_threshold", C.c_int),
+                ("max_entries", C.c_int), ("use_nss", C.c_int), ("alpha", C.c_float), ("k", C.c_int),
+                ("dislocal", C.c_int), ("max_db_results", C.c_int), ("min_nss_factor", C.c_float),
+                ("min_matches_per_group", C.c_int), ("max_intragroup_gap", C.c_int),
+                ("max_distance_between_groups", C.c_int), ("max_distance_between_queries", C.c_int),
+                ("min_Fpoints", C.c_int), ("max_ransac_iterations", C.c_int), ("ransac_probability", C.c_double),
+                ("max_reprojection_error", C.c_double), ("max_neighbor_ratio", C.c_double), ("seed", C.c_uint64)]
+
+
+LC_STATUS = ("LOOP_DETECTED", "CLOSE_MATCHES_ONLY", "NO_DB_RESULTS", "LOW_NSS_FACTOR", "LOW_SCORES", "NO_GROUPS",
+             "NO_TEMPORAL_CONSISTENCY", "NO_GEOMETRICAL_CONSISTENCY")
+
+
+class LoopDetector:
+    """checkLoopDetectorStatus's detector (src/optimizationStuff.cpp:49-64; ``svo_lc``)."""
+
+    def __init__(self, ctx: "Context", w: int, h: int, c: int, **overrides):
+        self.ctx = ctx
+        self.prm = LcParams()
+        ctx.lib.svo_lc_default_params(C.byref(self.prm))
+        for k, v in overrides.items():
+            assert hasattr(self.prm, k), k
+            setattr(self.prm, k, v)
+        self._h = C.c_void_p()
+        _check(ctx.lib.svo_lc_create(ctx._h, C.byref(self.prm), w, h, c, C.byref(self._h)))
+        ctx._children.add(self)
+
+    def detect(self, image):
+        """-> dict(status, query, match); a detection is status == 0 (LOOP_DETECTED)."""
+        mem = MEM_HOST if isinstance(image, np.ndarray) else MEM_DEVICE
+        st, q, m = C.c_int(), C.c_int(), C.c_int()
+        _check(self.ctx.lib.svo_lc_detect(self._h, _ptr(image), mem, C.byref(st), C.byref(q), C.byref(m)))
+        return dict(status=st.value, query=q.value, match=m.value)
+
+    def __len__(self):
+        return self.ctx.lib.svo_lc_size(self._h)
+
+    def close(self):
+        if self._h and self.ctx._h:
+            self.ctx.lib.svo_lc_destroy(self._h)
+        self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class PoseGraph:
     """SE3 pose graph on the GPU (``svo_posegraph``), mirroring globalPoseGraph
     (include/poseGraph.h:36-179).  Poses: tx ty tz qx qy qz qw."""

@@ -1,11 +1,12 @@
 """Host-side frame loop with the pose graph in it: the body of visualSLAM::initSequence
 (``src/VisualSLAM.cpp:54-169``) over a front-end (``VisualOdometry``) and a ``PoseGraph``.
 
-The loop-closure *detector* of the reference (ORB + DBoW2 + DLoopDetector,
-``src/optimizationStuff.cpp:49-64``) is outside the hot path; its result enters as
-``loop_match`` (the matched earlier frame id, or -1), and the reference's gating is applied to
-it here: accept iff ``query - match > 100`` and the cooldown is 0, then ``LCidx = match - 1``
-and ``cooldown = 100`` (``src/optimizationStuff.cpp:59-63``).
+The loop-closure detector of the reference (ORB + DLoopDetector,
+``src/optimizationStuff.cpp:49-64``) is either a ``detector`` object (``capi.LoopDetector`` or the
+oracle's ``LoopDetector``: ``detect(left)`` is called once per frame, frame 0 included) or, without
+one, an externally supplied ``loop_match`` (the matched earlier frame id, or -1).  The reference's
+gating is applied here: accept iff ``query - match > 100`` and the cooldown is 0, then
+``LCidx = match - 1`` and ``cooldown = 100`` (``src/optimizationStuff.cpp:58-63``).
 
 On an accepted closure the reference (``src/VisualSLAM.cpp:76-86``) adds the identity-measurement
 loop edge from the PREVIOUS vertex, adds the current vertex, optimises the whole graph for 10
@@ -23,8 +24,9 @@ from .chunked import pose7
 
 
 class StereoSlam:
-    def __init__(self, vo, pose_graph, min_gap: int = 100, cooldown: int = 100, optimize_iters: int = 10):
-        self.vo, self.pg = vo, pose_graph
+    def __init__(self, vo, pose_graph, min_gap: int = 100, cooldown: int = 100, optimize_iters: int = 10,
+                 detector=None):
+        self.vo, self.pg, self.detector = vo, pose_graph, detector
         self.min_gap, self.cooldown_frames, self.optimize_iters = min_gap, cooldown, optimize_iters
         self.frame = 0
         self.cooldown = 0
@@ -37,6 +39,8 @@ class StereoSlam:
     def start(self, left, right) -> int:
         """Frame 0: stereoTriangulate + initializeGraph (src/VisualSLAM.cpp:22-41)."""
         n = self.vo.init(left, right)
+        if self.detector is not None:
+            self.detector.detect(left)  # the reference's detector sees every frame from the first
         self.frame = 0
         self.trajectory = [(np.eye(3), np.zeros(3))]
         self.keyframes = [0]
@@ -52,6 +56,9 @@ class StereoSlam:
         if rc:
             self.shutdown = True  # SHUTDOWN_FLAG, src/VisualSLAM.cpp:65-67
             return False, R, t, {"inliers": n_inl, "tracked": n_trk}
+        if self.detector is not None:
+            r = self.detector.detect(left)
+            loop_match = r["match"] if r["status"] == 0 else -1
         lc = False
         if loop_match >= 0 and (self.frame - loop_match) > self.min_gap and self.cooldown == 0:
             lc = True

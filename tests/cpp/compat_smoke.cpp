@@ -88,6 +88,21 @@ int main()
             return 1;
         }
     }
+    // checkLoopDetectorStatus: 25 calls on the same image -- too young a database for a closure
+    // (query - match > 100 can not hold), every frame is stored, flags stay down
+    {
+        for (int i = 0; i < 25; i++)
+            s.checkLoopDetectorStatus(L, i);
+        if (s.LC_FLAG || s.lastLoopResult.query != 24 || s.cooldownTimer != 0) {
+            std::printf("FAIL checkLoopDetectorStatus: query %d status %d\n", s.lastLoopResult.query,
+                        s.lastLoopResult.status);
+            return 1;
+        }
+        if (s.lastLoopResult.status == SVO_LC_CLOSE_MATCHES_ONLY) {  // entries 0..3 are old enough to be queried
+            std::printf("FAIL checkLoopDetectorStatus: no database query at frame 24\n");
+            return 1;
+        }
+    }
     // pose graph adaptor: a square loop with drift closes
     globalPoseGraph pg;
     pg.writeResultFile = false;

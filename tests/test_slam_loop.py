@@ -136,3 +136,31 @@ def test_slam_loop_with_closure_matches_oracle(ctx, orc):
     print(f"ATE vs generator ground truth: GPU {ate_raw:.3f} m, oracle {ate_orc:.3f} m over {n} frames; "
           f"closure at {g.closures}; policies in step until frame {sync_until}")
     assert ate_raw < 1.0 and ate_orc < 1.0 and abs(ate_raw - ate_orc) < 0.1
+
+
+@pytest.mark.gpu
+def test_slam_loop_closes_with_its_own_detector(ctx):
+    """The whole pipeline on the GPU with nothing supplied from outside: front-end, loop detector
+    (features + database + geometric check) and pose graph.  The detector must find the revisit of
+    the start of the loop by itself, the graph must tighten, the trajectory stay near the truth."""
+    from ros_stereo_slam_amd import capi
+
+    n = 134
+    gt, frames, lc = _loop_frames(n)
+    kw = dict(grid_step=12, keyframe_min_inliers=150, seed=3, K4=K4)
+    det = capi.LoopDetector(ctx, SIZE[0], SIZE[1], 3, seed=5)
+    s = StereoSlam(capi.VisualOdometry(ctx, SIZE[0], SIZE[1], 3, **kw), capi.PoseGraph(ctx), detector=det)
+    s.start(*frames[0])
+    for i in range(1, n):
+        ok, R, t, info = s.step(*frames[i])
+        assert ok, f"frame {i}"
+    first_true = next(i for i, m in enumerate(lc) if m >= 0)
+    assert len(s.closures) == 1
+    frame, idx = s.closures[0]
+    assert abs(frame - first_true) <= 8 and idx <= 8
+    assert s.chi2[0][-1] < 0.05 * s.chi2[0][0]
+    gt_t = np.array([t for _, t in gt])
+    ate = chunked.ate_rmse([t for _, t in s.trajectory], gt_t)
+    print(f"closure found by the detector at frame {frame} -> vertex {idx}; ATE {ate:.3f} m")
+    assert ate < 1.0
+    assert len(det) == n
