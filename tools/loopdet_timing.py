@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Per-frame time of the GPU loop detector (svo_lc_detect) at 1241x376x3 as its database grows,
-next to the oracle's feature extractor on the host.  Not part of bench.py (the loop detector is
+"""Per-frame time of the GPU loop detector (svo_lc_detect) at 1241x376x3 as its database grows.
+Not part of bench.py (the loop detector is
 outside BASELINE's metric); numbers quoted in DESIGN.md come from this script:
 
     python tools/loopdet_timing.py [--frames 2000]
@@ -21,7 +21,6 @@ def main():
     args = ap.parse_args()
     import torch
     from ros_stereo_slam_amd import capi, synth
-    from oracle import orc
 
     ctx = capi.Context(0)
     sc = synth.Scene()
@@ -40,10 +39,6 @@ def main():
             t_last, n_last = now, i + 1
     for k, v in marks.items():
         print(f"database up to {k:5d} entries: {v:7.3f} ms per frame (features + scoring + bookkeeping)")
-    t0 = time.perf_counter()
-    for k in range(3):
-        orc.orb_extract(imgs[k], 500)
-    print(f"oracle feature extraction on the host: {(time.perf_counter() - t0) / 3 * 1e3:.1f} ms per frame")
 
 
 if __name__ == "__main__":
