@@ -40,11 +40,11 @@ GRID_STEP = 10            # 4428 lattice points -> ANMS keeps 4096 (SURVEY.md 8d
 KF_MIN_INLIERS = 2000     # the reference's 200-of-440 rule scaled to 4096 keypoints
 PYR_BYTES = 619930 * C    # sum of the 4 level sizes
 # HBM bytes per lk_track_kernel<3> launch from the PMC counters of this very workload
-# (profiles/r01_pmc_hbm_traffic_v2.csv: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes,
+# (profiles/r01_pmc_hbm_traffic_v3.csv: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes,
 # KB units, gfx950 correction for 16-B-per-lane reads: (2*FETCH_SIZE + WRITE_SIZE) * 1024).
 # PMC counters cannot be read from inside this process, so the figure is carried from the
 # committed profile; None would be the honest value for any other workload.
-LK_PMC_TRAFFIC_BYTES = 13262114
+LK_PMC_TRAFFIC_BYTES = 13349433
 
 
 def lk_algorithmic_bytes(n_pts: int) -> int:
@@ -253,7 +253,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / 8000.0,
                 "traffic": LK_PMC_TRAFFIC_BYTES if (W, H, C, N_KPTS) == (1241, 376, 3, 4096) else None,
-                "traffic_source": "profiles/r01_pmc_hbm_traffic_v2.csv (rocprofv3 --pmc, (2*FETCH_SIZE+WRITE_SIZE)*1024)",
+                "traffic_source": "profiles/r01_pmc_hbm_traffic_v3.csv (rocprofv3 --pmc, (2*FETCH_SIZE+WRITE_SIZE)*1024)",
                 "avg_launch_us": lk_avg_s * 1e6,
                 "launches_per_step": lk_launches / args.steps,
                 "algorithmic_bytes_per_launch": lk_algorithmic_bytes(N_KPTS),
