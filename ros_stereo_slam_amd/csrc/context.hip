@@ -140,6 +140,14 @@ int svo_ctx_create(int device, svo_ctx **out)
         svo_set_error("hipHostMalloc -> %s", hipGetErrorString(e));
         return SVO_ERR_HIP;
     }
+    if (hipMalloc(reinterpret_cast<void **>(&ctx->d_tickets), 256) != hipSuccess ||
+        hipMemset(ctx->d_tickets, 0, 256) != hipSuccess) {
+        (void)hipHostFree(ctx->pinned);
+        (void)hipStreamDestroy(ctx->stream);
+        delete ctx;
+        svo_set_error("hipMalloc(tickets) failed");
+        return SVO_ERR_HIP;
+    }
     e = hipEventCreateWithFlags(&ctx->wait_ev, hipEventDisableTiming);
     if (e != hipSuccess) {
         (void)hipHostFree(ctx->pinned);
@@ -169,6 +177,8 @@ int svo_ctx_destroy(svo_ctx *ctx)
                       &ctx->w_e};
     for (DevBuf *b : bufs)
         b->release();
+    if (ctx->d_tickets)
+        (void)hipFree(ctx->d_tickets);
     if (ctx->pinned)
         (void)hipHostFree(ctx->pinned);
     if (ctx->wait_ev)

@@ -310,41 +310,55 @@ __device__ __forceinline__ float f_error(const double (&F)[9], float x1, float y
     return (float)(e1 > e2 ? e1 : e2);
 }
 
+// One wavefront per model.  The LAST workgroup to finish (ticket counter) also replays the
+// sequential RANSAC loop over the iterations scored so far -- what used to be a launch of its own.
 __global__ __launch_bounds__(256) void fr_score_kernel(const float2 *__restrict__ p1,
                                                        const float2 *__restrict__ p2, int n_host,
                                                        const int *__restrict__ d_n, int it0, int it1,
-                                                       const RansacState *__restrict__ st,
-                                                       const double *__restrict__ Fm,
-                                                       const int *__restrict__ nmodels, float thr,
-                                                       int *__restrict__ counts)
+                                                       RansacState *st, const double *__restrict__ Fm,
+                                                       const int *__restrict__ nmodels, float thr, int *counts,
+                                                       int max_iters, double confidence, unsigned *ticket)
 {
     __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     const int it = it0 + w / 3, k = w - (w / 3) * 3;
-    if (it >= it1)
-        return;
-    if (it0 > 0 && st->done)
-        return;
-    const int nm = nmodels[it];
-    if (k >= nm) {
-        if (lane == 0)
-            counts[it * 3 + k] = 0;
-        return;
-    }
+    const bool skip_phase = it0 > 0 && st->done;  // the loop ended in the first phase
     const int n = d_n ? *d_n : n_host;
-    double F[9];
+    if (it < it1 && !skip_phase) {
+        const int nm = nmodels[it];
+        if (k >= nm) {
+            if (lane == 0)
+                counts[it * 3 + k] = 0;
+        } else {
+            double F[9];
 #pragma unroll
-    for (int i = 0; i < 9; i++)
-        F[i] = Fm[((size_t)it * 3 + k) * 9 + i];
-    int cnt = 0;
-    for (int i = lane; i < n; i += 64) {
-        const float2 a = p1[i], b = p2[i];
-        cnt += f_error(F, a.x, a.y, b.x, b.y) <= thr ? 1 : 0;
+            for (int i = 0; i < 9; i++)
+                F[i] = Fm[((size_t)it * 3 + k) * 9 + i];
+            int cnt = 0;
+            for (int i = lane; i < n; i += 64) {
+                const float2 a = p1[i], b = p2[i];
+                cnt += f_error(F, a.x, a.y, b.x, b.y) <= thr ? 1 : 0;
+            }
+            cnt = wave_sum_small(cnt);
+            if (lane == 0)
+                counts[it * 3 + k] = cnt;
+        }
     }
-    cnt = wave_sum_small(cnt);
-    if (lane == 0)
-        counts[it * 3 + k] = cnt;
+    // every workgroup takes a ticket once its counts are out; the holder of the last one sees them all
+    // (a skipped phase skips the tickets too: `done` is the same for every workgroup of the launch)
+    if (skip_phase)
+        return;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned t = atomicAdd(ticket, 1u);
+        if (t == gridDim.x - 1) {
+            *ticket = 0;  // ready for the next launch
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // other workgroups' counts, not this CU's stale lines
+            *st = ransac_replay<3>(st, it0 == 0 ? 1 : 0, it1, max_iters, n, confidence, nmodels, counts, M);
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void fr_mask_kernel(const float2 *__restrict__ p1,
@@ -404,6 +418,7 @@ int svo_launch_fransac(svo_ctx *ctx, const float *p1, const float *p2, int cap, 
     RansacState *st = reinterpret_cast<RansacState *>(ctx->w_b.p);
     int *nmodels = ctx->w_b.as<int>() + 16;
     int *counts = nmodels + max_iters;
+    unsigned *ticket = ctx->d_tickets;  // slot 0: fr_score
     const float thr = (float)(threshold * threshold);
     ScopedKernelTime tm(ctx, SVO_K_FRANSAC);
     const int bounds[3] = {0, max_iters < PHASE_A ? max_iters : PHASE_A, max_iters};
@@ -416,9 +431,7 @@ int svo_launch_fransac(svo_ctx *ctx, const float *p1, const float *p2, int cap, 
                            p1, p2, cap, d_n, seed, it0, it1, st, Fm, nmodels);
         hipLaunchKernelGGL(fr_score_kernel, dim3((iters * 3 + 3) / 4), dim3(256), 0, ctx->stream,
                            reinterpret_cast<const float2 *>(p1), reinterpret_cast<const float2 *>(p2), cap, d_n, it0,
-                           it1, st, Fm, nmodels, thr, counts);
-        hipLaunchKernelGGL(ransac_select_kernel<3>, dim3(1), dim3(64), 0, ctx->stream, st, ph == 0 ? 1 : 0, it1, max_iters,
-                           cap, d_n, confidence, nmodels, counts, M);
+                           it1, st, Fm, nmodels, thr, counts, max_iters, confidence, ticket);
     }
     hipLaunchKernelGGL(fr_mask_kernel, dim3((cap + 255) / 256), dim3(256), 0, ctx->stream,
                        reinterpret_cast<const float2 *>(p1), reinterpret_cast<const float2 *>(p2), cap, d_n, st, Fm,

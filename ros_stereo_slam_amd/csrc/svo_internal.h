@@ -84,6 +84,7 @@ struct svo_ctx {
     DevBuf s_img, s_a, s_b, s_c, s_d, s_e, s_f, s_g;
     // work buffers used inside multi-kernel entry points
     DevBuf w_a, w_b, w_c, w_d, w_e;
+    unsigned *d_tickets = nullptr;  // 64 zeroed counters for "last workgroup finishes the job" kernels (self-resetting)
     void *pinned = nullptr;  // small pinned host block for scalar read-backs
     size_t pinned_bytes = 0;
     hipEvent_t wait_ev = nullptr;  // svo_wait(): event polled by the host
