@@ -10,12 +10,13 @@
 //           cubic det(l*F1 + (1-l)*F2) = 0, up to three unit-norm models to HBM.
 //   score   one WAVEFRONT per model: the N correspondences strided over the 64 lanes,
 //           symmetric epipolar distance in f64, inlier count reduced with DPP.
-//   select  one thread replays the SEQUENTIAL loop over the counts (first-best-wins,
-//           adaptive iteration bound) so the answer equals the serial algorithm's.
+//           The LAST workgroup to finish (ticket counter) replays the SEQUENTIAL loop over the
+//           counts (first-best-wins, adaptive iteration bound), so the answer equals the serial
+//           algorithm's -- no launch of its own.
 //   mask    one thread per correspondence against the winning model.
-// solve/score/select run in two phases (iterations [0,64) and [64,max)); phase-two
-// kernels return at once when the adaptive bound was reached in phase one, which is the
-// common case at VO inlier ratios (0.99 confidence, 85% inliers -> 12 iterations).
+// solve/score run in two phases (iterations [0,64) and [64,max)); phase-two kernels return at
+// once when the adaptive bound was reached in phase one, which is the common case at VO
+// inlier ratios (0.99 confidence, 85% inliers -> 12 iterations).
 #include "ransac_common.cuh"
 #include "svo_internal.h"
 

@@ -13,9 +13,10 @@
 //           linearisations (N = 1, 2, 3) + Gauss-Newton + rigid alignment run on lanes
 //           0..2 side by side, entirely in registers.
 //   score   one WAVEFRONT per hypothesis, N correspondences strided over the lanes.
-//   select  sequential-semantics replay (ransac_common.cuh).
-//   refine  one workgroup: Levenberg-Marquardt on (R, t), 6x6 normal equations reduced
-//           with a fixed-order tree (deterministic), solved by one lane.
+//   finish  ONE workgroup, one launch: sequential-semantics replay (ransac_common.cuh) with the
+//           inlier count published to the host mailbox at once, mask + ordered inlier list of
+//           the winner (ballot scan), then Levenberg-Marquardt on (R, t): 6x6 normal equations
+//           reduced with a fixed-order tree (deterministic), solved by one lane.
 #include <cfloat>
 
 #include "ransac_common.cuh"

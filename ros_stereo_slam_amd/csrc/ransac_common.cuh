@@ -61,7 +61,8 @@ __device__ __forceinline__ int wave_sum_small(int v)
            __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
 }
 
-// Replays the SEQUENTIAL RANSAC loop over iterations [st->next_iter, it_end): first-best-wins,
+// Replays the SEQUENTIAL RANSAC loop over iterations [st->next_iter, it_end) (called by one
+// thread: the last workgroup of fr_score_kernel, thread 0 of pnp_finish_kernel): first-best-wins,
 // adaptive iteration bound, stop at a failed sample -- so that evaluating all hypotheses
 // concurrently gives exactly the serial algorithm's answer.  MPI = models per iteration slot
 // (nmodels[it] in -1 (sampling failed) .. MPI, counts[it * MPI + k]).
@@ -126,21 +127,6 @@ __device__ inline void publish_early(int *early_out, int early_tag, const Ransac
     early_out[2] = n;
     __threadfence_system();
     __hip_atomic_store(&early_out[0], early_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-template <int MPI>
-__global__ void ransac_select_kernel(RansacState *st, int first, int it_end, int max_iters, int n_host,
-                                     const int *__restrict__ d_n, double confidence,
-                                     const int *__restrict__ nmodels, const int *__restrict__ counts,
-                                     int model_points)
-{
-    __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
-    if (threadIdx.x != 0 || blockIdx.x != 0)
-        return;
-    if (!first && st->done)
-        return;
-    *st = ransac_replay<MPI>(st, first, it_end, max_iters, d_n ? *d_n : n_host, confidence, nmodels, counts,
-                             model_points);
 }
 
 // hand-off of LDS data between lanes of ONE wave (LDS ops of a wave execute in order; this
