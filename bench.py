@@ -45,6 +45,10 @@ PYR_BYTES = 619930 * C    # sum of the 4 level sizes
 # PMC counters cannot be read from inside this process, so the figure is carried from the
 # committed profile; None would be the honest value for any other workload.
 LK_PMC_TRAFFIC_BYTES = 13349433
+# VALU wave-instructions per lk_track_kernel<3> launch from the SQ counters of the same workload
+# (profiles/r01_pmc_sq_v3.csv, SQ_INSTS_VALU).  The kernel's own bound is VALU issue, not HBM:
+# 1024 SIMDs x one wave64 VALU instruction per 4 cycles at 2.4 GHz.
+LK_PMC_VALU_INSTS = 41912354
 
 
 def lk_algorithmic_bytes(n_pts: int) -> int:
@@ -257,6 +261,9 @@ def main():
                 "avg_launch_us": lk_avg_s * 1e6,
                 "launches_per_step": lk_launches / args.steps,
                 "algorithmic_bytes_per_launch": lk_algorithmic_bytes(N_KPTS),
+                "valu_issue_bound_us": (LK_PMC_VALU_INSTS * 4 / 1024 / 2.4e9 * 1e6) if N_KPTS == 4096 else None,
+                "valu_issue_frac": (LK_PMC_VALU_INSTS * 4 / 1024 / 2.4e9) / lk_avg_s
+                                   if (N_KPTS == 4096 and lk_avg_s > 0) else None,
                 "frame_hbm_frac": frame_algorithmic_bytes(N_KPTS, kf_rate) / (elapsed / args.steps) / 8e12,
             },
         }
