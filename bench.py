@@ -24,12 +24,13 @@ import time
 
 import numpy as np
 
-# One hardware queue per chunk stream PLUS one for the default stream (torch's copies): with the
-# runtime's default of 4 the fourth chunk stream shares a queue with another chunk (which queue a
-# stream gets is the runtime's least-referenced pick) and the two serialise.  More than four
-# queues busy at once dispatch worse (measured), so the chunk count stays at 4.  Must be set before
-# the HIP runtime initialises, i.e. before torch is imported.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "5")
+# One hardware queue per chunk stream, plus room for the default stream (torch's copies) and for
+# the streams RCCL creates in a multi-GPU run: with the runtime's default pool of 4 the fourth chunk
+# stream shares a queue with another chunk (which queue a stream gets is the runtime's
+# least-referenced pick) and the two serialise.  The pool may be larger than needed (5, 6, 8 and 12
+# measure the same); what hurts is more than four queues BUSY at once, so the chunk count stays at 4.
+# Must be set before the HIP runtime initialises, i.e. before torch is imported.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
