@@ -19,6 +19,7 @@ LIB_PATH = _HERE / "libsvo_hip.so"
 HEADER_PATH = _HERE.parent / "include" / "svo.h"
 
 SVO_OK = 0
+SVO_ERR_ARG = -1
 SVO_ERR_NO_DEVICE = -4
 SVO_ERR_TRACKING_LOST = -5
 MEM_HOST, MEM_DEVICE = 0, 1
@@ -189,7 +190,10 @@ def compact(self, mask, *arrays):
     """Order-preserving compaction of up to three float arrays by a byte mask."""
     mask = np.ascontiguousarray(mask, np.uint8)
     n = mask.shape[0]
-    arrs = [np.ascontiguousarray(a, np.float32).reshape(n, -1) for a in arrays]
+    arrs = []
+    for a in arrays:
+        a = np.ascontiguousarray(a, np.float32)
+        arrs.append(a.reshape(n, -1) if a.size else a.reshape(0, a.shape[1] if a.ndim > 1 else 1))
     assert 1 <= len(arrs) <= 3
     outs = [np.empty_like(a) for a in arrs]
     args = []
