@@ -142,3 +142,54 @@ def test_run_chunks_side_by_side_equals_one_by_one(ctx):
         capi.run_chunks([(vos[0], [], []), (w, [], [])])
     for c in ctxs:
         c.close()
+
+
+def test_chunk_sharded_run_against_the_sequential_one(ctx):
+    """SURVEY 8e on one GPU: the stream cut into three chunks with one frame of overlap, every
+    chunk re-initialised at its first frame and run side by side (svo_vo_run_chunks), the boundary
+    poses prefix-composed and the chunks rebased (chunked.py -- the arithmetic the RCCL all-gather
+    feeds on a multi-GPU node).  Results differ from the sequential run by construction (extra
+    keyframes at chunk starts); the tolerance is on the trajectory: both stay near the generator's
+    ground truth and within 5 cm of each other."""
+    import torch
+    from ros_stereo_slam_amd import chunked
+
+    n = 25
+    poses, frames = _frames(n, size=(620, 188))
+    K4 = (359.428, 359.428, 303.5964, 92.60785)            # the KITTI intrinsics at half resolution
+    dev = [(torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()) for l, r in
+           [synth.Scene().stereo(R, t, K=K4, size=(620, 188))[:2] for R, t in poses]]
+    torch.cuda.synchronize()
+    kw = dict(grid_step=12, keyframe_min_inliers=300, seed=2, K4=K4)
+    seq = capi.VisualOdometry(ctx, 620, 188, 3, **kw)
+    seq.init(*dev[0])
+    rc, done, R, t, *_ = seq.run_chunk([d[0] for d in dev[1:]], [d[1] for d in dev[1:]])
+    assert rc == 0 and done == n - 1
+    traj_seq = [np.zeros(3)] + [t[i] for i in range(n - 1)]
+    bounds = chunked.chunk_bounds(n, 3)
+    ctxs = [capi.Context(0) for _ in bounds]
+    vos = [capi.VisualOdometry(c, 620, 188, 3, **kw) for c in ctxs]
+    jobs = []
+    for v, (s, e) in zip(vos, bounds):
+        v.init(*dev[s])
+        jobs.append((v, [d[0] for d in dev[s + 1:e + 1]], [d[1] for d in dev[s + 1:e + 1]]))
+    res = capi.run_chunks(jobs)
+    local = []
+    for (s, e), (rc, done, Rc, tc, *_rest) in zip(bounds, res):
+        assert rc == 0 and done == e - s
+        local.append([(np.eye(3), np.zeros(3))] + [(Rc[i], tc[i]) for i in range(e - s)])
+    starts = chunked.prefix_transforms([loc[-1] for loc in local])
+    traj = []
+    for k, (loc, st) in enumerate(zip(local, starts)):
+        glob = chunked.rebase(loc, *st)
+        traj.extend(glob if k == 0 else glob[1:])          # the overlap frame is not duplicated
+    assert len(traj) == n
+    gt_t = np.array([R0t for R0t in [poses[i][1] - poses[0][1] for i in range(n)]])
+    ate_seq = chunked.ate_rmse(traj_seq, gt_t)
+    ate_sh = chunked.ate_rmse([t for _, t in traj], gt_t)
+    ate_rel = chunked.ate_rmse([t for _, t in traj], traj_seq)
+    print(f"ATE vs ground truth: sequential {ate_seq:.4f} m, 3 chunks {ate_sh:.4f} m; between them {ate_rel:.4f} m")
+    assert ate_seq < 0.1 and ate_sh < 0.1 and ate_rel < 0.05
+    for c in ctxs:
+        c.close()
+    seq.close()

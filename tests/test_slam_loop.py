@@ -135,7 +135,10 @@ def test_slam_loop_with_closure_matches_oracle(ctx, orc):
     ate_orc = chunked.ate_rmse([t for _, t in o.trajectory], gt_t)
     print(f"ATE vs generator ground truth: GPU {ate_raw:.3f} m, oracle {ate_orc:.3f} m over {n} frames; "
           f"closure at {g.closures}; policies in step until frame {sync_until}")
+    ate_go = chunked.ate_rmse([t for _, t in g.trajectory], np.array([t for _, t in o.trajectory]))
+    print(f"ATE of the GPU trajectory against the oracle trajectory: {ate_go:.4f} m")
     assert ate_raw < 1.0 and ate_orc < 1.0 and abs(ate_raw - ate_orc) < 0.1
+    assert ate_go < 0.05                                        # <= 5 cm on the synthetic loop
 
 
 @pytest.mark.gpu
