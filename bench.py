@@ -41,11 +41,11 @@ GRID_STEP = 10            # 4428 lattice points -> ANMS keeps 4096 (SURVEY.md 8d
 KF_MIN_INLIERS = 2000     # the reference's 200-of-440 rule scaled to 4096 keypoints
 PYR_BYTES = 619930 * C    # sum of the 4 level sizes
 # HBM bytes per lk_track_kernel<3> launch from the PMC counters of this very workload
-# (profiles/r01_pmc_hbm_traffic_v3.csv: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes,
+# (profiles/r01_pmc_hbm_traffic_v4.csv: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes,
 # KB units, gfx950 correction for 16-B-per-lane reads: (2*FETCH_SIZE + WRITE_SIZE) * 1024).
 # PMC counters cannot be read from inside this process, so the figure is carried from the
 # committed profile; None would be the honest value for any other workload.
-LK_PMC_TRAFFIC_BYTES = 13349433
+LK_PMC_TRAFFIC_BYTES = 12681000   # 20 011 838 B per launch / 1.578 tracking passes per launch
 # VALU wave-instructions per lk_track_kernel<3> launch from the SQ counters of the same workload
 # (profiles/r01_pmc_sq_v3.csv, SQ_INSTS_VALU).  The kernel's own bound is VALU issue, not HBM:
 # 1024 SIMDs x one wave64 VALU instruction per 4 cycles at 2.4 GHz.
@@ -79,9 +79,12 @@ def main():
     ap.add_argument("--pipeline", choices=("auto", "on", "off"), default="auto",
                     help="two-stream overlap of PnP(t) with pyramid + LK(t+1) inside a chunk; auto = on for one "
                          "chunk per GPU, off when several chunks already fill the hardware queues")
-    ap.add_argument("--chunks-per-gpu", type=int, default=int(os.environ.get("SVO_CHUNKS_PER_GPU", "4")),
+    ap.add_argument("--chunks-per-gpu", type=int, default=int(os.environ.get("SVO_CHUNKS_PER_GPU", "8")),
                     help="independent chunks of the stream run side by side on each GPU (svo_vo_run_chunks); "
-                         "4 = one in-order stream per default HIP hardware queue")
+                         "with --chunks-per-context 2 that is 4 contexts = 4 busy hardware queues")
+    ap.add_argument("--chunks-per-context", type=int, default=int(os.environ.get("SVO_CHUNKS_PER_CONTEXT", "2")),
+                    help="chunks that share one context (= one stream): advanced in lock step with ONE pyramidal-LK "
+                         "launch per frame for all of them (1..4)")
     ap.add_argument("--kpts", type=int, default=4096, choices=(4096, 8192),
                     help="keypoints per frame: 4096 = BASELINE's metric (grid step 10), 8192 = configs[4] shape "
                          "(grid step 7 -> 9152 lattice points -> ANMS 8192, keyframe rule 4000)")
@@ -120,6 +123,7 @@ def main():
     from ros_stereo_slam_amd import capi, synth
 
     M = max(1, args.chunks_per_gpu)
+    G = max(1, min(4, args.chunks_per_context))
     pipeline = args.pipeline == "on" or (args.pipeline == "auto" and M == 1)
     scene = synth.Scene()
     # every rank renders its own contiguous chunks of the stream (M per GPU, one context each)
@@ -130,8 +134,9 @@ def main():
         hf = [scene.stereo(R, t)[:2] for (R, t) in all_poses[c0:c0 + args.frames]]
         host_frames.append(hf)
         dev_frames.append([(torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()) for l, r in hf])
-        ctxs.append(capi.Context(local_rank))
-        vos.append(capi.VisualOdometry(ctxs[m], W, H, C, grid_step=GRID_STEP, anms_keep=N_KPTS,
+        if m % G == 0:
+            ctxs.append(capi.Context(local_rank))
+        vos.append(capi.VisualOdometry(ctxs[m // G], W, H, C, grid_step=GRID_STEP, anms_keep=N_KPTS,
                                        keyframe_min_inliers=KF_MIN_INLIERS, seed=20261003 + m))
     torch.cuda.synchronize()
     n0 = [vos[m].init(*dev_frames[m][0]) for m in range(M)][0]
@@ -217,7 +222,10 @@ def main():
         fps = world * args.steps / elapsed
         lk_ms, lk_launches = times["lk"]
         lk_avg_s = lk_ms / max(lk_launches, 1) * 1e-3
-        achieved = lk_algorithmic_bytes(N_KPTS) / lk_avg_s / 1e9 if lk_avg_s > 0 else 0.0
+        # a launch carries the tracking passes of the chunks of one context that are in step
+        jobs_per_launch = (args.steps * (1.0 + stats["keyframes"] / max(args.steps, 1))) / max(lk_launches, 1)
+        lk_bytes = lk_algorithmic_bytes(N_KPTS) * jobs_per_launch
+        achieved = lk_bytes / lk_avg_s / 1e9 if lk_avg_s > 0 else 0.0
         kf_rate = stats["keyframes"] / args.steps
         result = {
             "metric": f"stereo frames/sec @1241x376, {N_KPTS} kpts",
@@ -239,6 +247,7 @@ def main():
                 "keyframe_min_inliers": KF_MIN_INLIERS,
                 "parallelism": f"{M} contiguous chunk(s) per GPU x{world} GPU(s), all-gather of chunk-boundary poses",
                 "chunks_per_gpu": M,
+                "chunks_per_context": G,
                 "single_chunk_reference": "one chunk alone: 1.85 k frames/s with the two-stream pipeline "
                                           "(--chunks-per-gpu 1), 1.32 k serial (DESIGN.md section 6)",
                 "pipeline": "two HIP streams per chunk: PnP(t) beside pyramid+LK(t+1)" if pipeline
@@ -257,13 +266,16 @@ def main():
                 "peak": 8000.0,
                 "unit": "GB/s",
                 "frac": achieved / 8000.0,
-                "traffic": LK_PMC_TRAFFIC_BYTES if (W, H, C, N_KPTS) == (1241, 376, 3, 4096) else None,
-                "traffic_source": "profiles/r01_pmc_hbm_traffic_v3.csv (rocprofv3 --pmc, (2*FETCH_SIZE+WRITE_SIZE)*1024)",
+                "traffic": LK_PMC_TRAFFIC_BYTES * jobs_per_launch if (W, H, C, N_KPTS) == (1241, 376, 3, 4096) else None,
+                "traffic_source": "profiles/r01_pmc_hbm_traffic_v4.csv (rocprofv3 --pmc, (2*FETCH_SIZE+WRITE_SIZE)*1024, "
+                                  "per tracking pass) x passes per launch",
                 "avg_launch_us": lk_avg_s * 1e6,
                 "launches_per_step": lk_launches / args.steps,
-                "algorithmic_bytes_per_launch": lk_algorithmic_bytes(N_KPTS),
-                "valu_issue_bound_us": (LK_PMC_VALU_INSTS * 4 / 1024 / 2.4e9 * 1e6) if N_KPTS == 4096 else None,
-                "valu_issue_frac": (LK_PMC_VALU_INSTS * 4 / 1024 / 2.4e9) / lk_avg_s
+                "algorithmic_bytes_per_launch": lk_bytes,
+                "lk_passes_per_launch": jobs_per_launch,
+                "valu_issue_bound_us": (LK_PMC_VALU_INSTS * jobs_per_launch * 4 / 1024 / 2.4e9 * 1e6)
+                                       if N_KPTS == 4096 else None,
+                "valu_issue_frac": (LK_PMC_VALU_INSTS * jobs_per_launch * 4 / 1024 / 2.4e9) / lk_avg_s
                                    if (N_KPTS == 4096 and lk_avg_s > 0) else None,
                 "frame_hbm_frac": frame_algorithmic_bytes(N_KPTS, kf_rate) / (elapsed / args.steps) / 8e12,
             },

@@ -634,46 +634,267 @@ int svo_vo_run_chunk(svo_vo *v, const uint8_t *const *lefts, const uint8_t *cons
     return SVO_OK;
 }
 
+// Several chunks that share ONE context, advanced in lock step by one host thread on the context's
+// stream: per frame the pyramids of all of them, ONE pyramidal-LK launch carrying all their
+// tracking passes (the launch lasts as long as its slowest keypoint, so k jobs cost little more
+// than one), then each chunk's filters + PnP, then each chunk's policy.  Every chunk gets
+// exactly what svo_vo_run_chunk(pipeline = 0) gives it alone.
+static int run_chunk_group(svo_chunk_job **jobs, int k)
+{
+    struct GS {
+        svo_chunk_job *j;
+        svo_vo *v;
+        bool active = true;
+        int pending = -1, early_tag = 0, pose_tag[2] = {0, 0}, n = 0;
+        int *cnt_trk = nullptr;
+        PnpRecord *d_rec = nullptr;
+    };
+    std::vector<GS> gs(k);
+    svo_ctx *ctx = jobs[0]->vo->ctx;
+    hipStream_t st = ctx->stream;
+    int n_frames_max = 0;
+    for (int a = 0; a < k; a++) {
+        gs[a].j = jobs[a];
+        gs[a].v = jobs[a]->vo;
+        jobs[a]->n_done = 0;
+        jobs[a]->rc = SVO_OK;
+        if (jobs[a]->mem != SVO_MEM_DEVICE) {
+            svo_set_error("chunks that share a context take device images");
+            return SVO_ERR_ARG;
+        }
+        n_frames_max = jobs[a]->n_frames > n_frames_max ? jobs[a]->n_frames : n_frames_max;
+    }
+    auto wait_tag = [&](const int *slot, int tag) -> int {
+        for (unsigned spins = 1;; spins++) {
+            if (__atomic_load_n(slot, __ATOMIC_ACQUIRE) == tag)
+                return SVO_OK;
+            if ((spins & 0x3FFFF) == 0) {
+                hipError_t e = hipStreamQuery(st);
+                if (e == hipSuccess && __atomic_load_n(slot, __ATOMIC_ACQUIRE) != tag)
+                    e = hipErrorUnknown;
+                if (e != hipSuccess && e != hipErrorNotReady) {
+                    svo_set_error("waiting for the PnP mailbox -> %s", hipGetErrorString(e));
+                    return SVO_ERR_HIP;
+                }
+            }
+        }
+    };
+    auto harvest = [&](GS &g, int f) {  // pose composition (src/VisualSLAM.cpp:70-74)
+        const PnpRecord *rec = &g.v->mbox->rec[f & 1];
+        double *R9 = g.j->R_out + 9 * (size_t)f, *t3 = g.j->t_out + 3 * (size_t)f;
+        for (int i = 0; i < 3; i++)
+            for (int c = 0; c < 3; c++)
+                R9[3 * i + c] = rec->R[3 * c + i];
+        for (int i = 0; i < 3; i++)
+            t3[i] = -(R9[3 * i] * rec->tvec[0] + R9[3 * i + 1] * rec->tvec[1] + R9[3 * i + 2] * rec->tvec[2]);
+        memcpy(g.v->R, R9, sizeof(g.v->R));
+        memcpy(g.v->t, t3, sizeof(g.v->t));
+    };
+    auto launch_pnp = [&](GS &g, int f, double thr, double conf, int stage) -> int {
+        svo_vo *v = g.v;
+        const double K4[4] = {v->prm.fx, v->prm.fy, v->prm.cx, v->prm.cy};
+        g.early_tag = ++v->tag;
+        g.pose_tag[f & 1] = ++v->tag;
+        int r = svo_launch_pnp_ransac(ctx, v->trk3d, v->trk2d, g.n, g.cnt_trk, K4, 100, thr, conf, stage_seed(v, stage), 20,
+                                      v->idx, nullptr, g.d_rec, v->mbox->early, g.early_tag);
+        if (r)
+            return r;
+        hipLaunchKernelGGL(publish_record_kernel, dim3(1), dim3(64), 0, st, g.d_rec, g.cnt_trk, &v->mbox->rec[f & 1],
+                           &v->mbox->pose_tag[f & 1], g.pose_tag[f & 1]);
+        return SVO_OK;
+    };
+    auto stop = [&](GS &g, int rc) {  // this chunk ends here (tracking lost or an error); the others go on
+        g.active = false;
+        g.j->rc = rc;
+    };
+    int rc;
+    for (int f = 0; f < n_frames_max; f++) {
+        // ---- pyramids + ONE tracking launch for all the chunks still running ----
+        LkJob lk[SVO_LK_MAX_JOBS];
+        int nl = 0;
+        for (GS &g : gs) {
+            if (!g.active || f >= g.j->n_frames) {
+                g.active = g.active && f < g.j->n_frames;
+                continue;
+            }
+            svo_vo *v = g.v;
+            v->frame++;
+            g.n = v->nref;
+            if (g.n < 5) {
+                if (g.pending >= 0 && wait_tag(&v->mbox->pose_tag[g.pending & 1], g.pose_tag[g.pending & 1]) == SVO_OK)
+                    harvest(g, g.pending);
+                g.pending = -1;
+                svo_set_error("tracking lost: %d reference points", g.n);
+                stop(g, SVO_ERR_TRACKING_LOST);
+                continue;
+            }
+            if ((rc = svo_build_pyramid_from_device(ctx, v->pyr_cur, g.j->lefts[f])))
+                return rc;
+            LkJob &q = lk[nl++];
+            q.prev = v->pyr_ref->dev;
+            q.next = v->pyr_cur->dev;
+            q.prev_pts = v->ref2d;
+            q.n_cap = g.n;
+            q.d_n = nullptr;
+            q.next_pts = v->a2;
+            q.status = v->status;
+            q.err = nullptr;
+            q.min_eig = nullptr;
+        }
+        if (nl == 0)
+            break;
+        if ((rc = svo_launch_lk_batch(ctx, nl, lk)))
+            return rc;
+        // ---- filters + PnP of every chunk ----
+        for (GS &g : gs) {
+            if (!g.active)
+                continue;
+            svo_vo *v = g.v;
+            g.cnt_trk = v->d_cnt + ((f & 1) ? 9 : 1);
+            g.d_rec = v->d_rec + (f & 1);
+            if ((rc = svo_launch_compact(ctx, v->status, g.n, nullptr, v->ref2d, 2, v->b2, v->a2, 2, v->c2, v->ref3d, 3,
+                                         v->a3, v->d_cnt)) ||
+                (rc = svo_launch_fransac(ctx, v->b2, v->c2, g.n, v->d_cnt, v->prm.f_thr_temporal, 0.99, 1000,
+                                         stage_seed(v, 0), v->mask, nullptr, nullptr, nullptr)) ||
+                (rc = svo_launch_compact(ctx, v->mask, g.n, v->d_cnt, v->c2, 2, v->trk2d, v->a3, 3, v->trk3d, nullptr,
+                                         0, nullptr, g.cnt_trk)) ||
+                (rc = launch_pnp(g, f, 1.0, 0.99, 1)))
+                return rc;
+        }
+        // ---- policy of every chunk, in the order their counts arrive ----
+        for (GS &g : gs) {
+            if (!g.active)
+                continue;
+            svo_vo *v = g.v;
+            Mailbox *mb = v->mbox;
+            if ((rc = wait_tag(&mb->early[0], g.early_tag)))
+                return rc;
+            if (g.pending >= 0) {
+                if ((rc = wait_tag(&mb->pose_tag[g.pending & 1], g.pose_tag[g.pending & 1])))
+                    return rc;
+                harvest(g, g.pending);
+                g.pending = -1;
+            }
+            int ninl = mb->early[1];
+            if (ninl < 10) {  // retry at 8 px / 0.98 (src/keyFrameManagement.cpp:85-92)
+                if ((rc = wait_tag(&mb->pose_tag[f & 1], g.pose_tag[f & 1])) || (rc = launch_pnp(g, f, 8.0, 0.98, 2)) ||
+                    (rc = wait_tag(&mb->early[0], g.early_tag)))
+                    return rc;
+                ninl = mb->early[1];
+            }
+            v->ntrk = mb->early[2];
+            if (g.j->inliers_out)
+                g.j->inliers_out[f] = ninl;
+            if (g.j->tracked_out)
+                g.j->tracked_out[f] = v->ntrk;
+            if (ninl < 10) {
+                (void)wait_tag(&mb->pose_tag[f & 1], g.pose_tag[f & 1]);
+                svo_set_error("tracking lost at frame %d: %d PnP inliers", v->frame, ninl);
+                stop(g, SVO_ERR_TRACKING_LOST);
+                continue;
+            }
+            const bool kf = ninl < v->prm.keyframe_min_inliers;  // src/VisualSLAM.cpp:120
+            if (kf) {
+                if ((rc = wait_tag(&mb->pose_tag[f & 1], g.pose_tag[f & 1])))
+                    return rc;
+                harvest(g, f);
+                if ((rc = svo_build_pyramid_from_device(ctx, v->pyr_right, g.j->rights[f])))
+                    return rc;
+                const double *R9 = g.j->R_out + 9 * (size_t)f, *t3 = g.j->t_out + 3 * (size_t)f;
+                double Rt[12];
+                for (int i = 0; i < 3; i++) {
+                    Rt[4 * i] = R9[3 * i];
+                    Rt[4 * i + 1] = R9[3 * i + 1];
+                    Rt[4 * i + 2] = R9[3 * i + 2];
+                    Rt[4 * i + 3] = t3[i];
+                }
+                if ((rc = stereo_triangulate(v, v->pyr_cur, v->pyr_right, Rt, v->ref2d, v->ref3d, &v->nref)))
+                    return rc;
+            } else {
+                g.pending = f;
+                std::swap(v->ref2d, v->trk2d);
+                std::swap(v->ref3d, v->trk3d);
+                v->nref = v->ntrk;
+            }
+            std::swap(v->pyr_ref, v->pyr_cur);
+            if (g.j->keyframe_out)
+                g.j->keyframe_out[f] = kf ? 1 : 0;
+            g.j->n_done = f + 1;
+        }
+    }
+    for (GS &g : gs) {
+        if (g.pending >= 0) {
+            if ((rc = wait_tag(&g.v->mbox->pose_tag[g.pending & 1], g.pose_tag[g.pending & 1])))
+                return rc;
+            harvest(g, g.pending);
+        }
+        g.v->has_cur = false;
+    }
+    return SVO_OK;
+}
+
 int svo_vo_run_chunks(svo_chunk_job *jobs, int n_jobs)
 {
     SVO_CHECK_ARG(jobs && n_jobs >= 1);
+    // jobs that share a context form a group (lock step, one tracking launch for all of them);
+    // every group runs on its own host thread
+    std::vector<std::vector<svo_chunk_job *>> groups;
     for (int a = 0; a < n_jobs; a++) {
         SVO_CHECK_ARG(jobs[a].vo != nullptr);
-        for (int b = 0; b < a; b++)
-            if (jobs[a].vo->ctx == jobs[b].vo->ctx) {
-                svo_set_error("svo_vo_run_chunks: jobs %d and %d share a context", b, a);
-                return SVO_ERR_ARG;
+        bool placed = false;
+        for (auto &g : groups)
+            if (g[0]->vo->ctx == jobs[a].vo->ctx) {
+                for (svo_chunk_job *o : g)
+                    if (o->vo == jobs[a].vo) {
+                        svo_set_error("svo_vo_run_chunks: a front-end appears in two jobs");
+                        return SVO_ERR_ARG;
+                    }
+                if ((int)g.size() >= SVO_LK_MAX_JOBS) {
+                    svo_set_error("svo_vo_run_chunks: at most %d chunks per context", SVO_LK_MAX_JOBS);
+                    return SVO_ERR_ARG;
+                }
+                g.push_back(&jobs[a]);
+                placed = true;
+                break;
             }
+        if (!placed)
+            groups.push_back({&jobs[a]});
     }
-    std::vector<std::string> errs(n_jobs);
-    auto body = [&](int a) {
-        svo_chunk_job &j = jobs[a];
-        j.n_done = 0;
-        if (hipSetDevice(j.vo->ctx->device) != hipSuccess) {  // the current device is per host thread
-            j.rc = SVO_ERR_HIP;
-            errs[a] = "hipSetDevice failed";
+    const int ng = (int)groups.size();
+    std::vector<std::string> errs(ng);
+    std::vector<int> grc(ng, SVO_OK);
+    auto body = [&](int gi) {
+        auto &g = groups[gi];
+        if (hipSetDevice(g[0]->vo->ctx->device) != hipSuccess) {  // the current device is per host thread
+            grc[gi] = SVO_ERR_HIP;
+            errs[gi] = "hipSetDevice failed";
             return;
         }
-        j.rc = svo_vo_run_chunk(j.vo, j.lefts, j.rights, j.n_frames, j.mem, j.pipeline, j.R_out, j.t_out,
-                                j.inliers_out, j.tracked_out, j.keyframe_out, &j.n_done);
-        if (j.rc)
-            errs[a] = svo_last_error();  // the error text is thread-local
+        if (g.size() == 1) {
+            svo_chunk_job &j = *g[0];
+            j.n_done = 0;
+            j.rc = svo_vo_run_chunk(j.vo, j.lefts, j.rights, j.n_frames, j.mem, j.pipeline, j.R_out, j.t_out,
+                                    j.inliers_out, j.tracked_out, j.keyframe_out, &j.n_done);
+            if (j.rc && j.rc != SVO_ERR_TRACKING_LOST)
+                grc[gi] = j.rc;
+        } else {
+            grc[gi] = run_chunk_group(g.data(), (int)g.size());
+        }
+        if (grc[gi])
+            errs[gi] = svo_last_error();  // the error text is thread-local
     };
     std::vector<std::thread> th;
-    for (int a = 1; a < n_jobs; a++)
-        th.emplace_back(body, a);
+    for (int gi = 1; gi < ng; gi++)
+        th.emplace_back(body, gi);
     body(0);
     for (auto &t : th)
         t.join();
-    int rc = SVO_OK;
-    for (int a = 0; a < n_jobs; a++)
-        if (jobs[a].rc) {
-            if (rc == SVO_OK || (rc == SVO_ERR_TRACKING_LOST && jobs[a].rc != SVO_ERR_TRACKING_LOST)) {
-                rc = jobs[a].rc;
-                svo_set_error("chunk %d: %s", a, errs[a].c_str());
-            }
+    for (int gi = 0; gi < ng; gi++)
+        if (grc[gi]) {
+            svo_set_error("chunk group %d: %s", gi, errs[gi].c_str());
+            return grc[gi];
         }
-    return rc == SVO_ERR_TRACKING_LOST ? SVO_OK : rc;
+    return SVO_OK;
 }
 
 int svo_vo_get_reference(svo_vo *v, float *ref2d, float *ref3d, int cap, int *n, int mem)

@@ -244,12 +244,21 @@ __device__ __forceinline__ void lane_residual(const uint8_t *lds, int off, int w
     }
 }
 
+// One launch may carry the LK passes of several independent chunks of the stream (blockIdx.y picks
+// the job): the launch lasts as long as the slowest keypoint of ANY job, so two jobs cost little
+// more than one (svo_vo_run_chunks, chunks that share a context).
 template <int C>
-__global__ __launch_bounds__(64 * WAVES, 3) void lk_track_kernel(
-    PyrDev prev, PyrDev next, const float *__restrict__ prev_pts, int n_cap, const int *__restrict__ d_n,
-    float *__restrict__ next_pts, uint8_t *__restrict__ status, float *__restrict__ err,
-    float *__restrict__ min_eig_out, LkParams prm)
+__global__ __launch_bounds__(64 * WAVES, 3) void lk_track_kernel(LkBatch batch, LkParams prm)
 {
+    const LkJob &job = batch.j[blockIdx.y];
+    const PyrDev &prev = job.prev, &next = job.next;
+    const float *__restrict__ prev_pts = job.prev_pts;
+    const int n_cap = job.n_cap;
+    const int *__restrict__ d_n = job.d_n;
+    float *__restrict__ next_pts = job.next_pts;
+    uint8_t *__restrict__ status = job.status;
+    float *__restrict__ err = job.err;
+    float *__restrict__ min_eig_out = job.min_eig;
     const int n = d_n ? min(*d_n, n_cap) : n_cap;  // live count may sit in HBM (chained stages)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -488,33 +497,66 @@ __global__ void grid_keypoints_kernel(int rows, int cols, int step, int nx, int 
 
 }  // namespace
 
+int svo_launch_lk_batch(svo_ctx *ctx, int n_jobs, const LkJob *jobs)
+{
+    if (n_jobs <= 0)
+        return SVO_OK;
+    if (n_jobs > SVO_LK_MAX_JOBS) {
+        svo_set_error("lk: at most %d jobs per launch", SVO_LK_MAX_JOBS);
+        return SVO_ERR_ARG;
+    }
+    LkBatch batch;
+    int n_max = 0, c = jobs[0].prev.c, levels = jobs[0].prev.levels;
+    for (int k = 0; k < n_jobs; k++) {
+        batch.j[k] = jobs[k];
+        n_max = jobs[k].n_cap > n_max ? jobs[k].n_cap : n_max;
+        if (jobs[k].prev.c != c || jobs[k].prev.levels != levels) {
+            svo_set_error("lk: the jobs of one launch must share channel count and pyramid depth");
+            return SVO_ERR_ARG;
+        }
+    }
+    for (int k = n_jobs; k < SVO_LK_MAX_JOBS; k++)
+        batch.j[k] = jobs[0];
+    if (n_max == 0)
+        return SVO_OK;
+    LkParams prm;
+    prm.max_level = levels - 1;
+    prm.max_count = 30;
+    prm.eps_sq = 0.01 * 0.01;
+    prm.min_eig_thr = (float)1e-4;
+    dim3 grid(((n_max + 7) / 8) * 8, n_jobs), block(64 * WAVES);  // x: a multiple of 8, every XCD band has all its slots
+    ScopedKernelTime t(ctx, SVO_K_LK);
+    switch (c) {
+    case 1:
+        hipLaunchKernelGGL(lk_track_kernel<1>, grid, block, WAVES * Lds<1>::WAVE_BYTES, ctx->stream, batch, prm);
+        break;
+    case 3:
+        hipLaunchKernelGGL(lk_track_kernel<3>, grid, block, WAVES * Lds<3>::WAVE_BYTES, ctx->stream, batch, prm);
+        break;
+    default:
+        svo_set_error("lk: unsupported channel count %d (1 or 3)", c);
+        return SVO_ERR_ARG;
+    }
+    SVO_HIP(hipGetLastError());
+    return SVO_OK;
+}
+
 int svo_launch_lk(svo_ctx *ctx, const PyrDev &prev, const PyrDev &next, const float *prev_pts, int n,
                   float *next_pts, uint8_t *status, float *err, float *min_eig, const int *d_n)
 {
     if (n == 0)
         return SVO_OK;
-    LkParams prm;
-    prm.max_level = prev.levels - 1;
-    prm.max_count = 30;
-    prm.eps_sq = 0.01 * 0.01;
-    prm.min_eig_thr = (float)1e-4;
-    dim3 grid(((n + 7) / 8) * 8), block(64 * WAVES);  // a multiple of 8: every XCD band has all its slots
-    ScopedKernelTime t(ctx, SVO_K_LK);
-    switch (prev.c) {
-    case 1:
-        hipLaunchKernelGGL(lk_track_kernel<1>, grid, block, WAVES * Lds<1>::WAVE_BYTES, ctx->stream, prev,
-                           next, prev_pts, n, d_n, next_pts, status, err, min_eig, prm);
-        break;
-    case 3:
-        hipLaunchKernelGGL(lk_track_kernel<3>, grid, block, WAVES * Lds<3>::WAVE_BYTES, ctx->stream, prev,
-                           next, prev_pts, n, d_n, next_pts, status, err, min_eig, prm);
-        break;
-    default:
-        svo_set_error("lk: unsupported channel count %d (1 or 3)", prev.c);
-        return SVO_ERR_ARG;
-    }
-    SVO_HIP(hipGetLastError());
-    return SVO_OK;
+    LkJob job;
+    job.prev = prev;
+    job.next = next;
+    job.prev_pts = prev_pts;
+    job.n_cap = n;
+    job.d_n = d_n;
+    job.next_pts = next_pts;
+    job.status = status;
+    job.err = err;
+    job.min_eig = min_eig;
+    return svo_launch_lk_batch(ctx, 1, &job);
 }
 
 // number of lattice points of the reference's loop `for (v = s; v < dim - s; v += s)`

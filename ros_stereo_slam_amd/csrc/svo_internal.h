@@ -108,6 +108,20 @@ int svo_resolve_timers(svo_ctx *ctx);
 // pyramid.hip
 int svo_build_pyramid_from_device(svo_ctx *ctx, svo_pyramid *pyr, const uint8_t *d_image);
 // lk.hip
+#define SVO_LK_MAX_JOBS 4
+struct LkJob {  // one pyramidal-LK pass: prev/next pyramids, points in, points / status / err / minEig out
+    PyrDev prev, next;
+    const float *prev_pts;
+    int n_cap;
+    const int *d_n;  // live point count on the device, or null (n_cap points)
+    float *next_pts;
+    uint8_t *status;
+    float *err, *min_eig;  // optional
+};
+struct LkBatch {
+    LkJob j[SVO_LK_MAX_JOBS];
+};
+int svo_launch_lk_batch(svo_ctx *ctx, int n_jobs, const LkJob *jobs);
 int svo_launch_lk(svo_ctx *ctx, const PyrDev &prev, const PyrDev &next, const float *prev_pts,
                   int n, float *next_pts, uint8_t *status, float *err, float *min_eig,
                   const int *d_n = nullptr);

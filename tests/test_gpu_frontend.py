@@ -137,11 +137,51 @@ def test_run_chunks_side_by_side_equals_one_by_one(ctx):
         assert one[0] == par[0] == 0 and one[1] == par[1] == 3
         for x, y in zip(one[2:], par[2:]):
             assert np.array_equal(x, y)
-    with pytest.raises(capi.SvoError):  # two jobs on one context are refused
-        w = capi.VisualOdometry(ctxs[0], 1241, 376, 3, **kw)
-        capi.run_chunks([(vos[0], [], []), (w, [], [])])
+    with pytest.raises(capi.SvoError):  # one front-end in two jobs is refused
+        capi.run_chunks([(vos[0], [], []), (vos[0], [], [])])
     for c in ctxs:
         c.close()
+
+
+@pytest.mark.parametrize("lengths", [(4, 4, 4), (5, 3, 2, 4)])
+def test_chunks_sharing_a_context_run_in_lock_step_with_one_lk_launch(ctx, lengths):
+    """Jobs whose front-ends share ONE context form a group: one host thread, one pyramidal-LK
+    launch per frame for all of them (blockIdx.y = job).  Chunks of different lengths, keyframes
+    falling on different frames: every chunk must still get exactly its stand-alone result."""
+    import torch
+    total = sum(lengths)
+    poses, frames = _frames(total)
+    dev = [(torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()) for l, r in frames]
+    torch.cuda.synchronize()
+    kw = dict(grid_step=30, keyframe_min_inliers=200)
+    bounds, s0 = [], 0
+    for n in lengths:
+        bounds.append((s0, s0 + n))
+        s0 += n
+    alone = []
+    for k, (a, b) in enumerate(bounds):
+        v = capi.VisualOdometry(ctx, 1241, 376, 3, seed=20 + k, **kw)
+        v.init(*dev[a])
+        alone.append((v.run_chunk([d[0] for d in dev[a + 1:b]], [d[1] for d in dev[a + 1:b]], pipeline=False),
+                      v.reference()))
+        v.close()
+    shared = capi.Context(0)
+    vos = [capi.VisualOdometry(shared, 1241, 376, 3, seed=20 + k, **kw) for k in range(len(bounds))]
+    jobs = []
+    for v, (a, b) in zip(vos, bounds):
+        v.init(*dev[a])
+        jobs.append((v, [d[0] for d in dev[a + 1:b]], [d[1] for d in dev[a + 1:b]]))
+    res = capi.run_chunks(jobs)
+    saw_kf = False
+    for (one, ref_one), par, v in zip(alone, res, vos):
+        assert one[0] == par[0] == 0 and one[1] == par[1]
+        for x, y in zip(one[2:], par[2:]):
+            assert np.array_equal(x, y)
+        saw_kf |= bool(par[6].any())
+        r2, r3 = v.reference()
+        assert np.array_equal(r2, ref_one[0]) and np.array_equal(r3, ref_one[1])
+    assert saw_kf
+    shared.close()
 
 
 def test_chunk_sharded_run_against_the_sequential_one(ctx):
