@@ -745,7 +745,10 @@ static int run_chunk_group(svo_chunk_job **jobs, int k)
             break;
         if ((rc = svo_launch_lk_batch(ctx, nl, lk)))
             return rc;
-        // ---- filters + PnP of every chunk ----
+        // ---- filters of every chunk, then ONE set of PnP launches for all of them ----
+        svo_pnp_job pj[SVO_LK_MAX_JOBS];
+        GS *pg[SVO_LK_MAX_JOBS];
+        int np = 0;
         for (GS &g : gs) {
             if (!g.active)
                 continue;
@@ -757,9 +760,37 @@ static int run_chunk_group(svo_chunk_job **jobs, int k)
                 (rc = svo_launch_fransac(ctx, v->b2, v->c2, g.n, v->d_cnt, v->prm.f_thr_temporal, 0.99, 1000,
                                          stage_seed(v, 0), v->mask, nullptr, nullptr, nullptr)) ||
                 (rc = svo_launch_compact(ctx, v->mask, g.n, v->d_cnt, v->c2, 2, v->trk2d, v->a3, 3, v->trk3d, nullptr,
-                                         0, nullptr, g.cnt_trk)) ||
-                (rc = launch_pnp(g, f, 1.0, 0.99, 1)))
+                                         0, nullptr, g.cnt_trk)))
                 return rc;
+            g.early_tag = ++v->tag;
+            g.pose_tag[f & 1] = ++v->tag;
+            svo_pnp_job &q = pj[np];
+            q.obj = v->trk3d;
+            q.img = v->trk2d;
+            q.cap = g.n;
+            q.d_n = g.cnt_trk;
+            q.K4[0] = v->prm.fx;
+            q.K4[1] = v->prm.fy;
+            q.K4[2] = v->prm.cx;
+            q.K4[3] = v->prm.cy;
+            q.iterations = 100;
+            q.reproj_err = 1.0;
+            q.confidence = 0.99;
+            q.seed = stage_seed(v, 1);
+            q.refine_iters = 20;
+            q.inliers = v->idx;
+            q.mask = nullptr;
+            q.d_result = g.d_rec;
+            q.early_mbox = v->mbox->early;
+            q.early_tag = g.early_tag;
+            pg[np++] = &g;
+        }
+        if ((rc = svo_launch_pnp_ransac_batch(ctx, np, pj)))
+            return rc;
+        for (int a = 0; a < np; a++) {
+            GS &g = *pg[a];
+            hipLaunchKernelGGL(publish_record_kernel, dim3(1), dim3(64), 0, st, g.d_rec, g.cnt_trk, &g.v->mbox->rec[f & 1],
+                               &g.v->mbox->pose_tag[f & 1], g.pose_tag[f & 1]);
         }
         // ---- policy of every chunk, in the order their counts arrive ----
         for (GS &g : gs) {

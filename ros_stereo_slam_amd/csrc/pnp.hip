@@ -31,6 +31,33 @@ constexpr int MP = 5;  // model points
 struct K4 {
     double fx, fy, cx, cy;
 };
+struct PnpResult;
+// One PnP-RANSAC problem as the kernels see it.  A launch may carry several independent problems
+// (blockIdx.y picks the job): these kernels are chains of one wave's f64 latency, so the jobs of
+// chunks that run in lock step (svo_vo_run_chunks) cost the time of one.
+struct PnpJob {
+    const float *obj;
+    const float *img;
+    int n_host;
+    const int *d_n;
+    K4 K;
+    uint64_t seed;
+    int iterations;
+    double confidence;
+    float thr;
+    int max_lm_iters;
+    svo::RansacState *st;
+    double *hyp;
+    int *nmodels, *counts, *d_m;
+    uint8_t *mask;
+    int *inl;
+    PnpResult *out;
+    int *early_out;
+    int early_tag;
+};
+struct PnpBatch {
+    PnpJob j[SVO_LK_MAX_JOBS];
+};
 
 // ---- small dense helpers (registers, static indexing) --------------------------------------
 template <int N>
@@ -298,13 +325,19 @@ struct WaveLds {
     int pq[16];
 };
 
-__global__ __launch_bounds__(256) void pnp_solve_kernel(const float *__restrict__ obj, const float *__restrict__ img,
-                                                        int n_host, const int *__restrict__ d_n, K4 K,
-                                                        uint64_t seed, int it0, int it1,
-                                                        const RansacState *__restrict__ st,
-                                                        double *__restrict__ hyp, int *__restrict__ nmodels)
+__global__ __launch_bounds__(256) void pnp_solve_kernel(PnpBatch batch)
 {
     __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
+    const PnpJob &job = batch.j[blockIdx.y];
+    const float *__restrict__ obj = job.obj, *__restrict__ img = job.img;
+    const int n_host = job.n_host;
+    const int *__restrict__ d_n = job.d_n;
+    const K4 K = job.K;
+    const uint64_t seed = job.seed;
+    const int it0 = 0, it1 = job.iterations;
+    const RansacState *__restrict__ st = job.st;
+    double *__restrict__ hyp = job.hyp;
+    int *__restrict__ nmodels = job.nmodels;
     __shared__ WaveLds s_lds[4];
     const int lane = threadIdx.x & 63;
     const int it = __builtin_amdgcn_readfirstlane(it0 + blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -747,14 +780,21 @@ __device__ __forceinline__ float reproj_err_sq(const double (&P)[12], const K4 &
     return (float)((double)dx * dx + (double)dy * dy);
 }
 
-__global__ __launch_bounds__(256) void pnp_score_kernel(const float *__restrict__ obj, const float2 *__restrict__ img,
-                                                        int n_host, const int *__restrict__ d_n, K4 K, int it0,
-                                                        int it1, const RansacState *__restrict__ st,
-                                                        const double *__restrict__ hyp,
-                                                        const int *__restrict__ nmodels, float thr,
-                                                        int *__restrict__ counts)
+__global__ __launch_bounds__(256) void pnp_score_kernel(PnpBatch batch)
 {
     __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
+    const PnpJob &job = batch.j[blockIdx.y];
+    const float *__restrict__ obj = job.obj;
+    const float2 *__restrict__ img = reinterpret_cast<const float2 *>(job.img);
+    const int n_host = job.n_host;
+    const int *__restrict__ d_n = job.d_n;
+    const K4 K = job.K;
+    const int it0 = 0, it1 = job.iterations;
+    const RansacState *__restrict__ st = job.st;
+    const double *__restrict__ hyp = job.hyp;
+    const int *__restrict__ nmodels = job.nmodels;
+    const float thr = job.thr;
+    int *__restrict__ counts = job.counts;
     const int lane = threadIdx.x & 63;
     const int it = __builtin_amdgcn_readfirstlane(it0 + blockIdx.x * 4 + (threadIdx.x >> 6));
     if (it >= it1)
@@ -942,17 +982,29 @@ struct PnpResult {      // what the host reads back after a localisation
 // (2) the workgroup evaluates the winning hypothesis on every point, writes the mask and the
 // order-preserving inlier index list (ballot scan); (3) Levenberg-Marquardt refinement over the
 // inlier list.
-__global__ __launch_bounds__(256) void pnp_finish_kernel(const float *__restrict__ obj, const float2 *__restrict__ img,
-                                                         int n_host, const int *__restrict__ d_n, K4 K,
-                                                         RansacState *__restrict__ st, int iterations,
-                                                         double confidence, const int *__restrict__ nmodels,
-                                                         const int *__restrict__ counts,
-                                                         const double *__restrict__ hyp, float thr,
-                                                         uint8_t *__restrict__ mask, int *__restrict__ inl,
-                                                         int *__restrict__ d_m, int max_iters,
-                                                         PnpResult *__restrict__ out, int *early_out, int early_tag)
+__global__ __launch_bounds__(256) void pnp_finish_kernel(PnpBatch batch)
 {
     __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
+    const PnpJob &job = batch.j[blockIdx.x];  // one workgroup per job
+    const float *__restrict__ obj = job.obj;
+    const float2 *__restrict__ img = reinterpret_cast<const float2 *>(job.img);
+    const int n_host = job.n_host;
+    const int *__restrict__ d_n = job.d_n;
+    const K4 K = job.K;
+    RansacState *__restrict__ st = job.st;
+    const int iterations = job.iterations;
+    const double confidence = job.confidence;
+    const int *__restrict__ nmodels = job.nmodels;
+    const int *__restrict__ counts = job.counts;
+    const double *__restrict__ hyp = job.hyp;
+    const float thr = job.thr;
+    uint8_t *__restrict__ mask = job.mask;
+    int *__restrict__ inl = job.inl;
+    int *__restrict__ d_m = job.d_m;
+    const int max_iters = job.max_lm_iters;
+    PnpResult *__restrict__ out = job.out;
+    int *early_out = job.early_out;
+    const int early_tag = job.early_tag;
     __shared__ double s_all[NACC * RED_STRIDE], s_part[4 * NACC], s_sum[NACC], s_pose[12], s_trial[12];
     __shared__ int s_flag, s_wave[4], s_base;
     __shared__ RansacState s_state;
@@ -1127,41 +1179,91 @@ __global__ __launch_bounds__(256) void pnp_finish_kernel(const float *__restrict
 
 static_assert(sizeof(PnpResult) == 17 * 8, "PnpResult layout");
 
-// Device-pointer form.  inliers: cap ints; d_result: one PnpResult (136 bytes):
-// rvec[3] tvec[3] R[9] rms (doubles) n_inliers iters_run (ints).
+// Device-pointer form, several problems in one set of launches.  inliers: cap ints; d_result: one
+// PnpResult (136 bytes): rvec[3] tvec[3] R[9] rms (doubles) n_inliers iters_run (ints).
+int svo_launch_pnp_ransac_batch(svo_ctx *ctx, int n_jobs, const svo_pnp_job *jobs)
+{
+    if (n_jobs <= 0)
+        return SVO_OK;
+    if (n_jobs > SVO_LK_MAX_JOBS) {
+        svo_set_error("pnp: at most %d jobs per launch", SVO_LK_MAX_JOBS);
+        return SVO_ERR_ARG;
+    }
+    int it_max = 1;
+    for (int k = 0; k < n_jobs; k++)
+        it_max = jobs[k].iterations > it_max ? jobs[k].iterations : it_max;
+    // per-job workspace: hypotheses in w_c, state + counters in w_d
+    const size_t h_stride = (size_t)it_max * 12, i_stride = ((size_t)it_max * 2 + 32 + 15) / 16 * 16;
+    int rc;
+    if ((rc = ctx->w_c.ensure(h_stride * sizeof(double) * n_jobs)) || (rc = ctx->w_d.ensure(i_stride * sizeof(int) * n_jobs)))
+        return rc;
+    PnpBatch batch;
+    int nb = 0;
+    for (int k = 0; k < n_jobs; k++) {
+        const svo_pnp_job &h = jobs[k];
+        if (h.cap <= 0)
+            continue;
+        PnpJob &j = batch.j[nb];
+        const int iterations = h.iterations < 1 ? 1 : h.iterations;
+        int *ib = ctx->w_d.as<int>() + i_stride * nb;
+        j.obj = h.obj;
+        j.img = h.img;
+        j.n_host = h.cap;
+        j.d_n = h.d_n;
+        j.K = {h.K4[0], h.K4[1], h.K4[2], h.K4[3]};
+        j.seed = h.seed;
+        j.iterations = iterations;
+        j.confidence = h.confidence;
+        j.thr = (float)(h.reproj_err * h.reproj_err);
+        j.max_lm_iters = h.refine_iters > 0 ? h.refine_iters : 20;
+        j.st = reinterpret_cast<RansacState *>(ib);
+        j.d_m = ib + 8;  // inlier count of the winning hypothesis
+        j.nmodels = ib + 16;
+        j.counts = j.nmodels + iterations;
+        j.hyp = ctx->w_c.as<double>() + h_stride * nb;
+        j.mask = h.mask;
+        j.inl = h.inliers;
+        j.out = reinterpret_cast<PnpResult *>(h.d_result);
+        j.early_out = h.early_mbox;
+        j.early_tag = h.early_tag;
+        nb++;
+    }
+    if (nb == 0)
+        return SVO_OK;
+    for (int k = nb; k < SVO_LK_MAX_JOBS; k++)
+        batch.j[k] = batch.j[0];
+    ScopedKernelTime tm(ctx, SVO_K_PNP);
+    const int nblk = (it_max + 3) / 4;
+    hipLaunchKernelGGL(pnp_solve_kernel, dim3(nblk, nb), dim3(256), 0, ctx->stream, batch);
+    hipLaunchKernelGGL(pnp_score_kernel, dim3(nblk, nb), dim3(256), 0, ctx->stream, batch);
+    hipLaunchKernelGGL(pnp_finish_kernel, dim3(nb), dim3(256), 0, ctx->stream, batch);
+    SVO_HIP(hipGetLastError());
+    return SVO_OK;
+}
+
 int svo_launch_pnp_ransac(svo_ctx *ctx, const float *obj, const float *img, int cap, const int *d_n,
                           const double *K4h, int iterations, double reproj_err, double confidence, uint64_t seed,
                           int refine_iters, int *inliers, uint8_t *mask, void *d_result, int *early_mbox,
                           int early_tag)
 {
-    if (cap <= 0)
-        return SVO_OK;
-    if (iterations < 1)
-        iterations = 1;
-    int rc;
-    const size_t h_bytes = (size_t)iterations * 12 * sizeof(double);
-    const size_t i_bytes = (size_t)iterations * 2 * sizeof(int) + 128;
-    if ((rc = ctx->w_c.ensure(h_bytes)) || (rc = ctx->w_d.ensure(i_bytes)))
-        return rc;
-    double *hyp = ctx->w_c.as<double>();
-    RansacState *st = reinterpret_cast<RansacState *>(ctx->w_d.p);
-    int *d_m = ctx->w_d.as<int>() + 8;  // inlier count of the winning hypothesis
-    int *nmodels = ctx->w_d.as<int>() + 16;
-    int *counts = nmodels + iterations;
-    const K4 K = {K4h[0], K4h[1], K4h[2], K4h[3]};
-    const float thr = (float)(reproj_err * reproj_err);
-    const float2 *img2 = reinterpret_cast<const float2 *>(img);
-    ScopedKernelTime tm(ctx, SVO_K_PNP);
-    const int nblk = (iterations + 3) / 4;
-    hipLaunchKernelGGL(pnp_solve_kernel, dim3(nblk), dim3(256), 0, ctx->stream, obj, img, cap, d_n, K, seed, 0,
-                       iterations, st, hyp, nmodels);
-    hipLaunchKernelGGL(pnp_score_kernel, dim3(nblk), dim3(256), 0, ctx->stream, obj, img2, cap, d_n, K, 0, iterations,
-                       st, hyp, nmodels, thr, counts);
-    hipLaunchKernelGGL(pnp_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, obj, img2, cap, d_n, K, st, iterations,
-                       confidence, nmodels, counts, hyp, thr, mask, inliers, d_m, refine_iters > 0 ? refine_iters : 20,
-                       reinterpret_cast<PnpResult *>(d_result), early_mbox, early_tag);
-    SVO_HIP(hipGetLastError());
-    return SVO_OK;
+    svo_pnp_job j;
+    j.obj = obj;
+    j.img = img;
+    j.cap = cap;
+    j.d_n = d_n;
+    for (int k = 0; k < 4; k++)
+        j.K4[k] = K4h[k];
+    j.iterations = iterations;
+    j.reproj_err = reproj_err;
+    j.confidence = confidence;
+    j.seed = seed;
+    j.refine_iters = refine_iters;
+    j.inliers = inliers;
+    j.mask = mask;
+    j.d_result = d_result;
+    j.early_mbox = early_mbox;
+    j.early_tag = early_tag;
+    return svo_launch_pnp_ransac_batch(ctx, 1, &j);
 }
 
 extern "C" int svo_pnp_ransac(svo_ctx *ctx, const float *obj, const float *img, int n, const double *K4h,

@@ -150,6 +150,22 @@ int svo_orb_launch(svo_orb *o, const uint8_t *d_image, float *d_xy, int *d_oct, 
 int svo_launch_sor(svo_ctx *ctx, const float *xyz, const float *color, int cap, int mean_k, double stddev_mul,
                    float z_limit, float *xyz_out, float *color_out, int *d_count, float *d_mean_dist, int *d_pass);
 // pnp.hip
+struct svo_pnp_job {  // host-side description of one PnP-RANSAC problem (device pointers)
+    const float *obj, *img;
+    int cap;
+    const int *d_n;
+    double K4[4];
+    int iterations;
+    double reproj_err, confidence;
+    uint64_t seed;
+    int refine_iters;
+    int *inliers;
+    uint8_t *mask;
+    void *d_result;
+    int *early_mbox;
+    int early_tag;
+};
+int svo_launch_pnp_ransac_batch(svo_ctx *ctx, int n_jobs, const svo_pnp_job *jobs);
 int svo_launch_pnp_ransac(svo_ctx *ctx, const float *obj, const float *img, int cap, const int *d_n,
                           const double *K4h, int iterations, double reproj_err, double confidence, uint64_t seed,
                           int refine_iters, int *inliers, uint8_t *mask, void *d_result, int *early_mbox = nullptr,
