@@ -28,6 +28,28 @@ constexpr int M = 7;
 constexpr int SOLVE_T = 64;
 constexpr int PHASE_A = 64;
 
+// One F-matrix RANSAC problem as the kernels see it; a launch may carry several (blockIdx.y picks
+// the job) -- the chunks of a context that run in lock step (svo_vo_run_chunks).
+struct FrJob {
+    const float *p1, *p2;
+    int n_host;
+    const int *d_n;
+    uint64_t seed;
+    int max_iters;
+    double confidence;
+    float thr;
+    RansacState *st;
+    double *Fm;
+    int *nmodels, *counts;
+    unsigned *ticket;
+    uint8_t *mask;
+    double *Fbest;
+    int *out_count, *out_iters;
+};
+struct FrBatch {
+    FrJob j[SVO_LK_MAX_JOBS];
+};
+
 __device__ __forceinline__ double det3(const double *m)
 {
     return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) +
@@ -115,13 +137,18 @@ __device__ bool collinear_last(const float *__restrict__ p, const int (&idx)[M])
     return bad;
 }
 
-__global__ __launch_bounds__(SOLVE_T) void fr_solve_kernel(const float *__restrict__ p1,
-                                                           const float *__restrict__ p2, int n_host,
-                                                           const int *__restrict__ d_n, uint64_t seed, int it0,
-                                                           int it1, const RansacState *__restrict__ st,
-                                                           double *__restrict__ Fout, int *__restrict__ nmodels)
+__global__ __launch_bounds__(SOLVE_T) void fr_solve_kernel(FrBatch batch, int it0, int it1_cap)
 {
     __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
+    const FrJob &job = batch.j[blockIdx.y];
+    const float *__restrict__ p1 = job.p1, *__restrict__ p2 = job.p2;
+    const int n_host = job.n_host;
+    const int *__restrict__ d_n = job.d_n;
+    const uint64_t seed = job.seed;
+    const int it1 = it1_cap < job.max_iters ? it1_cap : job.max_iters;
+    const RansacState *__restrict__ st = job.st;
+    double *__restrict__ Fout = job.Fm;
+    int *__restrict__ nmodels = job.nmodels;
     __shared__ double sA[63][SOLVE_T];
     __shared__ double sV[18][SOLVE_T];
     __shared__ int sPerm[9][SOLVE_T];
@@ -313,14 +340,23 @@ __device__ __forceinline__ float f_error(const double (&F)[9], float x1, float y
 
 // One wavefront per model.  The LAST workgroup to finish (ticket counter) also replays the
 // sequential RANSAC loop over the iterations scored so far -- what used to be a launch of its own.
-__global__ __launch_bounds__(256) void fr_score_kernel(const float2 *__restrict__ p1,
-                                                       const float2 *__restrict__ p2, int n_host,
-                                                       const int *__restrict__ d_n, int it0, int it1,
-                                                       RansacState *st, const double *__restrict__ Fm,
-                                                       const int *__restrict__ nmodels, float thr, int *counts,
-                                                       int max_iters, double confidence, unsigned *ticket)
+__global__ __launch_bounds__(256) void fr_score_kernel(FrBatch batch, int it0, int it1_cap)
 {
     __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
+    const FrJob &job = batch.j[blockIdx.y];
+    const float2 *__restrict__ p1 = reinterpret_cast<const float2 *>(job.p1);
+    const float2 *__restrict__ p2 = reinterpret_cast<const float2 *>(job.p2);
+    const int n_host = job.n_host;
+    const int *__restrict__ d_n = job.d_n;
+    const int max_iters = job.max_iters;
+    const int it1 = it1_cap < max_iters ? it1_cap : max_iters;
+    RansacState *st = job.st;
+    const double *__restrict__ Fm = job.Fm;
+    const int *__restrict__ nmodels = job.nmodels;
+    const float thr = job.thr;
+    int *counts = job.counts;
+    const double confidence = job.confidence;
+    unsigned *ticket = job.ticket;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     const int it = it0 + w / 3, k = w - (w / 3) * 3;
@@ -362,15 +398,20 @@ __global__ __launch_bounds__(256) void fr_score_kernel(const float2 *__restrict_
     }
 }
 
-__global__ __launch_bounds__(256) void fr_mask_kernel(const float2 *__restrict__ p1,
-                                                      const float2 *__restrict__ p2, int n_host,
-                                                      const int *__restrict__ d_n,
-                                                      const RansacState *__restrict__ st,
-                                                      const double *__restrict__ Fm, float thr,
-                                                      uint8_t *__restrict__ mask, double *__restrict__ Fbest,
-                                                      int *__restrict__ out_count, int *__restrict__ out_iters)
+__global__ __launch_bounds__(256) void fr_mask_kernel(FrBatch batch)
 {
     __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
+    const FrJob &job = batch.j[blockIdx.y];
+    const float2 *__restrict__ p1 = reinterpret_cast<const float2 *>(job.p1);
+    const float2 *__restrict__ p2 = reinterpret_cast<const float2 *>(job.p2);
+    const int n_host = job.n_host;
+    const int *__restrict__ d_n = job.d_n;
+    const RansacState *__restrict__ st = job.st;
+    const double *__restrict__ Fm = job.Fm;
+    const float thr = job.thr;
+    uint8_t *__restrict__ mask = job.mask;
+    double *__restrict__ Fbest = job.Fbest;
+    int *__restrict__ out_count = job.out_count, *__restrict__ out_iters = job.out_iters;
     const int n = d_n ? *d_n : n_host;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const RansacState s = *st;
@@ -400,45 +441,92 @@ __global__ __launch_bounds__(256) void fr_mask_kernel(const float2 *__restrict__
 
 }  // namespace
 
-// device-pointer form used by the C ABI and by the fused front-end.  `cap` sizes the grids
-// (the number of correspondences is *d_n when d_n != nullptr, else cap).
-int svo_launch_fransac(svo_ctx *ctx, const float *p1, const float *p2, int cap, const int *d_n,
-                       double threshold, double confidence, int max_iters, uint64_t seed, uint8_t *mask,
-                       double *d_F, int *d_count, int *d_iters)
+// device-pointer form used by the C ABI and by the fused front-end, several problems at once.
+// `cap` sizes the grids (the number of correspondences is *d_n when d_n != nullptr, else cap).
+int svo_launch_fransac_batch(svo_ctx *ctx, int n_jobs, const svo_fransac_job *jobs)
 {
-    if (cap <= 0)
+    if (n_jobs <= 0)
         return SVO_OK;
-    if (max_iters < 1)
-        max_iters = 1;
+    if (n_jobs > SVO_LK_MAX_JOBS) {
+        svo_set_error("fransac: at most %d jobs per launch", SVO_LK_MAX_JOBS);
+        return SVO_ERR_ARG;
+    }
+    int it_max = 1, cap_max = 0;
+    for (int k = 0; k < n_jobs; k++) {
+        const int mi = jobs[k].max_iters < 1 ? 1 : jobs[k].max_iters;
+        it_max = mi > it_max ? mi : it_max;
+        cap_max = jobs[k].cap > cap_max ? jobs[k].cap : cap_max;
+    }
+    const size_t f_stride = (size_t)it_max * 27, i_stride = ((size_t)it_max * 4 + 32 + 15) / 16 * 16;
     int rc;
-    const size_t f_bytes = (size_t)max_iters * 27 * sizeof(double);
-    const size_t i_bytes = (size_t)max_iters * 4 * sizeof(int) + 64;
-    if ((rc = ctx->w_a.ensure(f_bytes)) || (rc = ctx->w_b.ensure(i_bytes)))
+    if ((rc = ctx->w_a.ensure(f_stride * sizeof(double) * n_jobs)) || (rc = ctx->w_b.ensure(i_stride * sizeof(int) * n_jobs)))
         return rc;
-    double *Fm = ctx->w_a.as<double>();
-    RansacState *st = reinterpret_cast<RansacState *>(ctx->w_b.p);
-    int *nmodels = ctx->w_b.as<int>() + 16;
-    int *counts = nmodels + max_iters;
-    unsigned *ticket = ctx->d_tickets;  // slot 0: fr_score
-    const float thr = (float)(threshold * threshold);
+    FrBatch batch;
+    int nb = 0;
+    for (int k = 0; k < n_jobs; k++) {
+        const svo_fransac_job &h = jobs[k];
+        if (h.cap <= 0)
+            continue;
+        FrJob &j = batch.j[nb];
+        const int mi = h.max_iters < 1 ? 1 : h.max_iters;
+        int *ib = ctx->w_b.as<int>() + i_stride * nb;
+        j.p1 = h.p1;
+        j.p2 = h.p2;
+        j.n_host = h.cap;
+        j.d_n = h.d_n;
+        j.seed = h.seed;
+        j.max_iters = mi;
+        j.confidence = h.confidence;
+        j.thr = (float)(h.threshold * h.threshold);
+        j.st = reinterpret_cast<RansacState *>(ib);
+        j.nmodels = ib + 16;
+        j.counts = j.nmodels + mi;
+        j.Fm = ctx->w_a.as<double>() + f_stride * nb;
+        j.ticket = ctx->d_tickets + nb;  // slots 0..3: fr_score of job 0..3
+        j.mask = h.mask;
+        j.Fbest = h.d_F;
+        j.out_count = h.d_count;
+        j.out_iters = h.d_iters;
+        nb++;
+    }
+    if (nb == 0)
+        return SVO_OK;
+    for (int k = nb; k < SVO_LK_MAX_JOBS; k++)
+        batch.j[k] = batch.j[0];
     ScopedKernelTime tm(ctx, SVO_K_FRANSAC);
-    const int bounds[3] = {0, max_iters < PHASE_A ? max_iters : PHASE_A, max_iters};
+    const int bounds[3] = {0, it_max < PHASE_A ? it_max : PHASE_A, it_max};
     for (int ph = 0; ph < 2; ph++) {
         const int it0 = bounds[ph], it1 = bounds[ph + 1];
         if (it1 <= it0)
             continue;
         const int iters = it1 - it0;
-        hipLaunchKernelGGL(fr_solve_kernel, dim3((iters + SOLVE_T - 1) / SOLVE_T), dim3(SOLVE_T), 0, ctx->stream,
-                           p1, p2, cap, d_n, seed, it0, it1, st, Fm, nmodels);
-        hipLaunchKernelGGL(fr_score_kernel, dim3((iters * 3 + 3) / 4), dim3(256), 0, ctx->stream,
-                           reinterpret_cast<const float2 *>(p1), reinterpret_cast<const float2 *>(p2), cap, d_n, it0,
-                           it1, st, Fm, nmodels, thr, counts, max_iters, confidence, ticket);
+        hipLaunchKernelGGL(fr_solve_kernel, dim3((iters + SOLVE_T - 1) / SOLVE_T, nb), dim3(SOLVE_T), 0, ctx->stream,
+                           batch, it0, it1);
+        hipLaunchKernelGGL(fr_score_kernel, dim3((iters * 3 + 3) / 4, nb), dim3(256), 0, ctx->stream, batch, it0, it1);
     }
-    hipLaunchKernelGGL(fr_mask_kernel, dim3((cap + 255) / 256), dim3(256), 0, ctx->stream,
-                       reinterpret_cast<const float2 *>(p1), reinterpret_cast<const float2 *>(p2), cap, d_n, st, Fm,
-                       thr, mask, d_F, d_count, d_iters);
+    hipLaunchKernelGGL(fr_mask_kernel, dim3((cap_max + 255) / 256, nb), dim3(256), 0, ctx->stream, batch);
     SVO_HIP(hipGetLastError());
     return SVO_OK;
+}
+
+int svo_launch_fransac(svo_ctx *ctx, const float *p1, const float *p2, int cap, const int *d_n,
+                       double threshold, double confidence, int max_iters, uint64_t seed, uint8_t *mask,
+                       double *d_F, int *d_count, int *d_iters)
+{
+    svo_fransac_job j;
+    j.p1 = p1;
+    j.p2 = p2;
+    j.cap = cap;
+    j.d_n = d_n;
+    j.threshold = threshold;
+    j.confidence = confidence;
+    j.max_iters = max_iters;
+    j.seed = seed;
+    j.mask = mask;
+    j.d_F = d_F;
+    j.d_count = d_count;
+    j.d_iters = d_iters;
+    return svo_launch_fransac_batch(ctx, 1, &j);
 }
 
 extern "C" int svo_fransac(svo_ctx *ctx, const float *p1, const float *p2, int n, double threshold,

@@ -745,8 +745,9 @@ static int run_chunk_group(svo_chunk_job **jobs, int k)
             break;
         if ((rc = svo_launch_lk_batch(ctx, nl, lk)))
             return rc;
-        // ---- filters of every chunk, then ONE set of PnP launches for all of them ----
+        // ---- filters and PnP: every stage is ONE set of launches for all the chunks ----
         svo_pnp_job pj[SVO_LK_MAX_JOBS];
+        svo_fransac_job fj[SVO_LK_MAX_JOBS];
         GS *pg[SVO_LK_MAX_JOBS];
         int np = 0;
         for (GS &g : gs) {
@@ -756,15 +757,34 @@ static int run_chunk_group(svo_chunk_job **jobs, int k)
             g.cnt_trk = v->d_cnt + ((f & 1) ? 9 : 1);
             g.d_rec = v->d_rec + (f & 1);
             if ((rc = svo_launch_compact(ctx, v->status, g.n, nullptr, v->ref2d, 2, v->b2, v->a2, 2, v->c2, v->ref3d, 3,
-                                         v->a3, v->d_cnt)) ||
-                (rc = svo_launch_fransac(ctx, v->b2, v->c2, g.n, v->d_cnt, v->prm.f_thr_temporal, 0.99, 1000,
-                                         stage_seed(v, 0), v->mask, nullptr, nullptr, nullptr)) ||
-                (rc = svo_launch_compact(ctx, v->mask, g.n, v->d_cnt, v->c2, 2, v->trk2d, v->a3, 3, v->trk3d, nullptr,
+                                         v->a3, v->d_cnt)))
+                return rc;
+            svo_fransac_job &q = fj[np];
+            q.p1 = v->b2;
+            q.p2 = v->c2;
+            q.cap = g.n;
+            q.d_n = v->d_cnt;
+            q.threshold = v->prm.f_thr_temporal;
+            q.confidence = 0.99;
+            q.max_iters = 1000;
+            q.seed = stage_seed(v, 0);
+            q.mask = v->mask;
+            q.d_F = nullptr;
+            q.d_count = nullptr;
+            q.d_iters = nullptr;
+            pg[np++] = &g;
+        }
+        if ((rc = svo_launch_fransac_batch(ctx, np, fj)))
+            return rc;
+        for (int a = 0; a < np; a++) {
+            GS &g = *pg[a];
+            svo_vo *v = g.v;
+            if ((rc = svo_launch_compact(ctx, v->mask, g.n, v->d_cnt, v->c2, 2, v->trk2d, v->a3, 3, v->trk3d, nullptr,
                                          0, nullptr, g.cnt_trk)))
                 return rc;
             g.early_tag = ++v->tag;
             g.pose_tag[f & 1] = ++v->tag;
-            svo_pnp_job &q = pj[np];
+            svo_pnp_job &q = pj[a];
             q.obj = v->trk3d;
             q.img = v->trk2d;
             q.cap = g.n;
@@ -783,7 +803,6 @@ static int run_chunk_group(svo_chunk_job **jobs, int k)
             q.d_result = g.d_rec;
             q.early_mbox = v->mbox->early;
             q.early_tag = g.early_tag;
-            pg[np++] = &g;
         }
         if ((rc = svo_launch_pnp_ransac_batch(ctx, np, pj)))
             return rc;

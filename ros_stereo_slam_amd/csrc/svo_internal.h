@@ -128,6 +128,18 @@ int svo_launch_lk(svo_ctx *ctx, const PyrDev &prev, const PyrDev &next, const fl
 int svo_launch_grid(svo_ctx *ctx, int rows, int cols, int step, float *out_xy, int cap);
 
 // fransac.hip
+struct svo_fransac_job {  // host-side description of one F-matrix RANSAC problem (device pointers)
+    const float *p1, *p2;
+    int cap;
+    const int *d_n;
+    double threshold, confidence;
+    int max_iters;
+    uint64_t seed;
+    uint8_t *mask;
+    double *d_F;
+    int *d_count, *d_iters;
+};
+int svo_launch_fransac_batch(svo_ctx *ctx, int n_jobs, const svo_fransac_job *jobs);
 int svo_launch_fransac(svo_ctx *ctx, const float *p1, const float *p2, int cap, const int *d_n,
                        double threshold, double confidence, int max_iters, uint64_t seed, uint8_t *mask,
                        double *d_F, int *d_count, int *d_iters);
