@@ -79,12 +79,12 @@ def main():
     ap.add_argument("--pipeline", choices=("auto", "on", "off"), default="auto",
                     help="two-stream overlap of PnP(t) with pyramid + LK(t+1) inside a chunk; auto = on for one "
                          "chunk per GPU, off when several chunks already fill the hardware queues")
-    ap.add_argument("--chunks-per-gpu", type=int, default=int(os.environ.get("SVO_CHUNKS_PER_GPU", "8")),
+    ap.add_argument("--chunks-per-gpu", type=int, default=int(os.environ.get("SVO_CHUNKS_PER_GPU", "16")),
                     help="independent chunks of the stream run side by side on each GPU (svo_vo_run_chunks); "
-                         "with --chunks-per-context 2 that is 4 contexts = 4 busy hardware queues")
-    ap.add_argument("--chunks-per-context", type=int, default=int(os.environ.get("SVO_CHUNKS_PER_CONTEXT", "2")),
-                    help="chunks that share one context (= one stream): advanced in lock step with ONE pyramidal-LK "
-                         "launch per frame for all of them (1..4)")
+                         "with --chunks-per-context 4 that is 4 contexts = 4 busy hardware queues")
+    ap.add_argument("--chunks-per-context", type=int, default=int(os.environ.get("SVO_CHUNKS_PER_CONTEXT", "4")),
+                    help="chunks that share one context (= one stream): advanced in lock step, every stage of the "
+                         "tracking path ONE set of launches for all of them (1..4)")
     ap.add_argument("--kpts", type=int, default=4096, choices=(4096, 8192),
                     help="keypoints per frame: 4096 = BASELINE's metric (grid step 10), 8192 = configs[4] shape "
                          "(grid step 7 -> 9152 lattice points -> ANMS 8192, keyframe rule 4000)")

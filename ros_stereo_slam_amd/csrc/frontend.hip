@@ -102,9 +102,20 @@ __global__ void store_count_kernel(const int *__restrict__ src, int *__restrict_
 
 // One wave: completes the pose record with the tracked-point count and publishes it into the
 // pinned mailbox slot, then releases the slot's tag at system scope.
-__global__ void publish_record_kernel(PnpRecord *__restrict__ d_rec, const int *__restrict__ cnt, PnpRecord *h_rec,
-                                      int *h_tag, int tag)
+struct PublishBatch {  // one workgroup (one wave) per job
+    PnpRecord *d_rec[SVO_LK_MAX_JOBS];
+    const int *cnt[SVO_LK_MAX_JOBS];
+    PnpRecord *h_rec[SVO_LK_MAX_JOBS];
+    int *h_tag[SVO_LK_MAX_JOBS];
+    int tag[SVO_LK_MAX_JOBS];
+};
+__global__ void publish_record_kernel(PublishBatch b)
 {
+    PnpRecord *__restrict__ d_rec = b.d_rec[blockIdx.x];
+    const int *__restrict__ cnt = b.cnt[blockIdx.x];
+    PnpRecord *h_rec = b.h_rec[blockIdx.x];
+    int *h_tag = b.h_tag[blockIdx.x];
+    const int tag = b.tag[blockIdx.x];
     __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     constexpr int WORDS = sizeof(PnpRecord) / 4, TRACKED = offsetof(PnpRecord, n_tracked) / 4;
     const int l = threadIdx.x;
@@ -546,8 +557,13 @@ int svo_vo_run_chunk(svo_vo *v, const uint8_t *const *lefts, const uint8_t *cons
             ctx->stream = sA;
             if (r)
                 return r;
-            hipLaunchKernelGGL(publish_record_kernel, dim3(1), dim3(64), 0, sP, d_rec, cnt_trk, &mb->rec[f & 1],
-                               &mb->pose_tag[f & 1], pose_tag[f & 1]);
+            PublishBatch pb = {};
+            pb.d_rec[0] = d_rec;
+            pb.cnt[0] = cnt_trk;
+            pb.h_rec[0] = &mb->rec[f & 1];
+            pb.h_tag[0] = &mb->pose_tag[f & 1];
+            pb.tag[0] = pose_tag[f & 1];
+            hipLaunchKernelGGL(publish_record_kernel, dim3(1), dim3(64), 0, sP, pb);
             return SVO_OK;
         };
         if ((rc = launch_pnp(1.0, 0.99, 1)))
@@ -699,8 +715,13 @@ static int run_chunk_group(svo_chunk_job **jobs, int k)
                                       v->idx, nullptr, g.d_rec, v->mbox->early, g.early_tag);
         if (r)
             return r;
-        hipLaunchKernelGGL(publish_record_kernel, dim3(1), dim3(64), 0, st, g.d_rec, g.cnt_trk, &v->mbox->rec[f & 1],
-                           &v->mbox->pose_tag[f & 1], g.pose_tag[f & 1]);
+        PublishBatch pb = {};
+        pb.d_rec[0] = g.d_rec;
+        pb.cnt[0] = g.cnt_trk;
+        pb.h_rec[0] = &v->mbox->rec[f & 1];
+        pb.h_tag[0] = &v->mbox->pose_tag[f & 1];
+        pb.tag[0] = g.pose_tag[f & 1];
+        hipLaunchKernelGGL(publish_record_kernel, dim3(1), dim3(64), 0, st, pb);
         return SVO_OK;
     };
     auto stop = [&](GS &g, int rc) {  // this chunk ends here (tracking lost or an error); the others go on
@@ -711,6 +732,8 @@ static int run_chunk_group(svo_chunk_job **jobs, int k)
     for (int f = 0; f < n_frames_max; f++) {
         // ---- pyramids + ONE tracking launch for all the chunks still running ----
         LkJob lk[SVO_LK_MAX_JOBS];
+        svo_pyramid *pyrs[SVO_LK_MAX_JOBS];
+        const uint8_t *imgs[SVO_LK_MAX_JOBS];
         int nl = 0;
         for (GS &g : gs) {
             if (!g.active || f >= g.j->n_frames) {
@@ -728,8 +751,8 @@ static int run_chunk_group(svo_chunk_job **jobs, int k)
                 stop(g, SVO_ERR_TRACKING_LOST);
                 continue;
             }
-            if ((rc = svo_build_pyramid_from_device(ctx, v->pyr_cur, g.j->lefts[f])))
-                return rc;
+            pyrs[nl] = v->pyr_cur;
+            imgs[nl] = g.j->lefts[f];
             LkJob &q = lk[nl++];
             q.prev = v->pyr_ref->dev;
             q.next = v->pyr_cur->dev;
@@ -743,11 +766,12 @@ static int run_chunk_group(svo_chunk_job **jobs, int k)
         }
         if (nl == 0)
             break;
-        if ((rc = svo_launch_lk_batch(ctx, nl, lk)))
+        if ((rc = svo_build_pyramids_from_device(ctx, nl, pyrs, imgs)) || (rc = svo_launch_lk_batch(ctx, nl, lk)))
             return rc;
         // ---- filters and PnP: every stage is ONE set of launches for all the chunks ----
         svo_pnp_job pj[SVO_LK_MAX_JOBS];
         svo_fransac_job fj[SVO_LK_MAX_JOBS];
+        svo_compact_job c1[SVO_LK_MAX_JOBS], c2[SVO_LK_MAX_JOBS];
         GS *pg[SVO_LK_MAX_JOBS];
         int np = 0;
         for (GS &g : gs) {
@@ -756,9 +780,9 @@ static int run_chunk_group(svo_chunk_job **jobs, int k)
             svo_vo *v = g.v;
             g.cnt_trk = v->d_cnt + ((f & 1) ? 9 : 1);
             g.d_rec = v->d_rec + (f & 1);
-            if ((rc = svo_launch_compact(ctx, v->status, g.n, nullptr, v->ref2d, 2, v->b2, v->a2, 2, v->c2, v->ref3d, 3,
-                                         v->a3, v->d_cnt)))
-                return rc;
+            // status filter (src/tracking.cpp:54-64) and, after the F-RANSAC, its mask filter (:77-88)
+            c1[np] = {v->status, g.n, nullptr, {v->ref2d, v->a2, v->ref3d}, {v->b2, v->c2, v->a3}, {2, 2, 3}, v->d_cnt};
+            c2[np] = {v->mask, g.n, v->d_cnt, {v->c2, v->a3, nullptr}, {v->trk2d, v->trk3d, nullptr}, {2, 3, 0}, g.cnt_trk};
             svo_fransac_job &q = fj[np];
             q.p1 = v->b2;
             q.p2 = v->c2;
@@ -774,14 +798,12 @@ static int run_chunk_group(svo_chunk_job **jobs, int k)
             q.d_iters = nullptr;
             pg[np++] = &g;
         }
-        if ((rc = svo_launch_fransac_batch(ctx, np, fj)))
+        if ((rc = svo_launch_compact_batch(ctx, np, c1)) || (rc = svo_launch_fransac_batch(ctx, np, fj)) ||
+            (rc = svo_launch_compact_batch(ctx, np, c2)))
             return rc;
         for (int a = 0; a < np; a++) {
             GS &g = *pg[a];
             svo_vo *v = g.v;
-            if ((rc = svo_launch_compact(ctx, v->mask, g.n, v->d_cnt, v->c2, 2, v->trk2d, v->a3, 3, v->trk3d, nullptr,
-                                         0, nullptr, g.cnt_trk)))
-                return rc;
             g.early_tag = ++v->tag;
             g.pose_tag[f & 1] = ++v->tag;
             svo_pnp_job &q = pj[a];
@@ -806,10 +828,17 @@ static int run_chunk_group(svo_chunk_job **jobs, int k)
         }
         if ((rc = svo_launch_pnp_ransac_batch(ctx, np, pj)))
             return rc;
-        for (int a = 0; a < np; a++) {
-            GS &g = *pg[a];
-            hipLaunchKernelGGL(publish_record_kernel, dim3(1), dim3(64), 0, st, g.d_rec, g.cnt_trk, &g.v->mbox->rec[f & 1],
-                               &g.v->mbox->pose_tag[f & 1], g.pose_tag[f & 1]);
+        {
+            PublishBatch pb = {};
+            for (int a = 0; a < np; a++) {
+                GS &g = *pg[a];
+                pb.d_rec[a] = g.d_rec;
+                pb.cnt[a] = g.cnt_trk;
+                pb.h_rec[a] = &g.v->mbox->rec[f & 1];
+                pb.h_tag[a] = &g.v->mbox->pose_tag[f & 1];
+                pb.tag[a] = g.pose_tag[f & 1];
+            }
+            hipLaunchKernelGGL(publish_record_kernel, dim3(np), dim3(64), 0, st, pb);
         }
         // ---- policy of every chunk, in the order their counts arrive ----
         for (GS &g : gs) {

@@ -157,13 +157,23 @@ struct CompactArgs {
     const float *in[3];
     float *out[3];
     int stride[3];
+    const uint8_t *mask;
+    int n_host;
+    const int *d_n;
+    int *d_count;
+};
+struct CompactBatch {  // one workgroup per job
+    CompactArgs j[SVO_LK_MAX_JOBS];
 };
 
-__global__ __launch_bounds__(1024) void compact_kernel(const uint8_t *__restrict__ mask, int n_host,
-                                                       const int *__restrict__ d_n, CompactArgs args,
-                                                       int *__restrict__ d_count)
+__global__ __launch_bounds__(1024) void compact_kernel(CompactBatch batch)
 {
     __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
+    const CompactArgs &args = batch.j[blockIdx.x];
+    const uint8_t *__restrict__ mask = args.mask;
+    const int n_host = args.n_host;
+    const int *__restrict__ d_n = args.d_n;
+    int *__restrict__ d_count = args.d_count;
     // One workgroup of 16 waves walks the array in 1024-element strips.  Inside a wave the
     // position of a kept element is a popcount of the ballot below its lane; wave totals are
     // combined through 16 LDS words; the running base carries from strip to strip.
@@ -256,23 +266,52 @@ int svo_launch_colors(svo_ctx *ctx, const svo_pyramid *pyr, const float *xy, int
     return SVO_OK;
 }
 
+int svo_launch_compact_batch(svo_ctx *ctx, int n_jobs, const svo_compact_job *jobs)
+{
+    if (n_jobs <= 0)
+        return SVO_OK;
+    if (n_jobs > SVO_LK_MAX_JOBS) {
+        svo_set_error("compact: at most %d jobs per launch", SVO_LK_MAX_JOBS);
+        return SVO_ERR_ARG;
+    }
+    CompactBatch batch;
+    for (int k = 0; k < SVO_LK_MAX_JOBS; k++) {
+        const svo_compact_job &h = jobs[k < n_jobs ? k : 0];
+        CompactArgs &a = batch.j[k];
+        for (int q = 0; q < 3; q++) {
+            a.in[q] = h.in[q];
+            a.out[q] = h.out[q];
+            a.stride[q] = h.stride[q];
+        }
+        a.mask = h.mask;
+        a.n_host = h.cap;
+        a.d_n = h.d_n;
+        a.d_count = h.d_count;
+    }
+    hipLaunchKernelGGL(compact_kernel, dim3(n_jobs), dim3(1024), 0, ctx->stream, batch);
+    SVO_HIP(hipGetLastError());
+    return SVO_OK;
+}
+
 int svo_launch_compact(svo_ctx *ctx, const uint8_t *mask, int cap, const int *d_n, const float *in_a, int stride_a,
                        float *out_a, const float *in_b, int stride_b, float *out_b, const float *in_c, int stride_c,
                        float *out_c, int *d_count)
 {
-    CompactArgs args;
-    args.in[0] = in_a;
-    args.out[0] = out_a;
-    args.stride[0] = stride_a;
-    args.in[1] = in_b;
-    args.out[1] = out_b;
-    args.stride[1] = stride_b;
-    args.in[2] = in_c;
-    args.out[2] = out_c;
-    args.stride[2] = stride_c;
-    hipLaunchKernelGGL(compact_kernel, dim3(1), dim3(1024), 0, ctx->stream, mask, cap, d_n, args, d_count);
-    SVO_HIP(hipGetLastError());
-    return SVO_OK;
+    svo_compact_job j;
+    j.mask = mask;
+    j.cap = cap;
+    j.d_n = d_n;
+    j.in[0] = in_a;
+    j.out[0] = out_a;
+    j.stride[0] = stride_a;
+    j.in[1] = in_b;
+    j.out[1] = out_b;
+    j.stride[1] = stride_b;
+    j.in[2] = in_c;
+    j.out[2] = out_c;
+    j.stride[2] = stride_c;
+    j.d_count = d_count;
+    return svo_launch_compact_batch(ctx, 1, &j);
 }
 
 extern "C" {

@@ -26,12 +26,19 @@ __device__ __forceinline__ int reflect101(int p, int len)
 constexpr int TW = 32, TH = 8;
 constexpr int SW = 2 * TW + 3, SH = 2 * TH + 3;
 
+// several pyramids of the same geometry per launch: blockIdx.z picks the job
+struct PyrPtrs {
+    const uint8_t *src[SVO_LK_MAX_JOBS];
+    uint8_t *dst[SVO_LK_MAX_JOBS];
+};
+
 template <int C>
-__global__ __launch_bounds__(256) void pyr_down_kernel(const uint8_t *__restrict__ src, int spitch,
-                                                       int w, int h, uint8_t *__restrict__ dst,
-                                                       int dpitch, int dw, int dh)
+__global__ __launch_bounds__(256) void pyr_down_kernel(PyrPtrs ptrs, int spitch, int w, int h, int dpitch, int dw,
+                                                       int dh)
 {
     __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
+    const uint8_t *__restrict__ src = ptrs.src[blockIdx.z];
+    uint8_t *__restrict__ dst = ptrs.dst[blockIdx.z];
     constexpr int SROW = ((SW * C + 3) / 4) * 4;
     __shared__ uint8_t s_src[SH * SROW];
     __shared__ uint16_t s_h[SH][TW * C];
@@ -67,10 +74,11 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const uint8_t *__restrict
 
 // image (row stride w*C) -> padded level 0, one thread per output dword
 template <int C>
-__global__ __launch_bounds__(256) void pad_copy_kernel(const uint8_t *__restrict__ src, int w, int h,
-                                                       uint8_t *__restrict__ padded, int pitch)
+__global__ __launch_bounds__(256) void pad_copy_kernel(PyrPtrs ptrs, int w, int h, int pitch)
 {
     __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
+    const uint8_t *__restrict__ src = ptrs.src[blockIdx.z];
+    uint8_t *__restrict__ padded = ptrs.dst[blockIdx.z];
     const int dwords_per_row = pitch >> 2;
     const int row = blockIdx.y;  // 0 .. h + 2*PAD - 1
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
@@ -92,8 +100,9 @@ __global__ __launch_bounds__(256) void pad_copy_kernel(const uint8_t *__restrict
 }
 
 struct BorderJob {
-    uint8_t *padded[SVO_MAX_LEVELS];
+    uint8_t *padded[SVO_LK_MAX_JOBS][SVO_MAX_LEVELS];
     int pitch[SVO_MAX_LEVELS], w[SVO_MAX_LEVELS], h[SVO_MAX_LEVELS];
+    int levels_m1;  // blockIdx.z = job * levels_m1 + (level - 1)
 };
 
 // fills the reflect-101 border of levels 1.. (blockIdx.z = level - 1) from their interior
@@ -101,7 +110,7 @@ template <int C>
 __global__ __launch_bounds__(256) void fill_border_kernel(BorderJob job)
 {
     __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
-    const int l = blockIdx.z + 1;
+    const int jb = blockIdx.z / job.levels_m1, l = blockIdx.z - jb * job.levels_m1 + 1;
     const int w = job.w[l], h = job.h[l], pitch = job.pitch[l];
     const int row = blockIdx.y;
     if (row >= h + 2 * SVO_PYR_PAD)
@@ -113,9 +122,9 @@ __global__ __launch_bounds__(256) void fill_border_kernel(BorderJob job)
     const int cb0 = d * 4;
     if (interior_row && cb0 >= SVO_PYR_PAD * C && cb0 + 3 < (SVO_PYR_PAD + w) * C)
         return;  // dword entirely inside the image: already written by pyr_down
-    uint8_t *prow = job.padded[l] + (size_t)row * pitch;
+    uint8_t *prow = job.padded[jb][l] + (size_t)row * pitch;
     const int Y = reflect101(row - SVO_PYR_PAD, h);
-    const uint8_t *srow = job.padded[l] + (size_t)(Y + SVO_PYR_PAD) * pitch + SVO_PYR_PAD * C;
+    const uint8_t *srow = job.padded[jb][l] + (size_t)(Y + SVO_PYR_PAD) * pitch + SVO_PYR_PAD * C;
 #pragma unroll
     for (int b = 0; b < 4; b++) {
         int cb = cb0 + b;
@@ -132,47 +141,78 @@ __global__ __launch_bounds__(256) void fill_border_kernel(BorderJob job)
 
 }  // namespace
 
-template <int C> static int build_levels(svo_ctx *ctx, svo_pyramid *pyr, const uint8_t *d_image)
+template <int C> static int build_levels(svo_ctx *ctx, int k, svo_pyramid *const *pyrs, const uint8_t *const *d_images)
 {
-    const PyrDev &d = pyr->dev;
+    const svo_pyramid *p0 = pyrs[0];
+    const PyrDev &d = p0->dev;
     {
-        dim3 grid(((d.pitch[0] >> 2) + 255) / 256, d.h[0] + 2 * SVO_PYR_PAD);
-        hipLaunchKernelGGL(pad_copy_kernel<C>, grid, dim3(256), 0, ctx->stream, d_image, d.w[0], d.h[0],
-                           pyr->base + pyr->off[0], d.pitch[0]);
+        PyrPtrs pp;
+        for (int a = 0; a < SVO_LK_MAX_JOBS; a++) {
+            pp.src[a] = d_images[a < k ? a : 0];
+            pp.dst[a] = pyrs[a < k ? a : 0]->base + pyrs[a < k ? a : 0]->off[0];
+        }
+        dim3 grid(((d.pitch[0] >> 2) + 255) / 256, d.h[0] + 2 * SVO_PYR_PAD, k);
+        hipLaunchKernelGGL(pad_copy_kernel<C>, grid, dim3(256), 0, ctx->stream, pp, d.w[0], d.h[0], d.pitch[0]);
     }
-    for (int l = 1; l < pyr->levels; l++) {
-        dim3 grid((d.w[l] + TW - 1) / TW, (d.h[l] + TH - 1) / TH);
-        hipLaunchKernelGGL(pyr_down_kernel<C>, grid, dim3(256), 0, ctx->stream, pyr->origin(l - 1),
-                           d.pitch[l - 1], d.w[l - 1], d.h[l - 1], pyr->origin(l), d.pitch[l], d.w[l], d.h[l]);
+    for (int l = 1; l < p0->levels; l++) {
+        PyrPtrs pp;
+        for (int a = 0; a < SVO_LK_MAX_JOBS; a++) {
+            pp.src[a] = pyrs[a < k ? a : 0]->origin(l - 1);
+            pp.dst[a] = pyrs[a < k ? a : 0]->origin(l);
+        }
+        dim3 grid((d.w[l] + TW - 1) / TW, (d.h[l] + TH - 1) / TH, k);
+        hipLaunchKernelGGL(pyr_down_kernel<C>, grid, dim3(256), 0, ctx->stream, pp, d.pitch[l - 1], d.w[l - 1],
+                           d.h[l - 1], d.pitch[l], d.w[l], d.h[l]);
     }
-    if (pyr->levels > 1) {
+    if (p0->levels > 1) {
         BorderJob job;
+        for (int a = 0; a < SVO_LK_MAX_JOBS; a++)
+            for (int l = 0; l < SVO_MAX_LEVELS; l++)
+                job.padded[a][l] = l < p0->levels ? pyrs[a < k ? a : 0]->base + pyrs[a < k ? a : 0]->off[l] : nullptr;
         for (int l = 0; l < SVO_MAX_LEVELS; l++) {
-            job.padded[l] = l < pyr->levels ? pyr->base + pyr->off[l] : nullptr;
             job.pitch[l] = d.pitch[l];
             job.w[l] = d.w[l];
             job.h[l] = d.h[l];
         }
-        dim3 grid(((d.pitch[1] >> 2) + 255) / 256, d.h[1] + 2 * SVO_PYR_PAD, pyr->levels - 1);
+        job.levels_m1 = p0->levels - 1;
+        dim3 grid(((d.pitch[1] >> 2) + 255) / 256, d.h[1] + 2 * SVO_PYR_PAD, (p0->levels - 1) * k);
         hipLaunchKernelGGL(fill_border_kernel<C>, grid, dim3(256), 0, ctx->stream, job);
     }
     SVO_HIP(hipGetLastError());
     return SVO_OK;
 }
 
+// k pyramids of the same geometry from k device images, one set of launches
+int svo_build_pyramids_from_device(svo_ctx *ctx, int k, svo_pyramid *const *pyrs, const uint8_t *const *d_images)
+{
+    if (k <= 0)
+        return SVO_OK;
+    if (k > SVO_LK_MAX_JOBS) {
+        svo_set_error("pyramid: at most %d per launch", SVO_LK_MAX_JOBS);
+        return SVO_ERR_ARG;
+    }
+    for (int a = 1; a < k; a++)
+        if (pyrs[a]->w != pyrs[0]->w || pyrs[a]->h != pyrs[0]->h || pyrs[a]->c != pyrs[0]->c ||
+            pyrs[a]->levels != pyrs[0]->levels) {
+            svo_set_error("pyramid: the pyramids of one launch must share their geometry");
+            return SVO_ERR_ARG;
+        }
+    ScopedKernelTime t(ctx, SVO_K_PYRAMID);
+    switch (pyrs[0]->c) {
+    case 1:
+        return build_levels<1>(ctx, k, pyrs, d_images);
+    case 3:
+        return build_levels<3>(ctx, k, pyrs, d_images);
+    case 4:
+        return build_levels<4>(ctx, k, pyrs, d_images);
+    }
+    svo_set_error("pyramid: unsupported channel count %d (1, 3 or 4)", pyrs[0]->c);
+    return SVO_ERR_ARG;
+}
+
 int svo_build_pyramid_from_device(svo_ctx *ctx, svo_pyramid *pyr, const uint8_t *d_image)
 {
-    ScopedKernelTime t(ctx, SVO_K_PYRAMID);
-    switch (pyr->c) {
-    case 1:
-        return build_levels<1>(ctx, pyr, d_image);
-    case 3:
-        return build_levels<3>(ctx, pyr, d_image);
-    case 4:
-        return build_levels<4>(ctx, pyr, d_image);
-    }
-    svo_set_error("pyramid: unsupported channel count %d (1, 3 or 4)", pyr->c);
-    return SVO_ERR_ARG;
+    return svo_build_pyramids_from_device(ctx, 1, &pyr, &d_image);
 }
 
 extern "C" {

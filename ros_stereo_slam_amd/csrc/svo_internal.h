@@ -17,6 +17,8 @@
 // side and a 16-byte-aligned row pitch, so the LK kernel stages tiles with aligned 16-byte
 // loads and no border arithmetic (the furthest it reaches outside the image is 26 px).
 #define SVO_PYR_PAD 32
+// independent jobs one batched launch may carry (chunks of a context that run in lock step)
+#define SVO_LK_MAX_JOBS 4
 
 void svo_set_error(const char *fmt, ...);
 
@@ -107,8 +109,8 @@ int svo_resolve_timers(svo_ctx *ctx);
 
 // pyramid.hip
 int svo_build_pyramid_from_device(svo_ctx *ctx, svo_pyramid *pyr, const uint8_t *d_image);
+int svo_build_pyramids_from_device(svo_ctx *ctx, int k, svo_pyramid *const *pyrs, const uint8_t *const *d_images);
 // lk.hip
-#define SVO_LK_MAX_JOBS 4
 struct LkJob {  // one pyramidal-LK pass: prev/next pyramids, points in, points / status / err / minEig out
     PyrDev prev, next;
     const float *prev_pts;
@@ -149,6 +151,16 @@ int svo_launch_triangulate(svo_ctx *ctx, const double *P1, const double *P2, con
                            float *out_world);
 int svo_launch_transform(svo_ctx *ctx, const double *Rt, const float *in, int cap, const int *d_n, float *out);
 int svo_launch_colors(svo_ctx *ctx, const svo_pyramid *pyr, const float *xy, int cap, const int *d_n, float *out);
+struct svo_compact_job {  // order-preserving compaction of up to three float arrays by one byte mask
+    const uint8_t *mask;
+    int cap;
+    const int *d_n;
+    const float *in[3];
+    float *out[3];
+    int stride[3];
+    int *d_count;
+};
+int svo_launch_compact_batch(svo_ctx *ctx, int n_jobs, const svo_compact_job *jobs);
 int svo_launch_compact(svo_ctx *ctx, const uint8_t *mask, int cap, const int *d_n, const float *in_a, int stride_a,
                        float *out_a, const float *in_b, int stride_b, float *out_b, const float *in_c, int stride_c,
                        float *out_c, int *d_count);
