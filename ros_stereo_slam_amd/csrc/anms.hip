@@ -30,12 +30,30 @@ __device__ __forceinline__ int wave_sum_int(int v)
 // keypoints (coalesced reads of a 17-50 KB array that stays in L2) and the per-lane partials
 // are combined with DPP / shuffles.  N waves instead of N/64 keep all 256 CUs busy.
 
+// One ANMS problem; a launch may carry several of the same size n (blockIdx.y picks the job).
+struct AnmsJob {
+    const float2 *xy;
+    const float *resp;
+    int *order;
+    float4 *sorted;
+    double *radius, *decision;
+    uint8_t *flags;
+    int *out_idx, *d_count;
+};
+struct AnmsBatch {
+    AnmsJob j[SVO_LK_MAX_JOBS];
+};
+
 // order[rank] = i, rank = #keypoints sorting before i (response descending, index ascending);
 // also emits the sorted (x, y, response) triples the radius pass streams through.
-__global__ __launch_bounds__(256) void anms_rank_kernel(const float2 *__restrict__ xy, const float *__restrict__ resp,
-                                                        int n, int *__restrict__ order, float4 *__restrict__ sorted)
+__global__ __launch_bounds__(256) void anms_rank_kernel(AnmsBatch batch, int n)
 {
     __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
+    const AnmsJob &job = batch.j[blockIdx.y];
+    const float2 *__restrict__ xy = job.xy;
+    const float *__restrict__ resp = job.resp;
+    int *__restrict__ order = job.order;
+    float4 *__restrict__ sorted = job.sorted;
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n)
@@ -55,10 +73,11 @@ __global__ __launch_bounds__(256) void anms_rank_kernel(const float2 *__restrict
 }
 
 // squared suppression radius of the s-th sorted keypoint (DBL_MAX when nothing dominates it)
-__global__ __launch_bounds__(256) void anms_radius_kernel(const float4 *__restrict__ sorted, int n,
-                                                          double *__restrict__ radius_sq)
+__global__ __launch_bounds__(256) void anms_radius_kernel(AnmsBatch batch, int n)
 {
     __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
+    const float4 *__restrict__ sorted = batch.j[blockIdx.y].sorted;
+    double *__restrict__ radius_sq = batch.j[blockIdx.y].radius;
     const int lane = threadIdx.x & 63;
     const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (s >= n)
@@ -92,10 +111,11 @@ __global__ __launch_bounds__(256) void anms_radius_kernel(const float4 *__restri
 }
 
 // decision radius = the (keep+1)-th largest radius
-__global__ __launch_bounds__(256) void anms_decide_kernel(const double *__restrict__ radius_sq, int n, int keep,
-                                                          double *__restrict__ decision)
+__global__ __launch_bounds__(256) void anms_decide_kernel(AnmsBatch batch, int n, int keep)
 {
     __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
+    const double *__restrict__ radius_sq = batch.j[blockIdx.y].radius;
+    double *__restrict__ decision = batch.j[blockIdx.y].decision;
     const int lane = threadIdx.x & 63;
     const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (s >= n)
@@ -114,22 +134,26 @@ __global__ __launch_bounds__(256) void anms_decide_kernel(const double *__restri
         *decision = ri;  // every wave that qualifies writes the same value
 }
 
-__global__ __launch_bounds__(256) void anms_flag_kernel(const double *__restrict__ radius_sq, int n,
-                                                        const double *__restrict__ decision,
-                                                        uint8_t *__restrict__ flags)
+__global__ __launch_bounds__(256) void anms_flag_kernel(AnmsBatch batch, int n)
 {
     __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
+    const double *__restrict__ radius_sq = batch.j[blockIdx.y].radius;
+    const double *__restrict__ decision = batch.j[blockIdx.y].decision;
+    uint8_t *__restrict__ flags = batch.j[blockIdx.y].flags;
     const int s = blockIdx.x * 256 + threadIdx.x;
     if (s < n)
         flags[s] = radius_sq[s] >= *decision ? 1 : 0;
 }
 
 // kept[] = order[s] for flagged s, in sorted order (single workgroup scan)
-__global__ __launch_bounds__(1024) void anms_gather_kernel(const uint8_t *__restrict__ flags,
-                                                           const int *__restrict__ order, int n,
-                                                           int *__restrict__ out_idx, int *__restrict__ d_count)
+__global__ __launch_bounds__(1024) void anms_gather_kernel(AnmsBatch batch, int n)
 {
     __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
+    const AnmsJob &job = batch.j[blockIdx.x];  // one workgroup per job
+    const uint8_t *__restrict__ flags = job.flags;
+    const int *__restrict__ order = job.order;
+    int *__restrict__ out_idx = job.out_idx;
+    int *__restrict__ d_count = job.d_count;
     __shared__ int s_sum[1024];
     const int t = threadIdx.x;
     const int per = (n + 1023) / 1024;
@@ -157,38 +181,59 @@ __global__ void set_int_kernel(int *p, int v) { *p = v; }
 
 }  // namespace
 
-// Device form.  out_idx: n ints (input indices of the kept keypoints, response order);
-// d_count: device int.  Uses ctx->w_a..w_d as scratch.
-int svo_launch_anms(svo_ctx *ctx, const float *xy, const float *resp, int n, int keep, int *out_idx, int *d_count)
+// Device form, several problems of the same size n.  out_idx: n ints (input indices of the kept
+// keypoints, response order); d_count: device int.  Uses ctx->w_a..w_d as scratch.
+int svo_launch_anms_batch(svo_ctx *ctx, int k, const float *const *xy, const float *const *resp, int n, int keep,
+                          int *const *out_idx, int *const *d_count)
 {
-    if (n <= 0)
+    if (n <= 0 || k <= 0)
         return SVO_OK;
+    if (k > SVO_LK_MAX_JOBS) {
+        svo_set_error("anms: at most %d jobs per launch", SVO_LK_MAX_JOBS);
+        return SVO_ERR_ARG;
+    }
     ScopedKernelTime tm(ctx, SVO_K_ANMS);
     int rc;
-    if ((rc = ctx->w_a.ensure((size_t)n * 4)) || (rc = ctx->w_b.ensure((size_t)n * 8 + 64)) ||
-        (rc = ctx->w_c.ensure((size_t)n)) || (rc = ctx->w_d.ensure((size_t)n * 16)))
+    const size_t na = ((size_t)n + 63) / 64 * 64;
+    if ((rc = ctx->w_a.ensure(na * 4 * k)) || (rc = ctx->w_b.ensure((na * 8 + 64) * k)) ||
+        (rc = ctx->w_c.ensure(na * k)) || (rc = ctx->w_d.ensure(na * 16 * k)))
         return rc;
-    int *order = ctx->w_a.as<int>();
-    double *radius = ctx->w_b.as<double>();
-    double *decision = radius + n;
-    uint8_t *flags = ctx->w_c.as<uint8_t>();
-    float4 *sorted = ctx->w_d.as<float4>();
-    const dim3 wgrid((n + 3) / 4), tgrid((n + 255) / 256), block(256);
-    hipLaunchKernelGGL(anms_rank_kernel, wgrid, block, 0, ctx->stream, reinterpret_cast<const float2 *>(xy), resp, n,
-                       order, sorted);
+    AnmsBatch batch;
+    for (int a = 0; a < SVO_LK_MAX_JOBS; a++) {
+        const int q = a < k ? a : 0;
+        AnmsJob &j = batch.j[a];
+        j.xy = reinterpret_cast<const float2 *>(xy[q]);
+        j.resp = resp[q];
+        j.order = ctx->w_a.as<int>() + na * q;
+        j.radius = reinterpret_cast<double *>(ctx->w_b.as<uint8_t>() + (na * 8 + 64) * q);
+        j.decision = j.radius + na;
+        j.flags = ctx->w_c.as<uint8_t>() + na * q;
+        j.sorted = ctx->w_d.as<float4>() + na * q;
+        j.out_idx = out_idx[q];
+        j.d_count = d_count[q];
+    }
+    const dim3 wgrid((n + 3) / 4, k), tgrid((n + 255) / 256, k), block(256);
+    hipLaunchKernelGGL(anms_rank_kernel, wgrid, block, 0, ctx->stream, batch, n);
     if (n <= keep) {
         // everything is kept, in sorted order
-        SVO_HIP(hipMemcpyAsync(out_idx, order, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
-        hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(1), 0, ctx->stream, d_count, n);
+        for (int a = 0; a < k; a++) {
+            SVO_HIP(hipMemcpyAsync(out_idx[a], batch.j[a].order, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+            hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(1), 0, ctx->stream, d_count[a], n);
+        }
         SVO_HIP(hipGetLastError());
         return SVO_OK;
     }
-    hipLaunchKernelGGL(anms_radius_kernel, wgrid, block, 0, ctx->stream, sorted, n, radius);
-    hipLaunchKernelGGL(anms_decide_kernel, wgrid, block, 0, ctx->stream, radius, n, keep, decision);
-    hipLaunchKernelGGL(anms_flag_kernel, tgrid, block, 0, ctx->stream, radius, n, decision, flags);
-    hipLaunchKernelGGL(anms_gather_kernel, dim3(1), dim3(1024), 0, ctx->stream, flags, order, n, out_idx, d_count);
+    hipLaunchKernelGGL(anms_radius_kernel, wgrid, block, 0, ctx->stream, batch, n);
+    hipLaunchKernelGGL(anms_decide_kernel, wgrid, block, 0, ctx->stream, batch, n, keep);
+    hipLaunchKernelGGL(anms_flag_kernel, tgrid, block, 0, ctx->stream, batch, n);
+    hipLaunchKernelGGL(anms_gather_kernel, dim3(k), dim3(1024), 0, ctx->stream, batch, n);
     SVO_HIP(hipGetLastError());
     return SVO_OK;
+}
+
+int svo_launch_anms(svo_ctx *ctx, const float *xy, const float *resp, int n, int keep, int *out_idx, int *d_count)
+{
+    return svo_launch_anms_batch(ctx, 1, &xy, &resp, n, keep, &out_idx, &d_count);
 }
 
 extern "C" int svo_anms(svo_ctx *ctx, const float *xy, const float *response, int n, int num_to_keep, int *out_idx,

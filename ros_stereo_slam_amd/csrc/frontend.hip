@@ -145,57 +145,135 @@ const uint8_t *stage_image(svo_vo *v, const uint8_t *img, int mem, int *rc)
     return v->d_img;
 }
 
+struct GatherBatch {  // blockIdx.y picks the job
+    const int *idx[SVO_LK_MAX_JOBS];
+    const int *d_count[SVO_LK_MAX_JOBS];
+    const float2 *in_a[SVO_LK_MAX_JOBS];
+    float2 *out_a[SVO_LK_MAX_JOBS];
+    const float2 *in_b[SVO_LK_MAX_JOBS];
+    float2 *out_b[SVO_LK_MAX_JOBS];
+    const uint8_t *in_s[SVO_LK_MAX_JOBS];
+    uint8_t *out_s[SVO_LK_MAX_JOBS];
+};
+__global__ void gather_batch_kernel(GatherBatch b, int cap)
+{
+    __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
+    const int q = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap || i >= *b.d_count[q])
+        return;
+    const int j = b.idx[q][i];
+    b.out_a[q][i] = b.in_a[q][j];
+    b.out_b[q][i] = b.in_b[q][j];
+    b.out_s[q][i] = b.in_s[q][j];
+}
+
 // visualSLAM::stereoTriangulate, dense branch (src/triangulation.cpp:87-103,137-165), with
-// the optional ANMS stage.  Leaves x1 in out2d, camera-frame points in v->b3 and, when Rt is
-// given, world points in out3d (else the camera-frame points).  Count -> d_cnt[4] and host.
+// the optional ANMS stage, for k front-ends of one context at once (same image size, grid step
+// and ANMS budget): every stage is one set of launches.  Per front-end: x1 -> out2d, camera-frame
+// points -> v->b3 and, when Rt is given, world points -> out3d (else the camera-frame points).
+// Count -> d_cnt[4] and host.
+int stereo_triangulate_batch(int k, svo_vo *const *vs, svo_pyramid *const *lefts, svo_pyramid *const *rights,
+                             const double *const *Rts, float *const *out2d, float *const *out3d, int *const *n_out)
+{
+    svo_vo *v0 = vs[0];
+    svo_ctx *ctx = v0->ctx;
+    int rc;
+    const int n = grid_axis(v0->w, v0->prm.grid_step) * grid_axis(v0->h, v0->prm.grid_step);
+    LkJob lk[SVO_LK_MAX_JOBS];
+    for (int a = 0; a < k; a++) {
+        svo_vo *v = vs[a];
+        if ((rc = svo_launch_grid(ctx, v->h, v->w, v->prm.grid_step, v->a2, n)))
+            return rc;
+        // denseLKtracking: LK left -> right (src/tracking.cpp:18); min-eig is the ANMS response
+        LkJob &q = lk[a];
+        q.prev = lefts[a]->dev;
+        q.next = rights[a]->dev;
+        q.prev_pts = v->a2;
+        q.n_cap = n;
+        q.d_n = nullptr;
+        q.next_pts = v->b2;
+        q.status = v->status;
+        q.err = nullptr;
+        q.min_eig = v->resp;
+    }
+    if ((rc = svo_launch_lk_batch(ctx, k, lk)))
+        return rc;
+    const float *pts[SVO_LK_MAX_JOBS], *trk[SVO_LK_MAX_JOBS];
+    const uint8_t *stt[SVO_LK_MAX_JOBS];
+    const int *d_n[SVO_LK_MAX_JOBS];
+    for (int a = 0; a < k; a++) {
+        pts[a] = vs[a]->a2;
+        trk[a] = vs[a]->b2;
+        stt[a] = vs[a]->status;
+        d_n[a] = nullptr;
+    }
+    if (v0->prm.anms_keep > 0) {
+        const float *xy[SVO_LK_MAX_JOBS], *resp[SVO_LK_MAX_JOBS];
+        int *oidx[SVO_LK_MAX_JOBS], *ocnt[SVO_LK_MAX_JOBS];
+        GatherBatch gb = {};
+        for (int a = 0; a < SVO_LK_MAX_JOBS; a++) {
+            svo_vo *v = vs[a < k ? a : 0];
+            if (a < k) {
+                xy[a] = v->a2;
+                resp[a] = v->resp;
+                oidx[a] = v->idx;
+                ocnt[a] = v->d_cnt + 2;
+            }
+            gb.idx[a] = v->idx;
+            gb.d_count[a] = v->d_cnt + 2;
+            gb.in_a[a] = reinterpret_cast<const float2 *>(v->a2);
+            gb.out_a[a] = reinterpret_cast<float2 *>(v->c2);
+            gb.in_b[a] = reinterpret_cast<const float2 *>(v->b2);
+            gb.out_b[a] = reinterpret_cast<float2 *>(v->d2);
+            gb.in_s[a] = v->status;
+            gb.out_s[a] = v->st2;
+        }
+        if ((rc = svo_launch_anms_batch(ctx, k, xy, resp, n, v0->prm.anms_keep, oidx, ocnt)))
+            return rc;
+        hipLaunchKernelGGL(gather_batch_kernel, dim3((n + 255) / 256, k), dim3(256), 0, ctx->stream, gb, n);
+        for (int a = 0; a < k; a++) {
+            pts[a] = vs[a]->c2;
+            trk[a] = vs[a]->d2;
+            stt[a] = vs[a]->st2;
+            d_n[a] = vs[a]->d_cnt + 2;
+        }
+    }
+    // status compaction (src/tracking.cpp:20-27); ping-pong between the (a2,b2) and (c2,d2) pairs
+    svo_compact_job c1[SVO_LK_MAX_JOBS], c2[SVO_LK_MAX_JOBS];
+    svo_fransac_job fj[SVO_LK_MAX_JOBS];
+    svo_tri_job tj[SVO_LK_MAX_JOBS];
+    for (int a = 0; a < k; a++) {
+        svo_vo *v = vs[a];
+        float *o1 = pts[a] == v->a2 ? v->c2 : v->a2, *o2 = pts[a] == v->a2 ? v->d2 : v->b2;
+        float *x1 = out2d[a], *x2 = o1 == v->a2 ? v->c2 : v->a2;
+        c1[a] = {stt[a], n, d_n[a], {pts[a], trk[a], nullptr}, {o1, o2, nullptr}, {2, 2, 0}, v->d_cnt + 3};
+        // FmatThresholding (src/tracking.cpp:30-43): 3 px, 0.99
+        fj[a] = {o1, o2, n, v->d_cnt + 3, v->prm.f_thr_stereo, 0.99, 1000, stage_seed(v, 3), v->mask, nullptr, nullptr,
+                 nullptr};
+        c2[a] = {v->mask, n, v->d_cnt + 3, {o1, o2, nullptr}, {x1, x2, nullptr}, {2, 2, 0}, v->d_cnt + 4};
+        tj[a] = {x1, x2, n, v->d_cnt + 4, Rts[a] ? v->b3 : out3d[a], nullptr, Rts[a], Rts[a] ? out3d[a] : nullptr};
+    }
+    double P1[12], P2[12];
+    svo_stereo_projections(v0->prm.fx, v0->prm.fy, v0->prm.cx, v0->prm.cy, v0->prm.baseline, P1, P2);
+    if ((rc = svo_launch_compact_batch(ctx, k, c1)) || (rc = svo_launch_fransac_batch(ctx, k, fj)) ||
+        (rc = svo_launch_compact_batch(ctx, k, c2)) || (rc = svo_launch_triangulate_batch(ctx, P1, P2, k, tj)))
+        return rc;
+    int *pin = reinterpret_cast<int *>(ctx->pinned);
+    for (int a = 0; a < k; a++)
+        SVO_HIP(hipMemcpyAsync(pin + a, vs[a]->d_cnt + 4, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = svo_wait(ctx)))
+        return rc;
+    for (int a = 0; a < k; a++)
+        *n_out[a] = pin[a];
+    return SVO_OK;
+}
+
 int stereo_triangulate(svo_vo *v, const svo_pyramid *left, const svo_pyramid *right, const double *Rt,
                        float *out2d, float *out3d, int *n_out)
 {
-    svo_ctx *ctx = v->ctx;
-    int rc;
-    int n = grid_axis(v->w, v->prm.grid_step) * grid_axis(v->h, v->prm.grid_step);
-    if ((rc = svo_launch_grid(ctx, v->h, v->w, v->prm.grid_step, v->a2, n)))
-        return rc;
-    // denseLKtracking: LK left -> right (src/tracking.cpp:18); min-eig is the ANMS response
-    if ((rc = svo_launch_lk(ctx, left->dev, right->dev, v->a2, n, v->b2, v->status, nullptr, v->resp)))
-        return rc;
-    const float *pts = v->a2, *trk = v->b2;
-    const uint8_t *st = v->status;
-    const int *d_n = nullptr;
-    if (v->prm.anms_keep > 0) {
-        if ((rc = svo_launch_anms(ctx, v->a2, v->resp, n, v->prm.anms_keep, v->idx, v->d_cnt + 2)))
-            return rc;
-        hipLaunchKernelGGL(gather_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, v->idx, v->d_cnt + 2, n,
-                           reinterpret_cast<const float2 *>(v->a2), reinterpret_cast<float2 *>(v->c2),
-                           reinterpret_cast<const float2 *>(v->b2), reinterpret_cast<float2 *>(v->d2), v->status,
-                           v->st2);
-        pts = v->c2;
-        trk = v->d2;
-        st = v->st2;
-        d_n = v->d_cnt + 2;
-    }
-    // status compaction (src/tracking.cpp:20-27); ping-pong between the (a2,b2) and (c2,d2) pairs
-    float *o1 = pts == v->a2 ? v->c2 : v->a2, *o2 = pts == v->a2 ? v->d2 : v->b2;
-    if ((rc = svo_launch_compact(ctx, st, n, d_n, pts, 2, o1, trk, 2, o2, nullptr, 0, nullptr, v->d_cnt + 3)))
-        return rc;
-    // FmatThresholding (src/tracking.cpp:30-43): 3 px, 0.99
-    if ((rc = svo_launch_fransac(ctx, o1, o2, n, v->d_cnt + 3, v->prm.f_thr_stereo, 0.99, 1000, stage_seed(v, 3),
-                                 v->mask, nullptr, nullptr, nullptr)))
-        return rc;
-    float *x1 = out2d, *x2 = o1 == v->a2 ? v->c2 : v->a2;
-    if ((rc = svo_launch_compact(ctx, v->mask, n, v->d_cnt + 3, o1, 2, x1, o2, 2, x2, nullptr, 0, nullptr,
-                                 v->d_cnt + 4)))
-        return rc;
-    double P1[12], P2[12];
-    svo_stereo_projections(v->prm.fx, v->prm.fy, v->prm.cx, v->prm.cy, v->prm.baseline, P1, P2);
-    if ((rc = svo_launch_triangulate(ctx, P1, P2, x1, x2, n, v->d_cnt + 4, Rt ? v->b3 : out3d, nullptr, Rt,
-                                     Rt ? out3d : nullptr)))
-        return rc;
-    SVO_HIP(hipMemcpyAsync(ctx->pinned, v->d_cnt + 4, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    if ((rc = svo_wait(ctx)))
-        return rc;
-    *n_out = *reinterpret_cast<int *>(ctx->pinned);
-    return SVO_OK;
+    svo_pyramid *l = const_cast<svo_pyramid *>(left), *r = const_cast<svo_pyramid *>(right);
+    return stereo_triangulate_batch(1, &v, &l, &r, &Rt, &out2d, &out3d, &n_out);
 }
 
 }  // namespace
@@ -840,7 +918,9 @@ static int run_chunk_group(svo_chunk_job **jobs, int k)
             }
             hipLaunchKernelGGL(publish_record_kernel, dim3(np), dim3(64), 0, st, pb);
         }
-        // ---- policy of every chunk, in the order their counts arrive ----
+        // ---- policy of every chunk; the chunks that keyframe are collected ----
+        GS *kfs[SVO_LK_MAX_JOBS];
+        int nk = 0;
         for (GS &g : gs) {
             if (!g.active)
                 continue;
@@ -874,30 +954,56 @@ static int run_chunk_group(svo_chunk_job **jobs, int k)
             }
             const bool kf = ninl < v->prm.keyframe_min_inliers;  // src/VisualSLAM.cpp:120
             if (kf) {
-                if ((rc = wait_tag(&mb->pose_tag[f & 1], g.pose_tag[f & 1])))
-                    return rc;
-                harvest(g, f);
-                if ((rc = svo_build_pyramid_from_device(ctx, v->pyr_right, g.j->rights[f])))
-                    return rc;
-                const double *R9 = g.j->R_out + 9 * (size_t)f, *t3 = g.j->t_out + 3 * (size_t)f;
-                double Rt[12];
-                for (int i = 0; i < 3; i++) {
-                    Rt[4 * i] = R9[3 * i];
-                    Rt[4 * i + 1] = R9[3 * i + 1];
-                    Rt[4 * i + 2] = R9[3 * i + 2];
-                    Rt[4 * i + 3] = t3[i];
-                }
-                if ((rc = stereo_triangulate(v, v->pyr_cur, v->pyr_right, Rt, v->ref2d, v->ref3d, &v->nref)))
-                    return rc;
+                kfs[nk++] = &g;
             } else {
                 g.pending = f;
                 std::swap(v->ref2d, v->trk2d);
                 std::swap(v->ref3d, v->trk3d);
                 v->nref = v->ntrk;
             }
-            std::swap(v->pyr_ref, v->pyr_cur);
             if (g.j->keyframe_out)
                 g.j->keyframe_out[f] = kf ? 1 : 0;
+        }
+        // ---- the keyframe path of all the chunks that need it, every stage one set of launches ----
+        if (nk > 0) {
+            svo_vo *vs[SVO_LK_MAX_JOBS];
+            svo_pyramid *lefts[SVO_LK_MAX_JOBS], *rights[SVO_LK_MAX_JOBS];
+            const uint8_t *rimg[SVO_LK_MAX_JOBS];
+            double Rt[SVO_LK_MAX_JOBS][12];
+            const double *Rts[SVO_LK_MAX_JOBS];
+            float *o2d[SVO_LK_MAX_JOBS], *o3d[SVO_LK_MAX_JOBS];
+            int *nout[SVO_LK_MAX_JOBS];
+            for (int a = 0; a < nk; a++) {
+                GS &g = *kfs[a];
+                svo_vo *v = g.v;
+                // the keyframe's points are placed with the refined pose: wait for it
+                if ((rc = wait_tag(&v->mbox->pose_tag[f & 1], g.pose_tag[f & 1])))
+                    return rc;
+                harvest(g, f);
+                const double *R9 = g.j->R_out + 9 * (size_t)f, *t3 = g.j->t_out + 3 * (size_t)f;
+                for (int i = 0; i < 3; i++) {
+                    Rt[a][4 * i] = R9[3 * i];
+                    Rt[a][4 * i + 1] = R9[3 * i + 1];
+                    Rt[a][4 * i + 2] = R9[3 * i + 2];
+                    Rt[a][4 * i + 3] = t3[i];
+                }
+                vs[a] = v;
+                lefts[a] = v->pyr_cur;
+                rights[a] = v->pyr_right;
+                rimg[a] = g.j->rights[f];
+                Rts[a] = Rt[a];
+                o2d[a] = v->ref2d;
+                o3d[a] = v->ref3d;
+                nout[a] = &v->nref;
+            }
+            if ((rc = svo_build_pyramids_from_device(ctx, nk, rights, rimg)) ||
+                (rc = stereo_triangulate_batch(nk, vs, lefts, rights, Rts, o2d, o3d, nout)))
+                return rc;
+        }
+        for (GS &g : gs) {
+            if (!g.active)
+                continue;
+            std::swap(g.v->pyr_ref, g.v->pyr_cur);
             g.j->n_done = f + 1;
         }
     }

@@ -78,13 +78,30 @@ __device__ void smallest_right_singular_vector4(double (&A)[4][4], double (&v)[4
         v[i] = best == 0 ? V[i][0] : best == 1 ? V[i][1] : best == 2 ? V[i][2] : V[i][3];
 }
 
-__global__ __launch_bounds__(128) void triangulate_kernel(Mat34 P1, Mat34 P2, const float2 *__restrict__ x1,
-                                                          const float2 *__restrict__ x2, int n_host,
-                                                          const int *__restrict__ d_n, float *__restrict__ out_xyz,
-                                                          float *__restrict__ out_h, Mat34 Rt, int apply_rt,
-                                                          float *__restrict__ out_world)
+struct TriJob {
+    const float2 *x1, *x2;
+    int n_host;
+    const int *d_n;
+    float *out_xyz, *out_h;
+    Mat34 Rt;
+    int apply_rt;
+    float *out_world;
+};
+struct TriBatch {  // blockIdx.y picks the job
+    TriJob j[SVO_LK_MAX_JOBS];
+};
+
+__global__ __launch_bounds__(128) void triangulate_kernel(Mat34 P1, Mat34 P2, TriBatch batch)
 {
     __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
+    const TriJob &job = batch.j[blockIdx.y];
+    const float2 *__restrict__ x1 = job.x1, *__restrict__ x2 = job.x2;
+    const int n_host = job.n_host;
+    const int *__restrict__ d_n = job.d_n;
+    float *__restrict__ out_xyz = job.out_xyz, *__restrict__ out_h = job.out_h;
+    const Mat34 &Rt = job.Rt;
+    const int apply_rt = job.apply_rt;
+    float *__restrict__ out_world = job.out_world;
     const int n = d_n ? *d_n : n_host;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n)
@@ -231,18 +248,46 @@ Mat34 to_mat34(const double *p)
 
 }  // namespace
 
+int svo_launch_triangulate_batch(svo_ctx *ctx, const double *P1, const double *P2, int k, const svo_tri_job *jobs)
+{
+    if (k <= 0)
+        return SVO_OK;
+    if (k > SVO_LK_MAX_JOBS) {
+        svo_set_error("triangulate: at most %d jobs per launch", SVO_LK_MAX_JOBS);
+        return SVO_ERR_ARG;
+    }
+    TriBatch batch;
+    int cap_max = 0;
+    for (int a = 0; a < SVO_LK_MAX_JOBS; a++) {
+        const svo_tri_job &h = jobs[a < k ? a : 0];
+        TriJob &j = batch.j[a];
+        j.x1 = reinterpret_cast<const float2 *>(h.x1);
+        j.x2 = reinterpret_cast<const float2 *>(h.x2);
+        j.n_host = h.cap;
+        j.d_n = h.d_n;
+        j.out_xyz = h.out_xyz;
+        j.out_h = h.out_h;
+        j.Rt = to_mat34(h.Rt);
+        j.apply_rt = (h.Rt && h.out_world) ? 1 : 0;
+        j.out_world = h.out_world;
+        if (a < k)
+            cap_max = h.cap > cap_max ? h.cap : cap_max;
+    }
+    if (cap_max <= 0)
+        return SVO_OK;
+    ScopedKernelTime tm(ctx, SVO_K_TRIANGULATE);
+    hipLaunchKernelGGL(triangulate_kernel, dim3((cap_max + 127) / 128, k), dim3(128), 0, ctx->stream, to_mat34(P1),
+                       to_mat34(P2), batch);
+    SVO_HIP(hipGetLastError());
+    return SVO_OK;
+}
+
 int svo_launch_triangulate(svo_ctx *ctx, const double *P1, const double *P2, const float *x1, const float *x2,
                            int cap, const int *d_n, float *out_xyz, float *out_h, const double *Rt,
                            float *out_world)
 {
-    if (cap <= 0)
-        return SVO_OK;
-    ScopedKernelTime tm(ctx, SVO_K_TRIANGULATE);
-    hipLaunchKernelGGL(triangulate_kernel, dim3((cap + 127) / 128), dim3(128), 0, ctx->stream, to_mat34(P1),
-                       to_mat34(P2), reinterpret_cast<const float2 *>(x1), reinterpret_cast<const float2 *>(x2), cap,
-                       d_n, out_xyz, out_h, to_mat34(Rt), (Rt && out_world) ? 1 : 0, out_world);
-    SVO_HIP(hipGetLastError());
-    return SVO_OK;
+    svo_tri_job j = {x1, x2, cap, d_n, out_xyz, out_h, Rt, out_world};
+    return svo_launch_triangulate_batch(ctx, P1, P2, 1, &j);
 }
 
 int svo_launch_transform(svo_ctx *ctx, const double *Rt, const float *in, int cap, const int *d_n, float *out)

@@ -149,6 +149,15 @@ int svo_launch_fransac(svo_ctx *ctx, const float *p1, const float *p2, int cap, 
 int svo_launch_triangulate(svo_ctx *ctx, const double *P1, const double *P2, const float *x1, const float *x2,
                            int cap, const int *d_n, float *out_xyz, float *out_h, const double *Rt,
                            float *out_world);
+struct svo_tri_job {  // one stereo DLT triangulation (device pointers; Rt: host 3x4 or null)
+    const float *x1, *x2;
+    int cap;
+    const int *d_n;
+    float *out_xyz, *out_h;
+    const double *Rt;
+    float *out_world;
+};
+int svo_launch_triangulate_batch(svo_ctx *ctx, const double *P1, const double *P2, int k, const svo_tri_job *jobs);
 int svo_launch_transform(svo_ctx *ctx, const double *Rt, const float *in, int cap, const int *d_n, float *out);
 int svo_launch_colors(svo_ctx *ctx, const svo_pyramid *pyr, const float *xy, int cap, const int *d_n, float *out);
 struct svo_compact_job {  // order-preserving compaction of up to three float arrays by one byte mask
@@ -195,4 +204,6 @@ int svo_launch_pnp_ransac(svo_ctx *ctx, const float *obj, const float *img, int 
                           int refine_iters, int *inliers, uint8_t *mask, void *d_result, int *early_mbox = nullptr,
                           int early_tag = 0);
 // anms.hip
+int svo_launch_anms_batch(svo_ctx *ctx, int k, const float *const *xy, const float *const *resp, int n, int keep,
+                          int *const *out_idx, int *const *d_count);
 int svo_launch_anms(svo_ctx *ctx, const float *xy, const float *resp, int n, int keep, int *out_idx, int *d_count);
