@@ -263,9 +263,10 @@ int svo_vo_run_chunk(svo_vo *vo, const uint8_t *const *lefts, const uint8_t *con
  * chunk sharding): every job is one svo_vo_run_chunk() call on its own host thread.  The
  * front-end's kernels are latency-bound (one wave per keypoint / hypothesis, a few hundred to a
  * few thousand waves per launch), so chunks on separate contexts interleave on the chip.  Jobs
- * whose svo_vo share one svo_ctx (at most 4, device images) form a group: one host thread
- * advances them in lock step and their tracking passes go out as ONE pyramidal-LK launch -- that
- * launch lasts as long as its slowest keypoint, so several jobs cost little more than one.
+ * whose svo_vo share one svo_ctx (at most 8, device images) form a group: one host thread
+ * advances them in lock step and every stage (pyramids, pyramidal LK, filters, F-RANSAC, PnP,
+ * keyframe path) goes out as ONE set of launches for all of them -- these kernels are latency
+ * chains, so several jobs cost little more than one.
  * Every job gets exactly what svo_vo_run_chunk gives it alone.  rc / n_done are filled per job;
  * the return value is the first failing group's code other than SVO_ERR_TRACKING_LOST, else SVO_OK. */
 typedef struct svo_chunk_job {
