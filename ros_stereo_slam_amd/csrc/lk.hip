@@ -248,7 +248,7 @@ __device__ __forceinline__ void lane_residual(const uint8_t *lds, int off, int w
 // the job): the launch lasts as long as the slowest keypoint of ANY job, so two jobs cost little
 // more than one (svo_vo_run_chunks, chunks that share a context).
 template <int C>
-__global__ __launch_bounds__(64 * WAVES, 3) void lk_track_kernel(LkBatch batch, LkParams prm)
+__global__ __launch_bounds__(64 * WAVES, 4) void lk_track_kernel(LkBatch batch, LkParams prm)
 {
     const LkJob &job = batch.j[blockIdx.y];
     const PyrDev &prev = job.prev, &next = job.next;
@@ -322,21 +322,46 @@ __global__ __launch_bounds__(64 * WAVES, 3) void lk_track_kernel(LkBatch batch, 
         wave_lds_sync();
         const uint8_t *Ts = T + stage_tile<C, PT>(T, I, pitch, ipx - 1, ipy - 1, lane);
         wave_lds_sync();
-        for (int i = lane; i < DT * DT * C; i += 64) {
-            int yy = i / (DT * C), cc = i - yy * (DT * C);
-            int xx = cc / C, ch = cc - xx * C;
-            int X = ipx + xx, Y = ipy + yy;
-            int packed = 0;
-            if (X >= 0 && X < lw && Y >= 0 && Y < lh) {
-                const uint8_t *t = Ts + yy * TROW + xx * C + ch;  // top-left of the 3x3
-                int a0 = t[0], a1 = t[C], a2 = t[2 * C];
-                int b0 = t[TROW], b2 = t[TROW + 2 * C];
-                int c0 = t[2 * TROW], c1 = t[2 * TROW + C], c2 = t[2 * TROW + 2 * C];
-                int dx = 3 * (a2 - a0) + 10 * (b2 - b0) + 3 * (c2 - c0);
-                int dy = 3 * (c0 - a0) + 10 * (c1 - a1) + 3 * (c2 - a2);
-                packed = (dx & 0xffff) | (dy << 16);
+        // Scharr tile: lane = (tile row, left / right half of its 22 pixels); the 3x3 window slides
+        // along the row, so a new entry costs one new column -- its vertical smooth 3a + 10b + 3c and
+        // vertical difference c - a -- instead of eight byte reads and per-entry index arithmetic:
+        //   dx(x) = S(x+2) - S(x),   dy(x) = 3 V(x) + 10 V(x+1) + 3 V(x+2)
+        if (lane < 2 * DT) {
+            constexpr int HALF = DT / 2;  // 11 pixels
+            const int r = lane >> 1, x0 = (lane & 1) * HALF;
+            const int Y = ipy + r;
+            const bool row_ok = Y >= 0 && Y < lh;
+            const bool cols_ok = ipx >= 0 && ipx + DT <= lw;  // wave-uniform: no per-entry column test needed
+            const uint8_t *t = Ts + r * TROW + x0 * C;
+            int *Drow = D + (r * DT + x0) * C;
+#pragma unroll
+            for (int ch = 0; ch < C; ch++) {
+                int S0, S1, V0, V1;
+                {
+                    const int a = t[ch], b = t[TROW + ch], c = t[2 * TROW + ch];
+                    S0 = 3 * a + 10 * b + 3 * c;
+                    V0 = c - a;
+                }
+                {
+                    const int a = t[C + ch], b = t[TROW + C + ch], c = t[2 * TROW + C + ch];
+                    S1 = 3 * a + 10 * b + 3 * c;
+                    V1 = c - a;
+                }
+#pragma unroll
+                for (int px = 0; px < HALF; px++) {
+                    const int o = (px + 2) * C + ch;
+                    const int a = t[o], b = t[TROW + o], c = t[2 * TROW + o];
+                    const int S2 = 3 * a + 10 * b + 3 * c, V2 = c - a;
+                    const int dx = S2 - S0, dy = 3 * V0 + 10 * V1 + 3 * V2;
+                    const int X = ipx + x0 + px;
+                    const bool ok = row_ok && (cols_ok || (X >= 0 && X < lw));
+                    Drow[px * C + ch] = ok ? ((dx & 0xffff) | (dy << 16)) : 0;
+                    S0 = S1;
+                    S1 = S2;
+                    V0 = V1;
+                    V1 = V2;
+                }
             }
-            D[i] = packed;
         }
         wave_lds_sync();
 
