@@ -477,6 +477,8 @@ __global__ __launch_bounds__(64 * WAVES, 4) void lk_track_kernel(LkBatch batch, 
                 st = 0;
                 continue;
             }
+            if (uniform(err == nullptr))
+                continue;  // the caller does not read err: only the bounds test above affects its outputs
             if (!have_tile || iqx < ox || iqx > ox + 2 * JR || iqy < oy || iqy > oy + 2 * JR) {
                 ox = iqx - JR;
                 oy = iqy - JR;
