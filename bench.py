@@ -41,15 +41,15 @@ GRID_STEP = 10            # 4428 lattice points -> ANMS keeps 4096 (SURVEY.md 8d
 KF_MIN_INLIERS = 2000     # the reference's 200-of-440 rule scaled to 4096 keypoints
 PYR_BYTES = 619930 * C    # sum of the 4 level sizes
 # HBM bytes per lk_track_kernel<3> launch from the PMC counters of this very workload
-# (profiles/r01_pmc_hbm_traffic_v4.csv: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes,
+# (profiles/r01_pmc_hbm_traffic_v6.csv: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes,
 # KB units, gfx950 correction for 16-B-per-lane reads: (2*FETCH_SIZE + WRITE_SIZE) * 1024).
 # PMC counters cannot be read from inside this process, so the figure is carried from the
 # committed profile; None would be the honest value for any other workload.
-LK_PMC_TRAFFIC_BYTES = 12681000   # 20 011 838 B per launch / 1.578 tracking passes per launch
+LK_PMC_TRAFFIC_BYTES = 16012306   # per tracking pass: 94 launches carrying 399.4 passes in the PMC run
 # VALU wave-instructions per lk_track_kernel<3> launch from the SQ counters of the same workload
-# (profiles/r01_pmc_sq_v3.csv, SQ_INSTS_VALU).  The kernel's own bound is VALU issue, not HBM:
+# (profiles/r01_pmc_sq_v6.csv, SQ_INSTS_VALU, per tracking pass).  The kernel's own bound is VALU issue, not HBM:
 # 1024 SIMDs x one wave64 VALU instruction per 4 cycles at 2.4 GHz.
-LK_PMC_VALU_INSTS = 41912354
+LK_PMC_VALU_INSTS = 44484806
 
 
 def lk_algorithmic_bytes(n_pts: int) -> int:
@@ -267,7 +267,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / 8000.0,
                 "traffic": LK_PMC_TRAFFIC_BYTES * jobs_per_launch if (W, H, C, N_KPTS) == (1241, 376, 3, 4096) else None,
-                "traffic_source": "profiles/r01_pmc_hbm_traffic_v4.csv (rocprofv3 --pmc, (2*FETCH_SIZE+WRITE_SIZE)*1024, "
+                "traffic_source": "profiles/r01_pmc_hbm_traffic_v6.csv (rocprofv3 --pmc, (2*FETCH_SIZE+WRITE_SIZE)*1024, "
                                   "per tracking pass) x passes per launch",
                 "avg_launch_us": lk_avg_s * 1e6,
                 "launches_per_step": lk_launches / args.steps,
