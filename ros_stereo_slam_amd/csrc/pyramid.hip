@@ -39,35 +39,64 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(PyrPtrs ptrs, int spitch,
     __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     const uint8_t *__restrict__ src = ptrs.src[blockIdx.z];
     uint8_t *__restrict__ dst = ptrs.dst[blockIdx.z];
-    constexpr int SROW = ((SW * C + 3) / 4) * 4;
-    __shared__ uint8_t s_src[SH * SROW];
+    constexpr int SDW = (SW * C + 3) / 4 + 1;  // dwords per staged row, one spare for the alignment shift
+    constexpr int SROW = SDW * 4;
+    __shared__ __attribute__((aligned(16))) uint8_t s_src[SH * SROW];
     __shared__ uint16_t s_h[SH][TW * C];
     const int tid = threadIdx.x;
     const int ox = blockIdx.x * TW, oy = blockIdx.y * TH;
-
-    for (int i = tid; i < SH * SW * C; i += 256) {
-        int r = i / (SW * C), cc = i - r * (SW * C);
-        int px = cc / C, ch = cc - px * C;
-        int sx = reflect101(2 * ox - 2 + px, w);
-        int sy = reflect101(2 * oy - 2 + r, h);
-        s_src[r * SROW + cc] = src[(size_t)sy * spitch + sx * C + ch];
+    const int x0 = 2 * ox - 2, y0 = 2 * oy - 2;
+    int sh = 0;  // byte offset of the tile inside the staged rows
+    if (x0 >= 0 && x0 + SW <= w && y0 >= 0 && y0 + SH <= h) {
+        // interior tile: whole aligned dwords, row by row (src is 4-byte aligned and spitch a multiple
+        // of 16, so every row of the tile starts at the same byte shift)
+        sh = (x0 * C) & 3;
+        const uint8_t *base = src + (ptrdiff_t)y0 * spitch + x0 * C - sh;
+        for (int i = tid; i < SH * SDW; i += 256) {
+            const int r = i / SDW, d = i - r * SDW;
+            reinterpret_cast<uint32_t *>(s_src + r * SROW)[d] =
+                reinterpret_cast<const uint32_t *>(base + (ptrdiff_t)r * spitch)[d];
+        }
+    } else {
+        for (int i = tid; i < SH * SW * C; i += 256) {
+            int r = i / (SW * C), cc = i - r * (SW * C);
+            int px = cc / C, ch = cc - px * C;
+            int sx = reflect101(x0 + px, w);
+            int sy = reflect101(y0 + r, h);
+            s_src[r * SROW + cc] = src[(size_t)sy * spitch + sx * C + ch];
+        }
     }
     __syncthreads();
     for (int i = tid; i < SH * TW * C; i += 256) {
         int r = i / (TW * C), cc = i - r * (TW * C);
         int x = cc / C, ch = cc - x * C;
-        const uint8_t *s = s_src + r * SROW + (2 * x) * C + ch;
-        s_h[r][cc] = (uint16_t)(s[0] + 4 * s[C] + 6 * s[2 * C] + 4 * s[3 * C] + s[4 * C]);
+        const uint8_t *sp = s_src + r * SROW + sh + (2 * x) * C + ch;
+        s_h[r][cc] = (uint16_t)(sp[0] + 4 * sp[C] + 6 * sp[2 * C] + 4 * sp[3 * C] + sp[4 * C]);
     }
     __syncthreads();
-    for (int i = tid; i < TH * TW * C; i += 256) {
-        int y = i / (TW * C), cc = i - y * (TW * C);
-        int X = ox + cc / C, Y = oy + y;
-        if (X < dw && Y < dh) {
-            int v = s_h[2 * y][cc] + 4 * s_h[2 * y + 1][cc] + 6 * s_h[2 * y + 2][cc] +
-                    4 * s_h[2 * y + 3][cc] + s_h[2 * y + 4][cc];
-            dst[(size_t)Y * dpitch + X * C + (cc % C)] = (uint8_t)((v + 128) >> 8);
+    // vertical pass; a thread produces four consecutive bytes of an output row = one aligned dword
+    // (ox * C and dpitch are multiples of 4), bytes beyond the level's width are not stored
+    for (int i = tid; i < TH * (TW * C / 4); i += 256) {
+        const int y = i / (TW * C / 4), q = i - y * (TW * C / 4);
+        const int Y = oy + y;
+        if (Y >= dh)
+            continue;
+        uint32_t out = 0;
+        int nvalid = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int cc = 4 * q + b;
+            const int v = s_h[2 * y][cc] + 4 * s_h[2 * y + 1][cc] + 6 * s_h[2 * y + 2][cc] + 4 * s_h[2 * y + 3][cc] +
+                          s_h[2 * y + 4][cc];
+            out |= (uint32_t)((v + 128) >> 8) << (8 * b);
+            nvalid += (ox + cc / C) < dw ? 1 : 0;
         }
+        uint8_t *drow = dst + (size_t)Y * dpitch + ox * C + 4 * q;
+        if (nvalid == 4)
+            *reinterpret_cast<uint32_t *>(drow) = out;
+        else
+            for (int b = 0; b < nvalid; b++)
+                drow[b] = (uint8_t)(out >> (8 * b));
     }
 }
 
@@ -87,13 +116,23 @@ __global__ __launch_bounds__(256) void pad_copy_kernel(PyrPtrs ptrs, int w, int 
     const int Y = reflect101(row - SVO_PYR_PAD, h);
     const uint8_t *srow = src + (size_t)Y * w * C;
     uint32_t out = 0;
+    const int k = d * 4 - SVO_PYR_PAD * C;  // byte index inside the source row of the dword's first byte
+    if (k >= 0 && k + 4 <= w * C && (Y < h - 1 || k + 8 <= w * C) && (Y > 0 || k >= 4)) {
+        // interior: four consecutive source bytes, fetched as two aligned dwords (the source rows have
+        // no particular alignment); neither dword reaches outside the image buffer
+        const uintptr_t a = reinterpret_cast<uintptr_t>(srow + k);
+        const uint32_t *p = reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3);
+        const uint32_t lo = p[0], hi = (a & 3) ? p[1] : 0u;
+        out = __builtin_amdgcn_alignbyte(hi, lo, (unsigned)(a & 3));
+    } else {
 #pragma unroll
-    for (int b = 0; b < 4; b++) {
-        int cb = d * 4 + b;
-        int px = cb / C, ch = cb - px * C;
-        if (px < w + 2 * SVO_PYR_PAD) {
-            int X = reflect101(px - SVO_PYR_PAD, w);
-            out |= (uint32_t)srow[X * C + ch] << (8 * b);
+        for (int b = 0; b < 4; b++) {
+            int cb = d * 4 + b;
+            int px = cb / C, ch = cb - px * C;
+            if (px < w + 2 * SVO_PYR_PAD) {
+                int X = reflect101(px - SVO_PYR_PAD, w);
+                out |= (uint32_t)srow[X * C + ch] << (8 * b);
+            }
         }
     }
     reinterpret_cast<uint32_t *>(padded + (size_t)row * pitch)[d] = out;
