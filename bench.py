@@ -72,19 +72,19 @@ def pingpong(i: int, n: int) -> int:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1600)
+    ap.add_argument("--steps", type=int, default=3200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--frames", type=int, default=6, help="distinct synthetic stereo frames kept in HBM per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--pipeline", choices=("auto", "on", "off"), default="auto",
                     help="two-stream overlap of PnP(t) with pyramid + LK(t+1) inside a chunk; auto = on for one "
                          "chunk per GPU, off when several chunks already fill the hardware queues")
-    ap.add_argument("--chunks-per-gpu", type=int, default=int(os.environ.get("SVO_CHUNKS_PER_GPU", "32")),
+    ap.add_argument("--chunks-per-gpu", type=int, default=int(os.environ.get("SVO_CHUNKS_PER_GPU", "64")),
                     help="independent chunks of the stream run side by side on each GPU (svo_vo_run_chunks); "
-                         "with --chunks-per-context 8 that is 4 contexts = 4 busy hardware queues")
-    ap.add_argument("--chunks-per-context", type=int, default=int(os.environ.get("SVO_CHUNKS_PER_CONTEXT", "8")),
+                         "with --chunks-per-context 16 that is 4 contexts = 4 busy hardware queues")
+    ap.add_argument("--chunks-per-context", type=int, default=int(os.environ.get("SVO_CHUNKS_PER_CONTEXT", "16")),
                     help="chunks that share one context (= one stream): advanced in lock step, every stage of the "
-                         "tracking path ONE set of launches for all of them (1..8)")
+                         "tracking path ONE set of launches for all of them (1..16)")
     ap.add_argument("--kpts", type=int, default=4096, choices=(4096, 8192),
                     help="keypoints per frame: 4096 = BASELINE's metric (grid step 10), 8192 = configs[4] shape "
                          "(grid step 7 -> 9152 lattice points -> ANMS 8192, keyframe rule 4000)")
@@ -123,7 +123,7 @@ def main():
     from ros_stereo_slam_amd import capi, synth
 
     M = max(1, args.chunks_per_gpu)
-    G = max(1, min(8, args.chunks_per_context))
+    G = max(1, min(16, args.chunks_per_context))
     pipeline = args.pipeline == "on" or (args.pipeline == "auto" and M == 1)
     scene = synth.Scene()
     # every rank renders its own contiguous chunks of the stream (M per GPU, one context each)

@@ -263,7 +263,7 @@ int svo_vo_run_chunk(svo_vo *vo, const uint8_t *const *lefts, const uint8_t *con
  * chunk sharding): every job is one svo_vo_run_chunk() call on its own host thread.  The
  * front-end's kernels are latency-bound (one wave per keypoint / hypothesis, a few hundred to a
  * few thousand waves per launch), so chunks on separate contexts interleave on the chip.  Jobs
- * whose svo_vo share one svo_ctx (at most 8, device images) form a group: one host thread
+ * whose svo_vo share one svo_ctx (at most 16, device images) form a group: one host thread
  * advances them in lock step and every stage (pyramids, pyramidal LK, filters, F-RANSAC, PnP,
  * keyframe path) goes out as ONE set of launches for all of them -- these kernels are latency
  * chains, so several jobs cost little more than one.

@@ -43,6 +43,7 @@ struct LkParams {
     double eps_sq;
     float min_eig_thr;
 };
+static_assert(sizeof(LkBatch) + sizeof(LkParams) <= 4096, "kernel arguments are limited to 4 KB");
 
 // An LDS tile keeps the 16-byte-aligned row segments exactly as loaded: row r, byte b of
 // the tile lives at r*ROW + shift + b, where shift = (address of the tile origin) & 15 is

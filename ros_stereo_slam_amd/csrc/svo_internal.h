@@ -18,7 +18,7 @@
 // loads and no border arithmetic (the furthest it reaches outside the image is 26 px).
 #define SVO_PYR_PAD 32
 // independent jobs one batched launch may carry (chunks of a context that run in lock step)
-#define SVO_LK_MAX_JOBS 8
+#define SVO_LK_MAX_JOBS 16
 
 void svo_set_error(const char *fmt, ...);
 

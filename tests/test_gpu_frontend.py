@@ -143,7 +143,7 @@ def test_run_chunks_side_by_side_equals_one_by_one(ctx):
         c.close()
 
 
-@pytest.mark.parametrize("lengths", [(4, 4, 4), (5, 3, 2, 4)])
+@pytest.mark.parametrize("lengths", [(4, 4, 4), (5, 3, 2, 4), (3, 2) * 8])  # the last: a full group of 16
 def test_chunks_sharing_a_context_run_in_lock_step_with_one_lk_launch(ctx, lengths):
     """Jobs whose front-ends share ONE context form a group: one host thread, one pyramidal-LK
     launch per frame for all of them (blockIdx.y = job).  Chunks of different lengths, keyframes
