@@ -100,6 +100,33 @@ __device__ __forceinline__ double wave_sum_exact(int v)
     return (double)shi * 65536. + (double)slo;
 }
 
+// the same total rounded to float (round to nearest even of the exact integer, like the double
+// path): the total nearly always fits 32 bits, then one v_cvt_f32_i32 does it (scalar test)
+__device__ __forceinline__ float wave_sum_float(int v)
+{
+    const int slo = wave_total_lane63(v & 0xffff), shi = wave_total_lane63(v >> 16);
+    const long long t = (long long)shi * 65536 + slo;
+    if (t == (long long)(int)t)
+        return (float)(int)t;
+    return (float)((double)shi * 65536. + (double)slo);
+}
+
+// Two exact totals at once.  When every lane's partials lie in [-2^25, 2^25) -- nearly always: a
+// lane would need a mean |residual * derivative| above 1.6e6 per element to leave it -- neither the
+// totals nor any partial sum of the butterflies can leave int32, so one DPP chain per total does
+// it; otherwise the split path.  Both are exact: the choice never changes a result.
+__device__ __forceinline__ void wave_sum2_float(int a, int b, float &fa, float &fb)
+{
+    const unsigned wide = ((unsigned)(a + (1 << 25)) | (unsigned)(b + (1 << 25))) >> 26;
+    if (__builtin_amdgcn_ballot_w64(wide != 0) == 0) {
+        fa = (float)wave_total_lane63(a);
+        fb = (float)wave_total_lane63(b);
+    } else {
+        fa = wave_sum_float(a);
+        fb = wave_sum_float(b);
+    }
+}
+
 __device__ __forceinline__ void bilinear_weights(float a, float b, int &w00, int &w01, int &w10,
                                                  int &w11)
 {
@@ -179,23 +206,6 @@ __device__ __forceinline__ void load_row_packed(const uint8_t *lds, int off, uns
         d[i] = __builtin_amdgcn_alignbyte(raw[i + 1], raw[i], sh);
 }
 
-// (byte k) | (byte k+C) << 16 of a packed row run: the two horizontal bilinear neighbours of
-// element k as an int16 pair, one v_perm_b32 (selector bytes 0-3 pick from the second source,
-// 4-7 from the first, 0x0c is a zero byte).
-template <int C, int K> __device__ __forceinline__ int pixel_pair(const unsigned (&d)[ndwords(C)])
-{
-    constexpr int a = K >> 2, b = (K + C) >> 2;
-    constexpr unsigned sel = (unsigned)(K & 3) | (0x0cu << 8) | ((4u + (unsigned)((K + C) & 3)) << 16) | (0x0cu << 24);
-    return (int)__builtin_amdgcn_perm(d[b], d[a], sel);
-}
-
-// low (HI = false) or high (HI = true) int16 halves of two dwords as a pair: (x.half, y.half)
-template <bool HI> __device__ __forceinline__ int half_pair(int x, int y)
-{
-    constexpr unsigned sel = HI ? 0x07060302u : 0x05040100u;
-    return (int)__builtin_amdgcn_perm((unsigned)y, (unsigned)x, sel);
-}
-
 template <int C, int K> struct ForEachElem {
     template <class F> static __device__ __forceinline__ void run(F &&f)
     {
@@ -207,34 +217,76 @@ template <int C> struct ForEachElem<C, 0> {
     template <class F> static __device__ __forceinline__ void run(F &&) {}
 };
 
+// (byte K of the upper row run) | (byte K of the lower row run) << 16: the two VERTICAL bilinear
+// neighbours of column K as an int16 pair, one v_perm_b32 (selector bytes 0-3 pick from the second
+// source, 4-7 from the first, 0x0c is a zero byte).  Element k needs columns k and k+C, so a lane
+// builds (SEG+1)*C such pairs per sample instead of 2*SEG*C horizontal ones.
+template <int C, int K>
+__device__ __forceinline__ int column_pair(const unsigned (&up)[ndwords(C)], const unsigned (&lo)[ndwords(C)])
+{
+    constexpr unsigned sel = (unsigned)(K & 3) | (0x0cu << 8) | ((4u + (unsigned)(K & 3)) << 16) | (0x0cu << 24);
+    return (int)__builtin_amdgcn_perm(lo[K >> 2], up[K >> 2], sel);
+}
+
+// The bilinear samples of a lane's SEG*C elements, descaled by `SHIFT` bits and packed as int16
+// pairs (low half = even element; an odd count is padded with 0):
+//   S_k = w00 p[k] + w10 q[k] + w01 p[k+C] + w11 q[k+C] + RND          (p, q: upper / lower row)
+// = two v_dot2_i32_i16 on column pairs with the weight pairs wv0 = (w00 | w10 << 16) and
+// wv1 = (w01 | w11 << 16) (pixel <= 255, -1 <= weight <= 2^14: exact).  S >> SHIFT of two elements is
+// packed without per-element shifts: one v_perm_b32 takes bits 8..23 of both sums (|S| < 2^23), one
+// v_pk_ashrrev_i16 drops the remaining SHIFT - 8 bits.
+template <int C, int SHIFT>
+__device__ __forceinline__ void lane_samples(const unsigned (&up)[ndwords(C)], const unsigned (&lo)[ndwords(C)],
+                                             int wv0, int wv1, int (&out)[npairs(C)])
+{
+    static_assert(SHIFT >= 8 && SHIFT < 16, "the packing below takes bits 8..23 of each sum");
+    constexpr int NE = SEG * C, NV = (SEG + 1) * C;
+    constexpr int RND = 1 << (SHIFT - 1);
+    int V[NV];
+    ForEachElem<C, NV>::run([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        V[k] = column_pair<C, k>(up, lo);
+    });
+    int S[NE + 1];
+    S[NE] = 0;
+#pragma unroll
+    for (int k = 0; k < NE; k++)
+        S[k] = sdot2(V[k + C], wv1, sdot2_sconst(V[k], wv0, RND));
+#pragma unroll
+    for (int j = 0; j < npairs(C); j++) {
+        const int k0 = 2 * j, k1 = 2 * j + 1 < NE ? 2 * j + 1 : NE;
+        const int mid = (int)__builtin_amdgcn_perm((unsigned)S[k1], (unsigned)S[k0], 0x06050201u);  // bytes 1,2 of each
+        const short2v sh = {(short)(SHIFT - 8), (short)(SHIFT - 8)};
+        out[j] = __builtin_bit_cast(int, (short2v)(__builtin_bit_cast(short2v, mid) >> sh));
+    }
+}
+
+// low (HI = false) or high (HI = true) int16 halves of two dwords as a pair: (x.half, y.half)
+template <bool HI> __device__ __forceinline__ int half_pair(int x, int y)
+{
+    constexpr unsigned sel = HI ? 0x07060302u : 0x05040100u;
+    return (int)__builtin_amdgcn_perm((unsigned)y, (unsigned)x, sel);
+}
+
 // One lane's share of  sum (J - I) * {Ix, Iy}  (or sum |J - I| when ABS) over its 7*C patch
-// elements.  Per element: two v_perm_b32 build the neighbour pairs of both rows, two
-// v_dot2_i32_i16 apply the four 14-bit weights (pixel <= 255, -1 <= weight <= 2^14: exact);
-// per element PAIR: pack, one v_pk_sub_i16 against the packed template, two v_dot2_i32_i16
-// against the packed derivatives.
+// elements: lane_samples, then per element PAIR one v_pk_sub_i16 against the packed template and
+// two v_dot2_i32_i16 against the packed derivatives.
 template <int C, bool ABS>
-__device__ __forceinline__ void lane_residual(const uint8_t *lds, int off, int wp0, int wp1,
+__device__ __forceinline__ void lane_residual(const uint8_t *lds, int off, int wv0, int wv1,
                                               const int (&Ivp)[npairs(C)], const int (&Ixp)[npairs(C)],
                                               const int (&Iyp)[npairs(C)], int &s1, int &s2)
 {
     constexpr int NE = SEG * C;
-    constexpr int RND = 1 << (W_BITS - 5 - 1);
     unsigned r0[ndwords(C)], r1[ndwords(C)];
     load_row_packed<C>(lds, off, r0);
     load_row_packed<C>(lds, off + Tile<C, TS>::ROW, r1);
-    int v[NE + 1];
-    v[NE] = 0;
-    ForEachElem<C, NE>::run([&](auto kc) {
-        constexpr int k = decltype(kc)::value;
-        v[k] = sdot2(pixel_pair<C, k>(r1), wp1, sdot2_sconst(pixel_pair<C, k>(r0), wp0, RND)) >> (W_BITS - 5);
-    });
+    int Jp[npairs(C)];
+    lane_samples<C, W_BITS - 5>(r0, r1, wv0, wv1, Jp);
     s1 = 0;
     s2 = 0;
 #pragma unroll
     for (int j = 0; j < npairs(C); j++) {
-        const int k0 = 2 * j, k1 = 2 * j + 1 < NE ? 2 * j + 1 : NE;  // v[NE] == 0 pads an odd count
-        // 0 <= v < 2^15: the low halves of the two words, packed by one v_perm_b32
-        const short2v d = __builtin_bit_cast(short2v, half_pair<false>(v[k0], v[k1])) - __builtin_bit_cast(short2v, Ivp[j]);
+        const short2v d = __builtin_bit_cast(short2v, Jp[j]) - __builtin_bit_cast(short2v, Ivp[j]);
         if (ABS) {
             int d0 = d.x, d1 = d.y;
             s1 += (d0 < 0 ? -d0 : d0) + (2 * j + 1 < NE ? (d1 < 0 ? -d1 : d1) : 0);
@@ -375,14 +427,13 @@ __global__ __launch_bounds__(64 * WAVES, 4) void lk_track_kernel(LkBatch batch, 
             const int toff = (int)(Ts - lds) + (wy + 1) * TROW + (wx + 1) * C;
             load_row_packed<C>(lds, toff, t0);
             load_row_packed<C>(lds, toff + TROW, t1);
+            lane_samples<C, W_BITS - 5>(t0, t1, (w00 & 0xffff) | (w10 << 16), (w01 & 0xffff) | (w11 << 16), Ivp);
             const int *d0 = D + (wy * DT + wx) * C;
             const int *d1 = d0 + DT * C;
-            int iv[NE + 1], ix[NE + 1], iy[NE + 1];
-            iv[NE] = ix[NE] = iy[NE] = 0;
+            int ix[NE + 1], iy[NE + 1];
+            ix[NE] = iy[NE] = 0;
             ForEachElem<C, NE>::run([&](auto kc) {
                 constexpr int k = decltype(kc)::value;
-                iv[k] = sdot2(pixel_pair<C, k>(t1), wp1, sdot2(pixel_pair<C, k>(t0), wp0, 1 << (W_BITS - 5 - 1))) >>
-                        (W_BITS - 5);
                 // derivative tile entries are (dx | dy << 16); |derivative| <= 4080: exact in int16 pairs
                 const int p00 = d0[k], p01 = d0[k + C], p10 = d1[k], p11 = d1[k + C];
                 constexpr int RD = 1 << (W_BITS - 1);
@@ -392,7 +443,6 @@ __global__ __launch_bounds__(64 * WAVES, 4) void lk_track_kernel(LkBatch batch, 
 #pragma unroll
             for (int j = 0; j < npairs(C); j++) {
                 const int k0 = 2 * j, k1 = 2 * j + 1 < NE ? 2 * j + 1 : NE;
-                Ivp[j] = iv[k0] | (iv[k1] << 16);
                 Ixp[j] = (ix[k0] & 0xffff) | (ix[k1] << 16);
                 Iyp[j] = (iy[k0] & 0xffff) | (iy[k1] << 16);
                 a11 = sdot2(Ixp[j], Ixp[j], a11);  // sums of squares of int16 pairs, exact
@@ -445,14 +495,16 @@ __global__ __launch_bounds__(64 * WAVES, 4) void lk_track_kernel(LkBatch batch, 
             bilinear_weights(nxp - (float)inx, nyp - (float)iny, w00, w01, w10, w11);
             int s1, s2;
             lane_residual<C, false>(lds, (int)(TJs - lds) + (iny - oy + wy) * Tile<C, TS>::ROW + (inx - ox + wx) * C,
-                                    (w00 & 0xffff) | (w01 << 16), (w10 & 0xffff) | (w11 << 16), Ivp, Ixp, Iyp, s1,
+                                    (w00 & 0xffff) | (w10 << 16), (w01 & 0xffff) | (w11 << 16), Ivp, Ixp, Iyp, s1,
                                     s2);
             if (!active) {
                 s1 = 0;
                 s2 = 0;
             }
-            const float b1 = (float)wave_sum_exact(s1) * FLT_SCALE;
-            const float b2 = (float)wave_sum_exact(s2) * FLT_SCALE;
+            float b1, b2;
+            wave_sum2_float(s1, s2, b1, b2);
+            b1 *= FLT_SCALE;
+            b2 *= FLT_SCALE;
             const float dx = (A12 * b2 - A22 * b1) * Dd;
             const float dy = (A12 * b1 - A11 * b2) * Dd;
             nxp += dx;
@@ -491,7 +543,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void lk_track_kernel(LkBatch batch, 
             bilinear_weights(qx - (float)iqx, qy - (float)iqy, w00, w01, w10, w11);
             int s1, s2;
             lane_residual<C, true>(lds, (int)(TJs - lds) + (iqy - oy + wy) * Tile<C, TS>::ROW + (iqx - ox + wx) * C,
-                                   (w00 & 0xffff) | (w01 << 16), (w10 & 0xffff) | (w11 << 16), Ivp, Ixp, Iyp, s1,
+                                   (w00 & 0xffff) | (w10 << 16), (w01 & 0xffff) | (w11 << 16), Ivp, Ixp, Iyp, s1,
                                    s2);
             if (!active)
                 s1 = 0;
