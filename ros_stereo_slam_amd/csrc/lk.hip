@@ -318,9 +318,9 @@ __global__ __launch_bounds__(64 * WAVES, 4) void lk_track_kernel(LkBatch batch, 
     // XCD-aware point order: workgroups go to the 8 XCDs round-robin, keypoints arrive in raster
     // order, so XCD x is given the x-th contiguous eighth of the list -- one band of the image.
     // Each XCD's L2 then fetches its band of both pyramids once instead of all of them.
-    const int slot = blockIdx.x * WAVES + wave, band = (n + 7) >> 3;
-    const int p = (slot & 7) * band + (slot >> 3);
-    if ((slot >> 3) >= band || p >= n)
+    const int band = (n + 7) >> 3, in_band = (blockIdx.x >> 3) * WAVES + wave;
+    const int p = (blockIdx.x & 7) * band + in_band;
+    if (in_band >= band || p >= n)
         return;  // whole wave leaves; no workgroup barrier is used below
     uint8_t *lds = smem + wave * Lds<C>::WAVE_BYTES;
     uint8_t *T = lds;                                           // PT x PT x C bytes
@@ -604,7 +604,7 @@ int svo_launch_lk_batch(svo_ctx *ctx, int n_jobs, const LkJob *jobs)
     prm.max_count = 30;
     prm.eps_sq = 0.01 * 0.01;
     prm.min_eig_thr = (float)1e-4;
-    dim3 grid(((n_max + 7) / 8) * 8, n_jobs), block(64 * WAVES);  // x: a multiple of 8, every XCD band has all its slots
+    dim3 grid(((n_max + 7) / 8 + WAVES - 1) / WAVES * 8, n_jobs), block(64 * WAVES);  // x: a multiple of 8, every XCD band has all its slots
     ScopedKernelTime t(ctx, SVO_K_LK);
     switch (c) {
     case 1:

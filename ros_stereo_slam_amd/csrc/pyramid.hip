@@ -24,6 +24,11 @@ __device__ __forceinline__ int reflect101(int p, int len)
 }
 
 constexpr int TW = 32, TH = 8;
+// Workgroups of ONE wave: beside a tracking launch, whose single-wave workgroups take every wave
+// slot the moment it frees, a multi-wave workgroup waits until a CU has several slots free at once
+// (measured: the pyramid stage 2.4x longer with 256-thread workgroups; the chip's throughput is the
+// same either way -- the tracking launch gives up exactly the slots the pyramids win).
+constexpr int PB = 64;
 constexpr int SW = 2 * TW + 3, SH = 2 * TH + 3;
 
 // several pyramids of the same geometry per launch: blockIdx.z picks the job
@@ -33,7 +38,7 @@ struct PyrPtrs {
 };
 
 template <int C>
-__global__ __launch_bounds__(256) void pyr_down_kernel(PyrPtrs ptrs, int spitch, int w, int h, int dpitch, int dw,
+__global__ __launch_bounds__(PB) void pyr_down_kernel(PyrPtrs ptrs, int spitch, int w, int h, int dpitch, int dw,
                                                        int dh)
 {
     __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
@@ -52,13 +57,13 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(PyrPtrs ptrs, int spitch,
         // of 16, so every row of the tile starts at the same byte shift)
         sh = (x0 * C) & 3;
         const uint8_t *base = src + (ptrdiff_t)y0 * spitch + x0 * C - sh;
-        for (int i = tid; i < SH * SDW; i += 256) {
+        for (int i = tid; i < SH * SDW; i += PB) {
             const int r = i / SDW, d = i - r * SDW;
             reinterpret_cast<uint32_t *>(s_src + r * SROW)[d] =
                 reinterpret_cast<const uint32_t *>(base + (ptrdiff_t)r * spitch)[d];
         }
     } else {
-        for (int i = tid; i < SH * SW * C; i += 256) {
+        for (int i = tid; i < SH * SW * C; i += PB) {
             int r = i / (SW * C), cc = i - r * (SW * C);
             int px = cc / C, ch = cc - px * C;
             int sx = reflect101(x0 + px, w);
@@ -67,7 +72,7 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(PyrPtrs ptrs, int spitch,
         }
     }
     __syncthreads();
-    for (int i = tid; i < SH * TW * C; i += 256) {
+    for (int i = tid; i < SH * TW * C; i += PB) {
         int r = i / (TW * C), cc = i - r * (TW * C);
         int x = cc / C, ch = cc - x * C;
         const uint8_t *sp = s_src + r * SROW + sh + (2 * x) * C + ch;
@@ -76,7 +81,7 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(PyrPtrs ptrs, int spitch,
     __syncthreads();
     // vertical pass; a thread produces four consecutive bytes of an output row = one aligned dword
     // (ox * C and dpitch are multiples of 4), bytes beyond the level's width are not stored
-    for (int i = tid; i < TH * (TW * C / 4); i += 256) {
+    for (int i = tid; i < TH * (TW * C / 4); i += PB) {
         const int y = i / (TW * C / 4), q = i - y * (TW * C / 4);
         const int Y = oy + y;
         if (Y >= dh)
@@ -103,7 +108,7 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(PyrPtrs ptrs, int spitch,
 
 // image (row stride w*C) -> padded level 0, one thread per output dword
 template <int C>
-__global__ __launch_bounds__(256) void pad_copy_kernel(PyrPtrs ptrs, int w, int h, int pitch)
+__global__ __launch_bounds__(PB) void pad_copy_kernel(PyrPtrs ptrs, int w, int h, int pitch)
 {
     __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     const uint8_t *__restrict__ src = ptrs.src[blockIdx.z];
@@ -146,7 +151,7 @@ struct BorderJob {
 
 // fills the reflect-101 border of levels 1.. (blockIdx.z = level - 1) from their interior
 template <int C>
-__global__ __launch_bounds__(256) void fill_border_kernel(BorderJob job)
+__global__ __launch_bounds__(PB) void fill_border_kernel(BorderJob job)
 {
     __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     const int jb = blockIdx.z / job.levels_m1, l = blockIdx.z - jb * job.levels_m1 + 1;
@@ -190,8 +195,8 @@ template <int C> static int build_levels(svo_ctx *ctx, int k, svo_pyramid *const
             pp.src[a] = d_images[a < k ? a : 0];
             pp.dst[a] = pyrs[a < k ? a : 0]->base + pyrs[a < k ? a : 0]->off[0];
         }
-        dim3 grid(((d.pitch[0] >> 2) + 255) / 256, d.h[0] + 2 * SVO_PYR_PAD, k);
-        hipLaunchKernelGGL(pad_copy_kernel<C>, grid, dim3(256), 0, ctx->stream, pp, d.w[0], d.h[0], d.pitch[0]);
+        dim3 grid(((d.pitch[0] >> 2) + PB - 1) / PB, d.h[0] + 2 * SVO_PYR_PAD, k);
+        hipLaunchKernelGGL(pad_copy_kernel<C>, grid, dim3(PB), 0, ctx->stream, pp, d.w[0], d.h[0], d.pitch[0]);
     }
     for (int l = 1; l < p0->levels; l++) {
         PyrPtrs pp;
@@ -200,7 +205,7 @@ template <int C> static int build_levels(svo_ctx *ctx, int k, svo_pyramid *const
             pp.dst[a] = pyrs[a < k ? a : 0]->origin(l);
         }
         dim3 grid((d.w[l] + TW - 1) / TW, (d.h[l] + TH - 1) / TH, k);
-        hipLaunchKernelGGL(pyr_down_kernel<C>, grid, dim3(256), 0, ctx->stream, pp, d.pitch[l - 1], d.w[l - 1],
+        hipLaunchKernelGGL(pyr_down_kernel<C>, grid, dim3(PB), 0, ctx->stream, pp, d.pitch[l - 1], d.w[l - 1],
                            d.h[l - 1], d.pitch[l], d.w[l], d.h[l]);
     }
     if (p0->levels > 1) {
@@ -214,8 +219,8 @@ template <int C> static int build_levels(svo_ctx *ctx, int k, svo_pyramid *const
             job.h[l] = d.h[l];
         }
         job.levels_m1 = p0->levels - 1;
-        dim3 grid(((d.pitch[1] >> 2) + 255) / 256, d.h[1] + 2 * SVO_PYR_PAD, (p0->levels - 1) * k);
-        hipLaunchKernelGGL(fill_border_kernel<C>, grid, dim3(256), 0, ctx->stream, job);
+        dim3 grid(((d.pitch[1] >> 2) + PB - 1) / PB, d.h[1] + 2 * SVO_PYR_PAD, (p0->levels - 1) * k);
+        hipLaunchKernelGGL(fill_border_kernel<C>, grid, dim3(PB), 0, ctx->stream, job);
     }
     SVO_HIP(hipGetLastError());
     return SVO_OK;
