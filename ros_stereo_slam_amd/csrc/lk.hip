@@ -41,6 +41,7 @@ struct LkParams {
     int max_level;
     int max_count;
     double eps_sq;
+    float eps_pre;  // a step with max(|dx|, |dy|) above this cannot pass the eps_sq test (1.01 * sqrt(eps_sq))
     float min_eig_thr;
 };
 static_assert(sizeof(LkBatch) + sizeof(LkParams) <= 4096, "kernel arguments are limited to 4 KB");
@@ -268,6 +269,14 @@ template <bool HI> __device__ __forceinline__ int half_pair(int x, int y)
     return (int)__builtin_amdgcn_perm((unsigned)y, (unsigned)x, sel);
 }
 
+// dot(a, b): the accumulator of a chain starts here, no v_mov 0 needed
+__device__ __forceinline__ int sdot2_first(int a, int b)
+{
+    int d;
+    asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
 // One lane's share of  sum (J - I) * {Ix, Iy}  (or sum |J - I| when ABS) over its 7*C patch
 // elements: lane_samples, then per element PAIR one v_pk_sub_i16 against the packed template and
 // two v_dot2_i32_i16 against the packed derivatives.
@@ -290,6 +299,9 @@ __device__ __forceinline__ void lane_residual(const uint8_t *lds, int off, int w
         if (ABS) {
             int d0 = d.x, d1 = d.y;
             s1 += (d0 < 0 ? -d0 : d0) + (2 * j + 1 < NE ? (d1 < 0 ? -d1 : d1) : 0);
+        } else if (j == 0) {
+            s1 = sdot2_first(__builtin_bit_cast(int, d), Ixp[j]);
+            s2 = sdot2_first(__builtin_bit_cast(int, d), Iyp[j]);
         } else {
             s1 = sdot2(__builtin_bit_cast(int, d), Ixp[j], s1);
             s2 = sdot2(__builtin_bit_cast(int, d), Iyp[j], s2);
@@ -474,6 +486,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void lk_track_kernel(LkBatch batch, 
         nxp -= half;
         nyp -= half;
         float pdx = 0.f, pdy = 0.f;
+        const int lane_off = wy * Tile<C, TS>::ROW + wx * C;  // this lane's row run inside the window
         int ox = 0, oy = 0;
         bool have_tile = false;
         const uint8_t *TJs = TJ;
@@ -494,7 +507,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void lk_track_kernel(LkBatch batch, 
             }
             bilinear_weights(nxp - (float)inx, nyp - (float)iny, w00, w01, w10, w11);
             int s1, s2;
-            lane_residual<C, false>(lds, (int)(TJs - lds) + (iny - oy + wy) * Tile<C, TS>::ROW + (inx - ox + wx) * C,
+            lane_residual<C, false>(lds, lane_off + uniform((int)(TJs - lds) + (iny - oy) * Tile<C, TS>::ROW + (inx - ox) * C),
                                     (w00 & 0xffff) | (w10 << 16), (w01 & 0xffff) | (w11 << 16), Ivp, Ixp, Iyp, s1,
                                     s2);
             if (!active) {
@@ -511,9 +524,13 @@ __global__ __launch_bounds__(64 * WAVES, 4) void lk_track_kernel(LkBatch batch, 
             nyp += dy;
             outx = nxp + half;
             outy = nyp + half;
-            if (uniform((double)dx * (double)dx + (double)dy * (double)dy <= prm.eps_sq))
+            // |dx|^2 + |dy|^2 <= eps^2 in double, as the reference; only a step that is small in float
+            // can pass, so the double arithmetic is skipped for all the others
+            if (uniform(fmaxf(fabsf(dx), fabsf(dy)) <= prm.eps_pre) &&
+                uniform((double)dx * (double)dx + (double)dy * (double)dy <= prm.eps_sq))
                 break;
-            if (j > 0 && uniform(fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01)) {
+            // fabs((double)x) < 0.01  <=>  |x| <= 0.01f for a float x: 0.01f is the largest float below 0.01
+            if (j > 0 && uniform(fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f)) {
                 outx -= dx * 0.5f;
                 outy -= dy * 0.5f;
                 break;
@@ -542,7 +559,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void lk_track_kernel(LkBatch batch, 
             }
             bilinear_weights(qx - (float)iqx, qy - (float)iqy, w00, w01, w10, w11);
             int s1, s2;
-            lane_residual<C, true>(lds, (int)(TJs - lds) + (iqy - oy + wy) * Tile<C, TS>::ROW + (iqx - ox + wx) * C,
+            lane_residual<C, true>(lds, lane_off + uniform((int)(TJs - lds) + (iqy - oy) * Tile<C, TS>::ROW + (iqx - ox) * C),
                                    (w00 & 0xffff) | (w10 << 16), (w01 & 0xffff) | (w11 << 16), Ivp, Ixp, Iyp, s1,
                                    s2);
             if (!active)
@@ -603,6 +620,7 @@ int svo_launch_lk_batch(svo_ctx *ctx, int n_jobs, const LkJob *jobs)
     prm.max_level = levels - 1;
     prm.max_count = 30;
     prm.eps_sq = 0.01 * 0.01;
+    prm.eps_pre = 0.0101f;
     prm.min_eig_thr = (float)1e-4;
     dim3 grid(((n_max + 7) / 8 + WAVES - 1) / WAVES * 8, n_jobs), block(64 * WAVES);  // x: a multiple of 8, every XCD band has all its slots
     ScopedKernelTime t(ctx, SVO_K_LK);
