@@ -53,6 +53,7 @@ struct svo_vo {
     float *ref2d = nullptr, *ref3d = nullptr, *trk2d = nullptr, *trk3d = nullptr;
     float *a2 = nullptr, *b2 = nullptr, *c2 = nullptr, *d2 = nullptr, *a3 = nullptr, *b3 = nullptr, *resp = nullptr;
     uint8_t *status = nullptr, *mask = nullptr, *st2 = nullptr;
+    float *grid_xy = nullptr;  // the keypoint lattice of src/triangulation.cpp:89-96, written once at creation
     int *idx = nullptr, *d_cnt = nullptr;  // d_cnt[0..7]: stage counts
     PnpRecord *d_rec = nullptr;
     uint8_t *d_img = nullptr;  // staging for host images
@@ -168,6 +169,17 @@ __global__ void gather_batch_kernel(GatherBatch b, int cap)
     b.out_s[q][i] = b.in_s[q][j];
 }
 
+// the counts of k jobs into the context's pinned block, one launch (k host copies otherwise)
+struct CountBatch {
+    const int *src[SVO_LK_MAX_JOBS];
+};
+__global__ void store_counts_kernel(CountBatch b, int k, int *__restrict__ dst)
+{
+    __builtin_amdgcn_s_setprio(3);
+    if ((int)threadIdx.x < k)
+        dst[threadIdx.x] = *b.src[threadIdx.x];
+}
+
 // visualSLAM::stereoTriangulate, dense branch (src/triangulation.cpp:87-103,137-165), with
 // the optional ANMS stage, for k front-ends of one context at once (same image size, grid step
 // and ANMS budget): every stage is one set of launches.  Per front-end: x1 -> out2d, camera-frame
@@ -183,13 +195,11 @@ int stereo_triangulate_batch(int k, svo_vo *const *vs, svo_pyramid *const *lefts
     LkJob lk[SVO_LK_MAX_JOBS];
     for (int a = 0; a < k; a++) {
         svo_vo *v = vs[a];
-        if ((rc = svo_launch_grid(ctx, v->h, v->w, v->prm.grid_step, v->a2, n)))
-            return rc;
         // denseLKtracking: LK left -> right (src/tracking.cpp:18); min-eig is the ANMS response
         LkJob &q = lk[a];
         q.prev = lefts[a]->dev;
         q.next = rights[a]->dev;
-        q.prev_pts = v->a2;
+        q.prev_pts = v->grid_xy;
         q.n_cap = n;
         q.d_n = nullptr;
         q.next_pts = v->b2;
@@ -203,7 +213,7 @@ int stereo_triangulate_batch(int k, svo_vo *const *vs, svo_pyramid *const *lefts
     const uint8_t *stt[SVO_LK_MAX_JOBS];
     const int *d_n[SVO_LK_MAX_JOBS];
     for (int a = 0; a < k; a++) {
-        pts[a] = vs[a]->a2;
+        pts[a] = vs[a]->grid_xy;
         trk[a] = vs[a]->b2;
         stt[a] = vs[a]->status;
         d_n[a] = nullptr;
@@ -215,14 +225,14 @@ int stereo_triangulate_batch(int k, svo_vo *const *vs, svo_pyramid *const *lefts
         for (int a = 0; a < SVO_LK_MAX_JOBS; a++) {
             svo_vo *v = vs[a < k ? a : 0];
             if (a < k) {
-                xy[a] = v->a2;
+                xy[a] = v->grid_xy;
                 resp[a] = v->resp;
                 oidx[a] = v->idx;
                 ocnt[a] = v->d_cnt + 2;
             }
             gb.idx[a] = v->idx;
             gb.d_count[a] = v->d_cnt + 2;
-            gb.in_a[a] = reinterpret_cast<const float2 *>(v->a2);
+            gb.in_a[a] = reinterpret_cast<const float2 *>(v->grid_xy);
             gb.out_a[a] = reinterpret_cast<float2 *>(v->c2);
             gb.in_b[a] = reinterpret_cast<const float2 *>(v->b2);
             gb.out_b[a] = reinterpret_cast<float2 *>(v->d2);
@@ -245,7 +255,7 @@ int stereo_triangulate_batch(int k, svo_vo *const *vs, svo_pyramid *const *lefts
     svo_tri_job tj[SVO_LK_MAX_JOBS];
     for (int a = 0; a < k; a++) {
         svo_vo *v = vs[a];
-        float *o1 = pts[a] == v->a2 ? v->c2 : v->a2, *o2 = pts[a] == v->a2 ? v->d2 : v->b2;
+        float *o1 = pts[a] == v->grid_xy ? v->c2 : v->a2, *o2 = pts[a] == v->grid_xy ? v->d2 : v->b2;
         float *x1 = out2d[a], *x2 = o1 == v->a2 ? v->c2 : v->a2;
         c1[a] = {stt[a], n, d_n[a], {pts[a], trk[a], nullptr}, {o1, o2, nullptr}, {2, 2, 0}, v->d_cnt + 3};
         // FmatThresholding (src/tracking.cpp:30-43): 3 px, 0.99
@@ -260,8 +270,11 @@ int stereo_triangulate_batch(int k, svo_vo *const *vs, svo_pyramid *const *lefts
         (rc = svo_launch_compact_batch(ctx, k, c2)) || (rc = svo_launch_triangulate_batch(ctx, P1, P2, k, tj)))
         return rc;
     int *pin = reinterpret_cast<int *>(ctx->pinned);
-    for (int a = 0; a < k; a++)
-        SVO_HIP(hipMemcpyAsync(pin + a, vs[a]->d_cnt + 4, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    CountBatch cb;
+    for (int a = 0; a < SVO_LK_MAX_JOBS; a++)
+        cb.src[a] = vs[a < k ? a : 0]->d_cnt + 4;
+    hipLaunchKernelGGL(store_counts_kernel, dim3(1), dim3(64), 0, ctx->stream, cb, k, pin);
+    SVO_HIP(hipGetLastError());
     if ((rc = svo_wait(ctx)))
         return rc;
     for (int a = 0; a < k; a++)
@@ -326,7 +339,9 @@ int svo_vo_create(svo_ctx *ctx, const svo_vo_params *params, int width, int heig
         (rc = dev_alloc(&v->d2, n * 2)) || (rc = dev_alloc(&v->a3, n * 3)) || (rc = dev_alloc(&v->b3, n * 3)) ||
         (rc = dev_alloc(&v->resp, n)) || (rc = dev_alloc(&v->status, n)) || (rc = dev_alloc(&v->mask, n)) ||
         (rc = dev_alloc(&v->st2, n)) || (rc = dev_alloc(&v->idx, n)) || (rc = dev_alloc(&v->d_cnt, 16)) ||
-        (rc = dev_alloc(&v->d_rec, 2)) || (rc = dev_alloc(&v->d_img, (size_t)width * height * channels))) {
+        (rc = dev_alloc(&v->d_rec, 2)) || (rc = dev_alloc(&v->d_img, (size_t)width * height * channels)) ||
+        (rc = dev_alloc(&v->grid_xy, n * 2)) ||
+        (rc = svo_launch_grid(ctx, height, width, params->grid_step, v->grid_xy, (int)n))) {
         svo_vo_destroy(v);
         return rc;
     }
@@ -367,7 +382,8 @@ int svo_vo_destroy(svo_vo *v)
     if (v->sstatus)
         (void)hipFree(v->sstatus);
     void *bufs[] = {v->ref2d, v->ref3d, v->trk2d, v->trk3d, v->a2,   v->b2,    v->c2,    v->d2,   v->a3,
-                    v->b3,    v->resp,  v->status, v->mask, v->st2, v->idx,   v->d_cnt, v->d_rec, v->d_img};
+                    v->b3,    v->resp,  v->status, v->mask, v->st2, v->idx,   v->d_cnt, v->d_rec, v->d_img,
+                    v->grid_xy};
     for (void *b : bufs)
         if (b)
             (void)hipFree(b);

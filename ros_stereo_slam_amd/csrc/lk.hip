@@ -144,25 +144,41 @@ __device__ __forceinline__ int stage_tile(uint8_t *tile, const uint8_t *__restri
                                           int oy, int lane)
 {
     using TL = Tile<C, SIDE>;
-    const uint8_t *origin = lvl + (ptrdiff_t)oy * pitch + (ptrdiff_t)ox * C;
-    const int shift = (int)(reinterpret_cast<uintptr_t>(origin) & 15);
-    const uint8_t *a16 = origin - shift;
-    constexpr int N = SIDE * TL::VEC;
-    constexpr int ITER = (N + 63) / 64;
-    uint4 v[ITER];
+    // wave-uniform base (said so explicitly: the loads then take an SGPR base + a 32-bit lane offset
+    // instead of 64-bit lane addresses that would be kept live -- and spilled -- across the levels)
+    const int off = oy * pitch + ox * C;  // inside one padded level: fits 32 bits
+    const int shift = (int)(((unsigned)reinterpret_cast<uintptr_t>(lvl) + (unsigned)off) & 15u);
+    const uint8_t *a16 = lvl + (ptrdiff_t)__builtin_amdgcn_readfirstlane(off - shift);
+    // lane -> (row group, 16-byte vector): LPR lanes per row (the lanes past VEC repeat the last
+    // vector), RPI rows per step; the k-th step differs from the first by k * RPI rows only, which
+    // goes into the scalar base and the ds_write immediate -- one lane offset for all the loads,
+    // written out as SGPR base + 32-bit lane offset (left to itself the compiler forms 64-bit lane
+    // addresses per load and level, keeps them across the iteration loop and spills)
+    constexpr int LPR = TL::VEC <= 4 ? 4 : 8, RPI = 64 / LPR, ITER = (SIDE + RPI - 1) / RPI;
+    static_assert(TL::VEC <= LPR, "row wider than a lane group");
+    const unsigned r0 = (unsigned)lane / LPR, vv = min((unsigned)lane % LPR, (unsigned)TL::VEC - 1);
+    typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+    uint4v v[ITER];
+    unsigned goff[ITER];
 #pragma unroll
     for (int k = 0; k < ITER; k++) {
-        int i = lane + 64 * k;
-        if (N % 64 != 0 && i >= N)
-            i = N - 1;
-        int r = i / TL::VEC, vv = i - r * TL::VEC;
-        v[k] = *reinterpret_cast<const uint4 *>(a16 + (ptrdiff_t)r * pitch + vv * 16);
+        // the last step may reach past the tile: those lanes repeat the last row
+        const bool clamp = (k + 1) * RPI > SIDE;
+        goff[k] = (clamp ? min(r0, (unsigned)(SIDE - 1 - k * RPI)) : r0) * (unsigned)pitch + vv * 16u;
+        asm volatile("global_load_dwordx4 %0, %1, %2"
+                     : "=&v"(v[k])
+                     : "v"(goff[k]), "s"(a16 + (ptrdiff_t)(k * RPI) * pitch)
+                     : "memory");
     }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0])::"memory");
+#pragma unroll
+    for (int k = 1; k < ITER; k++)
+        asm volatile("" : "+v"(v[k]));
 #pragma unroll
     for (int k = 0; k < ITER; k++) {
-        int i = lane + 64 * k;
-        if (N % 64 == 0 || i < N)
-            *reinterpret_cast<uint4 *>(tile + i * 16) = v[k];
+        const bool clamp = (k + 1) * RPI > SIDE;
+        const unsigned r = clamp ? min(r0, (unsigned)(SIDE - 1 - k * RPI)) : r0;
+        *reinterpret_cast<uint4v *>(tile + (k * RPI + r) * TL::ROW + vv * 16) = v[k];
     }
     return shift;
 }
