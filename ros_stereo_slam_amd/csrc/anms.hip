@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void anms_rank_kernel(AnmsBatch batch, int n)
     int *__restrict__ order = job.order;
     float4 *__restrict__ sorted = job.sorted;
     const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int i = blockIdx.x;  // one wave per workgroup (see svo_launch_anms_batch)
     if (i >= n)
         return;
     const float ri = resp[i];
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void anms_radius_kernel(AnmsBatch batch, int n
     const float4 *__restrict__ sorted = batch.j[blockIdx.y].sorted;
     double *__restrict__ radius_sq = batch.j[blockIdx.y].radius;
     const int lane = threadIdx.x & 63;
-    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int s = blockIdx.x;
     if (s >= n)
         return;
     const float4 me = sorted[s];
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void anms_decide_kernel(AnmsBatch batch, int n
     const double *__restrict__ radius_sq = batch.j[blockIdx.y].radius;
     double *__restrict__ decision = batch.j[blockIdx.y].decision;
     const int lane = threadIdx.x & 63;
-    const int s = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int s = blockIdx.x;
     if (s >= n)
         return;
     const double ri = radius_sq[s];
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void anms_flag_kernel(AnmsBatch batch, int n)
     const double *__restrict__ radius_sq = batch.j[blockIdx.y].radius;
     const double *__restrict__ decision = batch.j[blockIdx.y].decision;
     uint8_t *__restrict__ flags = batch.j[blockIdx.y].flags;
-    const int s = blockIdx.x * 256 + threadIdx.x;
+    const int s = blockIdx.x * 64 + threadIdx.x;
     if (s < n)
         flags[s] = radius_sq[s] >= *decision ? 1 : 0;
 }
@@ -212,7 +212,9 @@ int svo_launch_anms_batch(svo_ctx *ctx, int k, const float *const *xy, const flo
         j.out_idx = out_idx[q];
         j.d_count = d_count[q];
     }
-    const dim3 wgrid((n + 3) / 4, k), tgrid((n + 255) / 256, k), block(256);
+    // single-wave workgroups: beside a tracking launch (single-wave workgroups that take every freed wave
+    // slot at once) a multi-wave workgroup waits until one CU has a slot free on several SIMDs together
+    const dim3 wgrid(n, k), tgrid((n + 63) / 64, k), block(64);
     hipLaunchKernelGGL(anms_rank_kernel, wgrid, block, 0, ctx->stream, batch, n);
     if (n <= keep) {
         // everything is kept, in sorted order

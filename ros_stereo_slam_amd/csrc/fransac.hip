@@ -340,7 +340,7 @@ __device__ __forceinline__ float f_error(const double (&F)[9], float x1, float y
 
 // One wavefront per model.  The LAST workgroup to finish (ticket counter) also replays the
 // sequential RANSAC loop over the iterations scored so far -- what used to be a launch of its own.
-__global__ __launch_bounds__(256) void fr_score_kernel(FrBatch batch, int it0, int it1_cap)
+__global__ __launch_bounds__(64, 4) void fr_score_kernel(FrBatch batch, int it0, int it1_cap)
 {
     __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     const FrJob &job = batch.j[blockIdx.y];
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void fr_score_kernel(FrBatch batch, int it0, i
     const double confidence = job.confidence;
     unsigned *ticket = job.ticket;
     const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int w = __builtin_amdgcn_readfirstlane(blockIdx.x);  // one wave per workgroup
     const int it = it0 + w / 3, k = w - (w / 3) * 3;
     const bool skip_phase = it0 > 0 && st->done;  // the loop ended in the first phase
     const int n = d_n ? *d_n : n_host;
@@ -373,6 +373,7 @@ __global__ __launch_bounds__(256) void fr_score_kernel(FrBatch batch, int it0, i
             for (int i = 0; i < 9; i++)
                 F[i] = Fm[((size_t)it * 3 + k) * 9 + i];
             int cnt = 0;
+#pragma clang loop unroll(disable)  // unrolled, the f64 bodies take >128 VGPRs + scratch: the wave then needs two freed tracking slots
             for (int i = lane; i < n; i += 64) {
                 const float2 a = p1[i], b = p2[i];
                 cnt += f_error(F, a.x, a.y, b.x, b.y) <= thr ? 1 : 0;
@@ -502,9 +503,9 @@ int svo_launch_fransac_batch(svo_ctx *ctx, int n_jobs, const svo_fransac_job *jo
         const int iters = it1 - it0;
         hipLaunchKernelGGL(fr_solve_kernel, dim3((iters + SOLVE_T - 1) / SOLVE_T, nb), dim3(SOLVE_T), 0, ctx->stream,
                            batch, it0, it1);
-        hipLaunchKernelGGL(fr_score_kernel, dim3((iters * 3 + 3) / 4, nb), dim3(256), 0, ctx->stream, batch, it0, it1);
+        hipLaunchKernelGGL(fr_score_kernel, dim3(iters * 3, nb), dim3(64), 0, ctx->stream, batch, it0, it1);
     }
-    hipLaunchKernelGGL(fr_mask_kernel, dim3((cap_max + 255) / 256, nb), dim3(256), 0, ctx->stream, batch);
+    hipLaunchKernelGGL(fr_mask_kernel, dim3((cap_max + 63) / 64, nb), dim3(64), 0, ctx->stream, batch);
     SVO_HIP(hipGetLastError());
     return SVO_OK;
 }

@@ -241,7 +241,7 @@ int stereo_triangulate_batch(int k, svo_vo *const *vs, svo_pyramid *const *lefts
         }
         if ((rc = svo_launch_anms_batch(ctx, k, xy, resp, n, v0->prm.anms_keep, oidx, ocnt)))
             return rc;
-        hipLaunchKernelGGL(gather_batch_kernel, dim3((n + 255) / 256, k), dim3(256), 0, ctx->stream, gb, n);
+        hipLaunchKernelGGL(gather_batch_kernel, dim3((n + 63) / 64, k), dim3(64), 0, ctx->stream, gb, n);
         for (int a = 0; a < k; a++) {
             pts[a] = vs[a]->c2;
             trk[a] = vs[a]->d2;

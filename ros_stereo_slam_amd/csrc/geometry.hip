@@ -276,7 +276,7 @@ int svo_launch_triangulate_batch(svo_ctx *ctx, const double *P1, const double *P
     if (cap_max <= 0)
         return SVO_OK;
     ScopedKernelTime tm(ctx, SVO_K_TRIANGULATE);
-    hipLaunchKernelGGL(triangulate_kernel, dim3((cap_max + 127) / 128, k), dim3(128), 0, ctx->stream, to_mat34(P1),
+    hipLaunchKernelGGL(triangulate_kernel, dim3((cap_max + 63) / 64, k), dim3(64), 0, ctx->stream, to_mat34(P1),
                        to_mat34(P2), batch);
     SVO_HIP(hipGetLastError());
     return SVO_OK;

@@ -325,7 +325,7 @@ struct WaveLds {
     int pq[16];
 };
 
-__global__ __launch_bounds__(256) void pnp_solve_kernel(PnpBatch batch)
+__global__ __launch_bounds__(64, 2) void pnp_solve_kernel(PnpBatch batch)
 {
     __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     const PnpJob &job = batch.j[blockIdx.y];
@@ -338,14 +338,14 @@ __global__ __launch_bounds__(256) void pnp_solve_kernel(PnpBatch batch)
     const RansacState *__restrict__ st = job.st;
     double *__restrict__ hyp = job.hyp;
     int *__restrict__ nmodels = job.nmodels;
-    __shared__ WaveLds s_lds[4];
+    __shared__ WaveLds s_lds[1];
     const int lane = threadIdx.x & 63;
-    const int it = __builtin_amdgcn_readfirstlane(it0 + blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int it = __builtin_amdgcn_readfirstlane(it0 + blockIdx.x);  // one wave per workgroup
     if (it >= it1)
         return;
     if (it0 > 0 && st->done)
         return;
-    WaveLds &S = s_lds[threadIdx.x >> 6];
+    WaveLds &S = s_lds[0];
     const int n = d_n ? *d_n : n_host;
     if (n < MP) {
         if (lane == 0)
@@ -780,7 +780,7 @@ __device__ __forceinline__ float reproj_err_sq(const double (&P)[12], const K4 &
     return (float)((double)dx * dx + (double)dy * dy);
 }
 
-__global__ __launch_bounds__(256) void pnp_score_kernel(PnpBatch batch)
+__global__ __launch_bounds__(64, 4) void pnp_score_kernel(PnpBatch batch)
 {
     __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     const PnpJob &job = batch.j[blockIdx.y];
@@ -796,7 +796,7 @@ __global__ __launch_bounds__(256) void pnp_score_kernel(PnpBatch batch)
     const float thr = job.thr;
     int *__restrict__ counts = job.counts;
     const int lane = threadIdx.x & 63;
-    const int it = __builtin_amdgcn_readfirstlane(it0 + blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int it = __builtin_amdgcn_readfirstlane(it0 + blockIdx.x);  // one wave per workgroup
     if (it >= it1)
         return;
     if (it0 > 0 && st->done)
@@ -812,6 +812,7 @@ __global__ __launch_bounds__(256) void pnp_score_kernel(PnpBatch batch)
     for (int i = 0; i < 12; i++)
         P[i] = hyp[(size_t)it * 12 + i];
     int cnt = 0;
+#pragma clang loop unroll(disable)  // unrolled, the f64 bodies take >128 VGPRs + scratch: the wave then needs two freed tracking slots
     for (int i = lane; i < n; i += 64) {
         const float2 u = img[i];
         cnt += reproj_err_sq(P, K, obj[3 * i], obj[3 * i + 1], obj[3 * i + 2], u.x, u.y) <= thr ? 1 : 0;
@@ -1233,9 +1234,10 @@ int svo_launch_pnp_ransac_batch(svo_ctx *ctx, int n_jobs, const svo_pnp_job *job
     for (int k = nb; k < SVO_LK_MAX_JOBS; k++)
         batch.j[k] = batch.j[0];
     ScopedKernelTime tm(ctx, SVO_K_PNP);
-    const int nblk = (it_max + 3) / 4;
-    hipLaunchKernelGGL(pnp_solve_kernel, dim3(nblk, nb), dim3(256), 0, ctx->stream, batch);
-    hipLaunchKernelGGL(pnp_score_kernel, dim3(nblk, nb), dim3(256), 0, ctx->stream, batch);
+    // single-wave workgroups: they get wave slots beside a tracking launch as soon as one frees
+    const int nblk = it_max;
+    hipLaunchKernelGGL(pnp_solve_kernel, dim3(nblk, nb), dim3(64), 0, ctx->stream, batch);
+    hipLaunchKernelGGL(pnp_score_kernel, dim3(nblk, nb), dim3(64), 0, ctx->stream, batch);
     hipLaunchKernelGGL(pnp_finish_kernel, dim3(nb), dim3(256), 0, ctx->stream, batch);
     SVO_HIP(hipGetLastError());
     return SVO_OK;
