@@ -106,7 +106,8 @@ int svo_lk_track(svo_ctx *ctx, const svo_pyramid *prev, const svo_pyramid *next,
 /* replaces the push_back filters of src/tracking.cpp:20-27 (status), :35-42 and :66-84 (mask).
  * Up to three float arrays (a, b, c; stride = floats per element, NULL to skip) are compacted
  * with one mask; rows with mask == 1 are kept in order.  count: host int (SVO_MEM_HOST) or
- * device int (SVO_MEM_DEVICE).                                                              */
+ * device int (SVO_MEM_DEVICE).  Device outputs must not overlap the inputs (the segments of the
+ * array are compacted by independent wavefronts).                                           */
 int svo_compact(svo_ctx *ctx, const uint8_t *mask, int n, const float *in_a, int stride_a, float *out_a,
                 const float *in_b, int stride_b, float *out_b, const float *in_c, int stride_c, float *out_c,
                 int *count, int mem);

@@ -167,9 +167,11 @@ __global__ __launch_bounds__(256) void colors_kernel(const uint8_t *__restrict__
         out[3 * i + k] = (float)px[c >= 3 ? k : 0];
 }
 
-// Order-preserving compaction of up to three float arrays by a byte mask: one workgroup,
-// each thread owns a contiguous chunk; wave-level scan with DPP-free shuffles is not needed
-// at these sizes (N <= a few 10^4), a two-level LDS scan is enough.
+// Order-preserving compaction of up to three float arrays by a byte mask.  Single-wave workgroups
+// with no communication between them: wave w owns the w-th segment of `seg` elements and finds its
+// output base by counting the kept entries of the whole mask prefix itself (at most a few KB, 16
+// bytes per lane and load) -- redundant work, but no second launch, no look-back and no multi-wave
+// workgroup (which would wait for wave slots on several SIMDs of one CU beside a tracking launch).
 struct CompactArgs {
     const float *in[3];
     float *out[3];
@@ -183,42 +185,54 @@ struct CompactBatch {  // one workgroup per job
     CompactArgs j[SVO_LK_MAX_JOBS];
 };
 
-__global__ __launch_bounds__(1024) void compact_kernel(CompactBatch batch)
+__device__ __forceinline__ int wave_sum_int(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        v += __shfl_xor(v, o);
+    return v;
+}
+
+// number of bytes equal to 1 in a dword
+__device__ __forceinline__ int count_ones_bytes(uint32_t x)
+{
+    const uint32_t y = x ^ 0x01010101u;                                   // zero byte <=> the mask byte was 1
+    const uint32_t t = ~(((y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | y | 0x7f7f7f7fu);  // 0x80 in every zero byte
+    return __popc(t);
+}
+
+__global__ __launch_bounds__(64) void compact_kernel(CompactBatch batch, int seg)
 {
     __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
-    const CompactArgs &args = batch.j[blockIdx.x];
+    const CompactArgs &args = batch.j[blockIdx.y];
     const uint8_t *__restrict__ mask = args.mask;
-    const int n_host = args.n_host;
-    const int *__restrict__ d_n = args.d_n;
-    int *__restrict__ d_count = args.d_count;
-    // One workgroup of 16 waves walks the array in 1024-element strips.  Inside a wave the
-    // position of a kept element is a popcount of the ballot below its lane; wave totals are
-    // combined through 16 LDS words; the running base carries from strip to strip.
-    __shared__ int s_wave[16];
-    __shared__ int s_base;
-    const int n = d_n ? *d_n : n_host;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    if (t == 0)
-        s_base = 0;
-    __syncthreads();
-    for (int start = 0; start < n; start += 1024) {
-        const int i = start + t;
-        const bool keep = i < n && mask[i] == 1;
-        const unsigned long long bal = __ballot(keep);
-        const int below = __popcll(bal & ((1ull << lane) - 1ull));
-        if (lane == 0)
-            s_wave[wave] = __popcll(bal);
-        __syncthreads();
-        int wbase = 0, total = 0;
-#pragma unroll
-        for (int w = 0; w < 16; w++) {
-            const int c = s_wave[w];
-            wbase += w < wave ? c : 0;
-            total += c;
+    const int n = args.d_n ? *args.d_n : args.n_host;
+    const int lane = threadIdx.x;
+    const int first = blockIdx.x * seg;  // this wave's segment: [first, last)
+    if (first >= n && !(n <= 0 && blockIdx.x == 0))
+        return;
+    const int last = min(first + seg, n);
+    // kept entries before the segment
+    int part = 0;
+    if ((reinterpret_cast<uintptr_t>(mask) & 15) == 0) {
+        for (int i = lane * 16; i < first; i += 64 * 16) {  // `first` is a multiple of 64: whole dwords, all inside the prefix
+            const uint4 v = *reinterpret_cast<const uint4 *>(mask + i);
+            part += i + 0 < first ? count_ones_bytes(v.x) : 0;
+            part += i + 4 < first ? count_ones_bytes(v.y) : 0;
+            part += i + 8 < first ? count_ones_bytes(v.z) : 0;
+            part += i + 12 < first ? count_ones_bytes(v.w) : 0;
         }
-        const int base = s_base;
+    } else {
+        for (int i = lane; i < first; i += 64)
+            part += mask[i] == 1 ? 1 : 0;
+    }
+    int pos0 = __builtin_amdgcn_readfirstlane(wave_sum_int(part));
+    for (int start = first; start < last; start += 64) {
+        const int i = start + lane;
+        const bool keep = i < last && mask[i] == 1;
+        const unsigned long long bal = __ballot(keep);
         if (keep) {
-            const int pos = base + wbase + below;
+            const int pos = pos0 + __popcll(bal & ((1ull << lane) - 1ull));
 #pragma unroll
             for (int a = 0; a < 3; a++)
                 if (args.in[a]) {
@@ -227,13 +241,10 @@ __global__ __launch_bounds__(1024) void compact_kernel(CompactBatch batch)
                         args.out[a][(size_t)pos * st + k] = args.in[a][(size_t)i * st + k];
                 }
         }
-        __syncthreads();
-        if (t == 0)
-            s_base = base + total;
-        __syncthreads();
+        pos0 += __popcll(bal);
     }
-    if (t == 0 && d_count)
-        *d_count = s_base;
+    if (args.d_count && last >= n && lane == 0)  // the wave that owns the end of the array
+        *args.d_count = pos0;
 }
 
 Mat34 to_mat34(const double *p)
@@ -333,7 +344,12 @@ int svo_launch_compact_batch(svo_ctx *ctx, int n_jobs, const svo_compact_job *jo
         a.d_n = h.d_n;
         a.d_count = h.d_count;
     }
-    hipLaunchKernelGGL(compact_kernel, dim3(n_jobs), dim3(1024), 0, ctx->stream, batch);
+    int cap_max = 0;
+    for (int k = 0; k < n_jobs; k++)
+        cap_max = jobs[k].cap > cap_max ? jobs[k].cap : cap_max;
+    const int seg = ((cap_max + 15) / 16 + 63) / 64 * 64;  // 16 segments, whole 64-element strips
+    hipLaunchKernelGGL(compact_kernel, dim3(seg > 0 ? (cap_max + seg - 1) / seg : 1, n_jobs), dim3(64), 0, ctx->stream,
+                       batch, seg > 0 ? seg : 64);
     SVO_HIP(hipGetLastError());
     return SVO_OK;
 }
