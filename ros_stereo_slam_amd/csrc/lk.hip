@@ -415,34 +415,47 @@ __global__ __launch_bounds__(64 * WAVES, 4) void lk_track_kernel(LkBatch batch, 
             const bool cols_ok = ipx >= 0 && ipx + DT <= lw;  // wave-uniform: no per-entry column test needed
             const uint8_t *t = Ts + r * TROW + x0 * C;
             int *Drow = D + (r * DT + x0) * C;
+            // the whole 22x22 tile inside the image (wave-uniform, the usual case): no zeroing at all
+            const bool all_ok = cols_ok && ipy >= 0 && ipy + DT <= lh;
+            auto fill = [&](auto inside) {
+                constexpr bool INSIDE = decltype(inside)::value;
 #pragma unroll
-            for (int ch = 0; ch < C; ch++) {
-                int S0, S1, V0, V1;
-                {
-                    const int a = t[ch], b = t[TROW + ch], c = t[2 * TROW + ch];
-                    S0 = 3 * a + 10 * b + 3 * c;
-                    V0 = c - a;
-                }
-                {
-                    const int a = t[C + ch], b = t[TROW + C + ch], c = t[2 * TROW + C + ch];
-                    S1 = 3 * a + 10 * b + 3 * c;
-                    V1 = c - a;
-                }
+                for (int ch = 0; ch < C; ch++) {
+                    int S0, S1, V0, V1;
+                    {
+                        const int a = t[ch], b = t[TROW + ch], c = t[2 * TROW + ch];
+                        S0 = 3 * (a + c) + 10 * b;
+                        V0 = c - a;
+                    }
+                    {
+                        const int a = t[C + ch], b = t[TROW + C + ch], c = t[2 * TROW + C + ch];
+                        S1 = 3 * (a + c) + 10 * b;
+                        V1 = c - a;
+                    }
 #pragma unroll
-                for (int px = 0; px < HALF; px++) {
-                    const int o = (px + 2) * C + ch;
-                    const int a = t[o], b = t[TROW + o], c = t[2 * TROW + o];
-                    const int S2 = 3 * a + 10 * b + 3 * c, V2 = c - a;
-                    const int dx = S2 - S0, dy = 3 * V0 + 10 * V1 + 3 * V2;
-                    const int X = ipx + x0 + px;
-                    const bool ok = row_ok && (cols_ok || (X >= 0 && X < lw));
-                    Drow[px * C + ch] = ok ? ((dx & 0xffff) | (dy << 16)) : 0;
-                    S0 = S1;
-                    S1 = S2;
-                    V0 = V1;
-                    V1 = V2;
+                    for (int px = 0; px < HALF; px++) {
+                        const int o = (px + 2) * C + ch;
+                        const int a = t[o], b = t[TROW + o], c = t[2 * TROW + o];
+                        const int S2 = 3 * (a + c) + 10 * b, V2 = c - a;
+                        const int dx = S2 - S0, dy = 3 * (V0 + V2) + 10 * V1;
+                        int e = half_pair<false>(dx, dy);  // (dx & 0xffff) | (dy << 16), one v_perm_b32
+                        if (!INSIDE) {
+                            const int X = ipx + x0 + px;
+                            if (!(row_ok && (cols_ok || (X >= 0 && X < lw))))
+                                e = 0;
+                        }
+                        Drow[px * C + ch] = e;
+                        S0 = S1;
+                        S1 = S2;
+                        V0 = V1;
+                        V1 = V2;
+                    }
                 }
-            }
+            };
+            if (uniform(all_ok))
+                fill(std::true_type());
+            else
+                fill(std::false_type());
         }
         wave_lds_sync();
 
