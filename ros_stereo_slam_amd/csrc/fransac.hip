@@ -25,7 +25,7 @@ using namespace svo;
 namespace {
 
 constexpr int M = 7;
-constexpr int SOLVE_T = 64;
+constexpr int SOLVE_T = 16;  // 11 KB of LDS per workgroup: fits beside the waves of a tracking launch (44 KB with 64 waited for a CU to drain)
 constexpr int PHASE_A = 64;
 
 // One F-matrix RANSAC problem as the kernels see it; a launch may carry several (blockIdx.y picks

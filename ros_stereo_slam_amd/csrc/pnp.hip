@@ -914,26 +914,37 @@ constexpr int NACC = 28;  // [0] squared error, [1..21] upper-triangular J^T J, 
 
 // Fixed-order block reduction of the first NV of a thread's accumulators (256 threads):
 // every thread parks its partials in LDS ([value][thread], rows padded against bank
-// conflicts), thread (w*NV + k) adds the 64 partials of wave w for value k in lane order, and
+// conflicts), thread (w*CH + k) adds the 64 partials of wave w for value k in lane order, and
 // thread k adds the four wave totals.  The order never changes, so results are reproducible.
+// The values go through LDS RED_CHUNK at a time: the workgroup then needs 16 KB of LDS instead of
+// 59 KB and starts beside a tracking launch, whose waves leave about 24 KB of every CU's LDS free
+// (with the big buffer the kernel waited ~1 ms for a CU to drain).
 constexpr int RED_STRIDE = 257;
-template <int NV> __device__ void block_reduce(const double *v, double *s_all /*NACC*RED_STRIDE*/,
+constexpr int RED_CHUNK = 7;
+template <int NV> __device__ void block_reduce(const double *v, double *s_all /*RED_CHUNK*RED_STRIDE*/,
                                                double *s_part /*4*NACC*/, double *s_out /*NACC*/)
 {
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int k = 0; k < NV; k++)
-        s_all[k * RED_STRIDE + tid] = v[k];
-    __syncthreads();
-    if (tid < 4 * NV) {
-        const int w = tid / NV, k = tid - w * NV;
-        const double *src = s_all + k * RED_STRIDE + w * 64;
-        double x = 0;
-        for (int j = 0; j < 64; j++)
-            x += src[j];
-        s_part[w * NV + k] = x;
+    for (int c0 = 0; c0 < NV; c0 += RED_CHUNK) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int ch = NV - c0 < RED_CHUNK ? NV - c0 : RED_CHUNK;
+#pragma unroll
+        for (int k = 0; k < RED_CHUNK; k++)
+            if (k < ch)
+                s_all[k * RED_STRIDE + tid] = v[c0 + k];
+        __syncthreads();
+        if (tid < 4 * ch) {
+            const int w = tid / ch, k = tid - w * ch;
+            const double *src = s_all + k * RED_STRIDE + w * 64;
+            double x = 0;
+            for (int j = 0; j < 64; j++)
+                x += src[j];
+            s_part[w * NV + c0 + k] = x;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     if (tid < NV)
         s_out[tid] = ((s_part[tid] + s_part[NV + tid]) + s_part[2 * NV + tid]) + s_part[3 * NV + tid];
     __syncthreads();
@@ -983,7 +994,7 @@ struct PnpResult {      // what the host reads back after a localisation
 // (2) the workgroup evaluates the winning hypothesis on every point, writes the mask and the
 // order-preserving inlier index list (ballot scan); (3) Levenberg-Marquardt refinement over the
 // inlier list.
-__global__ __launch_bounds__(256) void pnp_finish_kernel(PnpBatch batch)
+__global__ __launch_bounds__(256, 4) void pnp_finish_kernel(PnpBatch batch)
 {
     __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     const PnpJob &job = batch.j[blockIdx.x];  // one workgroup per job
@@ -1006,7 +1017,7 @@ __global__ __launch_bounds__(256) void pnp_finish_kernel(PnpBatch batch)
     PnpResult *__restrict__ out = job.out;
     int *early_out = job.early_out;
     const int early_tag = job.early_tag;
-    __shared__ double s_all[NACC * RED_STRIDE], s_part[4 * NACC], s_sum[NACC], s_pose[12], s_trial[12];
+    __shared__ double s_all[RED_CHUNK * RED_STRIDE], s_part[4 * NACC], s_sum[NACC], s_pose[12], s_trial[12];
     __shared__ int s_flag, s_wave[4], s_base;
     __shared__ RansacState s_state;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
