@@ -325,6 +325,29 @@ __device__ __forceinline__ void lane_residual(const uint8_t *lds, int off, int w
     }
 }
 
+// The iteration's form of the same sums:  sum (J - I) * Ix = sum J * Ix - sum I * Ix, and the second
+// term does not change during a level -- the caller passes it (negated) as the start of the
+// accumulator chain, which saves the v_pk_sub_i16 per element pair.  Integer arithmetic, no
+// overflow (|sum J * Ix| and |sum I * Ix| < 2^30 per lane): the same value bit for bit.
+template <int C>
+__device__ __forceinline__ void lane_mismatch(const uint8_t *lds, int off, int wv0, int wv1,
+                                              const int (&Ixp)[npairs(C)], const int (&Iyp)[npairs(C)], int neg_c1,
+                                              int neg_c2, int &s1, int &s2)
+{
+    unsigned r0[ndwords(C)], r1[ndwords(C)];
+    load_row_packed<C>(lds, off, r0);
+    load_row_packed<C>(lds, off + Tile<C, TS>::ROW, r1);
+    int Jp[npairs(C)];
+    lane_samples<C, W_BITS - 5>(r0, r1, wv0, wv1, Jp);
+    s1 = neg_c1;
+    s2 = neg_c2;
+#pragma unroll
+    for (int j = 0; j < npairs(C); j++) {
+        s1 = sdot2(Jp[j], Ixp[j], s1);
+        s2 = sdot2(Jp[j], Iyp[j], s2);
+    }
+}
+
 // One launch may carry the LK passes of several independent chunks of the stream (blockIdx.y picks
 // the job): the launch lasts as long as the slowest keypoint of ANY job, so two jobs cost little
 // more than one (svo_vo_run_chunks, chunks that share a context).
@@ -496,6 +519,14 @@ __global__ __launch_bounds__(64 * WAVES, 4) void lk_track_kernel(LkBatch batch, 
             a12 = 0;
             a22 = 0;
         }
+        int neg_c1 = 0, neg_c2 = 0;  // - sum I * Ix, - sum I * Iy of this lane (see lane_mismatch)
+#pragma unroll
+        for (int j = 0; j < npairs(C); j++) {
+            neg_c1 = sdot2(Ivp[j], Ixp[j], neg_c1);
+            neg_c2 = sdot2(Ivp[j], Iyp[j], neg_c2);
+        }
+        neg_c1 = -neg_c1;
+        neg_c2 = -neg_c2;
         const float A11 = (float)wave_sum_exact(a11) * FLT_SCALE;
         const float A12 = (float)wave_sum_exact(a12) * FLT_SCALE;
         const float A22 = (float)wave_sum_exact(a22) * FLT_SCALE;
@@ -536,9 +567,8 @@ __global__ __launch_bounds__(64 * WAVES, 4) void lk_track_kernel(LkBatch batch, 
             }
             bilinear_weights(nxp - (float)inx, nyp - (float)iny, w00, w01, w10, w11);
             int s1, s2;
-            lane_residual<C, false>(lds, lane_off + uniform((int)(TJs - lds) + (iny - oy) * Tile<C, TS>::ROW + (inx - ox) * C),
-                                    (w00 & 0xffff) | (w10 << 16), (w01 & 0xffff) | (w11 << 16), Ivp, Ixp, Iyp, s1,
-                                    s2);
+            lane_mismatch<C>(lds, lane_off + uniform((int)(TJs - lds) + (iny - oy) * Tile<C, TS>::ROW + (inx - ox) * C),
+                             (w00 & 0xffff) | (w10 << 16), (w01 & 0xffff) | (w11 << 16), Ixp, Iyp, neg_c1, neg_c2, s1, s2);
             if (!active) {
                 s1 = 0;
                 s2 = 0;

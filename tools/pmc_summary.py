@@ -4,6 +4,9 @@
     python tools/pmc_summary.py sq    gpurun_out/pmc_sq/*_counter_collection.csv      > profiles/..._sq.csv
     python tools/pmc_summary.py hbm   fetch_counter_collection.csv write_counter_collection.csv > profiles/..._hbm.csv
 
+With SVO_PMC_LAST=N only the last N dispatches of every kernel are averaged (the timed region of a
+bench run: the chunks' initial keyframes and the warm-up steps come first).
+
 `hbm` joins the FETCH_SIZE and WRITE_SIZE passes (the two counters cannot share a pass) and adds
 (2*FETCH_SIZE + WRITE_SIZE)*1024, the gfx950 correction of MI355X_MICROARCH.md for kernels that
 read 16 bytes per lane.  Kernel names are shortened to the function name.
@@ -22,14 +25,27 @@ def short(name):
 
 
 def load(paths):
-    per = defaultdict(lambda: defaultdict(float))     # kernel -> counter -> sum
-    disp = defaultdict(set)
+    import os
+    last = int(os.environ.get("SVO_PMC_LAST", "0"))
+    rows = []
     for p in paths:
         with open(p, newline="") as f:
             for row in csv.DictReader(f):
-                k = short(row["Kernel_Name"])
-                per[k][row["Counter_Name"]] += float(row["Counter_Value"])
-                disp[k].add((p, row["Dispatch_Id"]))
+                rows.append((p, short(row["Kernel_Name"]), int(row["Dispatch_Id"]), row["Counter_Name"],
+                             float(row["Counter_Value"])))
+    keep = None
+    if last > 0:
+        ids = defaultdict(set)
+        for p, k, d, _, _ in rows:
+            ids[(p, k)].add(d)
+        keep = {pk: set(sorted(v)[-last:]) for pk, v in ids.items()}
+    per = defaultdict(lambda: defaultdict(float))     # kernel -> counter -> sum
+    disp = defaultdict(set)
+    for p, k, d, c, v in rows:
+        if keep is not None and d not in keep[(p, k)]:
+            continue
+        per[k][c] += v
+        disp[k].add((p, d))
     return per, disp
 
 
