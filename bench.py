@@ -41,15 +41,17 @@ GRID_STEP = 10            # 4428 lattice points -> ANMS keeps 4096 (SURVEY.md 8d
 KF_MIN_INLIERS = 2000     # the reference's 200-of-440 rule scaled to 4096 keypoints
 PYR_BYTES = 619930 * C    # sum of the 4 level sizes
 # HBM bytes per lk_track_kernel<3> launch from the PMC counters of this very workload
-# (profiles/r01_pmc_hbm_traffic_v6.csv: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes,
+# (profiles/r01_pmc_hbm_traffic_v8.csv: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes,
 # KB units, gfx950 correction for 16-B-per-lane reads: (2*FETCH_SIZE + WRITE_SIZE) * 1024).
 # PMC counters cannot be read from inside this process, so the figure is carried from the
 # committed profile; None would be the honest value for any other workload.
-LK_PMC_TRAFFIC_BYTES = 16012306   # per tracking pass: 94 launches carrying 399.4 passes in the PMC run
+LK_PMC_TRAFFIC_BYTES = 13144960   # per LK pass: 160.8 MB per launch, 12.23 passes per launch in the timed region of the PMC run
 # VALU wave-instructions per lk_track_kernel<3> launch from the SQ counters of the same workload
-# (profiles/r01_pmc_sq_v6.csv, SQ_INSTS_VALU, per tracking pass).  The kernel's own bound is VALU issue, not HBM:
-# 1024 SIMDs x one wave64 VALU instruction per 4 cycles at 2.4 GHz.
-LK_PMC_VALU_INSTS = 44484806
+# (profiles/r01_pmc_sq_v8.csv, SQ_INSTS_VALU: 367.1 M per launch of 12.23 passes).  The kernel's own bound is VALU
+# issue, not HBM: 1024 SIMDs x one wave64 VALU instruction per 4 cycles, at 2.4 GHz nominal; the same profile's
+# SQ_BUSY_CYCLES against the launch durations give 1.82 GHz under this load.
+LK_PMC_VALU_INSTS = 30007200
+LK_OBSERVED_SCLK_HZ = 1.82e9
 
 
 def lk_algorithmic_bytes(n_pts: int) -> int:
@@ -267,7 +269,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / 8000.0,
                 "traffic": LK_PMC_TRAFFIC_BYTES * jobs_per_launch if (W, H, C, N_KPTS) == (1241, 376, 3, 4096) else None,
-                "traffic_source": "profiles/r01_pmc_hbm_traffic_v6.csv (rocprofv3 --pmc, (2*FETCH_SIZE+WRITE_SIZE)*1024, "
+                "traffic_source": "profiles/r01_pmc_hbm_traffic_v8.csv (rocprofv3 --pmc, (2*FETCH_SIZE+WRITE_SIZE)*1024, "
                                   "per tracking pass) x passes per launch",
                 "avg_launch_us": lk_avg_s * 1e6,
                 "launches_per_step": lk_launches / args.steps,
@@ -277,6 +279,12 @@ def main():
                                        if N_KPTS == 4096 else None,
                 "valu_issue_frac": (LK_PMC_VALU_INSTS * jobs_per_launch * 4 / 1024 / 2.4e9) / lk_avg_s
                                    if (N_KPTS == 4096 and lk_avg_s > 0) else None,
+                # launches of the four contexts overlap, so the chip-level figure is the meaningful one: VALU issue
+                # cycles LK asks for per second over what 1024 SIMDs offer (LK issues 83 % of all VALU instructions)
+                "valu_chip_frac": (LK_PMC_VALU_INSTS * jobs_per_launch * lk_launches * 4 / 1024 / 2.4e9) / elapsed
+                                  if N_KPTS == 4096 else None,
+                "valu_chip_frac_at_observed_clock": (LK_PMC_VALU_INSTS * jobs_per_launch * lk_launches * 4 / 1024
+                                                     / LK_OBSERVED_SCLK_HZ) / elapsed if N_KPTS == 4096 else None,
                 "frame_hbm_frac": frame_algorithmic_bytes(N_KPTS, kf_rate) / (elapsed / args.steps) / 8e12,
             },
         }
