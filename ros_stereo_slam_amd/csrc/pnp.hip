@@ -325,7 +325,7 @@ struct WaveLds {
     int pq[16];
 };
 
-__global__ __launch_bounds__(64, 2) void pnp_solve_kernel(PnpBatch batch)
+__global__ __launch_bounds__(64, 4) void pnp_solve_kernel(PnpBatch batch)
 {
     __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     const PnpJob &job = batch.j[blockIdx.y];
