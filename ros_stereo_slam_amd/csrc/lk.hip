@@ -128,6 +128,20 @@ __device__ __forceinline__ void wave_sum2_float(int a, int b, float &fa, float &
     }
 }
 
+__device__ __forceinline__ void wave_sum3_float(int a, int b, int c, float &fa, float &fb, float &fc)
+{
+    const unsigned wide = ((unsigned)(a + (1 << 25)) | (unsigned)(b + (1 << 25)) | (unsigned)(c + (1 << 25))) >> 26;
+    if (__builtin_amdgcn_ballot_w64(wide != 0) == 0) {
+        fa = (float)wave_total_lane63(a);
+        fb = (float)wave_total_lane63(b);
+        fc = (float)wave_total_lane63(c);
+    } else {
+        fa = (float)wave_sum_exact(a);
+        fb = (float)wave_sum_exact(b);
+        fc = (float)wave_sum_exact(c);
+    }
+}
+
 __device__ __forceinline__ void bilinear_weights(float a, float b, int &w00, int &w01, int &w10,
                                                  int &w11)
 {
@@ -485,7 +499,9 @@ __global__ __launch_bounds__(64 * WAVES, 4) void lk_track_kernel(LkBatch batch, 
         int Ivp[npairs(C)], Ixp[npairs(C)], Iyp[npairs(C)];  // packed int16 pairs (low = even element)
         int a11 = 0, a12 = 0, a22 = 0;
         {
-            const int wp0 = (w00 & 0xffff) | (w01 << 16), wp1 = (w10 & 0xffff) | (w11 << 16);
+            // the spare lane (63) interpolates its derivative patch with zero weights: Ix = Iy = 0 there, so
+            // its share of every sum below and in the iterations is 0 without any masking
+            const int wp0 = active ? (w00 & 0xffff) | (w01 << 16) : 0, wp1 = active ? (w10 & 0xffff) | (w11 << 16) : 0;
             constexpr int NE = SEG * C;
             unsigned t0[ndwords(C)], t1[ndwords(C)];
             const int toff = (int)(Ts - lds) + (wy + 1) * TROW + (wx + 1) * C;
@@ -507,17 +523,12 @@ __global__ __launch_bounds__(64 * WAVES, 4) void lk_track_kernel(LkBatch batch, 
 #pragma unroll
             for (int j = 0; j < npairs(C); j++) {
                 const int k0 = 2 * j, k1 = 2 * j + 1 < NE ? 2 * j + 1 : NE;
-                Ixp[j] = (ix[k0] & 0xffff) | (ix[k1] << 16);
-                Iyp[j] = (iy[k0] & 0xffff) | (iy[k1] << 16);
+                Ixp[j] = half_pair<false>(ix[k0], ix[k1]);
+                Iyp[j] = half_pair<false>(iy[k0], iy[k1]);
                 a11 = sdot2(Ixp[j], Ixp[j], a11);  // sums of squares of int16 pairs, exact
                 a12 = sdot2(Ixp[j], Iyp[j], a12);
                 a22 = sdot2(Iyp[j], Iyp[j], a22);
             }
-        }
-        if (!active) {
-            a11 = 0;
-            a12 = 0;
-            a22 = 0;
         }
         int neg_c1 = 0, neg_c2 = 0;  // - sum I * Ix, - sum I * Iy of this lane (see lane_mismatch)
 #pragma unroll
@@ -527,9 +538,11 @@ __global__ __launch_bounds__(64 * WAVES, 4) void lk_track_kernel(LkBatch batch, 
         }
         neg_c1 = -neg_c1;
         neg_c2 = -neg_c2;
-        const float A11 = (float)wave_sum_exact(a11) * FLT_SCALE;
-        const float A12 = (float)wave_sum_exact(a12) * FLT_SCALE;
-        const float A22 = (float)wave_sum_exact(a22) * FLT_SCALE;
+        float A11, A12, A22;
+        wave_sum3_float(a11, a12, a22, A11, A12, A22);
+        A11 *= FLT_SCALE;
+        A12 *= FLT_SCALE;
+        A22 *= FLT_SCALE;
         float Dd = A11 * A22 - A12 * A12;
         const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) /
                              (float)(2 * WIN * WIN);
@@ -569,10 +582,6 @@ __global__ __launch_bounds__(64 * WAVES, 4) void lk_track_kernel(LkBatch batch, 
             int s1, s2;
             lane_mismatch<C>(lds, lane_off + uniform((int)(TJs - lds) + (iny - oy) * Tile<C, TS>::ROW + (inx - ox) * C),
                              (w00 & 0xffff) | (w10 << 16), (w01 & 0xffff) | (w11 << 16), Ixp, Iyp, neg_c1, neg_c2, s1, s2);
-            if (!active) {
-                s1 = 0;
-                s2 = 0;
-            }
             float b1, b2;
             wave_sum2_float(s1, s2, b1, b2);
             b1 *= FLT_SCALE;
