@@ -60,10 +60,27 @@ __global__ __launch_bounds__(256) void anms_rank_kernel(AnmsBatch batch, int n)
         return;
     const float ri = resp[i];
     int cnt = 0;
-    for (int j = lane; j < n; j += 64) {
-        const float rj = resp[j];
-        cnt += (rj > ri || (rj == ri && j < i)) ? 1 : 0;
+    // "j sorts before i"  <=>  r_j > r_i, or r_j == r_i and j < i.  Whole 64-entry stripes before i's
+    // own stripe need one compare (>=), the ones after it one compare (>); only i's stripe needs the
+    // tie-break.  Scalar loop bounds: no per-lane range test except in the last, partial stripe.
+    const float *__restrict__ rl = resp + lane;
+    const int own = (i >> 6) << 6;
+#pragma unroll 8
+    for (int j0 = 0; j0 < own; j0 += 64)
+        cnt += rl[j0] >= ri ? 1 : 0;
+    {
+        const int j = own + lane;
+        if (j < n) {
+            const float rj = rl[own];
+            cnt += (rj > ri || (rj == ri && j < i)) ? 1 : 0;
+        }
     }
+    int j0 = own + 64;
+#pragma unroll 8
+    for (; j0 + 64 <= n; j0 += 64)
+        cnt += rl[j0] > ri ? 1 : 0;
+    if (j0 < n && j0 + lane < n)
+        cnt += rl[j0] > ri ? 1 : 0;
     const int rank = wave_sum_int(cnt);
     if (lane == 0) {
         order[rank] = i;
@@ -122,8 +139,16 @@ __global__ __launch_bounds__(256) void anms_decide_kernel(AnmsBatch batch, int n
         return;
     const double ri = radius_sq[s];
     int gt = 0, ge = 0;
-    for (int j = lane; j < n; j += 64) {
-        const double rj = radius_sq[j];
+    const double *__restrict__ rl = radius_sq + lane;
+    int j0 = 0;
+#pragma unroll 8
+    for (; j0 + 64 <= n; j0 += 64) {  // scalar bounds: no per-lane range test in the body
+        const double rj = rl[j0];
+        gt += rj > ri ? 1 : 0;
+        ge += rj >= ri ? 1 : 0;
+    }
+    if (j0 + lane < n) {
+        const double rj = rl[j0];
         gt += rj > ri ? 1 : 0;
         ge += rj >= ri ? 1 : 0;
     }
