@@ -142,6 +142,27 @@ __device__ __forceinline__ void wave_sum3_float(int a, int b, int c, float &fa, 
     }
 }
 
+// The iteration's form of the weights, already packed as the column-pair sampling wants them:
+// wv0 = (w00 | w10 << 16), wv1 = (w01 | w11 << 16).  Same values as bilinear_weights bit for bit:
+//  - scaling by 2^14 is exact, so it is applied to (1 - a) and a once instead of to three products;
+//  - rint(x) for 0 <= x < 2^22 is the low mantissa of x + 1.5 * 2^23 (round to nearest even in the
+//    add), i.e. the low 16 bits of that float's bit pattern ARE the int16 weight: no v_rndne / v_cvt,
+//    and one v_perm_b32 packs two of them;
+//  - w11 = 2^14 - w00 - w01 - w10 from the same bit patterns (the three magic offsets cancel in the
+//    constant), low half taken by the permute (w11 may be -1).
+__device__ __forceinline__ void bilinear_weight_pairs(float a, float b, int &wv0, int &wv1)
+{
+    const float MAGIC = 12582912.f;  // 1.5 * 2^23, bit pattern 0x4B400000
+    const float na = 1.f - a, nb = 1.f - b;
+    const float A1 = na * (float)(1 << W_BITS), A0 = a * (float)(1 << W_BITS);
+    const unsigned b00 = __builtin_bit_cast(unsigned, A1 * nb + MAGIC);
+    const unsigned b01 = __builtin_bit_cast(unsigned, A0 * nb + MAGIC);
+    const unsigned b10 = __builtin_bit_cast(unsigned, A1 * b + MAGIC);
+    const unsigned b11 = (unsigned)(1 << W_BITS) + 3u * 0x4B400000u - (b00 + b01 + b10);
+    wv0 = (int)__builtin_amdgcn_perm(b10, b00, 0x05040100u);
+    wv1 = (int)__builtin_amdgcn_perm(b11, b01, 0x05040100u);
+}
+
 __device__ __forceinline__ void bilinear_weights(float a, float b, int &w00, int &w01, int &w10,
                                                  int &w11)
 {
@@ -578,10 +599,11 @@ __global__ __launch_bounds__(64 * WAVES, 4) void lk_track_kernel(LkBatch batch, 
                 wave_lds_sync();
                 have_tile = true;
             }
-            bilinear_weights(nxp - (float)inx, nyp - (float)iny, w00, w01, w10, w11);
+            int wv0, wv1;
+            bilinear_weight_pairs(nxp - (float)inx, nyp - (float)iny, wv0, wv1);
             int s1, s2;
             lane_mismatch<C>(lds, lane_off + uniform((int)(TJs - lds) + (iny - oy) * Tile<C, TS>::ROW + (inx - ox) * C),
-                             (w00 & 0xffff) | (w10 << 16), (w01 & 0xffff) | (w11 << 16), Ixp, Iyp, neg_c1, neg_c2, s1, s2);
+                             wv0, wv1, Ixp, Iyp, neg_c1, neg_c2, s1, s2);
             float b1, b2;
             wave_sum2_float(s1, s2, b1, b2);
             b1 *= FLT_SCALE;
