@@ -52,7 +52,9 @@ static_assert(sizeof(LkBatch) + sizeof(LkParams) <= 4096, "kernel arguments are 
 template <int C, int SIDE> struct Tile {
     static constexpr int ROWB = SIDE * C;
     static constexpr int VEC = (ROWB + 15 + 15) / 16;  // 16-byte vectors per row, any shift
-    static constexpr int ROW = VEC * 16;
+    // row stride: an ODD number of 16-byte units, so that the rows of a tile spread over the LDS banks
+    // (with 6 units = 24 dwords every 4th or 8th row of the Scharr pass's byte reads shared its banks)
+    static constexpr int ROW = (VEC | 1) * 16;
     static constexpr int BYTES = SIDE * ROW;
 };
 template <int C> struct Lds {
