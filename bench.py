@@ -47,11 +47,11 @@ PYR_BYTES = 619930 * C    # sum of the 4 level sizes
 # committed profile; None would be the honest value for any other workload.
 LK_PMC_TRAFFIC_BYTES = 13144960   # per LK pass: 160.8 MB per launch, 12.23 passes per launch in the timed region of the PMC run
 # VALU wave-instructions per lk_track_kernel<3> launch from the SQ counters of the same workload
-# (profiles/r01_pmc_sq_v9.csv, SQ_INSTS_VALU: 354.6 M per launch of 12.23 passes).  The kernel's own bound is VALU
+# (profiles/r01_pmc_sq_v10.csv, SQ_INSTS_VALU: 354.6 M per launch of 12.23 passes).  The kernel's own bound is VALU
 # issue, not HBM: 1024 SIMDs x one wave64 VALU instruction per 4 cycles, at 2.4 GHz nominal; the same profile's
-# SQ_BUSY_CYCLES against the launch durations give 1.86 GHz under this load.
+# SQ_BUSY_CYCLES against the launch durations give 1.74 GHz under this load.
 LK_PMC_VALU_INSTS = 28989000
-LK_OBSERVED_SCLK_HZ = 1.86e9
+LK_OBSERVED_SCLK_HZ = 1.74e9
 
 
 def lk_algorithmic_bytes(n_pts: int) -> int:
