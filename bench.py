@@ -74,7 +74,8 @@ def pingpong(i: int, n: int) -> int:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3200)
+    ap.add_argument("--steps", type=int, default=50,
+                    help="timed steps; one step = one frame of every chunk of the GPU (64 frames per GPU with the defaults)")
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--frames", type=int, default=6, help="distinct synthetic stereo frames kept in HBM per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -192,7 +193,10 @@ def main():
     torch.cuda.synchronize()
     sync_all()
     t0 = time.perf_counter()
-    last = run(args.warmup, split(args.steps), True)  # EXACTLY --steps frames on this GPU
+    # EXACTLY --steps steps; one step = one pass of the front-end over the batch this GPU keeps in flight,
+    # i.e. one frame of each of its M chunks (a lock-step group advances all its chunks per set of launches)
+    n_frames = args.steps * M
+    last = run(args.warmup, split(n_frames), True)
     if dist is not None:
         # the path's one exchange: chunk-boundary poses, 12 doubles per rank, over RCCL
         from ros_stereo_slam_amd import chunked
@@ -221,14 +225,14 @@ def main():
         elapsed = float(tt.item())
 
     if rank == 0:
-        fps = world * args.steps / elapsed
+        fps = world * n_frames / elapsed
         lk_ms, lk_launches = times["lk"]
         lk_avg_s = lk_ms / max(lk_launches, 1) * 1e-3
         # a launch carries the tracking passes of the chunks of one context that are in step
-        jobs_per_launch = (args.steps * (1.0 + stats["keyframes"] / max(args.steps, 1))) / max(lk_launches, 1)
+        jobs_per_launch = (n_frames * (1.0 + stats["keyframes"] / max(n_frames, 1))) / max(lk_launches, 1)
         lk_bytes = lk_algorithmic_bytes(N_KPTS) * jobs_per_launch
         achieved = lk_bytes / lk_avg_s / 1e9 if lk_avg_s > 0 else 0.0
-        kf_rate = stats["keyframes"] / args.steps
+        kf_rate = stats["keyframes"] / n_frames
         result = {
             "metric": f"stereo frames/sec @1241x376, {N_KPTS} kpts",
             "value": fps,
@@ -255,11 +259,12 @@ def main():
                 "pipeline": "two HIP streams per chunk: PnP(t) beside pyramid+LK(t+1)" if pipeline
                             else "one in-order HIP stream per chunk",
                 "keyframe_rate": kf_rate,
-                "mean_tracked": stats["tracked"] / args.steps,
-                "mean_pnp_inliers": stats["inliers"] / args.steps,
+                "frames_per_step": M * world,
+                "mean_tracked": stats["tracked"] / n_frames,
+                "mean_pnp_inliers": stats["inliers"] / n_frames,
                 "tracking_lost": stats["lost"],
                 "init_points": n0,
-                "stage_ms_per_step": {k: v[0] / args.steps for k, v in times.items()},
+                "stage_ms_per_frame": {k: v[0] / n_frames for k, v in times.items()},
             },
             "roofline": {
                 "kernel": "lk_track_kernel<3>",
@@ -273,6 +278,7 @@ def main():
                                   "per tracking pass) x passes per launch",
                 "avg_launch_us": lk_avg_s * 1e6,
                 "launches_per_step": lk_launches / args.steps,
+                "launches_per_frame": lk_launches / n_frames,
                 "algorithmic_bytes_per_launch": lk_bytes,
                 "lk_passes_per_launch": jobs_per_launch,
                 "valu_issue_bound_us": (LK_PMC_VALU_INSTS * jobs_per_launch * 4 / 1024 / 2.4e9 * 1e6)
@@ -285,7 +291,7 @@ def main():
                                   if N_KPTS == 4096 else None,
                 "valu_chip_frac_at_observed_clock": (LK_PMC_VALU_INSTS * jobs_per_launch * lk_launches * 4 / 1024
                                                      / LK_OBSERVED_SCLK_HZ) / elapsed if N_KPTS == 4096 else None,
-                "frame_hbm_frac": frame_algorithmic_bytes(N_KPTS, kf_rate) / (elapsed / args.steps) / 8e12,
+                "frame_hbm_frac": frame_algorithmic_bytes(N_KPTS, kf_rate) / (elapsed / n_frames) / 8e12,
             },
         }
         if not args.no_cpu_baseline and world == 1:
