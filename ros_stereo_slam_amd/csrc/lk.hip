@@ -10,9 +10,9 @@
 // 7-pixel segment (l%3) of it, i.e. 7*C patch elements that stay in VGPRs for the whole
 // level (template patch I and both derivative patches).  Per level a wave
 //   1. stages the 24x24 neighbourhood of the previous image in LDS (aligned 16-byte row
-//      loads from the padded pyramid level, no border arithmetic), derives the 22x22 Scharr tile LDS->LDS (zero outside the
-//      image, as OpenCV pads the derivative buffer), builds its patch registers and the
-//      2x2 normal matrix;
+//      loads from the padded pyramid level, no border arithmetic), derives the 22x22 Scharr
+//      tile LDS->LDS (zero outside the image, as OpenCV pads the derivative buffer), builds
+//      its patch registers and the 2x2 normal matrix;
 //   2. stages a (22+2*JR)^2 tile of the next image around the current guess and iterates
 //      out of LDS; the tile is re-staged only when the guess drifts more than JR pixels.
 // All sums of integer products are exact (int32 per lane, int64 across the wave via
@@ -322,21 +322,12 @@ template <bool HI> __device__ __forceinline__ int half_pair(int x, int y)
     return (int)__builtin_amdgcn_perm((unsigned)y, (unsigned)x, sel);
 }
 
-// dot(a, b): the accumulator of a chain starts here, no v_mov 0 needed
-__device__ __forceinline__ int sdot2_first(int a, int b)
-{
-    int d;
-    asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
-
-// One lane's share of  sum (J - I) * {Ix, Iy}  (or sum |J - I| when ABS) over its 7*C patch
-// elements: lane_samples, then per element PAIR one v_pk_sub_i16 against the packed template and
-// two v_dot2_i32_i16 against the packed derivatives.
-template <int C, bool ABS>
-__device__ __forceinline__ void lane_residual(const uint8_t *lds, int off, int wv0, int wv1,
-                                              const int (&Ivp)[npairs(C)], const int (&Ixp)[npairs(C)],
-                                              const int (&Iyp)[npairs(C)], int &s1, int &s2)
+// One lane's share of  sum |J - I|  over its 7*C patch elements (the err output of the reference,
+// level 0, once per keypoint): lane_samples, then per element pair one v_pk_sub_i16 against the
+// packed template.
+template <int C>
+__device__ __forceinline__ int lane_abs_residual(const uint8_t *lds, int off, int wv0, int wv1,
+                                                 const int (&Ivp)[npairs(C)])
 {
     constexpr int NE = SEG * C;
     unsigned r0[ndwords(C)], r1[ndwords(C)];
@@ -344,22 +335,14 @@ __device__ __forceinline__ void lane_residual(const uint8_t *lds, int off, int w
     load_row_packed<C>(lds, off + Tile<C, TS>::ROW, r1);
     int Jp[npairs(C)];
     lane_samples<C, W_BITS - 5>(r0, r1, wv0, wv1, Jp);
-    s1 = 0;
-    s2 = 0;
+    int s = 0;
 #pragma unroll
     for (int j = 0; j < npairs(C); j++) {
         const short2v d = __builtin_bit_cast(short2v, Jp[j]) - __builtin_bit_cast(short2v, Ivp[j]);
-        if (ABS) {
-            int d0 = d.x, d1 = d.y;
-            s1 += (d0 < 0 ? -d0 : d0) + (2 * j + 1 < NE ? (d1 < 0 ? -d1 : d1) : 0);
-        } else if (j == 0) {
-            s1 = sdot2_first(__builtin_bit_cast(int, d), Ixp[j]);
-            s2 = sdot2_first(__builtin_bit_cast(int, d), Iyp[j]);
-        } else {
-            s1 = sdot2(__builtin_bit_cast(int, d), Ixp[j], s1);
-            s2 = sdot2(__builtin_bit_cast(int, d), Iyp[j], s2);
-        }
+        const int d0 = d.x, d1 = d.y;
+        s += (d0 < 0 ? -d0 : d0) + (2 * j + 1 < NE ? (d1 < 0 ? -d1 : d1) : 0);
     }
+    return s;
 }
 
 // The iteration's form of the same sums:  sum (J - I) * Ix = sum J * Ix - sum I * Ix, and the second
@@ -650,10 +633,8 @@ __global__ __launch_bounds__(64 * WAVES, 4) void lk_track_kernel(LkBatch batch, 
                 have_tile = true;
             }
             bilinear_weights(qx - (float)iqx, qy - (float)iqy, w00, w01, w10, w11);
-            int s1, s2;
-            lane_residual<C, true>(lds, lane_off + uniform((int)(TJs - lds) + (iqy - oy) * Tile<C, TS>::ROW + (iqx - ox) * C),
-                                   (w00 & 0xffff) | (w10 << 16), (w01 & 0xffff) | (w11 << 16), Ivp, Ixp, Iyp, s1,
-                                   s2);
+            int s1 = lane_abs_residual<C>(lds, lane_off + uniform((int)(TJs - lds) + (iqy - oy) * Tile<C, TS>::ROW + (iqx - ox) * C),
+                                          (w00 & 0xffff) | (w10 << 16), (w01 & 0xffff) | (w11 << 16), Ivp);
             if (!active)
                 s1 = 0;
             const long long sabs = (long long)wave_sum_exact(s1);  // < 2^24
