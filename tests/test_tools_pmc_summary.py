@@ -1,0 +1,53 @@
+"""tools/pmc_summary.py on a hand-made rocprofv3 counter-collection file (host logic, no GPU)."""
+import csv
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+COLS = ["Correlation_Id", "Dispatch_Id", "Kernel_Name", "Counter_Name", "Counter_Value"]
+
+
+def _write(path, rows):
+    with open(path, "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=COLS)
+        w.writeheader()
+        for r in rows:
+            w.writerow(dict(zip(COLS, r)))
+
+
+def _run(args, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py")] + args, check=True,
+                         capture_output=True, text=True, env=e).stdout
+    return list(csv.DictReader(out.splitlines()))
+
+
+def test_sq_means_and_timed_region(tmp_path):
+    p = tmp_path / "sq_counter_collection.csv"
+    name = "void (anonymous namespace)::lk_track_kernel<3>(LkBatch, (anonymous namespace)::LkParams)"
+    rows = []
+    for d, v in ((1, 100), (2, 300), (3, 500)):
+        rows.append((d, d, name, "SQ_INSTS_VALU", v))
+        rows.append((d, d, name, "SQ_INSTS_LDS", v // 10))
+    rows.append((4, 4, "(anonymous namespace)::compact_kernel((anonymous namespace)::CompactBatch, int)", "SQ_INSTS_VALU", 7))
+    _write(p, rows)
+    out = {r["kernel"]: r for r in _run(["sq", str(p)])}
+    assert out["lk_track_kernel<3>"]["dispatches"] == "3"
+    assert out["lk_track_kernel<3>"]["SQ_INSTS_VALU_per_dispatch"] == "300"
+    assert out["lk_track_kernel<3>"]["SQ_INSTS_LDS_per_dispatch"] == "30"
+    assert out["compact_kernel"]["SQ_INSTS_VALU_per_dispatch"] == "7"
+    last = {r["kernel"]: r for r in _run(["sq", str(p)], {"SVO_PMC_LAST": "2"})}
+    assert last["lk_track_kernel<3>"]["dispatches"] == "2"
+    assert last["lk_track_kernel<3>"]["SQ_INSTS_VALU_per_dispatch"] == "400"
+
+
+def test_hbm_join_applies_the_gfx950_correction(tmp_path):
+    f, w = tmp_path / "fetch.csv", tmp_path / "write.csv"
+    _write(f, [(1, 1, "k(int)", "FETCH_SIZE", 10), (2, 2, "k(int)", "FETCH_SIZE", 30)])
+    _write(w, [(1, 1, "k(int)", "WRITE_SIZE", 4), (2, 2, "k(int)", "WRITE_SIZE", 6)])
+    (row,) = _run(["hbm", str(f), str(w)])
+    assert row["kernel"] == "k" and row["dispatches"] == "2"
+    assert float(row["FETCH_SIZE_KB_per_dispatch"]) == 20.0 and float(row["WRITE_SIZE_KB_per_dispatch"]) == 5.0
+    assert int(row["hbm_bytes_per_dispatch_2F_plus_W"]) == (2 * 20 + 5) * 1024
