@@ -2,21 +2,35 @@
 """bench.py -- stereo frames/s of the MI355X front-end on a synthetic 1241x376 stream.
 
 Contract (driver): ``python bench.py --gpus N --steps K --warmup W`` prints ONE JSON line on
-rank 0.  A step is one pass of the hot path over one stereo frame whose images are already
-resident in HBM: pyramid of the new left image, pyramidal LK of the reference keypoints,
-F-matrix RANSAC, PnP-RANSAC + refinement, pose composition, keyframe rule and -- when the
-rule fires -- the stereo keyframe path (right pyramid, grid + ANMS to 4096 keypoints, LK
-left->right, F-RANSAC, DLT triangulation, rigid transform).  That is BASELINE.json
-configs[1] ("front-end only, pose-graph off") on the synthetic stream of SURVEY.md 8d.
+rank 0.  A step is one pass of the hot path over one batch of stereo frames whose images are
+already resident in HBM: one frame of every chunk this GPU keeps in flight, each through the
+pyramid of the new left image, pyramidal LK of the reference keypoints, F-matrix RANSAC,
+PnP-RANSAC + refinement, pose composition, keyframe rule and -- when the rule fires -- the stereo
+keyframe path (right pyramid, grid + ANMS to 4096 keypoints, LK left->right, F-RANSAC, DLT
+triangulation, rigid transform).  That is BASELINE.json configs[1] ("front-end only, pose-graph
+off") on the synthetic stream of SURVEY.md 8d.
 
-For N > 1 the driver launches one rank per GPU (torch.distributed, backend nccl == RCCL).
-Every rank runs the front-end on its own contiguous chunk of the stream (weak scaling, no
-data-path collective); the one exchange step of the path is the all-gather of the
-chunk-boundary poses (12 doubles per rank) at the end of the timed region.
+The stream is ONE walk of the generator's rounded-rectangle loop (0.9 m per frame, a lap of 492
+frames), cut into contiguous chunks with one frame of overlap: rank r owns frames
+[r*M*L, (r+1)*M*L], chunk m of it frames [m*L, (m+1)*L] with L = warmup + steps; every chunk
+re-initialises at its first frame.  The warm-up steps are the first W frames of every chunk, the K
+timed steps the next K.  The one exchange step of the path -- the all-gather of the chunk-boundary
+poses, 12 doubles per chunk, RCCL for N > 1 -- is inside the timed region.  Weak scaling.
+
+Reported beside ``value`` (all measured in this invocation, nothing carried as a literal):
+  value_including_chunk_inits  the whole share again, every chunk's stereo initialisation included
+  single_chunk_frames_per_s    ONE contiguous chunk per GPU (the north-star's partitioning),
+                               pipelined, over rank 0's whole share
+  ate_*                        trajectory error of the stitched 64*N-chunk run and of the
+                               sequential run against the generator's truth, against each other,
+                               and of the GPU against the CPU oracle on the frames the oracle ran
+  posegraph_ms_per_iter        configs[3]'s global solve on the stitched trajectory with the
+                               generator's loop closures (one svo_pg_optimize, 10 GN iterations)
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -24,38 +38,21 @@ import time
 
 import numpy as np
 
-# One hardware queue per chunk stream, plus room for the default stream (torch's copies) and for
-# the streams RCCL creates in a multi-GPU run: with the runtime's default pool of 4 the fourth chunk
-# stream shares a queue with another chunk (which queue a stream gets is the runtime's
-# least-referenced pick) and the two serialise.  The pool may be larger than needed (5, 6, 8 and 12
-# measure the same); what hurts is more than four queues BUSY at once, so the chunk count stays at 4.
-# Must be set before the HIP runtime initialises, i.e. before torch is imported.
+# One hardware queue per context stream plus room for the default stream (torch's copies) and for
+# the streams RCCL creates in a multi-GPU run.  Must be set before the HIP
+# runtime initialises, i.e. before torch is imported.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 W, H, C = 1241, 376, 3
-N_KPTS = 4096
-GRID_STEP = 10            # 4428 lattice points -> ANMS keeps 4096
-KF_MIN_INLIERS = 2000     # the reference's 200-of-440 rule scaled to 4096 keypoints
 PYR_BYTES = 619930 * C    # sum of the 4 level sizes
-# HBM bytes per lk_track_kernel<3> launch from the PMC counters of this very workload
-# (profiles/r01_pmc_hbm_traffic_v8.csv: separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes,
-# KB units, gfx950 correction for 16-B-per-lane reads: (2*FETCH_SIZE + WRITE_SIZE) * 1024).
-# PMC counters cannot be read from inside this process, so the figure is carried from the
-# committed profile; None would be the honest value for any other workload.
-LK_PMC_TRAFFIC_BYTES = 13144960   # per LK pass: 160.8 MB per launch, 12.23 passes per launch in the timed region of the PMC run
-# VALU wave-instructions per lk_track_kernel<3> launch from the SQ counters of the same workload
-# (profiles/r01_pmc_sq_v10.csv, SQ_INSTS_VALU: 354.6 M per launch of 12.23 passes).  The kernel's own bound is VALU
-# issue, not HBM: 1024 SIMDs x one wave64 VALU instruction per 4 cycles, at 2.4 GHz nominal; the same profile's
-# SQ_BUSY_CYCLES against the launch durations give 1.74 GHz under this load.
-LK_PMC_VALU_INSTS = 28989000
-LK_OBSERVED_SCLK_HZ = 1.74e9
+LK_PMC_JSON = os.path.join(ROOT, "profiles", "r02_lk_pmc.json")
 
 
 def lk_algorithmic_bytes(n_pts: int) -> int:
-    """HBM bytes one LK launch must move: both pyramids once + 8 B in / 13 B out per point
+    """HBM bytes one LK pass must move: both pyramids once + 8 B in / 13 B out per point
     (the LK share of SURVEY 8d's B_track = 3*pyr + 71*N)."""
     return 2 * PYR_BYTES + 21 * n_pts
 
@@ -64,11 +61,44 @@ def frame_algorithmic_bytes(n_pts: int, keyframe_rate: float) -> float:
     return 3 * PYR_BYTES + 71 * n_pts + keyframe_rate * (3 * PYR_BYTES + 102 * n_pts)
 
 
-def pingpong(i: int, n: int) -> int:
-    """0,1,..,n-1,n-2,..,1,0,1,.. : a temporally continuous walk over n resident frames."""
-    p = 2 * (n - 1)
-    k = i % p
-    return k if k < n else p - k
+def lk_pmc_constants(n_kpts: int):
+    """Per-pass counter figures of lk_track_kernel<3> from the committed rocprofv3 --pmc passes
+    (tools/pmc_summary.py --json writes the file next to the CSVs).  They are only valid for the
+    build and workload they were taken on: the file names the sha256 of lk.hip and the keypoint
+    count, anything else gives None."""
+    try:
+        with open(LK_PMC_JSON) as f:
+            d = json.load(f)
+        with open(os.path.join(ROOT, "ros_stereo_slam_amd", "csrc", "lk.hip"), "rb") as f:
+            sha = hashlib.sha256(f.read()).hexdigest()
+    except (OSError, ValueError):
+        return None
+    if d.get("lk_hip_sha256") != sha or d.get("kpts") != n_kpts:
+        return None
+    return d
+
+
+def rel_truth(poses):
+    """Generator poses relative to the first one (the VO's frame): [(R, t)]."""
+    R0, t0 = poses[0]
+    return [(R0.T @ R, R0.T @ (t - t0)) for R, t in poses]
+
+
+def rot_angle(Ra, Rb):
+    return float(np.arccos(np.clip((np.trace(Ra.T @ Rb) - 1) / 2, -1, 1)))
+
+
+def kitti_leg(args):
+    """BASELINE configs[0-3] take a KITTI odometry directory from the CLI; the data
+    is not in the reference checkout nor on the GPU box, so this leg normally reports its absence."""
+    from ros_stereo_slam_amd import sequence
+
+    seq_dir = os.path.join(args.kitti, "sequences", args.seq)
+    if not os.path.isdir(seq_dir):
+        print(json.dumps({"skipped": "KITTI data absent", "looked_in": seq_dir,
+                          "config": {"workload": f"KITTI odometry sequence {args.seq} (BASELINE configs[0-3])"}}))
+        return 0
+    return sequence.bench_kitti(args, seq_dir)
 
 
 def main():
@@ -77,14 +107,14 @@ def main():
     ap.add_argument("--steps", type=int, default=50,
                     help="timed steps; one step = one frame of every chunk of the GPU (64 frames per GPU with the defaults)")
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--frames", type=int, default=6, help="distinct synthetic stereo frames kept in HBM per rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the contract's timed region (no re-run with inits, no single-chunk run, no pose graph)")
     ap.add_argument("--pipeline", choices=("auto", "on", "off"), default="auto",
                     help="two-stream overlap of PnP(t) with pyramid + LK(t+1) inside a chunk; auto = on for one "
                          "chunk per GPU, off when several chunks already fill the hardware queues")
     ap.add_argument("--chunks-per-gpu", type=int, default=int(os.environ.get("SVO_CHUNKS_PER_GPU", "64")),
-                    help="independent chunks of the stream run side by side on each GPU (svo_vo_run_chunks); "
-                         "with --chunks-per-context 16 that is 4 contexts = 4 busy hardware queues")
+                    help="contiguous chunks of this GPU's share of the stream run side by side (svo_vo_run_chunks)")
     ap.add_argument("--chunks-per-context", type=int, default=int(os.environ.get("SVO_CHUNKS_PER_CONTEXT", "16")),
                     help="chunks that share one context (= one stream): advanced in lock step, every stage of the "
                          "tracking path ONE set of launches for all of them (1..16)")
@@ -94,13 +124,15 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=24)
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="diagnostic: no HIP events around the kernels (the roofline object is then empty)")
+    ap.add_argument("--kitti", default=None, help="KITTI odometry root (holds sequences/<seq>/image_2, image_3)")
+    ap.add_argument("--seq", default="00")
     args = ap.parse_args()
+    if args.kitti is not None:
+        return kitti_leg(args)
 
     import torch
 
-    global N_KPTS, GRID_STEP, KF_MIN_INLIERS
-    if args.kpts == 8192:
-        N_KPTS, GRID_STEP, KF_MIN_INLIERS = 8192, 7, 4000
+    n_kpts, grid_step, kf_min = (4096, 10, 2000) if args.kpts == 4096 else (8192, 7, 4000)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -122,215 +154,311 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    coll_dev = "cpu" if rehearsal else "cuda"
 
-    from ros_stereo_slam_amd import capi, synth
+    from ros_stereo_slam_amd import capi, chunked, synth
 
     M = max(1, args.chunks_per_gpu)
     G = max(1, min(16, args.chunks_per_context))
+    Wn, K = max(0, args.warmup), max(1, args.steps)
+    L = Wn + K                       # frame-to-frame transitions per chunk
+    share = M * L                    # transitions per rank
     pipeline = args.pipeline == "on" or (args.pipeline == "auto" and M == 1)
-    scene = synth.Scene()
-    # every rank renders its own contiguous chunks of the stream (M per GPU, one context each)
-    all_poses = synth.corridor_trajectory(args.frames * world * M)
-    ctxs, vos, host_frames, dev_frames = [], [], [], []
-    for m in range(M):
-        c0 = (rank * M + m) * args.frames
-        hf = [scene.stereo(R, t)[:2] for (R, t) in all_poses[c0:c0 + args.frames]]
-        host_frames.append(hf)
-        dev_frames.append([(torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()) for l, r in hf])
-        if m % G == 0:
-            ctxs.append(capi.Context(local_rank))
-        vos.append(capi.VisualOdometry(ctxs[m // G], W, H, C, grid_step=GRID_STEP, anms_keep=N_KPTS,
-                                       keyframe_min_inliers=KF_MIN_INLIERS, seed=20261003 + m))
+    scene = synth.bench_scene()
+    poses_all = synth.loop_trajectory(world * share + 1, **synth.BENCH_LOOP)
+    my_poses = poses_all[rank * share:(rank + 1) * share + 1]
+    t_r0 = time.perf_counter()
+    lefts, rights = synth.stereo_torch(scene, my_poses, device=f"cuda:{local_rank}", batch=8)
     torch.cuda.synchronize()
-    n0 = [vos[m].init(*dev_frames[m][0]) for m in range(M)][0]
+    render_s = time.perf_counter() - t_r0
 
-    stats = {"keyframes": 0, "inliers": 0, "tracked": 0, "lost": 0}
+    vo_kw = dict(grid_step=grid_step, anms_keep=n_kpts, keyframe_min_inliers=kf_min)
+    sh = chunked.ShardedVO(capi, local_rank, W, H, C, M, G, first_chunk_id=rank * M, seed=20261003, **vo_kw)
+    bounds = chunked.chunk_bounds(share + 1, M)
+    assert all(e - s == L for s, e in bounds)
 
-    def run(first: int, counts, record: bool):
-        """Frames first+1 .. first+counts[m] of chunk m's ping-pong walk through the chunk runner
-        (one C call, no Python between frames; PnP of frame t overlaps pyramid + LK of frame t+1;
-        the M chunks of this GPU run side by side on their own contexts)."""
-        last = [None] * M
-        done_total = [0] * M
-        while any(done_total[m] < counts[m] for m in range(M)):
-            active = [m for m in range(M) if done_total[m] < counts[m]]
-            idx = {m: [pingpong(first + done_total[m] + k + 1, args.frames) for k in range(counts[m] - done_total[m])]
-                   for m in active}
-            jobs = [(vos[m], [dev_frames[m][i][0] for i in idx[m]], [dev_frames[m][i][1] for i in idx[m]])
-                    for m in active]
-            if M == 1:
-                res = [vos[0].run_chunk(jobs[0][1], jobs[0][2], pipeline=pipeline)]
-            else:
-                res = capi.run_chunks(jobs, pipeline=pipeline)
-            for m, (rc, done, Rs, ts, inl, trk, kf) in zip(active, res):
-                if record:
-                    stats["keyframes"] += int(kf[:done].sum())
-                    stats["inliers"] += int(inl[:done].sum())
-                    stats["tracked"] += int(trk[:done].sum())
-                if done:
-                    last[m] = (Rs[done - 1], ts[done - 1])
-                done_total[m] += done
-                if rc:  # tracking lost: re-seed on that frame (the reference would shut down)
-                    stats["lost"] += 1
-                    vos[m].init(*dev_frames[m][idx[m][done]])
-                    done_total[m] += 1
-        return last
+    def jobs_for(a: int, b: int):
+        """frames a+1 .. b of every chunk (chunk-local numbering; frame 0 is the chunk's seed)"""
+        return [(v, lefts[s + a:s + b + 1], rights[s + a:s + b + 1]) for v, (s, e) in zip(sh.vos, bounds)]
 
-    def split(total):
-        return [total // M + (1 if m < total % M else 0) for m in range(M)]
+    def run(a: int, b: int, init: bool, out, stats=None):
+        """advance every chunk from its local frame a to b (init: seed on frame a first)"""
+        res = capi.run_chunks(jobs_for(a, b), pipeline=pipeline, init=init)
+        for m, (rc, done, Rs, ts, inl, trk, kf) in enumerate(res):
+            if rc or done != b - a:
+                raise SystemExit(f"bench: chunk {rank * M + m} lost tracking at local frame {a + done + 1} (rc {rc})")
+            out[m].extend((Rs[i].copy(), ts[i].copy()) for i in range(done))
+            if stats is not None:
+                stats["keyframes"] += int(kf.sum())
+                stats["inliers"] += int(inl.sum())
+                stats["tracked"] += int(trk.sum())
 
-    def sync_all():
-        for c in ctxs:
-            c.sync()
+    ident = (np.eye(3), np.zeros(3))
+    local = [[ident] for _ in range(M)]
+    stats = {"keyframes": 0, "inliers": 0, "tracked": 0}
 
-    run(0, split(args.warmup * M), False)
-    sync_all()
-    for c in ctxs:
+    # ---- warm-up: every chunk's stereo initialisation + its first W frames (untimed) ----
+    run(0, Wn, True, local)
+    sh.sync()
+    for c in sh.ctxs:
         c.enable_kernel_timing(not args.no_kernel_timing)
         c.reset_kernel_time()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    sync_all()
+    sh.sync()
+    # ---- the timed region: EXACTLY --steps steps + the path's one exchange ----
     t0 = time.perf_counter()
-    # EXACTLY --steps steps; one step = one pass of the front-end over the batch this GPU keeps in flight,
-    # i.e. one frame of each of its M chunks (a lock-step group advances all its chunks per set of launches)
-    n_frames = args.steps * M
-    last = run(args.warmup, split(n_frames), True)
+    run(Wn, L, False, local, stats)
     if dist is not None:
-        # the path's one exchange: chunk-boundary poses, 12 doubles per rank, over RCCL
-        from ros_stereo_slam_amd import chunked
-
-        pairs = [p if p is not None else (np.eye(3), np.zeros(3)) for p in last]
-        boundaries = chunked.all_gather_chunk_boundaries(dist, pairs, device="cpu" if rehearsal else "cuda")
-        starts = chunked.prefix_transforms(boundaries)  # global pose of every chunk's first frame
-        assert len(starts) == world * M
-    sync_all()
+        boundaries = chunked.all_gather_chunk_boundaries(dist, [loc[-1] for loc in local], device=coll_dev)
+    else:
+        boundaries = [loc[-1] for loc in local]
+    starts = chunked.prefix_transforms(boundaries)  # global pose of every chunk's first frame
+    assert len(starts) == world * M
+    sh.sync()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
+    elapsed = time.perf_counter() - t0
     times = {}
     for name, kid in (("pyramid", capi.K_PYRAMID), ("lk", capi.K_LK), ("fransac", capi.K_FRANSAC),
                       ("triangulate", capi.K_TRIANGULATE), ("pnp", capi.K_PNP), ("anms", capi.K_ANMS)):
-        per = [c.kernel_time(kid) for c in ctxs]
+        per = [c.kernel_time(kid) for c in sh.ctxs]
         times[name] = (sum(p[0] for p in per), sum(p[1] for p in per))
-    for c in ctxs:
+    for c in sh.ctxs:
         c.enable_kernel_timing(False)
+    n_frames = K * M
 
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+    def max_over_ranks(x: float) -> float:
+        if dist is None:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        return float(tt.item())
 
+    elapsed = max_over_ranks(elapsed)
+
+    # ---- second timed figure: the whole share again, chunk initialisations inside the clock ----
+    extras = {}
+    local2 = None
+    if not args.no_extras:
+        local2 = [[ident] for _ in range(M)]
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(0, L, True, local2)
+        if dist is not None:
+            chunked.all_gather_chunk_boundaries(dist, [loc[-1] for loc in local2], device=coll_dev)
+        sh.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t_full = max_over_ranks(time.perf_counter() - t0)
+        extras["value_including_chunk_inits"] = world * share / t_full
+        extras["rerun_bit_identical"] = all(
+            np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+            for la, lb in zip(local, local2) for a, b in zip(la, lb))
+
+    # ---- stitch: rebase with the prefix transforms, gather the trajectories (configs[3]) ----
+    mine = chunked.join_chunks(local, starts[rank * M:(rank + 1) * M])
+    if dist is not None:
+        parts = chunked.gather_trajectories(dist, mine, device=coll_dev)
+        traj = list(parts[0])
+        for p in parts[1:]:
+            traj.extend(p[1:])
+    else:
+        traj = mine
+
+    result = None
     if rank == 0:
+        truth = rel_truth(poses_all)
+        t_truth = np.array([t for _, t in truth])
+        t_sh = np.array([t for _, t in traj])
+        path_len = float(np.sum(np.linalg.norm(np.diff(t_truth, axis=0), axis=1)))
         fps = world * n_frames / elapsed
         lk_ms, lk_launches = times["lk"]
         lk_avg_s = lk_ms / max(lk_launches, 1) * 1e-3
-        # a launch carries the tracking passes of the chunks of one context that are in step
-        jobs_per_launch = (n_frames * (1.0 + stats["keyframes"] / max(n_frames, 1))) / max(lk_launches, 1)
-        lk_bytes = lk_algorithmic_bytes(N_KPTS) * jobs_per_launch
+        # passes carried by the LK launches of the timed region: one tracking pass per frame + one
+        # stereo pass per keyframe
+        passes = n_frames + stats["keyframes"]
+        passes_per_launch = passes / max(lk_launches, 1)
+        lk_bytes = lk_algorithmic_bytes(n_kpts) * passes_per_launch
         achieved = lk_bytes / lk_avg_s / 1e9 if lk_avg_s > 0 else 0.0
         kf_rate = stats["keyframes"] / n_frames
+        pmc = lk_pmc_constants(n_kpts)
+        roof = {
+            "kernel": "lk_track_kernel<3>",
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": 8000.0,
+            "unit": "GB/s",
+            "frac": achieved / 8000.0,
+            "traffic": pmc["hbm_bytes_per_pass"] * passes_per_launch if pmc else None,
+            "traffic_source": (pmc["source"] + " x passes per launch") if pmc else
+                              "null: profiles/r02_lk_pmc.json absent or taken on another lk.hip / keypoint count",
+            "avg_launch_us": lk_avg_s * 1e6,
+            "launches_per_step": lk_launches / K,
+            "algorithmic_bytes_per_launch": lk_bytes,
+            "lk_passes_per_launch": passes_per_launch,
+            "frame_hbm_frac": frame_algorithmic_bytes(n_kpts, kf_rate) / (elapsed / n_frames) / 8e12,
+            "note": "HBM is the roofline the contract names; the kernel itself is bound by VALU issue "
+                    "(valu_* keys: wave-instructions per pass from SQ_INSTS_VALU x the measured cycles per "
+                    "wave-instruction of this instruction mix, tools/valu_rate.hip)",
+        }
+        if pmc:
+            cyc = pmc["valu_cycles_per_wave_inst"]       # measured on this chip, not assumed
+            clk = pmc["sclk_hz_under_load"]
+            need_s = pmc["valu_insts_per_pass"] * cyc / 1024.0 / clk   # per pass, all 1024 SIMDs issuing
+            roof.update({
+                "valu_insts_per_pass": pmc["valu_insts_per_pass"],
+                "valu_cycles_per_wave_inst": cyc,
+                "valu_sclk_hz": clk,
+                "valu_issue_bound_us_per_launch": need_s * passes_per_launch * 1e6,
+                "valu_kernel_frac": need_s * passes_per_launch / lk_avg_s if lk_avg_s > 0 else None,
+                "valu_chip_frac": need_s * passes / elapsed,
+            })
+        ate_sh = chunked.ate_rmse(t_sh, t_truth)
         result = {
-            "metric": f"stereo frames/sec @1241x376, {N_KPTS} kpts",
+            "metric": f"stereo frames/sec @1241x376, {n_kpts} kpts",
             "value": fps,
             "unit": "frames/s",
             "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "steps": K,
+            "warmup": Wn,
+            "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u8/i32 fixed-point (LK) + f32/f64 (geometry)",
             "data": "synthetic",
             "config": {
-                "workload": f"synthetic corridor 1241x376x3 stereo stream, grid step {GRID_STEP} -> ANMS {N_KPTS} keypoints, "
-                            "front-end only (BASELINE configs[1]): pyramid + LK + F-RANSAC + PnP-RANSAC + "
-                            "keyframe path (LK L->R, F-RANSAC, DLT triangulation)",
-                "keyframe_min_inliers": KF_MIN_INLIERS,
-                "parallelism": f"{M} contiguous chunk(s) per GPU x{world} GPU(s), all-gather of chunk-boundary poses",
+                "workload": f"synthetic loop stream 1241x376x3 (0.9 m/frame, 492-frame lap), {world * share + 1} frames, "
+                            f"grid step {grid_step} -> ANMS {n_kpts} keypoints, front-end only (BASELINE configs[1]): "
+                            "pyramid + LK + F-RANSAC + PnP-RANSAC + keyframe path (LK L->R, F-RANSAC, DLT triangulation)",
+                "keyframe_min_inliers": kf_min,
+                "parallelism": f"{M} contiguous chunk(s) of {L} frames per GPU x{world} GPU(s), one all-gather of "
+                               "chunk-boundary poses",
                 "chunks_per_gpu": M,
                 "chunks_per_context": G,
-                "single_chunk_reference": "one chunk alone: 1.85 k frames/s with the two-stream pipeline "
-                                          "(--chunks-per-gpu 1), 1.32 k serial (DESIGN.md section 6)",
+                "frames_per_chunk": L,
                 "pipeline": "two HIP streams per chunk: PnP(t) beside pyramid+LK(t+1)" if pipeline
-                            else "one in-order HIP stream per chunk",
+                            else "one in-order HIP stream per context",
                 "keyframe_rate": kf_rate,
                 "frames_per_step": M * world,
                 "mean_tracked": stats["tracked"] / n_frames,
                 "mean_pnp_inliers": stats["inliers"] / n_frames,
-                "tracking_lost": stats["lost"],
-                "init_points": n0,
+                "render_s": render_s,
                 "stage_ms_per_frame": {k: v[0] / n_frames for k, v in times.items()},
             },
-            "roofline": {
-                "kernel": "lk_track_kernel<3>",
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": 8000.0,
-                "unit": "GB/s",
-                "frac": achieved / 8000.0,
-                "traffic": LK_PMC_TRAFFIC_BYTES * jobs_per_launch if (W, H, C, N_KPTS) == (1241, 376, 3, 4096) else None,
-                "traffic_source": "profiles/r01_pmc_hbm_traffic_v8.csv (rocprofv3 --pmc, (2*FETCH_SIZE+WRITE_SIZE)*1024, "
-                                  "per tracking pass) x passes per launch",
-                "avg_launch_us": lk_avg_s * 1e6,
-                "launches_per_step": lk_launches / args.steps,
-                "launches_per_frame": lk_launches / n_frames,
-                "algorithmic_bytes_per_launch": lk_bytes,
-                "lk_passes_per_launch": jobs_per_launch,
-                "valu_issue_bound_us": (LK_PMC_VALU_INSTS * jobs_per_launch * 4 / 1024 / 2.4e9 * 1e6)
-                                       if N_KPTS == 4096 else None,
-                "valu_issue_frac": (LK_PMC_VALU_INSTS * jobs_per_launch * 4 / 1024 / 2.4e9) / lk_avg_s
-                                   if (N_KPTS == 4096 and lk_avg_s > 0) else None,
-                # launches of the four contexts overlap, so the chip-level figure is the meaningful one: VALU issue
-                # cycles LK asks for per second over what 1024 SIMDs offer (LK issues 83 % of all VALU instructions)
-                "valu_chip_frac": (LK_PMC_VALU_INSTS * jobs_per_launch * lk_launches * 4 / 1024 / 2.4e9) / elapsed
-                                  if N_KPTS == 4096 else None,
-                "valu_chip_frac_at_observed_clock": (LK_PMC_VALU_INSTS * jobs_per_launch * lk_launches * 4 / 1024
-                                                     / LK_OBSERVED_SCLK_HZ) / elapsed if N_KPTS == 4096 else None,
-                "frame_hbm_frac": frame_algorithmic_bytes(N_KPTS, kf_rate) / (elapsed / n_frames) / 8e12,
-            },
+            "path_length_m": path_len,
+            "ate_rmse_vs_truth": ate_sh,
+            "ate_over_path_length": ate_sh / path_len,
+            "roofline": roof,
         }
-        if not args.no_cpu_baseline and world == 1:
-            from oracle import orc  # the checker, timed as the CPU baseline ("port")
+        result.update(extras)
 
-            def oracle_rate(threads: int, frames: int) -> float:
-                orc.set_num_threads(threads)
-                o = orc.VO(W, H, C, grid_step=GRID_STEP, anms_keep=N_KPTS, keyframe_min_inliers=KF_MIN_INLIERS,
-                           seed=20261003)
-                o.init(*host_frames[0][0])
-                c0 = time.perf_counter()
-                for i in range(frames):
-                    l, r = host_frames[0][pingpong(i + 1, args.frames)]
-                    if o.track(l, r)[0]:
-                        o.init(l, r)
-                dt = time.perf_counter() - c0
-                o.close()
-                return frames / dt
+    # ---- one contiguous chunk per GPU (the north-star's partitioning), measured, rank 0's share ----
+    if rank == 0 and not args.no_extras:
+        ctx1 = capi.Context(local_rank)
+        one = capi.VisualOdometry(ctx1, W, H, C, seed=20261003, **vo_kw)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        one.init(lefts[0], rights[0])
+        rc, done, R1, t1, inl1, trk1, kf1 = one.run_chunk(lefts[1:], rights[1:], pipeline=True)
+        ctx1.sync()
+        dt = time.perf_counter() - t0
+        if rc or done != share:
+            result["single_chunk_frames_per_s"] = None
+            result["single_chunk_note"] = f"tracking lost after {done} frames"
+        else:
+            t_seq = np.vstack([np.zeros((1, 3)), t1])
+            result["single_chunk_frames_per_s"] = share / dt
+            result["single_chunk_frames"] = share
+            result["single_chunk_keyframe_rate"] = float(kf1.mean())
+            n1 = share + 1
+            result["ate_rmse_sequential_vs_truth"] = chunked.ate_rmse(t_seq, t_truth[:n1])
+            result["ate_rmse_sharded_vs_sequential"] = chunked.ate_rmse(t_sh[:n1], t_seq)
+            result["ate_rmse_sharded_vs_truth_same_frames"] = chunked.ate_rmse(t_sh[:n1], t_truth[:n1])
+            result["ate_sharded_vs_sequential_over_path_length"] = (
+                result["ate_rmse_sharded_vs_sequential"] / (path_len * share / (world * share)))
+        one.close()
+        ctx1.close()
 
-            cores = min(os.cpu_count() or 1, 16)
-            multi = oracle_rate(cores, args.cpu_frames)
-            single = oracle_rate(1, max(6, args.cpu_frames // 4))
-            result["cpu_baseline"] = {
-                "value": multi,
-                "unit": "frames/s",
-                "cores": cores,
-                "kind": "port",
-                "sample": f"{args.cpu_frames} frames of the same stream and stages, oracle C (-O2, OpenMP over "
-                          f"keypoints in LK and ANMS, RANSAC stages scalar), {cores} threads",
-                "single_thread_value": single,
-            }
+    # ---- configs[3]'s global solve on the stitched trajectory (rank 0; also configs[2]'s figure) ----
+    if rank == 0 and not args.no_extras:
+        matches = synth.loop_closures(poses_all, max_dist=0.3, max_angle_deg=10.0, min_gap=100, pick="nearest")
+        closures = chunked.gate_closures(matches)
+        ctxg = capi.Context(local_rank)
+        pg = capi.PoseGraph(ctxg)
+        ctxg.enable_kernel_timing(True)
+        t0 = time.perf_counter()
+        est, chi2 = chunked.global_solve(pg, traj, closures, iters=10)
+        dt = time.perf_counter() - t0
+        pg_ms, _ = ctxg.kernel_time(capi.K_POSEGRAPH)
+        result["posegraph"] = {
+            "vertices": len(traj), "loop_closures": len(closures), "gn_iterations": 10,
+            "posegraph_ms_per_iter": pg_ms / 10.0,
+            "solve_wall_ms_incl_graph_build": dt * 1e3,
+            "chi2_first": float(chi2[0]), "chi2_last": float(chi2[-1]),
+            "ate_rmse_vs_truth_before": ate_sh,
+            "ate_rmse_vs_truth_after": chunked.ate_rmse(est[:, :3], t_truth),
+        }
+        pg.close()
+        ctxg.close()
+
+    # ---- CPU baseline: the oracle on the node's own cores, a bounded sample of the same stream ----
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        from oracle import orc  # the checker, timed as the CPU baseline ("port")
+
+        native = orc.use_native_build()
+        nf = min(max(2, args.cpu_frames), L)
+        host = [(lefts[i].cpu().numpy(), rights[i].cpu().numpy()) for i in range(nf + 1)]
+
+        def oracle_run(threads: int, frames: int):
+            orc.set_num_threads(threads)
+            o = orc.VO(W, H, C, grid_step=grid_step, anms_keep=n_kpts, keyframe_min_inliers=kf_min, seed=20261003)
+            c0 = time.perf_counter()
+            o.init(*host[0])
+            out = []
+            for i in range(1, frames + 1):
+                rc, R, t, *_ = o.track(*host[i])
+                if rc:
+                    break
+                out.append((R.copy(), t.copy()))
+            dt = time.perf_counter() - c0
+            o.close()
+            return (len(out) + 1) / dt, out
+
+        cores = os.cpu_count() or 1
+        threads = min(cores, 32)
+        multi, o_poses = oracle_run(threads, nf)
+        single, _ = oracle_run(1, max(3, nf // 4))
+        g_poses = local[0][1:1 + len(o_poses)]   # chunk 0 of rank 0 started on the same frame with the same seed
+        dts = [float(np.linalg.norm(tg - to)) for (Rg, tg), (Ro, to) in zip(g_poses, o_poses)]
+        dRs = [rot_angle(Rg, Ro) for (Rg, tg), (Ro, to) in zip(g_poses, o_poses)]
+        result["ate_rmse_vs_oracle"] = chunked.ate_rmse([t for _, t in g_poses], [t for _, t in o_poses])
+        result["max_frame_delta_vs_oracle"] = {"translation_m": max(dts), "rotation_rad": max(dRs), "frames": len(dts)}
+        result["cpu_baseline"] = {
+            "value": multi,
+            "unit": "frames/s",
+            "cores": threads,
+            "host_cpu_count": cores,
+            "kind": "port",
+            "sample": f"chunk 0 of the same stream: stereo initialisation + {nf} frames, same stages, oracle C "
+                      f"({'-O3 -march=native, built on this host' if native else '-O3 -march=x86-64-v3 (prebuilt)'}, "
+                      f"OpenMP over keypoints in LK and ANMS, RANSAC stages scalar), {threads} threads",
+            "single_thread_value": single,
+        }
+
+    if rank == 0:
         print(json.dumps(result))
     if dist is not None:
         dist.destroy_process_group()
-    for v in vos:
-        v.close()
-    for c in ctxs:
-        c.close()
+    sh.close()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -28,6 +28,7 @@
 #ifndef SVO_H
 #define SVO_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -260,7 +261,9 @@ int svo_vo_track(svo_vo *vo, const uint8_t *left, const uint8_t *right, int mem,
 int svo_vo_run_chunk(svo_vo *vo, const uint8_t *const *lefts, const uint8_t *const *rights, int n_frames,
                      int mem, int pipeline, double *R_out, double *t_out, int *inliers_out,
                      int *tracked_out, uint8_t *keyframe_out, int *n_done);
-/* Several independent chunks of a stream at once on ONE GPU (the per-GPU form of SURVEY.md 8e's
+/* Precondition for jobs that share a context: identical image size, channels, grid step, ANMS budget,
+ * intrinsics and baseline (their stages are sized as one launch); SVO_ERR_ARG otherwise.
+ * Several independent chunks of a stream at once on ONE GPU (the per-GPU form of SURVEY.md 8e's
  * chunk sharding): every job is one svo_vo_run_chunk() call on its own host thread.  The
  * front-end's kernels are latency-bound (one wave per keypoint / hypothesis, a few hundred to a
  * few thousand waves per launch), so chunks on separate contexts interleave on the chip.  Jobs
@@ -279,6 +282,12 @@ typedef struct svo_chunk_job {
     int *inliers_out, *tracked_out;
     uint8_t *keyframe_out;
     int n_done, rc;
+    /* When both are set the chunk (re-)initialises on this stereo pair first -- svo_vo_init: stereo
+     * keyframe, identity pose (every chunk of a sharded stream starts like frame 0,
+     * src/VisualSLAM.cpp:22-41) -- and lefts / rights are the frames AFTER it.  The initialisations
+     * of the jobs of one group go out as one set of launches.  NULL: continue from the current state. */
+    const uint8_t *init_left, *init_right;
+    int n_init_points; /* out: points of the initial keyframe (when initialised here) */
 } svo_chunk_job;
 int svo_vo_run_chunks(svo_chunk_job *jobs, int n_jobs);
 /* the current reference point set (2-D in the reference image, 3-D world) */
@@ -321,6 +330,23 @@ int svo_io_write_kitti_poses(const char *path, const double *R9s, const double *
 /* trajectory.csv of the reference (createData / appendData, include/monoUtils.h:23-49): header
  * "Idx,Xm,Ym,Zm,Xgt,Ygt,Zgt,Const" when create != 0, then rows of 8 floats each followed by ','  */
 int svo_io_trajectory_csv(const char *path, const float *rows8, int n_rows, int create);
+/* Sequence input: visualSLAM::loadImageL / loadImageR (src/keyFrameManagement.cpp:48-71) =
+ * sprintf(FileName, pattern, iter) + cv::imread(FileName) -> BGR8.  pattern: the reference's
+ * "<dir>/image_2/%0.6d.png"-style string (src/VisualSLAM.cpp:220-222) with exactly one integer
+ * conversion.  Decoded here: binary PGM (P5) and PPM (P6), 8 bit; PNG decoding stays with the caller
+ * (ros_stereo_slam_amd/sequence.py uses PIL when present).  channels = 3 gives what imread's
+ * default IMREAD_COLOR gives (B,G,R interleaved; a grey file replicated), 1 a grey image.  A
+ * missing file is SVO_ERR_ARG with the reference's "failed to fetch frame, check the paths" text. */
+int svo_io_format_path(char *out, int cap, const char *pattern, int iter);
+int svo_io_image_info(const char *path, int *w, int *h, int *c);
+int svo_io_read_image(const char *path, int channels, uint8_t *out, size_t cap_bytes, int *w, int *h);
+int svo_io_load_frame(const char *pattern, int iter, int channels, uint8_t *out, size_t cap_bytes, int *w, int *h);
+/* the inverse (tests, dataset conversion): BGR / grey -> PPM / PGM */
+int svo_io_write_image(const char *path, const uint8_t *img, int w, int h, int channels);
+/* getAbsoluteScale(frame_id, X, Y, Z), include/monoUtils.h:130-158: position of frame_id - 1 in a
+ * KITTI pose file and the distance frame_id - 1 -> frame_id (the reference's ground-truth reader) */
+int svo_io_absolute_scale(const char *poses_path, int frame_id, double *x_prev, double *y_prev, double *z_prev,
+                          double *scale);
 /* absolute trajectory error: RMSE of |t_est - t_gt| (no alignment: both start at the identity)   */
 int svo_eval_ate_rmse(const double *t3_est, const double *t3_gt, int n, double *rmse);
 /* relative pose error over frame pairs (i, i + delta): E = (Qi^-1 Qj)^-1 (Pi^-1 Pj); RMSE of the

@@ -21,6 +21,21 @@ def build():
     subprocess.run(["make", "-s", "-C", os.fspath(_HERE)], check=True)
 
 
+def use_native_build() -> bool:
+    """bench.py's cpu_baseline leg: rebuild the oracle on THIS machine with -O3 -march=native
+    (oracle/_build_native/) and load that one.  Must be called before the first load().  Returns
+    False (and keeps the portable prebuilt library) when no compiler is available."""
+    global LIB_PATH
+    assert _lib is None, "use_native_build() must come before the oracle is first loaded"
+    try:
+        subprocess.run(["make", "-s", "-j", "8", "-C", os.fspath(_HERE), "OUTDIR=_build_native",
+                        "ARCHFLAGS=-march=native"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    except (OSError, subprocess.CalledProcessError):
+        return False
+    LIB_PATH = _HERE / "_build_native" / "libsvo_oracle.so"
+    return True
+
+
 def load() -> C.CDLL:
     global _lib
     if _lib is None:

@@ -481,15 +481,21 @@ class _ChunkJob(C.Structure):
     _fields_ = [("vo", C.c_void_p), ("lefts", C.c_void_p), ("rights", C.c_void_p), ("n_frames", C.c_int),
                 ("mem", C.c_int), ("pipeline", C.c_int), ("R_out", C.c_void_p), ("t_out", C.c_void_p),
                 ("inliers_out", C.c_void_p), ("tracked_out", C.c_void_p), ("keyframe_out", C.c_void_p),
-                ("n_done", C.c_int), ("rc", C.c_int)]
+                ("n_done", C.c_int), ("rc", C.c_int), ("init_left", C.c_void_p), ("init_right", C.c_void_p),
+                ("n_init_points", C.c_int)]
 
 
-def run_chunks(jobs, pipeline: bool = True):
-    """``svo_vo_run_chunks``: jobs = [(vo, lefts, rights), ...], one VisualOdometry per Context.
+def run_chunks(jobs, pipeline: bool = True, init: bool = False):
+    """``svo_vo_run_chunks``: jobs = [(vo, lefts, rights), ...]; front-ends that share a Context run in
+    lock step.  With ``init`` every chunk first (re-)initialises on its frame 0 (stereo keyframe,
+    identity pose) and tracks frames 1..; outputs then hold ``len(lefts) - 1`` frames.
     Returns one (rc, n_done, R, t, inliers, tracked, keyframe) tuple per job."""
     arr = (_ChunkJob * len(jobs))()
     keep, outs = [], []
     for k, (vo, lefts, rights) in enumerate(jobs):
+        if init:
+            arr[k].init_left, arr[k].init_right = _ptr(lefts[0]).value, _ptr(rights[0]).value
+            lefts, rights = lefts[1:], rights[1:]
         n = len(lefts)
         PtrArr = C.c_void_p * max(n, 1)
         la = PtrArr(*[_ptr(x).value for x in lefts])
@@ -501,7 +507,8 @@ def run_chunks(jobs, pipeline: bool = True):
         outs.append((R, t, inl, trk, kf))
         j = arr[k]
         j.vo, j.lefts, j.rights = vo._h, C.addressof(la), C.addressof(ra)
-        j.n_frames, j.mem, j.pipeline = n, (vo._mem(lefts[0]) if n else MEM_DEVICE), int(bool(pipeline))
+        j.n_frames, j.pipeline = n, int(bool(pipeline))
+        j.mem = vo._mem(jobs[k][1][0]) if len(jobs[k][1]) else MEM_DEVICE
         j.R_out, j.t_out, j.inliers_out = _ptr(R), _ptr(t), _ptr(inl)
         j.tracked_out, j.keyframe_out = _ptr(trk), _ptr(kf)
     _check(jobs[0][0].ctx.lib.svo_vo_run_chunks(arr, len(jobs)))

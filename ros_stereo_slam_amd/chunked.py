@@ -176,3 +176,106 @@ def ate_rmse(est_t, gt_t):
     trajectories start at the identity pose of frame 0)."""
     d = np.asarray(est_t, np.float64) - np.asarray(gt_t, np.float64)
     return float(np.sqrt(np.mean(np.sum(d * d, axis=1))))
+
+
+# ---- BASELINE configs[3] as one callable: shard -> all-gather -> rebase -> closures on global ids ->
+# ONE global solve (src/VisualSLAM.cpp:76-86, include/poseGraph.h:113-138, SURVEY.md 8e) -------------
+class ShardedVO:
+    """One rank's share of a chunk-sharded stream: ``n_chunks`` contiguous chunks of the rank's
+    frames run side by side on this GPU (``svo_vo_run_chunks``), ``chunks_per_context`` of them per
+    context in lock step.  Every chunk re-initialises at its first frame (stereo keyframe, identity
+    pose) inside the same call."""
+
+    def __init__(self, capi, device: int, w: int, h: int, c: int, n_chunks: int, chunks_per_context: int = 16,
+                 first_chunk_id: int = 0, seed: int = 0, **vo_kwargs):
+        self.capi = capi
+        self.n_chunks = n_chunks
+        g = max(1, min(16, chunks_per_context))
+        self.ctxs = [capi.Context(device) for _ in range((n_chunks + g - 1) // g)]
+        self.vos = [capi.VisualOdometry(self.ctxs[m // g], w, h, c, seed=seed + first_chunk_id + m, **vo_kwargs)
+                    for m in range(n_chunks)]
+
+    def run(self, lefts, rights, pipeline: bool = False):
+        """``lefts`` / ``rights``: this rank's frames INCLUDING the first frame of the next rank's
+        share (one frame of overlap).  Returns (local, stats): ``local[m]`` = chunk m's poses relative
+        to its own first frame, one per frame of the chunk incl. its overlap frame; ``stats[m]`` =
+        (inliers, tracked, keyframe) arrays.  Raises when a chunk loses tracking."""
+        bounds = chunk_bounds(len(lefts), self.n_chunks)
+        jobs = [(v, lefts[s:e + 1], rights[s:e + 1]) for v, (s, e) in zip(self.vos, bounds)]
+        res = self.capi.run_chunks(jobs, pipeline=pipeline, init=True)
+        local, stats = [], []
+        for (s, e), (rc, done, R, t, inl, trk, kf) in zip(bounds, res):
+            if rc or done != e - s:
+                raise RuntimeError(f"chunk [{s}, {e}]: tracking lost after {done} frames (rc {rc})")
+            local.append([(np.eye(3), np.zeros(3))] + [(R[i].copy(), t[i].copy()) for i in range(done)])
+            stats.append((inl, trk, kf))
+        return local, stats
+
+    def sync(self):
+        for c in self.ctxs:
+            c.sync()
+
+    def close(self):
+        for v in self.vos:
+            v.close()
+        for c in self.ctxs:
+            c.close()
+
+
+def join_chunks(local, starts):
+    """Chunk-local pose lists + the global pose of every chunk's first frame -> one pose list without
+    the duplicated overlap frames."""
+    traj = []
+    for k, (loc, st) in enumerate(zip(local, starts)):
+        glob = rebase(loc, *st)
+        traj.extend(glob if k == 0 else glob[1:])
+    return traj
+
+
+def stitch_chunks(dist, local, device=None):
+    """The exchange step for a rank that ran several chunks: ONE all-gather of the chunk-boundary
+    poses (12 doubles per chunk), prefix composition, rebase, then the gather of the rebased
+    trajectories.  ``dist`` None = single process.  Returns the global trajectory [(R, t)] (identical
+    on every rank)."""
+    pairs = [loc[-1] for loc in local]
+    if dist is None:
+        return join_chunks(local, prefix_transforms(pairs))
+    rank, m = dist.get_rank(), len(local)
+    boundaries = all_gather_chunk_boundaries(dist, pairs, device=device)
+    starts = prefix_transforms(boundaries)
+    mine = join_chunks(local, starts[rank * m:(rank + 1) * m])
+    # join_chunks rebases chunk 0 of this rank with starts[rank*m], so `mine` is already global
+    parts = gather_trajectories(dist, mine, device=device)
+    traj = list(parts[0])
+    for p in parts[1:]:
+        traj.extend(p[1:])  # a rank's first frame is the previous rank's last
+    return traj
+
+
+def global_solve(pg, traj, closures, iters: int = 10):
+    """The single global pose-graph solve of the sharded mode: vertices in frame order with the
+    reference's staging (a closure detected at frame q adds the identity edge from vertex q-1 to
+    ``LCidx = match - 1`` BEFORE vertex q is added, src/optimizationStuff.cpp:3-15,58-63), then one
+    ``globalOptimize`` (include/poseGraph.h:128-138).  ``closures``: {query frame: matched frame} on
+    GLOBAL frame ids.  Returns (estimates [n, 7], chi2 [iters + 1])."""
+    for q in range(1, len(traj)):
+        m = closures.get(q, -1) if closures else -1
+        if m >= 0:
+            pg.add_loop_closure(max(m - 1, 0))
+        pg.augment_node(pose7(*traj[q]))
+    chi2 = pg.optimize(iters)
+    return pg.estimates(), chi2
+
+
+def gate_closures(matches, min_gap: int = 100, cooldown: int = 100):
+    """The reference's acceptance rule applied to a per-frame match list (-1 = none): accept iff
+    ``query - match > min_gap`` and the cooldown has run out, then hold off for ``cooldown`` frames
+    (src/optimizationStuff.cpp:58-63, src/VisualSLAM.cpp:148-150).  -> {query: match}."""
+    out, cd = {}, 0
+    for q, m in enumerate(matches):
+        if m >= 0 and q - m > min_gap and cd == 0:
+            out[q] = m
+            cd = cooldown
+        if cd:
+            cd -= 1
+    return out

@@ -17,7 +17,7 @@
 // solve/score run in two phases (iterations [0,64) and [64,max)); phase-two kernels return at
 // once when the adaptive bound was reached in phase one, which is the common case at VO
 // inlier ratios (0.99 confidence, 85% inliers -> 12 iterations).
-#include "ransac_common.cuh"
+#include "ransac_common.hip.h"
 #include "svo_internal.h"
 
 using namespace svo;

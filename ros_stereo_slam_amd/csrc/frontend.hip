@@ -19,6 +19,7 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <chrono>
 #include <cmath>
 
 #include "svo_internal.h"
@@ -72,6 +73,37 @@ template <class T> int dev_alloc(T **p, size_t count)
         return SVO_ERR_HIP;
     }
     return SVO_OK;
+}
+
+// Spin on a tag a kernel releases into the pinned mailbox.  Now and then the stream is asked whether
+// it is still alive (an error, or a stream that drained without publishing, ends the wait), and a
+// wall-clock bound ends a wait on a stream that hangs without reporting an error.
+constexpr double SVO_MAILBOX_TIMEOUT_S = 60.0;
+int wait_mailbox_tag(const int *slot, int tag, hipStream_t stream)
+{
+    std::chrono::steady_clock::time_point t0;
+    bool timing = false;
+    for (unsigned spins = 1;; spins++) {
+        if (__atomic_load_n(slot, __ATOMIC_ACQUIRE) == tag)
+            return SVO_OK;
+        if ((spins & 0x3FFFF) == 0) {
+            hipError_t e = hipStreamQuery(stream);
+            if (e == hipSuccess && __atomic_load_n(slot, __ATOMIC_ACQUIRE) != tag)
+                e = hipErrorUnknown;  // drained without publishing
+            if (e != hipSuccess && e != hipErrorNotReady) {
+                svo_set_error("waiting for the PnP mailbox -> %s", hipGetErrorString(e));
+                return SVO_ERR_HIP;
+            }
+            const auto now = std::chrono::steady_clock::now();
+            if (!timing) {
+                t0 = now;
+                timing = true;
+            } else if (std::chrono::duration<double>(now - t0).count() > SVO_MAILBOX_TIMEOUT_S) {
+                svo_set_error("waiting for the PnP mailbox: no tag after %.0f s, the stream hangs", SVO_MAILBOX_TIMEOUT_S);
+                return SVO_ERR_HIP;
+            }
+        }
+    }
 }
 
 int grid_axis(int dim, int step)
@@ -352,6 +384,7 @@ int svo_vo_create(svo_ctx *ctx, const svo_vo_params *params, int width, int heig
         svo_vo_destroy(v);
         return SVO_ERR_HIP;
     }
+    memset(v->mbox, 0, sizeof(Mailbox));  // a recycled pinned block may hold a destroyed front-end's tags
     for (int i = 0; i < 9; i++)
         v->R[i] = (i % 4) == 0;
     v->t[0] = v->t[1] = v->t[2] = 0;
@@ -573,21 +606,7 @@ int svo_vo_run_chunk(svo_vo *v, const uint8_t *const *lefts, const uint8_t *cons
     int pending = -1;  // frame whose refined pose has not been collected yet
     int rc;
     // spin on a tag a kernel releases into the mailbox; now and then make sure the stream is alive
-    auto wait_tag = [&](const int *slot, int tag, hipStream_t stream) -> int {
-        for (unsigned spins = 1;; spins++) {
-            if (__atomic_load_n(slot, __ATOMIC_ACQUIRE) == tag)
-                return SVO_OK;
-            if ((spins & 0x3FFFF) == 0) {
-                hipError_t e = hipStreamQuery(stream);
-                if (e == hipSuccess && __atomic_load_n(slot, __ATOMIC_ACQUIRE) != tag)
-                    e = hipErrorUnknown;  // drained without publishing
-                if (e != hipSuccess && e != hipErrorNotReady) {
-                    svo_set_error("waiting for the PnP mailbox -> %s", hipGetErrorString(e));
-                    return SVO_ERR_HIP;
-                }
-            }
-        }
-    };
+    auto wait_tag = [&](const int *slot, int tag, hipStream_t stream) -> int { return wait_mailbox_tag(slot, tag, stream); };
     auto harvest = [&](int f) {  // record of frame f is on the host: pose composition (src/VisualSLAM.cpp:70-74)
         const PnpRecord *rec = &mb->rec[f & 1];
         double *R9 = R_out + 9 * (size_t)f, *t3 = t_out + 3 * (size_t)f;
@@ -774,21 +793,7 @@ static int run_chunk_group(svo_chunk_job **jobs, int k)
         }
         n_frames_max = jobs[a]->n_frames > n_frames_max ? jobs[a]->n_frames : n_frames_max;
     }
-    auto wait_tag = [&](const int *slot, int tag) -> int {
-        for (unsigned spins = 1;; spins++) {
-            if (__atomic_load_n(slot, __ATOMIC_ACQUIRE) == tag)
-                return SVO_OK;
-            if ((spins & 0x3FFFF) == 0) {
-                hipError_t e = hipStreamQuery(st);
-                if (e == hipSuccess && __atomic_load_n(slot, __ATOMIC_ACQUIRE) != tag)
-                    e = hipErrorUnknown;
-                if (e != hipSuccess && e != hipErrorNotReady) {
-                    svo_set_error("waiting for the PnP mailbox -> %s", hipGetErrorString(e));
-                    return SVO_ERR_HIP;
-                }
-            }
-        }
-    };
+    auto wait_tag = [&](const int *slot, int tag) -> int { return wait_mailbox_tag(slot, tag, st); };
     auto harvest = [&](GS &g, int f) {  // pose composition (src/VisualSLAM.cpp:70-74)
         const PnpRecord *rec = &g.v->mbox->rec[f & 1];
         double *R9 = g.j->R_out + 9 * (size_t)f, *t3 = g.j->t_out + 3 * (size_t)f;
@@ -823,6 +828,48 @@ static int run_chunk_group(svo_chunk_job **jobs, int k)
         g.j->rc = rc;
     };
     int rc;
+    {   // ---- chunks that start here: svo_vo_init of all of them as one set of launches ----
+        svo_vo *vs[SVO_LK_MAX_JOBS];
+        svo_pyramid *pl[SVO_LK_MAX_JOBS], *pr[SVO_LK_MAX_JOBS];
+        const uint8_t *il[SVO_LK_MAX_JOBS], *ir[SVO_LK_MAX_JOBS];
+        const double *Rts[SVO_LK_MAX_JOBS];
+        float *o2d[SVO_LK_MAX_JOBS], *o3d[SVO_LK_MAX_JOBS];
+        int *nout[SVO_LK_MAX_JOBS];
+        int ni = 0;
+        for (GS &g : gs) {
+            if (!g.j->init_left != !g.j->init_right) {
+                svo_set_error("svo_vo_run_chunks: init_left and init_right go together");
+                return SVO_ERR_ARG;
+            }
+            if (!g.j->init_left)
+                continue;
+            svo_vo *v = g.v;
+            v->frame = 0;
+            for (int i = 0; i < 9; i++)
+                v->R[i] = (i % 4) == 0;
+            v->t[0] = v->t[1] = v->t[2] = 0;
+            v->has_cur = false;
+            vs[ni] = v;
+            pl[ni] = v->pyr_ref;
+            pr[ni] = v->pyr_right;
+            il[ni] = g.j->init_left;
+            ir[ni] = g.j->init_right;
+            Rts[ni] = nullptr;
+            o2d[ni] = v->ref2d;
+            o3d[ni] = v->ref3d;
+            nout[ni] = &v->nref;
+            ni++;
+        }
+        if (ni > 0) {
+            if ((rc = svo_build_pyramids_from_device(ctx, ni, pl, il)) ||
+                (rc = svo_build_pyramids_from_device(ctx, ni, pr, ir)) ||
+                (rc = stereo_triangulate_batch(ni, vs, pl, pr, Rts, o2d, o3d, nout)))
+                return rc;
+            for (GS &g : gs)
+                if (g.j->init_left)
+                    g.j->n_init_points = g.v->nref;
+        }
+    }
     for (int f = 0; f < n_frames_max; f++) {
         // ---- pyramids + ONE tracking launch for all the chunks still running ----
         LkJob lk[SVO_LK_MAX_JOBS];
@@ -1050,6 +1097,17 @@ int svo_vo_run_chunks(svo_chunk_job *jobs, int n_jobs)
                         svo_set_error("svo_vo_run_chunks: a front-end appears in two jobs");
                         return SVO_ERR_ARG;
                     }
+                {  // a group's stages go out as one set of launches sized from its first member
+                    const svo_vo *x = g[0]->vo, *y = jobs[a].vo;
+                    const svo_vo_params &p = x->prm, &q = y->prm;
+                    if (x->w != y->w || x->h != y->h || x->c != y->c || x->cap != y->cap || p.grid_step != q.grid_step ||
+                        p.anms_keep != q.anms_keep || p.fx != q.fx || p.fy != q.fy || p.cx != q.cx || p.cy != q.cy ||
+                        p.baseline != q.baseline) {
+                        svo_set_error("svo_vo_run_chunks: the front-ends of one context must share image size, "
+                                      "grid step, ANMS budget, intrinsics and baseline");
+                        return SVO_ERR_ARG;
+                    }
+                }
                 if ((int)g.size() >= SVO_LK_MAX_JOBS) {
                     svo_set_error("svo_vo_run_chunks: at most %d chunks per context", SVO_LK_MAX_JOBS);
                     return SVO_ERR_ARG;
@@ -1074,6 +1132,16 @@ int svo_vo_run_chunks(svo_chunk_job *jobs, int n_jobs)
         if (g.size() == 1) {
             svo_chunk_job &j = *g[0];
             j.n_done = 0;
+            if (!j.init_left != !j.init_right) {
+                grc[gi] = SVO_ERR_ARG;
+                errs[gi] = "svo_vo_run_chunks: init_left and init_right go together";
+                return;
+            }
+            if (j.init_left && (j.rc = svo_vo_init(j.vo, j.init_left, j.init_right, j.mem, &j.n_init_points))) {
+                grc[gi] = j.rc;
+                errs[gi] = svo_last_error();
+                return;
+            }
             j.rc = svo_vo_run_chunk(j.vo, j.lefts, j.rights, j.n_frames, j.mem, j.pipeline, j.R_out, j.t_out,
                                     j.inliers_out, j.tracked_out, j.keyframe_out, &j.n_done);
             if (j.rc && j.rc != SVO_ERR_TRACKING_LOST)

@@ -238,3 +238,238 @@ int svo_io_write_ply(const char *path, const float *xyz, const uint8_t *rgb, int
 }
 
 }  // extern "C"
+
+// ---- sequence input: visualSLAM::loadImageL / loadImageR, src/keyFrameManagement.cpp:48-71 ----
+
+namespace {
+// header of a binary PGM (P5) / PPM (P6): magic, width, height, maxval with '#' comments between
+// tokens, then exactly one whitespace byte
+int pnm_header(FILE *f, const char *path, int *magic, int *w, int *h)
+{
+    char m[3] = {0, 0, 0};
+    if (fread(m, 1, 2, f) != 2 || m[0] != 'P' || (m[1] != '5' && m[1] != '6')) {
+        svo_set_error("%s: not a binary PGM (P5) / PPM (P6) file", path);
+        return SVO_ERR_ARG;
+    }
+    *magic = m[1] - '0';
+    int vals[3], got = 0;
+    while (got < 3) {
+        int ch = fgetc(f);
+        if (ch == EOF) {
+            svo_set_error("%s: truncated PNM header", path);
+            return SVO_ERR_ARG;
+        }
+        if (ch == '#') {
+            while (ch != '\n' && ch != EOF)
+                ch = fgetc(f);
+            continue;
+        }
+        if (ch == ' ' || ch == '\t' || ch == '\n' || ch == '\r')
+            continue;
+        if (ch < '0' || ch > '9') {
+            svo_set_error("%s: malformed PNM header", path);
+            return SVO_ERR_ARG;
+        }
+        long v = 0;
+        while (ch >= '0' && ch <= '9') {
+            v = v * 10 + (ch - '0');
+            if (v > (1 << 24)) {
+                svo_set_error("%s: PNM header value out of range", path);
+                return SVO_ERR_ARG;
+            }
+            ch = fgetc(f);
+        }
+        vals[got++] = (int)v;  // the byte after a number is the separator (consumed)
+    }
+    if (vals[0] <= 0 || vals[1] <= 0 || vals[2] <= 0 || vals[2] > 255) {
+        svo_set_error("%s: unsupported PNM geometry %dx%d maxval %d (8-bit only)", path, vals[0], vals[1], vals[2]);
+        return SVO_ERR_ARG;
+    }
+    *w = vals[0];
+    *h = vals[1];
+    return SVO_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int svo_io_format_path(char *out, int cap, const char *fmt, int iter)
+{
+    SVO_CHECK_ARG(out && cap > 0 && fmt);
+    // exactly one integer conversion may appear in the pattern (the reference passes "%0.6d")
+    int conv = 0;
+    for (const char *q = fmt; *q; q++) {
+        if (*q != '%')
+            continue;
+        if (q[1] == '%') {
+            q++;
+            continue;
+        }
+        const char *e = q + 1;
+        while (*e && strchr("0123456789.-+ #", *e))
+            e++;
+        if (*e != 'd' && *e != 'i' && *e != 'u') {
+            svo_set_error("frame pattern \"%s\": only one %%d-style conversion is allowed", fmt);
+            return SVO_ERR_ARG;
+        }
+        conv++;
+        q = e;
+    }
+    if (conv != 1) {
+        svo_set_error("frame pattern \"%s\" must hold exactly one integer conversion", fmt);
+        return SVO_ERR_ARG;
+    }
+    const int k = snprintf(out, (size_t)cap, fmt, iter);
+    if (k < 0 || k >= cap) {
+        svo_set_error("frame path longer than %d bytes", cap);
+        return SVO_ERR_CAPACITY;
+    }
+    return SVO_OK;
+}
+
+int svo_io_image_info(const char *path, int *w, int *h, int *c)
+{
+    SVO_CHECK_ARG(path && w && h && c);
+    FILE *f = fopen(path, "rb");
+    if (!f) {
+        svo_set_error("failed to fetch frame %s, check the paths", path);
+        return SVO_ERR_ARG;
+    }
+    int magic = 0;
+    const int rc = pnm_header(f, path, &magic, w, h);
+    fclose(f);
+    *c = magic == 6 ? 3 : 1;
+    return rc;
+}
+
+int svo_io_read_image(const char *path, int channels, uint8_t *out, size_t cap_bytes, int *w, int *h)
+{
+    SVO_CHECK_ARG(path && out && w && h && (channels == 1 || channels == 3));
+    FILE *f = fopen(path, "rb");
+    if (!f) {
+        svo_set_error("failed to fetch frame %s, check the paths", path);
+        return SVO_ERR_ARG;
+    }
+    int magic = 0;
+    int rc = pnm_header(f, path, &magic, w, h);
+    if (rc) {
+        fclose(f);
+        return rc;
+    }
+    const size_t px = (size_t)*w * *h, fc = magic == 6 ? 3 : 1;
+    if (cap_bytes < px * (size_t)channels) {
+        fclose(f);
+        svo_set_error("%s: %dx%dx%d does not fit %zu bytes", path, *w, *h, channels, cap_bytes);
+        return SVO_ERR_CAPACITY;
+    }
+    if (fc == 1 && channels == 1) {
+        rc = fread(out, 1, px, f) == px ? SVO_OK : SVO_ERR_ARG;
+    } else {
+        std::vector<uint8_t> row((size_t)*w * fc);
+        for (int y = 0; y < *h && rc == SVO_OK; y++) {
+            if (fread(row.data(), 1, row.size(), f) != row.size()) {
+                rc = SVO_ERR_ARG;
+                break;
+            }
+            uint8_t *o = out + (size_t)y * *w * channels;
+            for (int x = 0; x < *w; x++) {
+                if (fc == 3 && channels == 3) {  // file order R,G,B -> memory order B,G,R (cv::imread)
+                    o[3 * x] = row[3 * x + 2];
+                    o[3 * x + 1] = row[3 * x + 1];
+                    o[3 * x + 2] = row[3 * x];
+                } else if (fc == 1) {  // grey file read as colour: the value in all three channels
+                    o[3 * x] = o[3 * x + 1] = o[3 * x + 2] = row[x];
+                } else {  // colour file read as grey: cv's BGR2GRAY weights in 14-bit fixed point
+                    o[x] = (uint8_t)((row[3 * x] * 4899 + row[3 * x + 1] * 9617 + row[3 * x + 2] * 1868 + 8192) >> 14);
+                }
+            }
+        }
+    }
+    fclose(f);
+    if (rc)
+        svo_set_error("%s: truncated pixel data", path);
+    return rc;
+}
+
+int svo_io_load_frame(const char *pattern, int iter, int channels, uint8_t *out, size_t cap_bytes, int *w, int *h)
+{
+    char path[1024];
+    int rc = svo_io_format_path(path, (int)sizeof(path), pattern, iter);
+    if (rc)
+        return rc;
+    return svo_io_read_image(path, channels, out, cap_bytes, w, h);
+}
+
+int svo_io_write_image(const char *path, const uint8_t *img, int w, int h, int channels)
+{
+    SVO_CHECK_ARG(path && img && w > 0 && h > 0 && (channels == 1 || channels == 3));
+    FILE *f = fopen(path, "wb");
+    if (!f) {
+        svo_set_error("cannot open %s", path);
+        return SVO_ERR_ARG;
+    }
+    fprintf(f, "P%d\n%d %d\n255\n", channels == 3 ? 6 : 5, w, h);
+    bool ok = true;
+    if (channels == 1) {
+        ok = fwrite(img, 1, (size_t)w * h, f) == (size_t)w * h;
+    } else {
+        std::vector<uint8_t> row((size_t)w * 3);
+        for (int y = 0; y < h && ok; y++) {
+            const uint8_t *s = img + (size_t)y * w * 3;
+            for (int x = 0; x < w; x++) {
+                row[3 * x] = s[3 * x + 2];
+                row[3 * x + 1] = s[3 * x + 1];
+                row[3 * x + 2] = s[3 * x];
+            }
+            ok = fwrite(row.data(), 1, row.size(), f) == row.size();
+        }
+    }
+    fclose(f);
+    if (!ok) {
+        svo_set_error("%s: short write", path);
+        return SVO_ERR_ARG;
+    }
+    return SVO_OK;
+}
+
+int svo_io_absolute_scale(const char *poses_path, int frame_id, double *x_prev, double *y_prev, double *z_prev,
+                          double *scale)
+{
+    SVO_CHECK_ARG(poses_path && frame_id >= 0 && scale);
+    FILE *f = fopen(poses_path, "r");
+    if (!f) {
+        svo_set_error("Unable to open file %s", poses_path);
+        return SVO_ERR_ARG;
+    }
+    double x = 0, y = 0, z = 0, xp = 0, yp = 0, zp = 0;
+    char line[1024];
+    int i = 0;
+    while (i <= frame_id && fgets(line, sizeof(line), f)) {
+        double v[12];
+        if (sscanf(line, "%lf %lf %lf %lf %lf %lf %lf %lf %lf %lf %lf %lf", v, v + 1, v + 2, v + 3, v + 4, v + 5, v + 6,
+                   v + 7, v + 8, v + 9, v + 10, v + 11) != 12)
+            break;
+        xp = x;
+        yp = y;
+        zp = z;
+        x = v[3];
+        y = v[7];
+        z = v[11];
+        i++;
+    }
+    fclose(f);
+    if (i <= frame_id) {
+        svo_set_error("%s holds %d poses, frame %d asked for", poses_path, i, frame_id);
+        return SVO_ERR_ARG;
+    }
+    if (x_prev)
+        *x_prev = xp;
+    if (y_prev)
+        *y_prev = yp;
+    if (z_prev)
+        *z_prev = zp;
+    *scale = sqrt((x - xp) * (x - xp) + (y - yp) * (y - yp) + (z - zp) * (z - zp));
+    return SVO_OK;
+}
+
+}  // extern "C"

@@ -13,13 +13,13 @@
 //           linearisations (N = 1, 2, 3) + Gauss-Newton + rigid alignment run on lanes
 //           0..2 side by side, entirely in registers.
 //   score   one WAVEFRONT per hypothesis, N correspondences strided over the lanes.
-//   finish  ONE workgroup, one launch: sequential-semantics replay (ransac_common.cuh) with the
+//   finish  ONE workgroup, one launch: sequential-semantics replay (ransac_common.hip.h) with the
 //           inlier count published to the host mailbox at once, mask + ordered inlier list of
 //           the winner (ballot scan), then Levenberg-Marquardt on (R, t): 6x6 normal equations
 //           reduced with a fixed-order tree (deterministic), solved by one lane.
 #include <cfloat>
 
-#include "ransac_common.cuh"
+#include "ransac_common.hip.h"
 #include "svo_internal.h"
 
 using namespace svo;

@@ -1086,7 +1086,9 @@ int svo_pg_optimize(svo_posegraph *g, int iters, double *chi2)
         hipLaunchKernelGGL(pg_update_kernel, dim3((nv + 127) / 128), dim3(128), 0, st, nv, g->d_pose.as<double>(), dx);
     }
     SVO_HIP(hipGetLastError());
-    SVO_HIP(hipMemcpyAsync(g->pose.data(), g->d_pose.p, (size_t)nv * 56, hipMemcpyDeviceToHost, st));
+    // the optimised poses go into a temporary: a failed solve must not destroy the caller's estimate
+    std::vector<double> hpose((size_t)nv * 7);
+    SVO_HIP(hipMemcpyAsync(hpose.data(), g->d_pose.p, (size_t)nv * 56, hipMemcpyDeviceToHost, st));
     std::vector<double> hchi(iters + 1);
     SVO_HIP(hipMemcpyAsync(hchi.data(), d_chi, (size_t)(iters + 1) * 8, hipMemcpyDeviceToHost, st));
     int hstatus = 0;
@@ -1102,6 +1104,7 @@ int svo_pg_optimize(svo_posegraph *g, int iters, double *chi2)
             svo_set_error("pose graph: normal matrix not positive definite at block row %d", hstatus - 1);
         return SVO_ERR_STATE;
     }
+    g->pose.swap(hpose);
     return SVO_OK;
 }
 

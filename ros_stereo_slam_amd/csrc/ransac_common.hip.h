@@ -1,4 +1,4 @@
-// ransac_common.cuh -- device helpers shared by the F-matrix and PnP RANSAC kernels.
+// ransac_common.hip.h -- device helpers shared by the F-matrix and PnP RANSAC kernels.
 #pragma once
 #include <hip/hip_runtime.h>
 

@@ -13,7 +13,7 @@
 // order does not matter).  The cloud statistics are summed by one thread in point order, as
 // PCL's loop does, so the threshold is bit-identical to the sequential algorithm.
 // Brute force: N^2 distance evaluations out of L2 (N <= 9216: 110 kB), no HBM traffic to speak of.
-#include "ransac_common.cuh"
+#include "ransac_common.hip.h"
 #include "svo_internal.h"
 
 namespace {

@@ -1,0 +1,156 @@
+"""Stereo sequence input: the reference's ``loadImageL`` / ``loadImageR``
+(``src/keyFrameManagement.cpp:48-71``: ``sprintf(pattern, iter)`` + ``cv::imread`` -> BGR8) over the
+KITTI odometry layout its ``main`` hard-codes (``src/VisualSLAM.cpp:220-222``:
+``sequences/<seq>/image_2/%0.6d.png`` and ``image_3``), plus the ground-truth pose file
+(``include/monoUtils.h:130-158``) for the trajectory error.
+
+PGM / PPM frames are decoded by the library (``svo_io_load_frame``); PNG frames -- what KITTI ships --
+by PIL on the caller's side when PIL is importable (image decoding is outside the hot path,
+DESIGN.md section 8).  ``bench.py --kitti DIR --seq 00`` drives :func:`bench_kitti`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+import time
+
+import numpy as np
+
+from . import capi
+
+KITTI_00_02_K = (718.856, 718.856, 607.1928, 185.2157)  # include/visualSLAM.h:82-87
+KITTI_BASELINE = 0.54                                    # include/visualSLAM.h:68
+
+
+def format_path(pattern: str, it: int) -> str:
+    buf = C.create_string_buffer(1024)
+    capi._check(capi.load().svo_io_format_path(buf, 1024, pattern.encode(), int(it)))
+    return buf.value.decode()
+
+
+def read_image(path: str, channels: int = 3) -> np.ndarray:
+    """-> (H, W, channels) uint8, BGR order for 3 channels (cv::imread)."""
+    lib = capi.load()
+    if path.lower().endswith((".pgm", ".ppm", ".pnm")):
+        w, h, c = C.c_int(), C.c_int(), C.c_int()
+        capi._check(lib.svo_io_image_info(path.encode(), C.byref(w), C.byref(h), C.byref(c)))
+        out = np.empty((h.value, w.value, channels), np.uint8)
+        capi._check(lib.svo_io_read_image(path.encode(), channels, capi._ptr(out), C.c_size_t(out.nbytes),
+                                          C.byref(w), C.byref(h)))
+        return out
+    if not os.path.exists(path):
+        raise capi.SvoError(capi.SVO_ERR_ARG, f"failed to fetch frame {path}, check the paths")
+    try:
+        from PIL import Image
+    except ImportError as e:  # pragma: no cover
+        raise RuntimeError(f"{path}: only PGM / PPM are decoded by the library; PNG needs PIL") from e
+    im = Image.open(path)
+    if channels == 1:
+        return np.ascontiguousarray(np.asarray(im.convert("L"))[..., None])
+    return np.ascontiguousarray(np.asarray(im.convert("RGB"))[..., ::-1])
+
+
+def write_image(path: str, img: np.ndarray) -> None:
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape[:2]
+    c = 1 if img.ndim == 2 else img.shape[2]
+    capi._check(capi.load().svo_io_write_image(path.encode(), capi._ptr(img), w, h, c))
+
+
+def absolute_scale(poses_path: str, frame_id: int):
+    """getAbsoluteScale: -> (x, y, z of frame_id - 1, distance to frame_id)."""
+    x, y, z, s = C.c_double(), C.c_double(), C.c_double(), C.c_double()
+    capi._check(capi.load().svo_io_absolute_scale(poses_path.encode(), int(frame_id), C.byref(x), C.byref(y),
+                                                  C.byref(z), C.byref(s)))
+    return x.value, y.value, z.value, s.value
+
+
+class StereoSequence:
+    """``lFptr`` / ``rFptr`` of the reference: two printf patterns, frames by index."""
+
+    def __init__(self, left_pattern: str, right_pattern: str, channels: int = 3):
+        self.lp, self.rp, self.channels = left_pattern, right_pattern, channels
+
+    @classmethod
+    def kitti(cls, seq_dir: str, channels: int = 3) -> "StereoSequence":
+        for ext in ("png", "ppm", "pgm"):
+            if os.path.exists(os.path.join(seq_dir, "image_2", f"000000.{ext}")):
+                break
+        else:
+            raise capi.SvoError(capi.SVO_ERR_ARG, f"failed to fetch frame 0 under {seq_dir}/image_2, check the paths")
+        return cls(os.path.join(seq_dir, "image_2", f"%0.6d.{ext}"), os.path.join(seq_dir, "image_3", f"%0.6d.{ext}"),
+                   channels)
+
+    def exists(self, i: int) -> bool:
+        return os.path.exists(format_path(self.lp, i)) and os.path.exists(format_path(self.rp, i))
+
+    def __len__(self) -> int:
+        lo, hi = 0, 1
+        while self.exists(hi):
+            lo, hi = hi, hi * 2
+        while lo + 1 < hi:  # frames are numbered without gaps
+            mid = (lo + hi) // 2
+            lo, hi = (mid, hi) if self.exists(mid) else (lo, mid)
+        return lo + 1 if self.exists(0) else 0
+
+    def load(self, i: int):
+        return read_image(format_path(self.lp, i), self.channels), read_image(format_path(self.rp, i), self.channels)
+
+
+def read_calib(path: str):
+    """KITTI ``calib.txt`` -> ((fx, fy, cx, cy), baseline) from P0 / P1, or None when absent."""
+    try:
+        rows = {}
+        with open(path) as f:
+            for line in f:
+                k, _, rest = line.partition(":")
+                rows[k.strip()] = [float(x) for x in rest.split()]
+        p0, p1 = rows["P0"], rows["P1"]
+        return (p0[0], p0[5], p0[2], p0[6]), -p1[3] / p1[0]
+    except (OSError, KeyError, ValueError, IndexError):
+        return None
+
+
+def bench_kitti(args, seq_dir: str) -> int:
+    """BASELINE configs[1]: the front-end over a KITTI odometry sequence on one GPU, frames resident
+    in HBM, one contiguous chunk, pipelined; ATE against ``poses/<seq>.txt`` when it exists.  Prints
+    one JSON record."""
+    import torch
+
+    seq = StereoSequence.kitti(seq_dir)
+    n = min(len(seq), 4500)  # the reference's frame cap, src/VisualSLAM.cpp:54
+    l0, r0 = seq.load(0)
+    h, w, c = l0.shape
+    cal = read_calib(os.path.join(seq_dir, "calib.txt"))
+    K4, base = cal if cal else (KITTI_00_02_K, KITTI_BASELINE)
+    lefts, rights = [], []
+    for i in range(n):
+        l, r = (l0, r0) if i == 0 else seq.load(i)
+        lefts.append(torch.from_numpy(l).cuda())
+        rights.append(torch.from_numpy(r).cuda())
+    torch.cuda.synchronize()
+    n_kpts, grid_step, kf_min = (4096, 10, 2000) if args.kpts == 4096 else (8192, 7, 4000)
+    ctx = capi.Context(0)
+    vo = capi.VisualOdometry(ctx, w, h, c, grid_step=grid_step, anms_keep=n_kpts, keyframe_min_inliers=kf_min,
+                             seed=20261003, K4=K4, baseline=base)
+    t0 = time.perf_counter()
+    vo.init(lefts[0], rights[0])
+    rc, done, R, t, inl, trk, kf = vo.run_chunk(lefts[1:], rights[1:], pipeline=True)
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    rec = {"metric": f"stereo frames/sec @{w}x{h}, {n_kpts} kpts", "value": (done + 1) / dt, "unit": "frames/s",
+           "n_gpus": 1, "data": f"KITTI odometry {os.path.basename(seq_dir)}", "frames": done + 1,
+           "tracking_lost": bool(rc), "keyframe_rate": float(kf[:done].mean()) if done else None,
+           "config": {"workload": f"KITTI sequence {os.path.basename(seq_dir)}, front-end only (BASELINE configs[1])",
+                      "K4": K4, "baseline": base}}
+    gt_path = os.path.join(os.path.dirname(os.path.dirname(seq_dir)), "poses", os.path.basename(seq_dir) + ".txt")
+    if os.path.exists(gt_path):
+        Rg, tg = capi.read_kitti_poses(gt_path)
+        m = min(done + 1, len(tg))
+        est = np.vstack([np.zeros((1, 3)), t[:done]])[:m]
+        rec["ate_rmse_vs_ground_truth"] = capi.ate_rmse(est, (Rg[0].T @ (tg[:m] - tg[0]).T).T)
+    print(json.dumps(rec))
+    vo.close()
+    ctx.close()
+    return 0

@@ -135,6 +135,118 @@ class Scene:
         return left, right, depth
 
 
+# ---- the same ray-caster on torch tensors (GPU): bench.py and the full-size tests render thousands of
+# frames, which the numpy version (about 1 s per stereo pair) cannot supply in time.  Same arithmetic in
+# float64 / wrapped 32-bit integer hashing; images agree with the numpy renderer up to last-ulp effects
+# of the ray-direction product (tests/test_synth_torch.py).
+def _t_hash2(ix, iy, seed: int):
+    import torch
+
+    M = 0xFFFFFFFF
+    h = ((ix & M) * 0x9E3779B1 & M) ^ ((iy & M) * 0x85EBCA77 & M)
+    h = h ^ (seed & M)
+    h = h ^ (h >> 15)
+    h = (h * 0x2C1B3C6D) & M
+    h = h ^ (h >> 12)
+    h = (h * 0x297A2D39) & M
+    h = h ^ (h >> 15)
+    return (h >> 8).to(torch.float64) * (1.0 / (1 << 24))
+
+
+def _t_value_noise(u, v, seed: int):
+    import torch
+
+    fu, fv = torch.floor(u), torch.floor(v)
+    iu, iv = fu.to(torch.int64), fv.to(torch.int64)
+    a, b = u - fu, v - fv
+    a = a * a * (3.0 - 2.0 * a)
+    b = b * b * (3.0 - 2.0 * b)
+    n00 = _t_hash2(iu, iv, seed)
+    n10 = _t_hash2(iu + 1, iv, seed)
+    n01 = _t_hash2(iu, iv + 1, seed)
+    n11 = _t_hash2(iu + 1, iv + 1, seed)
+    return (n00 * (1 - a) + n10 * a) * (1 - b) + (n01 * (1 - a) + n11 * a) * b
+
+
+def render_torch(scene: "Scene", R, t, K=KITTI_K, size=KITTI_SIZE, channels=3, device="cuda"):
+    """Scene.render for a batch of poses on a torch device.  R: (B, 3, 3), t: (B, 3) array-likes.
+    Returns a (B, H, W, C) uint8 tensor on ``device``."""
+    import torch
+
+    fx, fy, cx, cy = K
+    w, h = size
+    R = torch.as_tensor(np.asarray(R, np.float64).reshape(-1, 3, 3), device=device)
+    t = torch.as_tensor(np.asarray(t, np.float64).reshape(-1, 3), device=device)
+    B = R.shape[0]
+    vv, uu = torch.meshgrid(torch.arange(h, dtype=torch.float64, device=device),
+                            torch.arange(w, dtype=torch.float64, device=device), indexing="ij")
+    dc = [((uu - cx) / fx)[None], ((vv - cy) / fy)[None], torch.ones_like(uu)[None]]
+    dw = [dc[0] * R[:, j, 0, None, None] + dc[1] * R[:, j, 1, None, None] + dc[2] * R[:, j, 2, None, None]
+          for j in range(3)]
+    tx, ty, tz = (t[:, k, None, None] for k in range(3))
+    inf = float("inf")
+    best_t = torch.full((B, h, w), inf, dtype=torch.float64, device=device)
+    tex_u = torch.zeros((B, h, w), dtype=torch.float64, device=device)
+    tex_v = torch.zeros_like(tex_u)
+    surf = torch.zeros((B, h, w), dtype=torch.int64, device=device)
+
+    def hit(tt, valid, u, v, sid):
+        nonlocal best_t, tex_u, tex_v, surf
+        m = valid & (tt > 1e-6) & (tt < best_t)
+        best_t = torch.where(m, tt, best_t)
+        tex_u = torch.where(m, u, tex_u)
+        tex_v = torch.where(m, v, tex_v)
+        surf = torch.where(m, torch.full_like(surf, sid), surf)
+
+    tt = (scene.ground_y - ty) / dw[1]
+    hit(tt, dw[1] > 1e-9, tx + tt * dw[0], tz + tt * dw[2], 1)
+    for sid, xw in ((2, -scene.wall_x), (3, scene.wall_x)):
+        tt = (xw - tx) / dw[0]
+        yw = ty + tt * dw[1]
+        hit(tt, (dw[0].abs() > 1e-9) & (yw < scene.ground_y) & (yw > scene.ground_y - 8.0), yw, tz + tt * dw[2], sid)
+    for sid, zw in ((4, scene.z_min), (5, scene.z_max)):
+        if zw is None:
+            continue
+        tt = (zw - tz) / dw[2]
+        yw = ty + tt * dw[1]
+        hit(tt, (dw[2].abs() > 1e-9) & (yw < scene.ground_y) & (yw > scene.ground_y - 8.0), tx + tt * dw[0], yw, sid)
+    found = torch.isfinite(best_t)
+    depth = torch.where(found, best_t, torch.zeros_like(best_t))
+    footprint = depth / fx * 1.5
+    grey = torch.zeros_like(depth)
+    for sid in (1, 2, 3, 4, 5):
+        m = surf == sid
+        acc = torch.zeros_like(depth)
+        wsum = 0.0
+        amp = 1.0
+        for k, wl in enumerate(scene.wavelengths):
+            fade = torch.clamp(1.5 - 2.0 * footprint / wl, 0.0, 1.0)
+            n = _t_value_noise(tex_u / wl, tex_v / wl, scene.seed + 7919 * sid + 104729 * k)
+            acc = acc + amp * fade * (n - 0.5)
+            wsum += amp
+            amp *= 0.7
+        alb = torch.clamp(128.0 + 230.0 * acc / wsum * 1.6, 0, 255)
+        grey = torch.where(m, alb, grey)
+    grey = torch.where(found, grey, torch.full_like(grey, float(scene.sky)))
+    img = torch.round(grey).to(torch.uint8)  # round half to even, as np.rint
+    return img[..., None].expand(B, h, w, channels).contiguous()
+
+
+def stereo_torch(scene: "Scene", poses, K=KITTI_K, size=KITTI_SIZE, channels=3, baseline=KITTI_BASELINE,
+                 device="cuda", batch: int = 8):
+    """[(R, t)] -> (lefts, rights): two lists of (H, W, C) uint8 tensors on ``device``."""
+    lefts, rights = [], []
+    for s in range(0, len(poses), batch):
+        Rs = np.stack([np.asarray(R, np.float64).reshape(3, 3) for R, _ in poses[s:s + batch]])
+        ts = np.stack([np.asarray(t, np.float64).reshape(3) for _, t in poses[s:s + batch]])
+        tr = ts + Rs @ np.array([baseline, 0.0, 0.0])
+        both = render_torch(scene, np.concatenate([Rs, Rs]), np.concatenate([ts, tr]), K, size, channels, device)
+        n = len(Rs)
+        lefts.extend(both[i] for i in range(n))
+        rights.extend(both[n + i] for i in range(n))
+    return lefts, rights
+
+
 def rot_y(a: float) -> np.ndarray:
     c, s = np.cos(a), np.sin(a)
     return np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]], np.float64)
@@ -153,10 +265,12 @@ def corridor_trajectory(n: int, step: float = 0.9, yaw_amp: float = 0.02, sway: 
 
 
 def loop_trajectory(n: int, half_x: float = 14.0, half_z: float = 30.0, radius: float = 8.0,
-                    step: float = 0.9):
+                    step: float = 0.9, closed: bool = False):
     """Rounded-rectangle loop (camera looks along its direction of travel).  Returns [(R, t)].
 
-    Use with ``Scene(wall_x=half_x+8, z_min=-half_z-8, z_max=half_z+8)``.
+    Use with ``Scene(wall_x=half_x+8, z_min=-half_z-8, z_max=half_z+8)``.  ``closed``: the step is
+    adjusted so that a lap is a whole number of frames, i.e. every later lap revisits exactly the
+    poses of the first (a loop-closure edge with identity measurement is then exact).
     """
     # build the closed path as straight segments + quarter circles, parametrised by arc length
     sx, sz = half_x - radius, half_z - radius
@@ -170,9 +284,12 @@ def loop_trajectory(n: int, half_x: float = 14.0, half_z: float = 30.0, radius: 
     segs.append(("line", 2 * sx, (np.array([-sx, -half_z]), np.array([1.0, 0.0]))))
     segs.append(("arc", 0.5 * np.pi * radius, (np.array([sx, -sz]), 1.5 * np.pi)))
     total = sum(s[1] for s in segs)
+    lap = max(1, int(round(total / step)))
+    if closed:
+        step = total / lap
     poses = []
     for i in range(n):
-        s = (step * i) % total
+        s = (step * (i % lap) if closed else step * i) % total
         for kind, length, data in segs:
             if s <= length:
                 if kind == "line":
@@ -212,18 +329,39 @@ def textured_pair(w: int, h: int, c: int, shift=(0.0, 0.0), seed: int = 1, wavel
     return a, b
 
 
-def loop_closures(poses, max_dist: float = 2.0, max_angle_deg: float = 10.0, min_gap: int = 100):
+def loop_closures(poses, max_dist: float = 2.0, max_angle_deg: float = 10.0, min_gap: int = 100,
+                  pick: str = "earliest"):
     """Stand-in for the reference's DBoW2 loop detector (vocabularies are not in the checkout):
-    for every frame the earliest frame at least ``min_gap`` frames back whose pose lies within
-    ``max_dist`` metres and ``max_angle_deg`` degrees, else -1."""
-    out = []
+    for every frame the earliest (``pick="earliest"``) or the closest (``"nearest"``) frame more than
+    ``min_gap`` frames back whose pose lies within ``max_dist`` metres and ``max_angle_deg`` degrees,
+    else -1."""
+    n = len(poses)
+    T = np.array([t for _, t in poses], np.float64).reshape(n, 3)
+    Rm = np.array([R for R, _ in poses], np.float64).reshape(n, 9)
     cosmax = np.cos(np.radians(max_angle_deg))
-    for i, (Ri, ti) in enumerate(poses):
-        match = -1
-        for j in range(0, i - min_gap):
-            Rj, tj = poses[j]
-            if np.linalg.norm(ti - tj) <= max_dist and (np.trace(Ri.T @ Rj) - 1) / 2 >= cosmax:
-                match = j
-                break
-        out.append(match)
+    out = []
+    for i in range(n):
+        m = i - min_gap
+        if m <= 0:
+            out.append(-1)
+            continue
+        d = np.linalg.norm(T[:m] - T[i], axis=1)
+        cosang = (Rm[:m] @ Rm[i] - 1) / 2  # trace(Ri^T Rj) = <Ri, Rj>
+        ok = np.nonzero((d <= max_dist) & (cosang >= cosmax))[0]
+        if ok.size == 0:
+            out.append(-1)
+        elif pick == "nearest":
+            out.append(int(ok[np.argmin(d[ok])]))
+        else:
+            out.append(int(ok[0]))
     return out
+
+
+# the benchmark's stream (SURVEY.md 8d): 0.9 m per frame, yaw <= 0.02 rad per frame (radius 45 m),
+# closing a rounded-rectangle loop of 492 frames; use with BENCH_SCENE
+BENCH_LOOP = dict(half_x=50.0, half_z=80.0, radius=45.0, step=0.9, closed=True)
+
+
+def bench_scene(seed: int = DEFAULT_SEED) -> Scene:
+    return Scene(seed=seed, wall_x=BENCH_LOOP["half_x"] + 8, z_min=-BENCH_LOOP["half_z"] - 8,
+                 z_max=BENCH_LOOP["half_z"] + 8)

@@ -142,3 +142,94 @@ def test_several_chunks_per_rank_over_gloo():
         assert p.exitcode == 0
     for rank, nb, err in res:
         assert nb == world * m and err < 1e-10
+
+
+# ---- BASELINE configs[3] as one flow on CPU: shard -> all-gather -> rebase -> closures on global
+# frame ids -> ONE global solve (fake VO = ground truth + drift; the oracle's pose graph solves) ----
+def _drifting_loop(n, lap):
+    """Ground truth: a circle of `lap` frames walked repeatedly; the fake VO's relative motions carry
+    a constant yaw and forward bias, so its trajectory drifts away from the loop."""
+    gt = []
+    for i in range(n):
+        a = 2 * np.pi * (i % lap) / lap
+        gt.append((Rot.from_euler("y", a).as_matrix(), np.array([20 * (1 - np.cos(a)), 0.0, 20 * np.sin(a)])))
+    bias_R = Rot.from_euler("y", 4e-4).as_matrix()
+    rel = []
+    for (Ra, ta), (Rb, tb) in zip(gt, gt[1:]):
+        dR, dt = Ra.T @ Rb, Ra.T @ (tb - ta)
+        rel.append((dR @ bias_R, dt * 1.004))
+    return gt, rel
+
+
+def _local_from_rel(rel, s, e):
+    loc = [(np.eye(3), np.zeros(3))]
+    for dR, dt in rel[s:e]:
+        loc.append(chunked.compose(*loc[-1], dR, dt))
+    return loc
+
+
+def _configs3_flow(dist, rank, world, m, n, lap):
+    from oracle import orc
+
+    gt, rel = _drifting_loop(n, lap)
+    share = (n - 1) // world
+    s0 = rank * share
+    bounds = chunked.chunk_bounds(share + 1, m)
+    local = [_local_from_rel(rel, s0 + s, s0 + e) for s, e in bounds]
+    traj = chunked.stitch_chunks(dist, local, device="cpu")
+    matches = [i - lap if i >= lap else -1 for i in range(n)]
+    closures = chunked.gate_closures(matches)
+    pg = orc.PoseGraph()
+    est, chi2 = chunked.global_solve(pg, traj, closures, iters=10)
+    gt_t = np.array([t for _, t in gt])
+    before = chunked.ate_rmse([t for _, t in traj], gt_t)
+    after = chunked.ate_rmse(est[:, :3], gt_t)
+    return len(traj), len(closures), before, after, float(chi2[0]), float(chi2[-1]), est
+
+
+def _worker_configs3(rank, world, port, q):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        r = _configs3_flow(dist, rank, world, 3, 361, 120)
+        q.put((rank,) + r[:6] + (float(np.abs(r[6]).sum()),))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gate_closures_follows_the_reference_rule():
+    m = [-1] * 300
+    for q in (50, 150, 151, 200, 260):
+        m[q] = q - 120 if q >= 120 else 0
+    m[50] = 0           # only 50 frames back: refused (query - match must exceed 100)
+    got = chunked.gate_closures(m)
+    assert got == {150: 30, 260: 140}  # 151 and 200 fall into the 100-frame cooldown after 150
+
+
+def test_configs3_flow_single_process_matches_two_ranks_over_gloo():
+    import torch.multiprocessing as mp
+
+    one = _configs3_flow(None, 0, 1, 6, 361, 120)
+    assert one[0] == 361 and one[1] >= 2
+    assert one[3] < 0.7 * one[2], f"global solve must pull the drift in: ATE {one[2]:.3f} -> {one[3]:.3f}"
+    assert one[5] < 1e-3 * one[4]
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_configs3, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ntraj, ncl, before, after, c0, c1, checksum in res:
+        assert ntraj == 361 and ncl == one[1]
+        # the same chunks in the same order, whoever ran them: identical trajectory and solve
+        assert before == pytest.approx(one[2], rel=1e-12) and after == pytest.approx(one[3], rel=1e-9)
+        assert checksum == pytest.approx(float(np.abs(one[6]).sum()), rel=1e-9)

@@ -1,0 +1,114 @@
+"""The benchmarked configuration, proven: one synthetic loop stream at full size (1241x376x3, grid
+step 10 -> ANMS 4096) run (a) sequentially as one chunk and (b) cut into 64 chunks that run side by
+side on one GPU (svo_vo_run_chunks, 4 lock-step groups of 16, every chunk initialising itself inside
+the call), stitched with the arithmetic the RCCL all-gather feeds (chunked.py).  SURVEY.md 8d's bound
+for the chunk-sharded mode: ATE against the sequential run <= 0.5 % of the path length.  Then
+BASELINE configs[3]'s tail: closures on global frame ids, ONE global solve, ATE must not get worse."""
+import numpy as np
+import pytest
+
+from ros_stereo_slam_amd import capi, chunked, synth
+
+pytestmark = pytest.mark.gpu
+
+W, H, C = 1241, 376, 3
+KW = dict(grid_step=10, anms_keep=4096, keyframe_min_inliers=2000)
+
+
+@pytest.fixture(scope="module")
+def stream():
+    import torch
+
+    n = 641                      # 640 transitions: 64 chunks of 10 frames, 1.3 laps of the loop
+    poses = synth.loop_trajectory(n, **synth.BENCH_LOOP)
+    lefts, rights = synth.stereo_torch(synth.bench_scene(), poses, device="cuda", batch=8)
+    torch.cuda.synchronize()
+    R0, t0 = poses[0]
+    truth = np.array([R0.T @ (t - t0) for _, t in poses])
+    return poses, lefts, rights, truth
+
+
+def test_64_chunks_against_the_sequential_run_at_full_size(ctx, stream):
+    poses, lefts, rights, truth = stream
+    n = len(lefts)
+    seq = capi.VisualOdometry(ctx, W, H, C, seed=20261003, **KW)
+    seq.init(lefts[0], rights[0])
+    rc, done, R, t, inl, trk, kf = seq.run_chunk(lefts[1:], rights[1:], pipeline=True)
+    assert rc == 0 and done == n - 1
+    t_seq = np.vstack([np.zeros((1, 3)), t])
+    seq.close()
+
+    sh = chunked.ShardedVO(capi, 0, W, H, C, 64, 16, seed=20261003, **KW)
+    local, stats = sh.run(lefts, rights)
+    assert len(local) == 64 and all(len(loc) == 11 for loc in local)
+    traj = chunked.stitch_chunks(None, local)
+    assert len(traj) == n
+    t_sh = np.array([tt for _, tt in traj])
+    # a second run of the same call gives the same poses bit for bit (no launch-order dependence)
+    local_b, _ = sh.run(lefts, rights)
+    assert all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+               for la, lb in zip(local, local_b) for a, b in zip(la, lb))
+    sh.close()
+
+    path = float(np.sum(np.linalg.norm(np.diff(truth, axis=0), axis=1)))
+    ate_seq, ate_sh = chunked.ate_rmse(t_seq, truth), chunked.ate_rmse(t_sh, truth)
+    ate_rel = chunked.ate_rmse(t_sh, t_seq)
+    print(f"\npath {path:.1f} m, keyframe rate sequential {kf.mean():.2f}; ATE vs generator truth: sequential "
+          f"{ate_seq:.3f} m, 64 chunks {ate_sh:.3f} m; 64 chunks vs sequential {ate_rel:.3f} m "
+          f"= {100 * ate_rel / path:.3f} % of the path")
+    assert ate_rel <= 0.005 * path
+    assert ate_seq <= 0.005 * path and ate_sh <= 0.005 * path
+
+    # ---- configs[3]: closures on GLOBAL frame ids, one global solve on the stitched trajectory ----
+    matches = synth.loop_closures(poses, max_dist=0.3, min_gap=100, pick="nearest")
+    closures = chunked.gate_closures(matches)
+    assert len(closures) >= 1 and min(closures) >= 492
+    pg = capi.PoseGraph(ctx)
+    est, chi2 = chunked.global_solve(pg, traj, closures, iters=10)
+    pg.close()
+    ate_after = chunked.ate_rmse(est[:, :3], truth)
+    print(f"global solve: {len(closures)} closure(s), chi2 {chi2[0]:.4g} -> {chi2[-1]:.4g}, "
+          f"ATE {ate_sh:.3f} -> {ate_after:.3f} m")
+    assert chi2[-1] <= chi2[0] and np.abs(est[0] - [0, 0, 0, 0, 0, 0, 1]).max() == 0
+    assert ate_after <= ate_sh * 1.02
+
+
+def test_init_inside_run_chunks_equals_init_then_run(ctx, stream):
+    """svo_chunk_job.init_left / init_right: the chunk's stereo initialisation inside the call (one
+    set of launches for the whole group) gives what svo_vo_init + svo_vo_run_chunks gives."""
+    poses, lefts, rights, truth = stream
+    shared_a, shared_b = capi.Context(0), capi.Context(0)
+    kw = dict(grid_step=30, keyframe_min_inliers=200)
+    spans = [(0, 5), (5, 9), (9, 15)]
+    a = [capi.VisualOdometry(shared_a, W, H, C, seed=3 + k, **kw) for k in range(3)]
+    b = [capi.VisualOdometry(shared_b, W, H, C, seed=3 + k, **kw) for k in range(3)]
+    for v, (s, e) in zip(a, spans):
+        v.init(lefts[s], rights[s])
+    ra = capi.run_chunks([(v, lefts[s + 1:e + 1], rights[s + 1:e + 1]) for v, (s, e) in zip(a, spans)])
+    rb = capi.run_chunks([(v, lefts[s:e + 1], rights[s:e + 1]) for v, (s, e) in zip(b, spans)], init=True)
+    for x, y in zip(ra, rb):
+        assert x[0] == y[0] == 0 and x[1] == y[1]
+        for p, q in zip(x[2:], y[2:]):
+            assert np.array_equal(p, q)
+    # a single job (its own context) takes the same route through svo_vo_init
+    solo_ctx = capi.Context(0)
+    solo = capi.VisualOdometry(solo_ctx, W, H, C, seed=3, **kw)
+    rs = capi.run_chunks([(solo, lefts[0:6], rights[0:6])], init=True)[0]
+    assert rs[1] == 5 and np.array_equal(rs[3], ra[0][3])
+    for c in (shared_a, shared_b, solo_ctx):
+        c.close()
+
+
+def test_heterogeneous_group_is_refused(ctx, stream):
+    """Front-ends that share a context are sized as one launch: different grid steps must be refused
+    (a coarser lattice would be indexed out of bounds), not run."""
+    poses, lefts, rights, truth = stream
+    shared = capi.Context(0)
+    a = capi.VisualOdometry(shared, W, H, C, grid_step=30)
+    b = capi.VisualOdometry(shared, W, H, C, grid_step=20)
+    c = capi.VisualOdometry(shared, W, H, C, grid_step=30, K4=(700.0, 700.0, 600.0, 180.0))
+    for pair in ((a, b), (a, c)):
+        with pytest.raises(capi.SvoError) as e:
+            capi.run_chunks([(v, lefts[0:3], rights[0:3]) for v in pair], init=True)
+        assert e.value.code == capi.SVO_ERR_ARG
+    shared.close()
