@@ -177,13 +177,15 @@ def main():
     bounds = chunked.chunk_bounds(share + 1, M)
     assert all(e - s == L for s, e in bounds)
 
-    def jobs_for(a: int, b: int):
-        """frames a+1 .. b of every chunk (chunk-local numbering; frame 0 is the chunk's seed)"""
-        return [(v, lefts[s + a:s + b + 1], rights[s + a:s + b + 1]) for v, (s, e) in zip(sh.vos, bounds)]
+    def jobs_for(a: int, b: int, init: bool):
+        """frames a+1 .. b of every chunk (chunk-local numbering), preceded by the seed frame a when
+        the chunks initialise in this call"""
+        lo = a if init else a + 1
+        return [(v, lefts[s + lo:s + b + 1], rights[s + lo:s + b + 1]) for v, (s, e) in zip(sh.vos, bounds)]
 
     def run(a: int, b: int, init: bool, out, stats=None):
         """advance every chunk from its local frame a to b (init: seed on frame a first)"""
-        res = capi.run_chunks(jobs_for(a, b), pipeline=pipeline, init=init)
+        res = capi.run_chunks(jobs_for(a, b, init), pipeline=pipeline, init=init)
         for m, (rc, done, Rs, ts, inl, trk, kf) in enumerate(res):
             if rc or done != b - a:
                 raise SystemExit(f"bench: chunk {rank * M + m} lost tracking at local frame {a + done + 1} (rc {rc})")
@@ -389,7 +391,7 @@ def main():
     # ---- configs[3]'s global solve on the stitched trajectory (rank 0; also configs[2]'s figure) ----
     if rank == 0 and not args.no_extras:
         matches = synth.loop_closures(poses_all, max_dist=0.3, max_angle_deg=10.0, min_gap=100, pick="nearest")
-        closures = chunked.gate_closures(matches)
+        closures = chunked.gate_closures([m if m >= 1 else -1 for m in matches])  # LCidx = match - 1 must exist
         ctxg = capi.Context(local_rank)
         pg = capi.PoseGraph(ctxg)
         ctxg.enable_kernel_timing(True)

@@ -220,6 +220,21 @@ int svo_pnp_ransac(svo_ctx *ctx, const float *obj, const float *img, int n, cons
                    int iterations, double reproj_err, double confidence, uint64_t seed, double *rvec,
                    double *tvec, int *inliers, int *n_inliers, int *iters_run, int mem);
 
+/* ---- motion BA: visualOdometry::BundleAdjust3d2d(points_2d, points_3d, K, R, t) ---------------- */
+/* src/bundleAdjust.cpp:551-613 (unbuilt upstream, kept for completeness of the path the north-star
+ * names): g2o Levenberg (BlockSolver<6,3>, dense pose solver) over ONE VertexSE3Expmap (R9 / t3:
+ * world -> camera, as solvePnP returns them) and n FREE VertexSBAPointXYZ that are marginalised
+ * (Schur-eliminated onto the 6x6 pose block, not fixed), one EdgeProjectXYZ2UV with identity
+ * information per point, optimize(iterations = 10 upstream).  K4 = {fx, fy, cx, cy} HOST doubles;
+ * upstream builds CameraParameters from K(0,0), K(0,2), K(1,2) only, so fy is NOT read (:588-590).
+ * t3 (HOST, in/out) receives the optimised translation -- the only value upstream writes back
+ * (:609-611).  Optional HOST outputs: R9_out, pts3d_out (n*3 doubles, the optimised points),
+ * info[5] = {chi2 before, chi2 after, final lambda, iterations run, trials}.  pts2d (n*2 floats) /
+ * pts3d (n*3 floats) follow `mem`.  The whole LM loop runs in one launch; the call synchronises.   */
+int svo_ba_3d2d(svo_ctx *ctx, const float *pts2d, const float *pts3d, int n, const double *K4,
+                const double *R9, double *t3, int iterations, double *R9_out, double *pts3d_out,
+                double *info, int mem);
+
 /* ---- the front-end frame loop: visualSLAM::initSequence, src/VisualSLAM.cpp:11-169 ----------- */
 typedef struct svo_vo_params {
     double fx, fy, cx, cy;    /* include/visualSLAM.h:82-87 (KITTI 00-02)                      */
@@ -293,6 +308,33 @@ int svo_vo_run_chunks(svo_chunk_job *jobs, int n_jobs);
 /* the current reference point set (2-D in the reference image, 3-D world) */
 int svo_vo_get_reference(svo_vo *vo, float *ref2d, float *ref3d, int cap, int *n, int mem);
 int svo_vo_capacity(const svo_vo *vo);
+
+/* ---- the keyframe map and its re-projection: visualSLAM::updateOdometry ------------------------ */
+/* src/optimizationStuff.cpp:17-47 over keyFrameHistory (src/VisualSLAM.cpp:152-166,
+ * include/visualSLAM.h:47-54).  The camera-frame clouds of the stored records stay in HBM;
+ * svo_map_update re-transforms ALL of them in one launch with [R_old | t_new]: the record's own,
+ * un-optimised rotation and the optimised translation of trajectory entry `traj_index` (:29-41).    */
+typedef struct svo_map svo_map;
+int svo_map_create(svo_ctx *ctx, svo_map **out);
+int svo_map_destroy(svo_map *map);
+/* keyFrameHistory.emplace_back(kf): kf.R = R9, kf.t = t3 (camera in the world), kf.ref3dCoords =
+ * xyz_cam (n*3 floats, camera frame: the `untransformed` cloud; follows `mem`), kf.retrack; traj_index =
+ * the record's index into the trajectory updateOdometry receives (upstream: the frame number).  The
+ * record's world cloud is placed at once as insertKeyFrames does (src/keyFrameManagement.cpp:20-30).  */
+int svo_map_add_keyframe(svo_map *map, int traj_index, const double *R9, const double *t3, const float *xyz_cam,
+                         int n, int retrack, int mem);
+int svo_map_num_keyframes(const svo_map *map);
+/* updateOdometry(T): t3s = the translations of T (n_poses*3 HOST doubles, e.g. columns 0-2 of
+ * svo_pg_get_estimates).  Asynchronous on the context's stream.                                      */
+int svo_map_update(svo_map *map, const double *t3s, int n_poses);
+/* mapHistory: the world clouds of the records with retrack, in order, back to back (xyz_world:
+ * cap_points*3 floats, follows `mem`) and their sizes (counts, HOST).  Both may be NULL to query the
+ * totals (*n_points, *n_keyframes: HOST).                                                           */
+int svo_map_get_points(svo_map *map, float *xyz_world, size_t cap_points, int *counts, int cap_keyframes,
+                       size_t *n_points, int *n_keyframes, int mem);
+/* the camera-frame cloud of the front-end's LAST keyframe (`untransformed`, src/keyFrameManagement.cpp:18),
+ * valid until the next keyframe; xyz_cam: cap*3 floats following `mem`.                              */
+int svo_vo_get_keyframe_cloud(svo_vo *vo, float *xyz_cam, int cap, int *n, int mem);
 
 /* ---- SE3 pose graph: globalPoseGraph, include/poseGraph.h:36-179 ------------------------------ */
 /* Poses are 7 doubles: tx ty tz qx qy qz qw (the VERTEX_SE3:QUAT order of g2o).  All pose and

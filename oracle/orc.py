@@ -347,6 +347,23 @@ def lc_nearest2(A, B):
 
 
 # ---- front-end frame loop -----------------------------------------------------------------
+
+def ba_3d2d(pts2d, pts3d, K4, R, t, iterations=10):
+    """BundleAdjust3d2d (src/bundleAdjust.cpp:551-613) -> (t, R, points, info)."""
+    p2 = np.ascontiguousarray(pts2d, np.float32).reshape(-1, 2)
+    p3 = np.ascontiguousarray(pts3d, np.float32).reshape(-1, 3)
+    n = p2.shape[0]
+    Rin = np.ascontiguousarray(R, np.float64).reshape(3, 3)
+    tio = np.array(t, np.float64).reshape(3).copy()
+    Rout, Xout, info = np.zeros((3, 3)), np.zeros((n, 3)), np.zeros(5)
+    rc = load().orc_ba_3d2d(_p(p2), _p(p3), n, _p(np.ascontiguousarray(K4, np.float64)), _p(Rin), _p(tio),
+                            int(iterations), _p(Rout), _p(Xout), _p(info))
+    if rc != 0:
+        raise ValueError("orc_ba_3d2d: bad arguments")
+    return tio, Rout, Xout, dict(chi2_before=info[0], chi2_after=info[1], lambda_final=info[2],
+                                 iterations=int(info[3]), trials=int(info[4]))
+
+
 class VoParams(C.Structure):
     _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
                 ("baseline", C.c_double), ("grid_step", C.c_int), ("anms_keep", C.c_int),

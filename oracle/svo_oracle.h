@@ -231,6 +231,15 @@ void orc_lc_scores(const uint32_t *q, int nq, const uint32_t *db, const int *db_
                    int hamming_thr, int *counts);
 void orc_lc_nearest2(const uint32_t *A, int na, const uint32_t *B, int nb, int *best_j, int *d1, int *d2);
 
+/* ---- motion BA: visualOdometry::BundleAdjust3d2d, src/bundleAdjust.cpp:551-613 --------------- */
+/* g2o Levenberg over one VertexSE3Expmap (world -> camera R9 / t3) and n free, marginalised points
+ * with one EdgeProjectXYZ2UV each; K4 = {fx, fy, cx, cy} of which upstream reads fx, cx, cy only;
+ * `iterations` = optimize(10).  t3 is overwritten (the only value upstream writes back).  Optional
+ * outputs: R9_out, pts3d_out (n*3 doubles), info[5] = {chi2 before, chi2 after, final lambda,
+ * iterations run, trials}.  Returns 0, -1 on bad arguments.                                       */
+int orc_ba_3d2d(const float *pts2d, const float *pts3d, int n, const double *K4, const double *R9, double *t3,
+                int iterations, double *R9_out, double *pts3d_out, double *info);
+
 #ifdef __cplusplus
 }
 #endif

@@ -314,6 +314,21 @@ def pnp_ransac(self, obj, img, K4, iterations=100, reproj_err=1.0, confidence=0.
     return cnt.value, rvec, tvec, inl[:cnt.value].copy(), iters.value
 
 
+@_ctx_method
+def ba_3d2d(self, pts2d, pts3d, K4, R, t, iterations=10):
+    """visualOdometry::BundleAdjust3d2d (src/bundleAdjust.cpp:551-613) -> (t, R, points, info)."""
+    p2 = np.ascontiguousarray(pts2d, np.float32).reshape(-1, 2)
+    p3 = np.ascontiguousarray(pts3d, np.float32).reshape(-1, 3)
+    n = p2.shape[0]
+    tio = np.array(t, np.float64).reshape(3).copy()
+    Rout, Xout, info = np.zeros((3, 3)), np.zeros((n, 3)), np.zeros(5)
+    _check(self.lib.svo_ba_3d2d(self._h, _ptr(p2), _ptr(p3), n, _ptr(np.ascontiguousarray(K4, np.float64)),
+                                _ptr(np.ascontiguousarray(R, np.float64).reshape(3, 3)), _ptr(tio), int(iterations),
+                                _ptr(Rout), _ptr(Xout), _ptr(info), MEM_HOST))
+    return tio, Rout, Xout, dict(chi2_before=info[0], chi2_after=info[1], lambda_final=info[2],
+                                 iterations=int(info[3]), trials=int(info[4]))
+
+
 class VoParams(C.Structure):
     _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
                 ("baseline", C.c_double), ("grid_step", C.c_int), ("anms_keep", C.c_int),
@@ -390,6 +405,14 @@ class VisualOdometry:
         if rc not in (SVO_OK, SVO_ERR_TRACKING_LOST):
             _check(rc)
         return rc, done.value, R, t, inl, trk, kf.astype(bool)
+
+    def keyframe_cloud(self):
+        """The last keyframe's camera-frame cloud (``untransformed``) -> (n, 3) float32."""
+        cap = self.ctx.lib.svo_vo_capacity(self._h)
+        a = np.zeros((cap, 3), np.float32)
+        n = C.c_int()
+        _check(self.ctx.lib.svo_vo_get_keyframe_cloud(self._h, _ptr(a), cap, C.byref(n), MEM_HOST))
+        return a[:n.value]
 
     def reference(self):
         cap = self.ctx.lib.svo_vo_capacity(self._h)
@@ -556,6 +579,68 @@ class LoopDetector:
     def close(self):
         if self._h and self.ctx._h:
             self.ctx.lib.svo_lc_destroy(self._h)
+        self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class KeyframeMap:
+    """keyFrameHistory / mapHistory in HBM and visualSLAM::updateOdometry on it
+    (src/optimizationStuff.cpp:17-47; ``svo_map``)."""
+
+    def __init__(self, ctx: "Context"):
+        self.ctx = ctx
+        self._h = C.c_void_p()
+        _check(ctx.lib.svo_map_create(ctx._h, C.byref(self._h)))
+        ctx._children.add(self)
+
+    def add_keyframe(self, traj_index: int, R, t, xyz_cam, retrack: bool = True, n: int | None = None):
+        """xyz_cam: numpy (n, 3) float32 or a device pointer / tensor with ``n`` given."""
+        if isinstance(xyz_cam, np.ndarray):
+            xyz_cam = np.ascontiguousarray(xyz_cam, np.float32).reshape(-1, 3)
+            n, mem = xyz_cam.shape[0], MEM_HOST
+        else:
+            mem = MEM_DEVICE
+        _check(self.ctx.lib.svo_map_add_keyframe(self._h, int(traj_index), _ptr(np.ascontiguousarray(R, np.float64)),
+                                                 _ptr(np.ascontiguousarray(t, np.float64)), _ptr(xyz_cam), int(n),
+                                                 int(bool(retrack)), mem))
+
+    def add_from_vo(self, vo: "VisualOdometry", traj_index: int, R, t, retrack: bool = True):
+        """The front-end's last keyframe cloud, device to device (no host copy)."""
+        import torch
+
+        n = C.c_int()
+        _check(self.ctx.lib.svo_vo_get_keyframe_cloud(vo._h, None, 0, C.byref(n), MEM_DEVICE))
+        buf = torch.empty((max(n.value, 1), 3), dtype=torch.float32, device="cuda")
+        _check(self.ctx.lib.svo_vo_get_keyframe_cloud(vo._h, _ptr(buf), n.value, C.byref(n), MEM_DEVICE))
+        self.add_keyframe(traj_index, R, t, buf, retrack, n=n.value)
+        self.ctx.sync()  # buf goes out of scope
+        return n.value
+
+    def update(self, translations):
+        t = np.ascontiguousarray(translations, np.float64).reshape(-1, 3)
+        _check(self.ctx.lib.svo_map_update(self._h, _ptr(t), t.shape[0]))
+
+    def __len__(self):
+        return self.ctx.lib.svo_map_num_keyframes(self._h)
+
+    def points(self):
+        """-> (xyz_world (N, 3) float32, counts per retrack keyframe)."""
+        npts, nkf = C.c_size_t(), C.c_int()
+        _check(self.ctx.lib.svo_map_get_points(self._h, None, C.c_size_t(0), None, 0, C.byref(npts), C.byref(nkf), MEM_HOST))
+        xyz = np.zeros((max(npts.value, 1), 3), np.float32)
+        counts = np.zeros(max(nkf.value, 1), np.int32)
+        _check(self.ctx.lib.svo_map_get_points(self._h, _ptr(xyz), C.c_size_t(npts.value), _ptr(counts), nkf.value,
+                                               C.byref(npts), C.byref(nkf), MEM_HOST))
+        return xyz[:npts.value], counts[:nkf.value]
+
+    def close(self):
+        if self._h and self.ctx._h:
+            self.ctx.lib.svo_map_destroy(self._h)
         self._h = C.c_void_p()
 
     def __del__(self):

@@ -59,6 +59,7 @@ struct svo_vo {
     PnpRecord *d_rec = nullptr;
     uint8_t *d_img = nullptr;  // staging for host images
     int nref = 0, ntrk = 0, frame = 0;
+    int kf_n = 0;  // points of the last keyframe's camera-frame cloud in b3
     double R[9], t[3];
     bool has_cur = false;
 };
@@ -309,8 +310,10 @@ int stereo_triangulate_batch(int k, svo_vo *const *vs, svo_pyramid *const *lefts
     SVO_HIP(hipGetLastError());
     if ((rc = svo_wait(ctx)))
         return rc;
-    for (int a = 0; a < k; a++)
+    for (int a = 0; a < k; a++) {
         *n_out[a] = pin[a];
+        vs[a]->kf_n = Rts[a] ? pin[a] : 0;  // b3 holds the keyframe's camera-frame cloud
+    }
     return SVO_OK;
 }
 
@@ -439,7 +442,10 @@ int svo_vo_init(svo_vo *v, const uint8_t *left, const uint8_t *right, int mem, i
     d = stage_image(v, right, mem, &rc);
     if (rc || (rc = svo_build_pyramid_from_device(v->ctx, v->pyr_right, d)))
         return rc;
-    if ((rc = stereo_triangulate(v, v->pyr_ref, v->pyr_right, nullptr, v->ref2d, v->ref3d, &v->nref)))
+    // identity [R|t]: the world cloud equals the camera-frame one bit for bit (x * 1 + y * 0 + z * 0 + 0 in
+    // double), and the camera-frame cloud lands in b3 as at every later keyframe (svo_vo_get_keyframe_cloud)
+    static const double I34[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    if ((rc = stereo_triangulate(v, v->pyr_ref, v->pyr_right, I34, v->ref2d, v->ref3d, &v->nref)))
         return rc;
     v->has_cur = false;
     if (n_points)
@@ -854,7 +860,8 @@ static int run_chunk_group(svo_chunk_job **jobs, int k)
             pr[ni] = v->pyr_right;
             il[ni] = g.j->init_left;
             ir[ni] = g.j->init_right;
-            Rts[ni] = nullptr;
+            static const double I34[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+            Rts[ni] = I34;  // as svo_vo_init
             o2d[ni] = v->ref2d;
             o3d[ni] = v->ref3d;
             nout[ni] = &v->nref;
@@ -1180,6 +1187,26 @@ int svo_vo_get_reference(svo_vo *v, float *ref2d, float *ref3d, int cap, int *n,
     if (ref3d)
         SVO_HIP(hipMemcpyAsync(ref3d, v->ref3d, (size_t)v->nref * 12, kind, v->ctx->stream));
     SVO_HIP(hipStreamSynchronize(v->ctx->stream));
+    return SVO_OK;
+}
+
+int svo_vo_get_keyframe_cloud(svo_vo *v, float *xyz_cam, int cap, int *n, int mem)
+{
+    SVO_CHECK_ARG(v && n);
+    SVO_CHECK_ARG(mem == SVO_MEM_HOST || mem == SVO_MEM_DEVICE);
+    *n = v->kf_n;
+    if (!xyz_cam)
+        return SVO_OK;
+    if (cap < v->kf_n) {
+        svo_set_error("keyframe cloud has %d points, capacity %d", v->kf_n, cap);
+        return SVO_ERR_CAPACITY;
+    }
+    if (v->kf_n == 0)
+        return SVO_OK;
+    SVO_HIP(hipMemcpyAsync(xyz_cam, v->b3, (size_t)v->kf_n * 12,
+                           mem == SVO_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, v->ctx->stream));
+    if (mem == SVO_MEM_HOST)
+        SVO_HIP(hipStreamSynchronize(v->ctx->stream));
     return SVO_OK;
 }
 

@@ -785,12 +785,46 @@ __global__ __launch_bounds__(256) void pg_chi2_kernel(const EdgeOut *__restrict_
 
 }  // namespace
 
+// DevBuf::ensure drops the old content; this one carries the first `keep` bytes over
+static int ensure_keep(DevBuf &b, size_t bytes, size_t keep, hipStream_t st)
+{
+    if (bytes <= b.cap)
+        return SVO_OK;
+    if (keep == 0 || !b.p)
+        return b.ensure(bytes);
+    DevBuf nb;
+    int rc = nb.ensure(bytes + bytes / 2);  // a graph grows vertex by vertex: leave room
+    if (rc)
+        return rc;
+    if (hipMemcpyAsync(nb.p, b.p, keep, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess) {
+        nb.release();
+        svo_set_error("pose graph: cannot carry the device copy over");
+        return SVO_ERR_HIP;
+    }
+    b.release();
+    b = nb;
+    return SVO_OK;
+}
+
 struct svo_posegraph {
     svo_ctx *ctx = nullptr;
     std::vector<double> pose;  // 7 per vertex
     std::vector<int> efrom, eto;
     std::vector<double> meas;  // 7 per edge
     int prev = -1;
+    // What the device already holds.  The graph only grows between two solves (augmentNode /
+    // addLoopClosure append), and after a solve the device poses ARE the host poses, so the next
+    // solve uploads the new vertices and edges only.  initializeGraph / read_g2o / a failed solve reset this.
+    int dev_nv = 0, dev_ne = 0;
+    // The elimination structure (separators, segments, gather lists) of the graph as last built; reused
+    // as long as no vertex or edge was added.  The host copies stay alive here so that their uploads
+    // need no synchronisation of their own.
+    int built_nv = -1, built_ne = -1;
+    std::vector<int> h_incptr, h_inc, h_struct;
+    int s_m = 0, s_nseg = 0, s_nrblocks = 0, s_T = 0, s_ldr = 0;
+    size_t o_seg_start = 0, o_seg_len = 0, o_sepidx = 0, o_lsep = 0, o_rsep = 0, o_rb_row = 0, o_rb_col = 0, o_rptr = 0,
+           o_rsrc = 0;
     DevBuf d_pose, d_from, d_to, d_meas, d_eo, d_incptr, d_inc, d_struct, d_Dg, d_Cc, d_rneg, d_Li, d_Lsub, d_Z7, d_Y,
         d_Wl, d_Wr, d_R, d_Lo, d_Tinv, d_rR, d_xR, d_dx, d_misc;
     int nv() const { return (int)(pose.size() / 7); }
@@ -831,6 +865,8 @@ int svo_pg_initialize(svo_posegraph *g)
     g->eto.clear();
     g->meas.clear();
     g->prev = 0;
+    g->dev_nv = g->dev_ne = 0;
+    g->built_nv = g->built_ne = -1;
     return SVO_OK;
 }
 
@@ -898,130 +934,155 @@ int svo_pg_optimize(svo_posegraph *g, int iters, double *chi2)
                 chi2[i] = 0;
         return SVO_OK;
     }
-    // ---- structure (host): incidence lists, separators, segments, gather lists ----
-    std::vector<int> incptr(nv + 1, 0), inc(2 * ne);
-    for (int e = 0; e < ne; e++) {
-        incptr[g->efrom[e] + 1]++;
-        incptr[g->eto[e] + 1]++;
-    }
-    for (int v = 0; v < nv; v++)
-        incptr[v + 1] += incptr[v];
-    {
-        std::vector<int> fill(incptr.begin(), incptr.end() - 1);
-        for (int e = 0; e < ne; e++) {  // ascending edge index within each vertex
-            inc[fill[g->efrom[e]]++] = 2 * e;
-            inc[fill[g->eto[e]]++] = 2 * e + 1;
+    // ---- structure (host): incidence lists, separators, segments, gather lists; rebuilt only when the
+    // graph grew since the last solve ----
+    const bool rebuild = g->built_nv != nv || g->built_ne != ne;
+    if (rebuild) {
+        std::vector<int> &incptr = g->h_incptr, &inc = g->h_inc, &hs = g->h_struct;
+        incptr.assign(nv + 1, 0);
+        inc.assign(2 * (size_t)ne, 0);
+        for (int e = 0; e < ne; e++) {
+            incptr[g->efrom[e] + 1]++;
+            incptr[g->eto[e] + 1]++;
         }
-    }
-    // separators: both ends of every chord (edge between non-neighbouring unknowns) + every SEG_L-th row
-    std::vector<int> sepidx(nb, -1);
-    std::vector<char> is_sep(nb, 0);
-    for (int b = SEG_L - 1; b < nb - 1; b += SEG_L)
-        is_sep[b] = 1;
-    for (int e = 0; e < ne; e++) {
-        const int i = g->efrom[e] - 1, j = g->eto[e] - 1;
-        if (i < 0 || j < 0 || i == j || i - j == 1 || j - i == 1)
-            continue;
-        is_sep[i] = 1;
-        is_sep[j] = 1;
-    }
-    std::vector<int> seps;
-    for (int b = 0; b < nb; b++)
-        if (is_sep[b]) {
-            sepidx[b] = (int)seps.size();
-            seps.push_back(b);
+        for (int v = 0; v < nv; v++)
+            incptr[v + 1] += incptr[v];
+        {
+            std::vector<int> fill(incptr.begin(), incptr.end() - 1);
+            for (int e = 0; e < ne; e++) {  // ascending edge index within each vertex
+                inc[fill[g->efrom[e]]++] = 2 * e;
+                inc[fill[g->eto[e]]++] = 2 * e + 1;
+            }
         }
-    const int m = (int)seps.size();
-    std::vector<int> seg_start, seg_len, lsep(nb, -1), rsep(nb, -1);
-    for (int b = 0; b < nb;) {
-        if (is_sep[b]) {
-            b++;
-            continue;
+        // separators: both ends of every chord (edge between non-neighbouring unknowns) + every SEG_L-th row
+        std::vector<int> sepidx(nb, -1);
+        std::vector<char> is_sep(nb, 0);
+        for (int b = SEG_L - 1; b < nb - 1; b += SEG_L)
+            is_sep[b] = 1;
+        for (int e = 0; e < ne; e++) {
+            const int i = g->efrom[e] - 1, j = g->eto[e] - 1;
+            if (i < 0 || j < 0 || i == j || i - j == 1 || j - i == 1)
+                continue;
+            is_sep[i] = 1;
+            is_sep[j] = 1;
         }
-        int z = b;
-        while (z + 1 < nb && !is_sep[z + 1])
-            z++;
-        seg_start.push_back(b);
-        seg_len.push_back(z - b + 1);
-        for (int r = b; r <= z; r++) {
-            lsep[r] = b > 0 ? sepidx[b - 1] : -1;
-            rsep[r] = z + 1 < nb ? sepidx[z + 1] : -1;
+        std::vector<int> seps;
+        for (int b = 0; b < nb; b++)
+            if (is_sep[b]) {
+                sepidx[b] = (int)seps.size();
+                seps.push_back(b);
+            }
+        const int m = (int)seps.size();
+        std::vector<int> seg_start, seg_len, lsep(nb, -1), rsep(nb, -1);
+        for (int b = 0; b < nb;) {
+            if (is_sep[b]) {
+                b++;
+                continue;
+            }
+            int z = b;
+            while (z + 1 < nb && !is_sep[z + 1])
+                z++;
+            seg_start.push_back(b);
+            seg_len.push_back(z - b + 1);
+            for (int r = b; r <= z; r++) {
+                lsep[r] = b > 0 ? sepidx[b - 1] : -1;
+                rsep[r] = z + 1 < nb ? sepidx[z + 1] : -1;
+            }
+            b = z + 1;
         }
-        b = z + 1;
-    }
-    const int nseg = (int)seg_start.size();
-    // gather lists of the reduced system: diagonal + sub-diagonal blocks in separator order, chords
-    struct Key {
-        int r, c;
-        bool operator<(const Key &o) const { return r != o.r ? r < o.r : c < o.c; }
-    };
-    std::map<Key, std::vector<int2>> blocks;
-    for (int k = 0; k < m; k++) {
-        const int sr = seps[k];
-        std::vector<int2> &d = blocks[{k, k}];
-        d.push_back(make_int2(0, sr));
-        if (sr + 1 < nb && !is_sep[sr + 1])
-            d.push_back(make_int2(4, sr));  // segment to the right
-        if (sr > 0 && !is_sep[sr - 1])
-            d.push_back(make_int2(5, sr - 1));  // segment to the left
-        if (k > 0) {
-            const int sl = seps[k - 1];
-            if (sl + 1 == sr)
-                blocks[{k, k - 1}].push_back(make_int2(1, sl));
+        // gather lists of the reduced system: diagonal + sub-diagonal blocks in separator order, chords
+        struct Key {
+            int r, c;
+            bool operator<(const Key &o) const { return r != o.r ? r < o.r : c < o.c; }
+        };
+        std::map<Key, std::vector<int2>> blocks;
+        for (int k = 0; k < m; k++) {
+            const int sr = seps[k];
+            std::vector<int2> &d = blocks[{k, k}];
+            d.push_back(make_int2(0, sr));
+            if (sr + 1 < nb && !is_sep[sr + 1])
+                d.push_back(make_int2(4, sr));  // segment to the right
+            if (sr > 0 && !is_sep[sr - 1])
+                d.push_back(make_int2(5, sr - 1));  // segment to the left
+            if (k > 0) {
+                const int sl = seps[k - 1];
+                if (sl + 1 == sr)
+                    blocks[{k, k - 1}].push_back(make_int2(1, sl));
+                else
+                    blocks[{k, k - 1}].push_back(make_int2(6, sr - 1));
+            }
+        }
+        for (int e = 0; e < ne; e++) {
+            const int i = g->efrom[e] - 1, j = g->eto[e] - 1;
+            if (i < 0 || j < 0 || i == j || i - j == 1 || j - i == 1)
+                continue;
+            // block(row i, col j) = Ji^T Jj; stored at (hi, lo)
+            if (i > j)
+                blocks[{sepidx[i], sepidx[j]}].push_back(make_int2(2, e));
             else
-                blocks[{k, k - 1}].push_back(make_int2(6, sr - 1));
+                blocks[{sepidx[j], sepidx[i]}].push_back(make_int2(3, e));
+        }
+        std::vector<int> rb_row, rb_col, rptr(1, 0);
+        std::vector<int2> rsrc;
+        for (auto &kv : blocks) {
+            rb_row.push_back(kv.first.r);
+            rb_col.push_back(kv.first.c);
+            rsrc.insert(rsrc.end(), kv.second.begin(), kv.second.end());
+            rptr.push_back((int)rsrc.size());
+        }
+        for (int k = 0; k < m; k++) {  // right-hand sides
+            const int sr = seps[k];
+            rsrc.push_back(make_int2(0, sr));
+            if (sr + 1 < nb && !is_sep[sr + 1])
+                rsrc.push_back(make_int2(4, sr));
+            if (sr > 0 && !is_sep[sr - 1])
+                rsrc.push_back(make_int2(5, sr - 1));
+            rptr.push_back((int)rsrc.size());
+        }
+        g->s_m = m;
+        g->s_nseg = (int)seg_start.size();
+        g->s_nrblocks = (int)blocks.size();
+        g->s_T = (6 * m + TB - 1) / TB;
+        g->s_ldr = g->s_T * TB;
+        // one int buffer for all the structure arrays
+        hs.clear();
+        auto put = [&](const std::vector<int> &v) {
+            const size_t off = hs.size();
+            hs.insert(hs.end(), v.begin(), v.end());
+            return off;
+        };
+        g->o_seg_start = put(seg_start);
+        g->o_seg_len = put(seg_len);
+        g->o_sepidx = put(sepidx);
+        g->o_lsep = put(lsep);
+        g->o_rsep = put(rsep);
+        g->o_rb_row = put(rb_row);
+        g->o_rb_col = put(rb_col);
+        g->o_rptr = put(rptr);
+        if (hs.size() & 1)
+            hs.push_back(0);
+        g->o_rsrc = hs.size();
+        for (const int2 &v : rsrc) {
+            hs.push_back(v.x);
+            hs.push_back(v.y);
         }
     }
-    for (int e = 0; e < ne; e++) {
-        const int i = g->efrom[e] - 1, j = g->eto[e] - 1;
-        if (i < 0 || j < 0 || i == j || i - j == 1 || j - i == 1)
-            continue;
-        // block(row i, col j) = Ji^T Jj; stored at (hi, lo)
-        if (i > j)
-            blocks[{sepidx[i], sepidx[j]}].push_back(make_int2(2, e));
-        else
-            blocks[{sepidx[j], sepidx[i]}].push_back(make_int2(3, e));
-    }
-    const int n_rblocks = (int)blocks.size();
-    std::vector<int> rb_row, rb_col, rptr(1, 0);
-    std::vector<int2> rsrc;
-    for (auto &kv : blocks) {
-        rb_row.push_back(kv.first.r);
-        rb_col.push_back(kv.first.c);
-        rsrc.insert(rsrc.end(), kv.second.begin(), kv.second.end());
-        rptr.push_back((int)rsrc.size());
-    }
-    for (int k = 0; k < m; k++) {  // right-hand sides
-        const int sr = seps[k];
-        rsrc.push_back(make_int2(0, sr));
-        if (sr + 1 < nb && !is_sep[sr + 1])
-            rsrc.push_back(make_int2(4, sr));
-        if (sr > 0 && !is_sep[sr - 1])
-            rsrc.push_back(make_int2(5, sr - 1));
-        rptr.push_back((int)rsrc.size());
-    }
-    const int T = (6 * m + TB - 1) / TB, ldr = T * TB;
-    // one int buffer for all the structure arrays
-    std::vector<int> hs;
-    auto put = [&](const std::vector<int> &v) {
-        const size_t off = hs.size();
-        hs.insert(hs.end(), v.begin(), v.end());
-        return off;
-    };
-    const size_t o_seg_start = put(seg_start), o_seg_len = put(seg_len), o_sepidx = put(sepidx), o_lsep = put(lsep),
-                 o_rsep = put(rsep), o_rb_row = put(rb_row), o_rb_col = put(rb_col), o_rptr = put(rptr);
-    if (hs.size() & 1)
-        hs.push_back(0);
-    const size_t o_rsrc = hs.size();
-    for (const int2 &v : rsrc) {
-        hs.push_back(v.x);
-        hs.push_back(v.y);
-    }
+    const int m = g->s_m, nseg = g->s_nseg, n_rblocks = g->s_nrblocks, T = g->s_T, ldr = g->s_ldr;
+    const size_t o_seg_start = g->o_seg_start, o_seg_len = g->o_seg_len, o_sepidx = g->o_sepidx, o_lsep = g->o_lsep,
+                 o_rsep = g->o_rsep, o_rb_row = g->o_rb_row, o_rb_col = g->o_rb_col, o_rptr = g->o_rptr,
+                 o_rsrc = g->o_rsrc;
+    hipStream_t st = ctx->stream;
     int rc;
-    if ((rc = g->d_pose.ensure((size_t)nv * 56)) || (rc = g->d_from.ensure((size_t)ne * 4)) ||
-        (rc = g->d_to.ensure((size_t)ne * 4)) || (rc = g->d_meas.ensure((size_t)ne * 56)) ||
-        (rc = g->d_eo.ensure((size_t)ne * sizeof(EdgeOut))) || (rc = g->d_incptr.ensure((size_t)(nv + 1) * 4)) ||
-        (rc = g->d_inc.ensure((size_t)2 * ne * 4)) || (rc = g->d_struct.ensure(hs.size() * 4 + 16)) ||
+    // the graph itself: grown buffers keep what the device already holds, only the tail is uploaded
+    if (g->dev_nv > nv || g->dev_ne > ne)
+        g->dev_nv = g->dev_ne = 0;
+    if ((rc = ensure_keep(g->d_pose, (size_t)nv * 56, (size_t)g->dev_nv * 56, st)) ||
+        (rc = ensure_keep(g->d_from, (size_t)ne * 4, (size_t)g->dev_ne * 4, st)) ||
+        (rc = ensure_keep(g->d_to, (size_t)ne * 4, (size_t)g->dev_ne * 4, st)) ||
+        (rc = ensure_keep(g->d_meas, (size_t)ne * 56, (size_t)g->dev_ne * 56, st)))
+        return rc;
+    if ((rc = g->d_eo.ensure((size_t)ne * sizeof(EdgeOut))) || (rc = g->d_incptr.ensure((size_t)(nv + 1) * 4)) ||
+        (rc = g->d_inc.ensure((size_t)2 * ne * 4)) || (rc = g->d_struct.ensure(g->h_struct.size() * 4 + 16)) ||
         (rc = g->d_Dg.ensure((size_t)nb * 288)) || (rc = g->d_Cc.ensure((size_t)nb * 288)) ||
         (rc = g->d_rneg.ensure((size_t)nb * 48)) || (rc = g->d_Li.ensure((size_t)nb * 288)) ||
         (rc = g->d_Lsub.ensure((size_t)(nb + 1) * 288)) || (rc = g->d_Z7.ensure((size_t)nb * 42 * 8)) ||
@@ -1031,16 +1092,24 @@ int svo_pg_optimize(svo_posegraph *g, int iters, double *chi2)
         (rc = g->d_rR.ensure((size_t)ldr * 8 + 64)) || (rc = g->d_xR.ensure((size_t)ldr * 8 + 64)) ||
         (rc = g->d_dx.ensure((size_t)nb * 48)) || (rc = g->d_misc.ensure(((size_t)iters + 4) * 8 + 64)))
         return rc;
-    hipStream_t st = ctx->stream;
-    SVO_HIP(hipMemcpyAsync(g->d_pose.p, g->pose.data(), (size_t)nv * 56, hipMemcpyHostToDevice, st));
-    SVO_HIP(hipMemcpyAsync(g->d_from.p, g->efrom.data(), (size_t)ne * 4, hipMemcpyHostToDevice, st));
-    SVO_HIP(hipMemcpyAsync(g->d_to.p, g->eto.data(), (size_t)ne * 4, hipMemcpyHostToDevice, st));
-    SVO_HIP(hipMemcpyAsync(g->d_meas.p, g->meas.data(), (size_t)ne * 56, hipMemcpyHostToDevice, st));
-    SVO_HIP(hipMemcpyAsync(g->d_incptr.p, incptr.data(), (size_t)(nv + 1) * 4, hipMemcpyHostToDevice, st));
-    SVO_HIP(hipMemcpyAsync(g->d_inc.p, inc.data(), (size_t)2 * ne * 4, hipMemcpyHostToDevice, st));
-    SVO_HIP(hipMemcpyAsync(g->d_struct.p, hs.data(), hs.size() * 4, hipMemcpyHostToDevice, st));
-    // the host vectors above must outlive the async copies
-    SVO_HIP(hipStreamSynchronize(st));
+    // (g->pose / efrom / eto / meas and the structure vectors live in *g: the copies below need no sync)
+    if (nv > g->dev_nv)
+        SVO_HIP(hipMemcpyAsync(g->d_pose.as<double>() + 7 * (size_t)g->dev_nv, g->pose.data() + 7 * (size_t)g->dev_nv,
+                               (size_t)(nv - g->dev_nv) * 56, hipMemcpyHostToDevice, st));
+    if (ne > g->dev_ne) {
+        const size_t e0 = (size_t)g->dev_ne, cnt = (size_t)(ne - g->dev_ne);
+        SVO_HIP(hipMemcpyAsync(g->d_from.as<int>() + e0, g->efrom.data() + e0, cnt * 4, hipMemcpyHostToDevice, st));
+        SVO_HIP(hipMemcpyAsync(g->d_to.as<int>() + e0, g->eto.data() + e0, cnt * 4, hipMemcpyHostToDevice, st));
+        SVO_HIP(hipMemcpyAsync(g->d_meas.as<double>() + 7 * e0, g->meas.data() + 7 * e0, cnt * 56, hipMemcpyHostToDevice, st));
+    }
+    if (rebuild) {
+        SVO_HIP(hipMemcpyAsync(g->d_incptr.p, g->h_incptr.data(), (size_t)(nv + 1) * 4, hipMemcpyHostToDevice, st));
+        SVO_HIP(hipMemcpyAsync(g->d_inc.p, g->h_inc.data(), (size_t)2 * ne * 4, hipMemcpyHostToDevice, st));
+        SVO_HIP(hipMemcpyAsync(g->d_struct.p, g->h_struct.data(), g->h_struct.size() * 4, hipMemcpyHostToDevice, st));
+        g->built_nv = nv;
+        g->built_ne = ne;
+    }
+    g->dev_nv = g->dev_ne = 0;  // until this solve has succeeded the device copy is not to be trusted
     const int *ds = g->d_struct.as<int>();
     double *d_chi = g->d_misc.as<double>();
     int *d_status = reinterpret_cast<int *>(d_chi + iters + 2);
@@ -1105,6 +1174,8 @@ int svo_pg_optimize(svo_posegraph *g, int iters, double *chi2)
         return SVO_ERR_STATE;
     }
     g->pose.swap(hpose);
+    g->dev_nv = nv;  // device poses == host poses, edges unchanged: the next solve uploads what is appended
+    g->dev_ne = ne;
     return SVO_OK;
 }
 
@@ -1218,6 +1289,8 @@ int svo_pg_read_g2o(svo_posegraph *g, const char *path)
     g->eto = et;
     g->meas = em;
     g->prev = n - 1;
+    g->dev_nv = g->dev_ne = 0;
+    g->built_nv = g->built_ne = -1;
     return SVO_OK;
 }
 
