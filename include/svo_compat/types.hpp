@@ -30,10 +30,6 @@ using Point2f = cv::Point2f;
 using Point3f = cv::Point3f;
 using KeyPoint = cv::KeyPoint;
 using Mat = cv::Mat;
-inline const uint8_t *mat_data(const Mat &m) { return m.data; }
-inline int mat_rows(const Mat &m) { return m.rows; }
-inline int mat_cols(const Mat &m) { return m.cols; }
-inline int mat_channels(const Mat &m) { return m.channels(); }
 #else
 struct Point2f {
     float x = 0, y = 0;
@@ -53,28 +49,52 @@ struct KeyPoint {
     KeyPoint() = default;
     KeyPoint(float x, float y, float s) : pt(x, y), size(s) {}
 };
-// An 8-bit interleaved image view/owner with cv::Mat's shallow-copy semantics
-// (cv::Mat by value = ref-counted header copy, no pixel copy).
+// cv::Mat's type codes for the two depths the hot path uses (depth + ((channels - 1) << 3))
+constexpr int CV_8U = 0, CV_64F = 6, CV_8UC1 = 0, CV_8UC3 = 16;
+// A dense continuous matrix with cv::Mat's shallow-copy semantics (by value = ref-counted header
+// copy, no element copy): CV_8UC1 / CV_8UC3 images and the CV_64F matrices (K, R, t, rvec, tvec,
+// [R|t]) the reference passes through its member functions as cv::Mat.
 struct Mat {
-    int rows = 0, cols = 0, chans = 0;
-    std::shared_ptr<std::vector<uint8_t>> store;
-    const uint8_t *data = nullptr;
+    int rows = 0, cols = 0;
+    uint8_t *data = nullptr;
     Mat() = default;
-    Mat(int r, int c, int ch) : rows(r), cols(c), chans(ch), store(std::make_shared<std::vector<uint8_t>>((size_t)r * c * ch))
+    Mat(int r, int c, int type) : rows(r), cols(c), type_(type)
     {
-        data = store->data();
+        store_ = std::make_shared<std::vector<uint8_t>>((size_t)r * c * elemSize(), (uint8_t)0);
+        data = store_->data();
     }
-    // non-owning view of caller memory (row stride = cols * channels)
-    Mat(int r, int c, int ch, const uint8_t *ptr) : rows(r), cols(c), chans(ch), data(ptr) {}
-    uint8_t *ptr() { return store ? store->data() : nullptr; }
-    int channels() const { return chans; }
-    bool empty() const { return data == nullptr; }
+    // non-owning view of caller memory (continuous: row stride = cols * elemSize())
+    Mat(int r, int c, int type, void *ptr) : rows(r), cols(c), data(static_cast<uint8_t *>(ptr)), type_(type) {}
+    static Mat zeros(int r, int c, int type) { return Mat(r, c, type); }
+    int type() const { return type_; }
+    int depth() const { return type_ & 7; }
+    int channels() const { return (type_ >> 3) + 1; }
+    size_t elemSize() const { return (size_t)channels() * (depth() == CV_64F ? 8 : 1); }
+    bool empty() const { return data == nullptr || rows == 0 || cols == 0; }
+    bool isContinuous() const { return true; }
+    uint8_t *ptr() { return data; }
+    template <class T> T &at(int r, int c) { return *reinterpret_cast<T *>(data + ((size_t)r * cols + c) * elemSize()); }
+    template <class T> const T &at(int r, int c) const
+    {
+        return *reinterpret_cast<const T *>(data + ((size_t)r * cols + c) * elemSize());
+    }
+    Mat clone() const
+    {
+        Mat m(rows, cols, type_);
+        if (data)
+            std::memcpy(m.data, data, (size_t)rows * cols * elemSize());
+        return m;
+    }
+
+  private:
+    int type_ = CV_8UC1;
+    std::shared_ptr<std::vector<uint8_t>> store_;
 };
+#endif
 inline const uint8_t *mat_data(const Mat &m) { return m.data; }
 inline int mat_rows(const Mat &m) { return m.rows; }
 inline int mat_cols(const Mat &m) { return m.cols; }
-inline int mat_channels(const Mat &m) { return m.chans; }
-#endif
+inline int mat_channels(const Mat &m) { return m.channels(); }
 
 // 3x3 / 3x1 / 3x4 double matrices of the reference (cv::Mat CV_64F there), row-major
 struct Mat33d {
@@ -105,59 +125,17 @@ struct Mat34d {
 
 #if defined(SVO_WITH_EIGEN)
 using Isometry3d = Eigen::Isometry3d;
-inline void iso_to_pose7(const Isometry3d &T, double *p)
-{
-    Eigen::Quaterniond q(T.linear());
-    if (q.w() < 0)
-        q.coeffs() *= -1;
-    p[0] = T.translation()(0);
-    p[1] = T.translation()(1);
-    p[2] = T.translation()(2);
-    p[3] = q.x();
-    p[4] = q.y();
-    p[5] = q.z();
-    p[6] = q.w();
-}
-inline Isometry3d pose7_to_iso(const double *p)
-{
-    Isometry3d T = Isometry3d::Identity();
-    T.linear() = Eigen::Quaterniond(p[6], p[3], p[4], p[5]).toRotationMatrix();
-    T.translation() = Eigen::Vector3d(p[0], p[1], p[2]);
-    return T;
-}
 #else
-// Eigen::Isometry3d stand-in: 4x4 double, column-major like Eigen
+// Eigen::Isometry3d stand-in: 4x4 double, column-major like Eigen, element access T(r, c)
 struct Isometry3d {
     double m[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     static Isometry3d Identity() { return Isometry3d(); }
     double &operator()(int r, int c) { return m[4 * c + r]; }
     double operator()(int r, int c) const { return m[4 * c + r]; }
-    Vec3d translation() const
-    {
-        Vec3d t;
-        for (int i = 0; i < 3; i++)
-            t(i) = (*this)(i, 3);
-        return t;
-    }
-    Mat33d linear() const
-    {
-        Mat33d R;
-        for (int i = 0; i < 3; i++)
-            for (int j = 0; j < 3; j++)
-                R(i, j) = (*this)(i, j);
-        return R;
-    }
-    static Isometry3d from(const Mat33d &R, const Vec3d &t)
-    {
-        Isometry3d T;
-        for (int i = 0; i < 3; i++) {
-            for (int j = 0; j < 3; j++)
-                T(i, j) = R(i, j);
-            T(i, 3) = t(i);
-        }
-        return T;
-    }
 };
+#endif
+// The conversions below touch an isometry through Identity() and T(r, c) only -- the part of
+// Eigen::Transform's interface the stand-in shares -- so the SVO_WITH_EIGEN build runs the same code.
 inline void iso_to_pose7(const Isometry3d &T, double *p)
 {
     const double r00 = T(0, 0), r11 = T(1, 1), r22 = T(2, 2), tr = r00 + r11 + r22;
@@ -198,7 +176,7 @@ inline void iso_to_pose7(const Isometry3d &T, double *p)
 inline Isometry3d pose7_to_iso(const double *p)
 {
     const double x = p[3], y = p[4], z = p[5], w = p[6];
-    Isometry3d T;
+    Isometry3d T = Isometry3d::Identity();
     T(0, 0) = 1 - 2 * (y * y + z * z);
     T(0, 1) = 2 * (x * y - z * w);
     T(0, 2) = 2 * (x * z + y * w);
@@ -213,7 +191,63 @@ inline Isometry3d pose7_to_iso(const double *p)
     T(2, 3) = p[2];
     return T;
 }
-#endif
+inline Isometry3d iso_from(const Mat33d &R, const Vec3d &t)
+{
+    Isometry3d T = Isometry3d::Identity();
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++)
+            T(i, j) = R(i, j);
+        T(i, 3) = t(i);
+    }
+    return T;
+}
+
+// ---- cv::Mat (CV_64F) <-> the typed 3x3 / 3x1 / 3x4 holders (both Mat flavours offer at<double>) ----
+inline Mat33d mat33_of(const Mat &m)
+{
+    if (m.rows != 3 || m.cols != 3 || m.type() != CV_64F)
+        throw std::invalid_argument("expected a 3x3 CV_64F matrix");
+    Mat33d R;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            R(i, j) = m.at<double>(i, j);
+    return R;
+}
+// 3x1 (tvec, rvec) or 1x3 (the reference's trajectory entries, include/monoUtils.h:109-127)
+inline Vec3d vec3_of(const Mat &m)
+{
+    if (m.type() != CV_64F || !((m.rows == 3 && m.cols == 1) || (m.rows == 1 && m.cols == 3)))
+        throw std::invalid_argument("expected a 3x1 or 1x3 CV_64F matrix");
+    Vec3d v;
+    for (int i = 0; i < 3; i++)
+        v(i) = m.rows == 3 ? m.at<double>(i, 0) : m.at<double>(0, i);
+    return v;
+}
+inline Mat34d mat34_of(const Mat &m)
+{
+    if (m.rows != 3 || m.cols != 4 || m.type() != CV_64F)
+        throw std::invalid_argument("expected a 3x4 CV_64F matrix");
+    Mat34d P;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 4; j++)
+            P(i, j) = m.at<double>(i, j);
+    return P;
+}
+inline Mat to_mat(const Mat33d &R)
+{
+    Mat m = Mat::zeros(3, 3, CV_64F);
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            m.at<double>(i, j) = R(i, j);
+    return m;
+}
+inline Mat to_mat(const Vec3d &v)  // 3x1, as solvePnPRansac returns rvec / tvec
+{
+    Mat m = Mat::zeros(3, 1, CV_64F);
+    for (int i = 0; i < 3; i++)
+        m.at<double>(i, 0) = v(i);
+    return m;
+}
 
 // The reference never checks return codes (it has none); the adaptors turn a failing C-ABI
 // call into an exception, the moral equivalent of the uncaught cv::Exception upstream.

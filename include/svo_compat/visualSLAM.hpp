@@ -46,6 +46,9 @@ class visualSLAM {
     double focal_y = 7.188560000000e+02, cy = 1.852157000000e+02;
     int gridStep = 30;              // src/triangulation.cpp:89
     int keyframeMinInliers = 200;   // src/VisualSLAM.cpp:120
+    int loopMinGap = 100;           // query - match > 100, src/optimizationStuff.cpp:58
+    int loopCooldown = 100;         // cooldownTimer = 100, src/optimizationStuff.cpp:62
+    bool mapSOR = true;             // SORcloud(untransformed, colors) before a record is stored, src/VisualSLAM.cpp:154
     uint64_t ransacSeed = 0;
     Mat referenceImg, currentImage;
     std::vector<Point3f> untransformed, colors;
@@ -63,6 +66,8 @@ class visualSLAM {
             svo_vo_destroy(vo_);
         if (lc_)
             svo_lc_destroy(lc_);
+        if (map_)
+            svo_map_destroy(map_);
     }
     visualSLAM(const visualSLAM &) = delete;
     visualSLAM &operator=(const visualSLAM &) = delete;
@@ -174,6 +179,12 @@ class visualSLAM {
         return out;
     }
 
+    // the reference's own signature (include/visualSLAM.h:165): pose4dTransform is a 3x4 CV_64F cv::Mat
+    std::vector<Point3f> update3dtransformation(std::vector<Point3f> &pt3d, Mat &pose4dTransform)
+    {
+        return update3dtransformation(pt3d, mat34_of(pose4dTransform));
+    }
+
     // ---- src/optimizationStuff.cpp:49-64: ORB features + DLoopDetector::detectLoop on the GPU.
     //      One call per frame, in order (the detector stores every frame).  lcParams may be
     //      edited before the first call; result.match / result.query are kept in lastLoopResult. ----
@@ -189,11 +200,11 @@ class visualSLAM {
         LoopResult r;
         check(svo_lc_detect(lc_, mat_data(img), SVO_MEM_HOST, &r.status, &r.query, &r.match));
         lastLoopResult = r;
-        if (r.detection() && (r.query - r.match > 100) && cooldownTimer == 0) {  // :58
+        if (r.detection() && (r.query - r.match > loopMinGap) && cooldownTimer == 0) {  // :58
             std::fprintf(stderr, "Found Loop Closure between %d and %d\n", idx, r.match);
             LC_FLAG = true;
             LCidx = r.match - 1;  // :61 (vertices[-1] when match == 0: callers clamp, see processFrame)
-            cooldownTimer = 100;
+            cooldownTimer = loopCooldown;
         }
     }
 
@@ -230,6 +241,14 @@ class visualSLAM {
         ftrPts = new2d;
     }
 
+    // the reference's own signature (include/visualSLAM.h:164): images by value, pose4dTransform a 3x4
+    // CV_64F cv::Mat
+    void insertKeyFrames(int start, Mat imL, Mat imR, Mat &pose4dTransform, std::vector<Point2f> &ftrPts,
+                         std::vector<Point3f> &ref3dCoords)
+    {
+        insertKeyFrames(start, imL, imR, mat34_of(pose4dTransform), ftrPts, ref3dCoords);
+    }
+
     // ---- src/keyFrameManagement.cpp:73-94 (uses the members referenceImg / currentImage) ----
     void PerspectiveNpointEstimation(Mat & /*prevImg*/, Mat & /*curImg*/, std::vector<Point2f> &ref2dPoints,
                                      std::vector<Point3f> &ref3dPoints, std::vector<Point2f> &tracked2dPoints,
@@ -253,7 +272,27 @@ class visualSLAM {
         inliers.resize((size_t)ninl);
     }
 
+    // the reference's own signature (include/visualSLAM.h:168-169): rvec / tvec come back as 3x1 CV_64F
+    // cv::Mat, as cv::solvePnPRansac fills them
+    void PerspectiveNpointEstimation(Mat &prevImg, Mat &curImg, std::vector<Point2f> &ref2dPoints,
+                                     std::vector<Point3f> &ref3dPoints, std::vector<Point2f> &tracked2dPoints,
+                                     std::vector<Point3f> &tracked3dPoints, Mat &rvec, Mat &tvec,
+                                     std::vector<int> &inliers)
+    {
+        Vec3d r, t;
+        PerspectiveNpointEstimation(prevImg, curImg, ref2dPoints, ref3dPoints, tracked2dPoints, tracked3dPoints, r, t,
+                                    inliers);
+        rvec = to_mat(r);
+        tvec = to_mat(t);
+    }
+
     // ---- src/optimizationStuff.cpp:3-15 ----
+    // the reference's own signature (include/visualSLAM.h:177): four CV_64F cv::Mat (R 3x3; t 3x1 --
+    // cvMat2Eigen reads tvec.at<double>(i, 0), include/monoUtils.h:102-104; a 1x3 t is accepted too)
+    void stageForPGO(Mat Rl, Mat tl, Mat Rg, Mat tg, bool loopClose)
+    {
+        stageForPGO(mat33_of(Rl), vec3_of(tl), mat33_of(Rg), vec3_of(tg), loopClose);
+    }
     void stageForPGO(const Mat33d & /*Rl*/, const Vec3d & /*tl*/, const Mat33d &Rg, const Vec3d &tg, bool loopClose)
     {
         const Isometry3d globalT = Isometry3d_from(Rg, tg);
@@ -266,6 +305,10 @@ class visualSLAM {
     }
 
     // ---- src/optimizationStuff.cpp:17-47 ----
+    // trajectory <- translations of T; every stored record's camera-frame cloud re-transformed with
+    // [R_old | t_new]; mapHistory rebuilt from the records with retrack.  Records that processFrame
+    // stored keep their clouds in HBM (svo_map): ONE launch re-transforms all of them.  Records a
+    // caller pushed into keyFrameHistory with a host cloud go through update3dtransformation as upstream.
     void updateOdometry(std::vector<Isometry3d> &T)
     {
         trajectory.clear();
@@ -273,6 +316,27 @@ class visualSLAM {
         for (const Isometry3d &iso : T)
             trajectory.push_back(translation_of(iso));
         mapHistory.clear();
+        if (map_ && svo_map_num_keyframes(map_) > 0) {
+            std::vector<double> ts(trajectory.size() * 3);
+            for (size_t j = 0; j < trajectory.size(); j++)
+                for (int i = 0; i < 3; i++)
+                    ts[3 * j + i] = trajectory[j](i);
+            check(svo_map_update(map_, ts.data(), (int)trajectory.size()));
+            for (size_t j = 0; j < keyFrameHistory.size() && j < trajectory.size(); j++)
+                keyFrameHistory[j].t = trajectory[j];  // R keeps its un-optimised value, as upstream (:29-32)
+            size_t npts = 0;
+            int nkf = 0;
+            check(svo_map_get_points(map_, nullptr, 0, nullptr, 0, &npts, &nkf, SVO_MEM_HOST));
+            std::vector<Point3f> all(npts);
+            std::vector<int> counts((size_t)nkf);
+            check(svo_map_get_points(map_, f3(all), npts, counts.data(), nkf, &npts, &nkf, SVO_MEM_HOST));
+            size_t o = 0;
+            for (int k = 0; k < nkf; k++) {
+                mapHistory.emplace_back(all.begin() + (long)o, all.begin() + (long)(o + (size_t)counts[k]));
+                o += (size_t)counts[k];
+            }
+            return;
+        }
         for (size_t j = 0; j < keyFrameHistory.size() && j < trajectory.size(); j++) {
             keyFrame &kf = keyFrameHistory[j];
             kf.t = trajectory[j];  // R keeps its un-optimised value, as upstream (:29-32)
@@ -306,8 +370,9 @@ class visualSLAM {
             poseGraph.initializeGraph();
             R = Mat33d();
             t = Vec3d();
-            keyFrame kf;
+            keyFrame kf;  // src/VisualSLAM.cpp:35-37: kf.ref3dCoords = ref3dCoords, retrack stays false
             kf.idx = 0;
+            store_record(kf, R, t, false, 0);
             keyFrameHistory.push_back(kf);
             isoVector.push_back(Isometry3d_from(R, t));
             frame_ = 0;
@@ -322,10 +387,10 @@ class visualSLAM {
         }
         check(rc);
         // checkLoopDetectorStatus (src/optimizationStuff.cpp:59-63) with the supplied match
-        if (loopMatch >= 0 && (frame_ - loopMatch > 100) && cooldownTimer == 0) {
+        if (loopMatch >= 0 && (frame_ - loopMatch > loopMinGap) && cooldownTimer == 0) {
             LC_FLAG = true;
             LCidx = loopMatch > 0 ? loopMatch - 1 : 0;  // the reference indexes vertices[-1] when match == 0
-            cooldownTimer = 100;
+            cooldownTimer = loopCooldown;
         }
         if (LC_FLAG) {  // src/VisualSLAM.cpp:76-86
             stageForPGO(R, t, R, t, true);
@@ -339,18 +404,30 @@ class visualSLAM {
         }
         int kf = 0;
         check(svo_vo_update(vo_, mat_data(right), SVO_MEM_HOST, R.m, t.v, ninl, LC_FLAG ? 1 : 0, &kf));
-        if (kf) {
+        if (kf) {  // src/VisualSLAM.cpp:122-140
+            // good3d = the new reference cloud (world), SORcloud'ed, appended to mapHistory; colorHistory is
+            // not filled by the fused path (colours: stereoTriangulate's `colors` member of the stage path)
+            const int cap = svo_vo_capacity(vo_);
+            std::vector<Point3f> good3d((size_t)cap), none;
+            int n = 0;
+            check(svo_vo_get_reference(vo_, nullptr, f3(good3d), cap, &n, SVO_MEM_HOST));
+            good3d.resize((size_t)n);
+            if (mapSOR && n > 0)
+                SORcloud(good3d, none);
+            mapHistory.emplace_back(good3d);
             isoVector.push_back(Isometry3d_from(R, t));
             trajectory.push_back(t);
         }
         if (cooldownTimer != 0)
             cooldownTimer--;
         LC_FLAG = false;
-        keyFrame k;
+        keyFrame k;  // src/VisualSLAM.cpp:154-166
         k.idx = frame_;
         k.R = R;
         k.t = t;
         k.retrack = kf != 0;
+        if (kf)
+            store_record(k, R, t, true, frame_);
         keyFrameHistory.push_back(k);
         return true;
     }
@@ -360,16 +437,7 @@ class visualSLAM {
     static float *f(std::vector<Point2f> &v) { return reinterpret_cast<float *>(v.data()); }
     static const float *f3(const std::vector<Point3f> &v) { return reinterpret_cast<const float *>(v.data()); }
     static float *f3(std::vector<Point3f> &v) { return reinterpret_cast<float *>(v.data()); }
-    static Isometry3d Isometry3d_from(const Mat33d &R, const Vec3d &t)
-    {
-        Isometry3d T = Isometry3d::Identity();
-        for (int i = 0; i < 3; i++) {
-            for (int j = 0; j < 3; j++)
-                T(i, j) = R(i, j);
-            T(i, 3) = t(i);
-        }
-        return T;
-    }
+    static Isometry3d Isometry3d_from(const Mat33d &R, const Vec3d &t) { return iso_from(R, t); }
     static Vec3d translation_of(const Isometry3d &T)
     {
         Vec3d t;
@@ -406,9 +474,33 @@ class visualSLAM {
         b.swap(ob);
     }
 
+    // The fused front-end's last keyframe cloud (camera frame, `untransformed`) becomes the record's
+    // cloud: SORcloud first when mapSOR (src/VisualSLAM.cpp:154), then into the device map.  Upstream
+    // stores the same cloud again in every non-keyframe record and re-transforms it on every closure only
+    // to discard the result (src/optimizationStuff.cpp:43-45); those copies are not kept here.
+    void store_record(keyFrame &k, const Mat33d &R, const Vec3d &t, bool retrack, int traj_index)
+    {
+        if (!map_)
+            check(svo_map_create(ctx_, &map_));
+        int n = 0;
+        check(svo_vo_get_keyframe_cloud(vo_, nullptr, 0, &n, SVO_MEM_HOST));
+        std::vector<Point3f> cloud((size_t)n);
+        if (n > 0)
+            check(svo_vo_get_keyframe_cloud(vo_, f3(cloud), n, &n, SVO_MEM_HOST));
+        untransformed = cloud;
+        if (mapSOR && n > 0) {
+            std::vector<Point3f> none;
+            SORcloud(untransformed, none);
+        }
+        k.ref3dCoords = untransformed;
+        check(svo_map_add_keyframe(map_, traj_index, R.m, t.v, f3(untransformed), (int)untransformed.size(),
+                                   retrack ? 1 : 0, SVO_MEM_HOST));
+    }
+
     svo_ctx *ctx_;
     svo_vo *vo_ = nullptr;
     svo_lc *lc_ = nullptr;
+    svo_map *map_ = nullptr;
     static svo_lc_params default_lc_params()
     {
         svo_lc_params p;

@@ -149,6 +149,7 @@ int svo_map_add_keyframe(svo_map *m, int traj_index, const double *R9, const dou
     }
     const int id = (int)m->rec.size();
     m->rec.push_back(r);
+    m->n_pts += (size_t)n;
     if (n == 0)
         return SVO_OK;
     hipStream_t st = m->ctx->stream;

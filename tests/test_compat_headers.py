@@ -1,6 +1,7 @@
 """The C++ adaptors of include/svo_compat/ (the reference's visualSLAM / globalPoseGraph /
-StereoProcess member surface on top of the C ABI) compile without OpenCV/Eigen/g2o/ROS and,
-on a GPU box, run."""
+StereoProcess / visualOdometry member surface on top of the C ABI) compile without
+OpenCV/Eigen/g2o/ROS, compile in their SVO_WITH_OPENCV / SVO_WITH_EIGEN form against minimal
+layout-compatible stub headers (tests/cpp/stubs/) and, on a GPU box, run in both forms."""
 import pathlib
 import subprocess
 
@@ -9,12 +10,14 @@ import pytest
 ROOT = pathlib.Path(__file__).resolve().parents[1]
 SRC = ROOT / "tests" / "cpp" / "compat_smoke.cpp"
 EXE = ROOT / "tests" / "cpp" / "compat_smoke"
+EXE_CV = ROOT / "tests" / "cpp" / "compat_smoke_cv"
+REAL_TYPES = ["-DSVO_WITH_OPENCV", "-DSVO_WITH_EIGEN", f"-I{ROOT / 'tests' / 'cpp' / 'stubs'}"]
 
 
-def _build():
-    cmd = ["g++", "-std=c++17", "-Wall", "-Werror", f"-I{ROOT / 'include'}", str(SRC),
+def _build(exe=EXE, extra=()):
+    cmd = ["g++", "-std=c++17", "-Wall", "-Werror", *extra, f"-I{ROOT / 'include'}", str(SRC),
            f"-L{ROOT / 'ros_stereo_slam_amd'}", "-l:libsvo_hip.so",
-           f"-Wl,-rpath,{ROOT / 'ros_stereo_slam_amd'}", "-o", str(EXE)]
+           f"-Wl,-rpath,{ROOT / 'ros_stereo_slam_amd'}", "-o", str(exe)]
     subprocess.run(cmd, check=True, capture_output=True, text=True)
 
 
@@ -23,11 +26,60 @@ def test_compat_headers_compile_and_link():
     assert EXE.exists()
 
 
-def test_each_header_is_self_contained(tmp_path):
-    for h in ("types.hpp", "poseGraph.hpp", "visualSLAM.hpp", "stereoCV.hpp"):
+def test_real_type_branches_compile_and_link():
+    """-DSVO_WITH_OPENCV -DSVO_WITH_EIGEN: Mat = cv::Mat, Point2f = cv::Point2f, Isometry3d =
+    Eigen::Isometry3d ... -- the branch a maintainer of the reference builds."""
+    _build(EXE_CV, REAL_TYPES)
+    assert EXE_CV.exists()
+
+
+@pytest.mark.parametrize("extra", [(), tuple(REAL_TYPES)], ids=["pod", "opencv_eigen"])
+def test_each_header_is_self_contained(tmp_path, extra):
+    for h in ("types.hpp", "poseGraph.hpp", "visualSLAM.hpp", "stereoCV.hpp", "bundleAdjust.hpp"):
         tu = tmp_path / f"tu_{h}.cpp"
         tu.write_text(f'#include "svo_compat/{h}"\nint main() {{ return 0; }}\n')
-        subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", f"-I{ROOT / 'include'}", str(tu)],
+        subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", *extra, f"-I{ROOT / 'include'}", str(tu)],
+                       check=True, capture_output=True, text=True)
+
+
+def test_adaptors_keep_the_reference_signatures(tmp_path):
+    """include/visualSLAM.h:152-178, include/poseGraph.h:62-66 and src/bundleAdjust.cpp:551: the member
+    functions must be callable with exactly the reference's argument types (cv::Mat& for the double
+    matrices) -- taking the address of each overload with that signature must compile."""
+    tu = tmp_path / "sig.cpp"
+    tu.write_text('''
+#include "svo_compat/bundleAdjust.hpp"
+#include "svo_compat/visualSLAM.hpp"
+using namespace svo_compat;
+using std::vector;
+int main() {
+    vector<KeyPoint> (visualSLAM::*a)(const Mat&, int) = &visualSLAM::denseKeypointExtractor;
+    void (visualSLAM::*b)(const Mat&, const Mat&, vector<Point2f>&, vector<Point2f>&) = &visualSLAM::denseLKtracking;
+    void (visualSLAM::*c)(vector<Point2f>&, vector<Point2f>&) = &visualSLAM::FmatThresholding;
+    void (visualSLAM::*d)(const Mat&, const Mat&, vector<Point3f>&, vector<Point2f>&) = &visualSLAM::stereoTriangulate;
+    void (visualSLAM::*e)(const Mat&, const Mat&, vector<Point2f>, vector<Point3f>, vector<Point2f>&, vector<Point3f>&) =
+        &visualSLAM::PyrLKtrackFrame2Frame;
+    void (visualSLAM::*f)(int, Mat, Mat, Mat&, vector<Point2f>&, vector<Point3f>&) = &visualSLAM::insertKeyFrames;
+    vector<Point3f> (visualSLAM::*g)(vector<Point3f>&, Mat&) = &visualSLAM::update3dtransformation;
+    void (visualSLAM::*h)(Mat&, Mat&, vector<Point2f>&, vector<Point3f>&, vector<Point2f>&, vector<Point3f>&, Mat&, Mat&,
+                          vector<int>&) = &visualSLAM::PerspectiveNpointEstimation;
+    void (visualSLAM::*i)(Mat, Mat, Mat, Mat, bool) = &visualSLAM::stageForPGO;
+    void (visualSLAM::*j)(vector<Isometry3d>&) = &visualSLAM::updateOdometry;
+    void (visualSLAM::*k)(const Mat&, int) = &visualSLAM::checkLoopDetectorStatus;
+    void (visualSLAM::*l)(vector<Point3f>&, vector<Point3f>&) = &visualSLAM::SORcloud;
+    void (globalPoseGraph::*m)() = &globalPoseGraph::initializeGraph;
+    void (globalPoseGraph::*n)(const Isometry3d&, const Isometry3d&) = &globalPoseGraph::augmentNode;
+    void (globalPoseGraph::*o)(const Isometry3d&, int) = &globalPoseGraph::addLoopClosure;
+    vector<Isometry3d> (globalPoseGraph::*p)() = &globalPoseGraph::globalOptimize;
+    void (globalPoseGraph::*q)() = &globalPoseGraph::saveStructure;
+    void (visualOdometry::*r)(vector<Point2f>, vector<Point3f>, Mat&, Mat&, Mat&) = &visualOdometry::BundleAdjust3d2d;
+    (void)a; (void)b; (void)c; (void)d; (void)e; (void)f; (void)g; (void)h; (void)i; (void)j; (void)k; (void)l;
+    (void)m; (void)n; (void)o; (void)p; (void)q; (void)r;
+    return 0;
+}
+''')
+    for extra in ((), REAL_TYPES):
+        subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", *extra, f"-I{ROOT / 'include'}", str(tu)],
                        check=True, capture_output=True, text=True)
 
 
@@ -39,8 +91,11 @@ def test_c_header_is_plain_c(tmp_path):
 
 
 @pytest.mark.gpu
-def test_compat_smoke_runs_on_gpu():
-    _build()
-    out = subprocess.run([str(EXE)], capture_output=True, text=True, timeout=300)
+@pytest.mark.parametrize("which", ["pod", "opencv_eigen"])
+def test_compat_smoke_runs_on_gpu(which):
+    exe = EXE if which == "pod" else EXE_CV
+    _build(exe, () if which == "pod" else REAL_TYPES)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "compat smoke ok" in out.stdout
+    print(out.stdout.strip())

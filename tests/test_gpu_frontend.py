@@ -20,6 +20,52 @@ def _rot_angle(Ra, Rb):
     return float(np.arccos(np.clip(c, -1, 1)))
 
 
+def _loop_frames(n):
+    """The benchmark's stream (synth.BENCH_LOOP), rendered on the GPU: host copies for the oracle."""
+    import torch
+
+    poses = synth.loop_trajectory(n, **synth.BENCH_LOOP)
+    lefts, rights = synth.stereo_torch(synth.bench_scene(), poses, device="cuda", batch=8)
+    torch.cuda.synchronize()
+    R0, t0 = poses[0]
+    rel = [(R0.T @ R, R0.T @ (t - t0)) for R, t in poses]
+    return rel, [(l.cpu().numpy(), r.cpu().numpy()) for l, r in zip(lefts, rights)]
+
+
+@pytest.mark.parametrize("grid_step,anms_keep,kf_min,nframes", [(10, 4096, 2000, 41), (7, 8192, 4000, 21)])
+def test_frontend_matches_oracle_on_the_benchmark_stream(ctx, orc, grid_step, anms_keep, kf_min, nframes):
+    """The benchmarked shapes -- 4096 keypoints (the metric) over 40 frames, 8192 (configs[4]) over 20 --
+    frame by frame against the oracle's frame loop: tracked counts equal, inliers within the threshold
+    flips, keyframe decisions equal, poses within 1e-3 m / 1e-4 rad, reference sets alike."""
+    poses, frames = _loop_frames(nframes)
+    orc.set_num_threads(16)
+    g = capi.VisualOdometry(ctx, 1241, 376, 3, grid_step=grid_step, anms_keep=anms_keep,
+                            keyframe_min_inliers=kf_min, seed=20261003)
+    o = orc.VO(1241, 376, 3, grid_step=grid_step, anms_keep=anms_keep, keyframe_min_inliers=kf_min, seed=20261003)
+    assert g.init(*frames[0]) == o.init(*frames[0])
+    n_kf = 0
+    worst_t = worst_r = 0.0
+    for i in range(1, nframes):
+        rg, Rg, tg, ig, kg, ng = g.track(*frames[i])
+        ro, Ro, to, io, ko, no = o.track(*frames[i])
+        assert rg == 0 and ro == 0
+        assert ng == no, f"frame {i}: tracked {ng} vs {no}"
+        assert abs(ig - io) <= 3, f"frame {i}: inliers {ig} vs {io}"
+        assert kg == ko, f"frame {i}: keyframe decision {kg} vs {ko} at {ig} / {io} inliers"
+        n_kf += kg
+        worst_t, worst_r = max(worst_t, np.linalg.norm(tg - to)), max(worst_r, _rot_angle(Rg, Ro))
+        assert np.linalg.norm(tg - to) < 1e-3 and _rot_angle(Rg, Ro) < 1e-4, f"frame {i}"
+        assert np.linalg.norm(tg - poses[i][1]) < 0.02 * i + 0.05     # both follow the generator's truth
+    a2, a3 = g.reference()
+    b2, b3 = o.ref()
+    assert a2.shape == b2.shape and np.allclose(a2, b2, atol=1e-4) and np.allclose(a3, b3, rtol=1e-4, atol=1e-3)
+    assert 0 < n_kf < nframes - 1                                     # both branches of the keyframe rule ran
+    print(f"\n{anms_keep} keypoints, {nframes - 1} frames, {n_kf} keyframes: worst pose delta vs oracle "
+          f"{worst_t:.2e} m / {worst_r:.2e} rad")
+    g.close()
+    o.close()
+
+
 @pytest.mark.parametrize("grid_step,anms_keep,kf_min", [(30, 0, 200), (10, 4096, 2000)])
 def test_frontend_matches_oracle(ctx, orc, grid_step, anms_keep, kf_min):
     nframes = 7 if grid_step == 30 else 4

@@ -70,12 +70,17 @@ def test_fransac_degenerate(ctx):
     assert cnt == 0
 
 
-def test_fransac_full_size(ctx, orc):
-    """BASELINE size: 4096 correspondences."""
-    x1, x2, gt, *_ = two_view(n=4096, n_out=500, seed=8, noise=0.2)
-    gc, gmask, gF, git = ctx.fransac(x1, x2, 1.0, seed=2)
-    oc, omask, oF, oit = orc.fransac(x1, x2, 1.0, seed=2)
+@pytest.mark.parametrize("n,n_out,thr", [(4096, 500, 1.0), (8192, 1000, 1.0), (9152, 2500, 3.0)])
+def test_fransac_full_size(ctx, orc, n, n_out, thr):
+    """BASELINE sizes: 4096 correspondences (the metric), 8192 (configs[4]) and the 9152-point lattice
+    of grid step 7 as the stereo filter sees it."""
+    x1, x2, gt, *_ = two_view(n=n, n_out=n_out, seed=8 + n, noise=0.2)
+    gc, gmask, gF, git = ctx.fransac(x1, x2, thr, seed=2)
+    oc, omask, oF, oit = orc.fransac(x1, x2, thr, seed=2)
     assert git == oit and (gmask != omask).sum() <= 3
+    s = np.sign(np.sum(gF * oF))
+    assert np.abs(gF * s - oF).max() < 1e-7
+    assert (gmask.astype(bool) & gt).sum() >= 0.85 * gt.sum()
 
 
 def test_triangulate_matches_oracle(ctx, orc):

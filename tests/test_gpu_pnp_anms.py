@@ -48,12 +48,15 @@ def test_pnp_hypotheses_agree_with_oracle(ctx, orc):
             assert np.abs(grv - orv).max() < 1e-7 and np.abs(gtv - otv).max() < 1e-6
 
 
-def test_pnp_full_size_and_degenerate(ctx, orc):
-    X, x, gt = _noisy(4096, 800, 5)
+@pytest.mark.parametrize("n,n_out", [(4096, 800), (8192, 1600)])
+def test_pnp_full_size_and_degenerate(ctx, orc, n, n_out):
+    """BASELINE sizes: 4096 keypoints (the metric) and 8192 (configs[4])."""
+    X, x, gt = _noisy(n, n_out, 5)
     gc, grv, gtv, ginl, git = ctx.pnp_ransac(X, x, K4, seed=3)
     oc, orv, otv, oinl, oit = orc.pnp_ransac(X, x, K4, seed=3)
     assert git == oit and len(np.setxor1d(ginl, oinl)) <= 3
-    assert np.abs(gtv - otv).max() < 1e-5
+    assert np.abs(grv - orv).max() < 1e-6 and np.abs(gtv - otv).max() < 1e-5
+    assert len(np.setdiff1d(ginl, gt)) == 0
     cnt, *_ = ctx.pnp_ransac(X[:4], x[:4], K4)
     assert cnt == 0
     cnt, *_ = ctx.pnp_ransac(np.zeros((0, 3)), np.zeros((0, 2)), K4)
