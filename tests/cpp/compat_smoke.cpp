@@ -32,9 +32,11 @@ static Mat make_view(int w, int h, double fx, double ppx, double ppy, double z0,
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++) {
             const double X = (x - ppx) / fx * z + cam_x, Y = (y - ppy) / fx * z;  // wall coordinates (m)
-            const double u = X * 9.1, v = Y * 10.7;
-            double g = 128 + 55 * std::sin(u) * std::cos(v) + 38 * std::sin(0.37 * u + 1.3 * v) + 22 * std::cos(2.1 * u - 0.7 * v) +
-                       12 * std::sin(5.3 * u + 0.4) * std::sin(4.1 * v);
+            // incommensurate waves from 200 px down to 7 px: nothing a 16 px disparity could alias onto
+            double g = 128 + 34 * std::sin(0.94 * X + 0.3 * Y + 0.5) + 30 * std::cos(0.41 * X - 1.9 * Y) +
+                       26 * std::sin(2.27 * X + 1.1 * Y) * std::cos(1.3 * Y - 0.7 * X) + 22 * std::sin(5.1 * X - 2.3 * Y + 1.0) +
+                       16 * std::cos(3.7 * X + 6.1 * Y) + 12 * std::sin(11.1 * X + 4.0 * Y) + 9 * std::cos(9.0 * Y - 13.0 * X) +
+                       6 * std::sin(27.0 * X) * std::sin(23.0 * Y);
             const uint8_t b = (uint8_t)(g < 0 ? 0 : (g > 255 ? 255 : g));
             for (int c = 0; c < 3; c++)
                 m.data[((size_t)y * w + x) * 3 + c] = b;
@@ -238,6 +240,7 @@ int main()
     configure(f, 7);
     f.loopMinGap = 3;  // upstream: 100 (src/optimizationStuff.cpp:58); lowered so that 8 frames reach the branch
     f.loopCooldown = 2;
+    f.keyframeMinInliers = 100000;  // every frame re-triangulates: several records with retrack for updateOdometry
     f.poseGraph.writeResultFile = false;
     Mat33d Rm;
     Vec3d t;
