@@ -220,6 +220,28 @@ int svo_pnp_ransac(svo_ctx *ctx, const float *obj, const float *img, int n, cons
                    int iterations, double reproj_err, double confidence, uint64_t seed, double *rvec,
                    double *tvec, int *inliers, int *n_inliers, int *iters_run, int mem);
 
+/* ---- plain PnP: cv::solvePnP(obj, img, K, dist = 0, rvec, tvec) -------------------------------- */
+/* SOLVEPNP_ITERATIVE without an extrinsic guess, the last rung of the older VO ladder
+ * (src/bundleAdjust.cpp:470-477: "skipping RANSAC all together"): DLT over ALL n >= 6 points
+ * (upstream's non-planar branch), then Levenberg-Marquardt on the reprojection error.  rvec / tvec /
+ * rms (optional: root mean square reprojection error) are HOST outputs; obj / img follow `mem`.
+ * SVO_ERR_STATE when the object points are planar (W[2] / W[1] < 1e-3 upstream; its homography
+ * branch is not built) or degenerate.  The call synchronises.                                      */
+int svo_solve_pnp(svo_ctx *ctx, const float *obj, const float *img, int n, const double *K4, double *rvec,
+                  double *tvec, double *rms, int mem);
+
+/* The pose ladder of the older visualOdometry::initSequence, src/bundleAdjust.cpp:462-480, on explicit
+ * point sets: (obj_f, img_f, n_f) = the tracked set after the F-matrix filter, (obj_s, img_s, n_s) = the
+ * status-filtered set that "retracking" without the filter yields.  rung (out): 0 = solvePnPRansac
+ * (100, 4.0, 0.99) on the filtered set decided; 1 = fewer than 20 inliers or tvec.x > 1000, the same on
+ * the status-filtered set; 2 = fewer than 10 (or tvec.x > 1000 again): plain solvePnP on the set last
+ * used.  n_inliers: the last RANSAC's count.  Stage seeds seed + 1 / seed + 2.  SVO_ERR_TRACKING_LOST
+ * when solvePnP has no solution (upstream: an uncaught cv::Exception).  svo_vo with
+ * policy = SVO_POLICY_VO_LADDER runs this per frame.                                               */
+int svo_pnp_ladder(svo_ctx *ctx, const float *obj_f, const float *img_f, int n_f, const float *obj_s,
+                   const float *img_s, int n_s, const double *K4, uint64_t seed, double *rvec, double *tvec,
+                   int *n_inliers, int *rung, int mem);
+
 /* ---- motion BA: visualOdometry::BundleAdjust3d2d(points_2d, points_3d, K, R, t) ---------------- */
 /* src/bundleAdjust.cpp:551-613 (unbuilt upstream, kept for completeness of the path the north-star
  * names): g2o Levenberg (BlockSolver<6,3>, dense pose solver) over ONE VertexSE3Expmap (R9 / t3:
@@ -245,7 +267,15 @@ typedef struct svo_vo_params {
     double f_thr_stereo;      /* src/tracking.cpp:34, 3.0 px                                   */
     double f_thr_temporal;    /* src/tracking.cpp:75, 1.0 px                                   */
     uint64_t seed;            /* RANSAC sampling seed; stage seeds are seed + 8*frame + stage  */
+    int policy;               /* SVO_POLICY_SLAM (0, default): visualSLAM::initSequence,
+                               * src/VisualSLAM.cpp:54-169.  SVO_POLICY_VO_LADDER (1): the older
+                               * visualOdometry::initSequence, src/bundleAdjust.cpp:427-548 -- PnP-RANSAC
+                               * at 4 px; < 20 inliers or tvec.x > 1000: again on the status-filtered
+                               * set without the F-matrix filter; < 10: plain solvePnP; a stereo
+                               * keyframe on EVERY frame; never shuts down.  Frame-by-frame entry
+                               * points only (svo_vo_localize / update / track).                    */
 } svo_vo_params;
+enum { SVO_POLICY_SLAM = 0, SVO_POLICY_VO_LADDER = 1 };
 void svo_vo_default_params(svo_vo_params *p);
 
 int svo_vo_create(svo_ctx *ctx, const svo_vo_params *params, int width, int height, int channels,

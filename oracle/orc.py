@@ -348,6 +348,28 @@ def lc_nearest2(A, B):
 
 # ---- front-end frame loop -----------------------------------------------------------------
 
+def solve_pnp(obj, img, K4):
+    """cv::solvePnP (ITERATIVE, no guess) -> (rc, rvec, tvec, rms)."""
+    obj = np.ascontiguousarray(obj, np.float32).reshape(-1, 3)
+    img = np.ascontiguousarray(img, np.float32).reshape(-1, 2)
+    rvec, tvec, rms = np.zeros(3), np.zeros(3), C.c_double()
+    rc = load().orc_solve_pnp(_p(obj), _p(img), obj.shape[0], _p(np.ascontiguousarray(K4, np.float64)), _p(rvec),
+                              _p(tvec), C.byref(rms))
+    return rc, rvec, tvec, rms.value
+
+
+def pnp_ladder(obj_f, img_f, obj_s, img_s, K4, seed=0):
+    """The older ladder's pose stage (src/bundleAdjust.cpp:462-480) -> (rc, rvec, tvec, n_inliers, rung)."""
+    of = np.ascontiguousarray(obj_f, np.float32).reshape(-1, 3)
+    uf = np.ascontiguousarray(img_f, np.float32).reshape(-1, 2)
+    os_ = np.ascontiguousarray(obj_s, np.float32).reshape(-1, 3)
+    us = np.ascontiguousarray(img_s, np.float32).reshape(-1, 2)
+    rvec, tvec, ninl, rung = np.zeros(3), np.zeros(3), C.c_int(), C.c_int()
+    rc = load().orc_pnp_ladder(_p(of), _p(uf), len(of), _p(os_), _p(us), len(os_), _p(np.ascontiguousarray(K4, np.float64)),
+                               C.c_uint64(seed), _p(rvec), _p(tvec), C.byref(ninl), C.byref(rung))
+    return rc, rvec, tvec, ninl.value, rung.value
+
+
 def ba_3d2d(pts2d, pts3d, K4, R, t, iterations=10):
     """BundleAdjust3d2d (src/bundleAdjust.cpp:551-613) -> (t, R, points, info)."""
     p2 = np.ascontiguousarray(pts2d, np.float32).reshape(-1, 2)
@@ -368,19 +390,20 @@ class VoParams(C.Structure):
     _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
                 ("baseline", C.c_double), ("grid_step", C.c_int), ("anms_keep", C.c_int),
                 ("keyframe_min_inliers", C.c_int), ("f_thr_stereo", C.c_double),
-                ("f_thr_temporal", C.c_double), ("seed", C.c_uint64)]
+                ("f_thr_temporal", C.c_double), ("seed", C.c_uint64), ("policy", C.c_int)]
 
 
 class VO:
     """Oracle front-end (src/VisualSLAM.cpp:11-169)."""
 
     def __init__(self, w, h, c, grid_step=30, anms_keep=0, keyframe_min_inliers=200, seed=0, K4=None,
-                 baseline=None):
+                 baseline=None, policy=0):
         lib = load()
         self.prm = VoParams()
         lib.orc_vo_default_params(C.byref(self.prm))
         self.prm.grid_step, self.prm.anms_keep = grid_step, anms_keep
         self.prm.keyframe_min_inliers, self.prm.seed = keyframe_min_inliers, seed
+        self.prm.policy = policy
         if K4 is not None:
             self.prm.fx, self.prm.fy, self.prm.cx, self.prm.cy = K4
         if baseline is not None:

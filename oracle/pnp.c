@@ -735,3 +735,106 @@ int orc_pnp_ransac(const float *obj, const float *img, int n, const double *K4, 
     memcpy(tvec, bestT, sizeof(bestT));
     return k;
 }
+
+/* ---- cv::solvePnP(obj, img, K, dist = 0, rvec, tvec): SOLVEPNP_ITERATIVE, no extrinsic guess ------
+ * The last rung of the reference's older ladder, src/bundleAdjust.cpp:470-477.  Upstream
+ * (cvFindExtrinsicCameraParams2): planarity test on the eigenvalues of the centred second moments of
+ * the object points (W[2] / W[1] < 1e-3 -> homography branch, NOT built here: returns -2); otherwise
+ * DLT: L rows [X Y Z 1 0 0 0 0 xX xY xZ x], [0 0 0 0 X Y Z 1 yX yY yZ y] with (x, y) = -(normalised
+ * image point); the eigenvector of the smallest eigenvalue of L^T L is [RR | tt] (3x4); sign from
+ * det(RR); R = U V^T of RR's SVD; t = tt * |R| / |RR|; then Levenberg-Marquardt over all points
+ * (here: orc_pnp_refine_Rt, the same minimiser).  Returns 0, -1 bad arguments / n < 6, -2 planar,
+ * -3 degenerate.                                                                                   */
+int orc_solve_pnp(const float *obj, const float *img, int n, const double *K4, double *rvec, double *tvec,
+                  double *rms_out)
+{
+    if (!obj || !img || !K4 || !rvec || !tvec || n < 6)
+        return -1;
+    double S[4][10];
+    memset(S, 0, sizeof(S));
+    const double ifx = 1. / K4[0], ify = 1. / K4[1];
+    for (int i = 0; i < n; i++) {
+        const double P[4] = {obj[3 * i], obj[3 * i + 1], obj[3 * i + 2], 1.};
+        const double x = -(((double)img[2 * i] - K4[2]) * ifx), y = -(((double)img[2 * i + 1] - K4[3]) * ify);
+        const double w3 = x * x + y * y;
+        int k = 0;
+        for (int r = 0; r < 4; r++)
+            for (int c = r; c < 4; c++) {
+                const double pp = P[r] * P[c];
+                S[0][k] += pp;
+                S[1][k] += x * pp;
+                S[2][k] += y * pp;
+                S[3][k] += w3 * pp;
+                k++;
+            }
+    }
+    {
+        const double inv_n = 1. / n, mx = S[0][3] * inv_n, my = S[0][6] * inv_n, mz = S[0][8] * inv_n;
+        double C[9] = {S[0][0] - n * mx * mx, S[0][1] - n * mx * my, S[0][2] - n * mx * mz,
+                       S[0][1] - n * mx * my, S[0][4] - n * my * my, S[0][5] - n * my * mz,
+                       S[0][2] - n * mx * mz, S[0][5] - n * my * mz, S[0][7] - n * mz * mz};
+        double U[9], V[9], w[3];
+        svd3(C, U, V);
+        for (int c = 0; c < 3; c++) {
+            double q = 0;
+            for (int r = 0; r < 3; r++) {
+                const double e = C[3 * r] * V[c] + C[3 * r + 1] * V[3 + c] + C[3 * r + 2] * V[6 + c];
+                q += e * e;
+            }
+            w[c] = sqrt(q);
+        }
+        if (!(w[1] > 0) || w[2] / w[1] < 1e-3)
+            return -2;
+    }
+    double A[144], V[144], w[12];
+    for (int e = 0; e < 144; e++) {
+        const int r = e / 12, c = e % 12, br = r >> 2, bc = c >> 2, i = r & 3, j = c & 3;
+        const int lo = i < j ? i : j, hi = i < j ? j : i, k = lo * 4 - lo * (lo - 1) / 2 + (hi - lo);
+        int blk = -1;
+        if (br == bc)
+            blk = br == 2 ? 3 : 0;
+        else if (br + bc == 2)
+            blk = 1;
+        else if (br + bc == 3)
+            blk = 2;
+        A[e] = blk < 0 ? 0. : S[blk][k];
+    }
+    orc_jacobi_eigen_sym(12, A, V, w, 10);
+    int best = 0;
+    for (int e = 1; e < 12; e++)
+        if (w[e] < w[best])
+            best = e;
+    double RR[9], tt[3];
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++)
+            RR[3 * r + c] = V[12 * (4 * r + c) + best];
+        tt[r] = V[12 * (4 * r + 3) + best];
+    }
+    const double det = RR[0] * (RR[4] * RR[8] - RR[5] * RR[7]) - RR[1] * (RR[3] * RR[8] - RR[5] * RR[6]) +
+                       RR[2] * (RR[3] * RR[7] - RR[4] * RR[6]);
+    if (det < 0) {
+        for (int i = 0; i < 9; i++)
+            RR[i] = -RR[i];
+        for (int i = 0; i < 3; i++)
+            tt[i] = -tt[i];
+    }
+    double sc = 0;
+    for (int i = 0; i < 9; i++)
+        sc += RR[i] * RR[i];
+    sc = sqrt(sc);
+    if (!(sc > DBL_EPSILON))
+        return -3;
+    double U[9], Vs[9], R[9], t[3];
+    svd3(RR, U, Vs);
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            R[3 * i + j] = U[3 * i] * Vs[3 * j] + U[3 * i + 1] * Vs[3 * j + 1] + U[3 * i + 2] * Vs[3 * j + 2];
+    for (int i = 0; i < 3; i++)
+        t[i] = tt[i] * (sqrt(3.) / sc);
+    const double rms = orc_pnp_refine_Rt(obj, img, 0, n, K4, R, t, 20);
+    orc_rodrigues_inv(R, rvec);
+    memcpy(tvec, t, sizeof(t));
+    if (rms_out)
+        *rms_out = rms;
+    return 0;
+}

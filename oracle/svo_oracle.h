@@ -181,6 +181,7 @@ typedef struct {
     int keyframe_min_inliers; /* 200 (VisualSLAM.cpp:120)                                 */
     double f_thr_stereo, f_thr_temporal; /* 3.0, 1.0                                      */
     uint64_t seed;
+    int policy;             /* 0: visualSLAM::initSequence; 1: the older ladder (bundleAdjust.cpp:427-548) */
 } orc_vo_params;
 void orc_vo_default_params(orc_vo_params *p);
 
@@ -230,6 +231,16 @@ int orc_hamming256(const uint32_t *a, const uint32_t *b);
 void orc_lc_scores(const uint32_t *q, int nq, const uint32_t *db, const int *db_n, int stride, int n_entries,
                    int hamming_thr, int *counts);
 void orc_lc_nearest2(const uint32_t *A, int na, const uint32_t *B, int nb, int *best_j, int *d1, int *d2);
+
+/* cv::solvePnP (SOLVEPNP_ITERATIVE, no guess): DLT over all n >= 6 points + LM; the last rung of the
+ * older VO ladder, src/bundleAdjust.cpp:470-477.  0 ok, -1 bad arguments, -2 planar points (upstream's
+ * homography branch is not built), -3 degenerate.                                                   */
+int orc_solve_pnp(const float *obj, const float *img, int n, const double *K4, double *rvec, double *tvec,
+                  double *rms_out);
+
+/* the pose ladder of the older visualOdometry::initSequence, src/bundleAdjust.cpp:462-480 (see vo.c) */
+int orc_pnp_ladder(const float *obj_f, const float *img_f, int n_f, const float *obj_s, const float *img_s, int n_s,
+                   const double *K4, uint64_t seed, double *rvec, double *tvec, int *n_inliers, int *rung);
 
 /* ---- motion BA: visualOdometry::BundleAdjust3d2d, src/bundleAdjust.cpp:551-613 --------------- */
 /* g2o Levenberg over one VertexSE3Expmap (world -> camera R9 / t3) and n free, marginalised points

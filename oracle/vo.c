@@ -37,6 +37,7 @@ void orc_vo_default_params(orc_vo_params *p)
     p->f_thr_stereo = 3.0;
     p->f_thr_temporal = 1.0;
     p->seed = 0;
+    p->policy = 0;
 }
 
 struct orc_vo {
@@ -170,6 +171,45 @@ int orc_vo_init(orc_vo *v, const uint8_t *left, const uint8_t *right)
     return v->nref;
 }
 
+/* The pose ladder of the older visualOdometry::initSequence, src/bundleAdjust.cpp:462-480:
+ * solvePnPRansac(100, 4.0, 0.99) on the F-filtered set; < 20 inliers or tvec.x > 1000: "skipping RANSAC
+ * layer and retracking" = the same on the status-filtered set (PyrLKtrackFrame2Frame(..., false)); < 10 or
+ * tvec.x > 1000: plain solvePnP; and plain solvePnP once more when the last RANSAC kept < 10 (:475-477).
+ * rung: 0 / 1 / 2 = which of them decided; n_inliers: the last RANSAC's count.  Stage seeds seed + 1 / + 2.
+ * Returns 0, -1 when solvePnP has no solution. */
+int orc_pnp_ladder(const float *obj_f, const float *img_f, int n_f, const float *obj_s, const float *img_s, int n_s,
+                   const double *K4, uint64_t seed, double *rvec, double *tvec, int *n_inliers, int *rung)
+{
+    const float *o3 = obj_f, *o2 = img_f;
+    int cnt = n_f, plain = 0, r = 0;
+    int *idx = (int *)malloc(sizeof(int) * (size_t)((n_f > n_s ? n_f : n_s) + 1));
+    orc_pnp_params p4 = {100, 4.0, 0.99, seed + 1, 20};
+    int ninl = orc_pnp_ransac(o3, o2, cnt, K4, &p4, rvec, tvec, idx, 0);
+    if (ninl < 20 || tvec[0] > 1000) {
+        r = 1;
+        o3 = obj_s;
+        o2 = img_s;
+        cnt = n_s;
+        orc_pnp_params p4b = {100, 4.0, 0.99, seed + 2, 20};
+        ninl = orc_pnp_ransac(o3, o2, cnt, K4, &p4b, rvec, tvec, idx, 0);
+        if (ninl < 10 || tvec[0] > 1000)
+            plain = 1;
+    }
+    free(idx);
+    if (ninl < 10)
+        plain = 1;
+    if (n_inliers)
+        *n_inliers = ninl;
+    int rc = 0;
+    if (plain) {
+        r = 2;
+        rc = orc_solve_pnp(o3, o2, cnt, K4, rvec, tvec, 0) != 0 ? -1 : 0;
+    }
+    if (rung)
+        *rung = r;
+    return rc;
+}
+
 /* PerspectiveNpointEstimation + pose composition (VisualSLAM.cpp:64-74).  Leaves the tracked
  * set in v->trk2d/trk3d.  Returns 0 ok, -1 tracking lost (SHUTDOWN_FLAG). */
 int orc_vo_localize(orc_vo *v, const uint8_t *left, double *R, double *t, int *n_inliers, int *n_tracked)
@@ -205,6 +245,24 @@ int orc_vo_localize(orc_vo *v, const uint8_t *left, double *R, double *t, int *n
         *n_tracked = k;
     const double K4[4] = {v->prm.fx, v->prm.fy, v->prm.cx, v->prm.cy};
     double rvec[3] = {0, 0, 0}, tvec[3] = {0, 0, 0};
+    if (v->prm.policy == 1) { /* visualOdometry::initSequence, src/bundleAdjust.cpp:452-480 */
+        int rung = 0, ninl = 0;
+        const int rc = orc_pnp_ladder(v->trk3d, v->trk2d, k, r3, t2, m, K4, v->prm.seed + 8ull * (uint64_t)v->frame,
+                                      rvec, tvec, &ninl, &rung);
+        if (rung >= 1) { /* the set the pose was computed from is the tracked set */
+            memcpy(v->trk2d, t2, (size_t)m * 8);
+            memcpy(v->trk3d, r3, (size_t)m * 12);
+            v->ntrk = m;
+            if (n_tracked)
+                *n_tracked = m;
+        }
+        if (n_inliers)
+            *n_inliers = ninl;
+        if (rc)
+            return -1; /* upstream: cv::Exception out of solvePnP */
+        orc_compose_camera_pose(rvec, tvec, R, t);
+        return 0;
+    }
     orc_pnp_params pp = {100, 1.0, 0.99, stage_seed(v, 1), 20};
     int ninl = orc_pnp_ransac(v->trk3d, v->trk2d, k, K4, &pp, rvec, tvec, v->idx, 0);
     if (ninl < 10) { /* src/keyFrameManagement.cpp:85-92 */
@@ -229,7 +287,8 @@ int orc_vo_update(orc_vo *v, const uint8_t *left, const uint8_t *right, const do
 {
     memcpy(v->R, R, sizeof(v->R));
     memcpy(v->t, t, sizeof(v->t));
-    int kf = n_inliers < v->prm.keyframe_min_inliers || force_keyframe;
+    /* policy 1: relocalizeFrames on EVERY frame, src/bundleAdjust.cpp:517-519 */
+    int kf = n_inliers < v->prm.keyframe_min_inliers || force_keyframe || v->prm.policy == 1;
     if (kf) {
         if (!right)
             return -2;

@@ -315,6 +315,33 @@ def pnp_ransac(self, obj, img, K4, iterations=100, reproj_err=1.0, confidence=0.
 
 
 @_ctx_method
+def pnp_ladder(self, obj_f, img_f, obj_s, img_s, K4, seed=0):
+    """The older ladder's pose stage (``svo_pnp_ladder``) -> (rc, rvec, tvec, n_inliers, rung)."""
+    of = np.ascontiguousarray(obj_f, np.float32).reshape(-1, 3)
+    uf = np.ascontiguousarray(img_f, np.float32).reshape(-1, 2)
+    os_ = np.ascontiguousarray(obj_s, np.float32).reshape(-1, 3)
+    us = np.ascontiguousarray(img_s, np.float32).reshape(-1, 2)
+    rvec, tvec, ninl, rung = np.zeros(3), np.zeros(3), C.c_int(), C.c_int()
+    rc = self.lib.svo_pnp_ladder(self._h, _ptr(of), _ptr(uf), len(of), _ptr(os_), _ptr(us), len(os_),
+                                 _ptr(np.ascontiguousarray(K4, np.float64)), C.c_uint64(seed), _ptr(rvec), _ptr(tvec),
+                                 C.byref(ninl), C.byref(rung), MEM_HOST)
+    if rc not in (SVO_OK, SVO_ERR_TRACKING_LOST):
+        _check(rc)
+    return rc, rvec, tvec, ninl.value, rung.value
+
+
+@_ctx_method
+def solve_pnp(self, obj, img, K4):
+    """cv::solvePnP (ITERATIVE, no guess; src/bundleAdjust.cpp:470-477) -> (rvec, tvec, rms)."""
+    obj = np.ascontiguousarray(obj, np.float32).reshape(-1, 3)
+    img = np.ascontiguousarray(img, np.float32).reshape(-1, 2)
+    rvec, tvec, rms = np.zeros(3), np.zeros(3), C.c_double()
+    _check(self.lib.svo_solve_pnp(self._h, _ptr(obj), _ptr(img), obj.shape[0], _ptr(np.ascontiguousarray(K4, np.float64)),
+                                  _ptr(rvec), _ptr(tvec), C.byref(rms), MEM_HOST))
+    return rvec, tvec, rms.value
+
+
+@_ctx_method
 def ba_3d2d(self, pts2d, pts3d, K4, R, t, iterations=10):
     """visualOdometry::BundleAdjust3d2d (src/bundleAdjust.cpp:551-613) -> (t, R, points, info)."""
     p2 = np.ascontiguousarray(pts2d, np.float32).reshape(-1, 2)
@@ -333,7 +360,7 @@ class VoParams(C.Structure):
     _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
                 ("baseline", C.c_double), ("grid_step", C.c_int), ("anms_keep", C.c_int),
                 ("keyframe_min_inliers", C.c_int), ("f_thr_stereo", C.c_double),
-                ("f_thr_temporal", C.c_double), ("seed", C.c_uint64)]
+                ("f_thr_temporal", C.c_double), ("seed", C.c_uint64), ("policy", C.c_int)]
 
 
 class VisualOdometry:
@@ -341,12 +368,13 @@ class VisualOdometry:
     (src/VisualSLAM.cpp:11-169).  Images: numpy (H, W, C) uint8 or device tensors."""
 
     def __init__(self, ctx: Context, w, h, c, grid_step=30, anms_keep=0, keyframe_min_inliers=200, seed=0,
-                 K4=None, baseline=None):
+                 K4=None, baseline=None, policy=0):
         self.ctx = ctx
         self.prm = VoParams()
         ctx.lib.svo_vo_default_params(C.byref(self.prm))
         self.prm.grid_step, self.prm.anms_keep = grid_step, anms_keep
         self.prm.keyframe_min_inliers, self.prm.seed = keyframe_min_inliers, seed
+        self.prm.policy = policy
         if K4 is not None:
             self.prm.fx, self.prm.fy, self.prm.cx, self.prm.cy = K4
         if baseline is not None:

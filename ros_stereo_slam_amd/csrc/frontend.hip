@@ -60,6 +60,7 @@ struct svo_vo {
     uint8_t *d_img = nullptr;  // staging for host images
     int nref = 0, ntrk = 0, frame = 0;
     int kf_n = 0;  // points of the last keyframe's camera-frame cloud in b3
+    int ladder_ransac_inliers = 0;
     double R[9], t[3];
     bool has_cur = false;
 };
@@ -317,6 +318,54 @@ int stereo_triangulate_batch(int k, svo_vo *const *vs, svo_pyramid *const *lefts
     return SVO_OK;
 }
 
+// The pose ladder of the older visualOdometry::initSequence, src/bundleAdjust.cpp:462-480, on device point
+// sets: (obj_f, img_f, cnt_f) = the tracked set after the F-matrix filter, (obj_s, img_s, cnt_s) = the
+// status-filtered set ("retracking" without the filter gives exactly that: LK is deterministic).
+//   rung 0  solvePnPRansac(100, 4.0, 0.99) on the filtered set
+//   rung 1  < 20 inliers or tvec.x > 1000: the same on the status-filtered set
+//   rung 2  < 10 inliers (or tvec.x > 1000 after rung 1): plain solvePnP on the set last used
+// The record of the deciding solve is left in the context's pinned block (n_tracked = size of the set
+// used; n_inliers = 0 when solvePnP had no solution); *ransac_inliers = the last RANSAC's count.
+int ladder_pose(svo_ctx *ctx, const float *obj_f, const float *img_f, const int *cnt_f, const float *obj_s,
+                const float *img_s, const int *cnt_s, int cap, const double *K4, uint64_t seed1, uint64_t seed2,
+                int *idx_scratch, PnpRecord *d_rec, int *rung, int *ransac_inliers = nullptr)
+{
+    int rc;
+    const PnpRecord *rec = reinterpret_cast<const PnpRecord *>(ctx->pinned);
+    auto fetch = [&](const int *cnt) -> int {
+        hipLaunchKernelGGL(store_count_kernel, dim3(1), dim3(1), 0, ctx->stream, cnt, &d_rec->n_tracked);
+        SVO_HIP(hipMemcpyAsync(ctx->pinned, d_rec, sizeof(PnpRecord), hipMemcpyDeviceToHost, ctx->stream));
+        return svo_wait(ctx);
+    };
+    const float *o3 = obj_f, *o2 = img_f;
+    const int *cnt = cnt_f;
+    *rung = 0;
+    if ((rc = svo_launch_pnp_ransac(ctx, o3, o2, cap, cnt, K4, 100, 4.0, 0.99, seed1, 20, idx_scratch, nullptr, d_rec)) ||
+        (rc = fetch(cnt)))
+        return rc;
+    bool plain = false;
+    if (rec->n_inliers < 20 || rec->tvec[0] > 1000) {
+        *rung = 1;
+        o3 = obj_s;
+        o2 = img_s;
+        cnt = cnt_s;
+        if ((rc = svo_launch_pnp_ransac(ctx, o3, o2, cap, cnt, K4, 100, 4.0, 0.99, seed2, 20, idx_scratch, nullptr,
+                                        d_rec)) ||
+            (rc = fetch(cnt)))
+            return rc;
+        plain = rec->n_inliers < 10 || rec->tvec[0] > 1000;
+    }
+    const int ninl = rec->n_inliers;
+    if (ransac_inliers)
+        *ransac_inliers = ninl;
+    if (plain || ninl < 10) {  // "Skipping RANSAC all together": cv::solvePnP on everything that was tracked
+        *rung = 2;
+        if ((rc = svo_launch_solve_pnp(ctx, o3, o2, cap, cnt, K4, 20, idx_scratch, d_rec)) || (rc = fetch(cnt)))
+            return rc;
+    }
+    return SVO_OK;
+}
+
 int stereo_triangulate(svo_vo *v, const svo_pyramid *left, const svo_pyramid *right, const double *Rt,
                        float *out2d, float *out3d, int *n_out)
 {
@@ -343,6 +392,7 @@ void svo_vo_default_params(svo_vo_params *p)
     p->f_thr_stereo = 3.0;          // src/tracking.cpp:34
     p->f_thr_temporal = 1.0;        // src/tracking.cpp:75
     p->seed = 0;
+    p->policy = SVO_POLICY_SLAM;
 }
 
 int svo_vo_create(svo_ctx *ctx, const svo_vo_params *params, int width, int height, int channels, svo_vo **out)
@@ -350,6 +400,7 @@ int svo_vo_create(svo_ctx *ctx, const svo_vo_params *params, int width, int heig
     SVO_CHECK_ARG(ctx && params && out);
     SVO_CHECK_ARG(channels == 1 || channels == 3);
     SVO_CHECK_ARG(params->grid_step > 0 && params->keyframe_min_inliers >= 0);
+    SVO_CHECK_ARG(params->policy == SVO_POLICY_SLAM || params->policy == SVO_POLICY_VO_LADDER);
     *out = nullptr;
     SVO_HIP(hipSetDevice(ctx->device));
     svo_vo *v = new svo_vo();
@@ -486,9 +537,35 @@ int svo_vo_localize(svo_vo *v, const uint8_t *left, int mem, double *R9, double 
     if ((rc = svo_launch_compact(ctx, v->mask, n, v->d_cnt, v->c2, 2, v->trk2d, v->a3, 3, v->trk3d, nullptr, 0,
                                  nullptr, v->d_cnt + 1)))
         return rc;
-    // solvePnPRansac (src/keyFrameManagement.cpp:84), retry (:85-92)
     const double K4[4] = {v->prm.fx, v->prm.fy, v->prm.cx, v->prm.cy};
     const PnpRecord *rec = reinterpret_cast<const PnpRecord *>(ctx->pinned);
+    if (v->prm.policy == SVO_POLICY_VO_LADDER) {
+        // visualOdometry::initSequence, src/bundleAdjust.cpp:452-480 (see svo_vo_params.policy)
+        int rung = 0;
+        if ((rc = ladder_pose(ctx, v->trk3d, v->trk2d, v->d_cnt + 1, v->a3, v->c2, v->d_cnt, n, K4, stage_seed(v, 1),
+                              stage_seed(v, 2), v->idx, v->d_rec, &rung, &v->ladder_ransac_inliers)))
+            return rc;
+        if (rung >= 1) {  // the set the pose was computed from is the tracked set
+            std::swap(v->trk2d, v->c2);
+            std::swap(v->trk3d, v->a3);
+        }
+        v->ntrk = rec->n_tracked;
+        if (n_inliers)
+            *n_inliers = rung == 2 ? v->ladder_ransac_inliers : rec->n_inliers;
+        if (n_tracked)
+            *n_tracked = rec->n_tracked;
+        if (rec->n_inliers == 0) {  // upstream: cv::Exception out of solvePnP (too few / planar points)
+            svo_set_error("tracking lost at frame %d: solvePnP has no solution for %d points", v->frame, rec->n_tracked);
+            return SVO_ERR_TRACKING_LOST;
+        }
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++)
+                R9[3 * i + j] = rec->R[3 * j + i];
+        for (int i = 0; i < 3; i++)
+            t3[i] = -(R9[3 * i] * rec->tvec[0] + R9[3 * i + 1] * rec->tvec[1] + R9[3 * i + 2] * rec->tvec[2]);
+        return SVO_OK;
+    }
+    // solvePnPRansac (src/keyFrameManagement.cpp:84), retry (:85-92)
     for (int attempt = 0; attempt < 2; attempt++) {
         if ((rc = svo_launch_pnp_ransac(ctx, v->trk3d, v->trk2d, n, v->d_cnt + 1, K4, 100, attempt ? 8.0 : 1.0,
                                         attempt ? 0.98 : 0.99, stage_seed(v, attempt ? 2 : 1), 20, v->idx, nullptr,
@@ -530,7 +607,8 @@ int svo_vo_update(svo_vo *v, const uint8_t *right, int mem, const double *R9, co
     }
     memcpy(v->R, R9, sizeof(v->R));
     memcpy(v->t, t3, sizeof(v->t));
-    const bool kf = n_inliers < v->prm.keyframe_min_inliers || force_keyframe;  // src/VisualSLAM.cpp:120
+    // src/VisualSLAM.cpp:120; the older ladder re-triangulates on every frame (src/bundleAdjust.cpp:517-519)
+    const bool kf = n_inliers < v->prm.keyframe_min_inliers || force_keyframe || v->prm.policy == SVO_POLICY_VO_LADDER;
     if (kf) {
         SVO_CHECK_ARG(right != nullptr);
         int rc;
@@ -589,6 +667,10 @@ int svo_vo_run_chunk(svo_vo *v, const uint8_t *const *lefts, const uint8_t *cons
 {
     SVO_CHECK_ARG(v && lefts && rights && n_frames >= 0 && R_out && t_out);
     SVO_CHECK_ARG(mem == SVO_MEM_HOST || mem == SVO_MEM_DEVICE);
+    if (v->prm.policy != SVO_POLICY_SLAM) {
+        svo_set_error("the chunk runner drives the live policy (SVO_POLICY_SLAM) only");
+        return SVO_ERR_ARG;
+    }
     svo_ctx *ctx = v->ctx;
     if (pipeline && mem == SVO_MEM_DEVICE && !v->stream_b) {
         // The PnP stream exists only once pipelining is asked for, and in the high-priority class:
@@ -795,6 +877,10 @@ static int run_chunk_group(svo_chunk_job **jobs, int k)
         jobs[a]->rc = SVO_OK;
         if (jobs[a]->mem != SVO_MEM_DEVICE) {
             svo_set_error("chunks that share a context take device images");
+            return SVO_ERR_ARG;
+        }
+        if (jobs[a]->vo->prm.policy != SVO_POLICY_SLAM) {
+            svo_set_error("the chunk runner drives the live policy (SVO_POLICY_SLAM) only");
             return SVO_ERR_ARG;
         }
         n_frames_max = jobs[a]->n_frames > n_frames_max ? jobs[a]->n_frames : n_frames_max;
@@ -1187,6 +1273,54 @@ int svo_vo_get_reference(svo_vo *v, float *ref2d, float *ref3d, int cap, int *n,
     if (ref3d)
         SVO_HIP(hipMemcpyAsync(ref3d, v->ref3d, (size_t)v->nref * 12, kind, v->ctx->stream));
     SVO_HIP(hipStreamSynchronize(v->ctx->stream));
+    return SVO_OK;
+}
+
+int svo_pnp_ladder(svo_ctx *ctx, const float *obj_f, const float *img_f, int n_f, const float *obj_s, const float *img_s,
+                   int n_s, const double *K4, uint64_t seed, double *rvec, double *tvec, int *n_inliers, int *rung, int mem)
+{
+    SVO_CHECK_ARG(ctx && obj_f && img_f && obj_s && img_s && n_f >= 0 && n_s >= 0 && K4 && rvec && tvec);
+    SVO_CHECK_ARG(mem == SVO_MEM_HOST || mem == SVO_MEM_DEVICE);
+    SVO_HIP(hipSetDevice(ctx->device));
+    int rc;
+    const int cap = n_f > n_s ? n_f : n_s;
+    if ((rc = ctx->s_e.ensure(sizeof(PnpRecord) * 2 + 64)) || (rc = ctx->s_f.ensure((size_t)(cap + 1) * 4)) ||
+        (rc = ctx->s_g.ensure(64)))
+        return rc;
+    const float *of = obj_f, *uf = img_f, *os = obj_s, *us = img_s;
+    if (mem == SVO_MEM_HOST) {
+        if ((rc = ctx->s_a.ensure((size_t)(n_f + 1) * 12)) || (rc = ctx->s_b.ensure((size_t)(n_f + 1) * 8)) ||
+            (rc = ctx->s_c.ensure((size_t)(n_s + 1) * 12)) || (rc = ctx->s_d.ensure((size_t)(n_s + 1) * 8)))
+            return rc;
+        SVO_HIP(hipMemcpyAsync(ctx->s_a.p, obj_f, (size_t)n_f * 12, hipMemcpyHostToDevice, ctx->stream));
+        SVO_HIP(hipMemcpyAsync(ctx->s_b.p, img_f, (size_t)n_f * 8, hipMemcpyHostToDevice, ctx->stream));
+        SVO_HIP(hipMemcpyAsync(ctx->s_c.p, obj_s, (size_t)n_s * 12, hipMemcpyHostToDevice, ctx->stream));
+        SVO_HIP(hipMemcpyAsync(ctx->s_d.p, img_s, (size_t)n_s * 8, hipMemcpyHostToDevice, ctx->stream));
+        of = ctx->s_a.as<float>();
+        uf = ctx->s_b.as<float>();
+        os = ctx->s_c.as<float>();
+        us = ctx->s_d.as<float>();
+    }
+    int *d_cnt = ctx->s_g.as<int>();
+    const int hc[2] = {n_f, n_s};
+    SVO_HIP(hipMemcpyAsync(d_cnt, hc, sizeof(hc), hipMemcpyHostToDevice, ctx->stream));
+    SVO_HIP(hipStreamSynchronize(ctx->stream));  // hc is a stack array
+    int r = 0, rin = 0;
+    // the launchers skip empty sets: the capacity is at least 1, the live count sits on the device
+    if ((rc = ladder_pose(ctx, of, uf, d_cnt, os, us, d_cnt + 1, cap > 0 ? cap : 1, K4, seed + 1, seed + 2,
+                          ctx->s_f.as<int>(), reinterpret_cast<PnpRecord *>(ctx->s_e.p), &r, &rin)))
+        return rc;
+    const PnpRecord *rec = reinterpret_cast<const PnpRecord *>(ctx->pinned);
+    if (rung)
+        *rung = r;
+    if (n_inliers)
+        *n_inliers = rin;
+    if (rec->n_inliers == 0) {
+        svo_set_error("pose ladder: no solution (rung %d, %d points)", r, rec->n_tracked);
+        return SVO_ERR_TRACKING_LOST;
+    }
+    memcpy(rvec, rec->rvec, sizeof(rec->rvec));
+    memcpy(tvec, rec->tvec, sizeof(rec->tvec));
     return SVO_OK;
 }
 

@@ -54,6 +54,8 @@ struct PnpJob {
     PnpResult *out;
     int *early_out;
     int early_tag;
+    int direct;             // 1: no RANSAC -- hypothesis 0 (written by pnp_dlt_kernel) is refined over ALL points
+    const int *dlt_status;  // direct mode: 0 = hypothesis 0 is valid
 };
 struct PnpBatch {
     PnpJob j[SVO_LK_MAX_JOBS];
@@ -982,6 +984,166 @@ __device__ __forceinline__ void pnp_point_terms(const float *__restrict__ obj, c
         acc[22 + p] += Ju[p] * ru + Jv[p] * rv;
 }
 
+// ---- cv::solvePnP(obj, img, K, dist = 0, rvec, tvec), SOLVEPNP_ITERATIVE, no extrinsic guess -----------
+// The reference's older ladder falls back to it when RANSAC finds too few inliers
+// (src/bundleAdjust.cpp:470-477).  Upstream (cvFindExtrinsicCameraParams2, non-planar branch): DLT --
+// rows [X Y Z 1 0 0 0 0 xX xY xZ x], [0 0 0 0 X Y Z 1 yX yY yZ y] with (x, y) = -(normalised image
+// point), the right singular vector of the smallest singular value of L^T L as a 3x4 [RR | tt], sign
+// by det(RR), R = U V^T of RR's SVD, t = tt * |R| / |RR| -- then Levenberg-Marquardt on all points.
+// One workgroup: 40 sums (the 12x12 L^T L is [[S1, 0, Sx], [0, S1, Sy], [Sx, Sy, Sxy]] with S* = sum of
+// w * P P^T, P = (X, Y, Z, 1), w = 1, x, y, x^2 + y^2: 10 unique entries each), fixed-order reduction,
+// wave 0 runs the 12x12 Jacobi eigen-decomposition in LDS and writes hypothesis 0; pnp_finish_kernel in
+// direct mode refines it over all points.  status: 0 ok, 1 = points planar (upstream's homography
+// branch is not built), 2 = fewer than 6 points, 3 = degenerate.
+struct DltArgs {
+    const float *obj, *img;
+    int n_host;
+    const int *d_n;
+    K4 K;
+    double *hyp;
+    int *status;
+};
+
+template <int KN> __device__ __forceinline__ void block_sum_fixed(double (&v)[KN], double *s_red /* [4][KN] */)
+{
+#pragma unroll
+    for (int k = 0; k < KN; k++) {
+        double x = v[k];
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1)
+            x = x + __shfl_xor(x, m, 64);  // balanced tree; commutative adds: every lane holds the same bits
+        v[k] = x;
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0)
+#pragma unroll
+        for (int k = 0; k < KN; k++)
+            s_red[wave * KN + k] = v[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < KN; k++)
+        v[k] = ((s_red[k] + s_red[KN + k]) + s_red[2 * KN + k]) + s_red[3 * KN + k];
+}
+
+__global__ __launch_bounds__(256) void pnp_dlt_kernel(DltArgs a)
+{
+    __shared__ double s_red[4 * 40], s_A[144], s_V[144], s_cs[16];
+    __shared__ int s_pq[16];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int n = a.d_n ? min(*a.d_n, a.n_host) : a.n_host;
+    const float2 *__restrict__ img = reinterpret_cast<const float2 *>(a.img);
+    double acc[40];
+#pragma unroll
+    for (int k = 0; k < 40; k++)
+        acc[k] = 0;
+    const double ifx = 1. / a.K.fx, ify = 1. / a.K.fy;
+    for (int i = tid; i < n; i += 256) {
+        const double P[4] = {(double)a.obj[3 * i], (double)a.obj[3 * i + 1], (double)a.obj[3 * i + 2], 1.};
+        const float2 u = img[i];
+        const double x = -(((double)u.x - a.K.cx) * ifx), y = -(((double)u.y - a.K.cy) * ify);
+        const double w3 = x * x + y * y;
+        int k = 0;
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int c = r; c < 4; c++) {
+                const double pp = P[r] * P[c];
+                acc[k] += pp;
+                acc[10 + k] += x * pp;
+                acc[20 + k] += y * pp;
+                acc[30 + k] += w3 * pp;
+                k++;
+            }
+    }
+    block_sum_fixed<40>(acc, s_red);
+    if (tid >= 64)
+        return;  // wave 0 goes on alone: no workgroup barrier below
+    int status = 0;
+    if (n < 6)
+        status = 2;
+    // planarity test of upstream: eigenvalues of the centred second moments, W[2] / W[1] < 1e-3
+    if (status == 0) {
+        const double inv_n = 1. / n;
+        const double mx = acc[3] * inv_n, my = acc[6] * inv_n, mz = acc[8] * inv_n;  // sums of X, Y, Z (P P^T entries 03, 13, 23)
+        double C[9] = {acc[0] - n * mx * mx, acc[1] - n * mx * my, acc[2] - n * mx * mz,
+                       acc[1] - n * mx * my, acc[4] - n * my * my, acc[5] - n * my * mz,
+                       acc[2] - n * mx * mz, acc[5] - n * my * mz, acc[7] - n * mz * mz};
+        double U[9], V[9];
+        svd3(C, U, V);
+        // singular values of the symmetric PSD matrix = |column of C V| in decreasing order
+        double w[3];
+        for (int c = 0; c < 3; c++) {
+            double q = 0;
+            for (int r = 0; r < 3; r++) {
+                const double e = C[3 * r] * V[c] + C[3 * r + 1] * V[3 + c] + C[3 * r + 2] * V[6 + c];
+                q += e * e;
+            }
+            w[c] = sqrt(q);
+        }
+        if (!(w[1] > 0) || w[2] / w[1] < 1e-3)
+            status = 1;
+    }
+    if (status == 0) {
+        // L^T L, row-major 12x12, from the four weighted second-moment blocks
+        for (int e = lane; e < 144; e += 64) {
+            const int r = e / 12, c = e - 12 * r;
+            const int br = r >> 2, bc = c >> 2, i = r & 3, j = c & 3;
+            const int lo = i < j ? i : j, hi = i < j ? j : i;
+            const int k = lo * 4 - lo * (lo - 1) / 2 + (hi - lo);  // index of (lo, hi) in the 10 unique entries
+            int blk = -1;  // 0: S1, 1: Sx, 2: Sy, 3: Sxy
+            if (br == bc)
+                blk = br == 2 ? 3 : 0;
+            else if (br + bc == 2 && (br == 2 || bc == 2))  // (0,2) / (2,0)
+                blk = 1;
+            else if (br + bc == 3)                          // (1,2) / (2,1)
+                blk = 2;
+            s_A[e] = blk < 0 ? 0. : acc[10 * blk + k];
+        }
+        wave_lds_fence();
+        wave_jacobi_eigen_sym<12>(s_A, s_V, s_cs, s_pq, 10, lane);
+        int best = 0;
+        for (int e = 1; e < 12; e++)
+            if (s_A[13 * e] < s_A[13 * best])
+                best = e;
+        double rt[12];  // 3x4 [RR | tt], row-major
+        for (int i = 0; i < 12; i++)
+            rt[i] = s_V[12 * i + best];
+        double RR[9] = {rt[0], rt[1], rt[2], rt[4], rt[5], rt[6], rt[8], rt[9], rt[10]};
+        double tt[3] = {rt[3], rt[7], rt[11]};
+        const double det = RR[0] * (RR[4] * RR[8] - RR[5] * RR[7]) - RR[1] * (RR[3] * RR[8] - RR[5] * RR[6]) +
+                           RR[2] * (RR[3] * RR[7] - RR[4] * RR[6]);
+        if (det < 0) {
+            for (int i = 0; i < 9; i++)
+                RR[i] = -RR[i];
+            for (int i = 0; i < 3; i++)
+                tt[i] = -tt[i];
+        }
+        double sc = 0;
+        for (int i = 0; i < 9; i++)
+            sc += RR[i] * RR[i];
+        sc = sqrt(sc);
+        if (!(sc > 2.220446049250313e-16)) {
+            status = 3;
+        } else {
+            double U[9], V[9], R[9];
+            svd3(RR, U, V);
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 3; j++)
+                    R[3 * i + j] = U[3 * i] * V[3 * j] + U[3 * i + 1] * V[3 * j + 1] + U[3 * i + 2] * V[3 * j + 2];
+            const double scale = sqrt(3.) / sc;  // cvNorm(R) / sc, |R|_F of a rotation = sqrt(3)
+            if (lane == 0) {
+                for (int i = 0; i < 9; i++)
+                    a.hyp[i] = R[i];
+                for (int i = 0; i < 3; i++)
+                    a.hyp[9 + i] = tt[i] * scale;
+            }
+        }
+    }
+    if (lane == 0)
+        *a.status = status;
+}
+
 struct PnpResult {      // what the host reads back after a localisation
     double rvec[3], tvec[3];
     double R[9];        // Rodrigues(rvec)
@@ -1023,7 +1185,17 @@ __global__ __launch_bounds__(256, 4) void pnp_finish_kernel(PnpBatch batch)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = d_n ? min(*d_n, n_host) : n_host;
     if (tid == 0) {
-        const RansacState r = ransac_replay<1>(nullptr, 1, iterations, iterations, n, confidence, nmodels, counts, MP);
+        RansacState r;
+        if (job.direct) {  // cv::solvePnP: every point takes part, the start is the DLT pose
+            r.niters = r.next_iter = r.iters_run = 0;
+            r.best_iter = (*job.dlt_status == 0 && n >= 6) ? 0 : -1;
+            r.best_model = 0;
+            r.best_count = r.best_iter == 0 ? n : 0;
+            r.done = 1;
+            r.pad = 0;
+        } else {
+            r = ransac_replay<1>(nullptr, 1, iterations, iterations, n, confidence, nmodels, counts, MP);
+        }
         *st = r;
         s_state = r;
         s_base = 0;
@@ -1043,7 +1215,7 @@ __global__ __launch_bounds__(256, 4) void pnp_finish_kernel(PnpBatch batch)
             bool keep = false;
             if (have_model && i < n) {
                 const float2 u = img[i];
-                keep = reproj_err_sq(P, K, obj[3 * i], obj[3 * i + 1], obj[3 * i + 2], u.x, u.y) <= thr;
+                keep = job.direct || reproj_err_sq(P, K, obj[3 * i], obj[3 * i + 1], obj[3 * i + 2], u.x, u.y) <= thr;
             }
             if (mask && i < n_host)
                 mask[i] = keep ? 1 : 0;
@@ -1238,6 +1410,8 @@ int svo_launch_pnp_ransac_batch(svo_ctx *ctx, int n_jobs, const svo_pnp_job *job
         j.out = reinterpret_cast<PnpResult *>(h.d_result);
         j.early_out = h.early_mbox;
         j.early_tag = h.early_tag;
+        j.direct = 0;
+        j.dlt_status = nullptr;
         nb++;
     }
     if (nb == 0)
@@ -1277,6 +1451,95 @@ int svo_launch_pnp_ransac(svo_ctx *ctx, const float *obj, const float *img, int 
     j.early_mbox = early_mbox;
     j.early_tag = early_tag;
     return svo_launch_pnp_ransac_batch(ctx, 1, &j);
+}
+
+// cv::solvePnP (ITERATIVE, no guess) on device arrays: DLT + LM over all points.  inliers: cap ints of
+// scratch (receives 0..n-1); d_result: one PnpResult (n_inliers = n, or 0 when there is no model).
+int svo_launch_solve_pnp(svo_ctx *ctx, const float *obj, const float *img, int cap, const int *d_n, const double *K4h,
+                         int refine_iters, int *inliers, void *d_result, int *early_mbox, int early_tag)
+{
+    if (cap <= 0)
+        return SVO_OK;
+    int rc;
+    if ((rc = ctx->w_c.ensure(12 * sizeof(double))) || (rc = ctx->w_d.ensure(64 * sizeof(int))))
+        return rc;
+    int *ib = ctx->w_d.as<int>();
+    DltArgs d;
+    d.obj = obj;
+    d.img = img;
+    d.n_host = cap;
+    d.d_n = d_n;
+    d.K = {K4h[0], K4h[1], K4h[2], K4h[3]};
+    d.hyp = ctx->w_c.as<double>();
+    d.status = ib + 12;
+    PnpBatch batch;
+    PnpJob &j = batch.j[0];
+    j.obj = obj;
+    j.img = img;
+    j.n_host = cap;
+    j.d_n = d_n;
+    j.K = d.K;
+    j.seed = 0;
+    j.iterations = 1;
+    j.confidence = 0.99;
+    j.thr = 0.f;
+    j.max_lm_iters = refine_iters > 0 ? refine_iters : 20;
+    j.st = reinterpret_cast<RansacState *>(ib);
+    j.d_m = ib + 8;
+    j.nmodels = ib + 16;
+    j.counts = ib + 17;
+    j.hyp = d.hyp;
+    j.mask = nullptr;
+    j.inl = inliers;
+    j.out = reinterpret_cast<PnpResult *>(d_result);
+    j.early_out = early_mbox;
+    j.early_tag = early_tag;
+    j.direct = 1;
+    j.dlt_status = d.status;
+    for (int k = 1; k < SVO_LK_MAX_JOBS; k++)
+        batch.j[k] = batch.j[0];
+    ScopedKernelTime tm(ctx, SVO_K_PNP);
+    hipLaunchKernelGGL(pnp_dlt_kernel, dim3(1), dim3(256), 0, ctx->stream, d);
+    hipLaunchKernelGGL(pnp_finish_kernel, dim3(1), dim3(256), 0, ctx->stream, batch);
+    SVO_HIP(hipGetLastError());
+    return SVO_OK;
+}
+
+extern "C" int svo_solve_pnp(svo_ctx *ctx, const float *obj, const float *img, int n, const double *K4h, double *rvec,
+                             double *tvec, double *rms, int mem)
+{
+    SVO_CHECK_ARG(ctx && K4h && obj && img && rvec && tvec);
+    SVO_CHECK_ARG(mem == SVO_MEM_HOST || mem == SVO_MEM_DEVICE);
+    if (n < 6) {
+        svo_set_error("solvePnP (DLT) needs at least 6 points, got %d", n);
+        return SVO_ERR_ARG;
+    }
+    int rc;
+    if ((rc = ctx->s_d.ensure(sizeof(PnpResult) + 64)) || (rc = ctx->s_c.ensure((size_t)n * 4)))
+        return rc;
+    const float *dobj = obj, *dimg = img;
+    if (mem == SVO_MEM_HOST) {
+        if ((rc = ctx->s_a.ensure((size_t)n * 12)) || (rc = ctx->s_b.ensure((size_t)n * 8)))
+            return rc;
+        SVO_HIP(hipMemcpyAsync(ctx->s_a.p, obj, (size_t)n * 12, hipMemcpyHostToDevice, ctx->stream));
+        SVO_HIP(hipMemcpyAsync(ctx->s_b.p, img, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+        dobj = ctx->s_a.as<float>();
+        dimg = ctx->s_b.as<float>();
+    }
+    if ((rc = svo_launch_solve_pnp(ctx, dobj, dimg, n, nullptr, K4h, 20, ctx->s_c.as<int>(), ctx->s_d.p, nullptr, 0)))
+        return rc;
+    SVO_HIP(hipMemcpyAsync(ctx->pinned, ctx->s_d.p, sizeof(PnpResult), hipMemcpyDeviceToHost, ctx->stream));
+    SVO_HIP(hipStreamSynchronize(ctx->stream));
+    const PnpResult *r = reinterpret_cast<const PnpResult *>(ctx->pinned);
+    if (r->n_inliers == 0) {
+        svo_set_error("solvePnP: no initial pose (planar or degenerate object points: upstream's homography branch is not built)");
+        return SVO_ERR_STATE;
+    }
+    memcpy(rvec, r->rvec, sizeof(r->rvec));
+    memcpy(tvec, r->tvec, sizeof(r->tvec));
+    if (rms)
+        *rms = r->rms;
+    return SVO_OK;
 }
 
 extern "C" int svo_pnp_ransac(svo_ctx *ctx, const float *obj, const float *img, int n, const double *K4h,

@@ -203,6 +203,8 @@ int svo_launch_pnp_ransac(svo_ctx *ctx, const float *obj, const float *img, int 
                           const double *K4h, int iterations, double reproj_err, double confidence, uint64_t seed,
                           int refine_iters, int *inliers, uint8_t *mask, void *d_result, int *early_mbox = nullptr,
                           int early_tag = 0);
+int svo_launch_solve_pnp(svo_ctx *ctx, const float *obj, const float *img, int cap, const int *d_n, const double *K4h,
+                         int refine_iters, int *inliers, void *d_result, int *early_mbox = nullptr, int early_tag = 0);
 // anms.hip
 int svo_launch_anms_batch(svo_ctx *ctx, int k, const float *const *xy, const float *const *resp, int n, int keep,
                           int *const *out_idx, int *const *d_count);

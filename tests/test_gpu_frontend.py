@@ -300,3 +300,30 @@ def test_chunk_sharded_run_against_the_sequential_one(ctx):
     for c in ctxs:
         c.close()
     seq.close()
+
+
+def test_older_vo_ladder_front_end_matches_oracle(ctx, orc):
+    """svo_vo_params.policy = SVO_POLICY_VO_LADDER: visualOdometry::initSequence, src/bundleAdjust.cpp:427-548
+    -- PnP-RANSAC at 4 px, a stereo keyframe on every frame, never shuts down -- frame by frame against the
+    oracle's ladder (the rungs below the first are exercised on explicit point sets in
+    test_gpu_pnp_anms.py::test_pnp_ladder_rungs_match_oracle)."""
+    sc = synth.Scene()
+    poses = synth.corridor_trajectory(6)
+    frames = [sc.stereo(R, t)[:2] for R, t in poses]
+    g = capi.VisualOdometry(ctx, 1241, 376, 3, grid_step=30, seed=3, policy=1)
+    o = orc.VO(1241, 376, 3, grid_step=30, seed=3, policy=1)
+    assert g.init(*frames[0]) == o.init(*frames[0])
+    for i in range(1, 6):
+        rg, Rg, tg, ig, kg, ng = g.track(*frames[i])
+        ro, Ro, to, io, ko, no = o.track(*frames[i])
+        assert rg == ro == 0 and kg and ko                     # every frame re-triangulates (:517-519)
+        assert ng == no and abs(ig - io) <= 2 and ig >= 20, f"frame {i}: {ng}/{ig} vs {no}/{io}"
+        assert np.linalg.norm(tg - to) < 1e-3 and _rot_angle(Rg, Ro) < 1e-4, f"frame {i}: {tg} vs {to}"
+        assert np.linalg.norm(tg - poses[i][1]) < 0.1
+        a2, a3 = g.reference()
+        b2, b3 = o.ref()
+        assert np.array_equal(a2, b2) and np.allclose(a3, b3, rtol=1e-4, atol=1e-3)
+    with pytest.raises(capi.SvoError):                         # the chunk runner drives the live policy only
+        g.run_chunk([frames[1][0]], [frames[1][1]])
+    g.close()
+    o.close()

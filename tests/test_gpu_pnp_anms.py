@@ -78,3 +78,67 @@ def test_anms_grid_with_zero_response(ctx, orc):
     xy = orc.grid_keypoints(376, 1241, 30)
     got = ctx.anms(xy, np.zeros(len(xy), np.float32), 100)
     assert np.array_equal(got, np.arange(len(xy)))
+
+
+@pytest.mark.parametrize("n,noise", [(6, 0.0), (9, 0.1), (500, 0.3), (4096, 0.3)])
+def test_solve_pnp_matches_oracle(ctx, orc, n, noise):
+    """cv::solvePnP (ITERATIVE, no guess) = DLT over all points + LM: the last rung of the older VO
+    ladder (src/bundleAdjust.cpp:470-477)."""
+    rng = np.random.default_rng(n)
+    X = scene_points(n, 11).astype(np.float32)
+    R, t = _pose()
+    x = (project(X, R, t) + rng.normal(0, noise, (n, 2))).astype(np.float32)
+    grv, gtv, grms = ctx.solve_pnp(X, x, K4)
+    rc, orv, otv, orms = orc.solve_pnp(X, x, K4)
+    assert rc == 0
+    assert np.abs(grv - orv).max() < 1e-6 and np.abs(gtv - otv).max() < 1e-5
+    assert grms == pytest.approx(orms, rel=1e-5, abs=1e-7)
+    assert np.abs(gtv - t).max() < (1e-4 if noise == 0 else 0.2)
+
+
+def test_solve_pnp_planar_and_too_few_points(ctx):
+    from ros_stereo_slam_amd import capi
+    X = scene_points(50, 2).astype(np.float32)
+    with pytest.raises(capi.SvoError) as e:
+        ctx.solve_pnp(X[:5], project(X[:5]), K4)
+    assert e.value.code == capi.SVO_ERR_ARG
+    Xp = X.copy()
+    Xp[:, 2] = 10.0
+    with pytest.raises(capi.SvoError) as e:
+        ctx.solve_pnp(Xp, project(Xp), K4)
+    assert e.value.code == -6            # SVO_ERR_STATE: upstream's homography branch is not built
+
+
+def _set(n, n_out, seed, noise=0.2):
+    rng = np.random.default_rng(1000 + seed)
+    X = scene_points(n, seed).astype(np.float32)
+    R, t = _pose()
+    x = (project(X, R, t) + rng.normal(0, noise, (n, 2))).astype(np.float32)
+    out = rng.choice(n, n_out, replace=False)
+    x[out] += rng.uniform(15, 60, (n_out, 2)).astype(np.float32)
+    return X, x
+
+
+@pytest.mark.parametrize("nf,of,ns,os_,rung", [(300, 30, 340, 70, 0),    # plenty of inliers: the first RANSAC decides
+                                               (15, 0, 60, 20, 1),       # < 20: RANSAC again without the F filter
+                                               (25, 12, 9, 0, 2),        # < 20, then < 10: plain solvePnP
+                                               (8, 0, 9, 0, 2)])
+def test_pnp_ladder_rungs_match_oracle(ctx, orc, nf, of, ns, os_, rung):
+    """The pose ladder of the older visualOdometry::initSequence (src/bundleAdjust.cpp:462-480) on explicit
+    point sets, one case per rung."""
+    Xf, xf = _set(nf, of, 3)
+    Xs, xs = _set(ns, os_, 4)
+    rg, grv, gtv, gin, grung = ctx.pnp_ladder(Xf, xf, Xs, xs, K4, seed=5)
+    ro, orv, otv, oin, orung = orc.pnp_ladder(Xf, xf, Xs, xs, K4, seed=5)
+    assert rg == ro == 0 and grung == orung == rung and abs(gin - oin) <= 2
+    assert np.abs(grv - orv).max() < 1e-5 and np.abs(gtv - otv).max() < 1e-4
+    assert np.abs(gtv - _pose()[1]).max() < 0.1
+
+
+def test_pnp_ladder_without_a_solution_reports_tracking_lost(ctx, orc):
+    from ros_stereo_slam_amd import capi
+    Xf, xf = _set(5, 0, 5)
+    Xs, xs = _set(5, 0, 6)
+    rg, *_rest, grung = ctx.pnp_ladder(Xf, xf, Xs, xs, K4, seed=5)
+    ro, *_rest, orung = orc.pnp_ladder(Xf, xf, Xs, xs, K4, seed=5)
+    assert rg == capi.SVO_ERR_TRACKING_LOST and ro == -1 and grung == orung == 2

@@ -123,3 +123,41 @@ def test_anms_zero_response_keeps_everything(orc):
     xy = np.stack(np.meshgrid(np.arange(10.0), np.arange(10.0)), -1).reshape(-1, 2).astype(np.float32)
     got, radii = orc.anms(xy, np.zeros(100, np.float32), 30)
     assert len(got) == 100 and np.array_equal(got, np.arange(100))
+
+
+# ---- cv::solvePnP (ITERATIVE, no guess): the last rung of the older ladder, src/bundleAdjust.cpp:470-477 ----
+def test_solve_pnp_recovers_a_known_pose_and_is_a_least_squares_optimum(orc):
+    from scipy.optimize import least_squares
+    from scipy.spatial.transform import Rotation as Rot
+
+    from geom_fixtures import K4, project, scene_points
+
+    R = Rot.from_rotvec([0.02, -0.05, 0.01]).as_matrix()
+    t = np.array([0.1, -0.05, -0.8])
+    for n in (6, 7, 60):
+        X = scene_points(n, 3)
+        rc, rv, tv, rms = orc.solve_pnp(X, project(X, R, t), K4)
+        assert rc == 0 and np.abs(rv - Rot.from_matrix(R).as_rotvec()).max() < 1e-6 and np.abs(tv - t).max() < 2e-5
+    # with noise the answer is the stationary point of the reprojection error over ALL points
+    X = scene_points(300, 4).astype(np.float32)
+    x = (project(X, R, t) + np.random.default_rng(0).normal(0, 0.4, (300, 2))).astype(np.float32)
+    rc, rv, tv, rms = orc.solve_pnp(X, x, K4)
+    assert rc == 0
+
+    def res(p):
+        Xc = X.astype(np.float64) @ Rot.from_rotvec(p[:3]).as_matrix().T + p[3:]
+        return np.c_[K4[0] * Xc[:, 0] / Xc[:, 2] + K4[2] - x[:, 0], K4[1] * Xc[:, 1] / Xc[:, 2] + K4[3] - x[:, 1]].ravel()
+
+    sol = least_squares(res, np.r_[rv, tv], xtol=1e-15, ftol=1e-15, gtol=1e-15)
+    assert np.abs(sol.x - np.r_[rv, tv]).max() < 1e-6
+    assert rms == pytest.approx(np.sqrt(np.sum(res(np.r_[rv, tv]) ** 2) / 300), rel=1e-6)
+
+
+def test_solve_pnp_refuses_what_upstream_cannot_solve_by_dlt(orc):
+    from geom_fixtures import K4, project, scene_points
+
+    X = scene_points(100, 1)
+    assert orc.solve_pnp(X[:5], project(X[:5]), K4)[0] == -1          # fewer than 6 points
+    Xp = X.copy()
+    Xp[:, 2] = 10.0                                                   # planar: upstream takes its homography branch
+    assert orc.solve_pnp(Xp, project(Xp), K4)[0] == -2
