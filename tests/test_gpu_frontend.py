@@ -64,8 +64,9 @@ def test_frontend_matches_oracle_on_the_benchmark_stream(ctx, orc, grid_step, an
         # 1e-3 m / 1e-4 rad while the inlier sets agree.  A point that sits on the 1 px
         # threshold may fall either side in f64 libm noise; from such a frame on the two runs refine over
         # inlier sets that differ by that point, and keyframes placed with the (millimetres apart) poses
-        # carry the offset forward: the bound is then 1e-2 m / 1e-3 rad.
-        lim_t, lim_r = (1e-3, 1e-4) if not flips else (1e-2, 1e-3)
+        # carry the offset forward and move later threshold decisions: the bound is then SURVEY.md 8d's
+        # trajectory bound, 5 cm (and 2e-3 rad), per frame.
+        lim_t, lim_r = (1e-3, 1e-4) if not flips else (5e-2, 2e-3)
         assert dt < lim_t and dr < lim_r, f"frame {i}: {dt:.2e} m, {dr:.2e} rad, flips so far {flips}"
         worst_t, worst_r = max(worst_t, dt), max(worst_r, dr)
         assert np.linalg.norm(tg - poses[i][1]) < 0.02 * i + 0.05     # both follow the generator's truth
