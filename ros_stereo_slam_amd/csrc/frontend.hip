@@ -233,6 +233,7 @@ int stereo_triangulate_batch(int k, svo_vo *const *vs, svo_pyramid *const *lefts
         LkJob &q = lk[a];
         q.prev = lefts[a]->dev;
         q.next = rights[a]->dev;
+        q.dprev = lefts[a]->dbase;
         q.prev_pts = v->grid_xy;
         q.n_cap = n;
         q.d_n = nullptr;
@@ -241,7 +242,7 @@ int stereo_triangulate_batch(int k, svo_vo *const *vs, svo_pyramid *const *lefts
         q.err = nullptr;
         q.min_eig = v->resp;
     }
-    if ((rc = svo_launch_lk_batch(ctx, k, lk)))
+    if ((rc = svo_launch_lk_batch(ctx, k, lk, lefts[0])))
         return rc;
     const float *pts[SVO_LK_MAX_JOBS], *trk[SVO_LK_MAX_JOBS];
     const uint8_t *stt[SVO_LK_MAX_JOBS];
@@ -416,7 +417,8 @@ int svo_vo_create(svo_ctx *ctx, const svo_vo_params *params, int width, int heig
     const size_t n = (size_t)v->cap;
     if ((rc = svo_pyramid_create(ctx, width, height, channels, SVO_MAX_LEVELS, &v->pyr_ref)) ||
         (rc = svo_pyramid_create(ctx, width, height, channels, SVO_MAX_LEVELS, &v->pyr_cur)) ||
-        (rc = svo_pyramid_create(ctx, width, height, channels, SVO_MAX_LEVELS, &v->pyr_right)) ||
+        // the right image is only ever the SECOND image of a tracking pass: no derivative levels
+        (rc = svo_pyramid_create_ex(ctx, width, height, channels, SVO_MAX_LEVELS, false, &v->pyr_right)) ||
         (rc = svo_pyramid_create(ctx, width, height, channels, SVO_MAX_LEVELS, &v->pyr_next)) ||
         (rc = dev_alloc(&v->sa2, n * 2)) || (rc = dev_alloc(&v->sstatus, n)) ||
         (rc = dev_alloc(&v->ref2d, n * 2)) || (rc = dev_alloc(&v->ref3d, n * 3)) ||
@@ -526,7 +528,7 @@ int svo_vo_localize(svo_vo *v, const uint8_t *left, int mem, double *R9, double 
         return SVO_ERR_TRACKING_LOST;
     }
     // PyrLKtrackFrame2Frame (src/tracking.cpp:46-91)
-    if ((rc = svo_launch_lk(ctx, v->pyr_ref->dev, v->pyr_cur->dev, v->ref2d, n, v->a2, v->status, nullptr, nullptr)))
+    if ((rc = svo_launch_lk(ctx, v->pyr_ref, v->pyr_cur, v->ref2d, n, v->a2, v->status, nullptr, nullptr)))
         return rc;
     if ((rc = svo_launch_compact(ctx, v->status, n, nullptr, v->ref2d, 2, v->b2, v->a2, 2, v->c2, v->ref3d, 3, v->a3,
                                  v->d_cnt)))
@@ -727,7 +729,7 @@ int svo_vo_run_chunk(svo_vo *v, const uint8_t *const *lefts, const uint8_t *cons
                 if (rc || (rc = svo_build_pyramid_from_device(ctx, v->pyr_cur, d)))
                     return rc;
             }
-            if ((rc = svo_launch_lk(ctx, v->pyr_ref->dev, v->pyr_cur->dev, v->ref2d, n, v->a2, v->status, nullptr,
+            if ((rc = svo_launch_lk(ctx, v->pyr_ref, v->pyr_cur, v->ref2d, n, v->a2, v->status, nullptr,
                                     nullptr)))
                 return rc;
         }
@@ -776,7 +778,7 @@ int svo_vo_run_chunk(svo_vo *v, const uint8_t *const *lefts, const uint8_t *cons
             if (rc || (rc = svo_build_pyramid_from_device(ctx, v->pyr_next, d)))
                 return rc;
             // next frame's reference = this frame's tracked set (its count lives in cnt_trk)
-            if ((rc = svo_launch_lk(ctx, v->pyr_cur->dev, v->pyr_next->dev, v->trk2d, n, v->sa2, v->sstatus, nullptr,
+            if ((rc = svo_launch_lk(ctx, v->pyr_cur, v->pyr_next, v->trk2d, n, v->sa2, v->sstatus, nullptr,
                                     nullptr, cnt_trk)))
                 return rc;
             speculated = true;
@@ -990,6 +992,7 @@ static int run_chunk_group(svo_chunk_job **jobs, int k)
             LkJob &q = lk[nl++];
             q.prev = v->pyr_ref->dev;
             q.next = v->pyr_cur->dev;
+            q.dprev = v->pyr_ref->dbase;
             q.prev_pts = v->ref2d;
             q.n_cap = g.n;
             q.d_n = nullptr;
@@ -1000,7 +1003,7 @@ static int run_chunk_group(svo_chunk_job **jobs, int k)
         }
         if (nl == 0)
             break;
-        if ((rc = svo_build_pyramids_from_device(ctx, nl, pyrs, imgs)) || (rc = svo_launch_lk_batch(ctx, nl, lk)))
+        if ((rc = svo_build_pyramids_from_device(ctx, nl, pyrs, imgs)) || (rc = svo_launch_lk_batch(ctx, nl, lk, pyrs[0])))
             return rc;
         // ---- filters and PnP: every stage is ONE set of launches for all the chunks ----
         svo_pnp_job pj[SVO_LK_MAX_JOBS];

@@ -9,10 +9,10 @@
 // of one point depend on each other, points never do).  Lane l owns window row l/3 and a
 // 7-pixel segment (l%3) of it, i.e. 7*C patch elements that stay in VGPRs for the whole
 // level (template patch I and both derivative patches).  Per level a wave
-//   1. stages the 24x24 neighbourhood of the previous image in LDS (aligned 16-byte row
-//      loads from the padded pyramid level, no border arithmetic), derives the 22x22 Scharr
-//      tile LDS->LDS (zero outside the image, as OpenCV pads the derivative buffer), builds
-//      its patch registers and the 2x2 normal matrix;
+//   1. stages the 24x24 neighbourhood of the previous image and the 22x22 tile of its Scharr
+//      derivative level (pyramid.hip materialises the derivative levels once per image, zero
+//      outside the image as OpenCV pads its derivative buffer) in LDS with aligned 16-byte row
+//      loads, builds its patch registers and the 2x2 normal matrix;
 //   2. stages a (22+2*JR)^2 tile of the next image around the current guess and iterates
 //      out of LDS; the tile is re-staged only when the guess drifts more than JR pixels.
 // All sums of integer products are exact (int32 per lane, int64 across the wave via
@@ -43,6 +43,8 @@ struct LkParams {
     double eps_sq;
     float eps_pre;  // a step with max(|dx|, |dy|) above this cannot pass the eps_sq test (1.01 * sqrt(eps_sq))
     float min_eig_thr;
+    int doff[SVO_MAX_LEVELS];    // derivative levels of the jobs' first pyramids: element (0,0), in ints
+    int dpitch[SVO_MAX_LEVELS];  // bytes, multiple of 16
 };
 static_assert(sizeof(LkBatch) + sizeof(LkParams) <= 4096, "kernel arguments are limited to 4 KB");
 
@@ -57,9 +59,16 @@ template <int C, int SIDE> struct Tile {
     static constexpr int ROW = (VEC | 1) * 16;
     static constexpr int BYTES = SIDE * ROW;
 };
+// the derivative tile: DT x DT "pixels" of 4 * C bytes, rows as loaded (16-byte vectors, any shift)
+template <int C> struct DTile {
+    static constexpr int ROWB = DT * C * 4;
+    static constexpr int VEC = (ROWB + 15 + 15) / 16;
+    static constexpr int ROW = (VEC | 1) * 16;  // odd number of 16-byte units: rows spread over the banks
+    static constexpr int BYTES = DT * ROW;
+};
 template <int C> struct Lds {
     static constexpr int T_BYTES = Tile<C, PT>::BYTES;
-    static constexpr int D_BYTES = DT * DT * C * 4;
+    static constexpr int D_BYTES = DTile<C>::BYTES;
     static constexpr int J_BYTES = Tile<C, TS>::BYTES;
     static constexpr int A = T_BYTES + D_BYTES;
     static constexpr int WAVE_BYTES = (((A > J_BYTES ? A : J_BYTES) + 15) / 16) * 16;
@@ -220,6 +229,50 @@ __device__ __forceinline__ int stage_tile(uint8_t *tile, const uint8_t *__restri
     return shift;
 }
 
+// Stage the DT x DT tile of a derivative level whose top-left element is pixel (ox, oy): rows of
+// DT * C ints, fetched as aligned 16-byte vectors (the level's pitch is a multiple of 16, so every
+// row starts at the same byte shift, a multiple of 4).  VEC vectors per row x DT rows, dealt to the
+// lanes in linear order.  Returns the byte shift.
+template <int C>
+__device__ __forceinline__ int stage_dtile(uint8_t *tile, const int *__restrict__ lvl, int dpitch, int ox, int oy,
+                                           int lane)
+{
+    using DL = DTile<C>;
+    const int off = oy * dpitch + ox * (C * 4);  // bytes from element (0,0); inside one padded level: fits 32 bits
+    const int shift = (int)(((unsigned)reinterpret_cast<uintptr_t>(lvl) + (unsigned)off) & 15u);
+    const uint8_t *a16 = reinterpret_cast<const uint8_t *>(lvl) + (ptrdiff_t)__builtin_amdgcn_readfirstlane(off - shift);
+    constexpr int TOTAL = DT * DL::VEC, ITER = (TOTAL + 63) / 64, HALF = (ITER + 1) / 2;
+    typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+    // two batches of loads: at most HALF vectors (16 registers) in flight, the kernel runs at 128 VGPRs
+#pragma unroll
+    for (int b = 0; b < ITER; b += HALF) {
+        uint4v v[HALF];
+        unsigned loff[HALF];
+#pragma unroll
+        for (int k = 0; k < HALF; k++) {
+            if (b + k >= ITER)
+                continue;
+            unsigned i = (unsigned)lane + 64u * (unsigned)(b + k);
+            if ((b + k + 1) * 64 > TOTAL)
+                i = min(i, (unsigned)TOTAL - 1);  // the last step's spare lanes repeat the last vector
+            const unsigned r = i / (unsigned)DL::VEC, c = i - r * (unsigned)DL::VEC;
+            loff[k] = r * (unsigned)DL::ROW + c * 16u;
+            const unsigned goff = r * (unsigned)dpitch + c * 16u;
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(v[k]) : "v"(goff), "s"(a16) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0])::"memory");
+#pragma unroll
+        for (int k = 1; k < HALF; k++)
+            if (b + k < ITER)
+                asm volatile("" : "+v"(v[k]));
+#pragma unroll
+        for (int k = 0; k < HALF; k++)
+            if (b + k < ITER)
+                *reinterpret_cast<uint4v *>(tile + loff[k]) = v[k];
+    }
+    return shift;
+}
+
 // Every lane of a wave computes the same control values (guess, step, tile origin): telling the
 // compiler so turns the loop's branches into scalar compares instead of exec-mask juggling.
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -376,6 +429,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void lk_track_kernel(LkBatch batch, 
 {
     const LkJob &job = batch.j[blockIdx.y];
     const PyrDev &prev = job.prev, &next = job.next;
+    const int *__restrict__ dprev = job.dprev;
     const float *__restrict__ prev_pts = job.prev_pts;
     const int n_cap = job.n_cap;
     const int *__restrict__ d_n = job.d_n;
@@ -395,7 +449,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void lk_track_kernel(LkBatch batch, 
         return;  // whole wave leaves; no workgroup barrier is used below
     uint8_t *lds = smem + wave * Lds<C>::WAVE_BYTES;
     uint8_t *T = lds;                                           // PT x PT x C bytes
-    int *D = reinterpret_cast<int *>(lds + Lds<C>::T_BYTES);    // DT x DT x C packed (dx | dy<<16)
+    uint8_t *DB = lds + Lds<C>::T_BYTES;                        // DT rows of packed (dx | dy<<16), as loaded
     uint8_t *TJ = lds;                                          // TS x TS x C bytes (reuses T/D)
 
     constexpr int TROW = Tile<C, PT>::ROW;
@@ -445,61 +499,10 @@ __global__ __launch_bounds__(64 * WAVES, 4) void lk_track_kernel(LkBatch batch, 
         // ---- 1. previous-image tile, Scharr tile, patch registers, normal matrix ----
         wave_lds_sync();
         const uint8_t *Ts = T + stage_tile<C, PT>(T, I, pitch, ipx - 1, ipy - 1, lane);
-        wave_lds_sync();
-        // Scharr tile: lane = (tile row, left / right half of its 22 pixels); the 3x3 window slides
-        // along the row, so a new entry costs one new column -- its vertical smooth 3a + 10b + 3c and
-        // vertical difference c - a -- instead of eight byte reads and per-entry index arithmetic:
-        //   dx(x) = S(x+2) - S(x),   dy(x) = 3 V(x) + 10 V(x+1) + 3 V(x+2)
-        if (lane < 2 * DT) {
-            constexpr int HALF = DT / 2;  // 11 pixels
-            const int r = lane >> 1, x0 = (lane & 1) * HALF;
-            const int Y = ipy + r;
-            const bool row_ok = Y >= 0 && Y < lh;
-            const bool cols_ok = ipx >= 0 && ipx + DT <= lw;  // wave-uniform: no per-entry column test needed
-            const uint8_t *t = Ts + r * TROW + x0 * C;
-            int *Drow = D + (r * DT + x0) * C;
-            // the whole 22x22 tile inside the image (wave-uniform, the usual case): no zeroing at all
-            const bool all_ok = cols_ok && ipy >= 0 && ipy + DT <= lh;
-            auto fill = [&](auto inside) {
-                constexpr bool INSIDE = decltype(inside)::value;
-#pragma unroll
-                for (int ch = 0; ch < C; ch++) {
-                    int S0, S1, V0, V1;
-                    {
-                        const int a = t[ch], b = t[TROW + ch], c = t[2 * TROW + ch];
-                        S0 = 3 * (a + c) + 10 * b;
-                        V0 = c - a;
-                    }
-                    {
-                        const int a = t[C + ch], b = t[TROW + C + ch], c = t[2 * TROW + C + ch];
-                        S1 = 3 * (a + c) + 10 * b;
-                        V1 = c - a;
-                    }
-#pragma unroll
-                    for (int px = 0; px < HALF; px++) {
-                        const int o = (px + 2) * C + ch;
-                        const int a = t[o], b = t[TROW + o], c = t[2 * TROW + o];
-                        const int S2 = 3 * (a + c) + 10 * b, V2 = c - a;
-                        const int dx = S2 - S0, dy = 3 * (V0 + V2) + 10 * V1;
-                        int e = half_pair<false>(dx, dy);  // (dx & 0xffff) | (dy << 16), one v_perm_b32
-                        if (!INSIDE) {
-                            const int X = ipx + x0 + px;
-                            if (!(row_ok && (cols_ok || (X >= 0 && X < lw))))
-                                e = 0;
-                        }
-                        Drow[px * C + ch] = e;
-                        S0 = S1;
-                        S1 = S2;
-                        V0 = V1;
-                        V1 = V2;
-                    }
-                }
-            };
-            if (uniform(all_ok))
-                fill(std::true_type());
-            else
-                fill(std::false_type());
-        }
+        // the Scharr derivatives of the window's 22x22 neighbourhood come from the derivative level
+        // (zero outside the image: the level's border is zero)
+        const int *D = reinterpret_cast<const int *>(
+            DB + stage_dtile<C>(DB, dprev + prm.doff[level], prm.dpitch[level], ipx, ipy, lane));
         wave_lds_sync();
 
         int Ivp[npairs(C)], Ixp[npairs(C)], Iyp[npairs(C)];  // packed int16 pairs (low = even element)
@@ -514,8 +517,9 @@ __global__ __launch_bounds__(64 * WAVES, 4) void lk_track_kernel(LkBatch batch, 
             load_row_packed<C>(lds, toff, t0);
             load_row_packed<C>(lds, toff + TROW, t1);
             lane_samples<C, W_BITS - 5>(t0, t1, (w00 & 0xffff) | (w10 << 16), (w01 & 0xffff) | (w11 << 16), Ivp);
-            const int *d0 = D + (wy * DT + wx) * C;
-            const int *d1 = d0 + DT * C;
+            constexpr int DROW = DTile<C>::ROW / 4;
+            const int *d0 = D + wy * DROW + wx * C;
+            const int *d1 = d0 + DROW;
             int ix[NE + 1], iy[NE + 1];
             ix[NE] = iy[NE] = 0;
             ForEachElem<C, NE>::run([&](auto kc) {
@@ -667,7 +671,7 @@ __global__ void grid_keypoints_kernel(int rows, int cols, int step, int nx, int 
 
 }  // namespace
 
-int svo_launch_lk_batch(svo_ctx *ctx, int n_jobs, const LkJob *jobs)
+int svo_launch_lk_batch(svo_ctx *ctx, int n_jobs, const LkJob *jobs, const svo_pyramid *geom)
 {
     if (n_jobs <= 0)
         return SVO_OK;
@@ -680,8 +684,9 @@ int svo_launch_lk_batch(svo_ctx *ctx, int n_jobs, const LkJob *jobs)
     for (int k = 0; k < n_jobs; k++) {
         batch.j[k] = jobs[k];
         n_max = jobs[k].n_cap > n_max ? jobs[k].n_cap : n_max;
-        if (jobs[k].prev.c != c || jobs[k].prev.levels != levels) {
-            svo_set_error("lk: the jobs of one launch must share channel count and pyramid depth");
+        if (jobs[k].prev.c != c || jobs[k].prev.levels != levels || jobs[k].prev.w[0] != geom->w ||
+            jobs[k].prev.h[0] != geom->h || !jobs[k].dprev) {
+            svo_set_error("lk: the jobs of one launch must share their pyramid geometry and carry derivative levels");
             return SVO_ERR_ARG;
         }
     }
@@ -695,6 +700,10 @@ int svo_launch_lk_batch(svo_ctx *ctx, int n_jobs, const LkJob *jobs)
     prm.eps_sq = 0.01 * 0.01;
     prm.eps_pre = 0.0101f;
     prm.min_eig_thr = (float)1e-4;
+    for (int l = 0; l < SVO_MAX_LEVELS; l++) {
+        prm.doff[l] = (int)geom->doff[l];
+        prm.dpitch[l] = geom->dpitch[l];
+    }
     dim3 grid(((n_max + 7) / 8 + WAVES - 1) / WAVES * 8, n_jobs), block(64 * WAVES);  // x: a multiple of 8, every XCD band has all its slots
     ScopedKernelTime t(ctx, SVO_K_LK);
     switch (c) {
@@ -712,14 +721,20 @@ int svo_launch_lk_batch(svo_ctx *ctx, int n_jobs, const LkJob *jobs)
     return SVO_OK;
 }
 
-int svo_launch_lk(svo_ctx *ctx, const PyrDev &prev, const PyrDev &next, const float *prev_pts, int n,
+int svo_launch_lk(svo_ctx *ctx, svo_pyramid *prev, const svo_pyramid *next, const float *prev_pts, int n,
                   float *next_pts, uint8_t *status, float *err, float *min_eig, const int *d_n)
 {
     if (n == 0)
         return SVO_OK;
+    if (!prev->has_deriv) {  // a pyramid built without its derivative levels: derive them now
+        int rc = svo_build_derivatives(ctx, 1, &prev);
+        if (rc)
+            return rc;
+    }
     LkJob job;
-    job.prev = prev;
-    job.next = next;
+    job.prev = prev->dev;
+    job.next = next->dev;
+    job.dprev = prev->dbase;
     job.prev_pts = prev_pts;
     job.n_cap = n;
     job.d_n = d_n;
@@ -727,7 +742,7 @@ int svo_launch_lk(svo_ctx *ctx, const PyrDev &prev, const PyrDev &next, const fl
     job.status = status;
     job.err = err;
     job.min_eig = min_eig;
-    return svo_launch_lk_batch(ctx, 1, &job);
+    return svo_launch_lk_batch(ctx, 1, &job, prev);
 }
 
 // number of lattice points of the reference's loop `for (v = s; v < dim - s; v += s)`
@@ -797,8 +812,9 @@ int svo_lk_track(svo_ctx *ctx, const svo_pyramid *prev, const svo_pyramid *next,
     if (n == 0)
         return SVO_OK;
     SVO_CHECK_ARG(prev_pts && next_pts && status);
+    svo_pyramid *pv = const_cast<svo_pyramid *>(prev);  // its derivative levels may be filled in on first use
     if (mem == SVO_MEM_DEVICE)
-        return svo_launch_lk(ctx, prev->dev, next->dev, prev_pts, n, next_pts, status, err, min_eig, nullptr);
+        return svo_launch_lk(ctx, pv, next, prev_pts, n, next_pts, status, err, min_eig, nullptr);
 
     int rc;
     if ((rc = ctx->s_a.ensure((size_t)n * 8)) || (rc = ctx->s_b.ensure((size_t)n * 8)) ||
@@ -806,7 +822,7 @@ int svo_lk_track(svo_ctx *ctx, const svo_pyramid *prev, const svo_pyramid *next,
         (rc = ctx->s_e.ensure((size_t)n * 4)))
         return rc;
     SVO_HIP(hipMemcpyAsync(ctx->s_a.p, prev_pts, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
-    rc = svo_launch_lk(ctx, prev->dev, next->dev, ctx->s_a.as<float>(), n, ctx->s_b.as<float>(),
+    rc = svo_launch_lk(ctx, pv, next, ctx->s_a.as<float>(), n, ctx->s_b.as<float>(),
                        ctx->s_c.as<uint8_t>(), ctx->s_d.as<float>(), ctx->s_e.as<float>(), nullptr);
     if (rc)
         return rc;

@@ -183,7 +183,127 @@ __global__ __launch_bounds__(PB) void fill_border_kernel(BorderJob job)
     }
 }
 
+// Scharr derivatives of every level in ONE launch: blockIdx.y walks the rows of all levels back to
+// back, blockIdx.z = job.  A thread produces four consecutive channel-bytes of a row = one aligned
+// 16-byte store of packed (dx | dy << 16); it reads three aligned dwords from each of the rows
+// y-1, y, y+1 of the padded level (the reflect-101 border supplies the neighbours of edge pixels).
+//   S(x) = 3 p(x, y-1) + 10 p(x, y) + 3 p(x, y+1),   V(x) = p(x, y+1) - p(x, y-1)
+//   dx(x) = S(x+1) - S(x-1),                           dy(x) = 3 V(x-1) + 10 V(x) + 3 V(x+1)
+// -- bit for bit what lk.hip derived per keypoint and level before (each pixel sat in ~5 keypoint
+// tiles per level; that Scharr tile was 17 % of the tracker's VALU instructions).
+struct DerivJob {
+    const uint8_t *lvl[SVO_LK_MAX_JOBS][SVO_MAX_LEVELS];  // pixel (0,0) of the padded levels
+    int *dlvl[SVO_LK_MAX_JOBS][SVO_MAX_LEVELS];            // element (0,0) of the derivative levels
+    int pitch[SVO_MAX_LEVELS], dpitch[SVO_MAX_LEVELS], w[SVO_MAX_LEVELS], h[SVO_MAX_LEVELS];
+    int row0[SVO_MAX_LEVELS + 1];                          // first blockIdx.y of each level
+    int levels;
+};
+
+template <int C> __global__ __launch_bounds__(PB) void scharr_kernel(DerivJob job)
+{
+    __builtin_amdgcn_s_setprio(3);  // short kernel: win issue arbitration against co-resident LK waves
+    int l = 0;
+    for (int i = 1; i < job.levels; i++)
+        l = (int)blockIdx.y >= job.row0[i] ? i : l;
+    const int y = blockIdx.y - job.row0[l], w = job.w[l];
+    const int q = blockIdx.x * PB + threadIdx.x;  // quad of channel-bytes 4q .. 4q+3 of the row
+    if (4 * q >= w * C)
+        return;
+    const int pitch = job.pitch[l];
+    const uint8_t *row = job.lvl[blockIdx.z][l] + (ptrdiff_t)y * pitch;  // 4-byte aligned (pad * C and pitch are)
+    uint32_t win[3][3];  // bytes 4q-4 .. 4q+7 of rows y-1, y, y+1
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const uint32_t *p = reinterpret_cast<const uint32_t *>(row + (ptrdiff_t)(r - 1) * pitch) + (q - 1);
+        win[r][0] = p[0];
+        win[r][1] = p[1];
+        win[r][2] = p[2];
+    }
+    auto byte_at = [&](int r, int pos) -> int { return (int)((win[r][pos >> 2] >> (8 * (pos & 3))) & 0xffu); };
+    // columns 4-C .. 7+C of the 12-byte window
+    int S[4 + 2 * C], V[4 + 2 * C];
+#pragma unroll
+    for (int i = 0; i < 4 + 2 * C; i++) {
+        const int pos = 4 - C + i;
+        const int a = byte_at(0, pos), b = byte_at(1, pos), c = byte_at(2, pos);
+        S[i] = 3 * (a + c) + 10 * b;
+        V[i] = c - a;
+    }
+    int out[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int dx = S[j + 2 * C] - S[j], dy = 3 * (V[j] + V[j + 2 * C]) + 10 * V[j + C];
+        out[j] = (int)__builtin_amdgcn_perm((unsigned)dy, (unsigned)dx, 0x05040100u);  // (dx & 0xffff) | (dy << 16)
+    }
+    int *drow = reinterpret_cast<int *>(reinterpret_cast<uint8_t *>(job.dlvl[blockIdx.z][l]) + (ptrdiff_t)y * job.dpitch[l]);
+    const int rem = w * C - 4 * q;  // elements of this row from 4q on
+    if (rem >= 4) {
+        typedef int int4v __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<int4v *>(drow + 4 * q) = int4v{out[0], out[1], out[2], out[3]};
+    } else {
+        for (int j = 0; j < rem; j++)
+            drow[4 * q + j] = out[j];
+    }
+}
+
+template <int C> static int launch_scharr(svo_ctx *ctx, int k, svo_pyramid *const *pyrs)
+{
+    const svo_pyramid *p0 = pyrs[0];
+    DerivJob job;
+    int rows = 0, wmax = 0;
+    for (int l = 0; l < SVO_MAX_LEVELS; l++) {
+        const bool on = l < p0->levels;
+        job.pitch[l] = p0->dev.pitch[l];
+        job.dpitch[l] = p0->dpitch[l];
+        job.w[l] = p0->dev.w[l];
+        job.h[l] = p0->dev.h[l];
+        job.row0[l] = rows;
+        if (on) {
+            rows += p0->dev.h[l];
+            wmax = p0->dev.w[l] > wmax ? p0->dev.w[l] : wmax;
+        }
+        for (int a = 0; a < SVO_LK_MAX_JOBS; a++) {
+            const svo_pyramid *p = pyrs[a < k ? a : 0];
+            job.lvl[a][l] = on ? p->dev.lvl[l] : nullptr;
+            job.dlvl[a][l] = on ? p->dbase + p->doff[l] : nullptr;
+        }
+    }
+    job.row0[SVO_MAX_LEVELS] = rows;
+    job.levels = p0->levels;
+    const int quads = (wmax * C + 3) / 4;
+    hipLaunchKernelGGL(scharr_kernel<C>, dim3((quads + PB - 1) / PB, rows, k), dim3(PB), 0, ctx->stream, job);
+    SVO_HIP(hipGetLastError());
+    return SVO_OK;
+}
+
 }  // namespace
+
+int svo_build_derivatives(svo_ctx *ctx, int k, svo_pyramid *const *pyrs)
+{
+    if (k <= 0)
+        return SVO_OK;
+    for (int a = 0; a < k; a++)
+        if (!pyrs[a]->dbase) {
+            svo_set_error("pyramid: created without derivative levels");
+            return SVO_ERR_STATE;
+        }
+    int rc;
+    switch (pyrs[0]->c) {
+    case 1:
+        rc = launch_scharr<1>(ctx, k, pyrs);
+        break;
+    case 3:
+        rc = launch_scharr<3>(ctx, k, pyrs);
+        break;
+    default:
+        svo_set_error("pyramid: derivative levels for 1 or 3 channels only");
+        return SVO_ERR_ARG;
+    }
+    if (rc == SVO_OK)
+        for (int a = 0; a < k; a++)
+            pyrs[a]->has_deriv = true;
+    return rc;
+}
 
 template <int C> static int build_levels(svo_ctx *ctx, int k, svo_pyramid *const *pyrs, const uint8_t *const *d_images)
 {
@@ -223,6 +343,10 @@ template <int C> static int build_levels(svo_ctx *ctx, int k, svo_pyramid *const
         hipLaunchKernelGGL(fill_border_kernel<C>, grid, dim3(PB), 0, ctx->stream, job);
     }
     SVO_HIP(hipGetLastError());
+    for (int a = 0; a < k; a++)
+        pyrs[a]->has_deriv = false;
+    if (p0->want_deriv && p0->dbase && (C == 1 || C == 3))
+        return svo_build_derivatives(ctx, k, pyrs);
     return SVO_OK;
 }
 
@@ -237,7 +361,7 @@ int svo_build_pyramids_from_device(svo_ctx *ctx, int k, svo_pyramid *const *pyrs
     }
     for (int a = 1; a < k; a++)
         if (pyrs[a]->w != pyrs[0]->w || pyrs[a]->h != pyrs[0]->h || pyrs[a]->c != pyrs[0]->c ||
-            pyrs[a]->levels != pyrs[0]->levels) {
+            pyrs[a]->levels != pyrs[0]->levels || pyrs[a]->want_deriv != pyrs[0]->want_deriv) {
             svo_set_error("pyramid: the pyramids of one launch must share their geometry");
             return SVO_ERR_ARG;
         }
@@ -263,6 +387,14 @@ extern "C" {
 
 int svo_pyramid_create(svo_ctx *ctx, int width, int height, int channels, int levels,
                        svo_pyramid **out)
+{
+    return svo_pyramid_create_ex(ctx, width, height, channels, levels, true, out);
+}
+
+}  // extern "C"
+
+int svo_pyramid_create_ex(svo_ctx *ctx, int width, int height, int channels, int levels, bool want_deriv,
+                          svo_pyramid **out)
 {
     SVO_CHECK_ARG(ctx && out);
     SVO_CHECK_ARG(width >= 2 * SVO_LK_WIN + 2 && height >= 2 * SVO_LK_WIN + 2);
@@ -305,9 +437,32 @@ int svo_pyramid_create(svo_ctx *ctx, int width, int height, int channels, int le
     p->dev.c = channels;
     for (int l = 0; l < SVO_MAX_LEVELS; l++)
         p->dev.lvl[l] = l < levels ? p->origin(l) : nullptr;
+    p->want_deriv = want_deriv && (channels == 1 || channels == 3);
+    if (p->want_deriv) {
+        size_t ints = 0;
+        for (int l = 0; l < levels; l++) {
+            p->dpitch[l] = (((p->dev.w[l] + 2 * SVO_DERIV_PAD) * channels * 4 + 15) / 16) * 16;
+            const size_t lvl_ints = (size_t)(p->dpitch[l] / 4) * (p->dev.h[l] + 2 * SVO_DERIV_PAD);
+            p->doff[l] = ints + (size_t)SVO_DERIV_PAD * (p->dpitch[l] / 4) + (size_t)SVO_DERIV_PAD * channels;
+            ints += (lvl_ints + 63) & ~(size_t)63;  // levels start 256-byte aligned
+        }
+        const size_t dbytes = ints * 4 + 1024;  // slack: 16-byte tile loads run a few vectors past a row
+        e = hipMalloc((void **)&p->dbase, dbytes);
+        if (e == hipSuccess)
+            e = hipMemsetAsync(p->dbase, 0, dbytes, ctx->stream);  // the zero border is never written again
+        if (e != hipSuccess) {
+            (void)hipFree(p->dbase);
+            (void)hipFree(p->base);
+            delete p;
+            svo_set_error("hipMalloc derivative levels -> %s", hipGetErrorString(e));
+            return SVO_ERR_HIP;
+        }
+    }
     *out = p;
     return SVO_OK;
 }
+
+extern "C" {
 
 int svo_pyramid_destroy(svo_ctx *ctx, svo_pyramid *pyr)
 {
@@ -319,6 +474,8 @@ int svo_pyramid_destroy(svo_ctx *ctx, svo_pyramid *pyr)
     }
     if (pyr->base)
         (void)hipFree(pyr->base);
+    if (pyr->dbase)
+        (void)hipFree(pyr->dbase);
     delete pyr;
     return SVO_OK;
 }

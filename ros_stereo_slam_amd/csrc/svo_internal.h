@@ -59,7 +59,19 @@ struct svo_pyramid {
     }
     size_t bytes;
     PyrDev dev;
+    // Scharr derivative levels (what cv::calcOpticalFlowPyrLK materialises per call for its first image):
+    // packed (dx & 0xffff) | (dy << 16) per pixel and channel, every level with a ZERO border of
+    // SVO_DERIV_PAD pixels (the reference pads its derivative buffer with zeros) and a 16-byte-aligned
+    // pitch.  Filled when the levels are built if want_deriv; LK needs them for its FIRST pyramid only.
+    int *dbase = nullptr;
+    size_t doff[SVO_MAX_LEVELS] = {0, 0, 0, 0};  // in ints: element (0, 0) of each level
+    int dpitch[SVO_MAX_LEVELS] = {0, 0, 0, 0};   // bytes
+    bool want_deriv = true, has_deriv = false;
 };
+#define SVO_DERIV_PAD 32
+int svo_build_derivatives(svo_ctx *ctx, int k, svo_pyramid *const *pyrs);
+int svo_pyramid_create_ex(svo_ctx *ctx, int width, int height, int channels, int levels, bool want_deriv,
+                          svo_pyramid **out);
 
 // growable device scratch
 struct DevBuf {
@@ -113,6 +125,7 @@ int svo_build_pyramids_from_device(svo_ctx *ctx, int k, svo_pyramid *const *pyrs
 // lk.hip
 struct LkJob {  // one pyramidal-LK pass: prev/next pyramids, points in, points / status / err / minEig out
     PyrDev prev, next;
+    const int *dprev;  // derivative levels of prev (svo_pyramid::dbase); geometry: svo_pyramid::doff / dpitch
     const float *prev_pts;
     int n_cap;
     const int *d_n;  // live point count on the device, or null (n_cap points)
@@ -123,8 +136,9 @@ struct LkJob {  // one pyramidal-LK pass: prev/next pyramids, points in, points 
 struct LkBatch {
     LkJob j[SVO_LK_MAX_JOBS];
 };
-int svo_launch_lk_batch(svo_ctx *ctx, int n_jobs, const LkJob *jobs);
-int svo_launch_lk(svo_ctx *ctx, const PyrDev &prev, const PyrDev &next, const float *prev_pts,
+// `geom`: any pyramid with the geometry of the jobs' prev pyramids (derivative level offsets / pitches)
+int svo_launch_lk_batch(svo_ctx *ctx, int n_jobs, const LkJob *jobs, const svo_pyramid *geom);
+int svo_launch_lk(svo_ctx *ctx, svo_pyramid *prev, const svo_pyramid *next, const float *prev_pts,
                   int n, float *next_pts, uint8_t *status, float *err, float *min_eig,
                   const int *d_n = nullptr);
 int svo_launch_grid(svo_ctx *ctx, int rows, int cols, int step, float *out_xy, int cap);
