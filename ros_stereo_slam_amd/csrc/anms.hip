@@ -44,9 +44,15 @@ struct AnmsBatch {
     AnmsJob j[SVO_LK_MAX_JOBS];
 };
 
+// KPW keypoints per wavefront in the all-pairs passes: a stripe of the other keypoints is loaded once
+// and compared against all KPW of them (an eighth of the loads), and a launch has an eighth of the
+// waves -- a wave per keypoint was 35 k waves per launch, every one of which queued for a wave slot
+// beside the tracking launches of the other contexts.
+constexpr int KPW = 8;
+
 // order[rank] = i, rank = #keypoints sorting before i (response descending, index ascending);
 // also emits the sorted (x, y, response) triples the radius pass streams through.
-__global__ __launch_bounds__(256) void anms_rank_kernel(AnmsBatch batch, int n)
+__global__ __launch_bounds__(64) void anms_rank_kernel(AnmsBatch batch, int n)
 {
     __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     const AnmsJob &job = batch.j[blockIdx.y];
@@ -55,108 +61,163 @@ __global__ __launch_bounds__(256) void anms_rank_kernel(AnmsBatch batch, int n)
     int *__restrict__ order = job.order;
     float4 *__restrict__ sorted = job.sorted;
     const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x;  // one wave per workgroup (see svo_launch_anms_batch)
-    if (i >= n)
+    const int i0 = blockIdx.x * KPW;  // one wave per workgroup (see svo_launch_anms_batch); KPW | 64
+    if (i0 >= n)
         return;
-    const float ri = resp[i];
-    int cnt = 0;
-    // "j sorts before i"  <=>  r_j > r_i, or r_j == r_i and j < i.  Whole 64-entry stripes before i's
-    // own stripe need one compare (>=), the ones after it one compare (>); only i's stripe needs the
-    // tie-break.  Scalar loop bounds: no per-lane range test except in the last, partial stripe.
+    float ri[KPW];
+    int cnt[KPW];
+#pragma unroll
+    for (int q = 0; q < KPW; q++) {
+        ri[q] = resp[min(i0 + q, n - 1)];
+        cnt[q] = 0;
+    }
+    // "j sorts before i"  <=>  r_j > r_i, or r_j == r_i and j < i.  Whole 64-entry stripes before the
+    // keypoints' own stripe need one compare (>=), the ones after it one compare (>); only their own
+    // stripe (the same for all KPW: i0 is a multiple of KPW, KPW divides 64) needs the tie-break.
     const float *__restrict__ rl = resp + lane;
-    const int own = (i >> 6) << 6;
-#pragma unroll 8
-    for (int j0 = 0; j0 < own; j0 += 64)
-        cnt += rl[j0] >= ri ? 1 : 0;
+    const int own = (i0 >> 6) << 6;
+#pragma unroll 2
+    for (int j0 = 0; j0 < own; j0 += 64) {
+        const float rj = rl[j0];
+#pragma unroll
+        for (int q = 0; q < KPW; q++)
+            cnt[q] += rj >= ri[q] ? 1 : 0;
+    }
     {
         const int j = own + lane;
         if (j < n) {
             const float rj = rl[own];
-            cnt += (rj > ri || (rj == ri && j < i)) ? 1 : 0;
+#pragma unroll
+            for (int q = 0; q < KPW; q++)
+                cnt[q] += (rj > ri[q] || (rj == ri[q] && j < i0 + q)) ? 1 : 0;
         }
     }
     int j0 = own + 64;
-#pragma unroll 8
-    for (; j0 + 64 <= n; j0 += 64)
-        cnt += rl[j0] > ri ? 1 : 0;
-    if (j0 < n && j0 + lane < n)
-        cnt += rl[j0] > ri ? 1 : 0;
-    const int rank = wave_sum_int(cnt);
-    if (lane == 0) {
-        order[rank] = i;
-        const float2 p = xy[i];
-        sorted[rank] = make_float4(p.x, p.y, ri, 0.f);
+#pragma unroll 2
+    for (; j0 + 64 <= n; j0 += 64) {
+        const float rj = rl[j0];
+#pragma unroll
+        for (int q = 0; q < KPW; q++)
+            cnt[q] += rj > ri[q] ? 1 : 0;
+    }
+    if (j0 < n && j0 + lane < n) {
+        const float rj = rl[j0];
+#pragma unroll
+        for (int q = 0; q < KPW; q++)
+            cnt[q] += rj > ri[q] ? 1 : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < KPW; q++) {
+        const int rank = wave_sum_int(cnt[q]);
+        if (lane == 0 && i0 + q < n) {
+            order[rank] = i0 + q;
+            const float2 p = xy[i0 + q];
+            sorted[rank] = make_float4(p.x, p.y, ri[q], 0.f);
+        }
     }
 }
 
 // squared suppression radius of the s-th sorted keypoint (DBL_MAX when nothing dominates it)
-__global__ __launch_bounds__(256) void anms_radius_kernel(AnmsBatch batch, int n)
+__global__ __launch_bounds__(64) void anms_radius_kernel(AnmsBatch batch, int n)
 {
     __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     const float4 *__restrict__ sorted = batch.j[blockIdx.y].sorted;
     double *__restrict__ radius_sq = batch.j[blockIdx.y].radius;
     const int lane = threadIdx.x & 63;
-    const int s = blockIdx.x;
-    if (s >= n)
+    const int s0 = blockIdx.x * KPW;
+    if (s0 >= n)
         return;
-    const float4 me = sorted[s];
-    const float thr = me.z * 1.11f;
-    double best = DBL_MAX;
-    for (int j0 = 0; j0 < s; j0 += 64) {
+    float mx[KPW], my[KPW], thr[KPW];
+    double best[KPW];
+    unsigned active = 0;  // wave-uniform: keypoints whose scan has not ended yet
+#pragma unroll
+    for (int q = 0; q < KPW; q++) {
+        const float4 me = sorted[min(s0 + q, n - 1)];
+        mx[q] = me.x;
+        my[q] = me.y;
+        thr[q] = me.z * 1.11f;
+        best[q] = DBL_MAX;
+        if (s0 + q < n && s0 + q > 0)
+            active |= 1u << q;
+    }
+    for (int j0 = 0; j0 < s0 + KPW - 1 && active; j0 += 64) {
         const int j = j0 + lane;
-        bool dom = false;
-        if (j < s) {
-            const float4 o = sorted[j];
-            dom = o.z > thr;
-            if (dom) {
-                const float dx = me.x - o.x, dy = me.y - o.y;
-                const double d = (double)dx * dx + (double)dy * dy;
-                best = d < best ? d : best;
+        const float4 o = sorted[min(j, n - 1)];
+#pragma unroll
+        for (int q = 0; q < KPW; q++) {
+            if (!((active >> q) & 1u))
+                continue;  // wave-uniform
+            bool dom = false;
+            if (j < s0 + q) {
+                dom = o.z > thr[q];
+                if (dom) {
+                    const float dx = mx[q] - o.x, dy = my[q] - o.y;
+                    const double d = (double)dx * dx + (double)dy * dy;
+                    best[q] = d < best[q] ? d : best[q];
+                }
             }
+            // sorted by response: once a whole stripe fails, nothing later dominates either; and the
+            // scan of keypoint s ends with the stripe that holds s - 1
+            if (!__any(dom) || j0 + 64 >= s0 + q)
+                active &= ~(1u << q);
         }
-        // sorted by response: once a whole stripe fails, nothing later dominates either
-        if (!__any(dom))
-            break;
     }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const double o = __shfl_xor(best, off);
-        best = o < best ? o : best;
+    for (int q = 0; q < KPW; q++) {
+        double b = best[q];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double o = __shfl_xor(b, off);
+            b = o < b ? o : b;
+        }
+        if (lane == 0 && s0 + q < n)
+            radius_sq[s0 + q] = b;
     }
-    if (lane == 0)
-        radius_sq[s] = best;
 }
 
 // decision radius = the (keep+1)-th largest radius
-__global__ __launch_bounds__(256) void anms_decide_kernel(AnmsBatch batch, int n, int keep)
+__global__ __launch_bounds__(64) void anms_decide_kernel(AnmsBatch batch, int n, int keep)
 {
     __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     const double *__restrict__ radius_sq = batch.j[blockIdx.y].radius;
     double *__restrict__ decision = batch.j[blockIdx.y].decision;
     const int lane = threadIdx.x & 63;
-    const int s = blockIdx.x;
-    if (s >= n)
+    const int s0 = blockIdx.x * KPW;
+    if (s0 >= n)
         return;
-    const double ri = radius_sq[s];
-    int gt = 0, ge = 0;
+    double ri[KPW];
+    int gt[KPW], ge[KPW];
+#pragma unroll
+    for (int q = 0; q < KPW; q++) {
+        ri[q] = radius_sq[min(s0 + q, n - 1)];
+        gt[q] = ge[q] = 0;
+    }
     const double *__restrict__ rl = radius_sq + lane;
     int j0 = 0;
-#pragma unroll 8
+#pragma unroll 2
     for (; j0 + 64 <= n; j0 += 64) {  // scalar bounds: no per-lane range test in the body
         const double rj = rl[j0];
-        gt += rj > ri ? 1 : 0;
-        ge += rj >= ri ? 1 : 0;
+#pragma unroll
+        for (int q = 0; q < KPW; q++) {
+            gt[q] += rj > ri[q] ? 1 : 0;
+            ge[q] += rj >= ri[q] ? 1 : 0;
+        }
     }
     if (j0 + lane < n) {
         const double rj = rl[j0];
-        gt += rj > ri ? 1 : 0;
-        ge += rj >= ri ? 1 : 0;
+#pragma unroll
+        for (int q = 0; q < KPW; q++) {
+            gt[q] += rj > ri[q] ? 1 : 0;
+            ge[q] += rj >= ri[q] ? 1 : 0;
+        }
     }
-    gt = wave_sum_int(gt);
-    ge = wave_sum_int(ge);
-    // radiiSorted[keep] (descending, 0-based) == ri  <=>  gt <= keep < ge
-    if (lane == 0 && gt <= keep && keep < ge)
-        *decision = ri;  // every wave that qualifies writes the same value
+#pragma unroll
+    for (int q = 0; q < KPW; q++) {
+        const int g = wave_sum_int(gt[q]), e = wave_sum_int(ge[q]);
+        // radiiSorted[keep] (descending, 0-based) == ri  <=>  gt <= keep < ge
+        if (lane == 0 && s0 + q < n && g <= keep && keep < e)
+            *decision = ri[q];  // every keypoint that qualifies writes the same value
+    }
 }
 
 __global__ __launch_bounds__(256) void anms_flag_kernel(AnmsBatch batch, int n)
@@ -239,7 +300,7 @@ int svo_launch_anms_batch(svo_ctx *ctx, int k, const float *const *xy, const flo
     }
     // single-wave workgroups: beside a tracking launch (single-wave workgroups that take every freed wave
     // slot at once) a multi-wave workgroup waits until one CU has a slot free on several SIMDs together
-    const dim3 wgrid(n, k), tgrid((n + 63) / 64, k), block(64);
+    const dim3 wgrid((n + KPW - 1) / KPW, k), tgrid((n + 63) / 64, k), block(64);
     hipLaunchKernelGGL(anms_rank_kernel, wgrid, block, 0, ctx->stream, batch, n);
     if (n <= keep) {
         // everything is kept, in sorted order

@@ -25,6 +25,7 @@ using namespace svo;
 namespace {
 
 constexpr int M = 7;
+constexpr int SCORE_WAVES = 384;  // scoring waves per job and phase; each takes every SCORE_WAVES-th model
 constexpr int SOLVE_T = 16;  // 11 KB of LDS per workgroup: fits beside the waves of a tracking launch (44 KB with 64 waited for a CU to drain)
 constexpr int PHASE_A = 64;
 
@@ -358,16 +359,20 @@ __global__ __launch_bounds__(64, 4) void fr_score_kernel(FrBatch batch, int it0,
     const double confidence = job.confidence;
     unsigned *ticket = job.ticket;
     const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(blockIdx.x);  // one wave per workgroup
-    const int it = it0 + w / 3, k = w - (w / 3) * 3;
     const bool skip_phase = it0 > 0 && st->done;  // the loop ended in the first phase
     const int n = d_n ? *d_n : n_host;
-    if (it < it1 && !skip_phase) {
-        const int nm = nmodels[it];
-        if (k >= nm) {
-            if (lane == 0)
-                counts[it * 3 + k] = 0;
-        } else {
+    // a wave takes the models w, w + gridDim.x, ...: the second phase (936 iterations x 3 models) is
+    // usually skipped, and a grid of one wave per model made 45 k waves per launch queue for wave slots
+    // beside the tracking launches only to exit
+    if (!skip_phase)
+        for (int w = __builtin_amdgcn_readfirstlane(blockIdx.x); w < (it1 - it0) * 3; w += gridDim.x) {
+            const int it = it0 + w / 3, k = w - (w / 3) * 3;
+            const int nm = nmodels[it];
+            if (k >= nm) {
+                if (lane == 0)
+                    counts[it * 3 + k] = 0;
+                continue;
+            }
             double F[9];
 #pragma unroll
             for (int i = 0; i < 9; i++)
@@ -382,7 +387,6 @@ __global__ __launch_bounds__(64, 4) void fr_score_kernel(FrBatch batch, int it0,
             if (lane == 0)
                 counts[it * 3 + k] = cnt;
         }
-    }
     // every workgroup takes a ticket once its counts are out; the holder of the last one sees them all
     // (a skipped phase skips the tickets too: `done` is the same for every workgroup of the launch)
     if (skip_phase)
@@ -503,7 +507,8 @@ int svo_launch_fransac_batch(svo_ctx *ctx, int n_jobs, const svo_fransac_job *jo
         const int iters = it1 - it0;
         hipLaunchKernelGGL(fr_solve_kernel, dim3((iters + SOLVE_T - 1) / SOLVE_T, nb), dim3(SOLVE_T), 0, ctx->stream,
                            batch, it0, it1);
-        hipLaunchKernelGGL(fr_score_kernel, dim3(iters * 3, nb), dim3(64), 0, ctx->stream, batch, it0, it1);
+        const int score_waves = iters * 3 < SCORE_WAVES ? iters * 3 : SCORE_WAVES;
+        hipLaunchKernelGGL(fr_score_kernel, dim3(score_waves, nb), dim3(64), 0, ctx->stream, batch, it0, it1);
     }
     hipLaunchKernelGGL(fr_mask_kernel, dim3((cap_max + 63) / 64, nb), dim3(64), 0, ctx->stream, batch);
     SVO_HIP(hipGetLastError());

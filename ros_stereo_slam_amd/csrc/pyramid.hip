@@ -106,7 +106,12 @@ __global__ __launch_bounds__(PB) void pyr_down_kernel(PyrPtrs ptrs, int spitch, 
 }
 
 
-// image (row stride w*C) -> padded level 0, one thread per output dword
+constexpr int ROWS_PER_BLOCK = 8;
+template <int C>
+__device__ __forceinline__ void pad_copy_row(const uint8_t *__restrict__ src, uint8_t *__restrict__ padded, int w, int h,
+                                             int pitch, int row, int d);
+
+// image (row stride w*C) -> padded level 0, one thread per output dword and row
 template <int C>
 __global__ __launch_bounds__(PB) void pad_copy_kernel(PyrPtrs ptrs, int w, int h, int pitch)
 {
@@ -114,10 +119,20 @@ __global__ __launch_bounds__(PB) void pad_copy_kernel(PyrPtrs ptrs, int w, int h
     const uint8_t *__restrict__ src = ptrs.src[blockIdx.z];
     uint8_t *__restrict__ padded = ptrs.dst[blockIdx.z];
     const int dwords_per_row = pitch >> 2;
-    const int row = blockIdx.y;  // 0 .. h + 2*PAD - 1
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= dwords_per_row)
         return;
+    // ROWS_PER_BLOCK rows per workgroup: these byte movers are bound by workgroup dispatch, not by
+    // bandwidth (a wave per 256 bytes was 83 k waves per image: beside a tracking launch every one of
+    // them queues for a wave slot)
+    for (int row = blockIdx.y * ROWS_PER_BLOCK, rend = min(row + ROWS_PER_BLOCK, h + 2 * SVO_PYR_PAD); row < rend; row++)
+        pad_copy_row<C>(src, padded, w, h, pitch, row, d);
+}
+
+template <int C>
+__device__ __forceinline__ void pad_copy_row(const uint8_t *__restrict__ src, uint8_t *__restrict__ padded, int w, int h,
+                                             int pitch, int row, int d)
+{
     const int Y = reflect101(row - SVO_PYR_PAD, h);
     const uint8_t *srow = src + (size_t)Y * w * C;
     uint32_t out = 0;
@@ -149,6 +164,9 @@ struct BorderJob {
     int levels_m1;  // blockIdx.z = job * levels_m1 + (level - 1)
 };
 
+template <int C>
+__device__ __forceinline__ void fill_border_row(uint8_t *__restrict__ level, int w, int h, int pitch, int row, int d);
+
 // fills the reflect-101 border of levels 1.. (blockIdx.z = level - 1) from their interior
 template <int C>
 __global__ __launch_bounds__(PB) void fill_border_kernel(BorderJob job)
@@ -156,19 +174,23 @@ __global__ __launch_bounds__(PB) void fill_border_kernel(BorderJob job)
     __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     const int jb = blockIdx.z / job.levels_m1, l = blockIdx.z - jb * job.levels_m1 + 1;
     const int w = job.w[l], h = job.h[l], pitch = job.pitch[l];
-    const int row = blockIdx.y;
-    if (row >= h + 2 * SVO_PYR_PAD)
-        return;
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= (pitch >> 2))
         return;
+    for (int row = blockIdx.y * ROWS_PER_BLOCK, rend = min(row + ROWS_PER_BLOCK, h + 2 * SVO_PYR_PAD); row < rend; row++)
+        fill_border_row<C>(job.padded[jb][l], w, h, pitch, row, d);
+}
+
+template <int C>
+__device__ __forceinline__ void fill_border_row(uint8_t *__restrict__ level, int w, int h, int pitch, int row, int d)
+{
     const bool interior_row = row >= SVO_PYR_PAD && row < SVO_PYR_PAD + h;
     const int cb0 = d * 4;
     if (interior_row && cb0 >= SVO_PYR_PAD * C && cb0 + 3 < (SVO_PYR_PAD + w) * C)
         return;  // dword entirely inside the image: already written by pyr_down
-    uint8_t *prow = job.padded[jb][l] + (size_t)row * pitch;
+    uint8_t *prow = level + (size_t)row * pitch;
     const int Y = reflect101(row - SVO_PYR_PAD, h);
-    const uint8_t *srow = job.padded[jb][l] + (size_t)(Y + SVO_PYR_PAD) * pitch + SVO_PYR_PAD * C;
+    const uint8_t *srow = level + (size_t)(Y + SVO_PYR_PAD) * pitch + SVO_PYR_PAD * C;
 #pragma unroll
     for (int b = 0; b < 4; b++) {
         int cb = cb0 + b;
@@ -195,9 +217,13 @@ struct DerivJob {
     const uint8_t *lvl[SVO_LK_MAX_JOBS][SVO_MAX_LEVELS];  // pixel (0,0) of the padded levels
     int *dlvl[SVO_LK_MAX_JOBS][SVO_MAX_LEVELS];            // element (0,0) of the derivative levels
     int pitch[SVO_MAX_LEVELS], dpitch[SVO_MAX_LEVELS], w[SVO_MAX_LEVELS], h[SVO_MAX_LEVELS];
-    int row0[SVO_MAX_LEVELS + 1];                          // first blockIdx.y of each level
+    int row0[SVO_MAX_LEVELS + 1];                          // first blockIdx.y of each level (ROWS_PER_BLOCK rows each)
     int levels;
 };
+
+template <int C>
+__device__ __forceinline__ void scharr_row(const uint8_t *__restrict__ lvl, int *__restrict__ dlvl, int pitch, int dpitch,
+                                           int w, int y, int q);
 
 template <int C> __global__ __launch_bounds__(PB) void scharr_kernel(DerivJob job)
 {
@@ -205,12 +231,21 @@ template <int C> __global__ __launch_bounds__(PB) void scharr_kernel(DerivJob jo
     int l = 0;
     for (int i = 1; i < job.levels; i++)
         l = (int)blockIdx.y >= job.row0[i] ? i : l;
-    const int y = blockIdx.y - job.row0[l], w = job.w[l];
+    const int w = job.w[l];
     const int q = blockIdx.x * PB + threadIdx.x;  // quad of channel-bytes 4q .. 4q+3 of the row
     if (4 * q >= w * C)
         return;
     const int pitch = job.pitch[l];
-    const uint8_t *row = job.lvl[blockIdx.z][l] + (ptrdiff_t)y * pitch;  // 4-byte aligned (pad * C and pitch are)
+    // ROWS_PER_BLOCK rows per workgroup (see pad_copy_kernel)
+    for (int y = (blockIdx.y - job.row0[l]) * ROWS_PER_BLOCK, yend = min(y + ROWS_PER_BLOCK, job.h[l]); y < yend; y++)
+        scharr_row<C>(job.lvl[blockIdx.z][l], job.dlvl[blockIdx.z][l], pitch, job.dpitch[l], w, y, q);
+}
+
+template <int C>
+__device__ __forceinline__ void scharr_row(const uint8_t *__restrict__ lvl, int *__restrict__ dlvl, int pitch, int dpitch,
+                                           int w, int y, int q)
+{
+    const uint8_t *row = lvl + (ptrdiff_t)y * pitch;  // 4-byte aligned (pad * C and pitch are)
     uint32_t win[3][3];  // bytes 4q-4 .. 4q+7 of rows y-1, y, y+1
 #pragma unroll
     for (int r = 0; r < 3; r++) {
@@ -235,7 +270,7 @@ template <int C> __global__ __launch_bounds__(PB) void scharr_kernel(DerivJob jo
         const int dx = S[j + 2 * C] - S[j], dy = 3 * (V[j] + V[j + 2 * C]) + 10 * V[j + C];
         out[j] = (int)__builtin_amdgcn_perm((unsigned)dy, (unsigned)dx, 0x05040100u);  // (dx & 0xffff) | (dy << 16)
     }
-    int *drow = reinterpret_cast<int *>(reinterpret_cast<uint8_t *>(job.dlvl[blockIdx.z][l]) + (ptrdiff_t)y * job.dpitch[l]);
+    int *drow = reinterpret_cast<int *>(reinterpret_cast<uint8_t *>(dlvl) + (ptrdiff_t)y * dpitch);
     const int rem = w * C - 4 * q;  // elements of this row from 4q on
     if (rem >= 4) {
         typedef int int4v __attribute__((ext_vector_type(4)));
@@ -259,7 +294,7 @@ template <int C> static int launch_scharr(svo_ctx *ctx, int k, svo_pyramid *cons
         job.h[l] = p0->dev.h[l];
         job.row0[l] = rows;
         if (on) {
-            rows += p0->dev.h[l];
+            rows += (p0->dev.h[l] + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;  // in workgroups
             wmax = p0->dev.w[l] > wmax ? p0->dev.w[l] : wmax;
         }
         for (int a = 0; a < SVO_LK_MAX_JOBS; a++) {
@@ -315,7 +350,7 @@ template <int C> static int build_levels(svo_ctx *ctx, int k, svo_pyramid *const
             pp.src[a] = d_images[a < k ? a : 0];
             pp.dst[a] = pyrs[a < k ? a : 0]->base + pyrs[a < k ? a : 0]->off[0];
         }
-        dim3 grid(((d.pitch[0] >> 2) + PB - 1) / PB, d.h[0] + 2 * SVO_PYR_PAD, k);
+        dim3 grid(((d.pitch[0] >> 2) + PB - 1) / PB, (d.h[0] + 2 * SVO_PYR_PAD + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, k);
         hipLaunchKernelGGL(pad_copy_kernel<C>, grid, dim3(PB), 0, ctx->stream, pp, d.w[0], d.h[0], d.pitch[0]);
     }
     for (int l = 1; l < p0->levels; l++) {
@@ -339,7 +374,8 @@ template <int C> static int build_levels(svo_ctx *ctx, int k, svo_pyramid *const
             job.h[l] = d.h[l];
         }
         job.levels_m1 = p0->levels - 1;
-        dim3 grid(((d.pitch[1] >> 2) + PB - 1) / PB, d.h[1] + 2 * SVO_PYR_PAD, (p0->levels - 1) * k);
+        dim3 grid(((d.pitch[1] >> 2) + PB - 1) / PB, (d.h[1] + 2 * SVO_PYR_PAD + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK,
+                  (p0->levels - 1) * k);
         hipLaunchKernelGGL(fill_border_kernel<C>, grid, dim3(PB), 0, ctx->stream, job);
     }
     SVO_HIP(hipGetLastError());
