@@ -968,8 +968,14 @@ static int run_chunk_group(svo_chunk_job **jobs, int k)
     for (int f = 0; f < n_frames_max; f++) {
         // ---- pyramids + ONE tracking launch for all the chunks still running ----
         LkJob lk[SVO_LK_MAX_JOBS];
-        svo_pyramid *pyrs[SVO_LK_MAX_JOBS];
-        const uint8_t *imgs[SVO_LK_MAX_JOBS];
+        // the pyramids of this step: the left images first, then -- in the same set of launches -- the
+        // right images of the same chunks.  A right pyramid is only read if its chunk turns out to keyframe
+        // in this step (about half of them do), but built here it costs workgroups, not launches: beside the
+        // other contexts' tracking launches every launch of this latency chain waits for its wave slots.
+        svo_pyramid *pyrs[2 * SVO_LK_MAX_JOBS];
+        const uint8_t *imgs[2 * SVO_LK_MAX_JOBS];
+        svo_pyramid *rpyr[SVO_LK_MAX_JOBS];
+        const uint8_t *rimg0[SVO_LK_MAX_JOBS];
         int nl = 0;
         for (GS &g : gs) {
             if (!g.active || f >= g.j->n_frames) {
@@ -989,6 +995,8 @@ static int run_chunk_group(svo_chunk_job **jobs, int k)
             }
             pyrs[nl] = v->pyr_cur;
             imgs[nl] = g.j->lefts[f];
+            rpyr[nl] = v->pyr_right;
+            rimg0[nl] = g.j->rights[f];
             LkJob &q = lk[nl++];
             q.prev = v->pyr_ref->dev;
             q.next = v->pyr_cur->dev;
@@ -1003,7 +1011,11 @@ static int run_chunk_group(svo_chunk_job **jobs, int k)
         }
         if (nl == 0)
             break;
-        if ((rc = svo_build_pyramids_from_device(ctx, nl, pyrs, imgs)) ||
+        for (int a = 0; a < nl; a++) {
+            pyrs[nl + a] = rpyr[a];
+            imgs[nl + a] = rimg0[a];
+        }
+        if ((rc = svo_build_pyramids_from_device(ctx, 2 * nl, pyrs, imgs)) ||
             (rc = svo_on_lk_stream(ctx, [&]() { return svo_launch_lk_batch(ctx, nl, lk, pyrs[0]); })))
             return rc;
         // ---- filters and PnP: every stage is ONE set of launches for all the chunks ----
@@ -1156,8 +1168,8 @@ static int run_chunk_group(svo_chunk_job **jobs, int k)
                 o3d[a] = v->ref3d;
                 nout[a] = &v->nref;
             }
-            if ((rc = svo_build_pyramids_from_device(ctx, nk, rights, rimg)) ||
-                (rc = stereo_triangulate_batch(nk, vs, lefts, rights, Rts, o2d, o3d, nout)))
+            (void)rimg;  // the right pyramids of this step were built with the left ones
+            if ((rc = stereo_triangulate_batch(nk, vs, lefts, rights, Rts, o2d, o3d, nout)))
                 return rc;
         }
         for (GS &g : gs) {

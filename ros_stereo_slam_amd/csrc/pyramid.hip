@@ -1,14 +1,25 @@
 // pyramid.hip -- 5-tap Gaussian pyramid (the pyrDown cv::calcOpticalFlowPyrLK applies to
-// both images on every call; reference call sites src/tracking.cpp:18,52).
+// both images on every call; reference call sites src/tracking.cpp:18,52) and the Scharr
+// derivative levels of the images that serve as a tracking pass's FIRST image.
 //
 // HBM layout: every level is stored with a reflect-101 border of SVO_PYR_PAD pixels and a
 // 16-byte-aligned row pitch (what cv::buildOpticalFlowPyramid does with pyrBorder =
 // BORDER_REFLECT_101), so the LK kernel stages its tiles with aligned 16-byte loads.
 //
-// Kernels: pad_copy (image -> padded level 0), pyr_down (one workgroup per 32x8 output
-// tile; the (2*32+3) x (2*8+3) source tile is staged in LDS with row-contiguous loads, the
-// separable [1 4 6 4 1] filter runs LDS -> LDS (horizontal, uint16) and LDS -> HBM
-// (vertical, (sum+128)>>8)), fill_border (levels 1..3 in one launch).
+// FOUR launches build up to 2 x SVO_LK_MAX_JOBS pyramids (the left AND right images of a lock-step
+// group of chunks), whatever their number -- the short kernels of this path are paced by launches,
+// not by bytes (beside the other contexts' tracking launches every launch waits tens of
+// microseconds for its first wave slots):
+//   1. base:    padded level 0 (copy + border) and, in the same launch, level 1 straight from the raw
+//               image (its own role of workgroups: no dependence on the padded level 0);
+//   2. down:    level 2 from level 1;            3. down: level 3 from level 2
+//               (one workgroup per 32x8 output tile; the (2*32+3) x (2*8+3) source tile is staged in LDS
+//               with row-contiguous loads, the separable [1 4 6 4 1] filter runs LDS -> LDS (horizontal,
+//               uint16) and LDS -> HBM (vertical, (sum+128)>>8); edge tiles read the INTERIOR of their
+//               source level through reflect-101 indices, so no level waits for a border);
+//   4. finish:  the reflect-101 borders of levels 1.. and, in the same launch, the Scharr derivative
+//               levels of the pyramids that carry them (edge pixels through reflect-101 indices again,
+//               so the two roles are independent).
 #include "svo_internal.h"
 
 namespace {
@@ -30,37 +41,50 @@ constexpr int TW = 32, TH = 8;
 // same either way -- the tracking launch gives up exactly the slots the pyramids win).
 constexpr int PB = 64;
 constexpr int SW = 2 * TW + 3, SH = 2 * TH + 3;
+// ROWS_PER_BLOCK rows per workgroup in the byte movers: they are bound by workgroup dispatch, not by
+// bandwidth (a wave per 256 bytes was 83 k waves per image)
+constexpr int ROWS_PER_BLOCK = 8;
+constexpr int PYR_JOBS = 2 * SVO_LK_MAX_JOBS;
 
-// several pyramids of the same geometry per launch: blockIdx.z picks the job
-struct PyrPtrs {
-    const uint8_t *src[SVO_LK_MAX_JOBS];
-    uint8_t *dst[SVO_LK_MAX_JOBS];
+// everything the four launches need, by value (2.4 KB of the 4 KB kernel-argument space)
+struct PyrBuild {
+    const uint8_t *img[PYR_JOBS];                 // raw images, row stride w[0] * C
+    uint8_t *lvl[PYR_JOBS][SVO_MAX_LEVELS];       // pixel (0, 0) of the padded levels
+    int *dlvl[PYR_JOBS];                          // derivative levels (svo_pyramid::dbase) or null
+    int doff[SVO_MAX_LEVELS];                     // element (0, 0) of each derivative level, in ints
+    int pitch[SVO_MAX_LEVELS], dpitch[SVO_MAX_LEVELS], w[SVO_MAX_LEVELS], h[SVO_MAX_LEVELS];
+    int levels;
 };
+static_assert(sizeof(PyrBuild) <= 3072, "kernel arguments are limited to 4 KB");
 
-template <int C>
-__global__ __launch_bounds__(PB) void pyr_down_kernel(PyrPtrs ptrs, int spitch, int w, int h, int dpitch, int dw,
-                                                       int dh)
+// One 32x8 output tile of level l from level l-1 (RAW = false: the padded level; RAW = true: the raw
+// image, rows of w * C bytes without padding or alignment).
+template <int C, bool RAW>
+__device__ __forceinline__ void down_tile(const uint8_t *__restrict__ src, int spitch, int w, int h,
+                                          uint8_t *__restrict__ dst, int dpitch, int dw, int dh, int tx, int ty)
 {
-    __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
-    const uint8_t *__restrict__ src = ptrs.src[blockIdx.z];
-    uint8_t *__restrict__ dst = ptrs.dst[blockIdx.z];
     constexpr int SDW = (SW * C + 3) / 4 + 1;  // dwords per staged row, one spare for the alignment shift
     constexpr int SROW = SDW * 4;
     __shared__ __attribute__((aligned(16))) uint8_t s_src[SH * SROW];
     __shared__ uint16_t s_h[SH][TW * C];
+    __shared__ int s_sh[SH];  // byte offset of the tile inside each staged row
     const int tid = threadIdx.x;
-    const int ox = blockIdx.x * TW, oy = blockIdx.y * TH;
+    const int ox = tx * TW, oy = ty * TH;
     const int x0 = 2 * ox - 2, y0 = 2 * oy - 2;
-    int sh = 0;  // byte offset of the tile inside the staged rows
-    if (x0 >= 0 && x0 + SW <= w && y0 >= 0 && y0 + SH <= h) {
-        // interior tile: whole aligned dwords, row by row (src is 4-byte aligned and spitch a multiple
-        // of 16, so every row of the tile starts at the same byte shift)
-        sh = (x0 * C) & 3;
-        const uint8_t *base = src + (ptrdiff_t)y0 * spitch + x0 * C - sh;
+    // the last dword of a staged row may reach 7 bytes past the tile: inside the padded level always;
+    // inside the raw image unless the tile ends at the very last bytes of the buffer
+    const bool interior = x0 >= 0 && x0 + SW <= w && y0 >= 0 && y0 + SH <= h &&
+                          (!RAW || (size_t)(y0 + SH - 1) * spitch + (size_t)x0 * C + SROW <= (size_t)h * spitch);
+    if (interior) {
+        // whole aligned dwords, row by row.  Padded level: 4-byte aligned rows of a pitch that is a multiple
+        // of 16, every row starts at the same shift; raw image: the shift differs from row to row.
         for (int i = tid; i < SH * SDW; i += PB) {
             const int r = i / SDW, d = i - r * SDW;
-            reinterpret_cast<uint32_t *>(s_src + r * SROW)[d] =
-                reinterpret_cast<const uint32_t *>(base + (ptrdiff_t)r * spitch)[d];
+            const uint8_t *row = src + (ptrdiff_t)(y0 + r) * spitch + x0 * C;
+            const int sh = (int)(reinterpret_cast<uintptr_t>(row) & 3);
+            reinterpret_cast<uint32_t *>(s_src + r * SROW)[d] = reinterpret_cast<const uint32_t *>(row - sh)[d];
+            if (d == 0)
+                s_sh[r] = sh;
         }
     } else {
         for (int i = tid; i < SH * SW * C; i += PB) {
@@ -69,13 +93,15 @@ __global__ __launch_bounds__(PB) void pyr_down_kernel(PyrPtrs ptrs, int spitch, 
             int sx = reflect101(x0 + px, w);
             int sy = reflect101(y0 + r, h);
             s_src[r * SROW + cc] = src[(size_t)sy * spitch + sx * C + ch];
+            if (cc == 0)
+                s_sh[r] = 0;
         }
     }
     __syncthreads();
     for (int i = tid; i < SH * TW * C; i += PB) {
         int r = i / (TW * C), cc = i - r * (TW * C);
         int x = cc / C, ch = cc - x * C;
-        const uint8_t *sp = s_src + r * SROW + sh + (2 * x) * C + ch;
+        const uint8_t *sp = s_src + r * SROW + s_sh[r] + (2 * x) * C + ch;
         s_h[r][cc] = (uint16_t)(sp[0] + 4 * sp[C] + 6 * sp[2 * C] + 4 * sp[3 * C] + sp[4 * C]);
     }
     __syncthreads();
@@ -105,30 +131,7 @@ __global__ __launch_bounds__(PB) void pyr_down_kernel(PyrPtrs ptrs, int spitch, 
     }
 }
 
-
-constexpr int ROWS_PER_BLOCK = 8;
-template <int C>
-__device__ __forceinline__ void pad_copy_row(const uint8_t *__restrict__ src, uint8_t *__restrict__ padded, int w, int h,
-                                             int pitch, int row, int d);
-
-// image (row stride w*C) -> padded level 0, one thread per output dword and row
-template <int C>
-__global__ __launch_bounds__(PB) void pad_copy_kernel(PyrPtrs ptrs, int w, int h, int pitch)
-{
-    __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
-    const uint8_t *__restrict__ src = ptrs.src[blockIdx.z];
-    uint8_t *__restrict__ padded = ptrs.dst[blockIdx.z];
-    const int dwords_per_row = pitch >> 2;
-    const int d = blockIdx.x * blockDim.x + threadIdx.x;
-    if (d >= dwords_per_row)
-        return;
-    // ROWS_PER_BLOCK rows per workgroup: these byte movers are bound by workgroup dispatch, not by
-    // bandwidth (a wave per 256 bytes was 83 k waves per image: beside a tracking launch every one of
-    // them queues for a wave slot)
-    for (int row = blockIdx.y * ROWS_PER_BLOCK, rend = min(row + ROWS_PER_BLOCK, h + 2 * SVO_PYR_PAD); row < rend; row++)
-        pad_copy_row<C>(src, padded, w, h, pitch, row, d);
-}
-
+// one row of the padded level 0 from the raw image, one thread per output dword
 template <int C>
 __device__ __forceinline__ void pad_copy_row(const uint8_t *__restrict__ src, uint8_t *__restrict__ padded, int w, int h,
                                              int pitch, int row, int d)
@@ -158,29 +161,35 @@ __device__ __forceinline__ void pad_copy_row(const uint8_t *__restrict__ src, ui
     reinterpret_cast<uint32_t *>(padded + (size_t)row * pitch)[d] = out;
 }
 
-struct BorderJob {
-    uint8_t *padded[SVO_LK_MAX_JOBS][SVO_MAX_LEVELS];
-    int pitch[SVO_MAX_LEVELS], w[SVO_MAX_LEVELS], h[SVO_MAX_LEVELS];
-    int levels_m1;  // blockIdx.z = job * levels_m1 + (level - 1)
-};
-
-template <int C>
-__device__ __forceinline__ void fill_border_row(uint8_t *__restrict__ level, int w, int h, int pitch, int row, int d);
-
-// fills the reflect-101 border of levels 1.. (blockIdx.z = level - 1) from their interior
-template <int C>
-__global__ __launch_bounds__(PB) void fill_border_kernel(BorderJob job)
+// launch 1: workgroups [0, n_tiles) build level 1 from the raw image, the rest the padded level 0
+template <int C> __global__ __launch_bounds__(PB) void pyr_base_kernel(PyrBuild b, int tiles_x, int n_tiles, int pad_x)
 {
     __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
-    const int jb = blockIdx.z / job.levels_m1, l = blockIdx.z - jb * job.levels_m1 + 1;
-    const int w = job.w[l], h = job.h[l], pitch = job.pitch[l];
-    const int d = blockIdx.x * blockDim.x + threadIdx.x;
-    if (d >= (pitch >> 2))
+    const int job = blockIdx.y;
+    if ((int)blockIdx.x < n_tiles) {
+        if (b.levels > 1)
+            down_tile<C, true>(b.img[job], b.w[0] * C, b.w[0], b.h[0], b.lvl[job][1], b.pitch[1], b.w[1], b.h[1],
+                               blockIdx.x % tiles_x, blockIdx.x / tiles_x);
         return;
-    for (int row = blockIdx.y * ROWS_PER_BLOCK, rend = min(row + ROWS_PER_BLOCK, h + 2 * SVO_PYR_PAD); row < rend; row++)
-        fill_border_row<C>(job.padded[jb][l], w, h, pitch, row, d);
+    }
+    const int i = blockIdx.x - n_tiles;
+    const int d = (i % pad_x) * PB + threadIdx.x, rb = i / pad_x;
+    if (d >= (b.pitch[0] >> 2))
+        return;
+    uint8_t *padded = b.lvl[job][0] - (size_t)SVO_PYR_PAD * b.pitch[0] - SVO_PYR_PAD * C;
+    for (int row = rb * ROWS_PER_BLOCK, rend = min(row + ROWS_PER_BLOCK, b.h[0] + 2 * SVO_PYR_PAD); row < rend; row++)
+        pad_copy_row<C>(b.img[job], padded, b.w[0], b.h[0], b.pitch[0], row, d);
 }
 
+// launches 2 and 3: level l from level l - 1
+template <int C> __global__ __launch_bounds__(PB) void pyr_down_kernel(PyrBuild b, int l)
+{
+    __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
+    down_tile<C, false>(b.lvl[blockIdx.z][l - 1], b.pitch[l - 1], b.w[l - 1], b.h[l - 1], b.lvl[blockIdx.z][l], b.pitch[l],
+                        b.w[l], b.h[l], blockIdx.x, blockIdx.y);
+}
+
+// one row of a level's reflect-101 border from its interior, one thread per dword
 template <int C>
 __device__ __forceinline__ void fill_border_row(uint8_t *__restrict__ level, int w, int h, int pitch, int row, int d)
 {
@@ -205,54 +214,44 @@ __device__ __forceinline__ void fill_border_row(uint8_t *__restrict__ level, int
     }
 }
 
-// Scharr derivatives of every level in ONE launch: blockIdx.y walks the rows of all levels back to
-// back, blockIdx.z = job.  A thread produces four consecutive channel-bytes of a row = one aligned
-// 16-byte store of packed (dx | dy << 16); it reads three aligned dwords from each of the rows
-// y-1, y, y+1 of the padded level (the reflect-101 border supplies the neighbours of edge pixels).
+// Scharr derivatives of four consecutive channel-bytes of row y = one aligned 16-byte store of packed
+// (dx | dy << 16):
 //   S(x) = 3 p(x, y-1) + 10 p(x, y) + 3 p(x, y+1),   V(x) = p(x, y+1) - p(x, y-1)
 //   dx(x) = S(x+1) - S(x-1),                           dy(x) = 3 V(x-1) + 10 V(x) + 3 V(x+1)
 // -- bit for bit what lk.hip derived per keypoint and level before (each pixel sat in ~5 keypoint
-// tiles per level; that Scharr tile was 17 % of the tracker's VALU instructions).
-struct DerivJob {
-    const uint8_t *lvl[SVO_LK_MAX_JOBS][SVO_MAX_LEVELS];  // pixel (0,0) of the padded levels
-    int *dlvl[SVO_LK_MAX_JOBS][SVO_MAX_LEVELS];            // element (0,0) of the derivative levels
-    int pitch[SVO_MAX_LEVELS], dpitch[SVO_MAX_LEVELS], w[SVO_MAX_LEVELS], h[SVO_MAX_LEVELS];
-    int row0[SVO_MAX_LEVELS + 1];                          // first blockIdx.y of each level (ROWS_PER_BLOCK rows each)
-    int levels;
-};
-
+// tiles per level; that Scharr tile was 17 % of the tracker's VALU instructions).  Image edges: rows and
+// pixels outside the image are their reflect-101 images (the level's border may not be written yet).
 template <int C>
 __device__ __forceinline__ void scharr_row(const uint8_t *__restrict__ lvl, int *__restrict__ dlvl, int pitch, int dpitch,
-                                           int w, int y, int q);
-
-template <int C> __global__ __launch_bounds__(PB) void scharr_kernel(DerivJob job)
+                                           int w, int h, int y, int q)
 {
-    __builtin_amdgcn_s_setprio(3);  // short kernel: win issue arbitration against co-resident LK waves
-    int l = 0;
-    for (int i = 1; i < job.levels; i++)
-        l = (int)blockIdx.y >= job.row0[i] ? i : l;
-    const int w = job.w[l];
-    const int q = blockIdx.x * PB + threadIdx.x;  // quad of channel-bytes 4q .. 4q+3 of the row
-    if (4 * q >= w * C)
-        return;
-    const int pitch = job.pitch[l];
-    // ROWS_PER_BLOCK rows per workgroup (see pad_copy_kernel)
-    for (int y = (blockIdx.y - job.row0[l]) * ROWS_PER_BLOCK, yend = min(y + ROWS_PER_BLOCK, job.h[l]); y < yend; y++)
-        scharr_row<C>(job.lvl[blockIdx.z][l], job.dlvl[blockIdx.z][l], pitch, job.dpitch[l], w, y, q);
-}
-
-template <int C>
-__device__ __forceinline__ void scharr_row(const uint8_t *__restrict__ lvl, int *__restrict__ dlvl, int pitch, int dpitch,
-                                           int w, int y, int q)
-{
-    const uint8_t *row = lvl + (ptrdiff_t)y * pitch;  // 4-byte aligned (pad * C and pitch are)
+    const uint8_t *rows[3] = {lvl + (ptrdiff_t)reflect101(y - 1, h) * pitch, lvl + (ptrdiff_t)y * pitch,
+                              lvl + (ptrdiff_t)reflect101(y + 1, h) * pitch};  // 4-byte aligned (pad * C and pitch are)
     uint32_t win[3][3];  // bytes 4q-4 .. 4q+7 of rows y-1, y, y+1
+    const bool edge = q == 0 || 4 * q + 4 + C > w * C;
+    if (!edge) {
 #pragma unroll
-    for (int r = 0; r < 3; r++) {
-        const uint32_t *p = reinterpret_cast<const uint32_t *>(row + (ptrdiff_t)(r - 1) * pitch) + (q - 1);
-        win[r][0] = p[0];
-        win[r][1] = p[1];
-        win[r][2] = p[2];
+        for (int r = 0; r < 3; r++) {
+            const uint32_t *p = reinterpret_cast<const uint32_t *>(rows[r]) + (q - 1);
+            win[r][0] = p[0];
+            win[r][1] = p[1];
+            win[r][2] = p[2];
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                uint32_t v = 0;
+#pragma unroll
+                for (int bb = 0; bb < 4; bb++) {
+                    const int cb = 4 * q - 4 + 4 * d + bb;                       // channel-byte index in the row
+                    const int px = cb >= 0 ? cb / C : -((-cb + C - 1) / C);      // floor division
+                    const int ch = cb - px * C;
+                    v |= (uint32_t)rows[r][reflect101(px, w) * C + ch] << (8 * bb);
+                }
+                win[r][d] = v;
+            }
     }
     auto byte_at = [&](int r, int pos) -> int { return (int)((win[r][pos >> 2] >> (8 * (pos & 3))) & 0xffu); };
     // columns 4-C .. 7+C of the 12-byte window
@@ -260,8 +259,8 @@ __device__ __forceinline__ void scharr_row(const uint8_t *__restrict__ lvl, int 
 #pragma unroll
     for (int i = 0; i < 4 + 2 * C; i++) {
         const int pos = 4 - C + i;
-        const int a = byte_at(0, pos), b = byte_at(1, pos), c = byte_at(2, pos);
-        S[i] = 3 * (a + c) + 10 * b;
+        const int a = byte_at(0, pos), bq = byte_at(1, pos), c = byte_at(2, pos);
+        S[i] = 3 * (a + c) + 10 * bq;
         V[i] = c - a;
     }
     int out[4];
@@ -281,59 +280,119 @@ __device__ __forceinline__ void scharr_row(const uint8_t *__restrict__ lvl, int 
     }
 }
 
-template <int C> static int launch_scharr(svo_ctx *ctx, int k, svo_pyramid *const *pyrs)
+// launch 4: blockIdx.y walks [border row blocks of levels 1..][Scharr row blocks of levels 0..]
+struct FinishPlan {
+    int border_y0[SVO_MAX_LEVELS + 1];  // first blockIdx.y of level l's border role (l >= 1); [levels] = end
+    int scharr_y0[SVO_MAX_LEVELS + 1];  // first blockIdx.y of level l's Scharr role; [levels] = end
+};
+template <int C> __global__ __launch_bounds__(PB) void pyr_finish_kernel(PyrBuild b, FinishPlan plan)
 {
-    const svo_pyramid *p0 = pyrs[0];
-    DerivJob job;
-    int rows = 0, wmax = 0;
-    for (int l = 0; l < SVO_MAX_LEVELS; l++) {
-        const bool on = l < p0->levels;
-        job.pitch[l] = p0->dev.pitch[l];
-        job.dpitch[l] = p0->dpitch[l];
-        job.w[l] = p0->dev.w[l];
-        job.h[l] = p0->dev.h[l];
-        job.row0[l] = rows;
-        if (on) {
-            rows += (p0->dev.h[l] + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;  // in workgroups
-            wmax = p0->dev.w[l] > wmax ? p0->dev.w[l] : wmax;
-        }
-        for (int a = 0; a < SVO_LK_MAX_JOBS; a++) {
-            const svo_pyramid *p = pyrs[a < k ? a : 0];
-            job.lvl[a][l] = on ? p->dev.lvl[l] : nullptr;
-            job.dlvl[a][l] = on ? p->dbase + p->doff[l] : nullptr;
-        }
+    __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
+    const int job = blockIdx.z, by = blockIdx.y;
+    if (by < plan.border_y0[b.levels]) {
+        int l = 1;
+        for (int i = 2; i < b.levels; i++)
+            l = by >= plan.border_y0[i] ? i : l;
+        const int d = blockIdx.x * PB + threadIdx.x;
+        if (d >= (b.pitch[l] >> 2))
+            return;
+        uint8_t *padded = b.lvl[job][l] - (size_t)SVO_PYR_PAD * b.pitch[l] - SVO_PYR_PAD * C;
+        for (int row = (by - plan.border_y0[l]) * ROWS_PER_BLOCK, rend = min(row + ROWS_PER_BLOCK, b.h[l] + 2 * SVO_PYR_PAD);
+             row < rend; row++)
+            fill_border_row<C>(padded, b.w[l], b.h[l], b.pitch[l], row, d);
+        return;
     }
-    job.row0[SVO_MAX_LEVELS] = rows;
-    job.levels = p0->levels;
-    const int quads = (wmax * C + 3) / 4;
-    hipLaunchKernelGGL(scharr_kernel<C>, dim3((quads + PB - 1) / PB, rows, k), dim3(PB), 0, ctx->stream, job);
-    SVO_HIP(hipGetLastError());
-    return SVO_OK;
+    if (!b.dlvl[job])
+        return;  // this pyramid carries no derivative levels (a right image)
+    int l = 0;
+    for (int i = 1; i < b.levels; i++)
+        l = by >= plan.scharr_y0[i] ? i : l;
+    const int q = blockIdx.x * PB + threadIdx.x;  // quad of channel-bytes 4q .. 4q+3 of the row
+    if (4 * q >= b.w[l] * C)
+        return;
+    for (int y = (by - plan.scharr_y0[l]) * ROWS_PER_BLOCK, yend = min(y + ROWS_PER_BLOCK, b.h[l]); y < yend; y++)
+        scharr_row<C>(b.lvl[job][l], b.dlvl[job] + b.doff[l], b.pitch[l], b.dpitch[l], b.w[l], b.h[l], y, q);
 }
 
 }  // namespace
 
+static void fill_build(PyrBuild &b, int k, svo_pyramid *const *pyrs, const uint8_t *const *d_images, bool deriv_only)
+{
+    const svo_pyramid *p0 = pyrs[0];
+    for (int l = 0; l < SVO_MAX_LEVELS; l++) {
+        b.pitch[l] = p0->dev.pitch[l];
+        b.w[l] = p0->dev.w[l];
+        b.h[l] = p0->dev.h[l];
+        b.dpitch[l] = 0;
+        b.doff[l] = 0;
+    }
+    b.levels = p0->levels;
+    for (int a = 0; a < PYR_JOBS; a++) {
+        svo_pyramid *p = pyrs[a < k ? a : 0];
+        b.img[a] = d_images ? d_images[a < k ? a : 0] : nullptr;
+        for (int l = 0; l < SVO_MAX_LEVELS; l++)
+            b.lvl[a][l] = l < p->levels ? const_cast<uint8_t *>(p->dev.lvl[l]) : nullptr;
+        const bool d = p->dbase && (deriv_only || p->want_deriv) && (p->c == 1 || p->c == 3);
+        b.dlvl[a] = d ? p->dbase : nullptr;
+        if (d)
+            for (int l = 0; l < SVO_MAX_LEVELS; l++) {
+                b.dpitch[l] = p->dpitch[l];
+                b.doff[l] = (int)p->doff[l];
+            }
+    }
+}
+
+template <int C> static int launch_finish(svo_ctx *ctx, int k, const PyrBuild &b, bool borders)
+{
+    FinishPlan plan;
+    int y = 0, xmax = 1;
+    for (int l = 0; l <= SVO_MAX_LEVELS; l++)
+        plan.border_y0[l] = plan.scharr_y0[l] = 0;
+    for (int l = 1; l < b.levels; l++) {
+        plan.border_y0[l] = y;
+        if (borders) {
+            y += (b.h[l] + 2 * SVO_PYR_PAD + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+            xmax = max(xmax, ((b.pitch[l] >> 2) + PB - 1) / PB);
+        }
+    }
+    for (int l = b.levels; l <= SVO_MAX_LEVELS; l++)
+        plan.border_y0[l] = y;
+    plan.border_y0[b.levels] = y;
+    bool any_deriv = false;
+    for (int a = 0; a < k; a++)
+        any_deriv = any_deriv || b.dlvl[a];
+    for (int l = 0; l < b.levels; l++) {
+        plan.scharr_y0[l] = y;
+        if (any_deriv) {
+            y += (b.h[l] + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+            xmax = max(xmax, ((b.w[l] * C + 3) / 4 + PB - 1) / PB);
+        }
+    }
+    plan.scharr_y0[b.levels] = y;
+    if (y == 0)
+        return SVO_OK;
+    hipLaunchKernelGGL(pyr_finish_kernel<C>, dim3(xmax, y, k), dim3(PB), 0, ctx->stream, b, plan);
+    SVO_HIP(hipGetLastError());
+    return SVO_OK;
+}
+
+// derivative levels of pyramids whose levels (and borders) are already built
 int svo_build_derivatives(svo_ctx *ctx, int k, svo_pyramid *const *pyrs)
 {
     if (k <= 0)
         return SVO_OK;
+    if (k > PYR_JOBS) {
+        svo_set_error("pyramid: at most %d per launch", PYR_JOBS);
+        return SVO_ERR_ARG;
+    }
     for (int a = 0; a < k; a++)
-        if (!pyrs[a]->dbase) {
+        if (!pyrs[a]->dbase || (pyrs[a]->c != 1 && pyrs[a]->c != 3)) {
             svo_set_error("pyramid: created without derivative levels");
             return SVO_ERR_STATE;
         }
-    int rc;
-    switch (pyrs[0]->c) {
-    case 1:
-        rc = launch_scharr<1>(ctx, k, pyrs);
-        break;
-    case 3:
-        rc = launch_scharr<3>(ctx, k, pyrs);
-        break;
-    default:
-        svo_set_error("pyramid: derivative levels for 1 or 3 channels only");
-        return SVO_ERR_ARG;
-    }
+    PyrBuild b;
+    fill_build(b, k, pyrs, nullptr, true);
+    const int rc = pyrs[0]->c == 1 ? launch_finish<1>(ctx, k, b, false) : launch_finish<3>(ctx, k, b, false);
     if (rc == SVO_OK)
         for (int a = 0; a < k; a++)
             pyrs[a]->has_deriv = true;
@@ -342,48 +401,31 @@ int svo_build_derivatives(svo_ctx *ctx, int k, svo_pyramid *const *pyrs)
 
 template <int C> static int build_levels(svo_ctx *ctx, int k, svo_pyramid *const *pyrs, const uint8_t *const *d_images)
 {
-    const svo_pyramid *p0 = pyrs[0];
-    const PyrDev &d = p0->dev;
+    PyrBuild b;
+    fill_build(b, k, pyrs, d_images, false);
     {
-        PyrPtrs pp;
-        for (int a = 0; a < SVO_LK_MAX_JOBS; a++) {
-            pp.src[a] = d_images[a < k ? a : 0];
-            pp.dst[a] = pyrs[a < k ? a : 0]->base + pyrs[a < k ? a : 0]->off[0];
-        }
-        dim3 grid(((d.pitch[0] >> 2) + PB - 1) / PB, (d.h[0] + 2 * SVO_PYR_PAD + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, k);
-        hipLaunchKernelGGL(pad_copy_kernel<C>, grid, dim3(PB), 0, ctx->stream, pp, d.w[0], d.h[0], d.pitch[0]);
+        const int tiles_x = b.levels > 1 ? (b.w[1] + TW - 1) / TW : 0, tiles_y = b.levels > 1 ? (b.h[1] + TH - 1) / TH : 0;
+        const int n_tiles = tiles_x * tiles_y;
+        const int pad_x = ((b.pitch[0] >> 2) + PB - 1) / PB,
+                  pad_y = (b.h[0] + 2 * SVO_PYR_PAD + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+        hipLaunchKernelGGL(pyr_base_kernel<C>, dim3(n_tiles + pad_x * pad_y, k), dim3(PB), 0, ctx->stream, b,
+                           tiles_x > 0 ? tiles_x : 1, n_tiles, pad_x);
     }
-    for (int l = 1; l < p0->levels; l++) {
-        PyrPtrs pp;
-        for (int a = 0; a < SVO_LK_MAX_JOBS; a++) {
-            pp.src[a] = pyrs[a < k ? a : 0]->origin(l - 1);
-            pp.dst[a] = pyrs[a < k ? a : 0]->origin(l);
-        }
-        dim3 grid((d.w[l] + TW - 1) / TW, (d.h[l] + TH - 1) / TH, k);
-        hipLaunchKernelGGL(pyr_down_kernel<C>, grid, dim3(PB), 0, ctx->stream, pp, d.pitch[l - 1], d.w[l - 1],
-                           d.h[l - 1], d.pitch[l], d.w[l], d.h[l]);
-    }
-    if (p0->levels > 1) {
-        BorderJob job;
-        for (int a = 0; a < SVO_LK_MAX_JOBS; a++)
-            for (int l = 0; l < SVO_MAX_LEVELS; l++)
-                job.padded[a][l] = l < p0->levels ? pyrs[a < k ? a : 0]->base + pyrs[a < k ? a : 0]->off[l] : nullptr;
-        for (int l = 0; l < SVO_MAX_LEVELS; l++) {
-            job.pitch[l] = d.pitch[l];
-            job.w[l] = d.w[l];
-            job.h[l] = d.h[l];
-        }
-        job.levels_m1 = p0->levels - 1;
-        dim3 grid(((d.pitch[1] >> 2) + PB - 1) / PB, (d.h[1] + 2 * SVO_PYR_PAD + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK,
-                  (p0->levels - 1) * k);
-        hipLaunchKernelGGL(fill_border_kernel<C>, grid, dim3(PB), 0, ctx->stream, job);
-    }
+    for (int l = 2; l < b.levels; l++)
+        hipLaunchKernelGGL(pyr_down_kernel<C>, dim3((b.w[l] + TW - 1) / TW, (b.h[l] + TH - 1) / TH, k), dim3(PB), 0,
+                           ctx->stream, b, l);
     SVO_HIP(hipGetLastError());
+    int rc = SVO_OK;
+    if constexpr (C == 1 || C == 3)
+        rc = launch_finish<C>(ctx, k, b, true);
+    else {
+        for (int a = 0; a < PYR_JOBS; a++)
+            b.dlvl[a] = nullptr;
+        rc = launch_finish<C>(ctx, k, b, true);
+    }
     for (int a = 0; a < k; a++)
-        pyrs[a]->has_deriv = false;
-    if (p0->want_deriv && p0->dbase && (C == 1 || C == 3))
-        return svo_build_derivatives(ctx, k, pyrs);
-    return SVO_OK;
+        pyrs[a]->has_deriv = rc == SVO_OK && b.dlvl[a] != nullptr;
+    return rc;
 }
 
 // k pyramids of the same geometry from k device images, one set of launches
@@ -391,13 +433,13 @@ int svo_build_pyramids_from_device(svo_ctx *ctx, int k, svo_pyramid *const *pyrs
 {
     if (k <= 0)
         return SVO_OK;
-    if (k > SVO_LK_MAX_JOBS) {
-        svo_set_error("pyramid: at most %d per launch", SVO_LK_MAX_JOBS);
+    if (k > PYR_JOBS) {
+        svo_set_error("pyramid: at most %d per launch", PYR_JOBS);
         return SVO_ERR_ARG;
     }
     for (int a = 1; a < k; a++)
         if (pyrs[a]->w != pyrs[0]->w || pyrs[a]->h != pyrs[0]->h || pyrs[a]->c != pyrs[0]->c ||
-            pyrs[a]->levels != pyrs[0]->levels || pyrs[a]->want_deriv != pyrs[0]->want_deriv) {
+            pyrs[a]->levels != pyrs[0]->levels) {
             svo_set_error("pyramid: the pyramids of one launch must share their geometry");
             return SVO_ERR_ARG;
         }
