@@ -245,6 +245,11 @@ __device__ __forceinline__ int stage_dtile(uint8_t *tile, const int *__restrict_
     const uint8_t *a16 = reinterpret_cast<const uint8_t *>(lvl) + (ptrdiff_t)__builtin_amdgcn_readfirstlane(off - shift);
     constexpr int TOTAL = DT * DL::VEC, ITER = (TOTAL + 63) / 64, HALF = (ITER + 1) / 2;
     typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+    // the (row, vector) of every step depends on the lane only: left to itself the compiler computes the
+    // seven LDS offsets once per keypoint and keeps them across the level loop -- seven registers the
+    // 128-VGPR kernel does not have (they were spilled: 118 MB of scratch traffic per launch).  An opaque
+    // copy of the lane makes them a few instructions per level instead.
+    asm volatile("" : "+v"(lane));
     // two batches of loads: at most HALF vectors (16 registers) in flight, the kernel runs at 128 VGPRs
 #pragma unroll
     for (int b = 0; b < ITER; b += HALF) {
