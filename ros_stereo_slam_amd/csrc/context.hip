@@ -1,6 +1,5 @@
 // context.hip -- svo_ctx: device, stream, scratch, kernel timers, error text.
 #include <cstdarg>
-#include <cstdlib>
 
 #include "svo_internal.h"
 
@@ -127,14 +126,7 @@ int svo_ctx_create(int device, svo_ctx **out)
     }
     svo_ctx *ctx = new svo_ctx();
     ctx->device = device;
-    const char *lkm = getenv("SVO_LK_STREAM");
-    ctx->lk_mode = lkm ? atoi(lkm) : 0;
-    int prio_lo = 0, prio_hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-    if (ctx->lk_mode == 1)
-        e = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, prio_hi);
-    else
-        e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete ctx;
         svo_set_error("hipStreamCreate -> %s", hipGetErrorString(e));
@@ -164,30 +156,6 @@ int svo_ctx_create(int device, svo_ctx **out)
         svo_set_error("hipEventCreate -> %s", hipGetErrorString(e));
         return SVO_ERR_HIP;
     }
-    if (ctx->lk_mode == 1 || ctx->lk_mode == 2) {
-        if (ctx->lk_mode == 1) {
-            e = hipStreamCreateWithPriority(&ctx->lk_stream, hipStreamNonBlocking, prio_lo);
-        } else {
-            // every 8th CU (one word of the mask covers 32 CUs) is kept free of tracking waves
-            const char *k = getenv("SVO_LK_CU_KEEP_FREE");
-            const int every = k ? atoi(k) : 8;
-            uint32_t mask[8];
-            for (int w = 0; w < 8; w++) {
-                mask[w] = 0;
-                for (int b = 0; b < 32; b++)
-                    if (every <= 0 || ((w * 32 + b) % every) != every - 1)
-                        mask[w] |= 1u << b;
-            }
-            e = hipExtStreamCreateWithCUMask(&ctx->lk_stream, 8, mask);
-        }
-        if (e != hipSuccess || hipEventCreateWithFlags(&ctx->lk_ev_a, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&ctx->lk_ev_b, hipEventDisableTiming) != hipSuccess) {
-            svo_set_error("tracking stream (SVO_LK_STREAM=%d) -> %s", ctx->lk_mode, hipGetErrorString(e));
-            ctx->lk_stream = nullptr;
-            svo_ctx_destroy(ctx);
-            return SVO_ERR_HIP;
-        }
-    }
     *out = ctx;
     return SVO_OK;
 }
@@ -215,14 +183,6 @@ int svo_ctx_destroy(svo_ctx *ctx)
         (void)hipHostFree(ctx->pinned);
     if (ctx->wait_ev)
         (void)hipEventDestroy(ctx->wait_ev);
-    if (ctx->lk_stream) {
-        (void)hipStreamSynchronize(ctx->lk_stream);
-        (void)hipStreamDestroy(ctx->lk_stream);
-    }
-    if (ctx->lk_ev_a)
-        (void)hipEventDestroy(ctx->lk_ev_a);
-    if (ctx->lk_ev_b)
-        (void)hipEventDestroy(ctx->lk_ev_b);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return SVO_OK;

@@ -242,7 +242,7 @@ int stereo_triangulate_batch(int k, svo_vo *const *vs, svo_pyramid *const *lefts
         q.err = nullptr;
         q.min_eig = v->resp;
     }
-    if ((rc = svo_on_lk_stream(ctx, [&]() { return svo_launch_lk_batch(ctx, k, lk, lefts[0]); })))
+    if ((rc = svo_launch_lk_batch(ctx, k, lk, lefts[0])))
         return rc;
     const float *pts[SVO_LK_MAX_JOBS], *trk[SVO_LK_MAX_JOBS];
     const uint8_t *stt[SVO_LK_MAX_JOBS];
@@ -1016,7 +1016,7 @@ static int run_chunk_group(svo_chunk_job **jobs, int k)
             imgs[nl + a] = rimg0[a];
         }
         if ((rc = svo_build_pyramids_from_device(ctx, 2 * nl, pyrs, imgs)) ||
-            (rc = svo_on_lk_stream(ctx, [&]() { return svo_launch_lk_batch(ctx, nl, lk, pyrs[0]); })))
+            (rc = svo_launch_lk_batch(ctx, nl, lk, pyrs[0])))
             return rc;
         // ---- filters and PnP: every stage is ONE set of launches for all the chunks ----
         svo_pnp_job pj[SVO_LK_MAX_JOBS];

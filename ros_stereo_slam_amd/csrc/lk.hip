@@ -21,8 +21,6 @@
 //
 // Roofline: the kernel's algorithmic HBM traffic is both pyramids once plus 21 B/point
 // (SURVEY.md section 8d); its time is VALU/LDS work, see DESIGN.md.
-#include <algorithm>
-#include <cstdlib>
 #include <type_traits>
 
 #include "svo_internal.h"
@@ -712,16 +710,13 @@ int svo_launch_lk_batch(svo_ctx *ctx, int n_jobs, const LkJob *jobs, const svo_p
         prm.dpitch[l] = geom->dpitch[l];
     }
     dim3 grid(((n_max + 7) / 8 + WAVES - 1) / WAVES * 8, n_jobs), block(64 * WAVES);  // x: a multiple of 8, every XCD band has all its slots
-    // experiment: SVO_LK_WAVES_PER_CU caps the tracker's residency through its LDS request
-    static const int cap_waves = getenv("SVO_LK_WAVES_PER_CU") ? atoi(getenv("SVO_LK_WAVES_PER_CU")) : 0;
-    const size_t lds_floor = cap_waves > 0 ? (size_t)(160 * 1024 / cap_waves) & ~(size_t)255 : 0;
     ScopedKernelTime t(ctx, SVO_K_LK);
     switch (c) {
     case 1:
-        hipLaunchKernelGGL(lk_track_kernel<1>, grid, block, std::max((size_t)WAVES * Lds<1>::WAVE_BYTES, lds_floor), ctx->stream, batch, prm);
+        hipLaunchKernelGGL(lk_track_kernel<1>, grid, block, WAVES * Lds<1>::WAVE_BYTES, ctx->stream, batch, prm);
         break;
     case 3:
-        hipLaunchKernelGGL(lk_track_kernel<3>, grid, block, std::max((size_t)WAVES * Lds<3>::WAVE_BYTES, lds_floor), ctx->stream, batch, prm);
+        hipLaunchKernelGGL(lk_track_kernel<3>, grid, block, WAVES * Lds<3>::WAVE_BYTES, ctx->stream, batch, prm);
         break;
     default:
         svo_set_error("lk: unsupported channel count %d (1 or 3)", c);

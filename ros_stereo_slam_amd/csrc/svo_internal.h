@@ -102,31 +102,7 @@ struct svo_ctx {
     void *pinned = nullptr;  // small pinned host block for scalar read-backs
     size_t pinned_bytes = 0;
     hipEvent_t wait_ev = nullptr;  // svo_wait(): event polled by the host
-    // The tracking launches of the chunk runner may go to a stream of their own (svo_lk_stream_*): a
-    // tracking launch fills every wave slot of the chip for a millisecond, and the short kernels of the
-    // OTHER contexts then wait for slots; a lower queue priority or a CU mask for the tracking stream
-    // lets them through.  lk_mode: 0 = same stream, 1 = low-priority stream, 2 = CU-masked stream.
-    hipStream_t lk_stream = nullptr;
-    hipEvent_t lk_ev_a = nullptr, lk_ev_b = nullptr;
-    int lk_mode = 0;
 };
-// runs `launch` (which queues on ctx->stream) on the tracking stream, ordered after / before the main stream
-template <class F> int svo_on_lk_stream(svo_ctx *ctx, F &&launch)
-{
-    if (!ctx->lk_stream)
-        return launch();
-    hipStream_t main_s = ctx->stream;
-    SVO_HIP(hipEventRecord(ctx->lk_ev_a, main_s));
-    SVO_HIP(hipStreamWaitEvent(ctx->lk_stream, ctx->lk_ev_a, 0));
-    ctx->stream = ctx->lk_stream;
-    const int rc = launch();
-    ctx->stream = main_s;
-    if (rc)
-        return rc;
-    SVO_HIP(hipEventRecord(ctx->lk_ev_b, ctx->lk_stream));
-    SVO_HIP(hipStreamWaitEvent(main_s, ctx->lk_ev_b, 0));
-    return SVO_OK;
-}
 
 // Low-latency host wait for everything queued on the context's stream: records an event and
 // polls it (hipStreamSynchronize parks the thread and costs tens of microseconds to wake).
