@@ -104,9 +104,11 @@ def gather_trajectories(dist, poses, device=None):
     dist.all_gather(counts, n)
     counts = [int(c.item()) for c in counts]
     m = max(counts)
-    buf = torch.zeros((m, 12), dtype=torch.float64, device=dev)
+    host = np.zeros((m, 12))
     for i, (R, t) in enumerate(poses):
-        buf[i] = torch.tensor(np.r_[np.asarray(R).ravel(), np.asarray(t).ravel()], dtype=torch.float64)
+        host[i, :9] = np.asarray(R, np.float64).ravel()
+        host[i, 9:] = np.asarray(t, np.float64).ravel()
+    buf = torch.from_numpy(host).to(dev)  # one copy, not one per pose
     got = [torch.empty_like(buf) for _ in range(dist.get_world_size())]
     dist.all_gather(got, buf)
     out = []
