@@ -37,8 +37,12 @@ struct AnmsJob {
     int *order;
     float4 *sorted;
     double *radius, *decision;
-    uint8_t *flags;
     int *out_idx, *d_count;
+    // optional payload gathered with the index list: out_x[i] = in_x[out_idx[i]]
+    const float2 *in_a, *in_b;
+    float2 *out_a, *out_b;
+    const uint8_t *in_s;
+    uint8_t *out_s;
 };
 struct AnmsBatch {
     AnmsJob j[SVO_LK_MAX_JOBS];
@@ -220,23 +224,14 @@ __global__ __launch_bounds__(64) void anms_decide_kernel(AnmsBatch batch, int n,
     }
 }
 
-__global__ __launch_bounds__(256) void anms_flag_kernel(AnmsBatch batch, int n)
-{
-    __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
-    const double *__restrict__ radius_sq = batch.j[blockIdx.y].radius;
-    const double *__restrict__ decision = batch.j[blockIdx.y].decision;
-    uint8_t *__restrict__ flags = batch.j[blockIdx.y].flags;
-    const int s = blockIdx.x * 64 + threadIdx.x;
-    if (s < n)
-        flags[s] = radius_sq[s] >= *decision ? 1 : 0;
-}
-
-// kept[] = order[s] for flagged s, in sorted order (single workgroup scan)
+// kept[] = order[s] for every s with radius[s] >= decision radius, in sorted order (single workgroup scan);
+// the payload arrays of the kept keypoints are gathered in the same pass
 __global__ __launch_bounds__(1024) void anms_gather_kernel(AnmsBatch batch, int n)
 {
     __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     const AnmsJob &job = batch.j[blockIdx.x];  // one workgroup per job
-    const uint8_t *__restrict__ flags = job.flags;
+    const double *__restrict__ radius_sq = job.radius;
+    const double decision = *job.decision;
     const int *__restrict__ order = job.order;
     int *__restrict__ out_idx = job.out_idx;
     int *__restrict__ d_count = job.d_count;
@@ -246,7 +241,7 @@ __global__ __launch_bounds__(1024) void anms_gather_kernel(AnmsBatch batch, int 
     const int b = t * per, e = min(b + per, n);
     int cnt = 0;
     for (int i = b; i < e; i++)
-        cnt += flags[i];
+        cnt += radius_sq[i] >= decision ? 1 : 0;
     s_sum[t] = cnt;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {
@@ -259,18 +254,39 @@ __global__ __launch_bounds__(1024) void anms_gather_kernel(AnmsBatch batch, int 
     if (t == 1023)
         *d_count = s_sum[1023];
     for (int i = b; i < e; i++)
-        if (flags[i])
-            out_idx[pos++] = order[i];
+        if (radius_sq[i] >= decision) {
+            const int j = order[i];
+            out_idx[pos] = j;
+            if (job.out_a) {
+                job.out_a[pos] = job.in_a[j];
+                job.out_b[pos] = job.in_b[j];
+                job.out_s[pos] = job.in_s[j];
+            }
+            pos++;
+        }
 }
 
 __global__ void set_int_kernel(int *p, int v) { *p = v; }
+
+// everything is kept (n <= numToKeep): the payload in sorted order
+__global__ __launch_bounds__(64) void anms_payload_kernel(AnmsBatch batch, int n)
+{
+    const AnmsJob &job = batch.j[blockIdx.y];
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n || !job.out_a)
+        return;
+    const int j = job.order[i];
+    job.out_a[i] = job.in_a[j];
+    job.out_b[i] = job.in_b[j];
+    job.out_s[i] = job.in_s[j];
+}
 
 }  // namespace
 
 // Device form, several problems of the same size n.  out_idx: n ints (input indices of the kept
 // keypoints, response order); d_count: device int.  Uses ctx->w_a..w_d as scratch.
 int svo_launch_anms_batch(svo_ctx *ctx, int k, const float *const *xy, const float *const *resp, int n, int keep,
-                          int *const *out_idx, int *const *d_count)
+                          int *const *out_idx, int *const *d_count, const svo_anms_gather *gather)
 {
     if (n <= 0 || k <= 0)
         return SVO_OK;
@@ -282,7 +298,7 @@ int svo_launch_anms_batch(svo_ctx *ctx, int k, const float *const *xy, const flo
     int rc;
     const size_t na = ((size_t)n + 63) / 64 * 64;
     if ((rc = ctx->w_a.ensure(na * 4 * k)) || (rc = ctx->w_b.ensure((na * 8 + 64) * k)) ||
-        (rc = ctx->w_c.ensure(na * k)) || (rc = ctx->w_d.ensure(na * 16 * k)))
+        (rc = ctx->w_d.ensure(na * 16 * k)))
         return rc;
     AnmsBatch batch;
     for (int a = 0; a < SVO_LK_MAX_JOBS; a++) {
@@ -293,14 +309,19 @@ int svo_launch_anms_batch(svo_ctx *ctx, int k, const float *const *xy, const flo
         j.order = ctx->w_a.as<int>() + na * q;
         j.radius = reinterpret_cast<double *>(ctx->w_b.as<uint8_t>() + (na * 8 + 64) * q);
         j.decision = j.radius + na;
-        j.flags = ctx->w_c.as<uint8_t>() + na * q;
         j.sorted = ctx->w_d.as<float4>() + na * q;
         j.out_idx = out_idx[q];
         j.d_count = d_count[q];
+        j.in_a = gather ? reinterpret_cast<const float2 *>(gather[q].in_a) : nullptr;
+        j.in_b = gather ? reinterpret_cast<const float2 *>(gather[q].in_b) : nullptr;
+        j.out_a = gather ? reinterpret_cast<float2 *>(gather[q].out_a) : nullptr;
+        j.out_b = gather ? reinterpret_cast<float2 *>(gather[q].out_b) : nullptr;
+        j.in_s = gather ? gather[q].in_s : nullptr;
+        j.out_s = gather ? gather[q].out_s : nullptr;
     }
     // single-wave workgroups: beside a tracking launch (single-wave workgroups that take every freed wave
     // slot at once) a multi-wave workgroup waits until one CU has a slot free on several SIMDs together
-    const dim3 wgrid((n + KPW - 1) / KPW, k), tgrid((n + 63) / 64, k), block(64);
+    const dim3 wgrid((n + KPW - 1) / KPW, k), block(64);
     hipLaunchKernelGGL(anms_rank_kernel, wgrid, block, 0, ctx->stream, batch, n);
     if (n <= keep) {
         // everything is kept, in sorted order
@@ -308,12 +329,13 @@ int svo_launch_anms_batch(svo_ctx *ctx, int k, const float *const *xy, const flo
             SVO_HIP(hipMemcpyAsync(out_idx[a], batch.j[a].order, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
             hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(1), 0, ctx->stream, d_count[a], n);
         }
+        if (gather)
+            hipLaunchKernelGGL(anms_payload_kernel, dim3((n + 63) / 64, k), dim3(64), 0, ctx->stream, batch, n);
         SVO_HIP(hipGetLastError());
         return SVO_OK;
     }
     hipLaunchKernelGGL(anms_radius_kernel, wgrid, block, 0, ctx->stream, batch, n);
     hipLaunchKernelGGL(anms_decide_kernel, wgrid, block, 0, ctx->stream, batch, n, keep);
-    hipLaunchKernelGGL(anms_flag_kernel, tgrid, block, 0, ctx->stream, batch, n);
     hipLaunchKernelGGL(anms_gather_kernel, dim3(k), dim3(1024), 0, ctx->stream, batch, n);
     SVO_HIP(hipGetLastError());
     return SVO_OK;

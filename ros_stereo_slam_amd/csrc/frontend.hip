@@ -118,53 +118,7 @@ int grid_axis(int dim, int step)
 
 uint64_t stage_seed(const svo_vo *v, int stage) { return v->prm.seed + 8ull * (uint64_t)v->frame + stage; }
 
-__global__ void gather_kernel(const int *__restrict__ idx, const int *__restrict__ d_count, int cap,
-                              const float2 *__restrict__ in_a, float2 *__restrict__ out_a,
-                              const float2 *__restrict__ in_b, float2 *__restrict__ out_b,
-                              const uint8_t *__restrict__ in_s, uint8_t *__restrict__ out_s)
-{
-    __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= cap || i >= *d_count)
-        return;
-    const int j = idx[i];
-    out_a[i] = in_a[j];
-    out_b[i] = in_b[j];
-    out_s[i] = in_s[j];
-}
-
 __global__ void store_count_kernel(const int *__restrict__ src, int *__restrict__ dst) { *dst = *src; }
-
-// One wave: completes the pose record with the tracked-point count and publishes it into the
-// pinned mailbox slot, then releases the slot's tag at system scope.
-struct PublishBatch {  // one workgroup (one wave) per job
-    PnpRecord *d_rec[SVO_LK_MAX_JOBS];
-    const int *cnt[SVO_LK_MAX_JOBS];
-    PnpRecord *h_rec[SVO_LK_MAX_JOBS];
-    int *h_tag[SVO_LK_MAX_JOBS];
-    int tag[SVO_LK_MAX_JOBS];
-};
-__global__ void publish_record_kernel(PublishBatch b)
-{
-    PnpRecord *__restrict__ d_rec = b.d_rec[blockIdx.x];
-    const int *__restrict__ cnt = b.cnt[blockIdx.x];
-    PnpRecord *h_rec = b.h_rec[blockIdx.x];
-    int *h_tag = b.h_tag[blockIdx.x];
-    const int tag = b.tag[blockIdx.x];
-    __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
-    constexpr int WORDS = sizeof(PnpRecord) / 4, TRACKED = offsetof(PnpRecord, n_tracked) / 4;
-    const int l = threadIdx.x;
-    if (l < WORDS) {
-        int w = l == TRACKED ? *cnt : reinterpret_cast<const int *>(d_rec)[l];
-        if (l == TRACKED)
-            d_rec->n_tracked = w;
-        reinterpret_cast<int *>(h_rec)[l] = w;
-    }
-    __threadfence_system();
-    __syncthreads();
-    if (l == 0)
-        __hip_atomic_store(h_tag, tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
 
 const uint8_t *stage_image(svo_vo *v, const uint8_t *img, int mem, int *rc)
 {
@@ -178,40 +132,6 @@ const uint8_t *stage_image(svo_vo *v, const uint8_t *img, int mem, int *rc)
         *rc = SVO_ERR_HIP;
     }
     return v->d_img;
-}
-
-struct GatherBatch {  // blockIdx.y picks the job
-    const int *idx[SVO_LK_MAX_JOBS];
-    const int *d_count[SVO_LK_MAX_JOBS];
-    const float2 *in_a[SVO_LK_MAX_JOBS];
-    float2 *out_a[SVO_LK_MAX_JOBS];
-    const float2 *in_b[SVO_LK_MAX_JOBS];
-    float2 *out_b[SVO_LK_MAX_JOBS];
-    const uint8_t *in_s[SVO_LK_MAX_JOBS];
-    uint8_t *out_s[SVO_LK_MAX_JOBS];
-};
-__global__ void gather_batch_kernel(GatherBatch b, int cap)
-{
-    __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
-    const int q = blockIdx.y;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= cap || i >= *b.d_count[q])
-        return;
-    const int j = b.idx[q][i];
-    b.out_a[q][i] = b.in_a[q][j];
-    b.out_b[q][i] = b.in_b[q][j];
-    b.out_s[q][i] = b.in_s[q][j];
-}
-
-// the counts of k jobs into the context's pinned block, one launch (k host copies otherwise)
-struct CountBatch {
-    const int *src[SVO_LK_MAX_JOBS];
-};
-__global__ void store_counts_kernel(CountBatch b, int k, int *__restrict__ dst)
-{
-    __builtin_amdgcn_s_setprio(3);
-    if ((int)threadIdx.x < k)
-        dst[threadIdx.x] = *b.src[threadIdx.x];
 }
 
 // visualSLAM::stereoTriangulate, dense branch (src/triangulation.cpp:87-103,137-165), with
@@ -256,27 +176,19 @@ int stereo_triangulate_batch(int k, svo_vo *const *vs, svo_pyramid *const *lefts
     if (v0->prm.anms_keep > 0) {
         const float *xy[SVO_LK_MAX_JOBS], *resp[SVO_LK_MAX_JOBS];
         int *oidx[SVO_LK_MAX_JOBS], *ocnt[SVO_LK_MAX_JOBS];
-        GatherBatch gb = {};
-        for (int a = 0; a < SVO_LK_MAX_JOBS; a++) {
-            svo_vo *v = vs[a < k ? a : 0];
-            if (a < k) {
-                xy[a] = v->grid_xy;
-                resp[a] = v->resp;
-                oidx[a] = v->idx;
-                ocnt[a] = v->d_cnt + 2;
-            }
-            gb.idx[a] = v->idx;
-            gb.d_count[a] = v->d_cnt + 2;
-            gb.in_a[a] = reinterpret_cast<const float2 *>(v->grid_xy);
-            gb.out_a[a] = reinterpret_cast<float2 *>(v->c2);
-            gb.in_b[a] = reinterpret_cast<const float2 *>(v->b2);
-            gb.out_b[a] = reinterpret_cast<float2 *>(v->d2);
-            gb.in_s[a] = v->status;
-            gb.out_s[a] = v->st2;
+        svo_anms_gather ga[SVO_LK_MAX_JOBS];
+        for (int a = 0; a < k; a++) {
+            svo_vo *v = vs[a];
+            xy[a] = v->grid_xy;
+            resp[a] = v->resp;
+            oidx[a] = v->idx;
+            ocnt[a] = v->d_cnt + 2;
+            ga[a] = {v->grid_xy, v->b2, v->c2, v->d2, v->status, v->st2};
         }
-        if ((rc = svo_launch_anms_batch(ctx, k, xy, resp, n, v0->prm.anms_keep, oidx, ocnt)))
+        // the kept keypoints' lattice points, tracked points and status bytes come out of the same launch
+        // that lists them (a gather launch of its own before)
+        if ((rc = svo_launch_anms_batch(ctx, k, xy, resp, n, v0->prm.anms_keep, oidx, ocnt, ga)))
             return rc;
-        hipLaunchKernelGGL(gather_batch_kernel, dim3((n + 63) / 64, k), dim3(64), 0, ctx->stream, gb, n);
         for (int a = 0; a < k; a++) {
             pts[a] = vs[a]->c2;
             trk[a] = vs[a]->d2;
@@ -297,7 +209,8 @@ int stereo_triangulate_batch(int k, svo_vo *const *vs, svo_pyramid *const *lefts
         fj[a] = {o1, o2, n, v->d_cnt + 3, v->prm.f_thr_stereo, 0.99, 1000, stage_seed(v, 3), v->mask, nullptr, nullptr,
                  nullptr};
         c2[a] = {v->mask, n, v->d_cnt + 3, {o1, o2, nullptr}, {x1, x2, nullptr}, {2, 2, 0}, v->d_cnt + 4};
-        tj[a] = {x1, x2, n, v->d_cnt + 4, Rts[a] ? v->b3 : out3d[a], nullptr, Rts[a], Rts[a] ? out3d[a] : nullptr};
+        tj[a] = {x1, x2, n, v->d_cnt + 4, Rts[a] ? v->b3 : out3d[a], nullptr, Rts[a], Rts[a] ? out3d[a] : nullptr,
+                 reinterpret_cast<int *>(ctx->pinned) + a};  // the count the host reads after the wait below
     }
     double P1[12], P2[12];
     svo_stereo_projections(v0->prm.fx, v0->prm.fy, v0->prm.cx, v0->prm.cy, v0->prm.baseline, P1, P2);
@@ -305,11 +218,6 @@ int stereo_triangulate_batch(int k, svo_vo *const *vs, svo_pyramid *const *lefts
         (rc = svo_launch_compact_batch(ctx, k, c2)) || (rc = svo_launch_triangulate_batch(ctx, P1, P2, k, tj)))
         return rc;
     int *pin = reinterpret_cast<int *>(ctx->pinned);
-    CountBatch cb;
-    for (int a = 0; a < SVO_LK_MAX_JOBS; a++)
-        cb.src[a] = vs[a < k ? a : 0]->d_cnt + 4;
-    hipLaunchKernelGGL(store_counts_kernel, dim3(1), dim3(64), 0, ctx->stream, cb, k, pin);
-    SVO_HIP(hipGetLastError());
     if ((rc = svo_wait(ctx)))
         return rc;
     for (int a = 0; a < k; a++) {
@@ -317,6 +225,37 @@ int stereo_triangulate_batch(int k, svo_vo *const *vs, svo_pyramid *const *lefts
         vs[a]->kf_n = Rts[a] ? pin[a] : 0;  // b3 holds the keyframe's camera-frame cloud
     }
     return SVO_OK;
+}
+
+// the PnP-RANSAC problem of a localisation as the chunk runners queue it: solvePnPRansac(100, thr, conf) with
+// the inlier count published early (mailbox `early`) and the finished record into mailbox slot `slot`
+svo_pnp_job pnp_job(svo_vo *v, int cap, const int *cnt_trk, double thr, double conf, uint64_t seed, PnpRecord *d_rec,
+                    int early_tag, int slot, int pose_tag)
+{
+    svo_pnp_job q;
+    q.obj = v->trk3d;
+    q.img = v->trk2d;
+    q.cap = cap;
+    q.d_n = cnt_trk;
+    q.K4[0] = v->prm.fx;
+    q.K4[1] = v->prm.fy;
+    q.K4[2] = v->prm.cx;
+    q.K4[3] = v->prm.cy;
+    q.iterations = 100;
+    q.reproj_err = thr;
+    q.confidence = conf;
+    q.seed = seed;
+    q.refine_iters = 20;
+    q.inliers = v->idx;
+    q.mask = nullptr;
+    q.d_result = d_rec;
+    q.early_mbox = v->mbox->early;
+    q.early_tag = early_tag;
+    q.h_rec = &v->mbox->rec[slot];
+    q.h_tag = &v->mbox->pose_tag[slot];
+    q.tag = pose_tag;
+    q.cnt_trk = cnt_trk;
+    return q;
 }
 
 // The pose ladder of the older visualOdometry::initSequence, src/bundleAdjust.cpp:462-480, on device point
@@ -689,7 +628,6 @@ int svo_vo_run_chunk(svo_vo *v, const uint8_t *const *lefts, const uint8_t *cons
         *n_done = 0;
     if (mem == SVO_MEM_HOST)
         pipeline = 0;  // host images go through one staging buffer; keep them strictly in order
-    const double K4[4] = {v->prm.fx, v->prm.fy, v->prm.cx, v->prm.cy};
     Mailbox *mb = v->mbox;
     int early_tag = 0, pose_tag[2] = {0, 0};
     bool spec = false, next_built = false;
@@ -755,19 +693,10 @@ int svo_vo_run_chunk(svo_vo *v, const uint8_t *const *lefts, const uint8_t *cons
             early_tag = ++v->tag;
             pose_tag[f & 1] = ++v->tag;
             ctx->stream = sP;
-            int r = svo_launch_pnp_ransac(ctx, v->trk3d, v->trk2d, n, cnt_trk, K4, 100, thr, conf, stage_seed(v, stage),
-                                          20, v->idx, nullptr, d_rec, mb->early, early_tag);
+            svo_pnp_job q = pnp_job(v, n, cnt_trk, thr, conf, stage_seed(v, stage), d_rec, early_tag, f & 1, pose_tag[f & 1]);
+            int r = svo_launch_pnp_ransac_batch(ctx, 1, &q);  // publishes the record itself
             ctx->stream = sA;
-            if (r)
-                return r;
-            PublishBatch pb = {};
-            pb.d_rec[0] = d_rec;
-            pb.cnt[0] = cnt_trk;
-            pb.h_rec[0] = &mb->rec[f & 1];
-            pb.h_tag[0] = &mb->pose_tag[f & 1];
-            pb.tag[0] = pose_tag[f & 1];
-            hipLaunchKernelGGL(publish_record_kernel, dim3(1), dim3(64), 0, sP, pb);
-            return SVO_OK;
+            return r;
         };
         if ((rc = launch_pnp(1.0, 0.99, 1)))
             return rc;
@@ -901,21 +830,10 @@ static int run_chunk_group(svo_chunk_job **jobs, int k)
     };
     auto launch_pnp = [&](GS &g, int f, double thr, double conf, int stage) -> int {
         svo_vo *v = g.v;
-        const double K4[4] = {v->prm.fx, v->prm.fy, v->prm.cx, v->prm.cy};
         g.early_tag = ++v->tag;
         g.pose_tag[f & 1] = ++v->tag;
-        int r = svo_launch_pnp_ransac(ctx, v->trk3d, v->trk2d, g.n, g.cnt_trk, K4, 100, thr, conf, stage_seed(v, stage), 20,
-                                      v->idx, nullptr, g.d_rec, v->mbox->early, g.early_tag);
-        if (r)
-            return r;
-        PublishBatch pb = {};
-        pb.d_rec[0] = g.d_rec;
-        pb.cnt[0] = g.cnt_trk;
-        pb.h_rec[0] = &v->mbox->rec[f & 1];
-        pb.h_tag[0] = &v->mbox->pose_tag[f & 1];
-        pb.tag[0] = g.pose_tag[f & 1];
-        hipLaunchKernelGGL(publish_record_kernel, dim3(1), dim3(64), 0, st, pb);
-        return SVO_OK;
+        svo_pnp_job q = pnp_job(v, g.n, g.cnt_trk, thr, conf, stage_seed(v, stage), g.d_rec, g.early_tag, f & 1, g.pose_tag[f & 1]);
+        return svo_launch_pnp_ransac_batch(ctx, 1, &q);
     };
     auto stop = [&](GS &g, int rc) {  // this chunk ends here (tracking lost or an error); the others go on
         g.active = false;
@@ -1056,40 +974,10 @@ static int run_chunk_group(svo_chunk_job **jobs, int k)
             svo_vo *v = g.v;
             g.early_tag = ++v->tag;
             g.pose_tag[f & 1] = ++v->tag;
-            svo_pnp_job &q = pj[a];
-            q.obj = v->trk3d;
-            q.img = v->trk2d;
-            q.cap = g.n;
-            q.d_n = g.cnt_trk;
-            q.K4[0] = v->prm.fx;
-            q.K4[1] = v->prm.fy;
-            q.K4[2] = v->prm.cx;
-            q.K4[3] = v->prm.cy;
-            q.iterations = 100;
-            q.reproj_err = 1.0;
-            q.confidence = 0.99;
-            q.seed = stage_seed(v, 1);
-            q.refine_iters = 20;
-            q.inliers = v->idx;
-            q.mask = nullptr;
-            q.d_result = g.d_rec;
-            q.early_mbox = v->mbox->early;
-            q.early_tag = g.early_tag;
+            pj[a] = pnp_job(v, g.n, g.cnt_trk, 1.0, 0.99, stage_seed(v, 1), g.d_rec, g.early_tag, f & 1, g.pose_tag[f & 1]);
         }
-        if ((rc = svo_launch_pnp_ransac_batch(ctx, np, pj)))
+        if ((rc = svo_launch_pnp_ransac_batch(ctx, np, pj)))  // every record is published by its own workgroup
             return rc;
-        {
-            PublishBatch pb = {};
-            for (int a = 0; a < np; a++) {
-                GS &g = *pg[a];
-                pb.d_rec[a] = g.d_rec;
-                pb.cnt[a] = g.cnt_trk;
-                pb.h_rec[a] = &g.v->mbox->rec[f & 1];
-                pb.h_tag[a] = &g.v->mbox->pose_tag[f & 1];
-                pb.tag[a] = g.pose_tag[f & 1];
-            }
-            hipLaunchKernelGGL(publish_record_kernel, dim3(np), dim3(64), 0, st, pb);
-        }
         // ---- policy of every chunk; the chunks that keyframe are collected ----
         GS *kfs[SVO_LK_MAX_JOBS];
         int nk = 0;

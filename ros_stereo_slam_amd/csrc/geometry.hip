@@ -86,6 +86,7 @@ struct TriJob {
     Mat34 Rt;
     int apply_rt;
     float *out_world;
+    int *h_count;  // pinned host int that receives the live point count (the host waits on the stream), or null
 };
 struct TriBatch {  // blockIdx.y picks the job
     TriJob j[SVO_LK_MAX_JOBS];
@@ -104,6 +105,8 @@ __global__ __launch_bounds__(128) void triangulate_kernel(Mat34 P1, Mat34 P2, Tr
     float *__restrict__ out_world = job.out_world;
     const int n = d_n ? *d_n : n_host;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && job.h_count)
+        *job.h_count = n;  // what a one-thread launch of its own did before (store_counts_kernel)
     if (i >= n)
         return;
     double A[4][4], v[4];
@@ -281,6 +284,7 @@ int svo_launch_triangulate_batch(svo_ctx *ctx, const double *P1, const double *P
         j.Rt = to_mat34(h.Rt);
         j.apply_rt = (h.Rt && h.out_world) ? 1 : 0;
         j.out_world = h.out_world;
+        j.h_count = a < k ? h.h_count : nullptr;
         if (a < k)
             cap_max = h.cap > cap_max ? h.cap : cap_max;
     }
@@ -297,7 +301,7 @@ int svo_launch_triangulate(svo_ctx *ctx, const double *P1, const double *P2, con
                            int cap, const int *d_n, float *out_xyz, float *out_h, const double *Rt,
                            float *out_world)
 {
-    svo_tri_job j = {x1, x2, cap, d_n, out_xyz, out_h, Rt, out_world};
+    svo_tri_job j = {x1, x2, cap, d_n, out_xyz, out_h, Rt, out_world, nullptr};
     return svo_launch_triangulate_batch(ctx, P1, P2, 1, &j);
 }
 

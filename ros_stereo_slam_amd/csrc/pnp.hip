@@ -56,6 +56,11 @@ struct PnpJob {
     int early_tag;
     int direct;             // 1: no RANSAC -- hypothesis 0 (written by pnp_dlt_kernel) is refined over ALL points
     const int *dlt_status;  // direct mode: 0 = hypothesis 0 is valid
+    // optional publication of the finished record into pinned host memory (see svo_pnp_job)
+    int *h_rec;
+    int *h_tag;
+    int tag;
+    const int *cnt_trk;
 };
 struct PnpBatch {
     PnpJob j[SVO_LK_MAX_JOBS];
@@ -327,6 +332,9 @@ struct WaveLds {
     int pq[16];
 };
 
+__device__ __forceinline__ float reproj_err_sq(const double (&P)[12], const K4 &K, float X, float Y, float Z, float u,
+                                               float v);
+
 __global__ __launch_bounds__(64, 4) void pnp_solve_kernel(PnpBatch batch)
 {
     __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
@@ -340,6 +348,7 @@ __global__ __launch_bounds__(64, 4) void pnp_solve_kernel(PnpBatch batch)
     const RansacState *__restrict__ st = job.st;
     double *__restrict__ hyp = job.hyp;
     int *__restrict__ nmodels = job.nmodels;
+    int *__restrict__ counts = job.counts;
     __shared__ WaveLds s_lds[1];
     const int lane = threadIdx.x & 63;
     const int it = __builtin_amdgcn_readfirstlane(it0 + blockIdx.x);  // one wave per workgroup
@@ -350,8 +359,10 @@ __global__ __launch_bounds__(64, 4) void pnp_solve_kernel(PnpBatch batch)
     WaveLds &S = s_lds[0];
     const int n = d_n ? *d_n : n_host;
     if (n < MP) {
-        if (lane == 0)
+        if (lane == 0) {
             nmodels[it] = -1;
+            counts[it] = 0;
+        }
         return;
     }
     // ---- sample (every lane draws the same indices) ----
@@ -382,6 +393,8 @@ __global__ __launch_bounds__(64, 4) void pnp_solve_kernel(PnpBatch batch)
     if (!filled) {
         if (lane == 0)
             nmodels[it] = -1;
+        if (lane == 0)
+            counts[it] = 0;
         return;
     }
     if (lane < MP) {
@@ -456,6 +469,8 @@ __global__ __launch_bounds__(64, 4) void pnp_solve_kernel(PnpBatch batch)
     if (!(fabs(det) > 1e-18 * scale * scale * scale) || !isfinite(det)) {
         if (lane == 0)
             nmodels[it] = 0;  // coplanar / coincident sample: no model, the loop continues
+        if (lane == 0)
+            counts[it] = 0;
         return;
     }
     const double id = 1. / det;
@@ -753,20 +768,39 @@ __global__ __launch_bounds__(64, 4) void pnp_solve_kernel(PnpBatch batch)
         eb = e2;
     }
     if (best < 0) {
-        if (lane == 0)
+        if (lane == 0) {
             nmodels[it] = 0;
+            counts[it] = 0;
+        }
         return;
     }
-    if (lane == best) {
+    double P[12];
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+        P[i] = __shfl(R[i], best);
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+        P[9 + i] = __shfl(t[i], best);
+    if (lane == 0) {
         double *dst = hyp + (size_t)it * 12;
 #pragma unroll
-        for (int i = 0; i < 9; i++)
-            dst[i] = R[i];
-        dst[9] = t[0];
-        dst[10] = t[1];
-        dst[11] = t[2];
+        for (int i = 0; i < 12; i++)
+            dst[i] = P[i];
         nmodels[it] = 1;
     }
+    // ---- PnPRansacCallback::computeError over all points: the hypothesis's inlier count (a launch of its
+    // own until round 2; same wave-per-hypothesis mapping, and one launch less in the chain) ----
+    const float2 *__restrict__ img2 = reinterpret_cast<const float2 *>(img);
+    const float thr = job.thr;
+    int cnt = 0;
+#pragma clang loop unroll(disable)  // unrolled, the f64 bodies take >128 VGPRs + scratch
+    for (int i = lane; i < n; i += 64) {
+        const float2 u = img2[i];
+        cnt += reproj_err_sq(P, K, obj[3 * i], obj[3 * i + 1], obj[3 * i + 2], u.x, u.y) <= thr ? 1 : 0;
+    }
+    cnt = wave_sum_small(cnt);
+    if (lane == 0)
+        counts[it] = cnt;
 }
 
 // PnPRansacCallback::computeError for one correspondence
@@ -780,48 +814,6 @@ __device__ __forceinline__ float reproj_err_sq(const double (&P)[12], const K4 &
     const float px = (float)(Xc * z * K.fx + K.cx), py = (float)(Yc * z * K.fy + K.cy);
     const float dx = u - px, dy = v - py;
     return (float)((double)dx * dx + (double)dy * dy);
-}
-
-__global__ __launch_bounds__(64, 4) void pnp_score_kernel(PnpBatch batch)
-{
-    __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
-    const PnpJob &job = batch.j[blockIdx.y];
-    const float *__restrict__ obj = job.obj;
-    const float2 *__restrict__ img = reinterpret_cast<const float2 *>(job.img);
-    const int n_host = job.n_host;
-    const int *__restrict__ d_n = job.d_n;
-    const K4 K = job.K;
-    const int it0 = 0, it1 = job.iterations;
-    const RansacState *__restrict__ st = job.st;
-    const double *__restrict__ hyp = job.hyp;
-    const int *__restrict__ nmodels = job.nmodels;
-    const float thr = job.thr;
-    int *__restrict__ counts = job.counts;
-    const int lane = threadIdx.x & 63;
-    const int it = __builtin_amdgcn_readfirstlane(it0 + blockIdx.x);  // one wave per workgroup
-    if (it >= it1)
-        return;
-    if (it0 > 0 && st->done)
-        return;
-    if (nmodels[it] <= 0) {
-        if (lane == 0)
-            counts[it] = 0;
-        return;
-    }
-    const int n = d_n ? *d_n : n_host;
-    double P[12];
-#pragma unroll
-    for (int i = 0; i < 12; i++)
-        P[i] = hyp[(size_t)it * 12 + i];
-    int cnt = 0;
-#pragma clang loop unroll(disable)  // unrolled, the f64 bodies take >128 VGPRs + scratch: the wave then needs two freed tracking slots
-    for (int i = lane; i < n; i += 64) {
-        const float2 u = img[i];
-        cnt += reproj_err_sq(P, K, obj[3 * i], obj[3 * i + 1], obj[3 * i + 2], u.x, u.y) <= thr ? 1 : 0;
-    }
-    cnt = wave_sum_small(cnt);
-    if (lane == 0)
-        counts[it] = cnt;
 }
 
 // ---- Levenberg-Marquardt refinement over the inlier list -------------------------------------
@@ -1151,6 +1143,23 @@ struct PnpResult {      // what the host reads back after a localisation
     int n_inliers, iters_run;
 };
 
+// One thread: the record (PnpResult, 34 words) and the tracked-point count behind it into the pinned
+// mailbox slot, then the slot's tag released at system scope -- the host spins on the tag.
+__device__ void publish_record(const PnpJob &job, const PnpResult &r, PnpResult *d_out)
+{
+    const int n_tracked = job.cnt_trk ? *job.cnt_trk : 0;
+    reinterpret_cast<int *>(d_out + 1)[0] = n_tracked;  // PnpRecord::n_tracked sits right behind the result
+    if (!job.h_rec)
+        return;
+    const int *w = reinterpret_cast<const int *>(&r);
+    constexpr int WORDS = sizeof(PnpResult) / 4;
+    for (int k = 0; k < WORDS; k++)
+        job.h_rec[k] = w[k];
+    job.h_rec[WORDS] = n_tracked;
+    __threadfence_system();
+    __hip_atomic_store(job.h_tag, job.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // The tail of solvePnPRansac in ONE single-workgroup launch: (1) thread 0 replays the sequential
 // RANSAC loop over the scored hypotheses and publishes the inlier count for the host policy;
 // (2) the workgroup evaluates the winning hypothesis on every point, writes the mask and the
@@ -1249,6 +1258,7 @@ __global__ __launch_bounds__(256, 4) void pnp_finish_kernel(PnpBatch batch)
             memset(&r, 0, sizeof(r));
             r.iters_run = s.iters_run;
             *out = r;
+            publish_record(job, r, out);
         }
         return;
     }
@@ -1356,6 +1366,7 @@ __global__ __launch_bounds__(256, 4) void pnp_finish_kernel(PnpBatch batch)
         r.n_inliers = m;
         r.iters_run = s.iters_run;
         *out = r;
+        publish_record(job, r, out);
     }
 }
 
@@ -1412,6 +1423,10 @@ int svo_launch_pnp_ransac_batch(svo_ctx *ctx, int n_jobs, const svo_pnp_job *job
         j.early_tag = h.early_tag;
         j.direct = 0;
         j.dlt_status = nullptr;
+        j.h_rec = reinterpret_cast<int *>(h.h_rec);
+        j.h_tag = h.h_tag;
+        j.tag = h.tag;
+        j.cnt_trk = h.cnt_trk;
         nb++;
     }
     if (nb == 0)
@@ -1421,8 +1436,7 @@ int svo_launch_pnp_ransac_batch(svo_ctx *ctx, int n_jobs, const svo_pnp_job *job
     ScopedKernelTime tm(ctx, SVO_K_PNP);
     // single-wave workgroups: they get wave slots beside a tracking launch as soon as one frees
     const int nblk = it_max;
-    hipLaunchKernelGGL(pnp_solve_kernel, dim3(nblk, nb), dim3(64), 0, ctx->stream, batch);
-    hipLaunchKernelGGL(pnp_score_kernel, dim3(nblk, nb), dim3(64), 0, ctx->stream, batch);
+    hipLaunchKernelGGL(pnp_solve_kernel, dim3(nblk, nb), dim3(64), 0, ctx->stream, batch);  // solves AND scores
     hipLaunchKernelGGL(pnp_finish_kernel, dim3(nb), dim3(256), 0, ctx->stream, batch);
     SVO_HIP(hipGetLastError());
     return SVO_OK;
@@ -1450,6 +1464,10 @@ int svo_launch_pnp_ransac(svo_ctx *ctx, const float *obj, const float *img, int 
     j.d_result = d_result;
     j.early_mbox = early_mbox;
     j.early_tag = early_tag;
+    j.h_rec = nullptr;
+    j.h_tag = nullptr;
+    j.tag = 0;
+    j.cnt_trk = nullptr;
     return svo_launch_pnp_ransac_batch(ctx, 1, &j);
 }
 
@@ -1496,6 +1514,10 @@ int svo_launch_solve_pnp(svo_ctx *ctx, const float *obj, const float *img, int c
     j.early_tag = early_tag;
     j.direct = 1;
     j.dlt_status = d.status;
+    j.h_rec = nullptr;
+    j.h_tag = nullptr;
+    j.tag = 0;
+    j.cnt_trk = nullptr;
     for (int k = 1; k < SVO_LK_MAX_JOBS; k++)
         batch.j[k] = batch.j[0];
     ScopedKernelTime tm(ctx, SVO_K_PNP);

@@ -170,6 +170,7 @@ struct svo_tri_job {  // one stereo DLT triangulation (device pointers; Rt: host
     float *out_xyz, *out_h;
     const double *Rt;
     float *out_world;
+    int *h_count;  // pinned host int that receives the live count, or null
 };
 int svo_launch_triangulate_batch(svo_ctx *ctx, const double *P1, const double *P2, int k, const svo_tri_job *jobs);
 int svo_launch_transform(svo_ctx *ctx, const double *Rt, const float *in, int cap, const int *d_n, float *out);
@@ -211,6 +212,12 @@ struct svo_pnp_job {  // host-side description of one PnP-RANSAC problem (device
     void *d_result;
     int *early_mbox;
     int early_tag;
+    // optional: the finished record (PnpResult + the tracked-point count *cnt_trk) published into pinned host
+    // memory, then h_tag released at system scope (what publish_record_kernel did as a launch of its own)
+    void *h_rec;
+    int *h_tag;
+    int tag;
+    const int *cnt_trk;
 };
 int svo_launch_pnp_ransac_batch(svo_ctx *ctx, int n_jobs, const svo_pnp_job *jobs);
 int svo_launch_pnp_ransac(svo_ctx *ctx, const float *obj, const float *img, int cap, const int *d_n,
@@ -220,6 +227,13 @@ int svo_launch_pnp_ransac(svo_ctx *ctx, const float *obj, const float *img, int 
 int svo_launch_solve_pnp(svo_ctx *ctx, const float *obj, const float *img, int cap, const int *d_n, const double *K4h,
                          int refine_iters, int *inliers, void *d_result, int *early_mbox = nullptr, int early_tag = 0);
 // anms.hip
+// optional gather of the kept keypoints in the same launch that lists them (out_x[i] = in_x[out_idx[i]])
+struct svo_anms_gather {
+    const float *in_a, *in_b;  // float2 arrays
+    float *out_a, *out_b;
+    const uint8_t *in_s;
+    uint8_t *out_s;
+};
 int svo_launch_anms_batch(svo_ctx *ctx, int k, const float *const *xy, const float *const *resp, int n, int keep,
-                          int *const *out_idx, int *const *d_count);
+                          int *const *out_idx, int *const *d_count, const svo_anms_gather *gather = nullptr);
 int svo_launch_anms(svo_ctx *ctx, const float *xy, const float *resp, int n, int keep, int *out_idx, int *d_count);
