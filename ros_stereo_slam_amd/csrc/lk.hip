@@ -515,8 +515,8 @@ __global__ __launch_bounds__(64 * WAVES, 4) void lk_track_kernel(LkBatch batch, 
         {
             // the spare lane (63) interpolates its derivative patch with zero weights: Ix = Iy = 0 there, so
             // its share of every sum below and in the iterations is 0 without any masking
-            const int wp0 = active ? (w00 & 0xffff) | (w01 << 16) : 0, wp1 = active ? (w10 & 0xffff) | (w11 << 16) : 0;
-            constexpr int NE = SEG * C;
+            const int wq0 = active ? (w00 & 0xffff) | (w10 << 16) : 0, wq1 = active ? (w01 & 0xffff) | (w11 << 16) : 0;
+            constexpr int NE = SEG * C, NV = (SEG + 1) * C;
             unsigned t0[ndwords(C)], t1[ndwords(C)];
             const int toff = (int)(Ts - lds) + (wy + 1) * TROW + (wx + 1) * C;
             load_row_packed<C>(lds, toff, t0);
@@ -525,21 +525,31 @@ __global__ __launch_bounds__(64 * WAVES, 4) void lk_track_kernel(LkBatch batch, 
             constexpr int DROW = DTile<C>::ROW / 4;
             const int *d0 = D + wy * DROW + wx * C;
             const int *d1 = d0 + DROW;
-            int ix[NE + 1], iy[NE + 1];
-            ix[NE] = iy[NE] = 0;
-            ForEachElem<C, NE>::run([&](auto kc) {
+            // Derivative tile entries are (4 dx | 4 dy << 16) (pyramid.hip; |4 d| <= 16320: int16).  As for the
+            // image samples, the VERTICAL neighbours of column k are paired once (element k uses columns k and
+            // k + C): 2 permutes per column instead of 4 per element.  With the factor 4 the descale by 2^14 is
+            // "take the high half" -- the permute that packs two elements does it, no shift:
+            //   (4 (sum w d) + 4 RD) >> 16  ==  (sum w d + RD) >> 14.
+            int vx[NV], vy[NV];
+            ForEachElem<C, NV>::run([&](auto kc) {
                 constexpr int k = decltype(kc)::value;
-                // derivative tile entries are (dx | dy << 16); |derivative| <= 4080: exact in int16 pairs
-                const int p00 = d0[k], p01 = d0[k + C], p10 = d1[k], p11 = d1[k + C];
-                constexpr int RD = 1 << (W_BITS - 1);
-                ix[k] = sdot2(half_pair<false>(p10, p11), wp1, sdot2(half_pair<false>(p00, p01), wp0, RD)) >> W_BITS;
-                iy[k] = sdot2(half_pair<true>(p10, p11), wp1, sdot2(half_pair<true>(p00, p01), wp0, RD)) >> W_BITS;
+                const int up = d0[k], lo = d1[k];
+                vx[k] = half_pair<false>(up, lo);
+                vy[k] = half_pair<true>(up, lo);
             });
+            constexpr int RD4 = 4 << (W_BITS - 1);
+            int sx[NE + 1], sy[NE + 1];
+            sx[NE] = sy[NE] = 0;
+#pragma unroll
+            for (int k = 0; k < NE; k++) {
+                sx[k] = sdot2(vx[k + C], wq1, sdot2_sconst(vx[k], wq0, RD4));
+                sy[k] = sdot2(vy[k + C], wq1, sdot2_sconst(vy[k], wq0, RD4));
+            }
 #pragma unroll
             for (int j = 0; j < npairs(C); j++) {
                 const int k0 = 2 * j, k1 = 2 * j + 1 < NE ? 2 * j + 1 : NE;
-                Ixp[j] = half_pair<false>(ix[k0], ix[k1]);
-                Iyp[j] = half_pair<false>(iy[k0], iy[k1]);
+                Ixp[j] = half_pair<true>(sx[k0], sx[k1]);
+                Iyp[j] = half_pair<true>(sy[k0], sy[k1]);
                 a11 = sdot2(Ixp[j], Ixp[j], a11);  // sums of squares of int16 pairs, exact
                 a12 = sdot2(Ixp[j], Iyp[j], a12);
                 a22 = sdot2(Iyp[j], Iyp[j], a22);
@@ -573,13 +583,16 @@ __global__ __launch_bounds__(64 * WAVES, 4) void lk_track_kernel(LkBatch batch, 
         // ---- 2. iterate on the next image out of an LDS tile ----
         nxp -= half;
         nyp -= half;
-        float pdx = 0.f, pdy = 0.f;
+        float pdx = 0.f, pdy = 0.f, ldx = 0.f, ldy = 0.f;
         const int lane_off = wy * Tile<C, TS>::ROW + wx * C;  // this lane's row run inside the window
         int ox = 0, oy = 0;
         bool have_tile = false;
-        const uint8_t *TJs = TJ;
+        int tj_off = 0;          // LDS byte offset of the staged tile's pixel (0, 0): TJ's offset + the staging shift
+        bool stepped = false;    // at least one Newton step taken: the output is nxp + half (else the guess itself)
+        bool halved = false;     // left through the oscillation test: the output backs off half a step
         for (int j = 0; j < prm.max_count; j++) {
-            const int inx = uniform((int)floorf(nxp)), iny = uniform((int)floorf(nyp));
+            const float fx = floorf(nxp), fy = floorf(nyp);
+            const int inx = uniform((int)fx), iny = uniform((int)fy);
             if (inx < -WIN || inx >= lw || iny < -WIN || iny >= lh) {
                 if (level == 0)
                     st = 0;
@@ -589,14 +602,14 @@ __global__ __launch_bounds__(64 * WAVES, 4) void lk_track_kernel(LkBatch batch, 
                 ox = inx - JR;
                 oy = iny - JR;
                 wave_lds_sync();
-                TJs = TJ + stage_tile<C, TS>(TJ, J, pitch, ox, oy, lane);
+                tj_off = (int)(TJ - lds) + uniform(stage_tile<C, TS>(TJ, J, pitch, ox, oy, lane));
                 wave_lds_sync();
                 have_tile = true;
             }
             int wv0, wv1;
-            bilinear_weight_pairs(nxp - (float)inx, nyp - (float)iny, wv0, wv1);
+            bilinear_weight_pairs(nxp - fx, nyp - fy, wv0, wv1);
             int s1, s2;
-            lane_mismatch<C>(lds, lane_off + uniform((int)(TJs - lds) + (iny - oy) * Tile<C, TS>::ROW + (inx - ox) * C),
+            lane_mismatch<C>(lds, lane_off + (tj_off + (iny - oy) * Tile<C, TS>::ROW + (inx - ox) * C),
                              wv0, wv1, Ixp, Iyp, neg_c1, neg_c2, s1, s2);
             float b1, b2;
             wave_sum2_float(s1, s2, b1, b2);
@@ -606,8 +619,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void lk_track_kernel(LkBatch batch, 
             const float dy = (A12 * b1 - A11 * b2) * Dd;
             nxp += dx;
             nyp += dy;
-            outx = nxp + half;
-            outy = nyp + half;
+            stepped = true;
             // |dx|^2 + |dy|^2 <= eps^2 in double, as the reference; only a step that is small in float
             // can pass, so the double arithmetic is skipped for all the others
             if (uniform(fmaxf(fabsf(dx), fabsf(dy)) <= prm.eps_pre) &&
@@ -615,12 +627,23 @@ __global__ __launch_bounds__(64 * WAVES, 4) void lk_track_kernel(LkBatch batch, 
                 break;
             // fabs((double)x) < 0.01  <=>  |x| <= 0.01f for a float x: 0.01f is the largest float below 0.01
             if (j > 0 && uniform(fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f)) {
-                outx -= dx * 0.5f;
-                outy -= dy * 0.5f;
+                halved = true;
+                ldx = dx;
+                ldy = dy;
                 break;
             }
             pdx = dx;
             pdy = dy;
+        }
+        // the reference keeps nextPt = guess + half up to date inside the loop; the same float operations
+        // in the same order, once, after it
+        if (stepped) {
+            outx = nxp + half;
+            outy = nyp + half;
+            if (halved) {
+                outx -= ldx * 0.5f;
+                outy -= ldy * 0.5f;
+            }
         }
 
         // ---- 3. level-0 residual (err output of calcOpticalFlowPyrLK) ----
@@ -637,12 +660,12 @@ __global__ __launch_bounds__(64 * WAVES, 4) void lk_track_kernel(LkBatch batch, 
                 ox = iqx - JR;
                 oy = iqy - JR;
                 wave_lds_sync();
-                TJs = TJ + stage_tile<C, TS>(TJ, J, pitch, ox, oy, lane);
+                tj_off = (int)(TJ - lds) + uniform(stage_tile<C, TS>(TJ, J, pitch, ox, oy, lane));
                 wave_lds_sync();
                 have_tile = true;
             }
             bilinear_weights(qx - (float)iqx, qy - (float)iqy, w00, w01, w10, w11);
-            int s1 = lane_abs_residual<C>(lds, lane_off + uniform((int)(TJs - lds) + (iqy - oy) * Tile<C, TS>::ROW + (iqx - ox) * C),
+            int s1 = lane_abs_residual<C>(lds, lane_off + (tj_off + (iqy - oy) * Tile<C, TS>::ROW + (iqx - ox) * C),
                                           (w00 & 0xffff) | (w10 << 16), (w01 & 0xffff) | (w11 << 16), Ivp);
             if (!active)
                 s1 = 0;

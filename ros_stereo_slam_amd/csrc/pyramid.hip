@@ -266,7 +266,9 @@ __device__ __forceinline__ void scharr_row(const uint8_t *__restrict__ lvl, int 
     int out[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const int dx = S[j + 2 * C] - S[j], dy = 3 * (V[j] + V[j + 2 * C]) + 10 * V[j + C];
+        // stored times 4 (|4 d| <= 16320 fits int16): the tracker's descale by 2^14 of the interpolated
+        // derivative then is "the high half of the sum", see lk.hip
+        const int dx = 4 * (S[j + 2 * C] - S[j]), dy = 12 * (V[j] + V[j + 2 * C]) + 40 * V[j + C];
         out[j] = (int)__builtin_amdgcn_perm((unsigned)dy, (unsigned)dx, 0x05040100u);  // (dx & 0xffff) | (dy << 16)
     }
     int *drow = reinterpret_cast<int *>(reinterpret_cast<uint8_t *>(dlvl) + (ptrdiff_t)y * dpitch);
