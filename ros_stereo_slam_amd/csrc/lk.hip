@@ -70,7 +70,10 @@ template <int C> struct Lds {
     static constexpr int T_BYTES = Tile<C, PT>::BYTES;
     static constexpr int D_BYTES = DTile<C>::BYTES;
     static constexpr int J_BYTES = Tile<C, TS>::BYTES;
-    static constexpr int A = T_BYTES + D_BYTES;
+    // the three tiles take turns in the same space: 6.7 KB per wave, so that the 16 waves of a tracking
+    // launch leave a third of a CU's LDS to the short kernels of the other chunks' stages (with the
+    // previous-image tile beside the derivative tile, 9.4 KB, those waited for tracking waves to end)
+    static constexpr int A = T_BYTES > D_BYTES ? T_BYTES : D_BYTES;
     static constexpr int WAVE_BYTES = (((A > J_BYTES ? A : J_BYTES) + 15) / 16) * 16;
 };
 
@@ -454,8 +457,8 @@ __global__ __launch_bounds__(64 * WAVES, 4) void lk_track_kernel(LkBatch batch, 
         return;  // whole wave leaves; no workgroup barrier is used below
     uint8_t *lds = smem + wave * Lds<C>::WAVE_BYTES;
     uint8_t *T = lds;                                           // PT x PT x C bytes
-    uint8_t *DB = lds + Lds<C>::T_BYTES;                        // DT rows of packed (dx | dy<<16), as loaded
-    uint8_t *TJ = lds;                                          // TS x TS x C bytes (reuses T/D)
+    uint8_t *DB = lds;                                          // DT rows of packed (4 dx | 4 dy << 16), as loaded (after T)
+    uint8_t *TJ = lds;                                          // TS x TS x C bytes (after D)
 
     constexpr int TROW = Tile<C, PT>::ROW;
     const bool active = lane < 3 * WIN;
@@ -501,13 +504,9 @@ __global__ __launch_bounds__(64 * WAVES, 4) void lk_track_kernel(LkBatch batch, 
         int w00, w01, w10, w11;
         bilinear_weights(px - (float)ipx, py - (float)ipy, w00, w01, w10, w11);
 
-        // ---- 1. previous-image tile, Scharr tile, patch registers, normal matrix ----
+        // ---- 1. previous-image tile -> template patch; derivative tile -> derivative patches, normal matrix ----
         wave_lds_sync();
         const uint8_t *Ts = T + stage_tile<C, PT>(T, I, pitch, ipx - 1, ipy - 1, lane);
-        // the Scharr derivatives of the window's 22x22 neighbourhood come from the derivative level
-        // (zero outside the image: the level's border is zero)
-        const int *D = reinterpret_cast<const int *>(
-            DB + stage_dtile<C>(DB, dprev + prm.doff[level], prm.dpitch[level], ipx, ipy, lane));
         wave_lds_sync();
 
         int Ivp[npairs(C)], Ixp[npairs(C)], Iyp[npairs(C)];  // packed int16 pairs (low = even element)
@@ -517,11 +516,19 @@ __global__ __launch_bounds__(64 * WAVES, 4) void lk_track_kernel(LkBatch batch, 
             // its share of every sum below and in the iterations is 0 without any masking
             const int wq0 = active ? (w00 & 0xffff) | (w10 << 16) : 0, wq1 = active ? (w01 & 0xffff) | (w11 << 16) : 0;
             constexpr int NE = SEG * C, NV = (SEG + 1) * C;
-            unsigned t0[ndwords(C)], t1[ndwords(C)];
-            const int toff = (int)(Ts - lds) + (wy + 1) * TROW + (wx + 1) * C;
-            load_row_packed<C>(lds, toff, t0);
-            load_row_packed<C>(lds, toff + TROW, t1);
-            lane_samples<C, W_BITS - 5>(t0, t1, (w00 & 0xffff) | (w10 << 16), (w01 & 0xffff) | (w11 << 16), Ivp);
+            {
+                unsigned t0[ndwords(C)], t1[ndwords(C)];
+                const int toff = (int)(Ts - lds) + (wy + 1) * TROW + (wx + 1) * C;
+                load_row_packed<C>(lds, toff, t0);
+                load_row_packed<C>(lds, toff + TROW, t1);
+                lane_samples<C, W_BITS - 5>(t0, t1, (w00 & 0xffff) | (w10 << 16), (w01 & 0xffff) | (w11 << 16), Ivp);
+            }
+            // the Scharr derivatives of the window's 22x22 neighbourhood come from the derivative level
+            // (zero outside the image: the level's border is zero); the tile takes the place of T
+            wave_lds_sync();
+            const int *D = reinterpret_cast<const int *>(
+                DB + stage_dtile<C>(DB, dprev + prm.doff[level], prm.dpitch[level], ipx, ipy, lane));
+            wave_lds_sync();
             constexpr int DROW = DTile<C>::ROW / 4;
             const int *d0 = D + wy * DROW + wx * C;
             const int *d1 = d0 + DROW;
