@@ -58,6 +58,7 @@ constexpr int KPW = 8;
 // also emits the sorted (x, y, response) triples the radius pass streams through.
 __global__ __launch_bounds__(64) void anms_rank_kernel(AnmsBatch batch, int n)
 {
+    svo_chain_priority();
     __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     const AnmsJob &job = batch.j[blockIdx.y];
     const float2 *__restrict__ xy = job.xy;
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(64) void anms_rank_kernel(AnmsBatch batch, int n)
 // squared suppression radius of the s-th sorted keypoint (DBL_MAX when nothing dominates it)
 __global__ __launch_bounds__(64) void anms_radius_kernel(AnmsBatch batch, int n)
 {
+    svo_chain_priority();
     __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     const float4 *__restrict__ sorted = batch.j[blockIdx.y].sorted;
     double *__restrict__ radius_sq = batch.j[blockIdx.y].radius;
@@ -182,6 +184,7 @@ __global__ __launch_bounds__(64) void anms_radius_kernel(AnmsBatch batch, int n)
 // decision radius = the (keep+1)-th largest radius
 __global__ __launch_bounds__(64) void anms_decide_kernel(AnmsBatch batch, int n, int keep)
 {
+    svo_chain_priority();
     __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     const double *__restrict__ radius_sq = batch.j[blockIdx.y].radius;
     double *__restrict__ decision = batch.j[blockIdx.y].decision;
@@ -228,6 +231,7 @@ __global__ __launch_bounds__(64) void anms_decide_kernel(AnmsBatch batch, int n,
 // the payload arrays of the kept keypoints are gathered in the same pass
 __global__ __launch_bounds__(1024) void anms_gather_kernel(AnmsBatch batch, int n)
 {
+    svo_chain_priority();
     __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     const AnmsJob &job = batch.j[blockIdx.x];  // one workgroup per job
     const double *__restrict__ radius_sq = job.radius;

@@ -337,6 +337,7 @@ __device__ __forceinline__ float reproj_err_sq(const double (&P)[12], const K4 &
 
 __global__ __launch_bounds__(64, 4) void pnp_solve_kernel(PnpBatch batch)
 {
+    svo_chain_priority();
     __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     const PnpJob &job = batch.j[blockIdx.y];
     const float *__restrict__ obj = job.obj, *__restrict__ img = job.img;
@@ -1165,8 +1166,9 @@ __device__ void publish_record(const PnpJob &job, const PnpResult &r, PnpResult 
 // (2) the workgroup evaluates the winning hypothesis on every point, writes the mask and the
 // order-preserving inlier index list (ballot scan); (3) Levenberg-Marquardt refinement over the
 // inlier list.
-__global__ __launch_bounds__(256, 4) void pnp_finish_kernel(PnpBatch batch)
+__global__ __launch_bounds__(256, 5) void pnp_finish_kernel(PnpBatch batch)
 {
+    svo_chain_priority();
     __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     const PnpJob &job = batch.j[blockIdx.x];  // one workgroup per job
     const float *__restrict__ obj = job.obj;

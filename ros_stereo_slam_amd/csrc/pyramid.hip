@@ -164,6 +164,7 @@ __device__ __forceinline__ void pad_copy_row(const uint8_t *__restrict__ src, ui
 // launch 1: workgroups [0, n_tiles) build level 1 from the raw image, the rest the padded level 0
 template <int C> __global__ __launch_bounds__(PB) void pyr_base_kernel(PyrBuild b, int tiles_x, int n_tiles, int pad_x)
 {
+    svo_chain_priority();
     __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     const int job = blockIdx.y;
     if ((int)blockIdx.x < n_tiles) {
@@ -184,6 +185,7 @@ template <int C> __global__ __launch_bounds__(PB) void pyr_base_kernel(PyrBuild 
 // launches 2 and 3: level l from level l - 1
 template <int C> __global__ __launch_bounds__(PB) void pyr_down_kernel(PyrBuild b, int l)
 {
+    svo_chain_priority();
     __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     down_tile<C, false>(b.lvl[blockIdx.z][l - 1], b.pitch[l - 1], b.w[l - 1], b.h[l - 1], b.lvl[blockIdx.z][l], b.pitch[l],
                         b.w[l], b.h[l], blockIdx.x, blockIdx.y);
@@ -289,6 +291,7 @@ struct FinishPlan {
 };
 template <int C> __global__ __launch_bounds__(PB) void pyr_finish_kernel(PyrBuild b, FinishPlan plan)
 {
+    svo_chain_priority();
     __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     const int job = blockIdx.z, by = blockIdx.y;
     if (by < plan.border_y0[b.levels]) {

@@ -22,6 +22,12 @@
 
 void svo_set_error(const char *fmt, ...);
 
+// The short kernels between two tracking launches (F-RANSAC, PnP, ANMS, compaction, pyramids) run beside the
+// tracking launches of the other contexts, whose waves keep every SIMD's issue port busy: a latency-bound
+// wave that takes its turn among four tracking waves runs at a fifth of its speed.  They raise their issue
+// priority instead (s_setprio: the arbiter picks the highest-priority ready wave); the tracker stays at 0.
+__device__ __forceinline__ void svo_chain_priority() { __builtin_amdgcn_s_setprio(3); }
+
 #define SVO_HIP(call)                                                                         \
     do {                                                                                      \
         hipError_t e_ = (call);                                                               \

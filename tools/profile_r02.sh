@@ -12,6 +12,7 @@ ARGS="--steps 20 --warmup 5 --no-cpu-baseline --no-extras"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/r02_trace -o bench -- python3 bench.py $ARGS > $OUT/trace_bench.json 2> $OUT/trace.err || exit 1
 cp /tmp/r02_trace/bench_kernel_stats.csv $OUT/kernel_stats_all.csv
 keep /tmp/r02_trace/bench_kernel_trace.csv $OUT/kernel_trace.csv
+[ "$1" = trace ] && exit 0   # `profile_r02.sh trace`: the kernel trace only
 PARGS="--steps 6 --warmup 1 --no-cpu-baseline --no-extras"
 timeout -k 10 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d /tmp/r02_sq -o sq -- python3 bench.py $PARGS > $OUT/sq_bench.json 2> $OUT/sq.err || exit 2
 keep /tmp/r02_sq/sq_counter_collection.csv $OUT/sq_counter_collection.csv
