@@ -59,7 +59,6 @@ constexpr int KPW = 8;
 __global__ __launch_bounds__(64) void anms_rank_kernel(AnmsBatch batch, int n)
 {
     svo_chain_priority();
-    __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     const AnmsJob &job = batch.j[blockIdx.y];
     const float2 *__restrict__ xy = job.xy;
     const float *__restrict__ resp = job.resp;
@@ -126,7 +125,6 @@ __global__ __launch_bounds__(64) void anms_rank_kernel(AnmsBatch batch, int n)
 __global__ __launch_bounds__(64) void anms_radius_kernel(AnmsBatch batch, int n)
 {
     svo_chain_priority();
-    __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     const float4 *__restrict__ sorted = batch.j[blockIdx.y].sorted;
     double *__restrict__ radius_sq = batch.j[blockIdx.y].radius;
     const int lane = threadIdx.x & 63;
@@ -185,7 +183,6 @@ __global__ __launch_bounds__(64) void anms_radius_kernel(AnmsBatch batch, int n)
 __global__ __launch_bounds__(64) void anms_decide_kernel(AnmsBatch batch, int n, int keep)
 {
     svo_chain_priority();
-    __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     const double *__restrict__ radius_sq = batch.j[blockIdx.y].radius;
     double *__restrict__ decision = batch.j[blockIdx.y].decision;
     const int lane = threadIdx.x & 63;
@@ -232,7 +229,6 @@ __global__ __launch_bounds__(64) void anms_decide_kernel(AnmsBatch batch, int n,
 __global__ __launch_bounds__(1024) void anms_gather_kernel(AnmsBatch batch, int n)
 {
     svo_chain_priority();
-    __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     const AnmsJob &job = batch.j[blockIdx.x];  // one workgroup per job
     const double *__restrict__ radius_sq = job.radius;
     const double decision = *job.decision;

@@ -141,7 +141,6 @@ __device__ bool collinear_last(const float *__restrict__ p, const int (&idx)[M])
 __global__ __launch_bounds__(SOLVE_T) void fr_solve_kernel(FrBatch batch, int it0, int it1_cap)
 {
     svo_chain_priority();
-    __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     const FrJob &job = batch.j[blockIdx.y];
     const float *__restrict__ p1 = job.p1, *__restrict__ p2 = job.p2;
     const int n_host = job.n_host;
@@ -345,7 +344,6 @@ __device__ __forceinline__ float f_error(const double (&F)[9], float x1, float y
 __global__ __launch_bounds__(64, 4) void fr_score_kernel(FrBatch batch, int it0, int it1_cap)
 {
     svo_chain_priority();
-    __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     const FrJob &job = batch.j[blockIdx.y];
     const float2 *__restrict__ p1 = reinterpret_cast<const float2 *>(job.p1);
     const float2 *__restrict__ p2 = reinterpret_cast<const float2 *>(job.p2);
@@ -408,7 +406,6 @@ __global__ __launch_bounds__(64, 4) void fr_score_kernel(FrBatch batch, int it0,
 __global__ __launch_bounds__(256) void fr_mask_kernel(FrBatch batch)
 {
     svo_chain_priority();
-    __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     const FrJob &job = batch.j[blockIdx.y];
     const float2 *__restrict__ p1 = reinterpret_cast<const float2 *>(job.p1);
     const float2 *__restrict__ p2 = reinterpret_cast<const float2 *>(job.p2);

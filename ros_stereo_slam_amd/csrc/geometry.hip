@@ -95,7 +95,6 @@ struct TriBatch {  // blockIdx.y picks the job
 __global__ __launch_bounds__(128) void triangulate_kernel(Mat34 P1, Mat34 P2, TriBatch batch)
 {
     svo_chain_priority();
-    __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     const TriJob &job = batch.j[blockIdx.y];
     const float2 *__restrict__ x1 = job.x1, *__restrict__ x2 = job.x2;
     const int n_host = job.n_host;
@@ -208,7 +207,6 @@ __device__ __forceinline__ int count_ones_bytes(uint32_t x)
 __global__ __launch_bounds__(64) void compact_kernel(CompactBatch batch, int seg)
 {
     svo_chain_priority();
-    __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     const CompactArgs &args = batch.j[blockIdx.y];
     const uint8_t *__restrict__ mask = args.mask;
     const int n = args.d_n ? *args.d_n : args.n_host;

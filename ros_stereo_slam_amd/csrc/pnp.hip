@@ -338,7 +338,6 @@ __device__ __forceinline__ float reproj_err_sq(const double (&P)[12], const K4 &
 __global__ __launch_bounds__(64, 4) void pnp_solve_kernel(PnpBatch batch)
 {
     svo_chain_priority();
-    __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     const PnpJob &job = batch.j[blockIdx.y];
     const float *__restrict__ obj = job.obj, *__restrict__ img = job.img;
     const int n_host = job.n_host;
@@ -1169,7 +1168,6 @@ __device__ void publish_record(const PnpJob &job, const PnpResult &r, PnpResult 
 __global__ __launch_bounds__(256, 5) void pnp_finish_kernel(PnpBatch batch)
 {
     svo_chain_priority();
-    __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     const PnpJob &job = batch.j[blockIdx.x];  // one workgroup per job
     const float *__restrict__ obj = job.obj;
     const float2 *__restrict__ img = reinterpret_cast<const float2 *>(job.img);
@@ -1191,6 +1189,7 @@ __global__ __launch_bounds__(256, 5) void pnp_finish_kernel(PnpBatch batch)
     int *early_out = job.early_out;
     const int early_tag = job.early_tag;
     __shared__ double s_all[RED_CHUNK * RED_STRIDE], s_part[4 * NACC], s_sum[NACC], s_pose[12], s_trial[12];
+    __shared__ double s_norm[NACC];  // the normal equations at the accepted pose (packed like the accumulators)
     __shared__ int s_flag, s_wave[4], s_base;
     __shared__ RansacState s_state;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1282,28 +1281,32 @@ __global__ __launch_bounds__(256, 5) void pnp_finish_kernel(PnpBatch batch)
     };
     accumulate(s_pose, true);
     double err = s_sum[0], lambda = 1e-3;
-    double JtJ[36], Jtr[6];
-    auto unpack = [&]() {
-        int k = 1;
-        for (int p = 0; p < 6; p++)
-            for (int q = p; q < 6; q++) {
-                JtJ[6 * p + q] = s_sum[k];
-                JtJ[6 * q + p] = s_sum[k];
-                k++;
-            }
-        for (int p = 0; p < 6; p++)
-            Jtr[p] = s_sum[22 + p];
+    // The accepted normal equations stay in LDS (only thread 0 solves with them): as 42 doubles in every
+    // thread's registers they put the kernel over the 96 VGPRs that let its workgroup start beside a full
+    // tracking launch.
+    auto keep_normal_equations = [&]() {
+        if (tid < NACC)
+            s_norm[tid] = s_sum[tid];
     };
-    unpack();
+    keep_normal_equations();
+    __syncthreads();
     for (int it = 0; it < max_iters; it++) {
         // thread 0 proposes a step; flag: 0 = trial pose ready, 1 = solve failed (raise lambda), 2 = stop
         if (tid == 0) {
             double A[36], nb[6], d[6];
-            for (int k = 0; k < 36; k++)
-                A[k] = JtJ[k];
+            {
+                int k = 1;
+                for (int p = 0; p < 6; p++)
+                    for (int q = p; q < 6; q++) {
+                        A[6 * p + q] = s_norm[k];
+                        A[6 * q + p] = s_norm[k];
+                        k++;
+                    }
+            }
             for (int k = 0; k < 6; k++) {
-                A[7 * k] += lambda * JtJ[7 * k] + 1e-300;
-                nb[k] = -Jtr[k];
+                const double dk = A[7 * k];
+                A[7 * k] = dk + (lambda * dk + 1e-300);
+                nb[k] = -s_norm[22 + k];
             }
             int flag = 0;
             if (!chol6_solve(A, nb, d)) {
@@ -1340,7 +1343,7 @@ __global__ __launch_bounds__(256, 5) void pnp_finish_kernel(PnpBatch batch)
                 s_pose[tid] = s_trial[tid];
             const double prev = err;
             err = e2;
-            unpack();
+            keep_normal_equations();
             lambda *= 0.1;
             if (lambda < 1e-12)
                 lambda = 1e-12;

@@ -165,7 +165,6 @@ __device__ __forceinline__ void pad_copy_row(const uint8_t *__restrict__ src, ui
 template <int C> __global__ __launch_bounds__(PB) void pyr_base_kernel(PyrBuild b, int tiles_x, int n_tiles, int pad_x)
 {
     svo_chain_priority();
-    __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     const int job = blockIdx.y;
     if ((int)blockIdx.x < n_tiles) {
         if (b.levels > 1)
@@ -186,7 +185,6 @@ template <int C> __global__ __launch_bounds__(PB) void pyr_base_kernel(PyrBuild 
 template <int C> __global__ __launch_bounds__(PB) void pyr_down_kernel(PyrBuild b, int l)
 {
     svo_chain_priority();
-    __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     down_tile<C, false>(b.lvl[blockIdx.z][l - 1], b.pitch[l - 1], b.w[l - 1], b.h[l - 1], b.lvl[blockIdx.z][l], b.pitch[l],
                         b.w[l], b.h[l], blockIdx.x, blockIdx.y);
 }
@@ -292,7 +290,6 @@ struct FinishPlan {
 template <int C> __global__ __launch_bounds__(PB) void pyr_finish_kernel(PyrBuild b, FinishPlan plan)
 {
     svo_chain_priority();
-    __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
     const int job = blockIdx.z, by = blockIdx.y;
     if (by < plan.border_y0[b.levels]) {
         int l = 1;
