@@ -234,8 +234,10 @@ __device__ __forceinline__ int stage_tile(uint8_t *tile, const uint8_t *__restri
 
 // Stage the DT x DT tile of a derivative level whose top-left element is pixel (ox, oy): rows of
 // DT * C ints, fetched as aligned 16-byte vectors (the level's pitch is a multiple of 16, so every
-// row starts at the same byte shift, a multiple of 4).  VEC vectors per row x DT rows, dealt to the
-// lanes in linear order.  Returns the byte shift.
+// row starts at the same byte shift, a multiple of 4).  Lane -> (row, vector) by shifts and masks only
+// (a linear deal of the VEC = 19 vectors per row cost a division per load, 70 instructions per level):
+// part A takes vectors 0..15 of four rows per step, part B the remaining VEC - 16 vectors of sixteen
+// rows per step (four lanes per row; spare lanes repeat the last vector).  Returns the byte shift.
 template <int C>
 __device__ __forceinline__ int stage_dtile(uint8_t *tile, const int *__restrict__ lvl, int dpitch, int ox, int oy,
                                            int lane)
@@ -244,39 +246,68 @@ __device__ __forceinline__ int stage_dtile(uint8_t *tile, const int *__restrict_
     const int off = oy * dpitch + ox * (C * 4);  // bytes from element (0,0); inside one padded level: fits 32 bits
     const int shift = (int)(((unsigned)reinterpret_cast<uintptr_t>(lvl) + (unsigned)off) & 15u);
     const uint8_t *a16 = reinterpret_cast<const uint8_t *>(lvl) + (ptrdiff_t)__builtin_amdgcn_readfirstlane(off - shift);
-    constexpr int TOTAL = DT * DL::VEC, ITER = (TOTAL + 63) / 64, HALF = (ITER + 1) / 2;
     typedef unsigned uint4v __attribute__((ext_vector_type(4)));
-    // the (row, vector) of every step depends on the lane only: left to itself the compiler computes the
-    // seven LDS offsets once per keypoint and keeps them across the level loop -- seven registers the
-    // 128-VGPR kernel does not have (they were spilled: 118 MB of scratch traffic per launch).  An opaque
-    // copy of the lane makes them a few instructions per level instead.
+    // the lane offsets are a handful of instructions: recomputed per level (an opaque copy of the lane stops
+    // the compiler from keeping them in registers across the level loop -- the kernel has none to spare)
     asm volatile("" : "+v"(lane));
-    // two batches of loads: at most HALF vectors (16 registers) in flight, the kernel runs at 128 VGPRs
+    constexpr int VA = DL::VEC < 16 ? DL::VEC : 16, VB = DL::VEC - VA;  // vectors per row in part A / part B
+    static_assert(VB <= 4, "part B deals four lanes to a row");
+    constexpr int ITA = (DT + 3) / 4, ITB = VB > 0 ? (DT + 15) / 16 : 0;
+    {
+        const unsigned r0 = (unsigned)lane >> 4, c = min((unsigned)lane & 15u, (unsigned)VA - 1);
+        constexpr int HALF = (ITA + 1) / 2;  // two batches: at most HALF vectors (12 registers) in flight
 #pragma unroll
-    for (int b = 0; b < ITER; b += HALF) {
-        uint4v v[HALF];
-        unsigned loff[HALF];
+        for (int b = 0; b < ITA; b += HALF) {
+            uint4v v[HALF];
 #pragma unroll
-        for (int k = 0; k < HALF; k++) {
-            if (b + k >= ITER)
-                continue;
-            unsigned i = (unsigned)lane + 64u * (unsigned)(b + k);
-            if ((b + k + 1) * 64 > TOTAL)
-                i = min(i, (unsigned)TOTAL - 1);  // the last step's spare lanes repeat the last vector
-            const unsigned r = i / (unsigned)DL::VEC, c = i - r * (unsigned)DL::VEC;
-            loff[k] = r * (unsigned)DL::ROW + c * 16u;
-            const unsigned goff = r * (unsigned)dpitch + c * 16u;
-            asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(v[k]) : "v"(goff), "s"(a16) : "memory");
+            for (int k = 0; k < HALF; k++) {
+                if (b + k >= ITA)
+                    continue;
+                const bool clamp = (b + k + 1) * 4 > DT;  // the last step may reach past the tile: those lanes repeat the last row
+                const unsigned goff = (clamp ? min(r0, (unsigned)(DT - 1 - (b + k) * 4)) : r0) * (unsigned)dpitch + c * 16u;
+                asm volatile("global_load_dwordx4 %0, %1, %2"
+                             : "=&v"(v[k])
+                             : "v"(goff), "s"(a16 + (ptrdiff_t)((b + k) * 4) * dpitch)
+                             : "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0])::"memory");
+#pragma unroll
+            for (int k = 1; k < HALF; k++)
+                if (b + k < ITA)
+                    asm volatile("" : "+v"(v[k]));
+#pragma unroll
+            for (int k = 0; k < HALF; k++) {
+                if (b + k >= ITA)
+                    continue;
+                const bool clamp = (b + k + 1) * 4 > DT;
+                const unsigned r = clamp ? min(r0, (unsigned)(DT - 1 - (b + k) * 4)) : r0;
+                *reinterpret_cast<uint4v *>(tile + ((b + k) * 4 + r) * DL::ROW + c * 16) = v[k];
+            }
+        }
+    }
+    if (VB > 0) {
+        asm volatile("" : "+v"(lane));
+        const unsigned r0 = (unsigned)lane >> 2, c = (unsigned)VA + min((unsigned)lane & 3u, (unsigned)(VB > 0 ? VB - 1 : 0));
+        uint4v v[ITB > 0 ? ITB : 1];
+#pragma unroll
+        for (int k = 0; k < ITB; k++) {
+            const bool clamp = (k + 1) * 16 > DT;
+            const unsigned goff = (clamp ? min(r0, (unsigned)(DT - 1 - k * 16)) : r0) * (unsigned)dpitch + c * 16u;
+            asm volatile("global_load_dwordx4 %0, %1, %2"
+                         : "=&v"(v[k])
+                         : "v"(goff), "s"(a16 + (ptrdiff_t)(k * 16) * dpitch)
+                         : "memory");
         }
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0])::"memory");
 #pragma unroll
-        for (int k = 1; k < HALF; k++)
-            if (b + k < ITER)
-                asm volatile("" : "+v"(v[k]));
+        for (int k = 1; k < ITB; k++)
+            asm volatile("" : "+v"(v[k]));
 #pragma unroll
-        for (int k = 0; k < HALF; k++)
-            if (b + k < ITER)
-                *reinterpret_cast<uint4v *>(tile + loff[k]) = v[k];
+        for (int k = 0; k < ITB; k++) {
+            const bool clamp = (k + 1) * 16 > DT;
+            const unsigned r = clamp ? min(r0, (unsigned)(DT - 1 - k * 16)) : r0;
+            *reinterpret_cast<uint4v *>(tile + (k * 16 + r) * DL::ROW + c * 16) = v[k];
+        }
     }
     return shift;
 }
@@ -524,39 +555,64 @@ __global__ __launch_bounds__(64 * WAVES, 4) void lk_track_kernel(LkBatch batch, 
                 lane_samples<C, W_BITS - 5>(t0, t1, (w00 & 0xffff) | (w10 << 16), (w01 & 0xffff) | (w11 << 16), Ivp);
             }
             // the Scharr derivatives of the window's 22x22 neighbourhood come from the derivative level
-            // (zero outside the image: the level's border is zero); the tile takes the place of T
+            // (zero outside the image: the level's border is zero); the tile takes the place of T.
+            // The template patch is finished before the staging starts: its operands are inputs of the asm that
+            // hands the staging its lane index (otherwise the compiler carries raw tile rows across the loads).
+            int dl = lane;
+            static_assert(npairs(C) == 11 || npairs(C) == 4, "list the template registers below");
+            if constexpr (npairs(C) == 11)
+                asm volatile("" : "+v"(dl) : "v"(Ivp[0]), "v"(Ivp[1]), "v"(Ivp[2]), "v"(Ivp[3]), "v"(Ivp[4]), "v"(Ivp[5]),
+                             "v"(Ivp[6]), "v"(Ivp[7]), "v"(Ivp[8]), "v"(Ivp[9]), "v"(Ivp[10]));
+            else
+                asm volatile("" : "+v"(dl) : "v"(Ivp[0]), "v"(Ivp[1]), "v"(Ivp[2]), "v"(Ivp[3]));
             wave_lds_sync();
             const int *D = reinterpret_cast<const int *>(
-                DB + stage_dtile<C>(DB, dprev + prm.doff[level], prm.dpitch[level], ipx, ipy, lane));
+                DB + stage_dtile<C>(DB, dprev + prm.doff[level], prm.dpitch[level], ipx, ipy, dl));
             wave_lds_sync();
             constexpr int DROW = DTile<C>::ROW / 4;
-            const int *d0 = D + wy * DROW + wx * C;
-            const int *d1 = d0 + DROW;
+            int dlane = wy * DROW + wx * C;  // this lane's first tile entry
             // Derivative tile entries are (4 dx | 4 dy << 16) (pyramid.hip; |4 d| <= 16320: int16).  As for the
             // image samples, the VERTICAL neighbours of column k are paired once (element k uses columns k and
             // k + C): 2 permutes per column instead of 4 per element.  With the factor 4 the descale by 2^14 is
             // "take the high half" -- the permute that packs two elements does it, no shift:
             //   (4 (sum w d) + 4 RD) >> 16  ==  (sum w d + RD) >> 14.
-            int vx[NV], vy[NV];
-            ForEachElem<C, NV>::run([&](auto kc) {
-                constexpr int k = decltype(kc)::value;
-                const int up = d0[k], lo = d1[k];
-                vx[k] = half_pair<false>(up, lo);
-                vy[k] = half_pair<true>(up, lo);
-            });
             constexpr int RD4 = 4 << (W_BITS - 1);
-            int sx[NE + 1], sy[NE + 1];
-            sx[NE] = sy[NE] = 0;
+            // x then y, each from its own read of the tile rows: half the registers in flight
+            {
+                const int *d0 = D + dlane, *d1 = d0 + DROW;
+                int vx[NV], sx[NE + 1];
+                ForEachElem<C, NV>::run([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    vx[k] = half_pair<false>(d0[k], d1[k]);
+                });
+                sx[NE] = 0;
 #pragma unroll
-            for (int k = 0; k < NE; k++) {
-                sx[k] = sdot2(vx[k + C], wq1, sdot2_sconst(vx[k], wq0, RD4));
-                sy[k] = sdot2(vy[k + C], wq1, sdot2_sconst(vy[k], wq0, RD4));
+                for (int k = 0; k < NE; k++)
+                    sx[k] = sdot2(vx[k + C], wq1, sdot2_sconst(vx[k], wq0, RD4));
+#pragma unroll
+                for (int j = 0; j < npairs(C); j++)
+                    Ixp[j] = half_pair<true>(sx[2 * j], sx[2 * j + 1 < NE ? 2 * j + 1 : NE]);
+            }
+            // the y pass starts when the x pass is done (left alone the compiler merges the two and needs 106
+            // registers; at most 104 keep a fifth wave slot's worth of every SIMD free for the short kernels)
+            asm volatile("" : "+v"(dlane), "+v"(Ixp[npairs(C) - 1]));
+            {
+                const int *d0 = D + dlane, *d1 = d0 + DROW;
+                int vy[NV], sy[NE + 1];
+                ForEachElem<C, NV>::run([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    vy[k] = half_pair<true>(d0[k], d1[k]);
+                });
+                sy[NE] = 0;
+#pragma unroll
+                for (int k = 0; k < NE; k++)
+                    sy[k] = sdot2(vy[k + C], wq1, sdot2_sconst(vy[k], wq0, RD4));
+#pragma unroll
+                for (int j = 0; j < npairs(C); j++)
+                    Iyp[j] = half_pair<true>(sy[2 * j], sy[2 * j + 1 < NE ? 2 * j + 1 : NE]);
             }
 #pragma unroll
             for (int j = 0; j < npairs(C); j++) {
-                const int k0 = 2 * j, k1 = 2 * j + 1 < NE ? 2 * j + 1 : NE;
-                Ixp[j] = half_pair<true>(sx[k0], sx[k1]);
-                Iyp[j] = half_pair<true>(sy[k0], sy[k1]);
                 a11 = sdot2(Ixp[j], Ixp[j], a11);  // sums of squares of int16 pairs, exact
                 a12 = sdot2(Ixp[j], Iyp[j], a12);
                 a22 = sdot2(Iyp[j], Iyp[j], a22);
@@ -590,13 +646,13 @@ __global__ __launch_bounds__(64 * WAVES, 4) void lk_track_kernel(LkBatch batch, 
         // ---- 2. iterate on the next image out of an LDS tile ----
         nxp -= half;
         nyp -= half;
-        float pdx = 0.f, pdy = 0.f, ldx = 0.f, ldy = 0.f;
+        float pdx = 0.f, pdy = 0.f;
         const int lane_off = wy * Tile<C, TS>::ROW + wx * C;  // this lane's row run inside the window
         int ox = 0, oy = 0;
         bool have_tile = false;
         int tj_off = 0;          // LDS byte offset of the staged tile's pixel (0, 0): TJ's offset + the staging shift
         bool stepped = false;    // at least one Newton step taken: the output is nxp + half (else the guess itself)
-        bool halved = false;     // left through the oscillation test: the output backs off half a step
+        bool out_set = false;    // left through the oscillation test: the output (backed off half a step) is written there
         for (int j = 0; j < prm.max_count; j++) {
             const float fx = floorf(nxp), fy = floorf(nyp);
             const int inx = uniform((int)fx), iny = uniform((int)fy);
@@ -634,9 +690,9 @@ __global__ __launch_bounds__(64 * WAVES, 4) void lk_track_kernel(LkBatch batch, 
                 break;
             // fabs((double)x) < 0.01  <=>  |x| <= 0.01f for a float x: 0.01f is the largest float below 0.01
             if (j > 0 && uniform(fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f)) {
-                halved = true;
-                ldx = dx;
-                ldy = dy;
+                outx = (nxp + half) - dx * 0.5f;
+                outy = (nyp + half) - dy * 0.5f;
+                out_set = true;
                 break;
             }
             pdx = dx;
@@ -644,13 +700,9 @@ __global__ __launch_bounds__(64 * WAVES, 4) void lk_track_kernel(LkBatch batch, 
         }
         // the reference keeps nextPt = guess + half up to date inside the loop; the same float operations
         // in the same order, once, after it
-        if (stepped) {
+        if (stepped && !out_set) {
             outx = nxp + half;
             outy = nyp + half;
-            if (halved) {
-                outx -= ldx * 0.5f;
-                outy -= ldy * 0.5f;
-            }
         }
 
         // ---- 3. level-0 residual (err output of calcOpticalFlowPyrLK) ----
