@@ -186,130 +186,154 @@ __device__ __forceinline__ void bilinear_weights(float a, float b, int &w00, int
     w11 = (1 << W_BITS) - w00 - w01 - w10;
 }
 
-// Stage a SIDE x SIDE pixel tile whose top-left pixel is (ox, oy) into LDS with aligned
-// 16-byte loads (global_load_dwordx4 -> ds_write_b128).  Returns the byte shift of the tile.
+// Stage a SIDE x SIDE pixel tile whose top-left pixel is (ox, oy) into LDS with aligned 16-byte loads
+// (global_load_dwordx4 -> ds_write_b128), in two halves so that a later staging's loads can be in flight
+// while this tile is consumed: tile_issue starts the loads into registers, tile_commit<LATER> waits until at
+// most LATER younger vector-memory loads are outstanding (loads return in order) and writes the LDS rows.
+// Between the two NOTHING may touch the registers of `t.v`.  lane -> (row group, 16-byte vector): LPR lanes
+// per row (the lanes past VEC repeat the last vector), RPI rows per step; the k-th step differs from the
+// first by k * RPI rows only, which goes into the scalar base and the ds_write immediate -- one lane offset
+// for all the loads, written out as SGPR base + 32-bit lane offset (left to itself the compiler forms 64-bit
+// lane addresses per load and level, keeps them across the iteration loop and spills).
+typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+template <int C, int SIDE> struct TileLoad {
+    using TL = Tile<C, SIDE>;
+    static constexpr int LPR = TL::VEC <= 4 ? 4 : 8, RPI = 64 / LPR, ITER = (SIDE + RPI - 1) / RPI;
+    static_assert(TL::VEC <= LPR, "row wider than a lane group");
+    uint4v v[ITER];
+    int shift;  // byte shift of the tile: pixel (0, 0) lives at tile + shift
+};
+
+template <int C, int SIDE>
+__device__ __forceinline__ void tile_issue(TileLoad<C, SIDE> &t, const uint8_t *__restrict__ lvl, int pitch, int ox,
+                                           int oy, int lane)
+{
+    using LD = TileLoad<C, SIDE>;
+    // wave-uniform base (said so explicitly: the loads then take an SGPR base + a 32-bit lane offset)
+    const int off = oy * pitch + ox * C;  // inside one padded level: fits 32 bits
+    t.shift = (int)(((unsigned)reinterpret_cast<uintptr_t>(lvl) + (unsigned)off) & 15u);
+    const uint8_t *a16 = lvl + (ptrdiff_t)__builtin_amdgcn_readfirstlane(off - t.shift);
+    const unsigned r0 = (unsigned)lane / LD::LPR, vv = min((unsigned)lane % LD::LPR, (unsigned)LD::TL::VEC - 1);
+#pragma unroll
+    for (int k = 0; k < LD::ITER; k++) {
+        // the last step may reach past the tile: those lanes repeat the last row
+        const bool clamp = (k + 1) * LD::RPI > SIDE;
+        const unsigned goff = (clamp ? min(r0, (unsigned)(SIDE - 1 - k * LD::RPI)) : r0) * (unsigned)pitch + vv * 16u;
+        asm volatile("global_load_dwordx4 %0, %1, %2"
+                     : "=&v"(t.v[k])
+                     : "v"(goff), "s"(a16 + (ptrdiff_t)(k * LD::RPI) * pitch)
+                     : "memory");
+    }
+}
+
+template <int C, int SIDE, int LATER = 0>
+__device__ __forceinline__ void tile_commit(TileLoad<C, SIDE> &t, uint8_t *tile, int lane)
+{
+    using LD = TileLoad<C, SIDE>;
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(t.v[0]) : "n"(LATER) : "memory");
+#pragma unroll
+    for (int k = 1; k < LD::ITER; k++)
+        asm volatile("" : "+v"(t.v[k]));
+    const unsigned r0 = (unsigned)lane / LD::LPR, vv = min((unsigned)lane % LD::LPR, (unsigned)LD::TL::VEC - 1);
+#pragma unroll
+    for (int k = 0; k < LD::ITER; k++) {
+        const bool clamp = (k + 1) * LD::RPI > SIDE;
+        const unsigned r = clamp ? min(r0, (unsigned)(SIDE - 1 - k * LD::RPI)) : r0;
+        *reinterpret_cast<uint4v *>(tile + (k * LD::RPI + r) * LD::TL::ROW + vv * 16) = t.v[k];
+    }
+}
+
+// issue + commit back to back; returns the byte shift
 template <int C, int SIDE>
 __device__ __forceinline__ int stage_tile(uint8_t *tile, const uint8_t *__restrict__ lvl, int pitch, int ox,
                                           int oy, int lane)
 {
-    using TL = Tile<C, SIDE>;
-    // wave-uniform base (said so explicitly: the loads then take an SGPR base + a 32-bit lane offset
-    // instead of 64-bit lane addresses that would be kept live -- and spilled -- across the levels)
-    const int off = oy * pitch + ox * C;  // inside one padded level: fits 32 bits
-    const int shift = (int)(((unsigned)reinterpret_cast<uintptr_t>(lvl) + (unsigned)off) & 15u);
-    const uint8_t *a16 = lvl + (ptrdiff_t)__builtin_amdgcn_readfirstlane(off - shift);
-    // lane -> (row group, 16-byte vector): LPR lanes per row (the lanes past VEC repeat the last
-    // vector), RPI rows per step; the k-th step differs from the first by k * RPI rows only, which
-    // goes into the scalar base and the ds_write immediate -- one lane offset for all the loads,
-    // written out as SGPR base + 32-bit lane offset (left to itself the compiler forms 64-bit lane
-    // addresses per load and level, keeps them across the iteration loop and spills)
-    constexpr int LPR = TL::VEC <= 4 ? 4 : 8, RPI = 64 / LPR, ITER = (SIDE + RPI - 1) / RPI;
-    static_assert(TL::VEC <= LPR, "row wider than a lane group");
-    const unsigned r0 = (unsigned)lane / LPR, vv = min((unsigned)lane % LPR, (unsigned)TL::VEC - 1);
-    typedef unsigned uint4v __attribute__((ext_vector_type(4)));
-    uint4v v[ITER];
-    unsigned goff[ITER];
-#pragma unroll
-    for (int k = 0; k < ITER; k++) {
-        // the last step may reach past the tile: those lanes repeat the last row
-        const bool clamp = (k + 1) * RPI > SIDE;
-        goff[k] = (clamp ? min(r0, (unsigned)(SIDE - 1 - k * RPI)) : r0) * (unsigned)pitch + vv * 16u;
-        asm volatile("global_load_dwordx4 %0, %1, %2"
-                     : "=&v"(v[k])
-                     : "v"(goff[k]), "s"(a16 + (ptrdiff_t)(k * RPI) * pitch)
-                     : "memory");
-    }
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0])::"memory");
-#pragma unroll
-    for (int k = 1; k < ITER; k++)
-        asm volatile("" : "+v"(v[k]));
-#pragma unroll
-    for (int k = 0; k < ITER; k++) {
-        const bool clamp = (k + 1) * RPI > SIDE;
-        const unsigned r = clamp ? min(r0, (unsigned)(SIDE - 1 - k * RPI)) : r0;
-        *reinterpret_cast<uint4v *>(tile + (k * RPI + r) * TL::ROW + vv * 16) = v[k];
-    }
-    return shift;
+    TileLoad<C, SIDE> t;
+    tile_issue<C, SIDE>(t, lvl, pitch, ox, oy, lane);
+    tile_commit<C, SIDE>(t, tile, lane);
+    return t.shift;
 }
 
-// Stage the DT x DT tile of a derivative level whose top-left element is pixel (ox, oy): rows of
-// DT * C ints, fetched as aligned 16-byte vectors (the level's pitch is a multiple of 16, so every
-// row starts at the same byte shift, a multiple of 4).  Lane -> (row, vector) by shifts and masks only
-// (a linear deal of the VEC = 19 vectors per row cost a division per load, 70 instructions per level):
-// part A takes vectors 0..15 of four rows per step, part B the remaining VEC - 16 vectors of sixteen
-// rows per step (four lanes per row; spare lanes repeat the last vector).  Returns the byte shift.
-template <int C>
-__device__ __forceinline__ int stage_dtile(uint8_t *tile, const int *__restrict__ lvl, int dpitch, int ox, int oy,
-                                           int lane)
-{
+// The DT x DT tile of a derivative level whose top-left element is pixel (ox, oy): rows of DT * C ints,
+// fetched as aligned 16-byte vectors (the level's pitch is a multiple of 16, so every row starts at the same
+// byte shift, a multiple of 4).  Lane -> (row, vector) by shifts and masks only (a linear deal of the VEC = 19
+// vectors per row cost a division per load, 70 instructions per level): part A takes vectors 0..15 of four
+// rows per step, part B the remaining VEC - 16 vectors of sixteen rows per step (four lanes per row; spare
+// lanes repeat the last vector).  dtile_issue starts ALL the loads (eight vectors per lane at C = 3: the tile
+// is in flight while the template patch is formed from the previous-image tile, which occupies the same LDS
+// area), dtile_commit waits for them and writes the rows.
+template <int C> struct DtileLoad {
     using DL = DTile<C>;
+    static constexpr int VA = DL::VEC < 16 ? DL::VEC : 16, VB = DL::VEC - VA;  // vectors per row in part A / part B
+    static_assert(VB <= 4, "part B deals four lanes to a row");
+    static constexpr int ITA = (DT + 3) / 4, ITB = VB > 0 ? (DT + 15) / 16 : 0, N = ITA + ITB;
+    uint4v v[N];
+    int shift;
+};
+
+template <int C>
+__device__ __forceinline__ void dtile_issue(DtileLoad<C> &t, const int *__restrict__ lvl, int dpitch, int ox, int oy,
+                                            int lane)
+{
+    using LD = DtileLoad<C>;
     const int off = oy * dpitch + ox * (C * 4);  // bytes from element (0,0); inside one padded level: fits 32 bits
-    const int shift = (int)(((unsigned)reinterpret_cast<uintptr_t>(lvl) + (unsigned)off) & 15u);
-    const uint8_t *a16 = reinterpret_cast<const uint8_t *>(lvl) + (ptrdiff_t)__builtin_amdgcn_readfirstlane(off - shift);
-    typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+    t.shift = (int)(((unsigned)reinterpret_cast<uintptr_t>(lvl) + (unsigned)off) & 15u);
+    const uint8_t *a16 = reinterpret_cast<const uint8_t *>(lvl) + (ptrdiff_t)__builtin_amdgcn_readfirstlane(off - t.shift);
     // the lane offsets are a handful of instructions: recomputed per level (an opaque copy of the lane stops
     // the compiler from keeping them in registers across the level loop -- the kernel has none to spare)
     asm volatile("" : "+v"(lane));
-    constexpr int VA = DL::VEC < 16 ? DL::VEC : 16, VB = DL::VEC - VA;  // vectors per row in part A / part B
-    static_assert(VB <= 4, "part B deals four lanes to a row");
-    constexpr int ITA = (DT + 3) / 4, ITB = VB > 0 ? (DT + 15) / 16 : 0;
     {
-        const unsigned r0 = (unsigned)lane >> 4, c = min((unsigned)lane & 15u, (unsigned)VA - 1);
-        constexpr int HALF = (ITA + 1) / 2;  // two batches: at most HALF vectors (12 registers) in flight
+        const unsigned r0 = (unsigned)lane >> 4, c = min((unsigned)lane & 15u, (unsigned)LD::VA - 1);
 #pragma unroll
-        for (int b = 0; b < ITA; b += HALF) {
-            uint4v v[HALF];
-#pragma unroll
-            for (int k = 0; k < HALF; k++) {
-                if (b + k >= ITA)
-                    continue;
-                const bool clamp = (b + k + 1) * 4 > DT;  // the last step may reach past the tile: those lanes repeat the last row
-                const unsigned goff = (clamp ? min(r0, (unsigned)(DT - 1 - (b + k) * 4)) : r0) * (unsigned)dpitch + c * 16u;
-                asm volatile("global_load_dwordx4 %0, %1, %2"
-                             : "=&v"(v[k])
-                             : "v"(goff), "s"(a16 + (ptrdiff_t)((b + k) * 4) * dpitch)
-                             : "memory");
-            }
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0])::"memory");
-#pragma unroll
-            for (int k = 1; k < HALF; k++)
-                if (b + k < ITA)
-                    asm volatile("" : "+v"(v[k]));
-#pragma unroll
-            for (int k = 0; k < HALF; k++) {
-                if (b + k >= ITA)
-                    continue;
-                const bool clamp = (b + k + 1) * 4 > DT;
-                const unsigned r = clamp ? min(r0, (unsigned)(DT - 1 - (b + k) * 4)) : r0;
-                *reinterpret_cast<uint4v *>(tile + ((b + k) * 4 + r) * DL::ROW + c * 16) = v[k];
-            }
+        for (int k = 0; k < LD::ITA; k++) {
+            const bool clamp = (k + 1) * 4 > DT;  // the last step may reach past the tile: those lanes repeat the last row
+            const unsigned goff = (clamp ? min(r0, (unsigned)(DT - 1 - k * 4)) : r0) * (unsigned)dpitch + c * 16u;
+            asm volatile("global_load_dwordx4 %0, %1, %2"
+                         : "=&v"(t.v[k])
+                         : "v"(goff), "s"(a16 + (ptrdiff_t)(k * 4) * dpitch)
+                         : "memory");
         }
     }
-    if (VB > 0) {
-        asm volatile("" : "+v"(lane));
-        const unsigned r0 = (unsigned)lane >> 2, c = (unsigned)VA + min((unsigned)lane & 3u, (unsigned)(VB > 0 ? VB - 1 : 0));
-        uint4v v[ITB > 0 ? ITB : 1];
+    if (LD::VB > 0) {
+        const unsigned r0 = (unsigned)lane >> 2, c = (unsigned)LD::VA + min((unsigned)lane & 3u, (unsigned)(LD::VB > 0 ? LD::VB - 1 : 0));
 #pragma unroll
-        for (int k = 0; k < ITB; k++) {
+        for (int k = 0; k < LD::ITB; k++) {
             const bool clamp = (k + 1) * 16 > DT;
             const unsigned goff = (clamp ? min(r0, (unsigned)(DT - 1 - k * 16)) : r0) * (unsigned)dpitch + c * 16u;
             asm volatile("global_load_dwordx4 %0, %1, %2"
-                         : "=&v"(v[k])
+                         : "=&v"(t.v[LD::ITA + k])
                          : "v"(goff), "s"(a16 + (ptrdiff_t)(k * 16) * dpitch)
                          : "memory");
         }
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0])::"memory");
+    }
+}
+
+template <int C> __device__ __forceinline__ void dtile_commit(DtileLoad<C> &t, uint8_t *tile, int lane)
+{
+    using LD = DtileLoad<C>;
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(t.v[0])::"memory");
 #pragma unroll
-        for (int k = 1; k < ITB; k++)
-            asm volatile("" : "+v"(v[k]));
+    for (int k = 1; k < LD::N; k++)
+        asm volatile("" : "+v"(t.v[k]));
+    asm volatile("" : "+v"(lane));
+    {
+        const unsigned r0 = (unsigned)lane >> 4, c = min((unsigned)lane & 15u, (unsigned)LD::VA - 1);
 #pragma unroll
-        for (int k = 0; k < ITB; k++) {
-            const bool clamp = (k + 1) * 16 > DT;
-            const unsigned r = clamp ? min(r0, (unsigned)(DT - 1 - k * 16)) : r0;
-            *reinterpret_cast<uint4v *>(tile + (k * 16 + r) * DL::ROW + c * 16) = v[k];
+        for (int k = 0; k < LD::ITA; k++) {
+            const bool clamp = (k + 1) * 4 > DT;
+            const unsigned r = clamp ? min(r0, (unsigned)(DT - 1 - k * 4)) : r0;
+            *reinterpret_cast<uint4v *>(tile + (k * 4 + r) * LD::DL::ROW + c * 16) = t.v[k];
         }
     }
-    return shift;
+    if (LD::VB > 0) {
+        const unsigned r0 = (unsigned)lane >> 2, c = (unsigned)LD::VA + min((unsigned)lane & 3u, (unsigned)(LD::VB > 0 ? LD::VB - 1 : 0));
+#pragma unroll
+        for (int k = 0; k < LD::ITB; k++) {
+            const bool clamp = (k + 1) * 16 > DT;
+            const unsigned r = clamp ? min(r0, (unsigned)(DT - 1 - k * 16)) : r0;
+            *reinterpret_cast<uint4v *>(tile + (k * 16 + r) * LD::DL::ROW + c * 16) = t.v[LD::ITA + k];
+        }
+    }
 }
 
 // Every lane of a wave computes the same control values (guess, step, tile origin): telling the
@@ -536,8 +560,15 @@ __global__ __launch_bounds__(64 * WAVES, 4) void lk_track_kernel(LkBatch batch, 
         bilinear_weights(px - (float)ipx, py - (float)ipy, w00, w01, w10, w11);
 
         // ---- 1. previous-image tile -> template patch; derivative tile -> derivative patches, normal matrix ----
+        // Both tiles' loads are issued at once: T is written to LDS as soon as it has arrived, the eight vectors
+        // of D stay in flight (in registers) while the template patch is formed from T, and take T's place after.
         wave_lds_sync();
-        const uint8_t *Ts = T + stage_tile<C, PT>(T, I, pitch, ipx - 1, ipy - 1, lane);
+        TileLoad<C, PT> tload;
+        tile_issue<C, PT>(tload, I, pitch, ipx - 1, ipy - 1, lane);
+        DtileLoad<C> dload;
+        dtile_issue<C>(dload, dprev + prm.doff[level], prm.dpitch[level], ipx, ipy, lane);
+        tile_commit<C, PT, DtileLoad<C>::N>(tload, T, lane);
+        const uint8_t *Ts = T + tload.shift;
         wave_lds_sync();
 
         int Ivp[npairs(C)], Ixp[npairs(C)], Iyp[npairs(C)];  // packed int16 pairs (low = even element)
@@ -566,8 +597,8 @@ __global__ __launch_bounds__(64 * WAVES, 4) void lk_track_kernel(LkBatch batch, 
             else
                 asm volatile("" : "+v"(dl) : "v"(Ivp[0]), "v"(Ivp[1]), "v"(Ivp[2]), "v"(Ivp[3]));
             wave_lds_sync();
-            const int *D = reinterpret_cast<const int *>(
-                DB + stage_dtile<C>(DB, dprev + prm.doff[level], prm.dpitch[level], ipx, ipy, dl));
+            dtile_commit<C>(dload, DB, dl);
+            const int *D = reinterpret_cast<const int *>(DB + dload.shift);
             wave_lds_sync();
             constexpr int DROW = DTile<C>::ROW / 4;
             int dlane = wy * DROW + wx * C;  // this lane's first tile entry
