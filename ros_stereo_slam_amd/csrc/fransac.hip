@@ -4,19 +4,20 @@
 // calls it at src/tracking.cpp:34 (FmatThresholding, 3 px) and src/tracking.cpp:75
 // (PyrLKtrackFrame2Frame, method 8 == FM_RANSAC, 1 px).  Only the mask is consumed there.
 //
-// Structure (all on the context's stream, no host round trip):
-//   solve   one THREAD per RANSAC iteration: counter-based 7-sample (collinear samples
-//           re-drawn), 7x9 Gauss-Jordan in LDS ([element][thread] layout, conflict-free),
-//           cubic det(l*F1 + (1-l)*F2) = 0, up to three unit-norm models to HBM.
-//   score   one WAVEFRONT per model: the N correspondences strided over the 64 lanes,
-//           symmetric epipolar distance in f64, inlier count reduced with DPP.
-//           The LAST workgroup to finish (ticket counter) replays the SEQUENTIAL loop over the
-//           counts (first-best-wins, adaptive iteration bound), so the answer equals the serial
-//           algorithm's -- no launch of its own.
-//   mask    one thread per correspondence against the winning model.
-// solve/score run in two phases (iterations [0,64) and [64,max)); phase-two kernels return at
-// once when the adaptive bound was reached in phase one, which is the common case at VO
-// inlier ratios (0.99 confidence, 85% inliers -> 12 iterations).
+// Structure (all on the context's stream, no host round trip): ONE kernel per phase,
+//   one WAVEFRONT per RANSAC iteration (a wave of the second phase takes every 64th):
+//     solve   lane 0: counter-based 7-sample (collinear samples re-drawn), 7x9 Gauss-Jordan in
+//             LDS, cubic det(l*F1 + (1-l)*F2) = 0, up to three unit-norm models (LDS + HBM);
+//     score   all lanes, model after model: the N correspondences strided over the 64 lanes,
+//             symmetric epipolar distance in f64, inlier count reduced with DPP;
+//     finish  the LAST wave to finish (ticket counter) replays the SEQUENTIAL loop over the
+//             counts (first-best-wins, adaptive iteration bound), so the answer equals the serial
+//             algorithm's, and -- once the loop has ended -- writes the mask of the winning model,
+//             the model and the counts.
+// Two phases (iterations [0,64) and [64,max)): the second launch (64 waves per problem) returns at
+// once when the adaptive bound was reached in the first, which is the common case at VO inlier
+// ratios (0.99 confidence, 85% inliers -> 12 iterations).  (Until round 2 this was five launches:
+// solve, score, solve, score, mask -- each waiting its turn beside the tracking launches.)
 #include "ransac_common.hip.h"
 #include "svo_internal.h"
 
@@ -25,9 +26,8 @@ using namespace svo;
 namespace {
 
 constexpr int M = 7;
-constexpr int SCORE_WAVES = 384;  // scoring waves per job and phase; each takes every SCORE_WAVES-th model
-constexpr int SOLVE_T = 16;  // 11 KB of LDS per workgroup: fits beside the waves of a tracking launch (44 KB with 64 waited for a CU to drain)
 constexpr int PHASE_A = 64;
+constexpr int PHASE_WAVES = 64;  // waves per problem and phase; a wave takes every PHASE_WAVES-th iteration
 
 // One F-matrix RANSAC problem as the kernels see it; a launch may carry several (blockIdx.y picks
 // the job) -- the chunks of a context that run in lock step (svo_vo_run_chunks).
@@ -138,32 +138,14 @@ __device__ bool collinear_last(const float *__restrict__ p, const int (&idx)[M])
     return bad;
 }
 
-__global__ __launch_bounds__(SOLVE_T) void fr_solve_kernel(FrBatch batch, int it0, int it1_cap)
+// One RANSAC iteration's models, by ONE lane: up to three unit-norm F (row-major) into Fk[27]; returns their
+// number, -1 when no sample could be drawn (the sequential loop stops there).  sA / sV / sPerm: this lane's
+// scratch in LDS (63 + 18 doubles, 9 ints).
+__device__ int fr_solve_one(const float *__restrict__ p1, const float *__restrict__ p2, int n, uint64_t seed, int it,
+                            double *sA, double *sV, int *sPerm, double *Fk_out)
 {
-    svo_chain_priority();
-    const FrJob &job = batch.j[blockIdx.y];
-    const float *__restrict__ p1 = job.p1, *__restrict__ p2 = job.p2;
-    const int n_host = job.n_host;
-    const int *__restrict__ d_n = job.d_n;
-    const uint64_t seed = job.seed;
-    const int it1 = it1_cap < job.max_iters ? it1_cap : job.max_iters;
-    const RansacState *__restrict__ st = job.st;
-    double *__restrict__ Fout = job.Fm;
-    int *__restrict__ nmodels = job.nmodels;
-    __shared__ double sA[63][SOLVE_T];
-    __shared__ double sV[18][SOLVE_T];
-    __shared__ int sPerm[9][SOLVE_T];
-    const int t = threadIdx.x;
-    const int it = it0 + blockIdx.x * SOLVE_T + t;
-    if (it0 > 0 && st->done)
-        return;
-    if (it >= it1)
-        return;
-    const int n = d_n ? *d_n : n_host;
-    if (n < M) {
-        nmodels[it] = -1;
-        return;
-    }
+    if (n < M)
+        return -1;
     // ---- sample: M distinct indices, degenerate samples re-drawn ----
     int idx[M];
     bool ok = false;
@@ -193,34 +175,32 @@ __global__ __launch_bounds__(SOLVE_T) void fr_solve_kernel(FrBatch batch, int it
             break;
         ok = !collinear_last(p1, idx) && !collinear_last(p2, idx);
     }
-    if (!ok) {
-        nmodels[it] = -1;  // getSubset failed: the sequential loop stops here
-        return;
-    }
+    if (!ok)
+        return -1;  // getSubset failed: the sequential loop stops here
     // ---- 7x9 epipolar system in LDS, Gauss-Jordan with full pivoting ----
 #pragma unroll
     for (int i = 0; i < M; i++) {
         const double u0 = p1[2 * idx[i]], v0 = p1[2 * idx[i] + 1];
         const double u1 = p2[2 * idx[i]], v1 = p2[2 * idx[i] + 1];
-        sA[i * 9 + 0][t] = u1 * u0;
-        sA[i * 9 + 1][t] = u1 * v0;
-        sA[i * 9 + 2][t] = u1;
-        sA[i * 9 + 3][t] = v1 * u0;
-        sA[i * 9 + 4][t] = v1 * v0;
-        sA[i * 9 + 5][t] = v1;
-        sA[i * 9 + 6][t] = u0;
-        sA[i * 9 + 7][t] = v0;
-        sA[i * 9 + 8][t] = 1.;
+        sA[i * 9 + 0] = u1 * u0;
+        sA[i * 9 + 1] = u1 * v0;
+        sA[i * 9 + 2] = u1;
+        sA[i * 9 + 3] = v1 * u0;
+        sA[i * 9 + 4] = v1 * v0;
+        sA[i * 9 + 5] = v1;
+        sA[i * 9 + 6] = u0;
+        sA[i * 9 + 7] = v0;
+        sA[i * 9 + 8] = 1.;
     }
     for (int j = 0; j < 9; j++)
-        sPerm[j][t] = j;
+        sPerm[j] = j;
     bool singular = false;
     for (int k = 0; k < M && !singular; k++) {
         int pr = k, pc = k;
         double best = -1;
         for (int i = k; i < M; i++)
             for (int j = k; j < 9; j++) {
-                double v = fabs(sA[i * 9 + j][t]);
+                double v = fabs(sA[i * 9 + j]);
                 if (v > best) {
                     best = v;
                     pr = i;
@@ -233,51 +213,49 @@ __global__ __launch_bounds__(SOLVE_T) void fr_solve_kernel(FrBatch batch, int it
         }
         if (pr != k)
             for (int j = 0; j < 9; j++) {
-                double tmp = sA[k * 9 + j][t];
-                sA[k * 9 + j][t] = sA[pr * 9 + j][t];
-                sA[pr * 9 + j][t] = tmp;
+                double tmp = sA[k * 9 + j];
+                sA[k * 9 + j] = sA[pr * 9 + j];
+                sA[pr * 9 + j] = tmp;
             }
         if (pc != k) {
             for (int i = 0; i < M; i++) {
-                double tmp = sA[i * 9 + k][t];
-                sA[i * 9 + k][t] = sA[i * 9 + pc][t];
-                sA[i * 9 + pc][t] = tmp;
+                double tmp = sA[i * 9 + k];
+                sA[i * 9 + k] = sA[i * 9 + pc];
+                sA[i * 9 + pc] = tmp;
             }
-            int tp = sPerm[k][t];
-            sPerm[k][t] = sPerm[pc][t];
-            sPerm[pc][t] = tp;
+            int tp = sPerm[k];
+            sPerm[k] = sPerm[pc];
+            sPerm[pc] = tp;
         }
-        const double inv = 1. / sA[k * 9 + k][t];
+        const double inv = 1. / sA[k * 9 + k];
         for (int j = 0; j < 9; j++)
-            sA[k * 9 + j][t] *= inv;
+            sA[k * 9 + j] *= inv;
         for (int i = 0; i < M; i++)
             if (i != k) {
-                const double f = sA[i * 9 + k][t];
+                const double f = sA[i * 9 + k];
                 if (f != 0)
                     for (int j = 0; j < 9; j++)
-                        sA[i * 9 + j][t] -= f * sA[k * 9 + j][t];
+                        sA[i * 9 + j] -= f * sA[k * 9 + j];
             }
     }
-    if (singular) {
-        nmodels[it] = 0;
-        return;
-    }
+    if (singular)
+        return 0;
     for (int k = 0; k < M; k++) {
-        const int c = sPerm[k][t];
-        sV[c][t] = -sA[k * 9 + 7][t];
-        sV[9 + c][t] = -sA[k * 9 + 8][t];
+        const int c = sPerm[k];
+        sV[c] = -sA[k * 9 + 7];
+        sV[9 + c] = -sA[k * 9 + 8];
     }
     {
-        const int c7 = sPerm[7][t], c8 = sPerm[8][t];
-        sV[c7][t] = 1;
-        sV[9 + c7][t] = 0;
-        sV[c8][t] = 0;
-        sV[9 + c8][t] = 1;
+        const int c7 = sPerm[7], c8 = sPerm[8];
+        sV[c7] = 1;
+        sV[9 + c7] = 0;
+        sV[c8] = 0;
+        sV[9 + c8] = 1;
     }
     double G[9], H[9], Mx[9], c[4];
 #pragma unroll
     for (int i = 0; i < 9; i++) {
-        const double f1 = sV[i][t], f2 = sV[9 + i][t];
+        const double f1 = sV[i], f2 = sV[9 + i];
         G[i] = f1 - f2;
         H[i] = f2;
     }
@@ -310,7 +288,7 @@ __global__ __launch_bounds__(SOLVE_T) void fr_solve_kernel(FrBatch batch, int it
             }
             nrm = sqrt(nrm);
             if (nrm > 1e-300 && isfinite(nrm)) {
-                double *dst = Fout + ((size_t)it * 3 + nm) * 9;
+                double *dst = Fk_out + nm * 9;
 #pragma unroll
                 for (int i = 0; i < 9; i++)
                     dst[i] = Fk[i] / nrm;
@@ -318,7 +296,7 @@ __global__ __launch_bounds__(SOLVE_T) void fr_solve_kernel(FrBatch batch, int it
             }
         }
     }
-    nmodels[it] = nm;
+    return nm;
 }
 
 // cv FMEstimatorCallback::computeError for one correspondence (float result)
@@ -339,9 +317,9 @@ __device__ __forceinline__ float f_error(const double (&F)[9], float x1, float y
     return (float)(e1 > e2 ? e1 : e2);
 }
 
-// One wavefront per model.  The LAST workgroup to finish (ticket counter) also replays the
-// sequential RANSAC loop over the iterations scored so far -- what used to be a launch of its own.
-__global__ __launch_bounds__(64, 4) void fr_score_kernel(FrBatch batch, int it0, int it1_cap)
+// One phase of the RANSAC loop: iterations [it0, min(it1_cap, max_iters)), one wave per iteration (see the
+// file header).  `final_phase`: no launch follows, so the last wave finishes the problem whatever the state.
+__global__ __launch_bounds__(64, 5) void fr_ransac_kernel(FrBatch batch, int it0, int it1_cap, int final_phase)
 {
     svo_chain_priority();
     const FrJob &job = batch.j[blockIdx.y];
@@ -352,96 +330,95 @@ __global__ __launch_bounds__(64, 4) void fr_score_kernel(FrBatch batch, int it0,
     const int max_iters = job.max_iters;
     const int it1 = it1_cap < max_iters ? it1_cap : max_iters;
     RansacState *st = job.st;
-    const double *__restrict__ Fm = job.Fm;
-    const int *__restrict__ nmodels = job.nmodels;
+    double *__restrict__ Fm = job.Fm;
+    int *__restrict__ nmodels = job.nmodels;
     const float thr = job.thr;
     int *counts = job.counts;
-    const double confidence = job.confidence;
     unsigned *ticket = job.ticket;
     const int lane = threadIdx.x & 63;
-    const bool skip_phase = it0 > 0 && st->done;  // the loop ended in the first phase
+    __shared__ double sA[63], sV[18], sF[27];
+    __shared__ int sPerm[9], s_nm;
+    if (it0 > 0 && st->done)  // the loop ended in an earlier phase (the same answer in every wave of the launch)
+        return;
     const int n = d_n ? *d_n : n_host;
-    // a wave takes the models w, w + gridDim.x, ...: the second phase (936 iterations x 3 models) is
-    // usually skipped, and a grid of one wave per model made 45 k waves per launch queue for wave slots
-    // beside the tracking launches only to exit
-    if (!skip_phase)
-        for (int w = __builtin_amdgcn_readfirstlane(blockIdx.x); w < (it1 - it0) * 3; w += gridDim.x) {
-            const int it = it0 + w / 3, k = w - (w / 3) * 3;
-            const int nm = nmodels[it];
-            if (k >= nm) {
-                if (lane == 0)
-                    counts[it * 3 + k] = 0;
-                continue;
-            }
-            double F[9];
-#pragma unroll
-            for (int i = 0; i < 9; i++)
-                F[i] = Fm[((size_t)it * 3 + k) * 9 + i];
+    for (int it = it0 + (int)blockIdx.x; it < it1; it += gridDim.x) {
+        if (lane == 0) {
+            const int nm = fr_solve_one(job.p1, job.p2, n, job.seed, it, sA, sV, sPerm, sF);
+            s_nm = nm;
+            nmodels[it] = nm;
+            for (int k = 0; k < 3; k++)
+                if (k < nm)
+                    for (int i = 0; i < 9; i++)
+                        Fm[((size_t)it * 3 + k) * 9 + i] = sF[k * 9 + i];  // the finishing wave reads the winner's
+        }
+        __syncthreads();
+        const int nm = s_nm;
+        for (int k = 0; k < 3; k++) {
             int cnt = 0;
-#pragma clang loop unroll(disable)  // unrolled, the f64 bodies take >128 VGPRs + scratch: the wave then needs two freed tracking slots
-            for (int i = lane; i < n; i += 64) {
-                const float2 a = p1[i], b = p2[i];
-                cnt += f_error(F, a.x, a.y, b.x, b.y) <= thr ? 1 : 0;
+            if (k < nm) {
+                double F[9];
+#pragma unroll
+                for (int i = 0; i < 9; i++)
+                    F[i] = sF[k * 9 + i];
+#pragma clang loop unroll(disable)  // unrolled, the f64 bodies take >128 VGPRs + scratch
+                for (int i = lane; i < n; i += 64) {
+                    const float2 a = p1[i], b = p2[i];
+                    cnt += f_error(F, a.x, a.y, b.x, b.y) <= thr ? 1 : 0;
+                }
+                cnt = wave_sum_small(cnt);
             }
-            cnt = wave_sum_small(cnt);
             if (lane == 0)
                 counts[it * 3 + k] = cnt;
         }
-    // every workgroup takes a ticket once its counts are out; the holder of the last one sees them all
-    // (a skipped phase skips the tickets too: `done` is the same for every workgroup of the launch)
-    if (skip_phase)
-        return;
-    __syncthreads();
-    if (threadIdx.x == 0) {
+        __syncthreads();  // sF / s_nm are rewritten by the next iteration of this wave
+    }
+    // every wave takes a ticket once its counts are out; the holder of the last one sees them all
+    int last = 0;
+    if (lane == 0) {
         __threadfence();
         const unsigned t = atomicAdd(ticket, 1u);
-        if (t == gridDim.x - 1) {
-            *ticket = 0;  // ready for the next launch
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // other workgroups' counts, not this CU's stale lines
-            *st = ransac_replay<3>(st, it0 == 0 ? 1 : 0, it1, max_iters, n, confidence, nmodels, counts, M);
-        }
+        last = t == gridDim.x - 1;
     }
-}
-
-__global__ __launch_bounds__(256) void fr_mask_kernel(FrBatch batch)
-{
-    svo_chain_priority();
-    const FrJob &job = batch.j[blockIdx.y];
-    const float2 *__restrict__ p1 = reinterpret_cast<const float2 *>(job.p1);
-    const float2 *__restrict__ p2 = reinterpret_cast<const float2 *>(job.p2);
-    const int n_host = job.n_host;
-    const int *__restrict__ d_n = job.d_n;
-    const RansacState *__restrict__ st = job.st;
-    const double *__restrict__ Fm = job.Fm;
-    const float thr = job.thr;
+    last = __builtin_amdgcn_readfirstlane(last);
+    if (!last)
+        return;
+    __shared__ RansacState s_state;
+    if (lane == 0) {
+        *ticket = 0;  // ready for the next launch
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // other waves' counts, not this CU's stale lines
+        const RansacState r = ransac_replay<3>(st, it0 == 0 ? 1 : 0, it1, max_iters, n, job.confidence, nmodels, counts, M);
+        *st = r;
+        s_state = r;
+    }
+    __syncthreads();
+    const RansacState s = s_state;
+    if (!s.done && !final_phase)
+        return;  // the next phase's last wave finishes
+    // ---- the winning model: mask (cv: computeError <= thr on every correspondence), model, counts ----
     uint8_t *__restrict__ mask = job.mask;
-    double *__restrict__ Fbest = job.Fbest;
-    int *__restrict__ out_count = job.out_count, *__restrict__ out_iters = job.out_iters;
-    const int n = d_n ? *d_n : n_host;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const RansacState s = *st;
-    double F[9];
     const bool have = s.best_iter >= 0 && s.best_count > 0;
+    double F[9];
 #pragma unroll
     for (int k = 0; k < 9; k++)
         F[k] = have ? Fm[((size_t)s.best_iter * 3 + s.best_model) * 9 + k] : 0.;
-    if (i == 0) {
-        if (out_count)
-            *out_count = have ? s.best_count : 0;
-        if (out_iters)
-            *out_iters = s.iters_run;
-        if (Fbest)
+    if (lane == 0) {
+        if (job.out_count)
+            *job.out_count = have ? s.best_count : 0;
+        if (job.out_iters)
+            *job.out_iters = s.iters_run;
+        if (job.Fbest)
             for (int k = 0; k < 9; k++)
-                Fbest[k] = F[k];
+                job.Fbest[k] = F[k];
     }
-    if (i >= n_host)  // n_host is the capacity the grid was sized for
-        return;
-    uint8_t m = 0;
-    if (have && i < n) {
-        const float2 a = p1[i], b = p2[i];
-        m = f_error(F, a.x, a.y, b.x, b.y) <= thr ? 1 : 0;
+#pragma clang loop unroll(disable)
+    for (int i = lane; i < n_host; i += 64) {  // n_host: the capacity of the mask
+        uint8_t m = 0;
+        if (have && i < n) {
+            const float2 a = p1[i], b = p2[i];
+            m = f_error(F, a.x, a.y, b.x, b.y) <= thr ? 1 : 0;
+        }
+        mask[i] = m;
     }
-    mask[i] = m;
 }
 
 }  // namespace
@@ -505,12 +482,9 @@ int svo_launch_fransac_batch(svo_ctx *ctx, int n_jobs, const svo_fransac_job *jo
         if (it1 <= it0)
             continue;
         const int iters = it1 - it0;
-        hipLaunchKernelGGL(fr_solve_kernel, dim3((iters + SOLVE_T - 1) / SOLVE_T, nb), dim3(SOLVE_T), 0, ctx->stream,
-                           batch, it0, it1);
-        const int score_waves = iters * 3 < SCORE_WAVES ? iters * 3 : SCORE_WAVES;
-        hipLaunchKernelGGL(fr_score_kernel, dim3(score_waves, nb), dim3(64), 0, ctx->stream, batch, it0, it1);
+        hipLaunchKernelGGL(fr_ransac_kernel, dim3(iters < PHASE_WAVES ? iters : PHASE_WAVES, nb), dim3(64), 0, ctx->stream,
+                           batch, it0, it1, it1 >= it_max ? 1 : 0);
     }
-    hipLaunchKernelGGL(fr_mask_kernel, dim3((cap_max + 63) / 64, nb), dim3(64), 0, ctx->stream, batch);
     SVO_HIP(hipGetLastError());
     return SVO_OK;
 }
