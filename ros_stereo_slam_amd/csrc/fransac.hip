@@ -46,10 +46,16 @@ struct FrJob {
     uint8_t *mask;
     double *Fbest;
     int *out_count, *out_iters;
+    // order-preserving compaction by the mask, done by the finishing wave (c_in[0] == nullptr: none)
+    const float *c_in[3];
+    float *c_out[3];
+    int c_stride[3];
+    int *c_count;
 };
 struct FrBatch {
     FrJob j[SVO_LK_MAX_JOBS];
 };
+static_assert(sizeof(FrBatch) + 16 <= 4096, "kernel arguments are limited to 4 KB");
 
 __device__ __forceinline__ double det3(const double *m)
 {
@@ -410,15 +416,35 @@ __global__ __launch_bounds__(64, 5) void fr_ransac_kernel(FrBatch batch, int it0
             for (int k = 0; k < 9; k++)
                 job.Fbest[k] = F[k];
     }
+    const bool compacting = job.c_in[0] != nullptr;
+    int pos0 = 0;
 #pragma clang loop unroll(disable)
-    for (int i = lane; i < n_host; i += 64) {  // n_host: the capacity of the mask
-        uint8_t m = 0;
+    for (int start = 0; start < n_host; start += 64) {  // n_host: the capacity of the mask
+        const int i = start + lane;
+        bool keep = false;
         if (have && i < n) {
             const float2 a = p1[i], b = p2[i];
-            m = f_error(F, a.x, a.y, b.x, b.y) <= thr ? 1 : 0;
+            keep = f_error(F, a.x, a.y, b.x, b.y) <= thr;
         }
-        mask[i] = m;
+        if (i < n_host)
+            mask[i] = keep ? 1 : 0;
+        if (compacting) {  // what compact_kernel does with this mask, in the same pass (order kept)
+            const unsigned long long bal = __ballot(keep);
+            if (keep) {
+                const int pos = pos0 + __popcll(bal & ((1ull << lane) - 1ull));
+#pragma unroll
+                for (int a = 0; a < 3; a++)
+                    if (job.c_in[a]) {
+                        const int stn = job.c_stride[a];
+                        for (int k = 0; k < stn; k++)
+                            job.c_out[a][(size_t)pos * stn + k] = job.c_in[a][(size_t)i * stn + k];
+                    }
+            }
+            pos0 += __popcll(bal);
+        }
     }
+    if (compacting && job.c_count && lane == 0)
+        *job.c_count = pos0;
 }
 
 }  // namespace
@@ -469,6 +495,13 @@ int svo_launch_fransac_batch(svo_ctx *ctx, int n_jobs, const svo_fransac_job *jo
         j.Fbest = h.d_F;
         j.out_count = h.d_count;
         j.out_iters = h.d_iters;
+        for (int a = 0; a < 3; a++) {
+            const svo_compact_job *c = h.then_compact;
+            j.c_in[a] = c ? c->in[a] : nullptr;
+            j.c_out[a] = c ? c->out[a] : nullptr;
+            j.c_stride[a] = c ? c->stride[a] : 0;
+        }
+        j.c_count = h.then_compact ? h.then_compact->d_count : nullptr;
         nb++;
     }
     if (nb == 0)
@@ -491,9 +524,10 @@ int svo_launch_fransac_batch(svo_ctx *ctx, int n_jobs, const svo_fransac_job *jo
 
 int svo_launch_fransac(svo_ctx *ctx, const float *p1, const float *p2, int cap, const int *d_n,
                        double threshold, double confidence, int max_iters, uint64_t seed, uint8_t *mask,
-                       double *d_F, int *d_count, int *d_iters)
+                       double *d_F, int *d_count, int *d_iters, const svo_compact_job *then_compact)
 {
     svo_fransac_job j;
+    j.then_compact = then_compact;
     j.p1 = p1;
     j.p2 = p2;
     j.cap = cap;

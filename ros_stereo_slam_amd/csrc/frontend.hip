@@ -206,16 +206,16 @@ int stereo_triangulate_batch(int k, svo_vo *const *vs, svo_pyramid *const *lefts
         float *x1 = out2d[a], *x2 = o1 == v->a2 ? v->c2 : v->a2;
         c1[a] = {stt[a], n, d_n[a], {pts[a], trk[a], nullptr}, {o1, o2, nullptr}, {2, 2, 0}, v->d_cnt + 3};
         // FmatThresholding (src/tracking.cpp:30-43): 3 px, 0.99
-        fj[a] = {o1, o2, n, v->d_cnt + 3, v->prm.f_thr_stereo, 0.99, 1000, stage_seed(v, 3), v->mask, nullptr, nullptr,
-                 nullptr};
         c2[a] = {v->mask, n, v->d_cnt + 3, {o1, o2, nullptr}, {x1, x2, nullptr}, {2, 2, 0}, v->d_cnt + 4};
+        fj[a] = {o1, o2, n, v->d_cnt + 3, v->prm.f_thr_stereo, 0.99, 1000, stage_seed(v, 3), v->mask, nullptr, nullptr,
+                 nullptr, &c2[a]};  // the mask compaction rides with the F-RANSAC
         tj[a] = {x1, x2, n, v->d_cnt + 4, Rts[a] ? v->b3 : out3d[a], nullptr, Rts[a], Rts[a] ? out3d[a] : nullptr,
                  reinterpret_cast<int *>(ctx->pinned) + a};  // the count the host reads after the wait below
     }
     double P1[12], P2[12];
     svo_stereo_projections(v0->prm.fx, v0->prm.fy, v0->prm.cx, v0->prm.cy, v0->prm.baseline, P1, P2);
     if ((rc = svo_launch_compact_batch(ctx, k, c1)) || (rc = svo_launch_fransac_batch(ctx, k, fj)) ||
-        (rc = svo_launch_compact_batch(ctx, k, c2)) || (rc = svo_launch_triangulate_batch(ctx, P1, P2, k, tj)))
+        (rc = svo_launch_triangulate_batch(ctx, P1, P2, k, tj)))
         return rc;
     int *pin = reinterpret_cast<int *>(ctx->pinned);
     if ((rc = svo_wait(ctx)))
@@ -472,12 +472,14 @@ int svo_vo_localize(svo_vo *v, const uint8_t *left, int mem, double *R9, double 
     if ((rc = svo_launch_compact(ctx, v->status, n, nullptr, v->ref2d, 2, v->b2, v->a2, 2, v->c2, v->ref3d, 3, v->a3,
                                  v->d_cnt)))
         return rc;
-    if ((rc = svo_launch_fransac(ctx, v->b2, v->c2, n, v->d_cnt, v->prm.f_thr_temporal, 0.99, 1000, stage_seed(v, 0),
-                                 v->mask, nullptr, nullptr, nullptr)))
-        return rc;
-    if ((rc = svo_launch_compact(ctx, v->mask, n, v->d_cnt, v->c2, 2, v->trk2d, v->a3, 3, v->trk3d, nullptr, 0,
-                                 nullptr, v->d_cnt + 1)))
-        return rc;
+    {
+        // the F-RANSAC's finishing wave also compacts by its mask (src/tracking.cpp:77-88)
+        const svo_compact_job by_mask = {v->mask, n, v->d_cnt, {v->c2, v->a3, nullptr}, {v->trk2d, v->trk3d, nullptr},
+                                         {2, 3, 0}, v->d_cnt + 1};
+        if ((rc = svo_launch_fransac(ctx, v->b2, v->c2, n, v->d_cnt, v->prm.f_thr_temporal, 0.99, 1000, stage_seed(v, 0),
+                                     v->mask, nullptr, nullptr, nullptr, &by_mask)))
+            return rc;
+    }
     const double K4[4] = {v->prm.fx, v->prm.fy, v->prm.cx, v->prm.cy};
     const PnpRecord *rec = reinterpret_cast<const PnpRecord *>(ctx->pinned);
     if (v->prm.policy == SVO_POLICY_VO_LADDER) {
@@ -676,12 +678,12 @@ int svo_vo_run_chunk(svo_vo *v, const uint8_t *const *lefts, const uint8_t *cons
         // f-1 (stream B) may still read its slot while this frame's filters (stream A) write theirs
         int *cnt_trk = v->d_cnt + ((f & 1) ? 9 : 1);
         PnpRecord *d_rec = v->d_rec + (f & 1);
+        const svo_compact_job by_mask = {v->mask, n, v->d_cnt, {v->c2, v->a3, nullptr}, {v->trk2d, v->trk3d, nullptr},
+                                         {2, 3, 0}, cnt_trk};  // done by the F-RANSAC's finishing wave
         if ((rc = svo_launch_compact(ctx, v->status, n, nullptr, v->ref2d, 2, v->b2, v->a2, 2, v->c2, v->ref3d, 3,
                                      v->a3, v->d_cnt)) ||
             (rc = svo_launch_fransac(ctx, v->b2, v->c2, n, v->d_cnt, v->prm.f_thr_temporal, 0.99, 1000,
-                                     stage_seed(v, 0), v->mask, nullptr, nullptr, nullptr)) ||
-            (rc = svo_launch_compact(ctx, v->mask, n, v->d_cnt, v->c2, 2, v->trk2d, v->a3, 3, v->trk3d, nullptr, 0,
-                                     nullptr, cnt_trk)))
+                                     stage_seed(v, 0), v->mask, nullptr, nullptr, nullptr, &by_mask)))
             return rc;
         // ---- PnP of this frame: stream B when pipelining ----
         hipStream_t sP = pipeline ? sB : sA;
@@ -964,10 +966,10 @@ static int run_chunk_group(svo_chunk_job **jobs, int k)
             q.d_F = nullptr;
             q.d_count = nullptr;
             q.d_iters = nullptr;
+            q.then_compact = &c2[np];  // the mask compaction rides with the F-RANSAC
             pg[np++] = &g;
         }
-        if ((rc = svo_launch_compact_batch(ctx, np, c1)) || (rc = svo_launch_fransac_batch(ctx, np, fj)) ||
-            (rc = svo_launch_compact_batch(ctx, np, c2)))
+        if ((rc = svo_launch_compact_batch(ctx, np, c1)) || (rc = svo_launch_fransac_batch(ctx, np, fj)))
             return rc;
         for (int a = 0; a < np; a++) {
             GS &g = *pg[a];

@@ -150,6 +150,15 @@ int svo_launch_lk(svo_ctx *ctx, svo_pyramid *prev, const svo_pyramid *next, cons
 int svo_launch_grid(svo_ctx *ctx, int rows, int cols, int step, float *out_xy, int cap);
 
 // fransac.hip
+struct svo_compact_job {  // order-preserving compaction of up to three float arrays by one byte mask
+    const uint8_t *mask;
+    int cap;
+    const int *d_n;
+    const float *in[3];
+    float *out[3];
+    int stride[3];
+    int *d_count;
+};
 struct svo_fransac_job {  // host-side description of one F-matrix RANSAC problem (device pointers)
     const float *p1, *p2;
     int cap;
@@ -160,11 +169,14 @@ struct svo_fransac_job {  // host-side description of one F-matrix RANSAC proble
     uint8_t *mask;
     double *d_F;
     int *d_count, *d_iters;
+    // optional: the compaction by the fresh mask (mask / cap / d_n of this job are used, the struct's own are
+    // ignored), done by the wave that writes the mask -- no launch of its own
+    const svo_compact_job *then_compact = nullptr;
 };
 int svo_launch_fransac_batch(svo_ctx *ctx, int n_jobs, const svo_fransac_job *jobs);
 int svo_launch_fransac(svo_ctx *ctx, const float *p1, const float *p2, int cap, const int *d_n,
                        double threshold, double confidence, int max_iters, uint64_t seed, uint8_t *mask,
-                       double *d_F, int *d_count, int *d_iters);
+                       double *d_F, int *d_count, int *d_iters, const svo_compact_job *then_compact = nullptr);
 // geometry.hip
 int svo_launch_triangulate(svo_ctx *ctx, const double *P1, const double *P2, const float *x1, const float *x2,
                            int cap, const int *d_n, float *out_xyz, float *out_h, const double *Rt,
@@ -181,15 +193,6 @@ struct svo_tri_job {  // one stereo DLT triangulation (device pointers; Rt: host
 int svo_launch_triangulate_batch(svo_ctx *ctx, const double *P1, const double *P2, int k, const svo_tri_job *jobs);
 int svo_launch_transform(svo_ctx *ctx, const double *Rt, const float *in, int cap, const int *d_n, float *out);
 int svo_launch_colors(svo_ctx *ctx, const svo_pyramid *pyr, const float *xy, int cap, const int *d_n, float *out);
-struct svo_compact_job {  // order-preserving compaction of up to three float arrays by one byte mask
-    const uint8_t *mask;
-    int cap;
-    const int *d_n;
-    const float *in[3];
-    float *out[3];
-    int stride[3];
-    int *d_count;
-};
 int svo_launch_compact_batch(svo_ctx *ctx, int n_jobs, const svo_compact_job *jobs);
 int svo_launch_compact(svo_ctx *ctx, const uint8_t *mask, int cap, const int *d_n, const float *in_a, int stride_a,
                        float *out_a, const float *in_b, int stride_b, float *out_b, const float *in_c, int stride_c,
