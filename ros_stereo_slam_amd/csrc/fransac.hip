@@ -305,6 +305,43 @@ __device__ int fr_solve_one(const float *__restrict__ p1, const float *__restric
     return nm;
 }
 
+// a wave-uniform double as a scalar-register value
+__device__ __forceinline__ double uniform_f64(double x)
+{
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+// four consecutive correspondences of one lane
+struct Quad {
+    float x1[4], y1[4], x2[4], y2[4];
+};
+// pairs base .. base+3 (those below n; the rest read as 0): two 16-byte loads per array when the arrays are
+// 16-byte aligned (`vec_ok`) and the four are inside, single pairs otherwise
+__device__ __forceinline__ void load_quad(Quad &q, const float2 *__restrict__ p1, const float2 *__restrict__ p2, int base,
+                                          int n, bool vec_ok)
+{
+    if (vec_ok && base + 3 < n) {
+        const float4 a0 = *reinterpret_cast<const float4 *>(p1 + base), a1 = *reinterpret_cast<const float4 *>(p1 + base + 2);
+        const float4 b0 = *reinterpret_cast<const float4 *>(p2 + base), b1 = *reinterpret_cast<const float4 *>(p2 + base + 2);
+        q.x1[0] = a0.x, q.y1[0] = a0.y, q.x1[1] = a0.z, q.y1[1] = a0.w;
+        q.x1[2] = a1.x, q.y1[2] = a1.y, q.x1[3] = a1.z, q.y1[3] = a1.w;
+        q.x2[0] = b0.x, q.y2[0] = b0.y, q.x2[1] = b0.z, q.y2[1] = b0.w;
+        q.x2[2] = b1.x, q.y2[2] = b1.y, q.x2[3] = b1.z, q.y2[3] = b1.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            float2 a = {0.f, 0.f}, b = {0.f, 0.f};
+            if (base + k < n) {
+                a = p1[base + k];
+                b = p2[base + k];
+            }
+            q.x1[k] = a.x, q.y1[k] = a.y, q.x2[k] = b.x, q.y2[k] = b.y;
+        }
+    }
+}
+
 // cv FMEstimatorCallback::computeError for one correspondence (float result)
 __device__ __forceinline__ float f_error(const double (&F)[9], float x1, float y1, float x2, float y2)
 {
@@ -347,6 +384,7 @@ __global__ __launch_bounds__(64, 5) void fr_ransac_kernel(FrBatch batch, int it0
     if (it0 > 0 && st->done)  // the loop ended in an earlier phase (the same answer in every wave of the launch)
         return;
     const int n = d_n ? *d_n : n_host;
+    const bool vec_ok = ((reinterpret_cast<uintptr_t>(p1) | reinterpret_cast<uintptr_t>(p2)) & 15) == 0;
     for (int it = it0 + (int)blockIdx.x; it < it1; it += gridDim.x) {
         if (lane == 0) {
             const int nm = fr_solve_one(job.p1, job.p2, n, job.seed, it, sA, sV, sPerm, sF);
@@ -359,22 +397,40 @@ __global__ __launch_bounds__(64, 5) void fr_ransac_kernel(FrBatch batch, int it0
         }
         __syncthreads();
         const int nm = s_nm;
-        for (int k = 0; k < 3; k++) {
-            int cnt = 0;
-            if (k < nm) {
-                double F[9];
+        // Score the (up to three) models in ONE pass over the correspondences.  The loop is bound by the latency
+        // of its loads (one wave, nothing else to switch to), so a lane takes FOUR consecutive pairs per step
+        // with 16-byte loads and requests the next step's before it uses this step's; the model being
+        // evaluated sits in scalar registers.
+        int c0 = 0, c1 = 0, c2 = 0;
+        if (nm > 0) {
+            Quad cur, nxt;
+            load_quad(cur, p1, p2, 4 * lane, n, vec_ok);
+            for (int base = 4 * lane; base < n; base += 256) {
+                if (base + 256 < n)
+                    load_quad(nxt, p1, p2, base + 256, n, vec_ok);
+                for (int k = 0; k < nm; k++) {
+                    double F[9];
 #pragma unroll
-                for (int i = 0; i < 9; i++)
-                    F[i] = sF[k * 9 + i];
-#pragma clang loop unroll(disable)  // unrolled, the f64 bodies take >128 VGPRs + scratch
-                for (int i = lane; i < n; i += 64) {
-                    const float2 a = p1[i], b = p2[i];
-                    cnt += f_error(F, a.x, a.y, b.x, b.y) <= thr ? 1 : 0;
+                    for (int i = 0; i < 9; i++)
+                        F[i] = uniform_f64(sF[k * 9 + i]);
+                    int c = 0;
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        c += (base + q < n && f_error(F, cur.x1[q], cur.y1[q], cur.x2[q], cur.y2[q]) <= thr) ? 1 : 0;
+                    c0 += k == 0 ? c : 0;
+                    c1 += k == 1 ? c : 0;
+                    c2 += k == 2 ? c : 0;
                 }
-                cnt = wave_sum_small(cnt);
+                cur = nxt;
             }
-            if (lane == 0)
-                counts[it * 3 + k] = cnt;
+            c0 = wave_sum_small(c0);
+            c1 = nm > 1 ? wave_sum_small(c1) : 0;
+            c2 = nm > 2 ? wave_sum_small(c2) : 0;
+        }
+        if (lane == 0) {
+            counts[it * 3 + 0] = c0;
+            counts[it * 3 + 1] = c1;
+            counts[it * 3 + 2] = c2;
         }
         __syncthreads();  // sF / s_nm are rewritten by the next iteration of this wave
     }
@@ -418,30 +474,41 @@ __global__ __launch_bounds__(64, 5) void fr_ransac_kernel(FrBatch batch, int it0
     }
     const bool compacting = job.c_in[0] != nullptr;
     int pos0 = 0;
-#pragma clang loop unroll(disable)
-    for (int start = 0; start < n_host; start += 64) {  // n_host: the capacity of the mask
-        const int i = start + lane;
-        bool keep = false;
-        if (have && i < n) {
-            const float2 a = p1[i], b = p2[i];
-            keep = f_error(F, a.x, a.y, b.x, b.y) <= thr;
-        }
-        if (i < n_host)
-            mask[i] = keep ? 1 : 0;
-        if (compacting) {  // what compact_kernel does with this mask, in the same pass (order kept)
-            const unsigned long long bal = __ballot(keep);
-            if (keep) {
-                const int pos = pos0 + __popcll(bal & ((1ull << lane) - 1ull));
+    Quad cur, nxt;
+    load_quad(cur, p1, p2, 4 * lane, n, vec_ok);
+    for (int start = 0; start < n_host; start += 256) {  // n_host: the capacity of the mask
+        const int base = start + 4 * lane;
+        if (base + 256 < n)  // the next four pairs are on their way while these are judged
+            load_quad(nxt, p1, p2, base + 256, n, vec_ok);
+        bool keep[4];
+        unsigned long long bal[4];
+        int before = 0;  // kept entries of lower lanes in this step (a lane's four entries are consecutive)
 #pragma unroll
-                for (int a = 0; a < 3; a++)
-                    if (job.c_in[a]) {
-                        const int stn = job.c_stride[a];
-                        for (int k = 0; k < stn; k++)
-                            job.c_out[a][(size_t)pos * stn + k] = job.c_in[a][(size_t)i * stn + k];
-                    }
-            }
-            pos0 += __popcll(bal);
+        for (int q = 0; q < 4; q++) {
+            keep[q] = have && base + q < n && f_error(F, cur.x1[q], cur.y1[q], cur.x2[q], cur.y2[q]) <= thr;
+            if (base + q < n_host)
+                mask[base + q] = keep[q] ? 1 : 0;
+            bal[q] = __ballot(keep[q]);
+            before += __popcll(bal[q] & ((1ull << lane) - 1ull));
         }
+        if (compacting) {  // what compact_kernel does with this mask, in the same pass (order kept)
+            int pos = pos0 + before;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (keep[q]) {
+                    const int i = base + q;
+#pragma unroll
+                    for (int r = 0; r < 3; r++)
+                        if (job.c_in[r]) {
+                            const int stn = job.c_stride[r];
+                            for (int k = 0; k < stn; k++)
+                                job.c_out[r][(size_t)pos * stn + k] = job.c_in[r][(size_t)i * stn + k];
+                        }
+                    pos++;
+                }
+            pos0 += __popcll(bal[0]) + __popcll(bal[1]) + __popcll(bal[2]) + __popcll(bal[3]);
+        }
+        cur = nxt;
     }
     if (compacting && job.c_count && lane == 0)
         *job.c_count = pos0;
