@@ -144,11 +144,23 @@ __device__ bool collinear_last(const float *__restrict__ p, const int (&idx)[M])
     return bad;
 }
 
-// One RANSAC iteration's models, by ONE lane: up to three unit-norm F (row-major) into Fk[27]; returns their
-// number, -1 when no sample could be drawn (the sequential loop stops there).  sA / sV / sPerm: this lane's
-// scratch in LDS (63 + 18 doubles, 9 ints).
-__device__ int fr_solve_one(const float *__restrict__ p1, const float *__restrict__ p2, int n, uint64_t seed, int it,
-                            double *sA, double *sV, int *sPerm, double *Fk_out)
+__device__ __forceinline__ double wave_max_f64(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// One RANSAC iteration's models, by one WAVE: up to three unit-norm F (row-major) into Fk_out[27] (LDS, written
+// by lane 0); returns their number (valid in lane 0), -1 when no sample could be drawn (the sequential loop
+// stops there).  The sample is drawn by every lane alike; the 7x9 Gauss-Jordan elimination with full pivoting
+// runs with ONE MATRIX ENTRY PER LANE (lane = 9 * row + column; as a loop of one lane over the matrix in LDS it
+// was 1300 dependent LDS round trips, most of the kernel's time): every entry sees exactly the operations of
+// the sequential elimination, in its order, so the result is the same bit for bit; the null-space tail (cubic,
+// models) is lane 0's.  sA / sV / sPerm: LDS scratch (63 + 18 doubles, 9 ints).
+__device__ int fr_solve_wave(const float *__restrict__ p1, const float *__restrict__ p2, int n, uint64_t seed, int it,
+                             double *sA, double *sV, int *sPerm, double *Fk_out, int lane)
 {
     if (n < M)
         return -1;
@@ -183,67 +195,64 @@ __device__ int fr_solve_one(const float *__restrict__ p1, const float *__restric
     }
     if (!ok)
         return -1;  // getSubset failed: the sequential loop stops here
-    // ---- 7x9 epipolar system in LDS, Gauss-Jordan with full pivoting ----
+    // ---- 7x9 epipolar system, one entry per lane; Gauss-Jordan with full pivoting ----
+    const bool valid = lane < 63;
+    const int li = valid ? lane / 9 : 7, lj = valid ? lane - 9 * li : 0;
+    double a = 0;
+    {
+        int my = idx[0];
 #pragma unroll
-    for (int i = 0; i < M; i++) {
-        const double u0 = p1[2 * idx[i]], v0 = p1[2 * idx[i] + 1];
-        const double u1 = p2[2 * idx[i]], v1 = p2[2 * idx[i] + 1];
-        sA[i * 9 + 0] = u1 * u0;
-        sA[i * 9 + 1] = u1 * v0;
-        sA[i * 9 + 2] = u1;
-        sA[i * 9 + 3] = v1 * u0;
-        sA[i * 9 + 4] = v1 * v0;
-        sA[i * 9 + 5] = v1;
-        sA[i * 9 + 6] = u0;
-        sA[i * 9 + 7] = v0;
-        sA[i * 9 + 8] = 1.;
+        for (int i = 1; i < M; i++)
+            my = li == i ? idx[i] : my;
+        const double u0 = p1[2 * my], v0 = p1[2 * my + 1];
+        const double u1 = p2[2 * my], v1 = p2[2 * my + 1];
+        const double row[9] = {u1 * u0, u1 * v0, u1, v1 * u0, v1 * v0, v1, u0, v0, 1.};
+#pragma unroll
+        for (int j = 0; j < 9; j++)
+            a = lj == j ? row[j] : a;
+        if (!valid)
+            a = 0;
     }
-    for (int j = 0; j < 9; j++)
-        sPerm[j] = j;
+    int permv = lane;  // lanes 0..8: the column permutation
     bool singular = false;
-    for (int k = 0; k < M && !singular; k++) {
-        int pr = k, pc = k;
-        double best = -1;
-        for (int i = k; i < M; i++)
-            for (int j = k; j < 9; j++) {
-                double v = fabs(sA[i * 9 + j]);
-                if (v > best) {
-                    best = v;
-                    pr = i;
-                    pc = j;
-                }
-            }
+#pragma unroll 1
+    for (int k = 0; k < M; k++) {
+        // the first entry (row-major) of the largest magnitude in rows >= k, columns >= k
+        const double v = (valid && li >= k && lj >= k) ? fabs(a) : -1.;
+        const double best = wave_max_f64(v);
         if (best < 1e-12) {
             singular = true;
             break;
         }
-        if (pr != k)
-            for (int j = 0; j < 9; j++) {
-                double tmp = sA[k * 9 + j];
-                sA[k * 9 + j] = sA[pr * 9 + j];
-                sA[pr * 9 + j] = tmp;
-            }
-        if (pc != k) {
-            for (int i = 0; i < M; i++) {
-                double tmp = sA[i * 9 + k];
-                sA[i * 9 + k] = sA[i * 9 + pc];
-                sA[i * 9 + pc] = tmp;
-            }
-            int tp = sPerm[k];
-            sPerm[k] = sPerm[pc];
-            sPerm[pc] = tp;
+        const int pl = __ffsll((unsigned long long)__ballot(v == best)) - 1;
+        const int pr = pl / 9, pc = pl - 9 * pr;
+        if (pr != k) {  // rows k <-> pr
+            const int src = li == k ? pr * 9 + lj : (li == pr ? k * 9 + lj : lane);
+            a = __shfl(a, src, 64);
         }
-        const double inv = 1. / sA[k * 9 + k];
-        for (int j = 0; j < 9; j++)
-            sA[k * 9 + j] *= inv;
-        for (int i = 0; i < M; i++)
-            if (i != k) {
-                const double f = sA[i * 9 + k];
-                if (f != 0)
-                    for (int j = 0; j < 9; j++)
-                        sA[i * 9 + j] -= f * sA[k * 9 + j];
-            }
+        if (pc != k) {  // columns k <-> pc
+            const int src = lj == k ? li * 9 + pc : (lj == pc ? li * 9 + k : lane);
+            a = __shfl(a, valid ? src : lane, 64);
+            const int psrc = lane == k ? pc : (lane == pc ? k : lane);
+            permv = __shfl(permv, psrc, 64);
+        }
+        const double inv = 1. / __shfl(a, k * 9 + k, 64);
+        if (li == k)
+            a *= inv;
+        const double rowk = __shfl(a, k * 9 + lj, 64);                   // A[k][j], scaled
+        const double f = __shfl(a, valid ? li * 9 + k : lane, 64);       // A[i][k]
+        if (valid && li != k && f != 0)
+            a -= f * rowk;
     }
+    if (valid)
+        sA[lane] = a;
+    if (lane < 9)
+        sPerm[lane] = permv;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane != 0)
+        return 0;  // the tail is lane 0's
     if (singular)
         return 0;
     for (int k = 0; k < M; k++) {
@@ -386,8 +395,9 @@ __global__ __launch_bounds__(64, 5) void fr_ransac_kernel(FrBatch batch, int it0
     const int n = d_n ? *d_n : n_host;
     const bool vec_ok = ((reinterpret_cast<uintptr_t>(p1) | reinterpret_cast<uintptr_t>(p2)) & 15) == 0;
     for (int it = it0 + (int)blockIdx.x; it < it1; it += gridDim.x) {
+        const int nm_l0 = fr_solve_wave(job.p1, job.p2, n, job.seed, it, sA, sV, sPerm, sF, lane);
         if (lane == 0) {
-            const int nm = fr_solve_one(job.p1, job.p2, n, job.seed, it, sA, sV, sPerm, sF);
+            const int nm = nm_l0;
             s_nm = nm;
             nmodels[it] = nm;
             for (int k = 0; k < 3; k++)
