@@ -339,6 +339,15 @@ template <int C> __device__ __forceinline__ void dtile_commit(DtileLoad<C> &t, u
 // Every lane of a wave computes the same control values (guess, step, tile origin): telling the
 // compiler so turns the loop's branches into scalar compares instead of exec-mask juggling.
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// (int)f of a wave-uniform, already floored float as a scalar: convert, then read the first lane.  Written
+// out because the compiler turns readfirstlane(cvt(f)) into cvt(readfirstlane(f)) and then needs a second
+// readfirstlane to get the integer out of the vector register again.
+__device__ __forceinline__ int uniform_int_of(float f)
+{
+    int i;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(i) : "v"(f));
+    return __builtin_amdgcn_readfirstlane(i);
+}
 __device__ __forceinline__ bool uniform(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0; }
 
 typedef short short2v __attribute__((ext_vector_type(2)));
@@ -548,7 +557,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void lk_track_kernel(LkBatch batch, 
         outy = nyp;
         px -= half;
         py -= half;
-        const int ipx = uniform((int)floorf(px)), ipy = uniform((int)floorf(py));
+        const int ipx = uniform_int_of(floorf(px)), ipy = uniform_int_of(floorf(py));
         if (ipx < -WIN || ipx >= lw || ipy < -WIN || ipy >= lh) {
             if (level == 0) {
                 st = 0;
@@ -686,7 +695,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void lk_track_kernel(LkBatch batch, 
         bool out_set = false;    // left through the oscillation test: the output (backed off half a step) is written there
         for (int j = 0; j < prm.max_count; j++) {
             const float fx = floorf(nxp), fy = floorf(nyp);
-            const int inx = uniform((int)fx), iny = uniform((int)fy);
+            const int inx = uniform_int_of(fx), iny = uniform_int_of(fy);
             if (inx < -WIN || inx >= lw || iny < -WIN || iny >= lh) {
                 if (level == 0)
                     st = 0;
@@ -739,7 +748,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void lk_track_kernel(LkBatch batch, 
         // ---- 3. level-0 residual (err output of calcOpticalFlowPyrLK) ----
         if (st && level == 0) {
             const float qx = outx - half, qy = outy - half;
-            const int iqx = uniform((int)floorf(qx)), iqy = uniform((int)floorf(qy));
+            const int iqx = uniform_int_of(floorf(qx)), iqy = uniform_int_of(floorf(qy));
             if (iqx < -WIN || iqx >= lw || iqy < -WIN || iqy >= lh) {
                 st = 0;
                 continue;
