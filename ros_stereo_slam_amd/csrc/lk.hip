@@ -484,10 +484,12 @@ __device__ __forceinline__ void lane_mismatch(const uint8_t *lds, int off, int w
     load_row_packed<C>(lds, off + Tile<C, TS>::ROW, r1);
     int Jp[npairs(C)];
     lane_samples<C, W_BITS - 5>(r0, r1, wv0, wv1, Jp);
-    s1 = neg_c1;
-    s2 = neg_c2;
+    // the chains start from the level's constants: the first link in the three-operand form (the compiler's
+    // accumulate-in-place form costs a copy of each constant per iteration)
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(s1) : "v"(Jp[0]), "v"(Ixp[0]), "v"(neg_c1));
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(s2) : "v"(Jp[0]), "v"(Iyp[0]), "v"(neg_c2));
 #pragma unroll
-    for (int j = 0; j < npairs(C); j++) {
+    for (int j = 1; j < npairs(C); j++) {
         s1 = sdot2(Jp[j], Ixp[j], s1);
         s2 = sdot2(Jp[j], Iyp[j], s2);
     }
