@@ -61,10 +61,12 @@ struct PnpJob {
     int *h_tag;
     int tag;
     const int *cnt_trk;
+    unsigned *ticket;  // "last wave of a phase" counter (self-resetting)
 };
 struct PnpBatch {
     PnpJob j[SVO_LK_MAX_JOBS];
 };
+static_assert(sizeof(PnpBatch) + 16 <= 4096, "kernel arguments are limited to 4 KB");
 
 // ---- small dense helpers (registers, static indexing) --------------------------------------
 template <int N>
@@ -335,29 +337,16 @@ struct WaveLds {
 __device__ __forceinline__ float reproj_err_sq(const double (&P)[12], const K4 &K, float X, float Y, float Z, float u,
                                                float v);
 
-__global__ __launch_bounds__(64, 4) void pnp_solve_kernel(PnpBatch batch)
+// One RANSAC iteration by one wave: sample, EPnP, the hypothesis into hyp[it], its inlier count into
+// counts[it], nmodels[it] = 1 / 0 (no model) / -1 (no sample: the sequential loop stops there).
+__device__ __forceinline__ void pnp_hypothesis(const PnpJob &job, int it, int n, WaveLds &S, int lane)
 {
-    svo_chain_priority();
-    const PnpJob &job = batch.j[blockIdx.y];
     const float *__restrict__ obj = job.obj, *__restrict__ img = job.img;
-    const int n_host = job.n_host;
-    const int *__restrict__ d_n = job.d_n;
     const K4 K = job.K;
     const uint64_t seed = job.seed;
-    const int it0 = 0, it1 = job.iterations;
-    const RansacState *__restrict__ st = job.st;
     double *__restrict__ hyp = job.hyp;
     int *__restrict__ nmodels = job.nmodels;
     int *__restrict__ counts = job.counts;
-    __shared__ WaveLds s_lds[1];
-    const int lane = threadIdx.x & 63;
-    const int it = __builtin_amdgcn_readfirstlane(it0 + blockIdx.x);  // one wave per workgroup
-    if (it >= it1)
-        return;
-    if (it0 > 0 && st->done)
-        return;
-    WaveLds &S = s_lds[0];
-    const int n = d_n ? *d_n : n_host;
     if (n < MP) {
         if (lane == 0) {
             nmodels[it] = -1;
@@ -801,6 +790,43 @@ __global__ __launch_bounds__(64, 4) void pnp_solve_kernel(PnpBatch batch)
     cnt = wave_sum_small(cnt);
     if (lane == 0)
         counts[it] = cnt;
+}
+
+// Iterations [it0, min(it1_cap, iterations)) of the RANSAC loop, one wave (= one workgroup) per iteration.
+// Two phases as in fransac.hip: the LAST wave of a phase that has a successor replays the sequential loop over
+// what has been scored so far and stores the state; the next phase's waves leave at once when the loop has
+// ended (at VO inlier ratios the adaptive bound is reached after about 15 of the 100 iterations -- all 100
+// hypotheses were 6 % of the vector instructions of a bench run).  pnp_finish_kernel replays the whole loop
+// itself, reads only iterations below the bound, and so never sees a skipped one.
+constexpr int PNP_PHASE_A = 32;
+__global__ __launch_bounds__(64, 4) void pnp_solve_kernel(PnpBatch batch, int it0, int it1_cap)
+{
+    svo_chain_priority();
+    const PnpJob &job = batch.j[blockIdx.y];
+    const int it1 = it1_cap < job.iterations ? it1_cap : job.iterations;
+    if (it0 > 0 && job.st->done)
+        return;  // the same answer in every wave of the launch
+    __shared__ WaveLds s_lds[1];
+    const int lane = threadIdx.x & 63;
+    const int it = __builtin_amdgcn_readfirstlane(it0 + blockIdx.x);
+    const int n = job.d_n ? *job.d_n : job.n_host;
+    if (it < it1)
+        pnp_hypothesis(job, it, n, s_lds[0], lane);
+    if (it1 >= job.iterations)
+        return;  // no phase follows: pnp_finish_kernel replays
+    int last = 0;
+    if (lane == 0) {
+        __threadfence();
+        last = atomicAdd(job.ticket, 1u) == gridDim.x - 1;
+    }
+    if (!__builtin_amdgcn_readfirstlane(last))
+        return;
+    if (lane == 0) {
+        *job.ticket = 0;  // ready for the next launch
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // other waves' counts, not this CU's stale lines
+        *job.st = ransac_replay<1>(job.st, it0 == 0 ? 1 : 0, it1, job.iterations, n, job.confidence, job.nmodels,
+                                   job.counts, MP);
+    }
 }
 
 // PnPRansacCallback::computeError for one correspondence
@@ -1432,6 +1458,7 @@ int svo_launch_pnp_ransac_batch(svo_ctx *ctx, int n_jobs, const svo_pnp_job *job
         j.h_tag = h.h_tag;
         j.tag = h.tag;
         j.cnt_trk = h.cnt_trk;
+        j.ticket = ctx->d_tickets + 16 + nb;  // slots 0..15: fransac.hip
         nb++;
     }
     if (nb == 0)
@@ -1440,8 +1467,11 @@ int svo_launch_pnp_ransac_batch(svo_ctx *ctx, int n_jobs, const svo_pnp_job *job
         batch.j[k] = batch.j[0];
     ScopedKernelTime tm(ctx, SVO_K_PNP);
     // single-wave workgroups: they get wave slots beside a tracking launch as soon as one frees
-    const int nblk = it_max;
-    hipLaunchKernelGGL(pnp_solve_kernel, dim3(nblk, nb), dim3(64), 0, ctx->stream, batch);  // solves AND scores
+    const int bounds[3] = {0, it_max < PNP_PHASE_A ? it_max : PNP_PHASE_A, it_max};
+    for (int ph = 0; ph < 2; ph++)
+        if (bounds[ph + 1] > bounds[ph])  // solves AND scores; the second phase usually leaves at once
+            hipLaunchKernelGGL(pnp_solve_kernel, dim3(bounds[ph + 1] - bounds[ph], nb), dim3(64), 0, ctx->stream, batch,
+                               bounds[ph], bounds[ph + 1]);
     hipLaunchKernelGGL(pnp_finish_kernel, dim3(nb), dim3(256), 0, ctx->stream, batch);
     SVO_HIP(hipGetLastError());
     return SVO_OK;
