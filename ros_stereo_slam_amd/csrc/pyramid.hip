@@ -14,9 +14,9 @@
 //               image (its own role of workgroups: no dependence on the padded level 0);
 //   2. down:    level 2 from level 1;            3. down: level 3 from level 2
 //               (one workgroup per 32x8 output tile; the (2*32+3) x (2*8+3) source tile is staged in LDS
-//               with row-contiguous loads, the separable [1 4 6 4 1] filter runs LDS -> LDS (horizontal,
-//               uint16) and LDS -> HBM (vertical, (sum+128)>>8); edge tiles read the INTERIOR of their
-//               source level through reflect-101 indices, so no level waits for a border);
+//               with row-contiguous loads, the separable [1 4 6 4 1] filter runs LDS -> LDS (down the byte
+//               columns, packed uint16) and LDS -> HBM (along the rows, (sum+128)>>8); edge tiles read the
+//               INTERIOR of their source level through reflect-101 indices, so no level waits for a border);
 //   4. finish:  the reflect-101 borders of levels 1.. and, in the same launch, the Scharr derivative
 //               levels of the pyramids that carry them (edge pixels through reflect-101 indices again,
 //               so the two roles are independent).
@@ -58,33 +58,43 @@ struct PyrBuild {
 static_assert(sizeof(PyrBuild) <= 3072, "kernel arguments are limited to 4 KB");
 
 // One 32x8 output tile of level l from level l-1 (RAW = false: the padded level; RAW = true: the raw
-// image, rows of w * C bytes without padding or alignment).
+// image, rows of w * C bytes without padding or alignment).  The (2*32+3) x (2*8+3) source tile is staged in
+// LDS with every row starting at byte 0 (misaligned source rows are shifted while they are staged), then
+//   vertical   [1 4 6 4 1] down the byte COLUMNS, for the 8 output rows only: a thread takes one dword
+//              column, five aligned dword reads, two uint16 pairs per dword and packed 16-bit arithmetic
+//              (sums <= 16 * 255): 18 vector instructions per four values, no per-byte index arithmetic;
+//   horizontal [1 4 6 4 1] along the rows of those sums (taps C apart), (sum + 128) >> 8, four output
+//              bytes per thread and store.
+// The filter is separable and the arithmetic integer, so the order of the two passes does not change a bit
+// of the result; rows first (as until round 2) filtered 19 rows of which the vertical pass used 8 outputs'
+// worth, and was 6 % of the vector instructions of a bench run.
 template <int C, bool RAW>
 __device__ __forceinline__ void down_tile(const uint8_t *__restrict__ src, int spitch, int w, int h,
                                           uint8_t *__restrict__ dst, int dpitch, int dw, int dh, int tx, int ty)
 {
-    constexpr int SDW = (SW * C + 3) / 4 + 1;  // dwords per staged row, one spare for the alignment shift
-    constexpr int SROW = SDW * 4;
+    constexpr int ND = (SW * C + 3) / 4;      // dwords of a staged row
+    constexpr int SROW = (ND + 1) * 4;        // bytes per staged row (odd dword count: rows spread over the banks)
+    constexpr int VROW = ND * 4 + 4;          // uint16 sums per row of the vertical pass's output (padded)
     __shared__ __attribute__((aligned(16))) uint8_t s_src[SH * SROW];
-    __shared__ uint16_t s_h[SH][TW * C];
-    __shared__ int s_sh[SH];  // byte offset of the tile inside each staged row
+    __shared__ __attribute__((aligned(16))) uint16_t s_v[TH][VROW];
     const int tid = threadIdx.x;
     const int ox = tx * TW, oy = ty * TH;
     const int x0 = 2 * ox - 2, y0 = 2 * oy - 2;
-    // the last dword of a staged row may reach 7 bytes past the tile: inside the padded level always;
-    // inside the raw image unless the tile ends at the very last bytes of the buffer
+    // a staged dword takes two source dwords (the shift): the furthest reaches 4 * ND + 3 bytes past the tile's
+    // first byte -- inside the padded level always; inside the raw image unless the tile ends at the very last
+    // bytes of the buffer
     const bool interior = x0 >= 0 && x0 + SW <= w && y0 >= 0 && y0 + SH <= h &&
-                          (!RAW || (size_t)(y0 + SH - 1) * spitch + (size_t)x0 * C + SROW <= (size_t)h * spitch);
+                          (!RAW || (size_t)(y0 + SH - 1) * spitch + (size_t)x0 * C + (ND + 1) * 4 + 4 <= (size_t)h * spitch);
     if (interior) {
-        // whole aligned dwords, row by row.  Padded level: 4-byte aligned rows of a pitch that is a multiple
-        // of 16, every row starts at the same shift; raw image: the shift differs from row to row.
-        for (int i = tid; i < SH * SDW; i += PB) {
-            const int r = i / SDW, d = i - r * SDW;
-            const uint8_t *row = src + (ptrdiff_t)(y0 + r) * spitch + x0 * C;
-            const int sh = (int)(reinterpret_cast<uintptr_t>(row) & 3);
-            reinterpret_cast<uint32_t *>(s_src + r * SROW)[d] = reinterpret_cast<const uint32_t *>(row - sh)[d];
-            if (d == 0)
-                s_sh[r] = sh;
+        for (int d = tid; d < ND; d += PB) {  // a thread per dword column (C = 4: 67 columns, two turns)
+            const uint8_t *col = src + (ptrdiff_t)y0 * spitch + x0 * C;
+#pragma unroll 1
+            for (int r = 0; r < SH; r++) {
+                const uint8_t *row = col + (ptrdiff_t)r * spitch;
+                const unsigned sh = (unsigned)(reinterpret_cast<uintptr_t>(row) & 3);
+                const uint32_t *p = reinterpret_cast<const uint32_t *>(row - sh) + d;
+                reinterpret_cast<uint32_t *>(s_src + r * SROW)[d] = __builtin_amdgcn_alignbyte(p[1], p[0], sh);
+            }
         }
     } else {
         for (int i = tid; i < SH * SW * C; i += PB) {
@@ -93,19 +103,36 @@ __device__ __forceinline__ void down_tile(const uint8_t *__restrict__ src, int s
             int sx = reflect101(x0 + px, w);
             int sy = reflect101(y0 + r, h);
             s_src[r * SROW + cc] = src[(size_t)sy * spitch + sx * C + ch];
-            if (cc == 0)
-                s_sh[r] = 0;
         }
     }
     __syncthreads();
-    for (int i = tid; i < SH * TW * C; i += PB) {
-        int r = i / (TW * C), cc = i - r * (TW * C);
-        int x = cc / C, ch = cc - x * C;
-        const uint8_t *sp = s_src + r * SROW + s_sh[r] + (2 * x) * C + ch;
-        s_h[r][cc] = (uint16_t)(sp[0] + 4 * sp[C] + 6 * sp[2 * C] + 4 * sp[3 * C] + sp[4 * C]);
+    typedef unsigned short ushort2v __attribute__((ext_vector_type(2)));
+    for (int d = tid; d < ND; d += PB) {
+        const uint32_t *colp = reinterpret_cast<const uint32_t *>(s_src) + d;
+#pragma unroll
+        for (int y = 0; y < TH; y++) {
+            uint32_t r[5];
+#pragma unroll
+            for (int k = 0; k < 5; k++)
+                r[k] = colp[(2 * y + k) * (SROW / 4)];
+            uint32_t out[2];
+#pragma unroll
+            for (int hh = 0; hh < 2; hh++) {
+                // bytes (2 hh, 2 hh + 1) of each row's dword as a uint16 pair
+                const unsigned sel = hh ? 0x0c030c02u : 0x0c010c00u;
+                ushort2v v[5];
+#pragma unroll
+                for (int k = 0; k < 5; k++)
+                    v[k] = __builtin_bit_cast(ushort2v, __builtin_amdgcn_perm(0u, r[k], sel));
+                const ushort2v four = {4, 4}, six = {6, 6};
+                const ushort2v acc = (v[0] + v[4]) + (v[1] + v[3]) * four + v[2] * six;
+                out[hh] = __builtin_bit_cast(uint32_t, acc);
+            }
+            *reinterpret_cast<uint2 *>(&s_v[y][4 * d]) = make_uint2(out[0], out[1]);
+        }
     }
     __syncthreads();
-    // vertical pass; a thread produces four consecutive bytes of an output row = one aligned dword
+    // horizontal pass; a thread produces four consecutive bytes of an output row = one aligned dword
     // (ox * C and dpitch are multiples of 4), bytes beyond the level's width are not stored
     for (int i = tid; i < TH * (TW * C / 4); i += PB) {
         const int y = i / (TW * C / 4), q = i - y * (TW * C / 4);
@@ -115,19 +142,20 @@ __device__ __forceinline__ void down_tile(const uint8_t *__restrict__ src, int s
         uint32_t out = 0;
         int nvalid = 0;
 #pragma unroll
-        for (int b = 0; b < 4; b++) {
-            const int cc = 4 * q + b;
-            const int v = s_h[2 * y][cc] + 4 * s_h[2 * y + 1][cc] + 6 * s_h[2 * y + 2][cc] + 4 * s_h[2 * y + 3][cc] +
-                          s_h[2 * y + 4][cc];
-            out |= (uint32_t)((v + 128) >> 8) << (8 * b);
-            nvalid += (ox + cc / C) < dw ? 1 : 0;
+        for (int bb = 0; bb < 4; bb++) {
+            const int cc = 4 * q + bb;
+            const int x = cc / C, ch = cc - x * C;
+            const uint16_t *sp = &s_v[y][2 * x * C + ch];  // source pixel 2x - 2 of the row, channel ch
+            const int v = sp[0] + 4 * sp[C] + 6 * sp[2 * C] + 4 * sp[3 * C] + sp[4 * C];
+            out |= (uint32_t)((v + 128) >> 8) << (8 * bb);
+            nvalid += (ox + x) < dw ? 1 : 0;
         }
         uint8_t *drow = dst + (size_t)Y * dpitch + ox * C + 4 * q;
         if (nvalid == 4)
             *reinterpret_cast<uint32_t *>(drow) = out;
         else
-            for (int b = 0; b < nvalid; b++)
-                drow[b] = (uint8_t)(out >> (8 * b));
+            for (int bb = 0; bb < nvalid; bb++)
+                drow[bb] = (uint8_t)(out >> (8 * bb));
     }
 }
 
