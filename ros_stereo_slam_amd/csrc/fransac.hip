@@ -371,7 +371,10 @@ __device__ __forceinline__ float f_error(const double (&F)[9], float x1, float y
 
 // One phase of the RANSAC loop: iterations [it0, min(it1_cap, max_iters)), one wave per iteration (see the
 // file header).  `final_phase`: no launch follows, so the last wave finishes the problem whatever the state.
-__global__ __launch_bounds__(64, 5) void fr_ransac_kernel(FrBatch batch, int it0, int it1_cap, int final_phase)
+// LEAN: capped at 96 VGPRs (with spills) so that a wave starts beside four tracking waves of another context on
+// its SIMD -- the lock-step groups; a lone problem takes the 128-VGPR build.
+template <bool LEAN>
+__global__ __launch_bounds__(64, LEAN ? 5 : 4) void fr_ransac_kernel(FrBatch batch, int it0, int it1_cap, int final_phase)
 {
     svo_chain_priority();
     const FrJob &job = batch.j[blockIdx.y];
@@ -592,8 +595,12 @@ int svo_launch_fransac_batch(svo_ctx *ctx, int n_jobs, const svo_fransac_job *jo
         if (it1 <= it0)
             continue;
         const int iters = it1 - it0;
-        hipLaunchKernelGGL(fr_ransac_kernel, dim3(iters < PHASE_WAVES ? iters : PHASE_WAVES, nb), dim3(64), 0, ctx->stream,
-                           batch, it0, it1, it1 >= it_max ? 1 : 0);
+        if (nb > 1)
+            hipLaunchKernelGGL(fr_ransac_kernel<true>, dim3(iters < PHASE_WAVES ? iters : PHASE_WAVES, nb), dim3(64), 0,
+                               ctx->stream, batch, it0, it1, it1 >= it_max ? 1 : 0);
+        else
+            hipLaunchKernelGGL(fr_ransac_kernel<false>, dim3(iters < PHASE_WAVES ? iters : PHASE_WAVES, nb), dim3(64), 0,
+                               ctx->stream, batch, it0, it1, it1 >= it_max ? 1 : 0);
     }
     SVO_HIP(hipGetLastError());
     return SVO_OK;
