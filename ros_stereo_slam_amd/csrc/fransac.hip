@@ -570,7 +570,7 @@ int svo_launch_fransac_batch(svo_ctx *ctx, int n_jobs, const svo_fransac_job *jo
         j.nmodels = ib + 16;
         j.counts = j.nmodels + mi;
         j.Fm = ctx->w_a.as<double>() + f_stride * nb;
-        j.ticket = ctx->d_tickets + nb;  // slots 0..3: fr_score of job 0..3
+        j.ticket = ctx->d_tickets + nb;  // slots 0..15 (16..31: pnp.hip)
         j.mask = h.mask;
         j.Fbest = h.d_F;
         j.out_count = h.d_count;

@@ -243,7 +243,7 @@ __device__ __forceinline__ void fill_border_row(uint8_t *__restrict__ level, int
 }
 
 // Scharr derivatives of four consecutive channel-bytes of row y = one aligned 16-byte store of packed
-// (dx | dy << 16):
+// (4 dx | 4 dy << 16):
 //   S(x) = 3 p(x, y-1) + 10 p(x, y) + 3 p(x, y+1),   V(x) = p(x, y+1) - p(x, y-1)
 //   dx(x) = S(x+1) - S(x-1),                           dy(x) = 3 V(x-1) + 10 V(x) + 3 V(x+1)
 // -- bit for bit what lk.hip derived per keypoint and level before (each pixel sat in ~5 keypoint
@@ -297,7 +297,7 @@ __device__ __forceinline__ void scharr_row(const uint8_t *__restrict__ lvl, int 
         // stored times 4 (|4 d| <= 16320 fits int16): the tracker's descale by 2^14 of the interpolated
         // derivative then is "the high half of the sum", see lk.hip
         const int dx = 4 * (S[j + 2 * C] - S[j]), dy = 12 * (V[j] + V[j + 2 * C]) + 40 * V[j + C];
-        out[j] = (int)__builtin_amdgcn_perm((unsigned)dy, (unsigned)dx, 0x05040100u);  // (dx & 0xffff) | (dy << 16)
+        out[j] = (int)__builtin_amdgcn_perm((unsigned)dy, (unsigned)dx, 0x05040100u);  // (4 dx & 0xffff) | (4 dy << 16)
     }
     int *drow = reinterpret_cast<int *>(reinterpret_cast<uint8_t *>(dlvl) + (ptrdiff_t)y * dpitch);
     const int rem = w * C - 4 * q;  // elements of this row from 4q on

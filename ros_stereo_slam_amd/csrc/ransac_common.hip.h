@@ -62,7 +62,7 @@ __device__ __forceinline__ int wave_sum_small(int v)
 }
 
 // Replays the SEQUENTIAL RANSAC loop over iterations [st->next_iter, it_end) (called by one
-// thread: the last workgroup of fr_score_kernel, thread 0 of pnp_finish_kernel): first-best-wins,
+// thread: the last wave of fr_ransac_kernel / of pnp_solve_kernel's first phase, thread 0 of pnp_finish_kernel): first-best-wins,
 // adaptive iteration bound, stop at a failed sample -- so that evaluating all hypotheses
 // concurrently gives exactly the serial algorithm's answer.  MPI = models per iteration slot
 // (nmodels[it] in -1 (sampling failed) .. MPI, counts[it * MPI + k]).

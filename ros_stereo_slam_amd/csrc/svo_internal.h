@@ -66,7 +66,7 @@ struct svo_pyramid {
     size_t bytes;
     PyrDev dev;
     // Scharr derivative levels (what cv::calcOpticalFlowPyrLK materialises per call for its first image):
-    // packed (dx & 0xffff) | (dy << 16) per pixel and channel, every level with a ZERO border of
+    // packed (4 dx & 0xffff) | (4 dy << 16) per pixel and channel (times 4: lk.hip), every level with a ZERO border of
     // SVO_DERIV_PAD pixels (the reference pads its derivative buffer with zeros) and a 16-byte-aligned
     // pitch.  Filled when the levels are built if want_deriv; LK needs them for its FIRST pyramid only.
     int *dbase = nullptr;
