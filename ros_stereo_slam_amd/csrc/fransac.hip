@@ -371,11 +371,15 @@ __device__ __forceinline__ float f_error(const double (&F)[9], float x1, float y
 
 // One phase of the RANSAC loop: iterations [it0, min(it1_cap, max_iters)), one wave per iteration (see the
 // file header).  `final_phase`: no launch follows, so the last wave finishes the problem whatever the state.
-// LEAN: capped at 96 VGPRs (with spills) so that a wave starts beside four tracking waves of another context on
-// its SIMD -- the lock-step groups; a lone problem takes the 128-VGPR build.
+// LEAN: the lock-step groups -- single-wave workgroups capped at 96 VGPRs (with spills), so that a wave starts beside
+// four tracking waves of another context on its SIMD.  !LEAN: a lone problem has the chip to itself, its 64
+// iterations would leave 15 of 16 SIMDs idle: FOUR waves per iteration (wave 0 solves, all four share the scoring
+// pass, and the finishing workgroup's four waves share the mask / compaction pass), 128-VGPR build.
 template <bool LEAN>
-__global__ __launch_bounds__(64, LEAN ? 5 : 4) void fr_ransac_kernel(FrBatch batch, int it0, int it1_cap, int final_phase)
+__global__ __launch_bounds__(LEAN ? 64 : 256, LEAN ? 5 : 4) void fr_ransac_kernel(FrBatch batch, int it0, int it1_cap,
+                                                                                   int final_phase)
 {
+    constexpr int NW = LEAN ? 1 : 4;  // waves per workgroup
     svo_chain_priority();
     const FrJob &job = batch.j[blockIdx.y];
     const float2 *__restrict__ p1 = reinterpret_cast<const float2 *>(job.p1);
@@ -390,37 +394,41 @@ __global__ __launch_bounds__(64, LEAN ? 5 : 4) void fr_ransac_kernel(FrBatch bat
     const float thr = job.thr;
     int *counts = job.counts;
     unsigned *ticket = job.ticket;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int pt0 = 4 * (int)threadIdx.x;  // this thread's first pair of a step; a step covers 256 * NW pairs
+    constexpr int STEP = 256 * NW;
     __shared__ double sA[63], sV[18], sF[27];
-    __shared__ int sPerm[9], s_nm;
+    __shared__ int sPerm[9], s_nm, s_cnt[NW][3], s_last;
     if (it0 > 0 && st->done)  // the loop ended in an earlier phase (the same answer in every wave of the launch)
         return;
     const int n = d_n ? *d_n : n_host;
     const bool vec_ok = ((reinterpret_cast<uintptr_t>(p1) | reinterpret_cast<uintptr_t>(p2)) & 15) == 0;
     for (int it = it0 + (int)blockIdx.x; it < it1; it += gridDim.x) {
-        const int nm_l0 = fr_solve_wave(job.p1, job.p2, n, job.seed, it, sA, sV, sPerm, sF, lane);
-        if (lane == 0) {
-            const int nm = nm_l0;
-            s_nm = nm;
-            nmodels[it] = nm;
-            for (int k = 0; k < 3; k++)
-                if (k < nm)
-                    for (int i = 0; i < 9; i++)
-                        Fm[((size_t)it * 3 + k) * 9 + i] = sF[k * 9 + i];  // the finishing wave reads the winner's
+        if (wave == 0) {
+            const int nm_l0 = fr_solve_wave(job.p1, job.p2, n, job.seed, it, sA, sV, sPerm, sF, lane);
+            if (lane == 0) {
+                const int nm = nm_l0;
+                s_nm = nm;
+                nmodels[it] = nm;
+                for (int k = 0; k < 3; k++)
+                    if (k < nm)
+                        for (int i = 0; i < 9; i++)
+                            Fm[((size_t)it * 3 + k) * 9 + i] = sF[k * 9 + i];  // the finishing wave reads the winner's
+            }
         }
         __syncthreads();
         const int nm = s_nm;
         // Score the (up to three) models in ONE pass over the correspondences.  The loop is bound by the latency
-        // of its loads (one wave, nothing else to switch to), so a lane takes FOUR consecutive pairs per step
-        // with 16-byte loads and requests the next step's before it uses this step's; the model being
-        // evaluated sits in scalar registers.
+        // of its loads (nothing else to switch to), so a lane takes FOUR consecutive pairs per step with 16-byte
+        // loads and requests the next step's before it uses this step's; the model being evaluated sits in
+        // scalar registers.
         int c0 = 0, c1 = 0, c2 = 0;
         if (nm > 0) {
             Quad cur, nxt;
-            load_quad(cur, p1, p2, 4 * lane, n, vec_ok);
-            for (int base = 4 * lane; base < n; base += 256) {
-                if (base + 256 < n)
-                    load_quad(nxt, p1, p2, base + 256, n, vec_ok);
+            load_quad(cur, p1, p2, pt0, n, vec_ok);
+            for (int base = pt0; base < n; base += STEP) {
+                if (base + STEP < n)
+                    load_quad(nxt, p1, p2, base + STEP, n, vec_ok);
                 for (int k = 0; k < nm; k++) {
                     double F[9];
 #pragma unroll
@@ -440,25 +448,39 @@ __global__ __launch_bounds__(64, LEAN ? 5 : 4) void fr_ransac_kernel(FrBatch bat
             c1 = nm > 1 ? wave_sum_small(c1) : 0;
             c2 = nm > 2 ? wave_sum_small(c2) : 0;
         }
-        if (lane == 0) {
+        if (NW > 1) {
+            if (lane == 0) {
+                s_cnt[wave][0] = c0;
+                s_cnt[wave][1] = c1;
+                s_cnt[wave][2] = c2;
+            }
+            __syncthreads();
+            c0 = c1 = c2 = 0;
+#pragma unroll
+            for (int w = 0; w < NW; w++) {
+                c0 += s_cnt[w][0];
+                c1 += s_cnt[w][1];
+                c2 += s_cnt[w][2];
+            }
+        }
+        if (threadIdx.x == 0) {
             counts[it * 3 + 0] = c0;
             counts[it * 3 + 1] = c1;
             counts[it * 3 + 2] = c2;
         }
-        __syncthreads();  // sF / s_nm are rewritten by the next iteration of this wave
+        __syncthreads();  // sF / s_nm / s_cnt are rewritten by the next iteration of this workgroup
     }
-    // every wave takes a ticket once its counts are out; the holder of the last one sees them all
-    int last = 0;
-    if (lane == 0) {
+    // every workgroup takes a ticket once its counts are out; the holder of the last one sees them all
+    if (threadIdx.x == 0) {
         __threadfence();
         const unsigned t = atomicAdd(ticket, 1u);
-        last = t == gridDim.x - 1;
+        s_last = t == gridDim.x - 1;
     }
-    last = __builtin_amdgcn_readfirstlane(last);
-    if (!last)
+    __syncthreads();
+    if (!s_last)
         return;
     __shared__ RansacState s_state;
-    if (lane == 0) {
+    if (threadIdx.x == 0) {
         *ticket = 0;  // ready for the next launch
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // other waves' counts, not this CU's stale lines
         const RansacState r = ransac_replay<3>(st, it0 == 0 ? 1 : 0, it1, max_iters, n, job.confidence, nmodels, counts, M);
@@ -468,7 +490,7 @@ __global__ __launch_bounds__(64, LEAN ? 5 : 4) void fr_ransac_kernel(FrBatch bat
     __syncthreads();
     const RansacState s = s_state;
     if (!s.done && !final_phase)
-        return;  // the next phase's last wave finishes
+        return;  // the next phase's last workgroup finishes
     // ---- the winning model: mask (cv: computeError <= thr on every correspondence), model, counts ----
     uint8_t *__restrict__ mask = job.mask;
     const bool have = s.best_iter >= 0 && s.best_count > 0;
@@ -476,7 +498,7 @@ __global__ __launch_bounds__(64, LEAN ? 5 : 4) void fr_ransac_kernel(FrBatch bat
 #pragma unroll
     for (int k = 0; k < 9; k++)
         F[k] = have ? Fm[((size_t)s.best_iter * 3 + s.best_model) * 9 + k] : 0.;
-    if (lane == 0) {
+    if (threadIdx.x == 0) {
         if (job.out_count)
             *job.out_count = have ? s.best_count : 0;
         if (job.out_iters)
@@ -486,13 +508,14 @@ __global__ __launch_bounds__(64, LEAN ? 5 : 4) void fr_ransac_kernel(FrBatch bat
                 job.Fbest[k] = F[k];
     }
     const bool compacting = job.c_in[0] != nullptr;
+    __shared__ int s_kept[NW];
     int pos0 = 0;
     Quad cur, nxt;
-    load_quad(cur, p1, p2, 4 * lane, n, vec_ok);
-    for (int start = 0; start < n_host; start += 256) {  // n_host: the capacity of the mask
-        const int base = start + 4 * lane;
-        if (base + 256 < n)  // the next four pairs are on their way while these are judged
-            load_quad(nxt, p1, p2, base + 256, n, vec_ok);
+    load_quad(cur, p1, p2, pt0, n, vec_ok);
+    for (int start = 0; start < n_host; start += STEP) {  // n_host: the capacity of the mask
+        const int base = start + pt0;
+        if (base + STEP < n)  // the next four pairs are on their way while these are judged
+            load_quad(nxt, p1, p2, base + STEP, n, vec_ok);
         bool keep[4];
         unsigned long long bal[4];
         int before = 0;  // kept entries of lower lanes in this step (a lane's four entries are consecutive)
@@ -505,7 +528,21 @@ __global__ __launch_bounds__(64, LEAN ? 5 : 4) void fr_ransac_kernel(FrBatch bat
             before += __popcll(bal[q] & ((1ull << lane) - 1ull));
         }
         if (compacting) {  // what compact_kernel does with this mask, in the same pass (order kept)
-            int pos = pos0 + before;
+            const int mine = __popcll(bal[0]) + __popcll(bal[1]) + __popcll(bal[2]) + __popcll(bal[3]);
+            int lower = 0, all = mine;  // kept by the waves below this one / by the whole workgroup in this step
+            if (NW > 1) {
+                if (lane == 0)
+                    s_kept[wave] = mine;
+                __syncthreads();
+                all = 0;
+#pragma unroll
+                for (int w = 0; w < NW; w++) {
+                    lower += w < wave ? s_kept[w] : 0;
+                    all += s_kept[w];
+                }
+                __syncthreads();  // s_kept is rewritten by the next step
+            }
+            int pos = pos0 + lower + before;
 #pragma unroll
             for (int q = 0; q < 4; q++)
                 if (keep[q]) {
@@ -519,11 +556,11 @@ __global__ __launch_bounds__(64, LEAN ? 5 : 4) void fr_ransac_kernel(FrBatch bat
                         }
                     pos++;
                 }
-            pos0 += __popcll(bal[0]) + __popcll(bal[1]) + __popcll(bal[2]) + __popcll(bal[3]);
+            pos0 += all;
         }
         cur = nxt;
     }
-    if (compacting && job.c_count && lane == 0)
+    if (compacting && job.c_count && threadIdx.x == 0)
         *job.c_count = pos0;
 }
 
@@ -599,7 +636,7 @@ int svo_launch_fransac_batch(svo_ctx *ctx, int n_jobs, const svo_fransac_job *jo
             hipLaunchKernelGGL(fr_ransac_kernel<true>, dim3(iters < PHASE_WAVES ? iters : PHASE_WAVES, nb), dim3(64), 0,
                                ctx->stream, batch, it0, it1, it1 >= it_max ? 1 : 0);
         else
-            hipLaunchKernelGGL(fr_ransac_kernel<false>, dim3(iters < PHASE_WAVES ? iters : PHASE_WAVES, nb), dim3(64), 0,
+            hipLaunchKernelGGL(fr_ransac_kernel<false>, dim3(iters < PHASE_WAVES ? iters : PHASE_WAVES, nb), dim3(256), 0,
                                ctx->stream, batch, it0, it1, it1 >= it_max ? 1 : 0);
     }
     SVO_HIP(hipGetLastError());

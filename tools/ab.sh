@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of library variants on ONE GPU box (boxes differ by a few percent, runs on one box by about one):
-#   tools/ab.sh ROUNDS name1 name2 ...   with the variants built as ab/lib_<name>.so (git-ignored scratch)
+#   [BENCH_FLAGS="..."] tools/ab.sh ROUNDS name1 name2 ...   with the variants built as ab/lib_<name>.so (git-ignored scratch)
 # Every round runs the default bench once per variant, alternating; prints frames/s per run and the medians.
 cd "$GRAFT_REPO_ROOT" || exit 1
 ROUNDS=$1; shift
@@ -9,7 +9,7 @@ cp ros_stereo_slam_amd/libsvo_hip.so /tmp/libsvo_saved.so
 for r in $(seq 1 $ROUNDS); do
   for v in "$@"; do
     cp ab/lib_$v.so ros_stereo_slam_amd/libsvo_hip.so
-    timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > gpurun_out/ab/${v}_$r.json 2> gpurun_out/ab/${v}_$r.err || { echo "$v round $r failed"; cp /tmp/libsvo_saved.so ros_stereo_slam_amd/libsvo_hip.so; exit 1; }
+    timeout -k 10 300 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras $BENCH_FLAGS > gpurun_out/ab/${v}_$r.json 2> gpurun_out/ab/${v}_$r.err || { echo "$v round $r failed"; cp /tmp/libsvo_saved.so ros_stereo_slam_amd/libsvo_hip.so; exit 1; }
     python3 -c "
 import json,sys
 d=json.loads(open('gpurun_out/ab/${v}_$r.json').read().strip().splitlines()[-1])
