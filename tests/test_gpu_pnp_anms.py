@@ -37,6 +37,19 @@ def test_pnp_ransac_matches_oracle(ctx, orc, seed, thr, conf):
     assert len(np.setdiff1d(ginl, gt)) <= (0 if thr == 1.0 else 30)
 
 
+@pytest.mark.parametrize("n_out,seed", [(680, 4), (900, 7)])
+def test_pnp_ransac_runs_its_second_phase(ctx, orc, n_out, seed):
+    """Inlier ratios of 0.55 / 0.40: the adaptive bound stays above the 32 iterations of the first phase of the
+    hypothesis kernel, so its last wave hands over to the second launch (the usual VO case ends in the first)."""
+    X, x, gt = _noisy(1500, n_out, seed)
+    gc, grv, gtv, ginl, git = ctx.pnp_ransac(X, x, K4, seed=seed)
+    oc, orv, otv, oinl, oit = orc.pnp_ransac(X, x, K4, seed=seed)
+    assert git == oit and git > 32, (git, oit)
+    assert len(np.setxor1d(ginl, oinl)) <= 2
+    assert np.abs(grv - orv).max() < 1e-6 and np.abs(gtv - otv).max() < 1e-5
+    assert len(np.setdiff1d(ginl, gt)) == 0
+
+
 def test_pnp_hypotheses_agree_with_oracle(ctx, orc):
     """With a single RANSAC iteration the result is hypothesis 0 refined over its inliers."""
     X, x, gt = _noisy(800, 0, 9, noise=0.0)
