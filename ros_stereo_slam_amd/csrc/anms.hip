@@ -52,11 +52,12 @@ struct AnmsBatch {
 // and compared against all KPW of them (an eighth of the loads), and a launch has an eighth of the
 // waves -- a wave per keypoint was 35 k waves per launch, every one of which queued for a wave slot
 // beside the tracking launches of the other contexts.
-constexpr int KPW = 8;
+constexpr int KPW_GROUP = 8;  // lock-step groups
+constexpr int KPW_LONE = 2;   // a lone problem has the chip to itself: four times the waves, a quarter of the work each
 
 // order[rank] = i, rank = #keypoints sorting before i (response descending, index ascending);
 // also emits the sorted (x, y, response) triples the radius pass streams through.
-__global__ __launch_bounds__(64) void anms_rank_kernel(AnmsBatch batch, int n)
+template <int KPW> __global__ __launch_bounds__(64) void anms_rank_kernel(AnmsBatch batch, int n)
 {
     svo_chain_priority();
     const AnmsJob &job = batch.j[blockIdx.y];
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(64) void anms_rank_kernel(AnmsBatch batch, int n)
 }
 
 // squared suppression radius of the s-th sorted keypoint (DBL_MAX when nothing dominates it)
-__global__ __launch_bounds__(64) void anms_radius_kernel(AnmsBatch batch, int n)
+template <int KPW> __global__ __launch_bounds__(64) void anms_radius_kernel(AnmsBatch batch, int n)
 {
     svo_chain_priority();
     const float4 *__restrict__ sorted = batch.j[blockIdx.y].sorted;
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(64) void anms_radius_kernel(AnmsBatch batch, int n)
 }
 
 // decision radius = the (keep+1)-th largest radius
-__global__ __launch_bounds__(64) void anms_decide_kernel(AnmsBatch batch, int n, int keep)
+template <int KPW> __global__ __launch_bounds__(64) void anms_decide_kernel(AnmsBatch batch, int n, int keep)
 {
     svo_chain_priority();
     const double *__restrict__ radius_sq = batch.j[blockIdx.y].radius;
@@ -321,8 +322,13 @@ int svo_launch_anms_batch(svo_ctx *ctx, int k, const float *const *xy, const flo
     }
     // single-wave workgroups: beside a tracking launch (single-wave workgroups that take every freed wave
     // slot at once) a multi-wave workgroup waits until one CU has a slot free on several SIMDs together
-    const dim3 wgrid((n + KPW - 1) / KPW, k), block(64);
-    hipLaunchKernelGGL(anms_rank_kernel, wgrid, block, 0, ctx->stream, batch, n);
+    const bool lone = k == 1;
+    const int kpw = lone ? KPW_LONE : KPW_GROUP;
+    const dim3 wgrid((n + kpw - 1) / kpw, k), block(64);
+    if (lone)
+        hipLaunchKernelGGL(anms_rank_kernel<KPW_LONE>, wgrid, block, 0, ctx->stream, batch, n);
+    else
+        hipLaunchKernelGGL(anms_rank_kernel<KPW_GROUP>, wgrid, block, 0, ctx->stream, batch, n);
     if (n <= keep) {
         // everything is kept, in sorted order
         for (int a = 0; a < k; a++) {
@@ -334,8 +340,13 @@ int svo_launch_anms_batch(svo_ctx *ctx, int k, const float *const *xy, const flo
         SVO_HIP(hipGetLastError());
         return SVO_OK;
     }
-    hipLaunchKernelGGL(anms_radius_kernel, wgrid, block, 0, ctx->stream, batch, n);
-    hipLaunchKernelGGL(anms_decide_kernel, wgrid, block, 0, ctx->stream, batch, n, keep);
+    if (lone) {
+        hipLaunchKernelGGL(anms_radius_kernel<KPW_LONE>, wgrid, block, 0, ctx->stream, batch, n);
+        hipLaunchKernelGGL(anms_decide_kernel<KPW_LONE>, wgrid, block, 0, ctx->stream, batch, n, keep);
+    } else {
+        hipLaunchKernelGGL(anms_radius_kernel<KPW_GROUP>, wgrid, block, 0, ctx->stream, batch, n);
+        hipLaunchKernelGGL(anms_decide_kernel<KPW_GROUP>, wgrid, block, 0, ctx->stream, batch, n, keep);
+    }
     hipLaunchKernelGGL(anms_gather_kernel, dim3(k), dim3(1024), 0, ctx->stream, batch, n);
     SVO_HIP(hipGetLastError());
     return SVO_OK;
