@@ -97,12 +97,24 @@ __device__ __forceinline__ void down_tile(const uint8_t *__restrict__ src, int s
             }
         }
     } else {
-        for (int i = tid; i < SH * SW * C; i += PB) {
-            int r = i / (SW * C), cc = i - r * (SW * C);
-            int px = cc / C, ch = cc - px * C;
-            int sx = reflect101(x0 + px, w);
-            int sy = reflect101(y0 + r, h);
-            s_src[r * SROW + cc] = src[(size_t)sy * spitch + sx * C + ch];
+        // an edge tile (at the small levels most tiles are): the same thread-per-dword-column shape, the four
+        // source byte offsets of the column through reflect-101 once for all rows, the row index per row.  (A
+        // byte per thread and turn with a division and a reflection each was 60 dependent turns: 20 us for a
+        // workgroup with 2 us of filter work, and the launch lasts as long as its slowest workgroup.)
+        for (int d = tid; d < ND; d += PB) {
+            int sx[4];
+#pragma unroll
+            for (int bb = 0; bb < 4; bb++) {
+                const int cc = min(4 * d + bb, SW * C - 1);  // the row's spare bytes repeat its last one
+                const int px = cc / C, ch = cc - px * C;
+                sx[bb] = reflect101(x0 + px, w) * C + ch;
+            }
+#pragma unroll 4
+            for (int r = 0; r < SH; r++) {
+                const uint8_t *row = src + (size_t)reflect101(y0 + r, h) * spitch;
+                reinterpret_cast<uint32_t *>(s_src + r * SROW)[d] =
+                    (uint32_t)row[sx[0]] | ((uint32_t)row[sx[1]] << 8) | ((uint32_t)row[sx[2]] << 16) | ((uint32_t)row[sx[3]] << 24);
+            }
         }
     }
     __syncthreads();
