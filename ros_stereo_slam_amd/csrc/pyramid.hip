@@ -261,15 +261,28 @@ __device__ __forceinline__ void fill_border_row(uint8_t *__restrict__ level, int
 // -- bit for bit what lk.hip derived per keypoint and level before (each pixel sat in ~5 keypoint
 // tiles per level; that Scharr tile was 17 % of the tracker's VALU instructions).  Image edges: rows and
 // pixels outside the image are their reflect-101 images (the level's border may not be written yet).
+// `edge_off`: for a quad at the left or right end of the row (scharr_edge), the row offsets of the window's 12
+// channel-bytes through reflect-101 -- computed ONCE per thread for all its rows (per row and byte they made the
+// one thread of a workgroup that owns the row's end take 8 x 400 instructions: as long as the rest of the launch).
+template <int C> __device__ __forceinline__ bool scharr_edge(int w, int q) { return q == 0 || 4 * q + 4 + C > w * C; }
+template <int C> __device__ __forceinline__ void scharr_edge_offsets(int w, int q, int (&off)[12])
+{
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        const int cb = 4 * q - 4 + i;                                // channel-byte index in the row
+        const int px = cb >= 0 ? cb / C : -((-cb + C - 1) / C);      // floor division
+        off[i] = reflect101(px, w) * C + (cb - px * C);
+    }
+}
+
 template <int C>
 __device__ __forceinline__ void scharr_row(const uint8_t *__restrict__ lvl, int *__restrict__ dlvl, int pitch, int dpitch,
-                                           int w, int h, int y, int q)
+                                           int w, int h, int y, int q, const int (&edge_off)[12])
 {
     const uint8_t *rows[3] = {lvl + (ptrdiff_t)reflect101(y - 1, h) * pitch, lvl + (ptrdiff_t)y * pitch,
                               lvl + (ptrdiff_t)reflect101(y + 1, h) * pitch};  // 4-byte aligned (pad * C and pitch are)
     uint32_t win[3][3];  // bytes 4q-4 .. 4q+7 of rows y-1, y, y+1
-    const bool edge = q == 0 || 4 * q + 4 + C > w * C;
-    if (!edge) {
+    if (!scharr_edge<C>(w, q)) {
 #pragma unroll
         for (int r = 0; r < 3; r++) {
             const uint32_t *p = reinterpret_cast<const uint32_t *>(rows[r]) + (q - 1);
@@ -284,12 +297,8 @@ __device__ __forceinline__ void scharr_row(const uint8_t *__restrict__ lvl, int 
             for (int d = 0; d < 3; d++) {
                 uint32_t v = 0;
 #pragma unroll
-                for (int bb = 0; bb < 4; bb++) {
-                    const int cb = 4 * q - 4 + 4 * d + bb;                       // channel-byte index in the row
-                    const int px = cb >= 0 ? cb / C : -((-cb + C - 1) / C);      // floor division
-                    const int ch = cb - px * C;
-                    v |= (uint32_t)rows[r][reflect101(px, w) * C + ch] << (8 * bb);
-                }
+                for (int bb = 0; bb < 4; bb++)
+                    v |= (uint32_t)rows[r][edge_off[4 * d + bb]] << (8 * bb);
                 win[r][d] = v;
             }
     }
@@ -352,8 +361,11 @@ template <int C> __global__ __launch_bounds__(PB) void pyr_finish_kernel(PyrBuil
     const int q = blockIdx.x * PB + threadIdx.x;  // quad of channel-bytes 4q .. 4q+3 of the row
     if (4 * q >= b.w[l] * C)
         return;
+    int edge_off[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (scharr_edge<C>(b.w[l], q))
+        scharr_edge_offsets<C>(b.w[l], q, edge_off);
     for (int y = (by - plan.scharr_y0[l]) * ROWS_PER_BLOCK, yend = min(y + ROWS_PER_BLOCK, b.h[l]); y < yend; y++)
-        scharr_row<C>(b.lvl[job][l], b.dlvl[job] + b.doff[l], b.pitch[l], b.dpitch[l], b.w[l], b.h[l], y, q);
+        scharr_row<C>(b.lvl[job][l], b.dlvl[job] + b.doff[l], b.pitch[l], b.dpitch[l], b.w[l], b.h[l], y, q, edge_off);
 }
 
 }  // namespace
