@@ -302,23 +302,38 @@ __device__ __forceinline__ void scharr_row(const uint8_t *__restrict__ lvl, int 
                 win[r][d] = v;
             }
     }
-    auto byte_at = [&](int r, int pos) -> int { return (int)((win[r][pos >> 2] >> (8 * (pos & 3))) & 0xffu); };
-    // columns 4-C .. 7+C of the 12-byte window
-    int S[4 + 2 * C], V[4 + 2 * C];
+    // Packed 16-bit arithmetic over the window's 12 byte columns (pos 0..11 = channel-bytes 4q-4 .. 4q+7), two
+    // columns per register: S = 3 (a + c) + 10 b <= 4080 and V = c - a fit int16, so do the outputs times 4.
+    typedef short short2v __attribute__((ext_vector_type(2)));
+    short2v S[6], V[6];  // [k] = columns (2k, 2k+1)
 #pragma unroll
-    for (int i = 0; i < 4 + 2 * C; i++) {
-        const int pos = 4 - C + i;
-        const int a = byte_at(0, pos), bq = byte_at(1, pos), c = byte_at(2, pos);
-        S[i] = 3 * (a + c) + 10 * bq;
-        V[i] = c - a;
+    for (int k = 0; k < 6; k++) {
+        const unsigned sel = (k & 1) ? 0x0c030c02u : 0x0c010c00u;  // bytes (2, 3) or (0, 1) of the dword, zero-extended
+        const short2v a = __builtin_bit_cast(short2v, __builtin_amdgcn_perm(0u, win[0][k >> 1], sel));
+        const short2v bq = __builtin_bit_cast(short2v, __builtin_amdgcn_perm(0u, win[1][k >> 1], sel));
+        const short2v c = __builtin_bit_cast(short2v, __builtin_amdgcn_perm(0u, win[2][k >> 1], sel));
+        const short2v three = {3, 3}, ten = {10, 10};
+        S[k] = (a + c) * three + bq * ten;
+        V[k] = c - a;
     }
+    // the pair of columns (pos, pos + 1): a register as it is for an even pos, halves of two neighbours otherwise
+    auto pair_at = [](const short2v (&P)[6], int pos) -> short2v {
+        if ((pos & 1) == 0)
+            return P[pos >> 1];
+        return __builtin_bit_cast(short2v, __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, P[(pos >> 1) + 1]),
+                                                                 __builtin_bit_cast(unsigned, P[pos >> 1]), 0x05040302u));
+    };
     int out[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < 4; j += 2) {
         // stored times 4 (|4 d| <= 16320 fits int16): the tracker's descale by 2^14 of the interpolated
         // derivative then is "the high half of the sum", see lk.hip
-        const int dx = 4 * (S[j + 2 * C] - S[j]), dy = 12 * (V[j] + V[j + 2 * C]) + 40 * V[j + C];
-        out[j] = (int)__builtin_amdgcn_perm((unsigned)dy, (unsigned)dx, 0x05040100u);  // (4 dx & 0xffff) | (4 dy << 16)
+        const short2v four = {4, 4}, twelve = {12, 12}, forty = {40, 40};
+        const short2v dx = (pair_at(S, 4 + C + j) - pair_at(S, 4 - C + j)) * four;
+        const short2v dy = (pair_at(V, 4 - C + j) + pair_at(V, 4 + C + j)) * twelve + pair_at(V, 4 + j) * forty;
+        const unsigned ux = __builtin_bit_cast(unsigned, dx), uy = __builtin_bit_cast(unsigned, dy);
+        out[j] = (int)__builtin_amdgcn_perm(uy, ux, 0x05040100u);      // (4 dx_j & 0xffff) | (4 dy_j << 16)
+        out[j + 1] = (int)__builtin_amdgcn_perm(uy, ux, 0x07060302u);  // the same of column j + 1
     }
     int *drow = reinterpret_cast<int *>(reinterpret_cast<uint8_t *>(dlvl) + (ptrdiff_t)y * dpitch);
     const int rem = w * C - 4 * q;  // elements of this row from 4q on
