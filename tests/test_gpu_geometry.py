@@ -83,6 +83,37 @@ def test_fransac_full_size(ctx, orc, n, n_out, thr):
     assert (gmask.astype(bool) & gt).sum() >= 0.85 * gt.sum()
 
 
+@pytest.mark.parametrize("n,skew", [(4099, 1), (2586, 0), (1023, 1)])
+def test_fransac_device_pointers_any_alignment(ctx, n, skew):
+    """Device-pointer form: correspondences that are only 8-byte aligned (the scoring pass then takes single
+    pairs instead of 16-byte loads) and counts that are no multiple of four give exactly the host form's answer."""
+    import ctypes as C
+
+    import torch
+
+    x1, x2, gt, *_ = two_view(n=n, n_out=n // 5, seed=31 + n, noise=0.2)
+    hc, hmask, hF, hit = ctx.fransac(x1, x2, 1.0, seed=5)
+    d1 = torch.zeros((n + skew, 2), dtype=torch.float32, device="cuda")
+    d2 = torch.zeros((n + skew, 2), dtype=torch.float32, device="cuda")
+    d1[skew:] = torch.from_numpy(np.ascontiguousarray(x1, np.float32)).cuda()
+    d2[skew:] = torch.from_numpy(np.ascontiguousarray(x2, np.float32)).cuda()
+    p1, p2 = d1[skew:], d2[skew:]
+    assert p1.data_ptr() % 16 == (8 if skew else 0)
+    dmask = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    dF = torch.zeros(9, dtype=torch.float64, device="cuda")
+    dcnt = torch.zeros(2, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    rc = ctx.lib.svo_fransac(ctx._h, C.c_void_p(p1.data_ptr()), C.c_void_p(p2.data_ptr()), n, C.c_double(1.0),
+                             C.c_double(0.99), 1000, C.c_uint64(5), C.c_void_p(dmask.data_ptr()),
+                             C.c_void_p(dF.data_ptr()), C.c_void_p(dcnt.data_ptr()),
+                             C.c_void_p(dcnt.data_ptr() + 4), capi.MEM_DEVICE)
+    assert rc == 0
+    ctx.sync()
+    assert int(dcnt[0]) == hc and int(dcnt[1]) == hit
+    assert np.array_equal(dmask.cpu().numpy(), hmask)
+    assert np.array_equal(dF.cpu().numpy().reshape(3, 3), hF)
+
+
 def test_triangulate_matches_oracle(ctx, orc):
     P1, P2 = capi.stereo_projections(*K4, BASELINE)
     o1, o2 = orc.stereo_projections(*K4, BASELINE)
