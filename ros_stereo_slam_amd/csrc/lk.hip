@@ -684,6 +684,11 @@ __global__ __launch_bounds__(64 * WAVES, 4) void lk_track_kernel(LkBatch batch, 
             continue;
         }
         Dd = 1.f / Dd;
+        // The reference scales the mismatch sums by 2^-20 before the 2x2 solve.  A power of two commutes with
+        // every rounding of  (A12 b2 - A22 b1) Dd  (no overflow: |b| < 2^31, no underflow: Dd <= 8.4e6 and the
+        // difference is a multiple of an ulp of its terms), so it is applied to Dd once per level instead of to
+        // both sums in every iteration: the same step bit for bit.
+        const float Dds = Dd * FLT_SCALE;
 
         // ---- 2. iterate on the next image out of an LDS tile ----
         nxp -= half;
@@ -718,10 +723,8 @@ __global__ __launch_bounds__(64 * WAVES, 4) void lk_track_kernel(LkBatch batch, 
                              wv0, wv1, Ixp, Iyp, neg_c1, neg_c2, s1, s2);
             float b1, b2;
             wave_sum2_float(s1, s2, b1, b2);
-            b1 *= FLT_SCALE;
-            b2 *= FLT_SCALE;
-            const float dx = (A12 * b2 - A22 * b1) * Dd;
-            const float dy = (A12 * b1 - A11 * b2) * Dd;
+            const float dx = (A12 * b2 - A22 * b1) * Dds;
+            const float dy = (A12 * b1 - A11 * b2) * Dds;
             nxp += dx;
             nyp += dy;
             stepped = true;
