@@ -101,6 +101,72 @@ def kitti_leg(args):
     return sequence.bench_kitti(args, seq_dir)
 
 
+def free_port() -> int:
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(n: int) -> int:
+    """``python bench.py --gpus N`` without a launcher: start N fresh rank processes -- one per GPU,
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, exactly what
+    ``python -m torch.distributed.run --nproc-per-node N`` would give them -- wait for all of them, forward
+    rank 0's single JSON line and fail if any rank failed.  This process never initialises the GPU
+    (no torch import, no HIP call): the ranks are children, not a replacement of this process."""
+    import subprocess
+
+    port = os.environ.get("MASTER_PORT") or str(free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": port, "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [q.wait() for q in procs[1:]]
+    lines = [ln for ln in (out0 or "").splitlines() if ln.strip()]
+    json_lines = [ln for ln in lines if ln.lstrip().startswith("{")]
+    for ln in lines:
+        if ln not in json_lines:
+            print(ln, file=sys.stderr)      # anything else rank 0 wrote is not the contract's line
+    if any(codes):
+        print(f"bench.py: rank exit codes {codes}", file=sys.stderr)
+        return next(c for c in codes if c) or 1
+    if len(json_lines) != 1:
+        print(f"bench.py: rank 0 printed {len(json_lines)} JSON lines, expected one", file=sys.stderr)
+        return 1
+    print(json_lines[0])
+    return 0
+
+
+def launcher_selftest(rank: int, world: int) -> int:
+    """SVO_BENCH_LAUNCHER_SELFTEST=1 (tests/test_bench_launcher.py, runs without a GPU): the rank only joins
+    the rendezvous over gloo, takes part in one real all-gather and rank 0 prints the line's launcher-relevant
+    keys -- the proof that ``--gpus N`` starts N ranks."""
+    import torch
+    import torch.distributed as dist
+
+    if world > 1:
+        dist.init_process_group("gloo")
+        got = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(got, torch.tensor([rank], dtype=torch.int64))
+        seen = sorted(int(g.item()) for g in got)
+        assert seen == list(range(world)), seen
+        ranks_seen = dist.get_world_size()
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        ranks_seen = 1
+    if os.environ.get("SVO_BENCH_SELFTEST_FAIL_RANK") == str(rank):
+        return 3
+    if rank == 0:
+        print(json.dumps({"metric": "launcher selftest", "n_gpus": world, "ranks_seen": ranks_seen}))
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,6 +195,12 @@ def main():
     args = ap.parse_args()
     if args.kitti is not None:
         return kitti_leg(args)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args.gpus)      # the ranks are children; this process stays off the GPU
+    if os.environ.get("SVO_BENCH_LAUNCHER_SELFTEST") == "1":
+        return launcher_selftest(int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")))
 
     import torch
 
@@ -203,8 +275,7 @@ def main():
     run(0, Wn, True, local)
     sh.sync()
     for c in sh.ctxs:
-        c.enable_kernel_timing(not args.no_kernel_timing)
-        c.reset_kernel_time()
+        c.enable_kernel_timing(False)   # the timed region carries NO event records
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -223,13 +294,38 @@ def main():
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    ranks_seen = dist.get_world_size() if dist is not None else 1   # after a real all-gather over the group
+
+    # ---- the SAME frames once more with HIP events around every launch: per-kernel launch durations for the
+    # roofline object and the stage table, and what the event records cost (elapsed_events / elapsed) ----
     times = {}
-    for name, kid in (("pyramid", capi.K_PYRAMID), ("lk", capi.K_LK), ("fransac", capi.K_FRANSAC),
-                      ("triangulate", capi.K_TRIANGULATE), ("pnp", capi.K_PNP), ("anms", capi.K_ANMS)):
-        per = [c.kernel_time(kid) for c in sh.ctxs]
-        times[name] = (sum(p[0] for p in per), sum(p[1] for p in per))
-    for c in sh.ctxs:
-        c.enable_kernel_timing(False)
+    elapsed_events = None
+    if not args.no_kernel_timing:
+        local_ev = [[ident] for _ in range(M)]
+        run(0, Wn, True, local_ev)
+        sh.sync()
+        for c in sh.ctxs:
+            c.enable_kernel_timing(True)
+            c.reset_kernel_time()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        sh.sync()
+        t0 = time.perf_counter()
+        run(Wn, L, False, local_ev)
+        sh.sync()
+        torch.cuda.synchronize()
+        elapsed_events = time.perf_counter() - t0
+        for name, kid in (("pyramid", capi.K_PYRAMID), ("lk", capi.K_LK), ("fransac", capi.K_FRANSAC),
+                          ("triangulate", capi.K_TRIANGULATE), ("pnp", capi.K_PNP), ("anms", capi.K_ANMS)):
+            per = [c.kernel_time(kid) for c in sh.ctxs]
+            times[name] = (sum(p[0] for p in per), sum(p[1] for p in per))
+        for c in sh.ctxs:
+            c.enable_kernel_timing(False)
+        same = all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+                   for la, lb in zip(local, local_ev) for a, b in zip(la, lb))
+        if not same:
+            raise SystemExit("bench: the instrumented pass did not reproduce the timed pass bit for bit")
     n_frames = K * M
 
     def max_over_ranks(x: float) -> float:
@@ -239,6 +335,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         return float(tt.item())
 
+    elapsed_local = elapsed
     elapsed = max_over_ranks(elapsed)
 
     # ---- second timed figure: the whole share again, chunk initialisations inside the clock ----
@@ -280,46 +377,56 @@ def main():
         t_sh = np.array([t for _, t in traj])
         path_len = float(np.sum(np.linalg.norm(np.diff(t_truth, axis=0), axis=1)))
         fps = world * n_frames / elapsed
-        lk_ms, lk_launches = times["lk"]
+        lk_ms, lk_launches = times.get("lk", (0.0, 0))
         lk_avg_s = lk_ms / max(lk_launches, 1) * 1e-3
         # passes carried by the LK launches of the timed region: one tracking pass per frame + one
         # stereo pass per keyframe
         passes = n_frames + stats["keyframes"]
         passes_per_launch = passes / max(lk_launches, 1)
         lk_bytes = lk_algorithmic_bytes(n_kpts) * passes_per_launch
-        achieved = lk_bytes / lk_avg_s / 1e9 if lk_avg_s > 0 else 0.0
+        achieved = lk_bytes / lk_avg_s / 1e9 if lk_avg_s > 0 else None
         kf_rate = stats["keyframes"] / n_frames
         pmc = lk_pmc_constants(n_kpts)
         roof = {
             "kernel": "lk_track_kernel<3>",
-            "bound": "hbm",
+            # achieved / peak / frac price the kernel against the HBM roofline, the one the contract and
+            # SURVEY.md 8d name; what LIMITS the kernel is vector-instruction issue (valu_* keys below)
+            "bound": "valu",
+            "bound_note": "achieved/peak/frac = algorithmic HBM bytes per launch / mean launch time / 8 TB/s (the "
+                          "contract's roofline); the binding limit is VALU issue: valu_frac_* = wave-instructions "
+                          "(SQ_INSTS_VALU) x cycles per wave-instruction / (1024 SIMDs x clock) / launch time, at "
+                          "the guide's rate (2 cycles at 2.4 GHz, v_fma_f32 wave64) and at the rate measured for "
+                          "this kernel's instruction mix (tools/valu_rate.hip)",
             "achieved": achieved,
             "peak": 8000.0,
             "unit": "GB/s",
-            "frac": achieved / 8000.0,
+            "frac": achieved / 8000.0 if achieved is not None else None,
             "traffic": pmc["hbm_bytes_per_pass"] * passes_per_launch if pmc else None,
             "traffic_source": (pmc["source"] + " x passes per launch") if pmc else
-                              "null: profiles/r02_lk_pmc.json absent or taken on another lk.hip / keypoint count",
-            "avg_launch_us": lk_avg_s * 1e6,
+                              f"null: {os.path.basename(LK_PMC_JSON)} absent or taken on another lk.hip / keypoint count",
+            "avg_launch_us": lk_avg_s * 1e6 if lk_launches else None,
+            "avg_launch_source": "HIP events on each context's stream in a SEPARATE instrumented pass over the same "
+                                 "frames (the timed region carries no event records); launches of several "
+                                 "contexts overlap, so this is a shared-chip duration",
             "launches_per_step": lk_launches / K,
             "algorithmic_bytes_per_launch": lk_bytes,
             "lk_passes_per_launch": passes_per_launch,
             "frame_hbm_frac": frame_algorithmic_bytes(n_kpts, kf_rate) / (elapsed / n_frames) / 8e12,
-            "note": "HBM is the roofline the contract names; the kernel itself is bound by VALU issue "
-                    "(valu_* keys: wave-instructions per pass from SQ_INSTS_VALU x the measured cycles per "
-                    "wave-instruction of this instruction mix, tools/valu_rate.hip)",
         }
         if pmc:
             cyc = pmc["valu_cycles_per_wave_inst"]       # measured on this chip, not assumed
             clk = pmc["sclk_hz_under_load"]
             need_s = pmc["valu_insts_per_pass"] * cyc / 1024.0 / clk   # per pass, all 1024 SIMDs issuing
+            need_guide_s = pmc["valu_insts_per_pass"] * 2.0 / 1024.0 / 2.4e9
             roof.update({
                 "valu_insts_per_pass": pmc["valu_insts_per_pass"],
                 "valu_cycles_per_wave_inst": cyc,
                 "valu_sclk_hz": clk,
                 "valu_issue_bound_us_per_launch": need_s * passes_per_launch * 1e6,
-                "valu_kernel_frac": need_s * passes_per_launch / lk_avg_s if lk_avg_s > 0 else None,
-                "valu_chip_frac": need_s * passes / elapsed,
+                "valu_frac_measured_rate": need_s * passes_per_launch / lk_avg_s if lk_avg_s > 0 else None,
+                "valu_frac_guide_rate": need_guide_s * passes_per_launch / lk_avg_s if lk_avg_s > 0 else None,
+                "valu_chip_frac_measured_rate": need_s * passes / elapsed,
+                "valu_chip_frac_guide_rate": need_guide_s * passes / elapsed,
             })
         ate_sh = chunked.ate_rmse(t_sh, t_truth)
         result = {
@@ -327,6 +434,7 @@ def main():
             "value": fps,
             "unit": "frames/s",
             "n_gpus": world,
+            "ranks_seen": ranks_seen,
             "steps": K,
             "warmup": Wn,
             "ms_per_step": elapsed / K * 1e3,
@@ -353,6 +461,13 @@ def main():
                 "mean_pnp_inliers": stats["inliers"] / n_frames,
                 "render_s": render_s,
                 "stage_ms_per_frame": {k: v[0] / n_frames for k, v in times.items()},
+                "stage_ms_source": "instrumented pass (HIP events), not the timed region",
+            },
+            "event_records": {
+                "timed_region": "none",
+                "value_with_event_records": (world * n_frames / elapsed_events) if elapsed_events else None,
+                "cost_frac": (elapsed_events / elapsed_local - 1.0) if elapsed_events else None,
+                "note": "the instrumented pass is rank-local (no collective inside its clock)",
             },
             "path_length_m": path_len,
             "ate_rmse_vs_truth": ate_sh,
@@ -411,7 +526,7 @@ def main():
         ctxg.close()
 
     # ---- CPU baseline: the oracle on the node's own cores, a bounded sample of the same stream ----
-    if rank == 0 and not args.no_cpu_baseline and world == 1:
+    if rank == 0 and not args.no_cpu_baseline:
         from oracle import orc  # the checker, timed as the CPU baseline ("port")
 
         native = orc.use_native_build()

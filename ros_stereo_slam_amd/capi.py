@@ -47,11 +47,14 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not LIB_PATH.exists():
+    # SVO_LIB=<path>: an A/B variant build (tools/ab.sh) is loaded INSTEAD of the installed library, which is
+    # never overwritten; the override must name an existing file (no silent fall-through to the default)
+    path = pathlib.Path(os.environ["SVO_LIB"]) if os.environ.get("SVO_LIB") else LIB_PATH
+    if not path.exists():
         raise ImportError(
-            f"{LIB_PATH} is missing: build it with `make -C ros_stereo_slam_amd/csrc` "
+            f"{path} is missing: build it with `make -C ros_stereo_slam_amd/csrc` "
             "(or __graft_entry__.build()); the HIP path has no CPU fallback")
-    lib = C.CDLL(os.fspath(LIB_PATH))
+    lib = C.CDLL(os.fspath(path))
     lib.svo_last_error.restype = C.c_char_p
     lib.svo_ctx_stream.restype = C.c_void_p
     _lib = lib

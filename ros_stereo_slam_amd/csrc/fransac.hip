@@ -401,7 +401,7 @@ __global__ __launch_bounds__(LEAN ? 64 : 256, LEAN ? 5 : 4) void fr_ransac_kerne
     __shared__ int sPerm[9], s_nm, s_cnt[NW][3], s_last;
     if (it0 > 0 && st->done)  // the loop ended in an earlier phase (the same answer in every wave of the launch)
         return;
-    const int n = d_n ? *d_n : n_host;
+    const int n = d_n ? min(*d_n, n_host) : n_host;  // a live count never exceeds the capacity the buffers were sized for
     const bool vec_ok = ((reinterpret_cast<uintptr_t>(p1) | reinterpret_cast<uintptr_t>(p2)) & 15) == 0;
     for (int it = it0 + (int)blockIdx.x; it < it1; it += gridDim.x) {
         if (wave == 0) {

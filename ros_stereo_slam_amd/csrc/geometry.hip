@@ -103,7 +103,7 @@ __global__ __launch_bounds__(128) void triangulate_kernel(Mat34 P1, Mat34 P2, Tr
     const Mat34 &Rt = job.Rt;
     const int apply_rt = job.apply_rt;
     float *__restrict__ out_world = job.out_world;
-    const int n = d_n ? *d_n : n_host;
+    const int n = d_n ? min(*d_n, n_host) : n_host;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0 && job.h_count)
         *job.h_count = n;  // what a one-thread launch of its own did before (store_counts_kernel)
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void transform_kernel(Mat34 Rt, const float *_
                                                         const int *__restrict__ d_n, float *__restrict__ out)
 {
     __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
-    const int n = d_n ? *d_n : n_host;
+    const int n = d_n ? min(*d_n, n_host) : n_host;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n)
         return;
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void colors_kernel(const uint8_t *__restrict__
                                                      const int *__restrict__ d_n, float *__restrict__ out)
 {
     __builtin_amdgcn_s_setprio(3);  // short latency-bound kernel: win issue arbitration against co-resident LK waves
-    const int n = d_n ? *d_n : n_host;
+    const int n = d_n ? min(*d_n, n_host) : n_host;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n)
         return;
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(64) void compact_kernel(CompactBatch batch, int seg
     svo_chain_priority();
     const CompactArgs &args = batch.j[blockIdx.y];
     const uint8_t *__restrict__ mask = args.mask;
-    const int n = args.d_n ? *args.d_n : args.n_host;
+    const int n = args.d_n ? min(*args.d_n, args.n_host) : args.n_host;
     const int lane = threadIdx.x;
     const int first = blockIdx.x * seg;  // this wave's segment: [first, last)
     if (first >= n && !(n <= 0 && blockIdx.x == 0))

@@ -32,13 +32,6 @@ struct svo_map {
 
 namespace {
 
-__global__ __launch_bounds__(256) void map_fill_id_kernel(int *__restrict__ id, int n, int value)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n)
-        id[i] = value;
-}
-
 __global__ __launch_bounds__(256) void map_transform_kernel(const float *__restrict__ cam, const int *__restrict__ id,
                                                             const double *__restrict__ rt, size_t first, size_t n,
                                                             float *__restrict__ world)
@@ -51,6 +44,24 @@ __global__ __launch_bounds__(256) void map_transform_kernel(const float *__restr
 #pragma unroll
     for (int r = 0; r < 3; r++)
         world[3 * i + r] = (float)(m[4 * r] * x + m[4 * r + 1] * y + m[4 * r + 2] * z + m[4 * r + 3]);
+}
+
+// one record, its 12 doubles in the kernel arguments: what svo_map_add_keyframe launches (no upload, no wait)
+struct MapRt {
+    double v[12];
+};
+__global__ __launch_bounds__(256) void map_transform_one_kernel(const float *__restrict__ cam, MapRt rt, size_t first,
+                                                                size_t n, float *__restrict__ world, int *__restrict__ id,
+                                                                int id_value)
+{
+    const size_t i = first + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= first + n)
+        return;
+    id[i] = id_value;
+    const float x = cam[3 * i], y = cam[3 * i + 1], z = cam[3 * i + 2];
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+        world[3 * i + r] = (float)(rt.v[4 * r] * x + rt.v[4 * r + 1] * y + rt.v[4 * r + 2] * z + rt.v[4 * r + 3]);
 }
 
 int map_reserve(svo_map *m, size_t want)
@@ -155,12 +166,13 @@ int svo_map_add_keyframe(svo_map *m, int traj_index, const double *R9, const dou
     hipStream_t st = m->ctx->stream;
     SVO_HIP(hipMemcpyAsync(m->d_cam + 3 * r.off, xyz_cam, (size_t)n * 12,
                            mem == SVO_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(map_fill_id_kernel, dim3((n + 255) / 256), dim3(256), 0, st, m->d_id + r.off, n, id);
-    // the record's world cloud as insertKeyFrames places it (src/keyFrameManagement.cpp:20-30)
-    if ((rc = map_upload_rt(m)))
-        return rc;
-    hipLaunchKernelGGL(map_transform_kernel, dim3((n + 255) / 256), dim3(256), 0, st, m->d_cam, m->d_id,
-                       m->d_rt.as<double>(), r.off, (size_t)n, m->d_world);
+    // the record's world cloud as insertKeyFrames places it (src/keyFrameManagement.cpp:20-30): ONE launch that
+    // also writes the record id of its points; the record's [R|t] travels in the kernel arguments, so nothing
+    // is uploaded and the stream is not waited for (svo_map_update uploads all records once per solve)
+    MapRt rt;
+    memcpy(rt.v, r.Rt, sizeof(rt.v));
+    hipLaunchKernelGGL(map_transform_one_kernel, dim3((n + 255) / 256), dim3(256), 0, st, m->d_cam, rt, r.off,
+                       (size_t)n, m->d_world, m->d_id, id);
     SVO_HIP(hipGetLastError());
     if (mem == SVO_MEM_HOST)
         SVO_HIP(hipStreamSynchronize(st));  // the caller's array may go away

@@ -809,7 +809,7 @@ __global__ __launch_bounds__(64, 4) void pnp_solve_kernel(PnpBatch batch, int it
     __shared__ WaveLds s_lds[1];
     const int lane = threadIdx.x & 63;
     const int it = __builtin_amdgcn_readfirstlane(it0 + blockIdx.x);
-    const int n = job.d_n ? *job.d_n : job.n_host;
+    const int n = job.d_n ? min(*job.d_n, job.n_host) : job.n_host;  // as pnp_finish: never past the capacity
     if (it < it1)
         pnp_hypothesis(job, it, n, s_lds[0], lane);
     if (it1 >= job.iterations)

@@ -7,7 +7,12 @@ This check reads the gfx950 assembly of lk.hip and fails if, for any hand-issued
 instruction between the load and the first following `s_waitcnt vmcnt(N)` that is guaranteed to cover it touches
 the load's destination registers.
 
-    python tools/check_lk_inflight.py [lk.s]     (without an argument: compiles lk.hip with the library's flags)
+    python tools/check_lk_inflight.py --so libsvo_hip.so   the SHIPPED library: its gfx950 code objects are
+                                                           extracted and disassembled (llvm-objdump); this is what
+                                                           csrc/Makefile runs after linking, and a violation fails
+                                                           the build
+    python tools/check_lk_inflight.py lk.s                 an assembly listing (hipcc -S or llvm-objdump -d)
+Checked: every lk_track_kernel<C> of the listing (the only kernels with hand-issued loads); none found = failure.
 """
 import os
 import re
@@ -17,13 +22,32 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "ros_stereo_slam_amd", "csrc")
-FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", "-S", "--cuda-device-only"]
+OBJDUMP = os.environ.get("LLVM_OBJDUMP", "/opt/rocm/lib/llvm/bin/llvm-objdump")
 
 
-def compile_asm():
-    out = os.path.join(tempfile.mkdtemp(prefix="lkasm"), "lk.s")
-    subprocess.run(["hipcc", *FLAGS, "-o", out, os.path.join(CSRC, "lk.hip")], check=True, stderr=subprocess.DEVNULL)
-    return out
+def disassemble_so(so_path):
+    """gfx950 disassembly of every code object bundled in the library, as one listing."""
+    import shutil
+
+    tmp = tempfile.mkdtemp(prefix="lkso")
+    try:
+        local = os.path.join(tmp, "lib.so")
+        shutil.copy(so_path, local)
+        subprocess.run([OBJDUMP, "--offloading", local], check=True, stdout=subprocess.DEVNULL, cwd=tmp)
+        parts = sorted(f for f in os.listdir(tmp) if "amdgcn" in f)
+        if not parts:
+            raise SystemExit(f"{so_path}: no gfx950 code object found")
+        text = []
+        for f in parts:
+            r = subprocess.run([OBJDUMP, "-d", "--symbolize-operands", os.path.join(tmp, f)], check=True,
+                               capture_output=True, text=True)
+            text.append(r.stdout)
+        out = os.path.join(tempfile.mkdtemp(prefix="lkasm"), "libsvo_hip.dis")
+        with open(out, "w") as fh:
+            fh.write("\n".join(text))
+        return out
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def regs_of(text):
@@ -35,12 +59,19 @@ def regs_of(text):
     return s
 
 
+LABEL = re.compile(r"^(?:[0-9a-f]+ )?(\.LBB\S*|<L\d+>):")
+KERNEL = re.compile(r"^(?:[0-9a-f]+ <)?(_ZN\S*lk_track_kernel[^>:\s]*)>?:")
+
+
 def check(path):
-    lines = open(path).read().split("\n")
+    """Only lk.hip issues loads by hand (asm volatile), and only in lk_track_kernel<C>: there EVERY
+    global_load_dwordx4 is hand-issued, so the kernel's own vmcnt bookkeeping can be replayed exactly.  Kernels the
+    compiler schedules by itself are not checked (it knows about its own loads)."""
+    lines = [l.split("//")[0].rstrip() for l in open(path).read().split("\n")]   # objdump puts the encoding there
     problems, kernels, loads_seen = [], 0, 0
     i = 0
     while i < len(lines):
-        m = re.match(r"^(_ZN\S*lk_track_kernel\S*):", lines[i])
+        m = KERNEL.match(lines[i])
         if not m:
             i += 1
             continue
@@ -48,11 +79,11 @@ def check(path):
         name = m.group(1)
         end = next(j for j in range(i, len(lines)) if "s_endpgm" in lines[j])
         body = [(j, lines[j].strip()) for j in range(i + 1, end)]
-        body = [(j, l) for j, l in body if l and not l.startswith(";") and not l.startswith(".") or re.match(r"^\.LBB", l)]
+        body = [(j, l) for j, l in body if l and not l.startswith(";") and not l.startswith(".") or LABEL.match(l)]
         # outstanding hand-issued loads, oldest first: (line, dest registers)
         pending = []
         for j, l in body:
-            if re.match(r"^\.LBB", l):
+            if LABEL.match(l):
                 # a label: control flow joins here; every in-flight window of lk.hip is straight-line code
                 if pending:
                     problems.append(f"{name}: label at line {j + 1} inside an in-flight window (loads from line {pending[0][0] + 1})")
@@ -90,7 +121,13 @@ def check(path):
 
 
 def main():
-    path = sys.argv[1] if len(sys.argv) > 1 else compile_asm()
+    if len(sys.argv) == 3 and sys.argv[1] == "--so":
+        path = disassemble_so(sys.argv[2])
+    elif len(sys.argv) == 2:
+        path = sys.argv[1]
+    else:
+        print(__doc__)
+        return 2
     kernels, loads, problems = check(path)
     for p in problems:
         print(p)
