@@ -79,6 +79,15 @@ int svo_ctx_enable_kernel_timing(svo_ctx *ctx, int enable);
 int svo_ctx_kernel_time(svo_ctx *ctx, int kernel_id, double *total_ms, int *launches);
 int svo_ctx_reset_kernel_time(svo_ctx *ctx);
 
+/* ---- shared transcendental functions (include/svo_math.h) ------------------------------------
+ * The geometry solvers on both sides of the parity tests call ONE software implementation of sin /
+ * cos / acos / cbrt / log (the reference reaches libm through OpenCV: Rodrigues at
+ * src/VisualSLAM.cpp:71, the cubic of findFundamentalMat at src/tracking.cpp:34,75, the adaptive
+ * RANSAC bound of solvePnPRansac at src/keyFrameManagement.cpp:84).  This entry evaluates one of them
+ * ON THE DEVICE over an array, so that a test can check the device and the host run it bit for bit. */
+enum { SVO_MATH_SIN = 0, SVO_MATH_COS = 1, SVO_MATH_ACOS = 2, SVO_MATH_CBRT = 3, SVO_MATH_LOG = 4 };
+int svo_math_eval(svo_ctx *ctx, int fn, const double *x, int n, double *y, int mem);
+
 /* ---- image pyramid ----------------------------------------------------------------------- */
 /* Replaces the pyramid cv::calcOpticalFlowPyrLK rebuilds on every call
  * (src/tracking.cpp:18,52).  A pyramid is built once per image and reused for the

@@ -170,7 +170,8 @@ static void ba_se3_exp_mul(const double *d, const double *R, const double *t, do
             E[k] = ((k % 4) == 0 ? 1. : 0.) + O[k] + O2[k];
         memcpy(V, E, sizeof(V));
     } else {
-        const double a = sin(th) / th, b = (1. - cos(th)) / (th * th), c = (th - sin(th)) / (th * th * th);
+        const double sn = svo_sin(th), cn = svo_cos(th);
+        const double a = sn / th, b = (1. - cn) / (th * th), c = (th - sn) / (th * th * th);
         for (int k = 0; k < 9; k++) {
             const double I = (k % 4) == 0 ? 1. : 0.;
             E[k] = I + a * O[k] + b * O2[k];

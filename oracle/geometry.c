@@ -85,11 +85,11 @@ static int update_num_iters(double p, double ep, int model_points, int max_iters
     double num = 1. - p;
     if (num < DBL_MIN)
         num = DBL_MIN;
-    double denom = 1. - pow(1. - ep, model_points);
+    double denom = 1. - svo_powi(1. - ep, model_points);
     if (denom < DBL_MIN)
         return 0;
-    num = log(num);
-    denom = log(denom);
+    num = svo_log(num);
+    denom = svo_log(denom);
     return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)lrint(num / denom);
 }
 int orc_update_num_iters(double p, double ep, int model_points, int max_iters)
@@ -133,22 +133,22 @@ static int solve_cubic(const double *c, double *r)
         double R = (2 * a1 * a1 * a1 - 9 * a1 * a2 + 27 * a3) * (1. / 54);
         double Qcubed = Q * Q * Q, dd = Qcubed - R * R;
         if (dd > 0) {
-            double theta = acos(R / sqrt(Qcubed));
+            double theta = svo_acos(R / sqrt(Qcubed));
             double sqrtQ = sqrt(Q);
             double t0 = -2 * sqrtQ, t1 = theta * (1. / 3), t2 = a1 * (1. / 3);
-            r[0] = t0 * cos(t1) - t2;
-            r[1] = t0 * cos(t1 + 2. * M_PI / 3) - t2;
-            r[2] = t0 * cos(t1 + 4. * M_PI / 3) - t2;
+            r[0] = t0 * svo_cos(t1) - t2;
+            r[1] = t0 * svo_cos(t1 + 2. * 3.14159265358979323846 / 3) - t2;
+            r[2] = t0 * svo_cos(t1 + 4. * 3.14159265358979323846 / 3) - t2;
             n = 3;
         } else if (dd == 0) {
-            double e = cbrt(fabs(R));
+            double e = svo_cbrt(fabs(R));
             if (R > 0)
                 e = -e;
             r[0] = 2 * e - a1 * (1. / 3);
             r[1] = -e - a1 * (1. / 3);
             n = 2;
         } else {
-            double e = cbrt(sqrt(-dd) + fabs(R));
+            double e = svo_cbrt(sqrt(-dd) + fabs(R));
             if (R > 0)
                 e = -e;
             r[0] = (e + Q / e) - a1 * (1. / 3);
@@ -499,7 +499,7 @@ void orc_rodrigues(const double *r, double *R)
             R[i] = (i % 4) == 0;
         return;
     }
-    double c = cos(th), s = sin(th), c1 = 1. - c, it = 1. / th;
+    double c = svo_cos(th), s = svo_sin(th), c1 = 1. - c, it = 1. / th;
     double x = r[0] * it, y = r[1] * it, z = r[2] * it;
     R[0] = c + c1 * x * x;
     R[1] = c1 * x * y - s * z;
@@ -519,7 +519,7 @@ void orc_rodrigues_inv(const double *R, double *r)
     double s = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
     double c = (R[0] + R[4] + R[8] - 1) * 0.5;
     c = c > 1. ? 1. : (c < -1. ? -1. : c);
-    double theta = acos(c);
+    double theta = svo_acos(c);
     if (s < 1e-5) {
         if (c > 0) {
             r[0] = r[1] = r[2] = 0;

@@ -52,6 +52,17 @@ def _p(a):
     return C.c_void_p(a.ctypes.data)
 
 
+MATH_FN = {"sin": 0, "cos": 1, "acos": 2, "cbrt": 3, "log": 4}
+
+
+def math_eval(fn: str, x) -> np.ndarray:
+    """include/svo_math.h as the oracle build (gcc) compiles it."""
+    x = np.ascontiguousarray(x, np.float64).ravel()
+    y = np.empty_like(x)
+    load().orc_math_eval(MATH_FN[fn], _p(x), x.size, _p(y))
+    return y
+
+
 def pyr_sizes(w, h, levels):
     ws, hs = [w], [h]
     for _ in range(1, levels):

@@ -580,16 +580,20 @@ static int chol6_solve(const double *Ain, const double *b, double *x)
     return 1;
 }
 
-/* accumulates J^T J (upper+lower), J^T r and the squared error for the pose (R,t) */
+/* accumulates J^T J (upper+lower), J^T r and the squared error for the pose (R,t).
+ *
+ * Summation order = the HIP kernel's (pnp.hip: pnp_finish_kernel / block_reduce), so that the two agree BIT FOR BIT
+ * (any fixed order is as good as upstream's sequential one, whose own order varies with the
+ * OpenCV build): 256 strided partial sums (element e goes to partial e mod 256, elements in ascending order), the
+ * partials of each group of 64 added in ascending order starting from 0, the four group totals as ((g0+g1)+g2)+g3. */
+#define PNP_NACC 28 /* error, 21 upper-triangular entries of J^T J, 6 of J^T r */
 static double pnp_normal_eq(const float *obj, const float *img, const int *idx, int m, const double *K4,
                             const double *R, const double *t, double *JtJ, double *Jtr)
 {
-    double err = 0;
-    if (JtJ)
-        memset(JtJ, 0, sizeof(double) * 36);
-    if (Jtr)
-        memset(Jtr, 0, sizeof(double) * 6);
+    static _Thread_local double part[256][PNP_NACC];
+    memset(part, 0, sizeof(part));
     for (int e = 0; e < m; e++) {
+        double *acc = part[e & 255];
         const int i = idx ? idx[e] : e;
         const float *X = obj + 3 * i;
         double rx = R[0] * X[0] + R[1] * X[1] + R[2] * X[2];
@@ -599,7 +603,7 @@ static double pnp_normal_eq(const float *obj, const float *img, const int *idx, 
         double iz = 1. / Zc;
         double u = K4[0] * Xc * iz + K4[2], v = K4[1] * Yc * iz + K4[3];
         double ru = u - img[2 * i], rv = v - img[2 * i + 1];
-        err += ru * ru + rv * rv;
+        acc[0] += ru * ru + rv * rv;
         if (!JtJ)
             continue;
         /* d(u,v)/d(Xc,Yc,Zc) */
@@ -608,13 +612,37 @@ static double pnp_normal_eq(const float *obj, const float *img, const int *idx, 
         /* dXc/dw = -[R X]x, dXc/dt = I */
         double Ju[6] = {a2 * ry, a0 * rz - a2 * rx, -a0 * ry, a0, 0, a2};
         double Jv[6] = {-b1 * rz + b2 * ry, -b2 * rx, b1 * rx, 0, b1, b2};
-        for (int p = 0; p < 6; p++) {
-            for (int q = 0; q < 6; q++)
-                JtJ[6 * p + q] += Ju[p] * Ju[q] + Jv[p] * Jv[q];
-            Jtr[p] += Ju[p] * ru + Jv[p] * rv;
-        }
+        int k = 1;
+        for (int p = 0; p < 6; p++)
+            for (int q = p; q < 6; q++)
+                acc[k++] += Ju[p] * Ju[q] + Jv[p] * Jv[q];
+        for (int p = 0; p < 6; p++)
+            acc[22 + p] += Ju[p] * ru + Jv[p] * rv;
     }
-    return err;
+    double tot[PNP_NACC];
+    const int nacc = JtJ ? PNP_NACC : 1;
+    for (int k = 0; k < nacc; k++) {
+        double g[4];
+        for (int w = 0; w < 4; w++) {
+            double x = 0;
+            for (int j = 0; j < 64; j++)
+                x += part[64 * w + j][k];
+            g[w] = x;
+        }
+        tot[k] = ((g[0] + g[1]) + g[2]) + g[3];
+    }
+    if (JtJ) {
+        int k = 1;
+        for (int p = 0; p < 6; p++)
+            for (int q = p; q < 6; q++) {
+                JtJ[6 * p + q] = tot[k];
+                JtJ[6 * q + p] = tot[k];
+                k++;
+            }
+        for (int p = 0; p < 6; p++)
+            Jtr[p] = tot[22 + p];
+    }
+    return tot[0];
 }
 
 double orc_pnp_refine_Rt(const float *obj, const float *img, const int *idx, int m, const double *K4,

@@ -19,6 +19,10 @@
 
 #include <stdint.h>
 
+/* sin / cos / acos / cbrt / log / integer power as ONE software implementation shared with the HIP library
+ * (include/svo_math.h says why); a header of the public include directory, not product code. */
+#include "../include/svo_math.h"
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -80,6 +84,8 @@ uint32_t orc_rng_u32(uint64_t seed, uint32_t iter, uint32_t draw);
 int orc_draw_subset_plain(uint64_t seed, uint32_t iter, int n, int m, int *idx);
 /* cv RANSACUpdateNumIters */
 int orc_update_num_iters(double p, double ep, int model_points, int max_iters);
+/* include/svo_math.h as this build compiles it: fn 0 sin, 1 cos, 2 acos, 3 cbrt, 4 log (mathwrap.c) */
+void orc_math_eval(int fn, const double *x, int n, double *y);
 
 /* ---- fundamental-matrix RANSAC: src/tracking.cpp:34 and :75 ---------------------------- */
 /* stands in for cv::findFundamentalMat(p1,p2,FM_RANSAC,thr,conf,mask).

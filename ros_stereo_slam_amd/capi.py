@@ -289,6 +289,19 @@ def orb_extract(self, img, n_features=500, fast_threshold=20):
     return xy[:k].copy(), octv[:k].copy(), resp[:k].copy(), d[:k].copy(), desc[:k].copy()
 
 
+MATH_FN = {"sin": 0, "cos": 1, "acos": 2, "cbrt": 3, "log": 4}
+
+
+@_ctx_method
+def math_eval(self, fn: str, x) -> np.ndarray:
+    """include/svo_math.h evaluated on the device (svo_math_eval); the parity tests compare the bits with
+    the host build of the same header."""
+    x = np.ascontiguousarray(x, np.float64).ravel()
+    y = np.empty_like(x)
+    _check(self.lib.svo_math_eval(self._h, MATH_FN[fn], _ptr(x), x.size, _ptr(y), MEM_HOST))
+    return y
+
+
 @_ctx_method
 def sor_filter(self, xyz, color=None, mean_k=200, stddev_mul=0.01, z_limit=500.0):
     """visualSLAM::SORcloud (src/rosFuncs.cpp:9-39) -> (xyz_kept, color_kept or None, mean_dist)."""

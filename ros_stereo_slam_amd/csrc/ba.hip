@@ -189,7 +189,8 @@ __device__ void ba_se3_exp_mul(const double *d, const double *R, const double *t
             V[k] = E[k];
         }
     } else {
-        const double a = sin(th) / th, b = (1. - cos(th)) / (th * th), c = (th - sin(th)) / (th * th * th);
+        const double sn = svo_sin(th), cn = svo_cos(th);
+        const double a = sn / th, b = (1. - cn) / (th * th), c = (th - sn) / (th * th * th);
         for (int k = 0; k < 9; k++) {
             const double I = (k % 4) == 0 ? 1. : 0.;
             E[k] = I + a * O[k] + b * O2[k];

@@ -91,22 +91,22 @@ __device__ int solve_cubic(const double *c, double *r)
         const double R = (2 * a1 * a1 * a1 - 9 * a1 * a2 + 27 * a3) * (1. / 54);
         const double Qcubed = Q * Q * Q, dd = Qcubed - R * R;
         if (dd > 0) {
-            double theta = acos(R / sqrt(Qcubed));
+            double theta = svo_acos(R / sqrt(Qcubed));
             double sqrtQ = sqrt(Q);
             double t0 = -2 * sqrtQ, t1 = theta * (1. / 3), t2 = a1 * (1. / 3);
-            r[0] = t0 * cos(t1) - t2;
-            r[1] = t0 * cos(t1 + 2. * 3.14159265358979323846 / 3) - t2;
-            r[2] = t0 * cos(t1 + 4. * 3.14159265358979323846 / 3) - t2;
+            r[0] = t0 * svo_cos(t1) - t2;
+            r[1] = t0 * svo_cos(t1 + 2. * 3.14159265358979323846 / 3) - t2;
+            r[2] = t0 * svo_cos(t1 + 4. * 3.14159265358979323846 / 3) - t2;
             n = 3;
         } else if (dd == 0) {
-            double e = cbrt(fabs(R));
+            double e = svo_cbrt(fabs(R));
             if (R > 0)
                 e = -e;
             r[0] = 2 * e - a1 * (1. / 3);
             r[1] = -e - a1 * (1. / 3);
             n = 2;
         } else {
-            double e = cbrt(sqrt(-dd) + fabs(R));
+            double e = svo_cbrt(sqrt(-dd) + fabs(R));
             if (R > 0)
                 e = -e;
             r[0] = (e + Q / e) - a1 * (1. / 3);

@@ -519,4 +519,58 @@ int svo_compact(svo_ctx *ctx, const uint8_t *mask, int n, const float *in_a, int
     return SVO_OK;
 }
 
+// include/svo_math.h on the device, element by element (the parity tests compare it with the host build)
+__global__ void math_eval_kernel(int fn, const double *__restrict__ x, int n, double *__restrict__ y)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const double v = x[i];
+    double r;
+    switch (fn) {
+    case SVO_MATH_SIN:
+        r = svo_sin(v);
+        break;
+    case SVO_MATH_COS:
+        r = svo_cos(v);
+        break;
+    case SVO_MATH_ACOS:
+        r = svo_acos(v);
+        break;
+    case SVO_MATH_CBRT:
+        r = svo_cbrt(v);
+        break;
+    default:
+        r = svo_log(v);
+        break;
+    }
+    y[i] = r;
+}
+
+int svo_math_eval(svo_ctx *ctx, int fn, const double *x, int n, double *y, int mem)
+{
+    SVO_CHECK_ARG(ctx && n >= 0 && (n == 0 || (x && y)) && fn >= SVO_MATH_SIN && fn <= SVO_MATH_LOG);
+    SVO_CHECK_ARG(mem == SVO_MEM_HOST || mem == SVO_MEM_DEVICE);
+    if (n == 0)
+        return SVO_OK;
+    SVO_HIP(hipSetDevice(ctx->device));
+    const double *dx = x;
+    double *dy = y;
+    if (mem == SVO_MEM_HOST) {
+        int rc;
+        if ((rc = ctx->s_a.ensure((size_t)n * 8)) || (rc = ctx->s_b.ensure((size_t)n * 8)))
+            return rc;
+        SVO_HIP(hipMemcpyAsync(ctx->s_a.p, x, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+        dx = ctx->s_a.as<double>();
+        dy = ctx->s_b.as<double>();
+    }
+    hipLaunchKernelGGL(math_eval_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, fn, dx, n, dy);
+    SVO_HIP(hipGetLastError());
+    if (mem == SVO_MEM_HOST) {
+        SVO_HIP(hipMemcpyAsync(y, dy, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        SVO_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return SVO_OK;
+}
+
 }  // extern "C"

@@ -851,7 +851,7 @@ __device__ void rodrigues_dev(const double *r, double *R)
             R[i] = (i % 4) == 0 ? 1. : 0.;
         return;
     }
-    const double c = cos(th), s = sin(th), c1 = 1. - c, it = 1. / th;
+    const double c = svo_cos(th), s = svo_sin(th), c1 = 1. - c, it = 1. / th;
     const double x = r[0] * it, y = r[1] * it, z = r[2] * it;
     R[0] = c + c1 * x * x;
     R[1] = c1 * x * y - s * z;
@@ -870,7 +870,7 @@ __device__ void rodrigues_inv_dev(const double *R, double *r)
     const double s = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
     double c = (R[0] + R[4] + R[8] - 1) * 0.5;
     c = c > 1. ? 1. : (c < -1. ? -1. : c);
-    double theta = acos(c);
+    double theta = svo_acos(c);
     if (s < 1e-5) {
         if (c > 0) {
             r[0] = r[1] = r[2] = 0;
@@ -1390,9 +1390,10 @@ template <bool LEAN> __global__ __launch_bounds__(256, LEAN ? 5 : 4) void pnp_fi
     __syncthreads();
     if (tid == 0) {
         PnpResult r;
-        for (int k = 0; k < 9; k++)
-            r.R[k] = s_pose[k];
         rodrigues_inv_dev(s_pose, r.rvec);
+        // R of the record is Rodrigues(rvec) -- what the reference forms from solvePnPRansac's output
+        // (src/VisualSLAM.cpp:71) -- not the refinement's own matrix, which differs from it in the last places
+        rodrigues_dev(r.rvec, r.R);
         r.tvec[0] = s_pose[9];
         r.tvec[1] = s_pose[10];
         r.tvec[2] = s_pose[11];

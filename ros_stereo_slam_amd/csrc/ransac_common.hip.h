@@ -5,6 +5,8 @@
 #include <cfloat>
 #include <cstdint>
 
+#include "../../include/svo_math.h"  // sin / cos / acos / cbrt / log shared with the oracle, bit for bit
+
 namespace svo {
 
 // Counter-based generator: draw k of RANSAC iteration i is a pure function of
@@ -30,11 +32,11 @@ __device__ __forceinline__ int update_num_iters(double p, double ep, int model_p
     double num = 1. - p;
     if (num < DBL_MIN)
         num = DBL_MIN;
-    double denom = 1. - pow(1. - ep, (double)model_points);
+    double denom = 1. - svo_powi(1. - ep, model_points);  // include/svo_math.h: the oracle runs the same operations
     if (denom < DBL_MIN)
         return 0;
-    num = log(num);
-    denom = log(denom);
+    num = svo_log(num);
+    denom = svo_log(denom);
     return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)rint(num / denom);
 }
 

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/svo.h"
+#include "../../include/svo_math.h"  // the transcendental functions of the geometry solvers, shared with the oracle
 
 #define SVO_MAX_LEVELS 4
 #define SVO_LK_WIN 21

@@ -37,18 +37,11 @@ def test_fransac_matches_oracle(ctx, orc, thr, seed):
     x1, x2, gt, *_ = two_view(n=1200, n_out=300, seed=seed, noise=0.15)
     gc, gmask, gF, git = ctx.fransac(x1, x2, thr, seed=seed)
     oc, omask, oF, oit = orc.fransac(x1, x2, thr, seed=seed)
-    # same samples, same sequential semantics: iteration count and winner agree
-    assert git == oit
-    # masks may differ only for correspondences within float noise of the threshold
-    diff = np.nonzero(gmask != omask)[0]
-    assert len(diff) <= 2, diff
-    if len(diff):
-        e = orc.f_error(oF, x1[diff], x2[diff])
-        assert np.all(np.abs(e - thr * thr) < 1e-3 * thr * thr)
-    assert abs(gc - oc) <= 2
-    # same model up to sign
-    s = np.sign(np.sum(gF * oF))
-    assert np.abs(gF * s - oF).max() < 1e-7
+    # same samples, same sequential semantics, the same arithmetic (include/svo_math.h for the cubic's acos / cos /
+    # cbrt): iteration count, mask, count and model agree BIT FOR BIT
+    assert git == oit and gc == oc
+    assert np.array_equal(gmask, omask)
+    assert np.array_equal(gF, oF)
     assert (gmask.astype(bool) & gt).sum() >= 0.85 * gt.sum()
 
 
@@ -58,7 +51,7 @@ def test_fransac_low_inlier_ratio_runs_phase_two(ctx, orc):
     gc, gmask, gF, git = ctx.fransac(x1, x2, 1.0, seed=11)
     oc, omask, oF, oit = orc.fransac(x1, x2, 1.0, seed=11)
     assert oit > 64 and git == oit
-    assert (gmask != omask).sum() <= 2
+    assert np.array_equal(gmask, omask) and np.array_equal(gF, oF)
     assert (gmask.astype(bool) & gt).sum() >= 0.80 * gt.sum()
 
 
@@ -77,9 +70,7 @@ def test_fransac_full_size(ctx, orc, n, n_out, thr):
     x1, x2, gt, *_ = two_view(n=n, n_out=n_out, seed=8 + n, noise=0.2)
     gc, gmask, gF, git = ctx.fransac(x1, x2, thr, seed=2)
     oc, omask, oF, oit = orc.fransac(x1, x2, thr, seed=2)
-    assert git == oit and (gmask != omask).sum() <= 3
-    s = np.sign(np.sum(gF * oF))
-    assert np.abs(gF * s - oF).max() < 1e-7
+    assert git == oit and np.array_equal(gmask, omask) and np.array_equal(gF, oF)
     assert (gmask.astype(bool) & gt).sum() >= 0.85 * gt.sum()
 
 
@@ -124,9 +115,7 @@ def test_triangulate_matches_oracle(ctx, orc):
     b = (project(X, np.eye(3), np.array([-BASELINE, 0, 0])) + rng.normal(0, 0.3, (4428, 2))).astype(np.float32)
     gx, gh = ctx.triangulate(P1, P2, a, b)
     ox, oh = orc.triangulate(P1, P2, a, b)
-    sign = np.sign(np.sum(gh * oh, axis=1, keepdims=True))
-    assert np.abs(gh * sign - oh).max() < 1e-6
-    assert np.allclose(gx, ox, rtol=1e-5, atol=1e-5)
+    assert np.array_equal(gh, oh) and np.array_equal(gx, ox)   # homogeneous and dehomogenised points, bit for bit
 
 
 def test_triangulate_degenerate_points_are_kept(ctx, orc):
