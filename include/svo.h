@@ -283,6 +283,8 @@ typedef struct svo_vo_params {
                                * set without the F-matrix filter; < 10: plain solvePnP; a stereo
                                * keyframe on EVERY frame; never shuts down.  Frame-by-frame entry
                                * points only (svo_vo_localize / update / track).                    */
+    int pnp_retry_below;      /* src/keyFrameManagement.cpp:85, 10: fewer PnP inliers at 1 px -> the 8 px retry   */
+    int pnp_lost_below;       /* src/keyFrameManagement.cpp:89, 10: fewer after the retry -> SHUTDOWN_FLAG        */
 } svo_vo_params;
 enum { SVO_POLICY_SLAM = 0, SVO_POLICY_VO_LADDER = 1 };
 void svo_vo_default_params(svo_vo_params *p);

@@ -401,20 +401,25 @@ class VoParams(C.Structure):
     _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
                 ("baseline", C.c_double), ("grid_step", C.c_int), ("anms_keep", C.c_int),
                 ("keyframe_min_inliers", C.c_int), ("f_thr_stereo", C.c_double),
-                ("f_thr_temporal", C.c_double), ("seed", C.c_uint64), ("policy", C.c_int)]
+                ("f_thr_temporal", C.c_double), ("seed", C.c_uint64), ("policy", C.c_int),
+                ("pnp_retry_below", C.c_int), ("pnp_lost_below", C.c_int)]
 
 
 class VO:
     """Oracle front-end (src/VisualSLAM.cpp:11-169)."""
 
     def __init__(self, w, h, c, grid_step=30, anms_keep=0, keyframe_min_inliers=200, seed=0, K4=None,
-                 baseline=None, policy=0):
+                 baseline=None, policy=0, pnp_retry_below=None, pnp_lost_below=None):
         lib = load()
         self.prm = VoParams()
         lib.orc_vo_default_params(C.byref(self.prm))
         self.prm.grid_step, self.prm.anms_keep = grid_step, anms_keep
         self.prm.keyframe_min_inliers, self.prm.seed = keyframe_min_inliers, seed
         self.prm.policy = policy
+        if pnp_retry_below is not None:
+            self.prm.pnp_retry_below = pnp_retry_below
+        if pnp_lost_below is not None:
+            self.prm.pnp_lost_below = pnp_lost_below
         if K4 is not None:
             self.prm.fx, self.prm.fy, self.prm.cx, self.prm.cy = K4
         if baseline is not None:

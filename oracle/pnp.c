@@ -684,7 +684,9 @@ double orc_pnp_refine_Rt(const float *obj, const float *img, const int *idx, int
             lambda *= 0.1;
             if (lambda < 1e-12)
                 lambda = 1e-12;
-            if (step <= 1e-20 * scale || prev - err <= 1e-14 * prev)
+            /* CvLevMarq's criterion as cv::solvePnP sets it (20 iterations, FLT_EPSILON): relative change of the
+             * parameter vector, FLT_EPSILON^2 = 2^-46, or an error that no longer decreases */
+            if (step <= 1.4210854715202004e-14 * scale || prev - err <= 1e-10 * prev)
                 break;
         } else {
             lambda *= 10;

@@ -188,6 +188,8 @@ typedef struct {
     double f_thr_stereo, f_thr_temporal; /* 3.0, 1.0                                      */
     uint64_t seed;
     int policy;             /* 0: visualSLAM::initSequence; 1: the older ladder (bundleAdjust.cpp:427-548) */
+    int pnp_retry_below;    /* src/keyFrameManagement.cpp:85, 10 */
+    int pnp_lost_below;     /* src/keyFrameManagement.cpp:89, 10 */
 } orc_vo_params;
 void orc_vo_default_params(orc_vo_params *p);
 

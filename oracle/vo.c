@@ -38,6 +38,8 @@ void orc_vo_default_params(orc_vo_params *p)
     p->f_thr_temporal = 1.0;
     p->seed = 0;
     p->policy = 0;
+    p->pnp_retry_below = 10; /* src/keyFrameManagement.cpp:85 */
+    p->pnp_lost_below = 10;  /* src/keyFrameManagement.cpp:89 */
 }
 
 struct orc_vo {
@@ -265,10 +267,10 @@ int orc_vo_localize(orc_vo *v, const uint8_t *left, double *R, double *t, int *n
     }
     orc_pnp_params pp = {100, 1.0, 0.99, stage_seed(v, 1), 20};
     int ninl = orc_pnp_ransac(v->trk3d, v->trk2d, k, K4, &pp, rvec, tvec, v->idx, 0);
-    if (ninl < 10) { /* src/keyFrameManagement.cpp:85-92 */
+    if (ninl < v->prm.pnp_retry_below) { /* src/keyFrameManagement.cpp:85-92 */
         orc_pnp_params pr = {100, 8.0, 0.98, stage_seed(v, 2), 20};
         ninl = orc_pnp_ransac(v->trk3d, v->trk2d, k, K4, &pr, rvec, tvec, v->idx, 0);
-        if (ninl < 10) {
+        if (ninl < v->prm.pnp_lost_below) {
             if (n_inliers)
                 *n_inliers = ninl;
             return -1;

@@ -43,6 +43,7 @@ struct AnmsJob {
     float2 *out_a, *out_b;
     const uint8_t *in_s;
     uint8_t *out_s;
+    const int *gate;  // optional: the job's workgroups leave at once when *gate == 0 (chain runner: no keyframe)
 };
 struct AnmsBatch {
     AnmsJob j[SVO_LK_MAX_JOBS];
@@ -61,6 +62,8 @@ template <int KPW> __global__ __launch_bounds__(64) void anms_rank_kernel(AnmsBa
 {
     svo_chain_priority();
     const AnmsJob &job = batch.j[blockIdx.y];
+    if (job.gate && *job.gate == 0)
+        return;
     const float2 *__restrict__ xy = job.xy;
     const float *__restrict__ resp = job.resp;
     int *__restrict__ order = job.order;
@@ -126,6 +129,8 @@ template <int KPW> __global__ __launch_bounds__(64) void anms_rank_kernel(AnmsBa
 template <int KPW> __global__ __launch_bounds__(64) void anms_radius_kernel(AnmsBatch batch, int n)
 {
     svo_chain_priority();
+    if (batch.j[blockIdx.y].gate && *batch.j[blockIdx.y].gate == 0)
+        return;
     const float4 *__restrict__ sorted = batch.j[blockIdx.y].sorted;
     double *__restrict__ radius_sq = batch.j[blockIdx.y].radius;
     const int lane = threadIdx.x & 63;
@@ -184,6 +189,8 @@ template <int KPW> __global__ __launch_bounds__(64) void anms_radius_kernel(Anms
 template <int KPW> __global__ __launch_bounds__(64) void anms_decide_kernel(AnmsBatch batch, int n, int keep)
 {
     svo_chain_priority();
+    if (batch.j[blockIdx.y].gate && *batch.j[blockIdx.y].gate == 0)
+        return;
     const double *__restrict__ radius_sq = batch.j[blockIdx.y].radius;
     double *__restrict__ decision = batch.j[blockIdx.y].decision;
     const int lane = threadIdx.x & 63;
@@ -231,6 +238,8 @@ __global__ __launch_bounds__(1024) void anms_gather_kernel(AnmsBatch batch, int 
 {
     svo_chain_priority();
     const AnmsJob &job = batch.j[blockIdx.x];  // one workgroup per job
+    if (job.gate && *job.gate == 0)
+        return;
     const double *__restrict__ radius_sq = job.radius;
     const double decision = *job.decision;
     const int *__restrict__ order = job.order;
@@ -267,19 +276,25 @@ __global__ __launch_bounds__(1024) void anms_gather_kernel(AnmsBatch batch, int 
         }
 }
 
-__global__ void set_int_kernel(int *p, int v) { *p = v; }
-
-// everything is kept (n <= numToKeep): the payload in sorted order
+// everything is kept (n <= numToKeep): the index list, its count and the payload in sorted order
 __global__ __launch_bounds__(64) void anms_payload_kernel(AnmsBatch batch, int n)
 {
     const AnmsJob &job = batch.j[blockIdx.y];
+    if (job.gate && *job.gate == 0)
+        return;
     const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= n || !job.out_a)
+    if (i == 0)
+        *job.d_count = n;
+    if (i >= n)
         return;
     const int j = job.order[i];
+    job.out_idx[i] = j;
+    if (!job.out_a)
+        return;
     job.out_a[i] = job.in_a[j];
     job.out_b[i] = job.in_b[j];
-    job.out_s[i] = job.in_s[j];
+    if (job.out_s)
+        job.out_s[i] = job.in_s[j];
 }
 
 }  // namespace
@@ -287,7 +302,7 @@ __global__ __launch_bounds__(64) void anms_payload_kernel(AnmsBatch batch, int n
 // Device form, several problems of the same size n.  out_idx: n ints (input indices of the kept
 // keypoints, response order); d_count: device int.  Uses ctx->w_a..w_d as scratch.
 int svo_launch_anms_batch(svo_ctx *ctx, int k, const float *const *xy, const float *const *resp, int n, int keep,
-                          int *const *out_idx, int *const *d_count, const svo_anms_gather *gather)
+                          int *const *out_idx, int *const *d_count, const svo_anms_gather *gather, const int *const *gates)
 {
     if (n <= 0 || k <= 0)
         return SVO_OK;
@@ -319,6 +334,7 @@ int svo_launch_anms_batch(svo_ctx *ctx, int k, const float *const *xy, const flo
         j.out_b = gather ? reinterpret_cast<float2 *>(gather[q].out_b) : nullptr;
         j.in_s = gather ? gather[q].in_s : nullptr;
         j.out_s = gather ? gather[q].out_s : nullptr;
+        j.gate = gates ? gates[q] : nullptr;
     }
     // single-wave workgroups: beside a tracking launch (single-wave workgroups that take every freed wave
     // slot at once) a multi-wave workgroup waits until one CU has a slot free on several SIMDs together
@@ -330,13 +346,8 @@ int svo_launch_anms_batch(svo_ctx *ctx, int k, const float *const *xy, const flo
     else
         hipLaunchKernelGGL(anms_rank_kernel<KPW_GROUP>, wgrid, block, 0, ctx->stream, batch, n);
     if (n <= keep) {
-        // everything is kept, in sorted order
-        for (int a = 0; a < k; a++) {
-            SVO_HIP(hipMemcpyAsync(out_idx[a], batch.j[a].order, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx->stream));
-            hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(1), 0, ctx->stream, d_count[a], n);
-        }
-        if (gather)
-            hipLaunchKernelGGL(anms_payload_kernel, dim3((n + 63) / 64, k), dim3(64), 0, ctx->stream, batch, n);
+        // everything is kept, in sorted order (one launch: index list, count, payload)
+        hipLaunchKernelGGL(anms_payload_kernel, dim3((n + 63) / 64, k), dim3(64), 0, ctx->stream, batch, n);
         SVO_HIP(hipGetLastError());
         return SVO_OK;
     }

@@ -51,6 +51,7 @@ struct FrJob {
     float *c_out[3];
     int c_stride[3];
     int *c_count;
+    const int *gate;  // optional: every wave of the job leaves at once when *gate == 0 (chain runner)
 };
 struct FrBatch {
     FrJob j[SVO_LK_MAX_JOBS];
@@ -382,6 +383,8 @@ __global__ __launch_bounds__(LEAN ? 64 : 256, LEAN ? 5 : 4) void fr_ransac_kerne
     constexpr int NW = LEAN ? 1 : 4;  // waves per workgroup
     svo_chain_priority();
     const FrJob &job = batch.j[blockIdx.y];
+    if (job.gate && *job.gate == 0)
+        return;  // not due (the frame is no keyframe / the chain halted): no ticket is taken, the counters stay at rest
     const float2 *__restrict__ p1 = reinterpret_cast<const float2 *>(job.p1);
     const float2 *__restrict__ p2 = reinterpret_cast<const float2 *>(job.p2);
     const int n_host = job.n_host;
@@ -619,6 +622,7 @@ int svo_launch_fransac_batch(svo_ctx *ctx, int n_jobs, const svo_fransac_job *jo
             j.c_stride[a] = c ? c->stride[a] : 0;
         }
         j.c_count = h.then_compact ? h.then_compact->d_count : nullptr;
+        j.gate = h.gate;
         nb++;
     }
     if (nb == 0)

@@ -30,26 +30,14 @@ struct PnpRecord {  // layout of pnp.hip's PnpResult + the tracked-point count b
     int n_tracked, pad;
 };
 
-// Pinned, fine-grained host memory the chunk runner's kernels publish into; the host spins on the
-// tags instead of asking the runtime about events (no copy engine, no runtime lock on the way).
-struct Mailbox {
-    int early[4];     // tag, RANSAC inlier count, tracked points
-    int pose_tag[2];  // per record slot
-    int pad[2];
-    PnpRecord rec[2];
-};
-
 struct svo_vo {
     svo_ctx *ctx = nullptr;
-    Mailbox *mbox = nullptr;
-    int tag = 0;
     svo_vo_params prm;
     int w = 0, h = 0, c = 0, cap = 0;
-    svo_pyramid *pyr_ref = nullptr, *pyr_cur = nullptr, *pyr_right = nullptr, *pyr_next = nullptr;
+    svo_pyramid *pyr_ref = nullptr, *pyr_cur = nullptr, *pyr_right = nullptr, *pyr_next = nullptr, *pyr_right2 = nullptr;
     hipStream_t stream_b = nullptr;          // second stream: PnP of frame t beside pyramid + LK of frame t+1
     hipEvent_t ev_a = nullptr;               // "tracked sets of frame t are ready" (stream A -> B)
-    float *sa2 = nullptr;                    // speculative LK output for frame t+1
-    uint8_t *sstatus = nullptr;
+    hipEvent_t ev_b = nullptr;               // "frame t is localised" (stream B -> A)
     // point sets (device)
     float *ref2d = nullptr, *ref3d = nullptr, *trk2d = nullptr, *trk3d = nullptr;
     float *a2 = nullptr, *b2 = nullptr, *c2 = nullptr, *d2 = nullptr, *a3 = nullptr, *b3 = nullptr, *resp = nullptr;
@@ -58,6 +46,11 @@ struct svo_vo {
     int *idx = nullptr, *d_cnt = nullptr;  // d_cnt[0..7]: stage counts
     PnpRecord *d_rec = nullptr;
     uint8_t *d_img = nullptr;  // staging for host images
+    // the chain runner's device-resident frame state (svo_internal.h: VoChain), its pinned staging copy and the pinned
+    // per-frame records the kernels fill
+    VoChain *d_chain = nullptr, *h_chain = nullptr;
+    VoOut *h_out = nullptr;
+    int out_cap = 0;
     int nref = 0, ntrk = 0, frame = 0;
     int kf_n = 0;  // points of the last keyframe's camera-frame cloud in b3
     int ladder_ransac_inliers = 0;
@@ -75,37 +68,6 @@ template <class T> int dev_alloc(T **p, size_t count)
         return SVO_ERR_HIP;
     }
     return SVO_OK;
-}
-
-// Spin on a tag a kernel releases into the pinned mailbox.  Now and then the stream is asked whether
-// it is still alive (an error, or a stream that drained without publishing, ends the wait), and a
-// wall-clock bound ends a wait on a stream that hangs without reporting an error.
-constexpr double SVO_MAILBOX_TIMEOUT_S = 60.0;
-int wait_mailbox_tag(const int *slot, int tag, hipStream_t stream)
-{
-    std::chrono::steady_clock::time_point t0;
-    bool timing = false;
-    for (unsigned spins = 1;; spins++) {
-        if (__atomic_load_n(slot, __ATOMIC_ACQUIRE) == tag)
-            return SVO_OK;
-        if ((spins & 0x3FFFF) == 0) {
-            hipError_t e = hipStreamQuery(stream);
-            if (e == hipSuccess && __atomic_load_n(slot, __ATOMIC_ACQUIRE) != tag)
-                e = hipErrorUnknown;  // drained without publishing
-            if (e != hipSuccess && e != hipErrorNotReady) {
-                svo_set_error("waiting for the PnP mailbox -> %s", hipGetErrorString(e));
-                return SVO_ERR_HIP;
-            }
-            const auto now = std::chrono::steady_clock::now();
-            if (!timing) {
-                t0 = now;
-                timing = true;
-            } else if (std::chrono::duration<double>(now - t0).count() > SVO_MAILBOX_TIMEOUT_S) {
-                svo_set_error("waiting for the PnP mailbox: no tag after %.0f s, the stream hangs", SVO_MAILBOX_TIMEOUT_S);
-                return SVO_ERR_HIP;
-            }
-        }
-    }
 }
 
 int grid_axis(int dim, int step)
@@ -139,8 +101,11 @@ const uint8_t *stage_image(svo_vo *v, const uint8_t *img, int mem, int *rc)
 // and ANMS budget): every stage is one set of launches.  Per front-end: x1 -> out2d, camera-frame
 // points -> v->b3 and, when Rt is given, world points -> out3d (else the camera-frame points).
 // Count -> d_cnt[4] and host.
+// chained: the chain runner's form -- every kernel of job a runs only when vs[a]->d_chain->kf is set, [R|t] is the
+// pose the device holds (Rts ignored), the count goes to the chain state, nothing is waited for (n_out untouched).
 int stereo_triangulate_batch(int k, svo_vo *const *vs, svo_pyramid *const *lefts, svo_pyramid *const *rights,
-                             const double *const *Rts, float *const *out2d, float *const *out3d, int *const *n_out)
+                             const double *const *Rts, float *const *out2d, float *const *out3d, int *const *n_out,
+                             bool chained = false)
 {
     svo_vo *v0 = vs[0];
     svo_ctx *ctx = v0->ctx;
@@ -161,9 +126,13 @@ int stereo_triangulate_batch(int k, svo_vo *const *vs, svo_pyramid *const *lefts
         q.status = v->status;
         q.err = nullptr;
         q.min_eig = v->resp;
+        q.gate = chained ? &v->d_chain->kf : nullptr;
     }
     if ((rc = svo_launch_lk_batch(ctx, k, lk, lefts[0])))
         return rc;
+    const int *gates[SVO_LK_MAX_JOBS];
+    for (int a = 0; a < k; a++)
+        gates[a] = chained ? &vs[a]->d_chain->kf : nullptr;
     const float *pts[SVO_LK_MAX_JOBS], *trk[SVO_LK_MAX_JOBS];
     const uint8_t *stt[SVO_LK_MAX_JOBS];
     const int *d_n[SVO_LK_MAX_JOBS];
@@ -187,7 +156,7 @@ int stereo_triangulate_batch(int k, svo_vo *const *vs, svo_pyramid *const *lefts
         }
         // the kept keypoints' lattice points, tracked points and status bytes come out of the same launch
         // that lists them (a gather launch of its own before)
-        if ((rc = svo_launch_anms_batch(ctx, k, xy, resp, n, v0->prm.anms_keep, oidx, ocnt, ga)))
+        if ((rc = svo_launch_anms_batch(ctx, k, xy, resp, n, v0->prm.anms_keep, oidx, ocnt, ga, chained ? gates : nullptr)))
             return rc;
         for (int a = 0; a < k; a++) {
             pts[a] = vs[a]->c2;
@@ -204,19 +173,24 @@ int stereo_triangulate_batch(int k, svo_vo *const *vs, svo_pyramid *const *lefts
         svo_vo *v = vs[a];
         float *o1 = pts[a] == v->grid_xy ? v->c2 : v->a2, *o2 = pts[a] == v->grid_xy ? v->d2 : v->b2;
         float *x1 = out2d[a], *x2 = o1 == v->a2 ? v->c2 : v->a2;
-        c1[a] = {stt[a], n, d_n[a], {pts[a], trk[a], nullptr}, {o1, o2, nullptr}, {2, 2, 0}, v->d_cnt + 3};
+        c1[a] = {stt[a], n, d_n[a], {pts[a], trk[a], nullptr}, {o1, o2, nullptr}, {2, 2, 0}, v->d_cnt + 3, gates[a]};
         // FmatThresholding (src/tracking.cpp:30-43): 3 px, 0.99
         c2[a] = {v->mask, n, v->d_cnt + 3, {o1, o2, nullptr}, {x1, x2, nullptr}, {2, 2, 0}, v->d_cnt + 4};
         fj[a] = {o1, o2, n, v->d_cnt + 3, v->prm.f_thr_stereo, 0.99, 1000, stage_seed(v, 3), v->mask, nullptr, nullptr,
-                 nullptr, &c2[a]};  // the mask compaction rides with the F-RANSAC
-        tj[a] = {x1, x2, n, v->d_cnt + 4, Rts[a] ? v->b3 : out3d[a], nullptr, Rts[a], Rts[a] ? out3d[a] : nullptr,
-                 reinterpret_cast<int *>(ctx->pinned) + a};  // the count the host reads after the wait below
+                 nullptr, &c2[a], gates[a]};  // the mask compaction rides with the F-RANSAC
+        if (chained)  // [R|t] and the gate come from the chain state; the count goes there
+            tj[a] = {x1, x2, n, v->d_cnt + 4, v->b3, nullptr, nullptr, out3d[a], nullptr, v->d_chain};
+        else
+            tj[a] = {x1, x2, n, v->d_cnt + 4, Rts[a] ? v->b3 : out3d[a], nullptr, Rts[a], Rts[a] ? out3d[a] : nullptr,
+                     reinterpret_cast<int *>(ctx->pinned) + a};  // the count the host reads after the wait below
     }
     double P1[12], P2[12];
     svo_stereo_projections(v0->prm.fx, v0->prm.fy, v0->prm.cx, v0->prm.cy, v0->prm.baseline, P1, P2);
     if ((rc = svo_launch_compact_batch(ctx, k, c1)) || (rc = svo_launch_fransac_batch(ctx, k, fj)) ||
         (rc = svo_launch_triangulate_batch(ctx, P1, P2, k, tj)))
         return rc;
+    if (chained)
+        return SVO_OK;
     int *pin = reinterpret_cast<int *>(ctx->pinned);
     if ((rc = svo_wait(ctx)))
         return rc;
@@ -227,33 +201,28 @@ int stereo_triangulate_batch(int k, svo_vo *const *vs, svo_pyramid *const *lefts
     return SVO_OK;
 }
 
-// the PnP-RANSAC problem of a localisation as the chunk runners queue it: solvePnPRansac(100, thr, conf) with
-// the inlier count published early (mailbox `early`) and the finished record into mailbox slot `slot`
-svo_pnp_job pnp_job(svo_vo *v, int cap, const int *cnt_trk, double thr, double conf, uint64_t seed, PnpRecord *d_rec,
-                    int early_tag, int slot, int pose_tag)
+// the PnP-RANSAC problem of a localisation as the chain runner queues it: solvePnPRansac(100, 1 px, 0.99) over the
+// tracked sets, the frame's policy decided by the finishing kernel (VoChain)
+svo_pnp_job pnp_job(svo_vo *v, const int *cnt_trk, uint64_t seed)
 {
     svo_pnp_job q;
     q.obj = v->trk3d;
     q.img = v->trk2d;
-    q.cap = cap;
+    q.cap = v->cap;
     q.d_n = cnt_trk;
     q.K4[0] = v->prm.fx;
     q.K4[1] = v->prm.fy;
     q.K4[2] = v->prm.cx;
     q.K4[3] = v->prm.cy;
     q.iterations = 100;
-    q.reproj_err = thr;
-    q.confidence = conf;
+    q.reproj_err = 1.0;
+    q.confidence = 0.99;
     q.seed = seed;
     q.refine_iters = 20;
     q.inliers = v->idx;
     q.mask = nullptr;
-    q.d_result = d_rec;
-    q.early_mbox = v->mbox->early;
-    q.early_tag = early_tag;
-    q.h_rec = &v->mbox->rec[slot];
-    q.h_tag = &v->mbox->pose_tag[slot];
-    q.tag = pose_tag;
+    q.d_result = v->d_rec;
+    q.chain = v->d_chain;
     q.cnt_trk = cnt_trk;
     return q;
 }
@@ -333,6 +302,8 @@ void svo_vo_default_params(svo_vo_params *p)
     p->f_thr_temporal = 1.0;        // src/tracking.cpp:75
     p->seed = 0;
     p->policy = SVO_POLICY_SLAM;
+    p->pnp_retry_below = 10;  // src/keyFrameManagement.cpp:85
+    p->pnp_lost_below = 10;   // src/keyFrameManagement.cpp:89
 }
 
 int svo_vo_create(svo_ctx *ctx, const svo_vo_params *params, int width, int height, int channels, svo_vo **out)
@@ -341,6 +312,7 @@ int svo_vo_create(svo_ctx *ctx, const svo_vo_params *params, int width, int heig
     SVO_CHECK_ARG(channels == 1 || channels == 3);
     SVO_CHECK_ARG(params->grid_step > 0 && params->keyframe_min_inliers >= 0);
     SVO_CHECK_ARG(params->policy == SVO_POLICY_SLAM || params->policy == SVO_POLICY_VO_LADDER);
+    SVO_CHECK_ARG(params->pnp_retry_below >= 1 && params->pnp_lost_below >= 1);
     *out = nullptr;
     SVO_HIP(hipSetDevice(ctx->device));
     svo_vo *v = new svo_vo();
@@ -358,8 +330,9 @@ int svo_vo_create(svo_ctx *ctx, const svo_vo_params *params, int width, int heig
         (rc = svo_pyramid_create(ctx, width, height, channels, SVO_MAX_LEVELS, &v->pyr_cur)) ||
         // the right image is only ever the SECOND image of a tracking pass: no derivative levels
         (rc = svo_pyramid_create_ex(ctx, width, height, channels, SVO_MAX_LEVELS, false, &v->pyr_right)) ||
+        (rc = svo_pyramid_create_ex(ctx, width, height, channels, SVO_MAX_LEVELS, false, &v->pyr_right2)) ||
         (rc = svo_pyramid_create(ctx, width, height, channels, SVO_MAX_LEVELS, &v->pyr_next)) ||
-        (rc = dev_alloc(&v->sa2, n * 2)) || (rc = dev_alloc(&v->sstatus, n)) ||
+        (rc = dev_alloc(&v->d_chain, 1)) ||
         (rc = dev_alloc(&v->ref2d, n * 2)) || (rc = dev_alloc(&v->ref3d, n * 3)) ||
         (rc = dev_alloc(&v->trk2d, n * 2)) || (rc = dev_alloc(&v->trk3d, n * 3)) ||
         (rc = dev_alloc(&v->a2, n * 2)) || (rc = dev_alloc(&v->b2, n * 2)) || (rc = dev_alloc(&v->c2, n * 2)) ||
@@ -373,13 +346,12 @@ int svo_vo_create(svo_ctx *ctx, const svo_vo_params *params, int width, int heig
         return rc;
     }
     if (hipEventCreateWithFlags(&v->ev_a, hipEventDisableTiming) != hipSuccess ||
-        hipHostMalloc(reinterpret_cast<void **>(&v->mbox), sizeof(Mailbox),
-                      hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
-        svo_set_error("front-end: cannot create the second stream / event");
+        hipEventCreateWithFlags(&v->ev_b, hipEventDisableTiming) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void **>(&v->h_chain), sizeof(VoChain), hipHostMallocDefault) != hipSuccess) {
+        svo_set_error("front-end: cannot create the events / the pinned state block");
         svo_vo_destroy(v);
         return SVO_ERR_HIP;
     }
-    memset(v->mbox, 0, sizeof(Mailbox));  // a recycled pinned block may hold a destroyed front-end's tags
     for (int i = 0; i < 9; i++)
         v->R[i] = (i % 4) == 0;
     v->t[0] = v->t[1] = v->t[2] = 0;
@@ -397,18 +369,21 @@ int svo_vo_destroy(svo_vo *v)
     svo_pyramid_destroy(v->ctx, v->pyr_cur);
     svo_pyramid_destroy(v->ctx, v->pyr_right);
     svo_pyramid_destroy(v->ctx, v->pyr_next);
+    svo_pyramid_destroy(v->ctx, v->pyr_right2);
     if (v->stream_b) {
         (void)hipStreamSynchronize(v->stream_b);
         (void)hipStreamDestroy(v->stream_b);
     }
     if (v->ev_a)
         (void)hipEventDestroy(v->ev_a);
-    if (v->mbox)
-        (void)hipHostFree(v->mbox);
-    if (v->sa2)
-        (void)hipFree(v->sa2);
-    if (v->sstatus)
-        (void)hipFree(v->sstatus);
+    if (v->ev_b)
+        (void)hipEventDestroy(v->ev_b);
+    if (v->h_chain)
+        (void)hipHostFree(v->h_chain);
+    if (v->h_out)
+        (void)hipHostFree(v->h_out);
+    if (v->d_chain)
+        (void)hipFree(v->d_chain);
     void *bufs[] = {v->ref2d, v->ref3d, v->trk2d, v->trk3d, v->a2,   v->b2,    v->c2,    v->d2,   v->a3,
                     v->b3,    v->resp,  v->status, v->mask, v->st2, v->idx,   v->d_cnt, v->d_rec, v->d_img,
                     v->grid_xy};
@@ -518,7 +493,7 @@ int svo_vo_localize(svo_vo *v, const uint8_t *left, int mem, double *R9, double 
         SVO_HIP(hipMemcpyAsync(ctx->pinned, v->d_rec, sizeof(PnpRecord), hipMemcpyDeviceToHost, ctx->stream));
         if ((rc = svo_wait(ctx)))
             return rc;
-        if (rec->n_inliers >= 10)
+        if (rec->n_inliers >= (attempt ? v->prm.pnp_lost_below : v->prm.pnp_retry_below))
             break;
     }
     v->ntrk = rec->n_tracked;
@@ -526,7 +501,7 @@ int svo_vo_localize(svo_vo *v, const uint8_t *left, int mem, double *R9, double 
         *n_inliers = rec->n_inliers;
     if (n_tracked)
         *n_tracked = rec->n_tracked;
-    if (rec->n_inliers < 10) {
+    if (rec->n_inliers < v->prm.pnp_lost_below) {
         svo_set_error("tracking lost at frame %d: %d PnP inliers", v->frame, rec->n_inliers);
         return SVO_ERR_TRACKING_LOST;
     }
@@ -592,18 +567,456 @@ int svo_vo_track(svo_vo *v, const uint8_t *left, const uint8_t *right, int mem, 
     return svo_vo_update(v, right, mem, R9, t3, ninl, force_keyframe, was_keyframe);
 }
 
-// A run of consecutive frames through the front-end without returning to the caller between
-// frames (the "chunk runner" of SURVEY.md 8b/8e): exactly the result of n_frames calls of
-// svo_vo_track(..., force_keyframe = 0), frame by frame.
+// ---- the chain runner --------------------------------------------------------------------------------------------
+// A run of consecutive frames WITHOUT the host in the loop (the "chunk runner" of SURVEY.md 8b/8e): the host queues the
+// launches of every frame and waits ONCE, when all of them are queued.  The per-frame decisions of the reference's
+// host policy are taken by pnp_finish_kernel on the device (VoChain, svo_internal.h):
+//   keyframe iff fewer than keyframe_min_inliers PnP inliers    src/VisualSLAM.cpp:120
+//   no keyframe: the tracked sets become the reference sets    src/VisualSLAM.cpp:143-146 (a copy inside pnp_finish)
+//   keyframe: insertKeyFrames at the refined pose               src/keyFrameManagement.cpp:9-31
+// The keyframe path (LK left -> right, ANMS, status filter, F-RANSAC, DLT triangulation) is queued for EVERY frame; its
+// kernels leave at once unless the device flag says keyframe.  The rare slow paths stop the chain (every later kernel
+// of the chunk leaves at once) and come back to the host: fewer than 10 inliers at 1 px -- the 8 px retry of
+// src/keyFrameManagement.cpp:85-92 -- and a reference set of fewer than 5 points.  The host handles the frame with the
+// frame-by-frame code and queues the rest of the chunk again.
 //
-// With pipeline != 0 the loop overlaps work on two HIP streams.  Stream A carries a frame's
-// pyramid, LK, filters and the keyframe path; the PnP-RANSAC of frame t (a handful of
-// wavefronts of f64 latency) runs on stream B while stream A already builds the pyramid of
-// frame t+1 and tracks into it from the points frame t kept -- which is what frame t+1 will do
-// unless frame t turns out to be a keyframe (fewer PnP inliers than the threshold).  In that
-// case the speculative tracking is discarded and redone from the new keyframe's points; the
-// pyramid is kept.  Scheduling only: every stage sees the same inputs as in the serial order,
-// so results are identical (tests/test_gpu_frontend.py::test_run_chunk_*).
+// Results: exactly those of n_frames calls of svo_vo_track(..., force_keyframe = 0) -- every stage sees the same
+// inputs and seeds (tests/test_gpu_frontend.py::test_run_chunk_*).
+//
+// pipeline (one chunk, device images): two HIP streams.  Stream A carries a frame's filters and the keyframe path;
+// the PnP-RANSAC of frame t runs on stream B while stream A builds the pyramid of frame t+1 and tracks into it from
+// the points frame t kept -- which is what frame t+1 does unless frame t turns out to be a keyframe, in which case a
+// second tracking launch (gated on the keyframe flag) redoes it from the new keyframe's points.
+struct ChainRun {            // one chunk of a lock-step set
+    svo_vo *v;
+    const uint8_t *const *lefts, *const *rights;
+    int n_frames, mem;
+    // results (caller's arrays, any may be null except R_out / t_out)
+    double *R_out, *t_out;
+    int *inliers_out, *tracked_out;
+    uint8_t *keyframe_out;
+    int n_done = 0, rc = SVO_OK;
+    // working state
+    int frame0 = 0;                                  // v->frame when the run was queued
+    svo_pyramid *p0 = nullptr, *p1 = nullptr, *p2 = nullptr;  // pyramid roles when the run was queued: ref, cur, next
+    VoChain end;                                     // the chain state after the run
+};
+
+static int chain_prepare(ChainRun &r)
+{
+    svo_vo *v = r.v;
+    if (r.n_frames > v->out_cap) {
+        if (v->h_out)
+            (void)hipHostFree(v->h_out);
+        v->h_out = nullptr;
+        v->out_cap = 0;
+        const int cap = r.n_frames + r.n_frames / 2 + 16;
+        SVO_HIP(hipHostMalloc(reinterpret_cast<void **>(&v->h_out), sizeof(VoOut) * (size_t)cap, hipHostMallocDefault));
+        v->out_cap = cap;
+    }
+    VoChain *c = v->h_chain;
+    memset(c, 0, sizeof(*c));
+    c->run = 1;
+    c->kf = 0;
+    c->nref = v->nref;
+    c->frame = 0;
+    c->halt_code = SVO_HALT_NONE;
+    c->kf_n = v->kf_n;
+    memcpy(c->R, v->R, sizeof(c->R));
+    memcpy(c->t, v->t, sizeof(c->t));
+    c->kf_min = v->prm.keyframe_min_inliers;
+    c->retry_below = v->prm.pnp_retry_below;  // src/keyFrameManagement.cpp:85
+    c->ref2d = v->ref2d;
+    c->ref3d = v->ref3d;
+    c->trk2d = v->trk2d;
+    c->trk3d = v->trk3d;
+    c->out = v->h_out;
+    // the previous run's wait has long returned: the pinned staging copy is free again
+    SVO_HIP(hipMemcpyAsync(v->d_chain, c, sizeof(VoChain), hipMemcpyHostToDevice, v->ctx->stream));
+    r.frame0 = v->frame;
+    r.p0 = v->pyr_ref;
+    r.p1 = v->pyr_cur;
+    r.p2 = v->pyr_next;
+    r.n_done = 0;
+    r.rc = SVO_OK;
+    return SVO_OK;
+}
+
+// queue the tracking pass ref -> cur of k chunks as one launch
+static int chain_lk(svo_ctx *ctx, int k, svo_vo *const *vs, svo_pyramid *const *prev, svo_pyramid *const *next,
+                    const float *const *pts, const int *const *d_n, const int *const *gates)
+{
+    LkJob lk[SVO_LK_MAX_JOBS];
+    for (int a = 0; a < k; a++) {
+        LkJob &q = lk[a];
+        q.prev = prev[a]->dev;
+        q.next = next[a]->dev;
+        q.dprev = prev[a]->dbase;
+        q.prev_pts = pts[a];
+        q.n_cap = vs[a]->cap;
+        q.d_n = d_n[a];
+        q.next_pts = vs[a]->a2;
+        q.status = vs[a]->status;
+        q.err = nullptr;
+        q.min_eig = nullptr;
+        q.gate = gates[a];
+    }
+    return svo_launch_lk_batch(ctx, k, lk, prev[0]);
+}
+
+// status filter (src/tracking.cpp:54-64), F-RANSAC at 1 px + its mask filter (:75-88): the tracked sets and their count
+static int chain_filters(svo_ctx *ctx, int k, svo_vo *const *vs)
+{
+    svo_compact_job c1[SVO_LK_MAX_JOBS], c2[SVO_LK_MAX_JOBS];
+    svo_fransac_job fj[SVO_LK_MAX_JOBS];
+    for (int a = 0; a < k; a++) {
+        svo_vo *v = vs[a];
+        const int *run = &v->d_chain->run;
+        c1[a] = {v->status, v->cap, &v->d_chain->nref, {v->ref2d, v->a2, v->ref3d}, {v->b2, v->c2, v->a3}, {2, 2, 3},
+                 v->d_cnt, run};
+        c2[a] = {v->mask, v->cap, v->d_cnt, {v->c2, v->a3, nullptr}, {v->trk2d, v->trk3d, nullptr}, {2, 3, 0}, v->d_cnt + 1};
+        svo_fransac_job &q = fj[a];
+        q.p1 = v->b2;
+        q.p2 = v->c2;
+        q.cap = v->cap;
+        q.d_n = v->d_cnt;
+        q.threshold = v->prm.f_thr_temporal;
+        q.confidence = 0.99;
+        q.max_iters = 1000;
+        q.seed = stage_seed(v, 0);
+        q.mask = v->mask;
+        q.d_F = nullptr;
+        q.d_count = nullptr;
+        q.d_iters = nullptr;
+        q.then_compact = &c2[a];  // the mask compaction rides with the F-RANSAC
+        q.gate = run;
+    }
+    int rc;
+    if ((rc = svo_launch_compact_batch(ctx, k, c1)) || (rc = svo_launch_fransac_batch(ctx, k, fj)))
+        return rc;
+    return SVO_OK;
+}
+
+static int chain_pnp(svo_ctx *ctx, int k, svo_vo *const *vs)
+{
+    svo_pnp_job pj[SVO_LK_MAX_JOBS];
+    for (int a = 0; a < k; a++)
+        pj[a] = pnp_job(vs[a], vs[a]->d_cnt + 1, stage_seed(vs[a], 1));
+    return svo_launch_pnp_ransac_batch(ctx, k, pj);
+}
+
+// Queue frames [0, n) of k chunks that share a context (lock step: every stage one set of launches for all of them;
+// chunks may differ in length).  pipeline: k == 1, device images.
+static int chain_enqueue(ChainRun *const *runs, int k, bool pipeline)
+{
+    svo_vo *v0 = runs[0]->v;
+    svo_ctx *ctx = v0->ctx;
+    hipStream_t sA = ctx->stream;
+    int n_max = 0, rc;
+    for (int a = 0; a < k; a++)
+        n_max = runs[a]->n_frames > n_max ? runs[a]->n_frames : n_max;
+    if (n_max == 0)
+        return SVO_OK;
+    auto upload = [&](svo_vo *v, const uint8_t *img, int mem) -> const uint8_t * {  // host images: the one staging buffer
+        return stage_image(v, img, mem, &rc);
+    };
+    svo_vo *vs[SVO_LK_MAX_JOBS];
+    svo_pyramid *prevs[SVO_LK_MAX_JOBS], *nexts[SVO_LK_MAX_JOBS];
+    const float *pts[SVO_LK_MAX_JOBS];
+    const int *dn[SVO_LK_MAX_JOBS], *gates[SVO_LK_MAX_JOBS];
+    // the pyramids of one frame of the active chunks: the left images and, in the same set of launches, the right ones
+    auto build = [&](int na, svo_vo *const *va, svo_pyramid *const *lp, svo_pyramid *const *rp, const uint8_t *const *li,
+                     const uint8_t *const *ri, int mem) -> int {
+        if (mem == SVO_MEM_HOST) {  // one chunk, one staging buffer: upload + build, twice
+            const int *g = &va[0]->d_chain->run;
+            const uint8_t *d = upload(va[0], li[0], mem);
+            if (rc || (rc = svo_build_pyramids_from_device(ctx, 1, &lp[0], &d, &g)))
+                return rc;
+            d = upload(va[0], ri[0], mem);
+            if (rc || (rc = svo_build_pyramids_from_device(ctx, 1, &rp[0], &d, &g)))
+                return rc;
+            return SVO_OK;
+        }
+        svo_pyramid *pyrs[2 * SVO_LK_MAX_JOBS];
+        const uint8_t *imgs[2 * SVO_LK_MAX_JOBS];
+        const int *g[2 * SVO_LK_MAX_JOBS];
+        for (int a = 0; a < na; a++) {
+            pyrs[a] = lp[a];
+            imgs[a] = li[a];
+            pyrs[na + a] = rp[a];
+            imgs[na + a] = ri[a];
+            g[a] = g[na + a] = &va[a]->d_chain->run;
+        }
+        return svo_build_pyramids_from_device(ctx, 2 * na, pyrs, imgs, g);
+    };
+    if (pipeline) {
+        ChainRun &r = *runs[0];
+        svo_vo *v = r.v;
+        hipStream_t sB = v->stream_b;
+        svo_pyramid *ref = v->pyr_ref, *cur = v->pyr_cur, *nxt = v->pyr_next;
+        svo_pyramid *right[2] = {v->pyr_right, v->pyr_right2};
+        const int *run = &v->d_chain->run, *kf = &v->d_chain->kf;
+        vs[0] = v;
+        // prologue: the pyramids of frame 0 and its tracking pass
+        {
+            const uint8_t *li = r.lefts[0], *ri = r.rights[0];
+            if ((rc = build(1, vs, &cur, &right[0], &li, &ri, r.mem)))
+                return rc;
+            pts[0] = v->ref2d;
+            dn[0] = &v->d_chain->nref;
+            gates[0] = run;
+            if ((rc = chain_lk(ctx, 1, vs, &ref, &cur, pts, dn, gates)))
+                return rc;
+        }
+        for (int f = 0; f < r.n_frames; f++) {
+            v->frame++;
+            if ((rc = chain_filters(ctx, 1, vs)))
+                return rc;
+            // PnP of this frame on stream B
+            SVO_HIP(hipEventRecord(v->ev_a, sA));
+            SVO_HIP(hipStreamWaitEvent(sB, v->ev_a, 0));
+            ctx->stream = sB;
+            rc = chain_pnp(ctx, 1, vs);
+            ctx->stream = sA;
+            if (rc)
+                return rc;
+            SVO_HIP(hipEventRecord(v->ev_b, sB));
+            const bool more = f + 1 < r.n_frames;
+            if (more) {  // beside it on stream A: the next frame's pyramids and its tracking pass from the tracked set
+                const uint8_t *li = r.lefts[f + 1], *ri = r.rights[f + 1];
+                if ((rc = build(1, vs, &nxt, &right[(f + 1) & 1], &li, &ri, r.mem)))
+                    return rc;
+                pts[0] = v->trk2d;
+                dn[0] = v->d_cnt + 1;
+                gates[0] = run;
+                if ((rc = chain_lk(ctx, 1, vs, &cur, &nxt, pts, dn, gates)))
+                    return rc;
+            }
+            SVO_HIP(hipStreamWaitEvent(sA, v->ev_b, 0));
+            // the keyframe path (leaves at once unless the frame is a keyframe), then the tracking pass again from
+            // the keyframe's points
+            {
+                float *o2 = v->ref2d, *o3 = v->ref3d;
+                const double *noRt = nullptr;
+                int *non = nullptr;
+                if ((rc = stereo_triangulate_batch(1, vs, &cur, &right[f & 1], &noRt, &o2, &o3, &non, true)))
+                    return rc;
+            }
+            if (more) {
+                pts[0] = v->ref2d;
+                dn[0] = &v->d_chain->nref;
+                gates[0] = kf;
+                if ((rc = chain_lk(ctx, 1, vs, &cur, &nxt, pts, dn, gates)))
+                    return rc;
+            }
+            svo_pyramid *t = ref;  // referenceImg = currentImage (src/VisualSLAM.cpp:151)
+            ref = cur;
+            cur = nxt;
+            nxt = t;
+        }
+        return SVO_OK;
+    }
+    // lock step on one stream
+    svo_pyramid *ref[SVO_LK_MAX_JOBS], *cur[SVO_LK_MAX_JOBS];
+    for (int a = 0; a < k; a++) {
+        ref[a] = runs[a]->v->pyr_ref;
+        cur[a] = runs[a]->v->pyr_cur;
+    }
+    for (int f = 0; f < n_max; f++) {
+        int na = 0, idx[SVO_LK_MAX_JOBS];
+        svo_pyramid *rp[SVO_LK_MAX_JOBS];
+        const uint8_t *li[SVO_LK_MAX_JOBS], *ri[SVO_LK_MAX_JOBS];
+        for (int a = 0; a < k; a++) {
+            if (f >= runs[a]->n_frames)
+                continue;
+            svo_vo *v = runs[a]->v;
+            v->frame++;
+            idx[na] = a;
+            vs[na] = v;
+            prevs[na] = ref[a];
+            nexts[na] = cur[a];
+            rp[na] = v->pyr_right;
+            li[na] = runs[a]->lefts[f];
+            ri[na] = runs[a]->rights[f];
+            pts[na] = v->ref2d;
+            dn[na] = &v->d_chain->nref;
+            gates[na] = &v->d_chain->run;
+            na++;
+        }
+        if (na == 0)
+            break;
+        float *o2[SVO_LK_MAX_JOBS], *o3[SVO_LK_MAX_JOBS];
+        const double *noRt[SVO_LK_MAX_JOBS];
+        int *non[SVO_LK_MAX_JOBS];
+        for (int a = 0; a < na; a++) {
+            o2[a] = vs[a]->ref2d;
+            o3[a] = vs[a]->ref3d;
+            noRt[a] = nullptr;
+            non[a] = nullptr;
+        }
+        if ((rc = build(na, vs, nexts, rp, li, ri, runs[idx[0]]->mem)) ||
+            (rc = chain_lk(ctx, na, vs, prevs, nexts, pts, dn, gates)) || (rc = chain_filters(ctx, na, vs)) ||
+            (rc = chain_pnp(ctx, na, vs)) || (rc = stereo_triangulate_batch(na, vs, nexts, rp, noRt, o2, o3, non, true)))
+            return rc;
+        for (int a = 0; a < na; a++)
+            std::swap(ref[idx[a]], cur[idx[a]]);
+    }
+    return SVO_OK;
+}
+
+// after the stream has drained: the chain state and the per-frame records of one chunk, the host mirror of the state
+static int chain_collect(ChainRun &r, bool pipeline)
+{
+    svo_vo *v = r.v;
+    svo_ctx *ctx = v->ctx;
+    SVO_HIP(hipMemcpyAsync(v->h_chain, v->d_chain, sizeof(VoChain), hipMemcpyDeviceToHost, ctx->stream));
+    int rc = svo_wait(ctx);
+    if (rc)
+        return rc;
+    r.end = *v->h_chain;
+    const int done = r.end.frame < r.n_frames ? r.end.frame : r.n_frames;
+    for (int f = 0; f < done; f++) {
+        const VoOut &o = v->h_out[f];
+        memcpy(r.R_out + 9 * (size_t)f, o.R, sizeof(o.R));
+        memcpy(r.t_out + 3 * (size_t)f, o.t, sizeof(o.t));
+        if (r.inliers_out)
+            r.inliers_out[f] = o.inliers;
+        if (r.tracked_out)
+            r.tracked_out[f] = o.tracked;
+        if (r.keyframe_out)
+            r.keyframe_out[f] = (uint8_t)o.keyframe;
+    }
+    r.n_done = done;
+    // host mirror of the device state after `done` frames
+    v->nref = r.end.nref;
+    v->kf_n = r.end.kf_n;
+    if (done > 0) {
+        memcpy(v->R, r.end.R, sizeof(v->R));
+        memcpy(v->t, r.end.t, sizeof(v->t));
+    }
+    v->frame = r.frame0 + done;
+    svo_pyramid *p[3] = {r.p0, r.p1, r.p2};
+    // a frame that halted in its PnP has its pyramid built (it is `cur`); the roles after `done` finished frames
+    if (pipeline) {
+        v->pyr_ref = p[done % 3];
+        v->pyr_cur = p[(done + 1) % 3];
+        v->pyr_next = p[(done + 2) % 3];
+    } else {
+        v->pyr_ref = p[done % 2];
+        v->pyr_cur = p[(done + 1) % 2];
+    }
+    v->has_cur = false;
+    return SVO_OK;
+}
+
+// The chain stopped in the PnP of frame h with fewer than 10 inliers at 1 px (SVO_HALT_RETRY): the host runs
+// PerspectiveNpointEstimation's second attempt (100, 8.0, 0.98; src/keyFrameManagement.cpp:85-92) on the tracked sets
+// the chain left in place, then the frame's policy as svo_vo_update does.  v->frame is the halted frame's number.
+static int chain_retry_frame(ChainRun &r, int h)
+{
+    svo_vo *v = r.v;
+    svo_ctx *ctx = v->ctx;
+    int rc;
+    v->frame = r.frame0 + h + 1;
+    const double K4[4] = {v->prm.fx, v->prm.fy, v->prm.cx, v->prm.cy};
+    const PnpRecord *rec = reinterpret_cast<const PnpRecord *>(ctx->pinned);
+    if ((rc = svo_launch_pnp_ransac(ctx, v->trk3d, v->trk2d, v->cap, v->d_cnt + 1, K4, 100, 8.0, 0.98, stage_seed(v, 2), 20,
+                                    v->idx, nullptr, v->d_rec)))
+        return rc;
+    hipLaunchKernelGGL(store_count_kernel, dim3(1), dim3(1), 0, ctx->stream, v->d_cnt + 1, &v->d_rec->n_tracked);
+    SVO_HIP(hipMemcpyAsync(ctx->pinned, v->d_rec, sizeof(PnpRecord), hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = svo_wait(ctx)))
+        return rc;
+    v->ntrk = rec->n_tracked;
+    if (r.inliers_out)
+        r.inliers_out[h] = rec->n_inliers;
+    if (r.tracked_out)
+        r.tracked_out[h] = rec->n_tracked;
+    if (rec->n_inliers < v->prm.pnp_lost_below) {
+        svo_set_error("tracking lost at frame %d: %d PnP inliers", v->frame, rec->n_inliers);
+        return SVO_ERR_TRACKING_LOST;
+    }
+    double *R9 = r.R_out + 9 * (size_t)h, *t3 = r.t_out + 3 * (size_t)h;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            R9[3 * i + j] = rec->R[3 * j + i];
+    for (int i = 0; i < 3; i++)
+        t3[i] = -(R9[3 * i] * rec->tvec[0] + R9[3 * i + 1] * rec->tvec[1] + R9[3 * i + 2] * rec->tvec[2]);
+    int was_kf = 0;
+    v->has_cur = true;  // the chain built this frame's pyramid: it is pyr_cur
+    if ((rc = svo_vo_update(v, r.rights[h], r.mem, R9, t3, rec->n_inliers, 0, &was_kf)))
+        return rc;
+    if (r.keyframe_out)
+        r.keyframe_out[h] = (uint8_t)was_kf;
+    return SVO_OK;
+}
+
+// Runs k chunks that share a context to the end: queue, wait, collect; a chunk whose chain halted is taken to the end
+// on its own (the slow paths are rare; the other chunks of the set are not held up by it).
+static int chain_run(ChainRun *const *runs, int k, bool pipeline)
+{
+    int rc;
+    svo_ctx *ctx = runs[0]->v->ctx;
+    for (int a = 0; a < k; a++)
+        if ((rc = chain_prepare(*runs[a])))
+            return rc;
+    if ((rc = chain_enqueue(runs, k, pipeline)))
+        return rc;
+    if ((rc = svo_wait(ctx)))
+        return rc;
+    for (int a = 0; a < k; a++)
+        if ((rc = chain_collect(*runs[a], pipeline)))
+            return rc;
+    for (int a = 0; a < k; a++) {
+        ChainRun &r = *runs[a];
+        svo_vo *v = r.v;
+        while (r.n_done < r.n_frames && r.rc == SVO_OK) {
+            if (r.end.halt_code == SVO_HALT_FEW_REF || (r.end.halt_code == SVO_HALT_NONE && v->nref < 5)) {
+                svo_set_error("tracking lost: %d reference points", v->nref);
+                r.rc = SVO_ERR_TRACKING_LOST;
+                break;
+            }
+            if (r.end.halt_code != SVO_HALT_RETRY) {
+                svo_set_error("front-end chain stopped after %d of %d frames without a reason", r.n_done, r.n_frames);
+                return SVO_ERR_STATE;
+            }
+            const int h = r.n_done;
+            rc = chain_retry_frame(r, h);
+            if (rc == SVO_ERR_TRACKING_LOST) {
+                r.rc = rc;
+                break;
+            }
+            if (rc)
+                return rc;
+            // the rest of the chunk as a run of its own
+            ChainRun rest = r;
+            rest.lefts = r.lefts + h + 1;
+            rest.rights = r.rights + h + 1;
+            rest.n_frames = r.n_frames - h - 1;
+            rest.R_out = r.R_out + 9 * (size_t)(h + 1);
+            rest.t_out = r.t_out + 3 * (size_t)(h + 1);
+            rest.inliers_out = r.inliers_out ? r.inliers_out + h + 1 : nullptr;
+            rest.tracked_out = r.tracked_out ? r.tracked_out + h + 1 : nullptr;
+            rest.keyframe_out = r.keyframe_out ? r.keyframe_out + h + 1 : nullptr;
+            r.n_done = h + 1;
+            if (rest.n_frames == 0)
+                break;
+            if (v->nref < 5) {
+                svo_set_error("tracking lost: %d reference points", v->nref);
+                r.rc = SVO_ERR_TRACKING_LOST;
+                break;
+            }
+            ChainRun *one = &rest;
+            if ((rc = chain_prepare(rest)) || (rc = chain_enqueue(&one, 1, pipeline)) || (rc = svo_wait(ctx)) ||
+                (rc = chain_collect(rest, pipeline)))
+                return rc;
+            r.n_done = h + 1 + rest.n_done;
+            r.end = rest.end;
+        }
+    }
+    return SVO_OK;
+}
+
 int svo_vo_run_chunk(svo_vo *v, const uint8_t *const *lefts, const uint8_t *const *rights, int n_frames, int mem,
                      int pipeline, double *R_out, double *t_out, int *inliers_out, int *tracked_out,
                      uint8_t *keyframe_out, int *n_done)
@@ -614,8 +1027,14 @@ int svo_vo_run_chunk(svo_vo *v, const uint8_t *const *lefts, const uint8_t *cons
         svo_set_error("the chunk runner drives the live policy (SVO_POLICY_SLAM) only");
         return SVO_ERR_ARG;
     }
-    svo_ctx *ctx = v->ctx;
-    if (pipeline && mem == SVO_MEM_DEVICE && !v->stream_b) {
+    if (n_done)
+        *n_done = 0;
+    if (n_frames == 0)
+        return SVO_OK;
+    SVO_HIP(hipSetDevice(v->ctx->device));
+    if (mem == SVO_MEM_HOST)
+        pipeline = 0;  // host images go through one staging buffer; keep them strictly in order
+    if (pipeline && !v->stream_b) {
         // The PnP stream exists only once pipelining is asked for, and in the high-priority class:
         // HIP keeps a separate pool of hardware queues per priority class, so the two streams of
         // a chunk never land on one queue (with both in the default class the runtime was seen to
@@ -625,187 +1044,38 @@ int svo_vo_run_chunk(svo_vo *v, const uint8_t *const *lefts, const uint8_t *cons
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
         SVO_HIP(hipStreamCreateWithPriority(&v->stream_b, hipStreamNonBlocking, prio_hi));
     }
-    hipStream_t sA = ctx->stream, sB = v->stream_b;
+    if (v->nref < 5) {
+        svo_set_error("tracking lost: %d reference points", v->nref);
+        return SVO_ERR_TRACKING_LOST;
+    }
+    ChainRun r;
+    r.v = v;
+    r.lefts = lefts;
+    r.rights = rights;
+    r.n_frames = n_frames;
+    r.mem = mem;
+    r.R_out = R_out;
+    r.t_out = t_out;
+    r.inliers_out = inliers_out;
+    r.tracked_out = tracked_out;
+    r.keyframe_out = keyframe_out;
+    ChainRun *one = &r;
+    int rc = chain_run(&one, 1, pipeline != 0);
     if (n_done)
-        *n_done = 0;
-    if (mem == SVO_MEM_HOST)
-        pipeline = 0;  // host images go through one staging buffer; keep them strictly in order
-    Mailbox *mb = v->mbox;
-    int early_tag = 0, pose_tag[2] = {0, 0};
-    bool spec = false, next_built = false;
-    int pending = -1;  // frame whose refined pose has not been collected yet
-    int rc;
-    // spin on a tag a kernel releases into the mailbox; now and then make sure the stream is alive
-    auto wait_tag = [&](const int *slot, int tag, hipStream_t stream) -> int { return wait_mailbox_tag(slot, tag, stream); };
-    auto harvest = [&](int f) {  // record of frame f is on the host: pose composition (src/VisualSLAM.cpp:70-74)
-        const PnpRecord *rec = &mb->rec[f & 1];
-        double *R9 = R_out + 9 * (size_t)f, *t3 = t_out + 3 * (size_t)f;
-        for (int i = 0; i < 3; i++)
-            for (int j = 0; j < 3; j++)
-                R9[3 * i + j] = rec->R[3 * j + i];
-        for (int i = 0; i < 3; i++)
-            t3[i] = -(R9[3 * i] * rec->tvec[0] + R9[3 * i + 1] * rec->tvec[1] + R9[3 * i + 2] * rec->tvec[2]);
-        memcpy(v->R, R9, sizeof(v->R));
-        memcpy(v->t, t3, sizeof(v->t));
-    };
-    for (int f = 0; f < n_frames; f++) {
-        v->frame++;
-        const int n = v->nref;
-        if (n < 5) {
-            if (pending >= 0 && wait_tag(&mb->pose_tag[pending & 1], pose_tag[pending & 1], pipeline ? sB : sA) == SVO_OK)
-                harvest(pending);
-            svo_set_error("tracking lost: %d reference points", n);
-            return SVO_ERR_TRACKING_LOST;
-        }
-        if (spec) {  // frame f was tracked speculatively during frame f-1's PnP
-            std::swap(v->pyr_cur, v->pyr_next);
-            std::swap(v->a2, v->sa2);
-            std::swap(v->status, v->sstatus);
-        } else {
-            if (next_built) {
-                std::swap(v->pyr_cur, v->pyr_next);
-            } else {
-                const uint8_t *d = stage_image(v, lefts[f], mem, &rc);
-                if (rc || (rc = svo_build_pyramid_from_device(ctx, v->pyr_cur, d)))
-                    return rc;
-            }
-            if ((rc = svo_launch_lk(ctx, v->pyr_ref, v->pyr_cur, v->ref2d, n, v->a2, v->status, nullptr,
-                                    nullptr)))
-                return rc;
-        }
-        spec = next_built = false;
-        // the tracked-point count alternates between two device slots: the refinement of frame
-        // f-1 (stream B) may still read its slot while this frame's filters (stream A) write theirs
-        int *cnt_trk = v->d_cnt + ((f & 1) ? 9 : 1);
-        PnpRecord *d_rec = v->d_rec + (f & 1);
-        const svo_compact_job by_mask = {v->mask, n, v->d_cnt, {v->c2, v->a3, nullptr}, {v->trk2d, v->trk3d, nullptr},
-                                         {2, 3, 0}, cnt_trk};  // done by the F-RANSAC's finishing wave
-        if ((rc = svo_launch_compact(ctx, v->status, n, nullptr, v->ref2d, 2, v->b2, v->a2, 2, v->c2, v->ref3d, 3,
-                                     v->a3, v->d_cnt)) ||
-            (rc = svo_launch_fransac(ctx, v->b2, v->c2, n, v->d_cnt, v->prm.f_thr_temporal, 0.99, 1000,
-                                     stage_seed(v, 0), v->mask, nullptr, nullptr, nullptr, &by_mask)))
-            return rc;
-        // ---- PnP of this frame: stream B when pipelining ----
-        hipStream_t sP = pipeline ? sB : sA;
-        if (pipeline) {
-            SVO_HIP(hipEventRecord(v->ev_a, sA));
-            SVO_HIP(hipStreamWaitEvent(sB, v->ev_a, 0));
-        }
-        auto launch_pnp = [&](double thr, double conf, int stage) -> int {
-            early_tag = ++v->tag;
-            pose_tag[f & 1] = ++v->tag;
-            ctx->stream = sP;
-            svo_pnp_job q = pnp_job(v, n, cnt_trk, thr, conf, stage_seed(v, stage), d_rec, early_tag, f & 1, pose_tag[f & 1]);
-            int r = svo_launch_pnp_ransac_batch(ctx, 1, &q);  // publishes the record itself
-            ctx->stream = sA;
-            return r;
-        };
-        if ((rc = launch_pnp(1.0, 0.99, 1)))
-            return rc;
-        // ---- speculation for the next frame on stream A ----
-        bool speculated = false;
-        if (pipeline && f + 1 < n_frames) {
-            const uint8_t *d = stage_image(v, lefts[f + 1], mem, &rc);
-            if (rc || (rc = svo_build_pyramid_from_device(ctx, v->pyr_next, d)))
-                return rc;
-            // next frame's reference = this frame's tracked set (its count lives in cnt_trk)
-            if ((rc = svo_launch_lk(ctx, v->pyr_cur, v->pyr_next, v->trk2d, n, v->sa2, v->sstatus, nullptr,
-                                    nullptr, cnt_trk)))
-                return rc;
-            speculated = true;
-        }
-        // ---- the policy needs only the RANSAC inlier count: known before mask / refinement end ----
-        if ((rc = wait_tag(&mb->early[0], early_tag, sP)))
-            return rc;
-        if (pending >= 0) {  // stream B runs in order: frame f-1's record landed before this count
-            if ((rc = wait_tag(&mb->pose_tag[pending & 1], pose_tag[pending & 1], sP)))
-                return rc;
-            harvest(pending);
-            pending = -1;
-        }
-        int ninl = mb->early[1];
-        if (ninl < 10) {  // retry at 8 px / 0.98 (src/keyFrameManagement.cpp:85-92)
-            if ((rc = wait_tag(&mb->pose_tag[f & 1], pose_tag[f & 1], sP)) || (rc = launch_pnp(8.0, 0.98, 2)) ||
-                (rc = wait_tag(&mb->early[0], early_tag, sP)))
-                return rc;
-            ninl = mb->early[1];
-        }
-        v->ntrk = mb->early[2];
-        if (inliers_out)
-            inliers_out[f] = ninl;
-        if (tracked_out)
-            tracked_out[f] = v->ntrk;
-        if (ninl < 10) {
-            (void)hipStreamSynchronize(sP);
-            if (speculated)
-                (void)hipStreamSynchronize(sA);
-            svo_set_error("tracking lost at frame %d: %d PnP inliers", v->frame, ninl);
-            return SVO_ERR_TRACKING_LOST;
-        }
-        const bool kf = ninl < v->prm.keyframe_min_inliers;  // src/VisualSLAM.cpp:120
-        if (kf) {
-            // the keyframe's points are placed with the refined pose: wait for it
-            if ((rc = wait_tag(&mb->pose_tag[f & 1], pose_tag[f & 1], sP)))
-                return rc;
-            harvest(f);
-            const uint8_t *d = stage_image(v, rights[f], mem, &rc);
-            if (rc || (rc = svo_build_pyramid_from_device(ctx, v->pyr_right, d)))
-                return rc;
-            const double *R9 = R_out + 9 * (size_t)f, *t3 = t_out + 3 * (size_t)f;
-            double Rt[12];
-            for (int i = 0; i < 3; i++) {
-                Rt[4 * i] = R9[3 * i];
-                Rt[4 * i + 1] = R9[3 * i + 1];
-                Rt[4 * i + 2] = R9[3 * i + 2];
-                Rt[4 * i + 3] = t3[i];
-            }
-            if ((rc = stereo_triangulate(v, v->pyr_cur, v->pyr_right, Rt, v->ref2d, v->ref3d, &v->nref)))
-                return rc;
-            next_built = speculated;  // the speculative tracking is void, the next pyramid is not
-        } else {
-            pending = f;  // its refinement may still be running beside the next frame's filters
-            std::swap(v->ref2d, v->trk2d);
-            std::swap(v->ref3d, v->trk3d);
-            v->nref = v->ntrk;
-            spec = speculated;
-        }
-        std::swap(v->pyr_ref, v->pyr_cur);
-        if (keyframe_out)
-            keyframe_out[f] = kf ? 1 : 0;
-        if (n_done)
-            *n_done = f + 1;
-    }
-    if (pending >= 0) {
-        if ((rc = wait_tag(&mb->pose_tag[pending & 1], pose_tag[pending & 1], pipeline ? sB : sA)))
-            return rc;
-        harvest(pending);
-    }
-    v->has_cur = false;
-    return SVO_OK;
+        *n_done = r.n_done;
+    return rc ? rc : r.rc;
 }
 
 // Several chunks that share ONE context, advanced in lock step by one host thread on the context's
 // stream: per frame the pyramids of all of them, ONE pyramidal-LK launch carrying all their
 // tracking passes (the launch lasts as long as its slowest keypoint, so k jobs cost little more
-// than one), then each chunk's filters + PnP, then each chunk's policy.  Every chunk gets
-// exactly what svo_vo_run_chunk(pipeline = 0) gives it alone.
+// than one), then each stage of the chain as one set of launches.  Every chunk gets exactly what
+// svo_vo_run_chunk(pipeline = 0) gives it alone.
 static int run_chunk_group(svo_chunk_job **jobs, int k)
 {
-    struct GS {
-        svo_chunk_job *j;
-        svo_vo *v;
-        bool active = true;
-        int pending = -1, early_tag = 0, pose_tag[2] = {0, 0}, n = 0;
-        int *cnt_trk = nullptr;
-        PnpRecord *d_rec = nullptr;
-    };
-    std::vector<GS> gs(k);
     svo_ctx *ctx = jobs[0]->vo->ctx;
-    hipStream_t st = ctx->stream;
-    int n_frames_max = 0;
+    int rc;
     for (int a = 0; a < k; a++) {
-        gs[a].j = jobs[a];
-        gs[a].v = jobs[a]->vo;
         jobs[a]->n_done = 0;
         jobs[a]->rc = SVO_OK;
         if (jobs[a]->mem != SVO_MEM_DEVICE) {
@@ -816,32 +1086,11 @@ static int run_chunk_group(svo_chunk_job **jobs, int k)
             svo_set_error("the chunk runner drives the live policy (SVO_POLICY_SLAM) only");
             return SVO_ERR_ARG;
         }
-        n_frames_max = jobs[a]->n_frames > n_frames_max ? jobs[a]->n_frames : n_frames_max;
+        if (!jobs[a]->init_left != !jobs[a]->init_right) {
+            svo_set_error("svo_vo_run_chunks: init_left and init_right go together");
+            return SVO_ERR_ARG;
+        }
     }
-    auto wait_tag = [&](const int *slot, int tag) -> int { return wait_mailbox_tag(slot, tag, st); };
-    auto harvest = [&](GS &g, int f) {  // pose composition (src/VisualSLAM.cpp:70-74)
-        const PnpRecord *rec = &g.v->mbox->rec[f & 1];
-        double *R9 = g.j->R_out + 9 * (size_t)f, *t3 = g.j->t_out + 3 * (size_t)f;
-        for (int i = 0; i < 3; i++)
-            for (int c = 0; c < 3; c++)
-                R9[3 * i + c] = rec->R[3 * c + i];
-        for (int i = 0; i < 3; i++)
-            t3[i] = -(R9[3 * i] * rec->tvec[0] + R9[3 * i + 1] * rec->tvec[1] + R9[3 * i + 2] * rec->tvec[2]);
-        memcpy(g.v->R, R9, sizeof(g.v->R));
-        memcpy(g.v->t, t3, sizeof(g.v->t));
-    };
-    auto launch_pnp = [&](GS &g, int f, double thr, double conf, int stage) -> int {
-        svo_vo *v = g.v;
-        g.early_tag = ++v->tag;
-        g.pose_tag[f & 1] = ++v->tag;
-        svo_pnp_job q = pnp_job(v, g.n, g.cnt_trk, thr, conf, stage_seed(v, stage), g.d_rec, g.early_tag, f & 1, g.pose_tag[f & 1]);
-        return svo_launch_pnp_ransac_batch(ctx, 1, &q);
-    };
-    auto stop = [&](GS &g, int rc) {  // this chunk ends here (tracking lost or an error); the others go on
-        g.active = false;
-        g.j->rc = rc;
-    };
-    int rc;
     {   // ---- chunks that start here: svo_vo_init of all of them as one set of launches ----
         svo_vo *vs[SVO_LK_MAX_JOBS];
         svo_pyramid *pl[SVO_LK_MAX_JOBS], *pr[SVO_LK_MAX_JOBS];
@@ -850,14 +1099,11 @@ static int run_chunk_group(svo_chunk_job **jobs, int k)
         float *o2d[SVO_LK_MAX_JOBS], *o3d[SVO_LK_MAX_JOBS];
         int *nout[SVO_LK_MAX_JOBS];
         int ni = 0;
-        for (GS &g : gs) {
-            if (!g.j->init_left != !g.j->init_right) {
-                svo_set_error("svo_vo_run_chunks: init_left and init_right go together");
-                return SVO_ERR_ARG;
-            }
-            if (!g.j->init_left)
+        for (int a = 0; a < k; a++) {
+            svo_chunk_job *j = jobs[a];
+            if (!j->init_left)
                 continue;
-            svo_vo *v = g.v;
+            svo_vo *v = j->vo;
             v->frame = 0;
             for (int i = 0; i < 9; i++)
                 v->R[i] = (i % 4) == 0;
@@ -866,8 +1112,8 @@ static int run_chunk_group(svo_chunk_job **jobs, int k)
             vs[ni] = v;
             pl[ni] = v->pyr_ref;
             pr[ni] = v->pyr_right;
-            il[ni] = g.j->init_left;
-            ir[ni] = g.j->init_right;
+            il[ni] = j->init_left;
+            ir[ni] = j->init_right;
             static const double I34[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
             Rts[ni] = I34;  // as svo_vo_init
             o2d[ni] = v->ref2d;
@@ -880,204 +1126,49 @@ static int run_chunk_group(svo_chunk_job **jobs, int k)
                 (rc = svo_build_pyramids_from_device(ctx, ni, pr, ir)) ||
                 (rc = stereo_triangulate_batch(ni, vs, pl, pr, Rts, o2d, o3d, nout)))
                 return rc;
-            for (GS &g : gs)
-                if (g.j->init_left)
-                    g.j->n_init_points = g.v->nref;
+            for (int a = 0; a < k; a++)
+                if (jobs[a]->init_left)
+                    jobs[a]->n_init_points = jobs[a]->vo->nref;
         }
     }
-    for (int f = 0; f < n_frames_max; f++) {
-        // ---- pyramids + ONE tracking launch for all the chunks still running ----
-        LkJob lk[SVO_LK_MAX_JOBS];
-        // the pyramids of this step: the left images first, then -- in the same set of launches -- the
-        // right images of the same chunks.  A right pyramid is only read if its chunk turns out to keyframe
-        // in this step (about half of them do), but built here it costs workgroups, not launches: beside the
-        // other contexts' tracking launches every launch of this latency chain waits for its wave slots.
-        svo_pyramid *pyrs[2 * SVO_LK_MAX_JOBS];
-        const uint8_t *imgs[2 * SVO_LK_MAX_JOBS];
-        svo_pyramid *rpyr[SVO_LK_MAX_JOBS];
-        const uint8_t *rimg0[SVO_LK_MAX_JOBS];
-        int nl = 0;
-        for (GS &g : gs) {
-            if (!g.active || f >= g.j->n_frames) {
-                g.active = g.active && f < g.j->n_frames;
-                continue;
-            }
-            svo_vo *v = g.v;
-            v->frame++;
-            g.n = v->nref;
-            if (g.n < 5) {
-                if (g.pending >= 0 && wait_tag(&v->mbox->pose_tag[g.pending & 1], g.pose_tag[g.pending & 1]) == SVO_OK)
-                    harvest(g, g.pending);
-                g.pending = -1;
-                svo_set_error("tracking lost: %d reference points", g.n);
-                stop(g, SVO_ERR_TRACKING_LOST);
-                continue;
-            }
-            pyrs[nl] = v->pyr_cur;
-            imgs[nl] = g.j->lefts[f];
-            rpyr[nl] = v->pyr_right;
-            rimg0[nl] = g.j->rights[f];
-            LkJob &q = lk[nl++];
-            q.prev = v->pyr_ref->dev;
-            q.next = v->pyr_cur->dev;
-            q.dprev = v->pyr_ref->dbase;
-            q.prev_pts = v->ref2d;
-            q.n_cap = g.n;
-            q.d_n = nullptr;
-            q.next_pts = v->a2;
-            q.status = v->status;
-            q.err = nullptr;
-            q.min_eig = nullptr;
+    ChainRun runs[SVO_LK_MAX_JOBS];
+    ChainRun *rp[SVO_LK_MAX_JOBS];
+    int nr = 0;
+    for (int a = 0; a < k; a++) {
+        svo_chunk_job *j = jobs[a];
+        if (j->n_frames <= 0)
+            continue;
+        if (j->vo->nref < 5) {
+            svo_set_error("tracking lost: %d reference points", j->vo->nref);
+            j->rc = SVO_ERR_TRACKING_LOST;
+            continue;
         }
-        if (nl == 0)
-            break;
-        for (int a = 0; a < nl; a++) {
-            pyrs[nl + a] = rpyr[a];
-            imgs[nl + a] = rimg0[a];
-        }
-        if ((rc = svo_build_pyramids_from_device(ctx, 2 * nl, pyrs, imgs)) ||
-            (rc = svo_launch_lk_batch(ctx, nl, lk, pyrs[0])))
-            return rc;
-        // ---- filters and PnP: every stage is ONE set of launches for all the chunks ----
-        svo_pnp_job pj[SVO_LK_MAX_JOBS];
-        svo_fransac_job fj[SVO_LK_MAX_JOBS];
-        svo_compact_job c1[SVO_LK_MAX_JOBS], c2[SVO_LK_MAX_JOBS];
-        GS *pg[SVO_LK_MAX_JOBS];
-        int np = 0;
-        for (GS &g : gs) {
-            if (!g.active)
-                continue;
-            svo_vo *v = g.v;
-            g.cnt_trk = v->d_cnt + ((f & 1) ? 9 : 1);
-            g.d_rec = v->d_rec + (f & 1);
-            // status filter (src/tracking.cpp:54-64) and, after the F-RANSAC, its mask filter (:77-88)
-            c1[np] = {v->status, g.n, nullptr, {v->ref2d, v->a2, v->ref3d}, {v->b2, v->c2, v->a3}, {2, 2, 3}, v->d_cnt};
-            c2[np] = {v->mask, g.n, v->d_cnt, {v->c2, v->a3, nullptr}, {v->trk2d, v->trk3d, nullptr}, {2, 3, 0}, g.cnt_trk};
-            svo_fransac_job &q = fj[np];
-            q.p1 = v->b2;
-            q.p2 = v->c2;
-            q.cap = g.n;
-            q.d_n = v->d_cnt;
-            q.threshold = v->prm.f_thr_temporal;
-            q.confidence = 0.99;
-            q.max_iters = 1000;
-            q.seed = stage_seed(v, 0);
-            q.mask = v->mask;
-            q.d_F = nullptr;
-            q.d_count = nullptr;
-            q.d_iters = nullptr;
-            q.then_compact = &c2[np];  // the mask compaction rides with the F-RANSAC
-            pg[np++] = &g;
-        }
-        if ((rc = svo_launch_compact_batch(ctx, np, c1)) || (rc = svo_launch_fransac_batch(ctx, np, fj)))
-            return rc;
-        for (int a = 0; a < np; a++) {
-            GS &g = *pg[a];
-            svo_vo *v = g.v;
-            g.early_tag = ++v->tag;
-            g.pose_tag[f & 1] = ++v->tag;
-            pj[a] = pnp_job(v, g.n, g.cnt_trk, 1.0, 0.99, stage_seed(v, 1), g.d_rec, g.early_tag, f & 1, g.pose_tag[f & 1]);
-        }
-        if ((rc = svo_launch_pnp_ransac_batch(ctx, np, pj)))  // every record is published by its own workgroup
-            return rc;
-        // ---- policy of every chunk; the chunks that keyframe are collected ----
-        GS *kfs[SVO_LK_MAX_JOBS];
-        int nk = 0;
-        for (GS &g : gs) {
-            if (!g.active)
-                continue;
-            svo_vo *v = g.v;
-            Mailbox *mb = v->mbox;
-            if ((rc = wait_tag(&mb->early[0], g.early_tag)))
-                return rc;
-            if (g.pending >= 0) {
-                if ((rc = wait_tag(&mb->pose_tag[g.pending & 1], g.pose_tag[g.pending & 1])))
-                    return rc;
-                harvest(g, g.pending);
-                g.pending = -1;
-            }
-            int ninl = mb->early[1];
-            if (ninl < 10) {  // retry at 8 px / 0.98 (src/keyFrameManagement.cpp:85-92)
-                if ((rc = wait_tag(&mb->pose_tag[f & 1], g.pose_tag[f & 1])) || (rc = launch_pnp(g, f, 8.0, 0.98, 2)) ||
-                    (rc = wait_tag(&mb->early[0], g.early_tag)))
-                    return rc;
-                ninl = mb->early[1];
-            }
-            v->ntrk = mb->early[2];
-            if (g.j->inliers_out)
-                g.j->inliers_out[f] = ninl;
-            if (g.j->tracked_out)
-                g.j->tracked_out[f] = v->ntrk;
-            if (ninl < 10) {
-                (void)wait_tag(&mb->pose_tag[f & 1], g.pose_tag[f & 1]);
-                svo_set_error("tracking lost at frame %d: %d PnP inliers", v->frame, ninl);
-                stop(g, SVO_ERR_TRACKING_LOST);
-                continue;
-            }
-            const bool kf = ninl < v->prm.keyframe_min_inliers;  // src/VisualSLAM.cpp:120
-            if (kf) {
-                kfs[nk++] = &g;
-            } else {
-                g.pending = f;
-                std::swap(v->ref2d, v->trk2d);
-                std::swap(v->ref3d, v->trk3d);
-                v->nref = v->ntrk;
-            }
-            if (g.j->keyframe_out)
-                g.j->keyframe_out[f] = kf ? 1 : 0;
-        }
-        // ---- the keyframe path of all the chunks that need it, every stage one set of launches ----
-        if (nk > 0) {
-            svo_vo *vs[SVO_LK_MAX_JOBS];
-            svo_pyramid *lefts[SVO_LK_MAX_JOBS], *rights[SVO_LK_MAX_JOBS];
-            const uint8_t *rimg[SVO_LK_MAX_JOBS];
-            double Rt[SVO_LK_MAX_JOBS][12];
-            const double *Rts[SVO_LK_MAX_JOBS];
-            float *o2d[SVO_LK_MAX_JOBS], *o3d[SVO_LK_MAX_JOBS];
-            int *nout[SVO_LK_MAX_JOBS];
-            for (int a = 0; a < nk; a++) {
-                GS &g = *kfs[a];
-                svo_vo *v = g.v;
-                // the keyframe's points are placed with the refined pose: wait for it
-                if ((rc = wait_tag(&v->mbox->pose_tag[f & 1], g.pose_tag[f & 1])))
-                    return rc;
-                harvest(g, f);
-                const double *R9 = g.j->R_out + 9 * (size_t)f, *t3 = g.j->t_out + 3 * (size_t)f;
-                for (int i = 0; i < 3; i++) {
-                    Rt[a][4 * i] = R9[3 * i];
-                    Rt[a][4 * i + 1] = R9[3 * i + 1];
-                    Rt[a][4 * i + 2] = R9[3 * i + 2];
-                    Rt[a][4 * i + 3] = t3[i];
-                }
-                vs[a] = v;
-                lefts[a] = v->pyr_cur;
-                rights[a] = v->pyr_right;
-                rimg[a] = g.j->rights[f];
-                Rts[a] = Rt[a];
-                o2d[a] = v->ref2d;
-                o3d[a] = v->ref3d;
-                nout[a] = &v->nref;
-            }
-            (void)rimg;  // the right pyramids of this step were built with the left ones
-            if ((rc = stereo_triangulate_batch(nk, vs, lefts, rights, Rts, o2d, o3d, nout)))
-                return rc;
-        }
-        for (GS &g : gs) {
-            if (!g.active)
-                continue;
-            std::swap(g.v->pyr_ref, g.v->pyr_cur);
-            g.j->n_done = f + 1;
-        }
+        ChainRun &r = runs[nr];
+        r.v = j->vo;
+        r.lefts = j->lefts;
+        r.rights = j->rights;
+        r.n_frames = j->n_frames;
+        r.mem = j->mem;
+        r.R_out = j->R_out;
+        r.t_out = j->t_out;
+        r.inliers_out = j->inliers_out;
+        r.tracked_out = j->tracked_out;
+        r.keyframe_out = j->keyframe_out;
+        rp[nr++] = &r;
     }
-    for (GS &g : gs) {
-        if (g.pending >= 0) {
-            if ((rc = wait_tag(&g.v->mbox->pose_tag[g.pending & 1], g.pose_tag[g.pending & 1])))
-                return rc;
-            harvest(g, g.pending);
-        }
-        g.v->has_cur = false;
+    if (nr == 0)
+        return SVO_OK;
+    rc = chain_run(rp, nr, false);
+    nr = 0;
+    for (int a = 0; a < k; a++) {
+        svo_chunk_job *j = jobs[a];
+        if (j->n_frames <= 0 || j->rc)
+            continue;
+        j->n_done = runs[nr].n_done;
+        j->rc = runs[nr].rc;
+        nr++;
     }
-    return SVO_OK;
+    return rc;
 }
 
 int svo_vo_run_chunks(svo_chunk_job *jobs, int n_jobs)

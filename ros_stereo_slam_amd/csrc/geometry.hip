@@ -87,6 +87,7 @@ struct TriJob {
     int apply_rt;
     float *out_world;
     int *h_count;  // pinned host int that receives the live point count (the host waits on the stream), or null
+    VoChain *chain;  // chain mode (svo_tri_job::chain) or null
 };
 struct TriBatch {  // blockIdx.y picks the job
     TriJob j[SVO_LK_MAX_JOBS];
@@ -96,17 +97,37 @@ __global__ __launch_bounds__(128) void triangulate_kernel(Mat34 P1, Mat34 P2, Tr
 {
     svo_chain_priority();
     const TriJob &job = batch.j[blockIdx.y];
+    VoChain *chain = job.chain;
+    if (chain && chain->kf == 0)
+        return;  // chain runner: the frame is no keyframe (or the chain halted)
     const float2 *__restrict__ x1 = job.x1, *__restrict__ x2 = job.x2;
     const int n_host = job.n_host;
     const int *__restrict__ d_n = job.d_n;
     float *__restrict__ out_xyz = job.out_xyz, *__restrict__ out_h = job.out_h;
-    const Mat34 &Rt = job.Rt;
+    Mat34 Rt = job.Rt;
+    if (chain) {  // insertKeyFrames places the cloud with the pose the frame was localised at (keyFrameManagement.cpp:20-30)
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            Rt.m[4 * r] = chain->R[3 * r];
+            Rt.m[4 * r + 1] = chain->R[3 * r + 1];
+            Rt.m[4 * r + 2] = chain->R[3 * r + 2];
+            Rt.m[4 * r + 3] = chain->t[r];
+        }
+    }
     const int apply_rt = job.apply_rt;
     float *__restrict__ out_world = job.out_world;
     const int n = d_n ? min(*d_n, n_host) : n_host;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0 && job.h_count)
         *job.h_count = n;  // what a one-thread launch of its own did before (store_counts_kernel)
+    if (i == 0 && chain) {  // the new reference set's size; a chunk cannot go on from fewer than 5 points
+        chain->nref = n;
+        chain->kf_n = n;
+        if (n < 5) {
+            chain->run = 0;
+            chain->halt_code = SVO_HALT_FEW_REF;
+        }
+    }
     if (i >= n)
         return;
     double A[4][4], v[4];
@@ -183,6 +204,7 @@ struct CompactArgs {
     int n_host;
     const int *d_n;
     int *d_count;
+    const int *gate;
 };
 struct CompactBatch {  // one workgroup per job
     CompactArgs j[SVO_LK_MAX_JOBS];
@@ -208,6 +230,8 @@ __global__ __launch_bounds__(64) void compact_kernel(CompactBatch batch, int seg
 {
     svo_chain_priority();
     const CompactArgs &args = batch.j[blockIdx.y];
+    if (args.gate && *args.gate == 0)
+        return;
     const uint8_t *__restrict__ mask = args.mask;
     const int n = args.d_n ? min(*args.d_n, args.n_host) : args.n_host;
     const int lane = threadIdx.x;
@@ -282,9 +306,10 @@ int svo_launch_triangulate_batch(svo_ctx *ctx, const double *P1, const double *P
         j.out_xyz = h.out_xyz;
         j.out_h = h.out_h;
         j.Rt = to_mat34(h.Rt);
-        j.apply_rt = (h.Rt && h.out_world) ? 1 : 0;
+        j.apply_rt = ((h.Rt || h.chain) && h.out_world) ? 1 : 0;
         j.out_world = h.out_world;
         j.h_count = a < k ? h.h_count : nullptr;
+        j.chain = h.chain;
         if (a < k)
             cap_max = h.cap > cap_max ? h.cap : cap_max;
     }
@@ -347,6 +372,7 @@ int svo_launch_compact_batch(svo_ctx *ctx, int n_jobs, const svo_compact_job *jo
         a.n_host = h.cap;
         a.d_n = h.d_n;
         a.d_count = h.d_count;
+        a.gate = h.gate;
     }
     int cap_max = 0;
     for (int k = 0; k < n_jobs; k++)

@@ -502,6 +502,8 @@ template <int C>
 __global__ __launch_bounds__(64 * WAVES, 4) void lk_track_kernel(LkBatch batch, LkParams prm)
 {
     const LkJob &job = batch.j[blockIdx.y];
+    if (job.gate && *job.gate == 0)
+        return;  // a pass of the chain runner that is not due (no keyframe / the chain halted): scalar load, scalar branch
     const PyrDev &prev = job.prev, &next = job.next;
     const int *__restrict__ dprev = job.dprev;
     const float *__restrict__ prev_pts = job.prev_pts;

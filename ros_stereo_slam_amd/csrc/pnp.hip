@@ -52,14 +52,9 @@ struct PnpJob {
     uint8_t *mask;
     int *inl;
     PnpResult *out;
-    int *early_out;
-    int early_tag;
     int direct;             // 1: no RANSAC -- hypothesis 0 (written by pnp_dlt_kernel) is refined over ALL points
     const int *dlt_status;  // direct mode: 0 = hypothesis 0 is valid
-    // optional publication of the finished record into pinned host memory (see svo_pnp_job)
-    int *h_rec;
-    int *h_tag;
-    int tag;
+    VoChain *chain;         // chain mode (svo_pnp_job::chain): the frame's policy is decided here, on the device
     const int *cnt_trk;
     unsigned *ticket;  // "last wave of a phase" counter (self-resetting)
 };
@@ -803,6 +798,8 @@ __global__ __launch_bounds__(64, 4) void pnp_solve_kernel(PnpBatch batch, int it
 {
     svo_chain_priority();
     const PnpJob &job = batch.j[blockIdx.y];
+    if (job.chain && job.chain->run == 0)
+        return;  // the chain halted at an earlier frame: nothing of this chunk runs any more
     const int it1 = it1_cap < job.iterations ? it1_cap : job.iterations;
     if (it0 > 0 && job.st->done)
         return;  // the same answer in every wave of the launch
@@ -1169,21 +1166,12 @@ struct PnpResult {      // what the host reads back after a localisation
     int n_inliers, iters_run;
 };
 
-// One thread: the record (PnpResult, 34 words) and the tracked-point count behind it into the pinned
-// mailbox slot, then the slot's tag released at system scope -- the host spins on the tag.
+// One thread: the tracked-point count behind the record (PnpRecord::n_tracked sits right behind the result).
 __device__ void publish_record(const PnpJob &job, const PnpResult &r, PnpResult *d_out)
 {
+    (void)r;
     const int n_tracked = job.cnt_trk ? *job.cnt_trk : 0;
-    reinterpret_cast<int *>(d_out + 1)[0] = n_tracked;  // PnpRecord::n_tracked sits right behind the result
-    if (!job.h_rec)
-        return;
-    const int *w = reinterpret_cast<const int *>(&r);
-    constexpr int WORDS = sizeof(PnpResult) / 4;
-    for (int k = 0; k < WORDS; k++)
-        job.h_rec[k] = w[k];
-    job.h_rec[WORDS] = n_tracked;
-    __threadfence_system();
-    __hip_atomic_store(job.h_tag, job.tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    reinterpret_cast<int *>(d_out + 1)[0] = n_tracked;
 }
 
 // The tail of solvePnPRansac in ONE single-workgroup launch: (1) thread 0 replays the sequential
@@ -1215,8 +1203,9 @@ template <bool LEAN> __global__ __launch_bounds__(256, LEAN ? 5 : 4) void pnp_fi
     int *__restrict__ d_m = job.d_m;
     const int max_iters = job.max_lm_iters;
     PnpResult *__restrict__ out = job.out;
-    int *early_out = job.early_out;
-    const int early_tag = job.early_tag;
+    VoChain *chain = job.chain;
+    if (chain && chain->run == 0)
+        return;  // the chain halted at an earlier frame
     __shared__ double s_all[RED_CHUNK * RED_STRIDE], s_part[4 * NACC], s_sum[NACC], s_pose[12], s_trial[12];
     __shared__ double s_norm[NACC];  // the normal equations at the accepted pose (packed like the accumulators)
     __shared__ int s_flag, s_wave[4], s_base;
@@ -1238,10 +1227,26 @@ template <bool LEAN> __global__ __launch_bounds__(256, LEAN ? 5 : 4) void pnp_fi
         *st = r;
         s_state = r;
         s_base = 0;
-        if (early_out)
-            publish_early(early_out, early_tag, r, n);
+        s_flag = 0;
+        if (chain) {
+            // The reference's host policy, on the device.  < 10 inliers at 1 px: PerspectiveNpointEstimation tries
+            // again at 8 px (src/keyFrameManagement.cpp:85-92) -- rare; the chain stops HERE with the tracked sets of
+            // this frame in place and the host runs the retry.  Otherwise: keyframe iff fewer than 200 inliers
+            // (src/VisualSLAM.cpp:120).
+            const int ninl = r.best_iter >= 0 ? r.best_count : 0;
+            if (ninl < chain->retry_below) {
+                chain->run = 0;
+                chain->kf = 0;
+                chain->halt_code = SVO_HALT_RETRY;
+                s_flag = 3;
+            } else {
+                chain->kf = ninl < chain->kf_min ? 1 : 0;
+            }
+        }
     }
     __syncthreads();
+    if (s_flag == 3)
+        return;  // halted: the host takes over at this frame
     const RansacState s = s_state;
     const bool have_model = s.best_iter >= 0 && s.best_count > 0;
     {
@@ -1249,7 +1254,8 @@ template <bool LEAN> __global__ __launch_bounds__(256, LEAN ? 5 : 4) void pnp_fi
 #pragma unroll
         for (int k = 0; k < 12; k++)
             P[k] = have_model ? hyp[(size_t)s.best_iter * 12 + k] : 0.;
-        for (int start = 0; start < n_host; start += 256) {
+        const int n_pass = mask ? n_host : n;  // the mask covers the capacity; the index list only the live points
+        for (int start = 0; start < n_pass; start += 256) {
             const int i = start + tid;
             bool keep = false;
             if (have_model && i < n) {
@@ -1377,8 +1383,12 @@ template <bool LEAN> __global__ __launch_bounds__(256, LEAN ? 5 : 4) void pnp_fi
             if (lambda < 1e-12)
                 lambda = 1e-12;
             __syncthreads();
+            // CvLevMarq's criterion as cv::solvePnP sets it (20 iterations, FLT_EPSILON): the relative change of
+            // the parameter vector, |step|^2 <= eps^2 * (1 + |t|^2) here (the increment is on the left, its norm is
+            // the norm of the change; the 1 keeps a pose at the origin from iterating to the cap), or an error that
+            // no longer decreases
             const double scale = 1. + s_pose[9] * s_pose[9] + s_pose[10] * s_pose[10] + s_pose[11] * s_pose[11];
-            if (step <= 1e-20 * scale || prev - err <= 1e-14 * prev)
+            if (step <= 1.4210854715202004e-14 * scale || prev - err <= 1e-10 * prev)
                 break;
         } else {
             lambda *= 10;
@@ -1402,6 +1412,52 @@ template <bool LEAN> __global__ __launch_bounds__(256, LEAN ? 5 : 4) void pnp_fi
         r.iters_run = s.iters_run;
         *out = r;
         publish_record(job, r, out);
+        if (chain) {
+            // Rodrigues; R = R^T; t = -R * tvec (src/VisualSLAM.cpp:70-74): the same operations, in the same order, as
+            // the host code of svo_vo_localize
+            VoOut *o = chain->out + chain->frame;
+            double R9[9];
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 3; j++)
+                    R9[3 * i + j] = r.R[3 * j + i];
+            for (int i = 0; i < 3; i++) {
+                const double ti = -(R9[3 * i] * r.tvec[0] + R9[3 * i + 1] * r.tvec[1] + R9[3 * i + 2] * r.tvec[2]);
+                chain->t[i] = ti;
+                o->t[i] = ti;
+            }
+            for (int k = 0; k < 9; k++) {
+                chain->R[k] = R9[k];
+                o->R[k] = R9[k];
+            }
+            o->inliers = s.best_count;
+            o->tracked = n;
+            o->keyframe = chain->kf;
+            o->pad = 0;
+        }
+    }
+    if (chain) {
+        // no keyframe: the tracked sets become the reference sets (src/VisualSLAM.cpp:143-146); a keyframe's sets are
+        // written by the stereo path that follows
+        if (chain->kf == 0) {
+            const float2 *__restrict__ s2 = reinterpret_cast<const float2 *>(chain->trk2d);
+            float2 *__restrict__ d2 = reinterpret_cast<float2 *>(chain->ref2d);
+            const float *__restrict__ s3 = chain->trk3d;
+            float *__restrict__ d3 = chain->ref3d;
+            for (int i = tid; i < n; i += 256)
+                d2[i] = s2[i];
+            for (int i = tid; i < 3 * n; i += 256)
+                d3[i] = s3[i];
+        }
+        if (tid == 0) {
+            if (chain->kf == 0) {
+                chain->nref = n;
+                if (n < 5) {  // svo_vo_run_chunk: "tracking lost: n reference points" at the next frame
+                    chain->run = 0;
+                    chain->halt_code = SVO_HALT_FEW_REF;
+                }
+            }
+            chain->frame = chain->frame + 1;
+        }
     }
 }
 
@@ -1454,13 +1510,9 @@ int svo_launch_pnp_ransac_batch(svo_ctx *ctx, int n_jobs, const svo_pnp_job *job
         j.mask = h.mask;
         j.inl = h.inliers;
         j.out = reinterpret_cast<PnpResult *>(h.d_result);
-        j.early_out = h.early_mbox;
-        j.early_tag = h.early_tag;
         j.direct = 0;
         j.dlt_status = nullptr;
-        j.h_rec = reinterpret_cast<int *>(h.h_rec);
-        j.h_tag = h.h_tag;
-        j.tag = h.tag;
+        j.chain = h.chain;
         j.cnt_trk = h.cnt_trk;
         j.ticket = ctx->d_tickets + 16 + nb;  // slots 0..15: fransac.hip
         nb++;
@@ -1486,8 +1538,7 @@ int svo_launch_pnp_ransac_batch(svo_ctx *ctx, int n_jobs, const svo_pnp_job *job
 
 int svo_launch_pnp_ransac(svo_ctx *ctx, const float *obj, const float *img, int cap, const int *d_n,
                           const double *K4h, int iterations, double reproj_err, double confidence, uint64_t seed,
-                          int refine_iters, int *inliers, uint8_t *mask, void *d_result, int *early_mbox,
-                          int early_tag)
+                          int refine_iters, int *inliers, uint8_t *mask, void *d_result)
 {
     svo_pnp_job j;
     j.obj = obj;
@@ -1504,11 +1555,7 @@ int svo_launch_pnp_ransac(svo_ctx *ctx, const float *obj, const float *img, int 
     j.inliers = inliers;
     j.mask = mask;
     j.d_result = d_result;
-    j.early_mbox = early_mbox;
-    j.early_tag = early_tag;
-    j.h_rec = nullptr;
-    j.h_tag = nullptr;
-    j.tag = 0;
+    j.chain = nullptr;
     j.cnt_trk = nullptr;
     return svo_launch_pnp_ransac_batch(ctx, 1, &j);
 }
@@ -1516,7 +1563,7 @@ int svo_launch_pnp_ransac(svo_ctx *ctx, const float *obj, const float *img, int 
 // cv::solvePnP (ITERATIVE, no guess) on device arrays: DLT + LM over all points.  inliers: cap ints of
 // scratch (receives 0..n-1); d_result: one PnpResult (n_inliers = n, or 0 when there is no model).
 int svo_launch_solve_pnp(svo_ctx *ctx, const float *obj, const float *img, int cap, const int *d_n, const double *K4h,
-                         int refine_iters, int *inliers, void *d_result, int *early_mbox, int early_tag)
+                         int refine_iters, int *inliers, void *d_result)
 {
     if (cap <= 0)
         return SVO_OK;
@@ -1552,13 +1599,9 @@ int svo_launch_solve_pnp(svo_ctx *ctx, const float *obj, const float *img, int c
     j.mask = nullptr;
     j.inl = inliers;
     j.out = reinterpret_cast<PnpResult *>(d_result);
-    j.early_out = early_mbox;
-    j.early_tag = early_tag;
     j.direct = 1;
     j.dlt_status = d.status;
-    j.h_rec = nullptr;
-    j.h_tag = nullptr;
-    j.tag = 0;
+    j.chain = nullptr;
     j.cnt_trk = nullptr;
     for (int k = 1; k < SVO_LK_MAX_JOBS; k++)
         batch.j[k] = batch.j[0];
@@ -1590,7 +1633,7 @@ extern "C" int svo_solve_pnp(svo_ctx *ctx, const float *obj, const float *img, i
         dobj = ctx->s_a.as<float>();
         dimg = ctx->s_b.as<float>();
     }
-    if ((rc = svo_launch_solve_pnp(ctx, dobj, dimg, n, nullptr, K4h, 20, ctx->s_c.as<int>(), ctx->s_d.p, nullptr, 0)))
+    if ((rc = svo_launch_solve_pnp(ctx, dobj, dimg, n, nullptr, K4h, 20, ctx->s_c.as<int>(), ctx->s_d.p)))
         return rc;
     SVO_HIP(hipMemcpyAsync(ctx->pinned, ctx->s_d.p, sizeof(PnpResult), hipMemcpyDeviceToHost, ctx->stream));
     SVO_HIP(hipStreamSynchronize(ctx->stream));
@@ -1635,7 +1678,7 @@ extern "C" int svo_pnp_ransac(svo_ctx *ctx, const float *obj, const float *img, 
         dinl = ctx->s_c.as<int>();
     }
     rc = svo_launch_pnp_ransac(ctx, dobj, dimg, n, nullptr, K4h, iterations, reproj_err, confidence, seed, 20, dinl,
-                               nullptr, ctx->s_d.p, nullptr, 0);
+                               nullptr, ctx->s_d.p);
     if (rc)
         return rc;
     // rvec / tvec / counts are host outputs in both modes (the caller decides on them)

@@ -51,6 +51,7 @@ struct PyrBuild {
     const uint8_t *img[PYR_JOBS];                 // raw images, row stride w[0] * C
     uint8_t *lvl[PYR_JOBS][SVO_MAX_LEVELS];       // pixel (0, 0) of the padded levels
     int *dlvl[PYR_JOBS];                          // derivative levels (svo_pyramid::dbase) or null
+    const int *gate[PYR_JOBS];                    // optional: the pyramid is left untouched when *gate == 0 (chain runner)
     int doff[SVO_MAX_LEVELS];                     // element (0, 0) of each derivative level, in ints
     int pitch[SVO_MAX_LEVELS], dpitch[SVO_MAX_LEVELS], w[SVO_MAX_LEVELS], h[SVO_MAX_LEVELS];
     int levels;
@@ -206,6 +207,8 @@ template <int C> __global__ __launch_bounds__(PB) void pyr_base_kernel(PyrBuild 
 {
     svo_chain_priority();
     const int job = blockIdx.y;
+    if (b.gate[job] && *b.gate[job] == 0)
+        return;
     if ((int)blockIdx.x < n_tiles) {
         if (b.levels > 1)
             down_tile<C, true>(b.img[job], b.w[0] * C, b.w[0], b.h[0], b.lvl[job][1], b.pitch[1], b.w[1], b.h[1],
@@ -225,6 +228,8 @@ template <int C> __global__ __launch_bounds__(PB) void pyr_base_kernel(PyrBuild 
 template <int C> __global__ __launch_bounds__(PB) void pyr_down_kernel(PyrBuild b, int l)
 {
     svo_chain_priority();
+    if (b.gate[blockIdx.z] && *b.gate[blockIdx.z] == 0)
+        return;
     down_tile<C, false>(b.lvl[blockIdx.z][l - 1], b.pitch[l - 1], b.w[l - 1], b.h[l - 1], b.lvl[blockIdx.z][l], b.pitch[l],
                         b.w[l], b.h[l], blockIdx.x, blockIdx.y);
 }
@@ -355,6 +360,8 @@ template <int C> __global__ __launch_bounds__(PB) void pyr_finish_kernel(PyrBuil
 {
     svo_chain_priority();
     const int job = blockIdx.z, by = blockIdx.y;
+    if (b.gate[job] && *b.gate[job] == 0)
+        return;
     if (by < plan.border_y0[b.levels]) {
         int l = 1;
         for (int i = 2; i < b.levels; i++)
@@ -385,8 +392,11 @@ template <int C> __global__ __launch_bounds__(PB) void pyr_finish_kernel(PyrBuil
 
 }  // namespace
 
-static void fill_build(PyrBuild &b, int k, svo_pyramid *const *pyrs, const uint8_t *const *d_images, bool deriv_only)
+static void fill_build(PyrBuild &b, int k, svo_pyramid *const *pyrs, const uint8_t *const *d_images, bool deriv_only,
+                       const int *const *gates = nullptr)
 {
+    for (int a = 0; a < PYR_JOBS; a++)
+        b.gate[a] = gates ? gates[a < k ? a : 0] : nullptr;
     const svo_pyramid *p0 = pyrs[0];
     for (int l = 0; l < SVO_MAX_LEVELS; l++) {
         b.pitch[l] = p0->dev.pitch[l];
@@ -468,10 +478,11 @@ int svo_build_derivatives(svo_ctx *ctx, int k, svo_pyramid *const *pyrs)
     return rc;
 }
 
-template <int C> static int build_levels(svo_ctx *ctx, int k, svo_pyramid *const *pyrs, const uint8_t *const *d_images)
+template <int C>
+static int build_levels(svo_ctx *ctx, int k, svo_pyramid *const *pyrs, const uint8_t *const *d_images, const int *const *gates)
 {
     PyrBuild b;
-    fill_build(b, k, pyrs, d_images, false);
+    fill_build(b, k, pyrs, d_images, false, gates);
     {
         const int tiles_x = b.levels > 1 ? (b.w[1] + TW - 1) / TW : 0, tiles_y = b.levels > 1 ? (b.h[1] + TH - 1) / TH : 0;
         const int n_tiles = tiles_x * tiles_y;
@@ -498,7 +509,8 @@ template <int C> static int build_levels(svo_ctx *ctx, int k, svo_pyramid *const
 }
 
 // k pyramids of the same geometry from k device images, one set of launches
-int svo_build_pyramids_from_device(svo_ctx *ctx, int k, svo_pyramid *const *pyrs, const uint8_t *const *d_images)
+int svo_build_pyramids_from_device(svo_ctx *ctx, int k, svo_pyramid *const *pyrs, const uint8_t *const *d_images,
+                                   const int *const *gates)
 {
     if (k <= 0)
         return SVO_OK;
@@ -515,11 +527,11 @@ int svo_build_pyramids_from_device(svo_ctx *ctx, int k, svo_pyramid *const *pyrs
     ScopedKernelTime t(ctx, SVO_K_PYRAMID);
     switch (pyrs[0]->c) {
     case 1:
-        return build_levels<1>(ctx, k, pyrs, d_images);
+        return build_levels<1>(ctx, k, pyrs, d_images, gates);
     case 3:
-        return build_levels<3>(ctx, k, pyrs, d_images);
+        return build_levels<3>(ctx, k, pyrs, d_images, gates);
     case 4:
-        return build_levels<4>(ctx, k, pyrs, d_images);
+        return build_levels<4>(ctx, k, pyrs, d_images, gates);
     }
     svo_set_error("pyramid: unsupported channel count %d (1, 3 or 4)", pyrs[0]->c);
     return SVO_ERR_ARG;
@@ -527,7 +539,7 @@ int svo_build_pyramids_from_device(svo_ctx *ctx, int k, svo_pyramid *const *pyrs
 
 int svo_build_pyramid_from_device(svo_ctx *ctx, svo_pyramid *pyr, const uint8_t *d_image)
 {
-    return svo_build_pyramids_from_device(ctx, 1, &pyr, &d_image);
+    return svo_build_pyramids_from_device(ctx, 1, &pyr, &d_image, nullptr);
 }
 
 extern "C" {

@@ -121,16 +121,6 @@ __device__ inline RansacState ransac_replay(const RansacState *st_in, int first,
     return s;
 }
 
-// What the host policy branches on -- RANSAC inlier count and tracked-point count -- published
-// straight into pinned host memory (the host spins on the tag) while the rest of the stage runs.
-__device__ inline void publish_early(int *early_out, int early_tag, const RansacState &s, int n)
-{
-    early_out[1] = s.best_iter >= 0 ? s.best_count : 0;
-    early_out[2] = n;
-    __threadfence_system();
-    __hip_atomic_store(&early_out[0], early_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
 // hand-off of LDS data between lanes of ONE wave (LDS ops of a wave execute in order; this
 // only pins the compiler)
 __device__ __forceinline__ void wave_lds_fence()

@@ -126,9 +126,39 @@ struct ScopedKernelTime {
 };
 int svo_resolve_timers(svo_ctx *ctx);
 
+// ---- the front-end's device-resident frame state (frontend.hip: the chain runner) --------------------------------
+// A chunk of frames is queued WITHOUT the host in the loop: the decisions the reference's host policy takes per
+// frame -- keyframe iff fewer than 200 PnP inliers (src/VisualSLAM.cpp:120), retry / shutdown below 10
+// (src/keyFrameManagement.cpp:85-92) -- are taken by pnp_finish_kernel and left here; the keyframe path's kernels are
+// queued for EVERY frame and leave at once unless `kf` is set, every kernel leaves at once after a halt.
+enum { SVO_HALT_NONE = 0, SVO_HALT_RETRY = 1 /* < pnp_retry_below inliers at 1 px: the host runs the 8 px retry */,
+       SVO_HALT_FEW_REF = 2 /* fewer than 5 reference points for the next frame */ };
+struct VoOut {  // one per frame of a run, in pinned host memory (what svo_vo_run_chunk returns per frame)
+    double R[9], t[3];
+    int inliers, tracked, keyframe, pad;
+};
+struct VoChain {
+    // state, written by kernels
+    int run;        // 1 while the chain is live; 0 after a halt
+    int kf;         // 1: the frame just localised is a keyframe, its stereo path runs (implies run)
+    int nref;       // live count of the reference set (ref2d / ref3d)
+    int frame;      // frames of this run finished = index of the next one
+    int halt_code;  // SVO_HALT_*
+    int kf_n;       // points of the last keyframe's camera-frame cloud
+    int pad[2];
+    double R[9], t[3];  // pose of the frame just localised, camera in world: the keyframe's [R|t]
+    // configuration, written by the host before a run
+    int kf_min, retry_below;
+    float *ref2d, *ref3d;        // hand-over destination (src/VisualSLAM.cpp:143-146)
+    const float *trk2d, *trk3d;  // hand-over source: the tracked sets of the frame
+    VoOut *out;                  // pinned host array, one record per frame of the run
+};
+
 // pyramid.hip
 int svo_build_pyramid_from_device(svo_ctx *ctx, svo_pyramid *pyr, const uint8_t *d_image);
-int svo_build_pyramids_from_device(svo_ctx *ctx, int k, svo_pyramid *const *pyrs, const uint8_t *const *d_images);
+// gates (optional, one per pyramid): a pyramid whose *gate == 0 is left untouched (chain runner after a halt)
+int svo_build_pyramids_from_device(svo_ctx *ctx, int k, svo_pyramid *const *pyrs, const uint8_t *const *d_images,
+                                   const int *const *gates = nullptr);
 // lk.hip
 struct LkJob {  // one pyramidal-LK pass: prev/next pyramids, points in, points / status / err / minEig out
     PyrDev prev, next;
@@ -139,6 +169,7 @@ struct LkJob {  // one pyramidal-LK pass: prev/next pyramids, points in, points 
     float *next_pts;
     uint8_t *status;
     float *err, *min_eig;  // optional
+    const int *gate = nullptr;  // optional: the job's workgroups leave at once when *gate == 0 (VoChain::run / ::kf)
 };
 struct LkBatch {
     LkJob j[SVO_LK_MAX_JOBS];
@@ -159,6 +190,7 @@ struct svo_compact_job {  // order-preserving compaction of up to three float ar
     float *out[3];
     int stride[3];
     int *d_count;
+    const int *gate = nullptr;  // optional: leave at once when *gate == 0
 };
 struct svo_fransac_job {  // host-side description of one F-matrix RANSAC problem (device pointers)
     const float *p1, *p2;
@@ -173,6 +205,7 @@ struct svo_fransac_job {  // host-side description of one F-matrix RANSAC proble
     // optional: the compaction by the fresh mask (mask / cap / d_n of this job are used, the struct's own are
     // ignored), done by the wave that writes the mask -- no launch of its own
     const svo_compact_job *then_compact = nullptr;
+    const int *gate = nullptr;  // optional: every wave leaves at once when *gate == 0
 };
 int svo_launch_fransac_batch(svo_ctx *ctx, int n_jobs, const svo_fransac_job *jobs);
 int svo_launch_fransac(svo_ctx *ctx, const float *p1, const float *p2, int cap, const int *d_n,
@@ -190,6 +223,9 @@ struct svo_tri_job {  // one stereo DLT triangulation (device pointers; Rt: host
     const double *Rt;
     float *out_world;
     int *h_count;  // pinned host int that receives the live count, or null
+    // chain mode (optional): [R|t] is read from chain->R / chain->t on the device (Rt must be null), the job runs only
+    // when chain->kf is set, the live count goes to chain->nref / chain->kf_n and fewer than 5 points halt the chain
+    VoChain *chain = nullptr;
 };
 int svo_launch_triangulate_batch(svo_ctx *ctx, const double *P1, const double *P2, int k, const svo_tri_job *jobs);
 int svo_launch_transform(svo_ctx *ctx, const double *Rt, const float *in, int cap, const int *d_n, float *out);
@@ -220,22 +256,19 @@ struct svo_pnp_job {  // host-side description of one PnP-RANSAC problem (device
     int *inliers;
     uint8_t *mask;
     void *d_result;
-    int *early_mbox;
-    int early_tag;
-    // optional: the finished record (PnpResult + the tracked-point count *cnt_trk) published into pinned host
-    // memory, then h_tag released at system scope (what publish_record_kernel did as a launch of its own)
-    void *h_rec;
-    int *h_tag;
-    int tag;
+    // optional: chain mode -- the policy of the frame is decided on the device (see VoChain): inlier count against
+    // chain->retry_below / chain->kf_min, pose composition (src/VisualSLAM.cpp:70-74), the per-frame record into
+    // chain->out[chain->frame], the reference hand-over when the frame is no keyframe; the job's kernels leave at
+    // once when chain->run == 0
+    VoChain *chain = nullptr;
     const int *cnt_trk;
 };
 int svo_launch_pnp_ransac_batch(svo_ctx *ctx, int n_jobs, const svo_pnp_job *jobs);
 int svo_launch_pnp_ransac(svo_ctx *ctx, const float *obj, const float *img, int cap, const int *d_n,
                           const double *K4h, int iterations, double reproj_err, double confidence, uint64_t seed,
-                          int refine_iters, int *inliers, uint8_t *mask, void *d_result, int *early_mbox = nullptr,
-                          int early_tag = 0);
+                          int refine_iters, int *inliers, uint8_t *mask, void *d_result);
 int svo_launch_solve_pnp(svo_ctx *ctx, const float *obj, const float *img, int cap, const int *d_n, const double *K4h,
-                         int refine_iters, int *inliers, void *d_result, int *early_mbox = nullptr, int early_tag = 0);
+                         int refine_iters, int *inliers, void *d_result);
 // anms.hip
 // optional gather of the kept keypoints in the same launch that lists them (out_x[i] = in_x[out_idx[i]])
 struct svo_anms_gather {
@@ -244,6 +277,8 @@ struct svo_anms_gather {
     const uint8_t *in_s;
     uint8_t *out_s;
 };
+// gates (optional): per job, the job's workgroups leave at once when *gates[a] == 0
 int svo_launch_anms_batch(svo_ctx *ctx, int k, const float *const *xy, const float *const *resp, int n, int keep,
-                          int *const *out_idx, int *const *d_count, const svo_anms_gather *gather = nullptr);
+                          int *const *out_idx, int *const *d_count, const svo_anms_gather *gather = nullptr,
+                          const int *const *gates = nullptr);
 int svo_launch_anms(svo_ctx *ctx, const float *xy, const float *resp, int n, int keep, int *out_idx, int *d_count);

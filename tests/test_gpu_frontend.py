@@ -314,3 +314,121 @@ def test_older_vo_ladder_front_end_matches_oracle(ctx, orc):
         g.run_chunk([frames[1][0]], [frames[1][1]])
     g.close()
     o.close()
+
+
+@pytest.mark.parametrize("pipeline", [False, True])
+def test_run_chunk_takes_the_8px_retry_on_the_host_and_resumes(ctx, orc, pipeline):
+    """The chain runner keeps the host out of the frame loop; the rare slow path -- fewer than pnp_retry_below inliers
+    at 1 px, PerspectiveNpointEstimation's second attempt at 8 px (src/keyFrameManagement.cpp:85-92) -- stops the
+    chain on the device and is run by the host, which then queues the rest of the chunk again.  With the threshold
+    raised so that many frames take it: the chunk runner == frame by frame == the oracle, bit for bit."""
+    import torch
+    poses, frames = _frames(10)
+    dev = [(torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()) for l, r in frames]
+    torch.cuda.synchronize()
+    kw = dict(grid_step=30, keyframe_min_inliers=200, seed=3, pnp_retry_below=230, pnp_lost_below=10)
+    a = capi.VisualOdometry(ctx, 1241, 376, 3, **kw)
+    b = capi.VisualOdometry(ctx, 1241, 376, 3, **kw)
+    o = orc.VO(1241, 376, 3, **kw)
+    assert a.init(*dev[0]) == b.init(*dev[0]) == o.init(*frames[0])
+    ref = [a.track(*dev[i]) for i in range(1, 10)]
+    oref = [o.track(*frames[i]) for i in range(1, 10)]
+    rc, done, R, t, inl, trk, kf = b.run_chunk([d[0] for d in dev[1:]], [d[1] for d in dev[1:]], pipeline=pipeline)
+    assert rc == 0 and done == 9
+    for i, ((rc_i, R_i, t_i, inl_i, kf_i, trk_i), (rc_o, R_o, t_o, inl_o, kf_o, trk_o)) in enumerate(zip(ref, oref)):
+        assert rc_i == 0 and rc_o == 0
+        assert np.array_equal(R[i], R_i) and np.array_equal(t[i], t_i), f"frame {i + 1} vs frame by frame"
+        assert np.array_equal(R[i], R_o) and np.array_equal(t[i], t_o), f"frame {i + 1} vs oracle"
+        assert inl[i] == inl_i == inl_o and trk[i] == trk_i == trk_o and bool(kf[i]) == kf_i == bool(kf_o)
+    a2, a3 = a.reference()
+    b2, b3 = b.reference()
+    o2, o3 = o.ref()
+    assert np.array_equal(a2, b2) and np.array_equal(a3, b3) and np.array_equal(b2, o2) and np.array_equal(b3, o3)
+    # the 1 px attempt of a 440-point grid finds fewer than 230 inliers on most frames: the slow path really ran
+    plain = capi.VisualOdometry(ctx, 1241, 376, 3, grid_step=30, keyframe_min_inliers=200, seed=3)
+    plain.init(*dev[0])
+    counts = [plain.track(*dev[i])[3] for i in range(1, 10)]
+    assert sum(c < 230 for c in counts) >= 3
+    for v in (a, b, plain):
+        v.close()
+    o.close()
+
+
+def test_lock_step_group_with_a_chunk_on_the_slow_path(ctx):
+    """A lock-step group in which ONE chunk takes the host's retry path: that chunk is finished on its own after the
+    others, every chunk still gets its stand-alone result."""
+    import torch
+    poses, frames = _frames(12)
+    dev = [(torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()) for l, r in frames]
+    torch.cuda.synchronize()
+    bounds = [(0, 4), (4, 8), (8, 12)]
+    kws = [dict(grid_step=30, keyframe_min_inliers=200, seed=40 + k, pnp_retry_below=230 if k == 1 else 10) for k in range(3)]
+    alone = []
+    for kw, (a, b) in zip(kws, bounds):
+        v = capi.VisualOdometry(ctx, 1241, 376, 3, **kw)
+        v.init(*dev[a])
+        ref = [v.track(*dev[i]) for i in range(a + 1, b)]
+        alone.append((ref, v.reference()))
+        v.close()
+    shared = capi.Context(0)
+    vos = [capi.VisualOdometry(shared, 1241, 376, 3, **kw) for kw in kws]
+    jobs = []
+    for v, (a, b) in zip(vos, bounds):
+        v.init(*dev[a])
+        jobs.append((v, [d[0] for d in dev[a + 1:b]], [d[1] for d in dev[a + 1:b]]))
+    res = capi.run_chunks(jobs)
+    for (ref, ref_sets), (rc, done, R, t, inl, trk, kf), v in zip(alone, res, vos):
+        assert rc == 0 and done == len(ref)
+        for i, (rc_i, R_i, t_i, inl_i, kf_i, trk_i) in enumerate(ref):
+            assert np.array_equal(R[i], R_i) and np.array_equal(t[i], t_i)
+            assert inl[i] == inl_i and trk[i] == trk_i and bool(kf[i]) == kf_i
+        r2, r3 = v.reference()
+        assert np.array_equal(r2, ref_sets[0]) and np.array_equal(r3, ref_sets[1])
+    shared.close()
+
+
+@pytest.mark.parametrize("pipeline", [False, True])
+def test_run_chunk_reports_tracking_lost_in_the_middle_of_a_chunk(ctx, pipeline):
+    """An unrelated image in the middle of a chunk: the chain halts there on the device, the host's retry fails too ->
+    SVO_ERR_TRACKING_LOST with n_done = the frames before it, their results intact (SHUTDOWN_FLAG,
+    src/keyFrameManagement.cpp:89-92)."""
+    import torch
+    poses, frames = _frames(6)
+    rng = np.random.default_rng(0)
+    junk = rng.integers(0, 256, (376, 1241, 3), dtype=np.uint8)
+    frames = frames[:4] + [(junk, junk)] + frames[4:]
+    dev = [(torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()) for l, r in frames]
+    torch.cuda.synchronize()
+    kw = dict(grid_step=30, keyframe_min_inliers=200, seed=2)
+    a = capi.VisualOdometry(ctx, 1241, 376, 3, **kw)
+    b = capi.VisualOdometry(ctx, 1241, 376, 3, **kw)
+    a.init(*dev[0])
+    b.init(*dev[0])
+    ref = [a.track(*dev[i]) for i in range(1, 4)]
+    assert a.track(*dev[4])[0] == capi.SVO_ERR_TRACKING_LOST
+    rc, done, R, t, inl, trk, kf = b.run_chunk([d[0] for d in dev[1:]], [d[1] for d in dev[1:]], pipeline=pipeline)
+    assert rc == capi.SVO_ERR_TRACKING_LOST and done == 3
+    for i, (rc_i, R_i, t_i, inl_i, kf_i, trk_i) in enumerate(ref):
+        assert np.array_equal(R[i], R_i) and np.array_equal(t[i], t_i) and inl[i] == inl_i and bool(kf[i]) == kf_i
+    a.close()
+    b.close()
+
+
+def test_run_chunk_takes_host_images(ctx):
+    """Host images go through the front-end's staging buffer, in order: the same results as device images."""
+    import torch
+    poses, frames = _frames(6)
+    dev = [(torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()) for l, r in frames]
+    torch.cuda.synchronize()
+    kw = dict(grid_step=30, keyframe_min_inliers=200, seed=8)
+    a = capi.VisualOdometry(ctx, 1241, 376, 3, **kw)
+    b = capi.VisualOdometry(ctx, 1241, 376, 3, **kw)
+    a.init(*dev[0])
+    b.init(*frames[0])
+    ra = a.run_chunk([d[0] for d in dev[1:]], [d[1] for d in dev[1:]], pipeline=True)
+    rb = b.run_chunk([f[0] for f in frames[1:]], [f[1] for f in frames[1:]], pipeline=False)
+    assert ra[0] == rb[0] == 0 and ra[1] == rb[1] == 5
+    for x, y in zip(ra[2:], rb[2:]):
+        assert np.array_equal(x, y)
+    a.close()
+    b.close()
