@@ -37,7 +37,18 @@ struct svo_vo {
     svo_pyramid *pyr_ref = nullptr, *pyr_cur = nullptr, *pyr_right = nullptr, *pyr_next = nullptr, *pyr_right2 = nullptr;
     hipStream_t stream_b = nullptr;          // second stream: PnP of frame t beside pyramid + LK of frame t+1
     hipEvent_t ev_a = nullptr;               // "tracked sets of frame t are ready" (stream A -> B)
-    hipEvent_t ev_b = nullptr;               // "frame t is localised" (stream B -> A)
+    hipEvent_t ev_b = nullptr;               // "frame t's policy is decided" (stream B -> A)
+    // one chunk per GPU, pipelined: the stereo half of the keyframe path (LK left -> right, ANMS, filters) does not
+    // depend on the frame's pose, so it runs for EVERY frame on a third stream with its own context (stream, scratch,
+    // tickets) and its own point buffers, a frame ahead; only the triangulation waits for the keyframe decision
+    svo_ctx *ctx_s = nullptr;
+    hipEvent_t ev_pyr = nullptr, ev_p1 = nullptr, ev_tri = nullptr, ev_end = nullptr;
+    float *s_a2 = nullptr, *s_b2 = nullptr, *s_c2 = nullptr, *s_d2 = nullptr, *s_x1 = nullptr, *s_x2 = nullptr, *s_resp = nullptr;
+    uint8_t *s_status = nullptr, *s_st2 = nullptr, *s_mask = nullptr;
+    int *s_idx = nullptr, *s_cnt = nullptr;
+    // second set of tracked points / inlier list: frame t's refinement reads its set while frame t+1's filters write theirs
+    float *trk2d_b = nullptr, *trk3d_b = nullptr;
+    int *idx_b = nullptr;
     // point sets (device)
     float *ref2d = nullptr, *ref3d = nullptr, *trk2d = nullptr, *trk3d = nullptr;
     float *a2 = nullptr, *b2 = nullptr, *c2 = nullptr, *d2 = nullptr, *a3 = nullptr, *b3 = nullptr, *resp = nullptr;
@@ -201,13 +212,75 @@ int stereo_triangulate_batch(int k, svo_vo *const *vs, svo_pyramid *const *lefts
     return SVO_OK;
 }
 
+// The stereo half of the keyframe path for ONE pipelined chunk, on the front-end's third stream (v->ctx_s) and its
+// own buffers: LK left -> right from the lattice (src/tracking.cpp:18), ANMS, status filter (:20-27), F-RANSAC at 3 px
+// with its mask filter (:30-43) -- everything of stereoTriangulate that does not need the frame's pose.  Leaves
+// x1 / x2 / count in s_x1 / s_x2 / s_cnt[4].  `frame_no`: the frame the pass belongs to (its seed).
+int stereo_part1_spec(svo_vo *v, svo_pyramid *left, svo_pyramid *right, int frame_no)
+{
+    svo_ctx *cs = v->ctx_s;
+    int rc;
+    const int n = grid_axis(v->w, v->prm.grid_step) * grid_axis(v->h, v->prm.grid_step);
+    const int *run = &v->d_chain->run;
+    LkJob q;
+    q.prev = left->dev;
+    q.next = right->dev;
+    q.dprev = left->dbase;
+    q.prev_pts = v->grid_xy;
+    q.n_cap = n;
+    q.d_n = nullptr;
+    q.next_pts = v->s_b2;
+    q.status = v->s_status;
+    q.err = nullptr;
+    q.min_eig = v->s_resp;
+    q.gate = run;
+    if ((rc = svo_launch_lk_batch(cs, 1, &q, left)))
+        return rc;
+    const float *pts = v->grid_xy, *trk = v->s_b2;
+    const uint8_t *stt = v->s_status;
+    const int *d_n = nullptr;
+    if (v->prm.anms_keep > 0) {
+        const float *xy = v->grid_xy, *resp = v->s_resp;
+        int *oidx = v->s_idx, *ocnt = v->s_cnt + 2;
+        const svo_anms_gather ga = {v->grid_xy, v->s_b2, v->s_c2, v->s_d2, v->s_status, v->s_st2};
+        if ((rc = svo_launch_anms_batch(cs, 1, &xy, &resp, n, v->prm.anms_keep, &oidx, &ocnt, &ga, &run)))
+            return rc;
+        pts = v->s_c2;
+        trk = v->s_d2;
+        stt = v->s_st2;
+        d_n = v->s_cnt + 2;
+    }
+    float *o1 = pts == v->grid_xy ? v->s_c2 : v->s_a2, *o2 = pts == v->grid_xy ? v->s_d2 : v->s_b2;
+    const svo_compact_job c1 = {stt, n, d_n, {pts, trk, nullptr}, {o1, o2, nullptr}, {2, 2, 0}, v->s_cnt + 3, run};
+    const svo_compact_job c2 = {v->s_mask, n, v->s_cnt + 3, {o1, o2, nullptr}, {v->s_x1, v->s_x2, nullptr}, {2, 2, 0},
+                                v->s_cnt + 4};
+    const uint64_t seed = v->prm.seed + 8ull * (uint64_t)frame_no + 3;  // stage_seed(frame_no, 3)
+    const svo_fransac_job fj = {o1, o2, n, v->s_cnt + 3, v->prm.f_thr_stereo, 0.99, 1000, seed, v->s_mask, nullptr, nullptr,
+                                nullptr, &c2, run};
+    if ((rc = svo_launch_compact_batch(cs, 1, &c1)) || (rc = svo_launch_fransac_batch(cs, 1, &fj)))
+        return rc;
+    return SVO_OK;
+}
+
+// ... and the half that does: DLT triangulation of the filtered pairs and the cloud's placement with the frame's refined
+// pose (src/triangulation.cpp:142-160, src/keyFrameManagement.cpp:20-30), on the main stream, only when the device flag
+// says keyframe.  The keyframe's 2-D set is copied from the staging buffer by the same kernel.
+int stereo_part2_spec(svo_vo *v)
+{
+    const int n = grid_axis(v->w, v->prm.grid_step) * grid_axis(v->h, v->prm.grid_step);
+    svo_tri_job tj = {v->s_x1, v->s_x2, n, v->s_cnt + 4, v->b3, nullptr, nullptr, v->ref3d, nullptr, v->d_chain, v->ref2d};
+    double P1[12], P2[12];
+    svo_stereo_projections(v->prm.fx, v->prm.fy, v->prm.cx, v->prm.cy, v->prm.baseline, P1, P2);
+    return svo_launch_triangulate_batch(v->ctx, P1, P2, 1, &tj);
+}
+
 // the PnP-RANSAC problem of a localisation as the chain runner queues it: solvePnPRansac(100, 1 px, 0.99) over the
 // tracked sets, the frame's policy decided by the finishing kernel (VoChain)
-svo_pnp_job pnp_job(svo_vo *v, const int *cnt_trk, uint64_t seed)
+svo_pnp_job pnp_job(svo_vo *v, const int *cnt_trk, uint64_t seed, int set = 0)
 {
     svo_pnp_job q;
-    q.obj = v->trk3d;
-    q.img = v->trk2d;
+    q.obj = set ? v->trk3d_b : v->trk3d;
+    q.img = set ? v->trk2d_b : v->trk2d;
     q.cap = v->cap;
     q.d_n = cnt_trk;
     q.K4[0] = v->prm.fx;
@@ -219,9 +292,9 @@ svo_pnp_job pnp_job(svo_vo *v, const int *cnt_trk, uint64_t seed)
     q.confidence = 0.99;
     q.seed = seed;
     q.refine_iters = 20;
-    q.inliers = v->idx;
+    q.inliers = set ? v->idx_b : v->idx;
     q.mask = nullptr;
-    q.d_result = v->d_rec;
+    q.d_result = v->d_rec + set;
     q.chain = v->d_chain;
     q.cnt_trk = cnt_trk;
     return q;
@@ -378,6 +451,20 @@ int svo_vo_destroy(svo_vo *v)
         (void)hipEventDestroy(v->ev_a);
     if (v->ev_b)
         (void)hipEventDestroy(v->ev_b);
+    for (hipEvent_t e : {v->ev_pyr, v->ev_p1, v->ev_tri, v->ev_end})
+        if (e)
+            (void)hipEventDestroy(e);
+    if (v->ctx_s) {
+        (void)hipStreamSynchronize(v->ctx_s->stream);
+        (void)svo_ctx_destroy(v->ctx_s);
+    }
+    {
+        void *sb[] = {v->s_a2, v->s_b2, v->s_c2, v->s_d2, v->s_x1, v->s_x2, v->s_resp, v->s_status, v->s_st2, v->s_mask,
+                      v->s_idx, v->s_cnt, v->trk2d_b, v->trk3d_b, v->idx_b};
+        for (void *b : sb)
+            if (b)
+                (void)hipFree(b);
+    }
     if (v->h_chain)
         (void)hipHostFree(v->h_chain);
     if (v->h_out)
@@ -600,6 +687,7 @@ struct ChainRun {            // one chunk of a lock-step set
     int frame0 = 0;                                  // v->frame when the run was queued
     svo_pyramid *p0 = nullptr, *p1 = nullptr, *p2 = nullptr;  // pyramid roles when the run was queued: ref, cur, next
     VoChain end;                                     // the chain state after the run
+    int halt_set = 0;                                // which tracked set the frame that halted the chain wrote
 };
 
 static int chain_prepare(ChainRun &r)
@@ -628,8 +716,6 @@ static int chain_prepare(ChainRun &r)
     c->retry_below = v->prm.pnp_retry_below;  // src/keyFrameManagement.cpp:85
     c->ref2d = v->ref2d;
     c->ref3d = v->ref3d;
-    c->trk2d = v->trk2d;
-    c->trk3d = v->trk3d;
     c->out = v->h_out;
     // the previous run's wait has long returned: the pinned staging copy is free again
     SVO_HIP(hipMemcpyAsync(v->d_chain, c, sizeof(VoChain), hipMemcpyHostToDevice, v->ctx->stream));
@@ -665,7 +751,8 @@ static int chain_lk(svo_ctx *ctx, int k, svo_vo *const *vs, svo_pyramid *const *
 }
 
 // status filter (src/tracking.cpp:54-64), F-RANSAC at 1 px + its mask filter (:75-88): the tracked sets and their count
-static int chain_filters(svo_ctx *ctx, int k, svo_vo *const *vs)
+// set: which of the two tracked sets / count slots the frame writes (pipelined chunks alternate)
+static int chain_filters(svo_ctx *ctx, int k, svo_vo *const *vs, int set = 0)
 {
     svo_compact_job c1[SVO_LK_MAX_JOBS], c2[SVO_LK_MAX_JOBS];
     svo_fransac_job fj[SVO_LK_MAX_JOBS];
@@ -674,7 +761,8 @@ static int chain_filters(svo_ctx *ctx, int k, svo_vo *const *vs)
         const int *run = &v->d_chain->run;
         c1[a] = {v->status, v->cap, &v->d_chain->nref, {v->ref2d, v->a2, v->ref3d}, {v->b2, v->c2, v->a3}, {2, 2, 3},
                  v->d_cnt, run};
-        c2[a] = {v->mask, v->cap, v->d_cnt, {v->c2, v->a3, nullptr}, {v->trk2d, v->trk3d, nullptr}, {2, 3, 0}, v->d_cnt + 1};
+        c2[a] = {v->mask, v->cap, v->d_cnt, {v->c2, v->a3, nullptr},
+                 {set ? v->trk2d_b : v->trk2d, set ? v->trk3d_b : v->trk3d, nullptr}, {2, 3, 0}, v->d_cnt + (set ? 9 : 1)};
         svo_fransac_job &q = fj[a];
         q.p1 = v->b2;
         q.p2 = v->c2;
@@ -697,12 +785,14 @@ static int chain_filters(svo_ctx *ctx, int k, svo_vo *const *vs)
     return SVO_OK;
 }
 
-static int chain_pnp(svo_ctx *ctx, int k, svo_vo *const *vs)
+static int chain_pnp(svo_ctx *ctx, int k, svo_vo *const *vs, int set = 0, bool split = false, bool refine_only = false)
 {
     svo_pnp_job pj[SVO_LK_MAX_JOBS];
     for (int a = 0; a < k; a++)
-        pj[a] = pnp_job(vs[a], vs[a]->d_cnt + 1, stage_seed(vs[a], 1));
-    return svo_launch_pnp_ransac_batch(ctx, k, pj);
+        pj[a] = pnp_job(vs[a], vs[a]->d_cnt + (set ? 9 : 1), stage_seed(vs[a], 1), set);
+    if (refine_only)
+        return svo_launch_pnp_refine(ctx, k, pj);
+    return svo_launch_pnp_ransac_batch(ctx, k, pj, split);
 }
 
 // Queue frames [0, n) of k chunks that share a context (lock step: every stage one set of launches for all of them;
@@ -750,70 +840,91 @@ static int chain_enqueue(ChainRun *const *runs, int k, bool pipeline)
         return svo_build_pyramids_from_device(ctx, 2 * na, pyrs, imgs, g);
     };
     if (pipeline) {
+        // Three streams.  A (the context's): the frame's filters, the next frame's pyramids and its tracking pass from
+        // the tracked set, then -- once B has decided the frame -- the keyframe's triangulation and the tracking pass
+        // again from its points (both leave at once unless the frame is a keyframe).  B: PnP-RANSAC, the policy,
+        // the refinement (a keyframe is refined before A goes on; any other frame beside the next frame's filters).
+        // C: the pose-free half of the stereo path of EVERY frame, a frame ahead.
         ChainRun &r = *runs[0];
         svo_vo *v = r.v;
-        hipStream_t sB = v->stream_b;
+        hipStream_t sB = v->stream_b, sC = v->ctx_s->stream;
         svo_pyramid *ref = v->pyr_ref, *cur = v->pyr_cur, *nxt = v->pyr_next;
         svo_pyramid *right[2] = {v->pyr_right, v->pyr_right2};
         const int *run = &v->d_chain->run, *kf = &v->d_chain->kf;
         vs[0] = v;
-        // prologue: the pyramids of frame 0 and its tracking pass
+        const int frame0 = v->frame;
+        // prologue: the pyramids of frame 0, its tracking pass, the stereo half of frame 0
         {
             const uint8_t *li = r.lefts[0], *ri = r.rights[0];
             if ((rc = build(1, vs, &cur, &right[0], &li, &ri, r.mem)))
                 return rc;
+            SVO_HIP(hipEventRecord(v->ev_pyr, sA));
             pts[0] = v->ref2d;
             dn[0] = &v->d_chain->nref;
             gates[0] = run;
             if ((rc = chain_lk(ctx, 1, vs, &ref, &cur, pts, dn, gates)))
                 return rc;
+            SVO_HIP(hipStreamWaitEvent(sC, v->ev_pyr, 0));
+            if ((rc = stereo_part1_spec(v, cur, right[0], frame0 + 1)))
+                return rc;
+            SVO_HIP(hipEventRecord(v->ev_p1, sC));
         }
         for (int f = 0; f < r.n_frames; f++) {
             v->frame++;
-            if ((rc = chain_filters(ctx, 1, vs)))
+            const int set = f & 1;
+            if ((rc = chain_filters(ctx, 1, vs, set)))
                 return rc;
-            // PnP of this frame on stream B
+            // PnP of this frame on stream B: solve, decide (A goes on from here), refine
             SVO_HIP(hipEventRecord(v->ev_a, sA));
             SVO_HIP(hipStreamWaitEvent(sB, v->ev_a, 0));
             ctx->stream = sB;
-            rc = chain_pnp(ctx, 1, vs);
+            rc = chain_pnp(ctx, 1, vs, set, true);
+            if (!rc) {
+                SVO_HIP(hipEventRecord(v->ev_b, sB));
+                rc = chain_pnp(ctx, 1, vs, set, true, true);
+            }
             ctx->stream = sA;
             if (rc)
                 return rc;
-            SVO_HIP(hipEventRecord(v->ev_b, sB));
             const bool more = f + 1 < r.n_frames;
             if (more) {  // beside it on stream A: the next frame's pyramids and its tracking pass from the tracked set
                 const uint8_t *li = r.lefts[f + 1], *ri = r.rights[f + 1];
                 if ((rc = build(1, vs, &nxt, &right[(f + 1) & 1], &li, &ri, r.mem)))
                     return rc;
-                pts[0] = v->trk2d;
-                dn[0] = v->d_cnt + 1;
+                SVO_HIP(hipEventRecord(v->ev_pyr, sA));
+                pts[0] = set ? v->trk2d_b : v->trk2d;
+                dn[0] = v->d_cnt + (set ? 9 : 1);
                 gates[0] = run;
                 if ((rc = chain_lk(ctx, 1, vs, &cur, &nxt, pts, dn, gates)))
                     return rc;
             }
+            // the frame is decided (and, a keyframe, refined); its stereo half has long been ready
             SVO_HIP(hipStreamWaitEvent(sA, v->ev_b, 0));
-            // the keyframe path (leaves at once unless the frame is a keyframe), then the tracking pass again from
-            // the keyframe's points
-            {
-                float *o2 = v->ref2d, *o3 = v->ref3d;
-                const double *noRt = nullptr;
-                int *non = nullptr;
-                if ((rc = stereo_triangulate_batch(1, vs, &cur, &right[f & 1], &noRt, &o2, &o3, &non, true)))
-                    return rc;
-            }
+            SVO_HIP(hipStreamWaitEvent(sA, v->ev_p1, 0));
+            if ((rc = stereo_part2_spec(v)))
+                return rc;
+            SVO_HIP(hipEventRecord(v->ev_tri, sA));
             if (more) {
-                pts[0] = v->ref2d;
+                pts[0] = v->ref2d;  // a keyframe: the next frame is tracked from its points
                 dn[0] = &v->d_chain->nref;
                 gates[0] = kf;
                 if ((rc = chain_lk(ctx, 1, vs, &cur, &nxt, pts, dn, gates)))
                     return rc;
+                // the stereo half of the next frame: its pyramids are built, this frame's staging buffers are free
+                SVO_HIP(hipStreamWaitEvent(sC, v->ev_pyr, 0));
+                SVO_HIP(hipStreamWaitEvent(sC, v->ev_tri, 0));
+                if ((rc = stereo_part1_spec(v, nxt, right[(f + 1) & 1], frame0 + f + 2)))
+                    return rc;
+                SVO_HIP(hipEventRecord(v->ev_p1, sC));
             }
             svo_pyramid *t = ref;  // referenceImg = currentImage (src/VisualSLAM.cpp:151)
             ref = cur;
             cur = nxt;
             nxt = t;
         }
+        // the last frame's refinement runs on B: the caller's wait on A covers it
+        SVO_HIP(hipEventRecord(v->ev_end, sB));
+        SVO_HIP(hipStreamWaitEvent(sA, v->ev_end, 0));
         return SVO_OK;
     }
     // lock step on one stream
@@ -887,6 +998,7 @@ static int chain_collect(ChainRun &r, bool pipeline)
             r.keyframe_out[f] = (uint8_t)o.keyframe;
     }
     r.n_done = done;
+    r.halt_set = pipeline ? (r.end.frame & 1) : 0;  // pipelined chunks alternate between two tracked sets
     // host mirror of the device state after `done` frames
     v->nref = r.end.nref;
     v->kf_n = r.end.kf_n;
@@ -918,12 +1030,17 @@ static int chain_retry_frame(ChainRun &r, int h)
     svo_ctx *ctx = v->ctx;
     int rc;
     v->frame = r.frame0 + h + 1;
+    if (r.halt_set) {  // the frame wrote the second tracked set: make it the front-end's (svo_vo_update swaps pointers)
+        std::swap(v->trk2d, v->trk2d_b);
+        std::swap(v->trk3d, v->trk3d_b);
+    }
+    int *cnt = v->d_cnt + (r.halt_set ? 9 : 1);
     const double K4[4] = {v->prm.fx, v->prm.fy, v->prm.cx, v->prm.cy};
     const PnpRecord *rec = reinterpret_cast<const PnpRecord *>(ctx->pinned);
-    if ((rc = svo_launch_pnp_ransac(ctx, v->trk3d, v->trk2d, v->cap, v->d_cnt + 1, K4, 100, 8.0, 0.98, stage_seed(v, 2), 20,
-                                    v->idx, nullptr, v->d_rec)))
+    if ((rc = svo_launch_pnp_ransac(ctx, v->trk3d, v->trk2d, v->cap, cnt, K4, 100, 8.0, 0.98, stage_seed(v, 2), 20, v->idx,
+                                    nullptr, v->d_rec)))
         return rc;
-    hipLaunchKernelGGL(store_count_kernel, dim3(1), dim3(1), 0, ctx->stream, v->d_cnt + 1, &v->d_rec->n_tracked);
+    hipLaunchKernelGGL(store_count_kernel, dim3(1), dim3(1), 0, ctx->stream, cnt, &v->d_rec->n_tracked);
     SVO_HIP(hipMemcpyAsync(ctx->pinned, v->d_rec, sizeof(PnpRecord), hipMemcpyDeviceToHost, ctx->stream));
     if ((rc = svo_wait(ctx)))
         return rc;
@@ -1012,6 +1129,7 @@ static int chain_run(ChainRun *const *runs, int k, bool pipeline)
                 return rc;
             r.n_done = h + 1 + rest.n_done;
             r.end = rest.end;
+            r.halt_set = rest.halt_set;
         }
     }
     return SVO_OK;
@@ -1043,6 +1161,19 @@ int svo_vo_run_chunk(svo_vo *v, const uint8_t *const *lefts, const uint8_t *cons
         int prio_lo = 0, prio_hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
         SVO_HIP(hipStreamCreateWithPriority(&v->stream_b, hipStreamNonBlocking, prio_hi));
+    }
+    if (pipeline && !v->ctx_s) {  // the stereo stream: a context of its own (stream, scratch, tickets) + staging buffers
+        int rc;
+        const size_t n = (size_t)v->cap;
+        if ((rc = svo_ctx_create(v->ctx->device, &v->ctx_s)) || (rc = dev_alloc(&v->s_a2, n * 2)) ||
+            (rc = dev_alloc(&v->s_b2, n * 2)) || (rc = dev_alloc(&v->s_c2, n * 2)) || (rc = dev_alloc(&v->s_d2, n * 2)) ||
+            (rc = dev_alloc(&v->s_x1, n * 2)) || (rc = dev_alloc(&v->s_x2, n * 2)) || (rc = dev_alloc(&v->s_resp, n)) ||
+            (rc = dev_alloc(&v->s_status, n)) || (rc = dev_alloc(&v->s_st2, n)) || (rc = dev_alloc(&v->s_mask, n)) ||
+            (rc = dev_alloc(&v->s_idx, n)) || (rc = dev_alloc(&v->s_cnt, 16)) || (rc = dev_alloc(&v->trk2d_b, n * 2)) ||
+            (rc = dev_alloc(&v->trk3d_b, n * 3)) || (rc = dev_alloc(&v->idx_b, n)))
+            return rc;
+        for (hipEvent_t *e : {&v->ev_pyr, &v->ev_p1, &v->ev_tri, &v->ev_end})
+            SVO_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
     }
     if (v->nref < 5) {
         svo_set_error("tracking lost: %d reference points", v->nref);

@@ -88,6 +88,7 @@ struct TriJob {
     float *out_world;
     int *h_count;  // pinned host int that receives the live point count (the host waits on the stream), or null
     VoChain *chain;  // chain mode (svo_tri_job::chain) or null
+    float2 *out_x1;  // optional copy of x1
 };
 struct TriBatch {  // blockIdx.y picks the job
     TriJob j[SVO_LK_MAX_JOBS];
@@ -132,6 +133,8 @@ __global__ __launch_bounds__(128) void triangulate_kernel(Mat34 P1, Mat34 P2, Tr
         return;
     double A[4][4], v[4];
     const float2 a = x1[i], b = x2[i];
+    if (job.out_x1)
+        job.out_x1[i] = a;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         A[0][k] = (double)a.x * P1.m[8 + k] - P1.m[k];
@@ -310,6 +313,7 @@ int svo_launch_triangulate_batch(svo_ctx *ctx, const double *P1, const double *P
         j.out_world = h.out_world;
         j.h_count = a < k ? h.h_count : nullptr;
         j.chain = h.chain;
+        j.out_x1 = reinterpret_cast<float2 *>(h.out_x1);
         if (a < k)
             cap_max = h.cap > cap_max ? h.cap : cap_max;
     }

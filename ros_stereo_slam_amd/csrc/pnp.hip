@@ -1182,7 +1182,12 @@ __device__ void publish_record(const PnpJob &job, const PnpResult &r, PnpResult 
 // LEAN: capped at 96 VGPRs (with spills) so that the four-wave workgroup starts beside a full tracking launch
 // of another context -- the lock-step groups; a lone chunk has the chip to itself between its tracking
 // launches and takes the 128-VGPR build without spills (45 us faster alone).
-template <bool LEAN> __global__ __launch_bounds__(256, LEAN ? 5 : 4) void pnp_finish_kernel(PnpBatch batch)
+// mode (chain runner, one chunk per GPU): PNP_FINISH_ALL does everything; PNP_FINISH_DECIDE stops after the frame's
+// policy, the inlier list and the hand-over when the frame is NO keyframe -- what the next frame's filters wait for --
+// and leaves the refinement to a PNP_FINISH_REFINE launch that runs beside them (a keyframe is refined at once: its
+// stereo path needs the pose).
+enum { PNP_FINISH_ALL = 0, PNP_FINISH_DECIDE = 1, PNP_FINISH_REFINE = 2 };
+template <bool LEAN> __global__ __launch_bounds__(256, LEAN ? 5 : 4) void pnp_finish_kernel(PnpBatch batch, int mode)
 {
     svo_chain_priority();
     const PnpJob &job = batch.j[blockIdx.x];  // one workgroup per job
@@ -1204,15 +1209,19 @@ template <bool LEAN> __global__ __launch_bounds__(256, LEAN ? 5 : 4) void pnp_fi
     const int max_iters = job.max_lm_iters;
     PnpResult *__restrict__ out = job.out;
     VoChain *chain = job.chain;
-    if (chain && chain->run == 0)
+    if (mode == PNP_FINISH_REFINE) {
+        if (!chain || chain->refine_due == 0)
+            return;  // refined by the deciding launch (a keyframe), or the frame never got that far
+    } else if (chain && chain->run == 0) {
         return;  // the chain halted at an earlier frame
+    }
     __shared__ double s_all[RED_CHUNK * RED_STRIDE], s_part[4 * NACC], s_sum[NACC], s_pose[12], s_trial[12];
     __shared__ double s_norm[NACC];  // the normal equations at the accepted pose (packed like the accumulators)
     __shared__ int s_flag, s_wave[4], s_base;
     __shared__ RansacState s_state;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = d_n ? min(*d_n, n_host) : n_host;
-    if (tid == 0) {
+    if (tid == 0 && mode != PNP_FINISH_REFINE) {
         RansacState r;
         if (job.direct) {  // cv::solvePnP: every point takes part, the start is the DLT pose
             r.niters = r.next_iter = r.iters_run = 0;
@@ -1244,12 +1253,17 @@ template <bool LEAN> __global__ __launch_bounds__(256, LEAN ? 5 : 4) void pnp_fi
             }
         }
     }
+    if (tid == 0 && mode == PNP_FINISH_REFINE) {
+        s_state = *st;  // what the deciding launch left
+        s_base = *d_m;
+        s_flag = 0;
+    }
     __syncthreads();
     if (s_flag == 3)
         return;  // halted: the host takes over at this frame
     const RansacState s = s_state;
     const bool have_model = s.best_iter >= 0 && s.best_count > 0;
-    {
+    if (mode != PNP_FINISH_REFINE) {
         double P[12];
 #pragma unroll
         for (int k = 0; k < 12; k++)
@@ -1286,8 +1300,41 @@ template <bool LEAN> __global__ __launch_bounds__(256, LEAN ? 5 : 4) void pnp_fi
         }
     }
     const int m = s_base;
-    if (tid == 0)
+    if (tid == 0 && mode != PNP_FINISH_REFINE)
         *d_m = m;
+    if (chain && mode != PNP_FINISH_REFINE) {
+        // The frame's policy is known: its counts go to the per-frame record; no keyframe -> the tracked sets become
+        // the reference sets (src/VisualSLAM.cpp:143-146; a keyframe's sets are written by the stereo path that
+        // follows).  The refinement below reads the tracked sets and the inlier list, not the reference sets.
+        const int kf = chain->kf;  // written by thread 0 before the barriers of the pass above
+        if (kf == 0) {
+            const float2 *__restrict__ s2 = img;  // the job's point sets ARE the frame's tracked sets
+            float2 *__restrict__ d2 = reinterpret_cast<float2 *>(chain->ref2d);
+            const float *__restrict__ s3 = obj;
+            float *__restrict__ d3 = chain->ref3d;
+            for (int i = tid; i < n; i += 256)
+                d2[i] = s2[i];
+            for (int i = tid; i < 3 * n; i += 256)
+                d3[i] = s3[i];
+        }
+        if (tid == 0) {
+            VoOut *o = chain->out + chain->frame;
+            o->inliers = s.best_count;
+            o->tracked = n;
+            o->keyframe = kf;
+            o->pad = 0;
+            if (kf == 0) {
+                chain->nref = n;
+                if (n < 5) {  // svo_vo_run_chunk: "tracking lost: n reference points" at the next frame
+                    chain->run = 0;
+                    chain->halt_code = SVO_HALT_FEW_REF;
+                }
+            }
+            chain->refine_due = (mode == PNP_FINISH_DECIDE && kf == 0) ? 1 : 0;
+        }
+        if (mode == PNP_FINISH_DECIDE && kf == 0)
+            return;  // PNP_FINISH_REFINE finishes the frame beside the next frame's filters
+    }
     if (!have_model || m <= 0) {
         if (tid == 0) {
             PnpResult r;
@@ -1429,34 +1476,8 @@ template <bool LEAN> __global__ __launch_bounds__(256, LEAN ? 5 : 4) void pnp_fi
                 chain->R[k] = R9[k];
                 o->R[k] = R9[k];
             }
-            o->inliers = s.best_count;
-            o->tracked = n;
-            o->keyframe = chain->kf;
-            o->pad = 0;
-        }
-    }
-    if (chain) {
-        // no keyframe: the tracked sets become the reference sets (src/VisualSLAM.cpp:143-146); a keyframe's sets are
-        // written by the stereo path that follows
-        if (chain->kf == 0) {
-            const float2 *__restrict__ s2 = reinterpret_cast<const float2 *>(chain->trk2d);
-            float2 *__restrict__ d2 = reinterpret_cast<float2 *>(chain->ref2d);
-            const float *__restrict__ s3 = chain->trk3d;
-            float *__restrict__ d3 = chain->ref3d;
-            for (int i = tid; i < n; i += 256)
-                d2[i] = s2[i];
-            for (int i = tid; i < 3 * n; i += 256)
-                d3[i] = s3[i];
-        }
-        if (tid == 0) {
-            if (chain->kf == 0) {
-                chain->nref = n;
-                if (n < 5) {  // svo_vo_run_chunk: "tracking lost: n reference points" at the next frame
-                    chain->run = 0;
-                    chain->halt_code = SVO_HALT_FEW_REF;
-                }
-            }
-            chain->frame = chain->frame + 1;
+            chain->refine_due = 0;
+            chain->frame = chain->frame + 1;  // the frame is finished
         }
     }
 }
@@ -1465,12 +1486,10 @@ template <bool LEAN> __global__ __launch_bounds__(256, LEAN ? 5 : 4) void pnp_fi
 
 static_assert(sizeof(PnpResult) == 17 * 8, "PnpResult layout");
 
-// Device-pointer form, several problems in one set of launches.  inliers: cap ints; d_result: one
-// PnpResult (136 bytes): rvec[3] tvec[3] R[9] rms (doubles) n_inliers iters_run (ints).
-int svo_launch_pnp_ransac_batch(svo_ctx *ctx, int n_jobs, const svo_pnp_job *jobs)
+// the kernels' view of the jobs (workspace: hypotheses in w_c, state + counters in w_d, per job); returns the number
+// of jobs with points, < 0 on an error
+static int pnp_fill_batch(svo_ctx *ctx, int n_jobs, const svo_pnp_job *jobs, PnpBatch &batch, int *it_max_out)
 {
-    if (n_jobs <= 0)
-        return SVO_OK;
     if (n_jobs > SVO_LK_MAX_JOBS) {
         svo_set_error("pnp: at most %d jobs per launch", SVO_LK_MAX_JOBS);
         return SVO_ERR_ARG;
@@ -1478,12 +1497,11 @@ int svo_launch_pnp_ransac_batch(svo_ctx *ctx, int n_jobs, const svo_pnp_job *job
     int it_max = 1;
     for (int k = 0; k < n_jobs; k++)
         it_max = jobs[k].iterations > it_max ? jobs[k].iterations : it_max;
-    // per-job workspace: hypotheses in w_c, state + counters in w_d
+    *it_max_out = it_max;
     const size_t h_stride = (size_t)it_max * 12, i_stride = ((size_t)it_max * 2 + 32 + 15) / 16 * 16;
     int rc;
     if ((rc = ctx->w_c.ensure(h_stride * sizeof(double) * n_jobs)) || (rc = ctx->w_d.ensure(i_stride * sizeof(int) * n_jobs)))
         return rc;
-    PnpBatch batch;
     int nb = 0;
     for (int k = 0; k < n_jobs; k++) {
         const svo_pnp_job &h = jobs[k];
@@ -1517,10 +1535,22 @@ int svo_launch_pnp_ransac_batch(svo_ctx *ctx, int n_jobs, const svo_pnp_job *job
         j.ticket = ctx->d_tickets + 16 + nb;  // slots 0..15: fransac.hip
         nb++;
     }
-    if (nb == 0)
-        return SVO_OK;
     for (int k = nb; k < SVO_LK_MAX_JOBS; k++)
         batch.j[k] = batch.j[0];
+    return nb;
+}
+
+// Device-pointer form, several problems in one set of launches.  inliers: cap ints; d_result: one
+// PnpResult (136 bytes): rvec[3] tvec[3] R[9] rms (doubles) n_inliers iters_run (ints).
+int svo_launch_pnp_ransac_batch(svo_ctx *ctx, int n_jobs, const svo_pnp_job *jobs, bool split)
+{
+    if (n_jobs <= 0)
+        return SVO_OK;
+    PnpBatch batch;
+    int it_max = 1;
+    const int nb = pnp_fill_batch(ctx, n_jobs, jobs, batch, &it_max);
+    if (nb <= 0)
+        return nb;
     ScopedKernelTime tm(ctx, SVO_K_PNP);
     // single-wave workgroups: they get wave slots beside a tracking launch as soon as one frees
     const int bounds[3] = {0, it_max < PNP_PHASE_A ? it_max : PNP_PHASE_A, it_max};
@@ -1528,10 +1558,35 @@ int svo_launch_pnp_ransac_batch(svo_ctx *ctx, int n_jobs, const svo_pnp_job *job
         if (bounds[ph + 1] > bounds[ph])  // solves AND scores; the second phase usually leaves at once
             hipLaunchKernelGGL(pnp_solve_kernel, dim3(bounds[ph + 1] - bounds[ph], nb), dim3(64), 0, ctx->stream, batch,
                                bounds[ph], bounds[ph + 1]);
+    const int mode = split ? PNP_FINISH_DECIDE : PNP_FINISH_ALL;
     if (nb > 1)
-        hipLaunchKernelGGL(pnp_finish_kernel<true>, dim3(nb), dim3(256), 0, ctx->stream, batch);
+        hipLaunchKernelGGL(pnp_finish_kernel<true>, dim3(nb), dim3(256), 0, ctx->stream, batch, mode);
     else
-        hipLaunchKernelGGL(pnp_finish_kernel<false>, dim3(nb), dim3(256), 0, ctx->stream, batch);
+        hipLaunchKernelGGL(pnp_finish_kernel<false>, dim3(nb), dim3(256), 0, ctx->stream, batch, mode);
+    SVO_HIP(hipGetLastError());
+    return SVO_OK;
+}
+
+int svo_launch_pnp_ransac_batch(svo_ctx *ctx, int n_jobs, const svo_pnp_job *jobs)
+{
+    return svo_launch_pnp_ransac_batch(ctx, n_jobs, jobs, false);
+}
+
+// the refinement a split launch left undone (frames that are no keyframes); same jobs, same workspace
+int svo_launch_pnp_refine(svo_ctx *ctx, int n_jobs, const svo_pnp_job *jobs)
+{
+    if (n_jobs <= 0)
+        return SVO_OK;
+    PnpBatch batch;
+    int it_max = 1;
+    const int nb = pnp_fill_batch(ctx, n_jobs, jobs, batch, &it_max);
+    if (nb <= 0)
+        return nb;
+    ScopedKernelTime tm(ctx, SVO_K_PNP);
+    if (nb > 1)
+        hipLaunchKernelGGL(pnp_finish_kernel<true>, dim3(nb), dim3(256), 0, ctx->stream, batch, (int)PNP_FINISH_REFINE);
+    else
+        hipLaunchKernelGGL(pnp_finish_kernel<false>, dim3(nb), dim3(256), 0, ctx->stream, batch, (int)PNP_FINISH_REFINE);
     SVO_HIP(hipGetLastError());
     return SVO_OK;
 }
@@ -1607,7 +1662,7 @@ int svo_launch_solve_pnp(svo_ctx *ctx, const float *obj, const float *img, int c
         batch.j[k] = batch.j[0];
     ScopedKernelTime tm(ctx, SVO_K_PNP);
     hipLaunchKernelGGL(pnp_dlt_kernel, dim3(1), dim3(256), 0, ctx->stream, d);
-    hipLaunchKernelGGL(pnp_finish_kernel<false>, dim3(1), dim3(256), 0, ctx->stream, batch);
+    hipLaunchKernelGGL(pnp_finish_kernel<false>, dim3(1), dim3(256), 0, ctx->stream, batch, (int)PNP_FINISH_ALL);
     SVO_HIP(hipGetLastError());
     return SVO_OK;
 }

@@ -145,12 +145,12 @@ struct VoChain {
     int frame;      // frames of this run finished = index of the next one
     int halt_code;  // SVO_HALT_*
     int kf_n;       // points of the last keyframe's camera-frame cloud
-    int pad[2];
+    int refine_due; // 1: the frame's policy is decided, its refinement is left to a PNP_FINISH_REFINE launch
+    int pad;
     double R[9], t[3];  // pose of the frame just localised, camera in world: the keyframe's [R|t]
     // configuration, written by the host before a run
     int kf_min, retry_below;
-    float *ref2d, *ref3d;        // hand-over destination (src/VisualSLAM.cpp:143-146)
-    const float *trk2d, *trk3d;  // hand-over source: the tracked sets of the frame
+    float *ref2d, *ref3d;        // hand-over destination (src/VisualSLAM.cpp:143-146); the source is the PnP job's sets
     VoOut *out;                  // pinned host array, one record per frame of the run
 };
 
@@ -226,6 +226,7 @@ struct svo_tri_job {  // one stereo DLT triangulation (device pointers; Rt: host
     // chain mode (optional): [R|t] is read from chain->R / chain->t on the device (Rt must be null), the job runs only
     // when chain->kf is set, the live count goes to chain->nref / chain->kf_n and fewer than 5 points halt the chain
     VoChain *chain = nullptr;
+    float *out_x1 = nullptr;  // optional: a copy of x1 (the keyframe's 2-D reference set when x1 is a staging buffer)
 };
 int svo_launch_triangulate_batch(svo_ctx *ctx, const double *P1, const double *P2, int k, const svo_tri_job *jobs);
 int svo_launch_transform(svo_ctx *ctx, const double *Rt, const float *in, int cap, const int *d_n, float *out);
@@ -263,6 +264,10 @@ struct svo_pnp_job {  // host-side description of one PnP-RANSAC problem (device
     VoChain *chain = nullptr;
     const int *cnt_trk;
 };
+// split: the finishing launch is queued as PNP_FINISH_DECIDE, the refinement of a frame that is no keyframe is left to
+// svo_launch_pnp_refine (chain jobs only; the caller queues it where it runs beside the next frame's filters)
+int svo_launch_pnp_ransac_batch(svo_ctx *ctx, int n_jobs, const svo_pnp_job *jobs, bool split);
+int svo_launch_pnp_refine(svo_ctx *ctx, int n_jobs, const svo_pnp_job *jobs);
 int svo_launch_pnp_ransac_batch(svo_ctx *ctx, int n_jobs, const svo_pnp_job *jobs);
 int svo_launch_pnp_ransac(svo_ctx *ctx, const float *obj, const float *img, int cap, const int *d_n,
                           const double *K4h, int iterations, double reproj_err, double confidence, uint64_t seed,
