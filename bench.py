@@ -246,6 +246,29 @@ def main():
 
     vo_kw = dict(grid_step=grid_step, anms_keep=n_kpts, keyframe_min_inliers=kf_min)
     sh = chunked.ShardedVO(capi, local_rank, W, H, C, M, G, first_chunk_id=rank * M, seed=20261003, **vo_kw)
+    # The path's one collective behind the C ABI: an RCCL communicator made by the library itself (what a C++ host of
+    # INTEGRATION.md section 4 uses); the 128-byte id travels through torch.distributed here.  Any failure falls back
+    # to torch.distributed's all-gather (also RCCL) and says so in the line.
+    comm, collective = None, None
+    if not rehearsal:
+        try:
+            ident_bytes = [capi.shard_unique_id() if rank == 0 else None]
+            if dist is not None:
+                dist.broadcast_object_list(ident_bytes, src=0)
+            comm = capi.ShardComm(sh.ctxs[0], rank, world, ident_bytes[0])
+            collective = f"ncclAllGather through svo_shard_allgather_boundaries (C ABI, librccl), {world} rank(s)"
+        except Exception as e:   # noqa: BLE001 -- the bench must not die on the optional path
+            comm = None
+            collective = f"torch.distributed all_gather (C-ABI communicator unavailable: {type(e).__name__}: {e})"
+    if collective is None:
+        collective = "gloo rehearsal on one GPU"
+    if dist is not None:
+        ok = torch.tensor([1 if comm is not None else 0], device=coll_dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)      # every rank takes the same path
+        if int(ok.item()) == 0 and comm is not None:
+            comm.close()
+            comm = None
+            collective = "torch.distributed all_gather (another rank has no C-ABI communicator)"
     bounds = chunked.chunk_bounds(share + 1, M)
     assert all(e - s == L for s, e in bounds)
 
@@ -283,8 +306,8 @@ def main():
     # ---- the timed region: EXACTLY --steps steps + the path's one exchange ----
     t0 = time.perf_counter()
     run(Wn, L, False, local, stats)
-    if dist is not None:
-        boundaries = chunked.all_gather_chunk_boundaries(dist, [loc[-1] for loc in local], device=coll_dev)
+    if dist is not None or comm is not None:
+        boundaries = chunked.all_gather_chunk_boundaries(dist, [loc[-1] for loc in local], device=coll_dev, comm=comm)
     else:
         boundaries = [loc[-1] for loc in local]
     starts = chunked.prefix_transforms(boundaries)  # global pose of every chunk's first frame
@@ -348,8 +371,8 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         run(0, L, True, local2)
-        if dist is not None:
-            chunked.all_gather_chunk_boundaries(dist, [loc[-1] for loc in local2], device=coll_dev)
+        if dist is not None or comm is not None:
+            chunked.all_gather_chunk_boundaries(dist, [loc[-1] for loc in local2], device=coll_dev, comm=comm)
         sh.sync()
         torch.cuda.synchronize()
         if dist is not None:
@@ -450,6 +473,7 @@ def main():
                 "keyframe_min_inliers": kf_min,
                 "parallelism": f"{M} contiguous chunk(s) of {L} frames per GPU x{world} GPU(s), one all-gather of "
                                "chunk-boundary poses",
+                "collective": collective,
                 "chunks_per_gpu": M,
                 "chunks_per_context": G,
                 "frames_per_chunk": L,
@@ -571,6 +595,8 @@ def main():
 
     if rank == 0:
         print(json.dumps(result))
+    if comm is not None:
+        comm.close()
     if dist is not None:
         dist.destroy_process_group()
     sh.close()

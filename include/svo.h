@@ -349,6 +349,33 @@ int svo_vo_run_chunks(svo_chunk_job *jobs, int n_jobs);
 /* the current reference point set (2-D in the reference image, 3-D world) */
 int svo_vo_get_reference(svo_vo *vo, float *ref2d, float *ref3d, int cap, int *n, int mem);
 int svo_vo_capacity(const svo_vo *vo);
+/* `colors` of the last keyframe (getColors(imL, its 2-D points): B, G, R as floats per point,
+ * include/monoUtils.h:180-193, src/triangulation.cpp:139-140), point for point with svo_vo_get_keyframe_cloud:
+ * what src/VisualSLAM.cpp:125-136 pushes into colorHistory.  Gathered by the triangulation launch itself. */
+int svo_vo_get_keyframe_colors(svo_vo *vo, float *bgr, int cap, int *n, int mem);
+
+/* ---- the chunk-sharded batch across GPUs: its one exchange step ------------------
+ * The frame loop is sequential in time (src/VisualSLAM.cpp:54-200: frame n consumes frame n-1's
+ * surviving points), so a batch shards across GPUs only as contiguous chunks that re-initialise at
+ * their first frame and end ON the next chunk's first frame.  One process per GPU, each with its own
+ * svo_ctx; the ranks exchange their chunk-boundary poses ONCE -- 12 doubles per chunk, [R row-major | t]
+ * of the chunk's last frame in the chunk's own frame -- with an RCCL all-gather, prefix-compose them
+ * and rebase their poses; the rebased trajectories then feed one pose graph (svo_pg_*).
+ * librccl is loaded at run time; without it these calls return SVO_ERR_STATE.
+ *   id128: 128 bytes (ncclUniqueId) made by ONE rank and carried to the others by the host's own means. */
+typedef struct svo_shard_comm svo_shard_comm;
+int svo_shard_unique_id(void *id128);
+int svo_shard_comm_create(svo_ctx *ctx, int rank, int nranks, const void *id128, svo_shard_comm **out);
+int svo_shard_comm_destroy(svo_shard_comm *comm);
+int svo_shard_comm_rank(const svo_shard_comm *comm);
+int svo_shard_comm_size(const svo_shard_comm *comm);
+/* local12: this rank's n_chunks x 12 doubles (host); all12: nranks x n_chunks x 12 (host), rank-major */
+int svo_shard_allgather_boundaries(svo_shard_comm *comm, const double *local12, int n_chunks, double *all12);
+/* boundaries of ALL chunks in global order -> the global pose of every chunk's first frame
+ * (identity, B0, B0 B1, ...); host arithmetic, no communicator needed */
+int svo_shard_prefix_starts(const double *boundaries12, int n_total, double *starts12);
+/* chunk-local poses (n x 12, relative to the chunk's first frame) -> global poses, in place */
+int svo_shard_rebase(const double *start12, double *poses12, int n);
 
 /* ---- the keyframe map and its re-projection: visualSLAM::updateOdometry ------------------------ */
 /* src/optimizationStuff.cpp:17-47 over keyFrameHistory (src/VisualSLAM.cpp:152-166,

@@ -405,16 +405,21 @@ class visualSLAM {
         int kf = 0;
         check(svo_vo_update(vo_, mat_data(right), SVO_MEM_HOST, R.m, t.v, ninl, LC_FLAG ? 1 : 0, &kf));
         if (kf) {  // src/VisualSLAM.cpp:122-140
-            // good3d = the new reference cloud (world), SORcloud'ed, appended to mapHistory; colorHistory is
-            // not filled by the fused path (colours: stereoTriangulate's `colors` member of the stage path)
+            // good3d = the new reference cloud (world) with its colours -- stereoTriangulate's `colors` member, gathered
+            // by the fused path's triangulation launch --, SORcloud'ed together, appended to mapHistory / colorHistory
+            // (src/VisualSLAM.cpp:125-136)
             const int cap = svo_vo_capacity(vo_);
-            std::vector<Point3f> good3d((size_t)cap), none;
-            int n = 0;
+            std::vector<Point3f> good3d((size_t)cap), goodColors((size_t)cap);
+            int n = 0, nc = 0;
             check(svo_vo_get_reference(vo_, nullptr, f3(good3d), cap, &n, SVO_MEM_HOST));
+            check(svo_vo_get_keyframe_colors(vo_, f3(goodColors), cap, &nc, SVO_MEM_HOST));
             good3d.resize((size_t)n);
+            goodColors.resize((size_t)(nc == n ? n : 0));  // point for point with the cloud, or none
+            colors = goodColors;
             if (mapSOR && n > 0)
-                SORcloud(good3d, none);
+                SORcloud(good3d, goodColors);
             mapHistory.emplace_back(good3d);
+            colorHistory.emplace_back(goodColors);
             isoVector.push_back(Isometry3d_from(R, t));
             trajectory.push_back(t);
         }

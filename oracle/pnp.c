@@ -813,8 +813,114 @@ int orc_solve_pnp(const float *obj, const float *img, int n, const double *K4, d
             }
             w[c] = sqrt(q);
         }
-        if (!(w[1] > 0) || w[2] / w[1] < 1e-3)
+        if (!(w[1] > 0))
             return -2;
+        if (w[2] / w[1] < 1e-3) {
+            /* upstream's planar branch (cvFindExtrinsicCameraParams2): plane-aligned coordinates, homography by the
+             * normalised DLT of findHomography(method 0), [h1 h2 h1 x h2] orthonormalised, t = 2 h3 / (|h1| + |h2|),
+             * back through the plane transform; then the same refinement as the other branch.  (Upstream polishes
+             * the homography with ten LM steps of its own first; the pose refinement minimises the same error.) */
+            const double inv_n = 1. / n, mx = S[0][3] * inv_n, my = S[0][6] * inv_n, mz = S[0][8] * inv_n;
+            double Rp[9], Tp[3];
+            for (int r = 0; r < 3; r++)
+                for (int c = 0; c < 3; c++)
+                    Rp[3 * r + c] = V[3 * c + r];
+            if (Rp[2] * Rp[2] + Rp[5] * Rp[5] < 1e-10)
+                for (int i = 0; i < 9; i++)
+                    Rp[i] = (i % 4) == 0 ? 1. : 0.;
+            const double detp = Rp[0] * (Rp[4] * Rp[8] - Rp[5] * Rp[7]) - Rp[1] * (Rp[3] * Rp[8] - Rp[5] * Rp[6]) +
+                                Rp[2] * (Rp[3] * Rp[7] - Rp[4] * Rp[6]);
+            if (detp < 0)
+                for (int i = 0; i < 9; i++)
+                    Rp[i] = -Rp[i];
+            for (int r = 0; r < 3; r++)
+                Tp[r] = -(Rp[3 * r] * mx + Rp[3 * r + 1] * my + Rp[3 * r + 2] * mz);
+            double *q = (double *)malloc(sizeof(double) * 4 * (size_t)n);
+            double c4[4] = {0, 0, 0, 0}, d4[4] = {0, 0, 0, 0}, sc4[4];
+            for (int i = 0; i < n; i++) {
+                const double px = obj[3 * i], py = obj[3 * i + 1], pz = obj[3 * i + 2];
+                q[4 * i] = Rp[0] * px + Rp[1] * py + Rp[2] * pz + Tp[0];
+                q[4 * i + 1] = Rp[3] * px + Rp[4] * py + Rp[5] * pz + Tp[1];
+                q[4 * i + 2] = ((double)img[2 * i] - K4[2]) * ifx;
+                q[4 * i + 3] = ((double)img[2 * i + 1] - K4[3]) * ify;
+                for (int k = 0; k < 4; k++)
+                    c4[k] += q[4 * i + k];
+            }
+            for (int k = 0; k < 4; k++)
+                c4[k] *= inv_n;
+            for (int i = 0; i < n; i++)
+                for (int k = 0; k < 4; k++)
+                    d4[k] += fabs(q[4 * i + k] - c4[k]);
+            for (int k = 0; k < 4; k++) {
+                if (!(d4[k] > DBL_EPSILON)) {
+                    free(q);
+                    return -2;
+                }
+                sc4[k] = n / d4[k];
+            }
+            double LtL[81], Vh9[81], w9[9];
+            memset(LtL, 0, sizeof(LtL));
+            for (int i = 0; i < n; i++) {
+                const double X = (q[4 * i] - c4[0]) * sc4[0], Y = (q[4 * i + 1] - c4[1]) * sc4[1];
+                const double u = (q[4 * i + 2] - c4[2]) * sc4[2], v = (q[4 * i + 3] - c4[3]) * sc4[3];
+                const double Lx[9] = {X, Y, 1, 0, 0, 0, -u * X, -u * Y, -u};
+                const double Ly[9] = {0, 0, 0, X, Y, 1, -v * X, -v * Y, -v};
+                for (int r = 0; r < 9; r++)
+                    for (int c = r; c < 9; c++)
+                        LtL[9 * r + c] += Lx[r] * Lx[c] + Ly[r] * Ly[c];
+            }
+            free(q);
+            for (int r = 0; r < 9; r++)
+                for (int c = 0; c < r; c++)
+                    LtL[9 * r + c] = LtL[9 * c + r];
+            orc_jacobi_eigen_sym(9, LtL, Vh9, w9, 10);
+            int best = 0;
+            for (int e = 1; e < 9; e++)
+                if (w9[e] < w9[best])
+                    best = e;
+            double H0[9], H1[9], H[9];
+            for (int i = 0; i < 9; i++)
+                H0[i] = Vh9[9 * i + best];
+            const double Ti[9] = {1. / sc4[2], 0, c4[2], 0, 1. / sc4[3], c4[3], 0, 0, 1};
+            const double Tm[9] = {sc4[0], 0, -c4[0] * sc4[0], 0, sc4[1], -c4[1] * sc4[1], 0, 0, 1};
+            for (int r = 0; r < 3; r++)
+                for (int c = 0; c < 3; c++)
+                    H1[3 * r + c] = H0[3 * r] * Tm[c] + H0[3 * r + 1] * Tm[3 + c] + H0[3 * r + 2] * Tm[6 + c];
+            for (int r = 0; r < 3; r++)
+                for (int c = 0; c < 3; c++)
+                    H[3 * r + c] = Ti[3 * r] * H1[c] + Ti[3 * r + 1] * H1[3 + c] + Ti[3 * r + 2] * H1[6 + c];
+            if (!(fabs(H[8]) > DBL_EPSILON))
+                return -2;
+            const double ih = 1. / H[8];
+            for (int i = 0; i < 9; i++)
+                H[i] *= ih;
+            const double n1 = sqrt(H[0] * H[0] + H[3] * H[3] + H[6] * H[6]);
+            const double n2 = sqrt(H[1] * H[1] + H[4] * H[4] + H[7] * H[7]);
+            const double i1 = 1. / fmax(n1, DBL_EPSILON), i2 = 1. / fmax(n2, DBL_EPSILON), it = 2. / fmax(n1 + n2, DBL_EPSILON);
+            const double h1[3] = {H[0] * i1, H[3] * i1, H[6] * i1}, h2[3] = {H[1] * i2, H[4] * i2, H[7] * i2};
+            const double th[3] = {H[2] * it, H[5] * it, H[8] * it};
+            const double h3[3] = {h1[1] * h2[2] - h1[2] * h2[1], h1[2] * h2[0] - h1[0] * h2[2], h1[0] * h2[1] - h1[1] * h2[0]};
+            const double Hm[9] = {h1[0], h2[0], h3[0], h1[1], h2[1], h3[1], h1[2], h2[2], h3[2]};
+            double Uh[9], Vh[9], Rh[9], R[9], t[3];
+            svd3(Hm, Uh, Vh);
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 3; j++)
+                    Rh[3 * i + j] = Uh[3 * i] * Vh[3 * j] + Uh[3 * i + 1] * Vh[3 * j + 1] + Uh[3 * i + 2] * Vh[3 * j + 2];
+            for (int i = 0; i < 3; i++) {
+                t[i] = Rh[3 * i] * Tp[0] + Rh[3 * i + 1] * Tp[1] + Rh[3 * i + 2] * Tp[2] + th[i];
+                for (int j = 0; j < 3; j++)
+                    R[3 * i + j] = Rh[3 * i] * Rp[j] + Rh[3 * i + 1] * Rp[3 + j] + Rh[3 * i + 2] * Rp[6 + j];
+            }
+            for (int i = 0; i < 9; i++)
+                if (!isfinite(R[i]))
+                    return -2;
+            const double rms = orc_pnp_refine_Rt(obj, img, 0, n, K4, R, t, 20);
+            orc_rodrigues_inv(R, rvec);
+            memcpy(tvec, t, sizeof(t));
+            if (rms_out)
+                *rms_out = rms;
+            return 0;
+        }
     }
     double A[144], V[144], w[12];
     for (int e = 0; e < 144; e++) {

@@ -463,6 +463,14 @@ class VisualOdometry:
         _check(self.ctx.lib.svo_vo_get_keyframe_cloud(self._h, _ptr(a), cap, C.byref(n), MEM_HOST))
         return a[:n.value]
 
+    def keyframe_colors(self):
+        """``colors`` of the last keyframe (B, G, R floats per point, point for point with keyframe_cloud())."""
+        cap = self.ctx.lib.svo_vo_capacity(self._h)
+        a = np.zeros((cap, 3), np.float32)
+        n = C.c_int()
+        _check(self.ctx.lib.svo_vo_get_keyframe_colors(self._h, _ptr(a), cap, C.byref(n), MEM_HOST))
+        return a[:n.value]
+
     def reference(self):
         cap = self.ctx.lib.svo_vo_capacity(self._h)
         a, b = np.zeros((cap, 2), np.float32), np.zeros((cap, 3), np.float32)
@@ -547,6 +555,55 @@ def write_ply(path, xyz, rgb=None):
     xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
     col = None if rgb is None else np.ascontiguousarray(rgb, np.uint8).reshape(-1, 3)
     _check(load().svo_io_write_ply(str(path).encode(), _ptr(xyz), _ptr(col), len(xyz)))
+
+
+class ShardComm:
+    """The chunk-sharded batch's one collective behind the C ABI (``svo_shard_*``): an RCCL communicator of one rank
+    per GPU and the all-gather of chunk-boundary poses.  ``id128``: bytes from :func:`shard_unique_id` of ONE rank."""
+
+    def __init__(self, ctx: "Context", rank: int, nranks: int, id128: bytes):
+        self.ctx = ctx
+        self._h = C.c_void_p()
+        buf = (C.c_char * 128).from_buffer_copy(id128)
+        _check(ctx.lib.svo_shard_comm_create(ctx._h, rank, nranks, buf, C.byref(self._h)))
+        self.rank, self.nranks = rank, nranks
+
+    def allgather_boundaries(self, pairs):
+        """pairs: this rank's [(R, t)] chunk-boundary poses -> all ranks' in global chunk order."""
+        loc = np.ascontiguousarray([np.r_[np.asarray(R, np.float64).ravel(), np.asarray(t, np.float64).ravel()]
+                                    for R, t in pairs], np.float64)
+        out = np.zeros((self.nranks * len(pairs), 12))
+        _check(self.ctx.lib.svo_shard_allgather_boundaries(self._h, _ptr(loc), len(pairs), _ptr(out)))
+        return [(row[:9].reshape(3, 3).copy(), row[9:].copy()) for row in out]
+
+    def close(self):
+        if self._h:
+            self.ctx.lib.svo_shard_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+
+def shard_unique_id() -> bytes:
+    buf = (C.c_char * 128)()
+    _check(load().svo_shard_unique_id(buf))
+    return bytes(buf.raw)
+
+
+def shard_prefix_starts(boundaries):
+    """``svo_shard_prefix_starts``: [(R, t)] boundaries of all chunks -> global pose of every chunk's first frame."""
+    b = np.ascontiguousarray([np.r_[np.asarray(R, np.float64).ravel(), np.asarray(t, np.float64).ravel()]
+                              for R, t in boundaries], np.float64)
+    out = np.zeros_like(b)
+    _check(load().svo_shard_prefix_starts(_ptr(b), len(boundaries), _ptr(out)))
+    return [(row[:9].reshape(3, 3).copy(), row[9:].copy()) for row in out]
+
+
+def shard_rebase(start, poses):
+    """``svo_shard_rebase``: chunk-local [(R, t)] -> global, given the chunk's start pose (R, t)."""
+    s12 = np.r_[np.asarray(start[0], np.float64).ravel(), np.asarray(start[1], np.float64).ravel()]
+    p = np.ascontiguousarray([np.r_[np.asarray(R, np.float64).ravel(), np.asarray(t, np.float64).ravel()]
+                              for R, t in poses], np.float64).reshape(-1, 12)
+    _check(load().svo_shard_rebase(_ptr(s12), _ptr(p), len(poses)))
+    return [(row[:9].reshape(3, 3).copy(), row[9:].copy()) for row in p]
 
 
 class _ChunkJob(C.Structure):

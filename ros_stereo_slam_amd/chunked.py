@@ -73,11 +73,17 @@ def all_gather_boundaries(dist, R, t, device=None):
     return res
 
 
-def all_gather_chunk_boundaries(dist, pairs, device=None):
+def all_gather_chunk_boundaries(dist, pairs, device=None, comm=None):
     """As :func:`all_gather_boundaries` when every rank runs several chunks side by side
     (``svo_vo_run_chunks``): ``pairs`` = this rank's chunk-boundary poses in chunk order, the
     same number on every rank.  Still ONE all-gather (12 doubles per chunk); returns the
-    boundaries of all chunks in global chunk order (rank-major)."""
+    boundaries of all chunks in global chunk order (rank-major).
+
+    ``comm``: a ``capi.ShardComm`` -- the collective then runs behind the C ABI
+    (``svo_shard_allgather_boundaries``: ncclAllGather on the context's stream), which is what a C++ host
+    calls; ``dist`` is not touched."""
+    if comm is not None:
+        return comm.allgather_boundaries(pairs)
     import torch
 
     dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")

@@ -52,6 +52,7 @@ struct svo_vo {
     // point sets (device)
     float *ref2d = nullptr, *ref3d = nullptr, *trk2d = nullptr, *trk3d = nullptr;
     float *a2 = nullptr, *b2 = nullptr, *c2 = nullptr, *d2 = nullptr, *a3 = nullptr, *b3 = nullptr, *resp = nullptr;
+    float *kf_col = nullptr;  // colours of the last keyframe's points (B, G, R as floats), beside its cloud in b3
     uint8_t *status = nullptr, *mask = nullptr, *st2 = nullptr;
     float *grid_xy = nullptr;  // the keypoint lattice of src/triangulation.cpp:89-96, written once at creation
     int *idx = nullptr, *d_cnt = nullptr;  // d_cnt[0..7]: stage counts
@@ -194,6 +195,8 @@ int stereo_triangulate_batch(int k, svo_vo *const *vs, svo_pyramid *const *lefts
         else
             tj[a] = {x1, x2, n, v->d_cnt + 4, Rts[a] ? v->b3 : out3d[a], nullptr, Rts[a], Rts[a] ? out3d[a] : nullptr,
                      reinterpret_cast<int *>(ctx->pinned) + a};  // the count the host reads after the wait below
+        tj[a].color_src = lefts[a];  // `colors` of stereoTriangulate (src/triangulation.cpp:139-140), same launch
+        tj[a].color_out = v->kf_col;
     }
     double P1[12], P2[12];
     svo_stereo_projections(v0->prm.fx, v0->prm.fy, v0->prm.cx, v0->prm.cy, v0->prm.baseline, P1, P2);
@@ -265,10 +268,12 @@ int stereo_part1_spec(svo_vo *v, svo_pyramid *left, svo_pyramid *right, int fram
 // ... and the half that does: DLT triangulation of the filtered pairs and the cloud's placement with the frame's refined
 // pose (src/triangulation.cpp:142-160, src/keyFrameManagement.cpp:20-30), on the main stream, only when the device flag
 // says keyframe.  The keyframe's 2-D set is copied from the staging buffer by the same kernel.
-int stereo_part2_spec(svo_vo *v)
+int stereo_part2_spec(svo_vo *v, const svo_pyramid *left)
 {
     const int n = grid_axis(v->w, v->prm.grid_step) * grid_axis(v->h, v->prm.grid_step);
     svo_tri_job tj = {v->s_x1, v->s_x2, n, v->s_cnt + 4, v->b3, nullptr, nullptr, v->ref3d, nullptr, v->d_chain, v->ref2d};
+    tj.color_src = left;
+    tj.color_out = v->kf_col;
     double P1[12], P2[12];
     svo_stereo_projections(v->prm.fx, v->prm.fy, v->prm.cx, v->prm.cy, v->prm.baseline, P1, P2);
     return svo_launch_triangulate_batch(v->ctx, P1, P2, 1, &tj);
@@ -411,6 +416,7 @@ int svo_vo_create(svo_ctx *ctx, const svo_vo_params *params, int width, int heig
         (rc = dev_alloc(&v->a2, n * 2)) || (rc = dev_alloc(&v->b2, n * 2)) || (rc = dev_alloc(&v->c2, n * 2)) ||
         (rc = dev_alloc(&v->d2, n * 2)) || (rc = dev_alloc(&v->a3, n * 3)) || (rc = dev_alloc(&v->b3, n * 3)) ||
         (rc = dev_alloc(&v->resp, n)) || (rc = dev_alloc(&v->status, n)) || (rc = dev_alloc(&v->mask, n)) ||
+        (rc = dev_alloc(&v->kf_col, n * 3)) ||
         (rc = dev_alloc(&v->st2, n)) || (rc = dev_alloc(&v->idx, n)) || (rc = dev_alloc(&v->d_cnt, 16)) ||
         (rc = dev_alloc(&v->d_rec, 2)) || (rc = dev_alloc(&v->d_img, (size_t)width * height * channels)) ||
         (rc = dev_alloc(&v->grid_xy, n * 2)) ||
@@ -471,6 +477,8 @@ int svo_vo_destroy(svo_vo *v)
         (void)hipHostFree(v->h_out);
     if (v->d_chain)
         (void)hipFree(v->d_chain);
+    if (v->kf_col)
+        (void)hipFree(v->kf_col);
     void *bufs[] = {v->ref2d, v->ref3d, v->trk2d, v->trk3d, v->a2,   v->b2,    v->c2,    v->d2,   v->a3,
                     v->b3,    v->resp,  v->status, v->mask, v->st2, v->idx,   v->d_cnt, v->d_rec, v->d_img,
                     v->grid_xy};
@@ -901,7 +909,7 @@ static int chain_enqueue(ChainRun *const *runs, int k, bool pipeline)
             // the frame is decided (and, a keyframe, refined); its stereo half has long been ready
             SVO_HIP(hipStreamWaitEvent(sA, v->ev_b, 0));
             SVO_HIP(hipStreamWaitEvent(sA, v->ev_p1, 0));
-            if ((rc = stereo_part2_spec(v)))
+            if ((rc = stereo_part2_spec(v, cur)))
                 return rc;
             SVO_HIP(hipEventRecord(v->ev_tri, sA));
             if (more) {
@@ -1466,6 +1474,26 @@ int svo_vo_get_keyframe_cloud(svo_vo *v, float *xyz_cam, int cap, int *n, int me
     if (v->kf_n == 0)
         return SVO_OK;
     SVO_HIP(hipMemcpyAsync(xyz_cam, v->b3, (size_t)v->kf_n * 12,
+                           mem == SVO_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, v->ctx->stream));
+    if (mem == SVO_MEM_HOST)
+        SVO_HIP(hipStreamSynchronize(v->ctx->stream));
+    return SVO_OK;
+}
+
+int svo_vo_get_keyframe_colors(svo_vo *v, float *bgr, int cap, int *n, int mem)
+{
+    SVO_CHECK_ARG(v && n);
+    SVO_CHECK_ARG(mem == SVO_MEM_HOST || mem == SVO_MEM_DEVICE);
+    *n = v->kf_n;
+    if (!bgr)
+        return SVO_OK;
+    if (cap < v->kf_n) {
+        svo_set_error("keyframe colours: %d points, capacity %d", v->kf_n, cap);
+        return SVO_ERR_CAPACITY;
+    }
+    if (v->kf_n == 0)
+        return SVO_OK;
+    SVO_HIP(hipMemcpyAsync(bgr, v->kf_col, (size_t)v->kf_n * 12,
                            mem == SVO_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, v->ctx->stream));
     if (mem == SVO_MEM_HOST)
         SVO_HIP(hipStreamSynchronize(v->ctx->stream));

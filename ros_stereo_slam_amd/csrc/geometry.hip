@@ -89,6 +89,9 @@ struct TriJob {
     int *h_count;  // pinned host int that receives the live point count (the host waits on the stream), or null
     VoChain *chain;  // chain mode (svo_tri_job::chain) or null
     float2 *out_x1;  // optional copy of x1
+    const uint8_t *cimg;  // optional colour gather at x1: level 0 of the left pyramid (pixel (0,0)), its pitch and size
+    int cpitch, cw, chh, cc;
+    float *cout;
 };
 struct TriBatch {  // blockIdx.y picks the job
     TriJob j[SVO_LK_MAX_JOBS];
@@ -135,6 +138,15 @@ __global__ __launch_bounds__(128) void triangulate_kernel(Mat34 P1, Mat34 P2, Tr
     const float2 a = x1[i], b = x2[i];
     if (job.out_x1)
         job.out_x1[i] = a;
+    if (job.cout) {  // as colors_kernel: truncation, clamped where the reference reads out of bounds
+        int cx = (int)a.x, cy = (int)a.y;
+        cx = cx < 0 ? 0 : (cx >= job.cw ? job.cw - 1 : cx);
+        cy = cy < 0 ? 0 : (cy >= job.chh ? job.chh - 1 : cy);
+        const uint8_t *px = job.cimg + (size_t)cy * job.cpitch + cx * job.cc;
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+            job.cout[3 * i + k] = (float)px[job.cc >= 3 ? k : 0];
+    }
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         A[0][k] = (double)a.x * P1.m[8 + k] - P1.m[k];
@@ -314,6 +326,12 @@ int svo_launch_triangulate_batch(svo_ctx *ctx, const double *P1, const double *P
         j.h_count = a < k ? h.h_count : nullptr;
         j.chain = h.chain;
         j.out_x1 = reinterpret_cast<float2 *>(h.out_x1);
+        j.cimg = h.color_src && h.color_out ? h.color_src->dev.lvl[0] : nullptr;
+        j.cpitch = h.color_src ? h.color_src->dev.pitch[0] : 0;
+        j.cw = h.color_src ? h.color_src->w : 0;
+        j.chh = h.color_src ? h.color_src->h : 0;
+        j.cc = h.color_src ? h.color_src->c : 0;
+        j.cout = h.color_src ? h.color_out : nullptr;
         if (a < k)
             cap_max = h.cap > cap_max ? h.cap : cap_max;
     }

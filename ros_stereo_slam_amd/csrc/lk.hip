@@ -21,6 +21,7 @@
 //
 // Roofline: the kernel's algorithmic HBM traffic is both pyramids once plus 21 B/point
 // (SURVEY.md section 8d); its time is VALU/LDS work, see DESIGN.md.
+#include <cstdlib>
 #include <type_traits>
 
 #include "svo_internal.h"
@@ -45,6 +46,7 @@ struct LkParams {
     float min_eig_thr;
     int doff[SVO_MAX_LEVELS];    // derivative levels of the jobs' first pyramids: element (0,0), in ints
     int dpitch[SVO_MAX_LEVELS];  // bytes, multiple of 16
+    int interleave;              // 1: keypoint = workgroup index (a lone launch: balance before L2 locality), 0: XCD bands
 };
 static_assert(sizeof(LkBatch) + sizeof(LkParams) <= 4096, "kernel arguments are limited to 4 KB");
 
@@ -520,8 +522,10 @@ __global__ __launch_bounds__(64 * WAVES, 4) void lk_track_kernel(LkBatch batch, 
     // order, so XCD x is given the x-th contiguous eighth of the list -- one band of the image.
     // Each XCD's L2 then fetches its band of both pyramids once instead of all of them.
     const int band = (n + 7) >> 3, in_band = (blockIdx.x >> 3) * WAVES + wave;
-    const int p = (blockIdx.x & 7) * band + in_band;
-    if (in_band >= band || p >= n)
+    // A launch that has the chip to itself holds one wave per slot from start to end: with bands, the XCD whose band
+    // of the image needs the most iterations sets the launch's length; dealt out round-robin every XCD gets the same mix.
+    const int p = prm.interleave ? (int)blockIdx.x * WAVES + wave : (blockIdx.x & 7) * band + in_band;
+    if ((!prm.interleave && in_band >= band) || p >= n)
         return;  // whole wave leaves; no workgroup barrier is used below
     uint8_t *lds = smem + wave * Lds<C>::WAVE_BYTES;
     uint8_t *T = lds;                                           // PT x PT x C bytes
@@ -838,6 +842,8 @@ int svo_launch_lk_batch(svo_ctx *ctx, int n_jobs, const LkJob *jobs, const svo_p
         prm.doff[l] = (int)geom->doff[l];
         prm.dpitch[l] = geom->dpitch[l];
     }
+    static const int lone_interleave = getenv("SVO_LK_INTERLEAVE") ? atoi(getenv("SVO_LK_INTERLEAVE")) : 1;  // A/B: +2.8 % frames/s for one chunk per GPU
+    prm.interleave = n_jobs == 1 ? lone_interleave : 0;
     dim3 grid(((n_max + 7) / 8 + WAVES - 1) / WAVES * 8, n_jobs), block(64 * WAVES);  // x: a multiple of 8, every XCD band has all its slots
     ScopedKernelTime t(ctx, SVO_K_LK);
     switch (c) {

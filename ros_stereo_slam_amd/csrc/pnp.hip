@@ -1008,8 +1008,8 @@ __device__ __forceinline__ void pnp_point_terms(const float *__restrict__ obj, c
 // One workgroup: 40 sums (the 12x12 L^T L is [[S1, 0, Sx], [0, S1, Sy], [Sx, Sy, Sxy]] with S* = sum of
 // w * P P^T, P = (X, Y, Z, 1), w = 1, x, y, x^2 + y^2: 10 unique entries each), fixed-order reduction,
 // wave 0 runs the 12x12 Jacobi eigen-decomposition in LDS and writes hypothesis 0; pnp_finish_kernel in
-// direct mode refines it over all points.  status: 0 ok, 1 = points planar (upstream's homography
-// branch is not built), 2 = fewer than 6 points, 3 = degenerate.
+// direct mode refines it over all points.  Coplanar object points take upstream's homography branch instead
+// (see the kernel).  status: 0 ok, 1 = planar and degenerate (no homography), 2 = fewer than 6 points, 3 = degenerate.
 struct DltArgs {
     const float *obj, *img;
     int n_host;
@@ -1098,8 +1098,166 @@ __global__ __launch_bounds__(256) void pnp_dlt_kernel(DltArgs a)
         }
         if (!(w[1] > 0) || w[2] / w[1] < 1e-3)
             status = 1;
+        if (status == 1 && w[1] > 0) {
+            // ---- upstream's PLANAR branch (cvFindExtrinsicCameraParams2): all object points in one plane ----
+            // R_transform = V^T of the second moments (rows: the plane's two axes, then its normal), identity when
+            // the plane is z = const already; T_transform = -R_transform * mean; homography from the in-plane
+            // coordinates to the normalised image points by the normalised DLT of findHomography(method 0: centroid +
+            // mean absolute deviation scaling, 9x9 L^T L, eigenvector of the smallest eigenvalue); [h1 h2 h1 x h2]
+            // orthonormalised (the Rodrigues round trip upstream = U V^T), t = 2 h3 / (|h1| + |h2|); back through
+            // the plane transform.  (Upstream polishes the homography with ten LM steps of its own before the
+            // decomposition; the pose refinement that follows here minimises the same reprojection error.)
+            double Rp[9];
+            for (int r = 0; r < 3; r++)
+                for (int c = 0; c < 3; c++)
+                    Rp[3 * r + c] = V[3 * c + r];
+            if (Rp[2] * Rp[2] + Rp[5] * Rp[5] < 1e-10)
+                for (int i = 0; i < 9; i++)
+                    Rp[i] = (i % 4) == 0 ? 1. : 0.;
+            const double detp = Rp[0] * (Rp[4] * Rp[8] - Rp[5] * Rp[7]) - Rp[1] * (Rp[3] * Rp[8] - Rp[5] * Rp[6]) +
+                                Rp[2] * (Rp[3] * Rp[7] - Rp[4] * Rp[6]);
+            if (detp < 0)
+                for (int i = 0; i < 9; i++)
+                    Rp[i] = -Rp[i];
+            double Tp[3];
+            for (int r = 0; r < 3; r++)
+                Tp[r] = -(Rp[3 * r] * mx + Rp[3 * r + 1] * my + Rp[3 * r + 2] * mz);
+            auto wave_sum = [&](double x) {
+#pragma unroll
+                for (int m = 1; m < 64; m <<= 1)
+                    x = x + __shfl_xor(x, m, 64);
+                return x;
+            };
+            auto plane_xy = [&](int i, double &X, double &Y, double &u, double &v) {
+                const double px = a.obj[3 * i], py = a.obj[3 * i + 1], pz = a.obj[3 * i + 2];
+                X = Rp[0] * px + Rp[1] * py + Rp[2] * pz + Tp[0];
+                Y = Rp[3] * px + Rp[4] * py + Rp[5] * pz + Tp[1];
+                const float2 o = img[i];
+                u = ((double)o.x - a.K.cx) * ifx;
+                v = ((double)o.y - a.K.cy) * ify;
+            };
+            double c4[4] = {0, 0, 0, 0};  // centroids: X, Y, u, v
+            for (int i = lane; i < n; i += 64) {
+                double X, Y, u, v;
+                plane_xy(i, X, Y, u, v);
+                c4[0] += X;
+                c4[1] += Y;
+                c4[2] += u;
+                c4[3] += v;
+            }
+            for (int k = 0; k < 4; k++)
+                c4[k] = wave_sum(c4[k]) * inv_n;
+            double d4[4] = {0, 0, 0, 0};  // mean absolute deviations
+            for (int i = lane; i < n; i += 64) {
+                double X, Y, u, v;
+                plane_xy(i, X, Y, u, v);
+                d4[0] += fabs(X - c4[0]);
+                d4[1] += fabs(Y - c4[1]);
+                d4[2] += fabs(u - c4[2]);
+                d4[3] += fabs(v - c4[3]);
+            }
+            bool ok = true;
+            for (int k = 0; k < 4; k++) {
+                d4[k] = wave_sum(d4[k]);
+                ok = ok && d4[k] > 2.220446049250313e-16;
+            }
+            if (ok) {
+                double sc4[4];
+                for (int k = 0; k < 4; k++)
+                    sc4[k] = n / d4[k];
+                double L45[45];
+#pragma unroll
+                for (int k = 0; k < 45; k++)
+                    L45[k] = 0;
+                for (int i = lane; i < n; i += 64) {
+                    double X, Y, u, v;
+                    plane_xy(i, X, Y, u, v);
+                    X = (X - c4[0]) * sc4[0];
+                    Y = (Y - c4[1]) * sc4[1];
+                    u = (u - c4[2]) * sc4[2];
+                    v = (v - c4[3]) * sc4[3];
+                    const double Lx[9] = {X, Y, 1, 0, 0, 0, -u * X, -u * Y, -u};
+                    const double Ly[9] = {0, 0, 0, X, Y, 1, -v * X, -v * Y, -v};
+                    int k = 0;
+#pragma unroll
+                    for (int r = 0; r < 9; r++)
+#pragma unroll
+                        for (int c = r; c < 9; c++)
+                            L45[k++] += Lx[r] * Lx[c] + Ly[r] * Ly[c];
+                }
+                {
+                    int k = 0;
+                    for (int r = 0; r < 9; r++)
+                        for (int c = r; c < 9; c++) {
+                            const double t = wave_sum(L45[k++]);
+                            if (lane == 0) {
+                                s_A[9 * r + c] = t;
+                                s_A[9 * c + r] = t;
+                            }
+                        }
+                }
+                wave_lds_fence();
+                wave_jacobi_eigen_sym<9>(s_A, s_V, s_cs, s_pq, 10, lane);
+                int best = 0;
+                for (int e = 1; e < 9; e++)
+                    if (s_A[10 * e] < s_A[10 * best])
+                        best = e;
+                double H0[9], H1[9], H[9];
+                for (int i = 0; i < 9; i++)
+                    H0[i] = s_V[9 * i + best];
+                // H = inv(T_image) * H0 * T_plane
+                const double Ti[9] = {1. / sc4[2], 0, c4[2], 0, 1. / sc4[3], c4[3], 0, 0, 1};
+                const double Tm[9] = {sc4[0], 0, -c4[0] * sc4[0], 0, sc4[1], -c4[1] * sc4[1], 0, 0, 1};
+                for (int r = 0; r < 3; r++)
+                    for (int c = 0; c < 3; c++)
+                        H1[3 * r + c] = H0[3 * r] * Tm[c] + H0[3 * r + 1] * Tm[3 + c] + H0[3 * r + 2] * Tm[6 + c];
+                for (int r = 0; r < 3; r++)
+                    for (int c = 0; c < 3; c++)
+                        H[3 * r + c] = Ti[3 * r] * H1[c] + Ti[3 * r + 1] * H1[3 + c] + Ti[3 * r + 2] * H1[6 + c];
+                if (fabs(H[8]) > 2.220446049250313e-16) {
+                    const double ih = 1. / H[8];
+                    for (int i = 0; i < 9; i++)
+                        H[i] *= ih;
+                    const double n1 = sqrt(H[0] * H[0] + H[3] * H[3] + H[6] * H[6]);
+                    const double n2 = sqrt(H[1] * H[1] + H[4] * H[4] + H[7] * H[7]);
+                    const double i1 = 1. / fmax(n1, 2.220446049250313e-16), i2 = 1. / fmax(n2, 2.220446049250313e-16);
+                    const double it = 2. / fmax(n1 + n2, 2.220446049250313e-16);
+                    const double h1[3] = {H[0] * i1, H[3] * i1, H[6] * i1}, h2[3] = {H[1] * i2, H[4] * i2, H[7] * i2};
+                    const double th[3] = {H[2] * it, H[5] * it, H[8] * it};
+                    const double h3[3] = {h1[1] * h2[2] - h1[2] * h2[1], h1[2] * h2[0] - h1[0] * h2[2],
+                                          h1[0] * h2[1] - h1[1] * h2[0]};
+                    const double Hm[9] = {h1[0], h2[0], h3[0], h1[1], h2[1], h3[1], h1[2], h2[2], h3[2]};
+                    double Uh[9], Vh[9], Rh[9], R[9], t[3];
+                    svd3(Hm, Uh, Vh);
+                    for (int i = 0; i < 3; i++)
+                        for (int j = 0; j < 3; j++)
+                            Rh[3 * i + j] = Uh[3 * i] * Vh[3 * j] + Uh[3 * i + 1] * Vh[3 * j + 1] + Uh[3 * i + 2] * Vh[3 * j + 2];
+                    for (int i = 0; i < 3; i++) {
+                        t[i] = Rh[3 * i] * Tp[0] + Rh[3 * i + 1] * Tp[1] + Rh[3 * i + 2] * Tp[2] + th[i];
+                        for (int j = 0; j < 3; j++)
+                            R[3 * i + j] = Rh[3 * i] * Rp[j] + Rh[3 * i + 1] * Rp[3 + j] + Rh[3 * i + 2] * Rp[6 + j];
+                    }
+                    bool fin = true;
+                    for (int i = 0; i < 9; i++)
+                        fin = fin && isfinite(R[i]);
+                    for (int i = 0; i < 3; i++)
+                        fin = fin && isfinite(t[i]);
+                    if (fin) {
+                        if (lane == 0) {
+                            for (int i = 0; i < 9; i++)
+                                a.hyp[i] = R[i];
+                            for (int i = 0; i < 3; i++)
+                                a.hyp[9 + i] = t[i];
+                        }
+                        status = 4;  // planar start written; reported as a solution (status 0) below
+                    }
+                }
+            }
+        }
     }
-    if (status == 0) {
+    if (status == 4) {
+        status = 0;
+    } else if (status == 0) {
         // L^T L, row-major 12x12, from the four weighted second-moment blocks
         for (int e = lane; e < 144; e += 64) {
             const int r = e / 12, c = e - 12 * r;
@@ -1694,7 +1852,7 @@ extern "C" int svo_solve_pnp(svo_ctx *ctx, const float *obj, const float *img, i
     SVO_HIP(hipStreamSynchronize(ctx->stream));
     const PnpResult *r = reinterpret_cast<const PnpResult *>(ctx->pinned);
     if (r->n_inliers == 0) {
-        svo_set_error("solvePnP: no initial pose (planar or degenerate object points: upstream's homography branch is not built)");
+        svo_set_error("solvePnP: no initial pose (degenerate object points: collinear, coincident or behind the camera)");
         return SVO_ERR_STATE;
     }
     memcpy(rvec, r->rvec, sizeof(r->rvec));

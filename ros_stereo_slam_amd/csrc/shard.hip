@@ -1,0 +1,195 @@
+// shard.hip -- the one exchange step of the chunk-sharded front-end behind the C ABI.
+//
+// A batch of stereo frames shards as one contiguous chunk (or several) per GPU; every chunk re-initialises at its
+// first frame and ends on the next chunk's first frame, so its last pose is the boundary transform
+// T(s_g -> s_g+1).  The path's single collective is an all-gather of those boundary poses -- 12 doubles per chunk
+// ([R | t], row-major R then t) -- over RCCL; every rank then prefix-composes them and rebases its poses.  This file
+// gives a C++ host (the reference's main loop, src/VisualSLAM.cpp:54-200, sharded) both halves without Python:
+//   svo_shard_unique_id / svo_shard_comm_create      bootstrap an RCCL communicator (the 128-byte id travels
+//                                                    between the ranks by whatever the host has: MPI, a file, TCP)
+//   svo_shard_allgather_boundaries                   ncclAllGather of n_chunks x 12 doubles per rank on the context's
+//                                                    stream, host arrays in / out
+//   svo_shard_prefix_starts / svo_shard_rebase       the arithmetic on the gathered boundaries (host, f64)
+// librccl is loaded at run time (dlopen), not linked: a single-GPU user of the library never needs it, and a
+// process that already carries an RCCL (PyTorch ships its own copy) shares that one instead of loading a second.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include "svo_internal.h"
+
+namespace {
+
+struct Rccl {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+Rccl *rccl()
+{
+    static Rccl r;
+    static bool tried = false;
+    if (tried)
+        return r.handle ? &r : nullptr;
+    tried = true;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (r.handle)
+            break;
+    }
+    if (!r.handle)
+        return nullptr;
+    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.handle, "ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.handle, "ncclCommInitRank"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.handle, "ncclCommDestroy"));
+    r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.handle, "ncclAllGather"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.handle, "ncclGetErrorString"));
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.GetErrorString) {
+        dlclose(r.handle);
+        r.handle = nullptr;
+        return nullptr;
+    }
+    return &r;
+}
+
+#define SVO_NCCL(lib, call)                                                                              \
+    do {                                                                                                 \
+        ncclResult_t e_ = (call);                                                                        \
+        if (e_ != ncclSuccess) {                                                                         \
+            svo_set_error("%s:%d %s -> %s", __FILE__, __LINE__, #call, (lib)->GetErrorString(e_));       \
+            return SVO_ERR_HIP;                                                                          \
+        }                                                                                                \
+    } while (0)
+
+// T_a * T_b for camera-in-world poses stored as 12 doubles (R row-major, then t): X_w = R X_c + t
+void compose12(const double *a, const double *b, double *out)
+{
+    double R[9], t[3];
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++)
+            R[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+        t[i] = a[3 * i] * b[9] + a[3 * i + 1] * b[10] + a[3 * i + 2] * b[11] + a[9 + i];
+    }
+    memcpy(out, R, sizeof(R));
+    memcpy(out + 9, t, sizeof(t));
+}
+
+}  // namespace
+
+struct svo_shard_comm {
+    svo_ctx *ctx = nullptr;
+    int rank = 0, nranks = 1;
+    ncclComm_t comm = nullptr;
+    DevBuf send, recv;
+};
+
+extern "C" {
+
+int svo_shard_unique_id(void *id128)
+{
+    SVO_CHECK_ARG(id128 != nullptr);
+    Rccl *lib = rccl();
+    if (!lib) {
+        svo_set_error("librccl could not be loaded (%s)", dlerror() ? dlerror() : "no loader message");
+        return SVO_ERR_STATE;
+    }
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    ncclUniqueId id;
+    SVO_NCCL(lib, lib->GetUniqueId(&id));
+    memcpy(id128, &id, sizeof(id));
+    return SVO_OK;
+}
+
+int svo_shard_comm_create(svo_ctx *ctx, int rank, int nranks, const void *id128, svo_shard_comm **out)
+{
+    SVO_CHECK_ARG(ctx && out && id128 && nranks >= 1 && rank >= 0 && rank < nranks);
+    *out = nullptr;
+    Rccl *lib = rccl();
+    if (!lib) {
+        svo_set_error("librccl could not be loaded");
+        return SVO_ERR_STATE;
+    }
+    SVO_HIP(hipSetDevice(ctx->device));
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    svo_shard_comm *c = new svo_shard_comm();
+    c->ctx = ctx;
+    c->rank = rank;
+    c->nranks = nranks;
+    ncclResult_t e = lib->CommInitRank(&c->comm, nranks, id, rank);
+    if (e != ncclSuccess) {
+        svo_set_error("ncclCommInitRank(rank %d of %d) -> %s", rank, nranks, lib->GetErrorString(e));
+        delete c;
+        return SVO_ERR_HIP;
+    }
+    *out = c;
+    return SVO_OK;
+}
+
+int svo_shard_comm_destroy(svo_shard_comm *c)
+{
+    if (!c)
+        return SVO_OK;
+    (void)hipSetDevice(c->ctx->device);
+    (void)hipStreamSynchronize(c->ctx->stream);
+    Rccl *lib = rccl();
+    if (lib && c->comm)
+        (void)lib->CommDestroy(c->comm);
+    c->send.release();
+    c->recv.release();
+    delete c;
+    return SVO_OK;
+}
+
+int svo_shard_allgather_boundaries(svo_shard_comm *c, const double *local12, int n_chunks, double *all12)
+{
+    SVO_CHECK_ARG(c && local12 && all12 && n_chunks >= 1);
+    Rccl *lib = rccl();
+    if (!lib) {
+        svo_set_error("librccl could not be loaded");
+        return SVO_ERR_STATE;
+    }
+    svo_ctx *ctx = c->ctx;
+    SVO_HIP(hipSetDevice(ctx->device));
+    const size_t count = (size_t)n_chunks * 12, bytes = count * sizeof(double);
+    int rc;
+    if ((rc = c->send.ensure(bytes)) || (rc = c->recv.ensure(bytes * (size_t)c->nranks)))
+        return rc;
+    SVO_HIP(hipMemcpyAsync(c->send.p, local12, bytes, hipMemcpyHostToDevice, ctx->stream));
+    SVO_NCCL(lib, lib->AllGather(c->send.p, c->recv.p, count, ncclDouble, c->comm, ctx->stream));
+    SVO_HIP(hipMemcpyAsync(all12, c->recv.p, bytes * (size_t)c->nranks, hipMemcpyDeviceToHost, ctx->stream));
+    SVO_HIP(hipStreamSynchronize(ctx->stream));
+    return SVO_OK;
+}
+
+// boundaries12[g]: pose of chunk g's LAST frame in chunk g's own frame; starts12[g]: global pose of chunk g's FIRST
+// frame = identity, B0, B0 * B1, ...
+int svo_shard_prefix_starts(const double *boundaries12, int n_total, double *starts12)
+{
+    SVO_CHECK_ARG(boundaries12 && starts12 && n_total >= 1);
+    static const double I12[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+    memcpy(starts12, I12, sizeof(I12));
+    for (int g = 1; g < n_total; g++)
+        compose12(starts12 + 12 * (size_t)(g - 1), boundaries12 + 12 * (size_t)(g - 1), starts12 + 12 * (size_t)g);
+    return SVO_OK;
+}
+
+// chunk-local poses (relative to the chunk's first frame) -> global poses, in place
+int svo_shard_rebase(const double *start12, double *poses12, int n)
+{
+    SVO_CHECK_ARG(start12 && n >= 0 && (n == 0 || poses12));
+    for (int i = 0; i < n; i++) {
+        double out[12];
+        compose12(start12, poses12 + 12 * (size_t)i, out);
+        memcpy(poses12 + 12 * (size_t)i, out, sizeof(out));
+    }
+    return SVO_OK;
+}
+
+int svo_shard_comm_rank(const svo_shard_comm *c) { return c ? c->rank : -1; }
+int svo_shard_comm_size(const svo_shard_comm *c) { return c ? c->nranks : 0; }
+
+}  // extern "C"

@@ -227,6 +227,10 @@ struct svo_tri_job {  // one stereo DLT triangulation (device pointers; Rt: host
     // when chain->kf is set, the live count goes to chain->nref / chain->kf_n and fewer than 5 points halt the chain
     VoChain *chain = nullptr;
     float *out_x1 = nullptr;  // optional: a copy of x1 (the keyframe's 2-D reference set when x1 is a staging buffer)
+    // optional: getColors(imL, x1) -- img.at<Vec3b>(int(y), int(x)) as 3 floats (include/monoUtils.h:180-193), the
+    // `colors` member stereoTriangulate fills at src/triangulation.cpp:139-140 -- gathered by the same kernel
+    const svo_pyramid *color_src = nullptr;
+    float *color_out = nullptr;
 };
 int svo_launch_triangulate_batch(svo_ctx *ctx, const double *P1, const double *P2, int k, const svo_tri_job *jobs);
 int svo_launch_transform(svo_ctx *ctx, const double *Rt, const float *in, int cap, const int *d_n, float *out);

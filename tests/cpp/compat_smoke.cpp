@@ -292,6 +292,22 @@ int main()
     if (f.keyFrameHistory.size() != (size_t)NF || !f.keyFrameHistory[5].retrack || f.keyFrameHistory[0].retrack)
         FAIL("processFrame: %zu records, closure frame keyframe %d", f.keyFrameHistory.size(),
              (int)f.keyFrameHistory[5].retrack);
+    {   // every keyframe of the fused loop pushes its colours (src/VisualSLAM.cpp:125-136): B, G, R floats in [0, 255],
+        // point for point with the cloud pushed in the same step
+        if (f.colorHistory.empty() || f.mapHistory.empty())
+            FAIL("processFrame: colorHistory %zu, mapHistory %zu", f.colorHistory.size(), f.mapHistory.size());
+        const std::vector<Point3f> &c = f.colorHistory.back(), &m3 = f.mapHistory.back();
+        if (c.size() != m3.size() || c.empty())
+            FAIL("processFrame: last colour cloud has %zu entries, its map cloud %zu", c.size(), m3.size());
+        double sum = 0;
+        for (const Point3f &q : c) {
+            if (q.x < 0 || q.x > 255 || q.y < 0 || q.y > 255 || q.z < 0 || q.z > 255 || q.x != (float)(int)q.x)
+                FAIL("processFrame: colour (%g, %g, %g) is no pixel value", q.x, q.y, q.z);
+            sum += q.x + q.y + q.z;
+        }
+        if (sum == 0)
+            FAIL("processFrame: colours are all zero");
+    }
 
     // ---- BundleAdjust3d2d with the reference's signature -----------------------------------------
     double ba_move = 0;

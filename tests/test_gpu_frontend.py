@@ -432,3 +432,36 @@ def test_run_chunk_takes_host_images(ctx):
         assert np.array_equal(x, y)
     a.close()
     b.close()
+
+
+def test_keyframe_colors_on_the_fused_path(ctx, orc):
+    """`colors` of stereoTriangulate (getColors(imL, x1): B, G, R floats, include/monoUtils.h:180-193) come out of the
+    fused path's triangulation launch, point for point with the keyframe's 2-D set -- at initialisation, at a forced
+    keyframe and at the keyframes of a pipelined chunk (what src/VisualSLAM.cpp:125-136 pushes into colorHistory)."""
+    import torch
+    poses, frames = _frames(8)
+    rng = np.random.default_rng(3)
+    frames = [(np.ascontiguousarray(l + rng.integers(0, 3, l.shape, dtype=np.uint8) * np.array([0, 2, 4], np.uint8)), r)
+              for l, r in frames]           # channels that differ, so that B / G / R order matters
+    dev = [(torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()) for l, r in frames]
+    torch.cuda.synchronize()
+    g = capi.VisualOdometry(ctx, 1241, 376, 3, grid_step=30, keyframe_min_inliers=200, seed=4)
+    n0 = g.init(*dev[0])
+    ref2d, _ = g.reference()
+    col = g.keyframe_colors()
+    assert col.shape == (n0, 3) and np.array_equal(col, orc.get_colors(frames[0][0], ref2d))
+    rc, R, t, inl, kf, trk = g.track(*dev[1], force_keyframe=True)
+    assert rc == 0 and kf
+    ref2d, _ = g.reference()
+    assert np.array_equal(g.keyframe_colors(), orc.get_colors(frames[1][0], ref2d))
+    rc, done, R, t, inl, trk, kfs = g.run_chunk([d[0] for d in dev[2:]], [d[1] for d in dev[2:]], pipeline=True)
+    assert rc == 0 and kfs.any()
+    last_kf = 2 + int(np.nonzero(kfs)[0][-1])
+    col = g.keyframe_colors()
+    assert len(col) == len(g.keyframe_cloud())
+    if kfs[-1]:     # the reference set is still the keyframe's: compare point for point
+        ref2d, _ = g.reference()
+        assert np.array_equal(col, orc.get_colors(frames[last_kf][0], ref2d))
+    else:           # colours are pixel values of that keyframe's left image
+        assert set(np.unique(col)).issubset(set(np.unique(frames[last_kf][0]).astype(np.float32)))
+    g.close()

@@ -108,17 +108,48 @@ def test_solve_pnp_matches_oracle(ctx, orc, n, noise):
     assert np.abs(gtv - t).max() < (1e-4 if noise == 0 else 0.2)
 
 
-def test_solve_pnp_planar_and_too_few_points(ctx):
+@pytest.mark.parametrize("plane,noise", [("z", 0.0), ("z", 0.3), ("ground", 0.3), ("tilted", 0.2)])
+def test_solve_pnp_planar_points_take_the_homography_branch(ctx, orc, plane, noise):
+    """Coplanar object points (a road, a wall -- not exotic for a ground-plane inlier set): cv::solvePnP switches to its
+    homography initialisation (cvFindExtrinsicCameraParams2, planar branch; the last rung of the older ladder,
+    src/bundleAdjust.cpp:470-477).  GPU == oracle within the tolerance of the non-planar branch, and both recover the
+    pose the points were projected with."""
+    rng = np.random.default_rng(17)
+    n = 400
+    X = scene_points(n, 5).astype(np.float64)
+    if plane == "z":
+        X[:, 2] = 12.0                                   # fronto-parallel: R_transform = identity upstream
+    elif plane == "ground":
+        X[:, 1] = 1.65                                   # the road in front of the camera
+        X[:, 2] = rng.uniform(6, 40, n)
+        X[:, 0] = rng.uniform(-6, 6, n)
+    else:
+        a, b = rng.uniform(-5, 5, n), rng.uniform(-3, 3, n)
+        X = np.c_[a, b, 15 + 0.4 * a - 0.25 * b]         # a tilted wall
+    X = X.astype(np.float32)
+    R, t = _pose()
+    x = (project(X, R, t) + rng.normal(0, noise, (n, 2))).astype(np.float32)
+    grv, gtv, grms = ctx.solve_pnp(X, x, K4)
+    rc, orv, otv, orms = orc.solve_pnp(X, x, K4)
+    assert rc == 0
+    assert np.abs(grv - orv).max() < 1e-6 and np.abs(gtv - otv).max() < 1e-5
+    assert grms == pytest.approx(orms, rel=1e-5, abs=1e-7)
+    assert np.abs(gtv - t).max() < (1e-4 if noise == 0 else 0.25)
+    assert np.abs(Rot.from_rotvec(grv).as_matrix() - R).max() < (1e-5 if noise == 0 else 0.02)
+
+
+def test_solve_pnp_too_few_and_degenerate_points(ctx):
     from ros_stereo_slam_amd import capi
     X = scene_points(50, 2).astype(np.float32)
     with pytest.raises(capi.SvoError) as e:
         ctx.solve_pnp(X[:5], project(X[:5]), K4)
     assert e.value.code == capi.SVO_ERR_ARG
-    Xp = X.copy()
-    Xp[:, 2] = 10.0
+    Xl = X.copy()
+    Xl[:, 1] = 1.0
+    Xl[:, 2] = 10.0                      # collinear: neither the DLT nor a homography exists
     with pytest.raises(capi.SvoError) as e:
-        ctx.solve_pnp(Xp, project(Xp), K4)
-    assert e.value.code == -6            # SVO_ERR_STATE: upstream's homography branch is not built
+        ctx.solve_pnp(Xl, project(Xl), K4)
+    assert e.value.code == -6            # SVO_ERR_STATE
 
 
 def _set(n, n_out, seed, noise=0.2):

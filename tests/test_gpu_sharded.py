@@ -116,3 +116,23 @@ def test_heterogeneous_group_is_refused(ctx, stream):
             capi.run_chunks([(v, lefts[0:3], rights[0:3]) for v in pair], init=True)
         assert e.value.code == capi.SVO_ERR_ARG
     shared.close()
+
+
+def test_rccl_all_gather_behind_the_c_abi_on_a_one_rank_communicator(ctx):
+    """svo_shard_*: the library's own RCCL communicator (librccl loaded at run time) and the all-gather of chunk-boundary
+    poses, as a C++ host would call them.  One GPU here, so one rank: every rank's contribution must come back unchanged
+    and in order; the N-rank arithmetic is covered by tests/test_shard_capi.py and tests/test_chunked.py."""
+    rng = np.random.default_rng(4)
+    from scipy.spatial.transform import Rotation as Rot
+
+    pairs = [(Rot.from_rotvec(rng.normal(0, 0.2, 3)).as_matrix(), rng.normal(0, 2, 3)) for _ in range(64)]
+    ident = capi.shard_unique_id()
+    assert len(ident) == 128 and any(ident)
+    comm = capi.ShardComm(ctx, 0, 1, ident)
+    got = comm.allgather_boundaries(pairs)
+    assert len(got) == 64
+    for (Ra, ta), (Rb, tb) in zip(got, pairs):
+        assert np.array_equal(Ra, Rb) and np.array_equal(ta, tb)
+    again = chunked.all_gather_chunk_boundaries(None, pairs[:3], comm=comm)   # chunked.py's entry with the C-ABI path
+    assert len(again) == 3 and np.array_equal(again[2][1], pairs[2][1])
+    comm.close()

@@ -158,6 +158,39 @@ def test_solve_pnp_refuses_what_upstream_cannot_solve_by_dlt(orc):
 
     X = scene_points(100, 1)
     assert orc.solve_pnp(X[:5], project(X[:5]), K4)[0] == -1          # fewer than 6 points
-    Xp = X.copy()
-    Xp[:, 2] = 10.0                                                   # planar: upstream takes its homography branch
-    assert orc.solve_pnp(Xp, project(Xp), K4)[0] == -2
+    Xl = X.copy()
+    Xl[:, 1] = 1.0
+    Xl[:, 2] = 10.0                                                   # collinear: no DLT, no homography
+    assert orc.solve_pnp(Xl, project(Xl), K4)[0] == -2
+
+
+def test_oracle_solve_pnp_planar_branch_recovers_the_pose(orc):
+    """cv::solvePnP's planar (homography) initialisation, restated in oracle/pnp.c: object points in one plane --
+    fronto-parallel, the ground plane, a tilted wall -- projected with a known pose come back to 1e-6 noise-free, and the
+    result is a stationary point of the reprojection error (scipy least_squares started there does not move)."""
+    from scipy.optimize import least_squares
+    from scipy.spatial.transform import Rotation as Rot
+
+    from geom_fixtures import K4, project
+
+    rng = np.random.default_rng(23)
+    R, t = Rot.from_rotvec([0.02, -0.05, 0.01]).as_matrix(), np.array([0.1, -0.05, -0.8])
+    n = 300
+    a, b = rng.uniform(-5, 5, n), rng.uniform(-3, 3, n)
+    planes = [np.c_[a, b, np.full(n, 12.0)], np.c_[rng.uniform(-6, 6, n), np.full(n, 1.65), rng.uniform(6, 40, n)],
+              np.c_[a, b, 15 + 0.4 * a - 0.25 * b]]
+    for X in planes:
+        X = X.astype(np.float32)
+        x0 = project(X, R, t)
+        rc, rv, tv, rms = orc.solve_pnp(X, x0.astype(np.float32), K4)
+        assert rc == 0 and np.abs(tv - t).max() < 2e-4 and np.abs(Rot.from_rotvec(rv).as_matrix() - R).max() < 2e-5
+        x = (x0 + rng.normal(0, 0.3, x0.shape)).astype(np.float32)
+        rc, rv, tv, rms = orc.solve_pnp(X, x, K4)
+        assert rc == 0
+
+        def res(p):
+            return (project(X, Rot.from_rotvec(p[:3]).as_matrix(), p[3:]) - x).ravel()
+
+        sol = least_squares(res, np.r_[rv, tv], method="lm", xtol=1e-15, ftol=1e-15, gtol=1e-15)
+        assert np.abs(sol.x - np.r_[rv, tv]).max() < 1e-5
+        assert np.sqrt(np.mean(res(np.r_[rv, tv]).reshape(-1, 2) ** 2)) <= np.sqrt(np.mean(sol.fun.reshape(-1, 2) ** 2)) * (1 + 1e-9) + 1e-12
