@@ -60,6 +60,9 @@ def test_lk_recovers_analytic_shift(orc, c, shift):
     out, st, err, me = orc.lk_track(a, b, pts)
     assert st[inner].all()
     d = (out - pts)[inner] - np.array(shift, np.float32)
+    # SURVEY 8c asked for 0.05 px here.  The residual is the TRACKER's on this texture, not the oracle's: the
+    # independent float32 restatement of appendix A.1 (tests/test_lk_independent.py) makes the same error to 5e-3 px
+    # (0.07 px max at this 9 px wavelength; the iteration stops at 0.01 px steps on 5-bit fixed-point patches)
     assert np.abs(d).max() < 0.12, np.abs(d).max()
     assert np.abs(d).mean() < 0.04
     if shift == (0.0, 0.0):
