@@ -188,6 +188,8 @@ def main():
                     help="keypoints per frame: 4096 = BASELINE's metric (grid step 10), 8192 = configs[4] shape "
                          "(grid step 7 -> 9152 lattice points -> ANMS 8192, keyframe rule 4000)")
     ap.add_argument("--cpu-frames", type=int, default=24)
+    ap.add_argument("--no-detector", action="store_true",
+                    help="pose-graph leg: take the loop closures from the generator instead of running the detector")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="diagnostic: no HIP events around the kernels (the roofline object is then empty)")
     ap.add_argument("--kitti", default=None, help="KITTI odometry root (holds sequences/<seq>/image_2, image_3)")
@@ -531,6 +533,34 @@ def main():
     if rank == 0 and not args.no_extras:
         matches = synth.loop_closures(poses_all, max_dist=0.3, max_angle_deg=10.0, min_gap=100, pick="nearest")
         closures = chunked.gate_closures([m if m >= 1 else -1 for m in matches])  # LCidx = match - 1 must exist
+        closure_source = "generator (frame pairs within 0.3 m / 10 deg, SURVEY.md 8d)"
+        det_info = None
+        if world == 1 and not args.no_detector:
+            # configs[2] / [3]: the closures come from the library's own detector (ORB features + database + geometric
+            # check, svo_lc_*), run over the left image of EVERY frame of the stitched stream on a context of its own:
+            # all frames are queued (svo_lc_submit), then collected; entry id = global frame id
+            ctxd = capi.Context(local_rank)
+            det = capi.LoopDetector(ctxd, W, H, C, seed=5, max_entries=len(lefts) + 8)
+            t0 = time.perf_counter()
+            for img in lefts:
+                det.submit(img)
+            t_submit = time.perf_counter() - t0
+            verdicts = [det.collect() for _ in lefts]
+            t_det = time.perf_counter() - t0
+            det_matches = [v["match"] if v["status"] == 0 and v["match"] >= 1 else -1 for v in verdicts]
+            det_closures = chunked.gate_closures(det_matches)
+            det_info = {"frames": len(lefts), "ms_per_frame": t_det / len(lefts) * 1e3,
+                        "host_submit_ms_per_frame": t_submit / len(lefts) * 1e3,
+                        "detections": int(sum(v["status"] == 0 for v in verdicts)),
+                        "accepted_closures": len(det_closures), "generator_closures": len(closures),
+                        # an accepted closure is TRUE when the two frames' generator poses are within 2 m
+                        "accepted_true": int(sum(np.linalg.norm(poses_all[q][1] - poses_all[m][1]) < 2.0
+                                                 for q, m in det_closures.items()))}
+            det.close()
+            ctxd.close()
+            if det_closures:
+                closures = det_closures
+                closure_source = "svo_lc detector on the stitched stream's left images (global frame ids)"
         ctxg = capi.Context(local_rank)
         pg = capi.PoseGraph(ctxg)
         ctxg.enable_kernel_timing(True)
@@ -539,7 +569,8 @@ def main():
         dt = time.perf_counter() - t0
         pg_ms, _ = ctxg.kernel_time(capi.K_POSEGRAPH)
         result["posegraph"] = {
-            "vertices": len(traj), "loop_closures": len(closures), "gn_iterations": 10,
+            "vertices": len(traj), "loop_closures": len(closures), "closure_source": closure_source,
+            "detector": det_info, "gn_iterations": 10,
             "posegraph_ms_per_iter": pg_ms / 10.0,
             "solve_wall_ms_incl_graph_build": dt * 1e3,
             "chi2_first": float(chi2[0]), "chi2_last": float(chi2[-1]),

@@ -210,6 +210,16 @@ int svo_lc_size(const svo_lc *lc);
 /* detectLoop for the next frame: *status = DetectionStatus, *query = this frame's entry id,
  * *match = the matched entry (-1 if none); a detection is status == SVO_LC_LOOP_DETECTED.        */
 int svo_lc_detect(svo_lc *lc, const uint8_t *image, int mem, int *status, int *query, int *match);
+/* The same in two halves, so that the detector never holds up the frame loop (src/VisualSLAM.cpp:54-169 calls
+ * checkLoopDetectorStatus inside it): svo_lc_submit queues the frame's features, its scoring against the database
+ * and a reduction of the scores to the <= max_db_results candidates the host logic reads (one small record in
+ * pinned memory) on the detector's OWN context and returns at once; svo_lc_collect gives the verdict of the oldest
+ * queued frame (it waits, on the detector's stream only, if that frame is not through yet).  Frames are collected in
+ * the order they were submitted; svo_lc_pending = queued and not collected.  Give the detector a context of its
+ * own (svo_ctx_create) and it runs beside the front-end's streams. */
+int svo_lc_submit(svo_lc *lc, const uint8_t *image, int mem);
+int svo_lc_collect(svo_lc *lc, int *status, int *query, int *match);
+int svo_lc_pending(const svo_lc *lc);
 
 /* ---- ANMS: adaptiveNonMaximalSuppresion(keypoints, numToKeep), src/ANMS.cpp:18-67 ------------ */
 /* xy: n*2 floats, response: n floats (the reference's grid keypoints carry response 0; the

@@ -679,6 +679,20 @@ class LoopDetector:
         _check(self.ctx.lib.svo_lc_detect(self._h, _ptr(image), mem, C.byref(st), C.byref(q), C.byref(m)))
         return dict(status=st.value, query=q.value, match=m.value)
 
+    def submit(self, image):
+        """Queue a frame (``svo_lc_submit``): nothing is waited for."""
+        mem = MEM_HOST if isinstance(image, np.ndarray) else MEM_DEVICE
+        _check(self.ctx.lib.svo_lc_submit(self._h, _ptr(image), mem))
+
+    def collect(self):
+        """The verdict of the oldest queued frame (``svo_lc_collect``) -> dict(status, query, match)."""
+        st, q, m = C.c_int(), C.c_int(), C.c_int()
+        _check(self.ctx.lib.svo_lc_collect(self._h, C.byref(st), C.byref(q), C.byref(m)))
+        return dict(status=st.value, query=q.value, match=m.value)
+
+    def pending(self) -> int:
+        return self.ctx.lib.svo_lc_pending(self._h)
+
     def __len__(self):
         return self.ctx.lib.svo_lc_size(self._h)
 

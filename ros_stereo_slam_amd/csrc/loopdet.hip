@@ -100,6 +100,96 @@ __global__ __launch_bounds__(256) void lc_nearest2_kernel(const uint32_t *__rest
     d2[i] = b2;
 }
 
+// What the host logic of one frame needs, reduced on the device and left in pinned memory: the number of query
+// features, the similarity count against the previous entry (the normalisation score, :736-739) and the
+// max_db_results best entries below `dislocal` -- count descending, entry id ascending on ties, what
+// std::stable_sort + resize of the full result list gives (:714-722) -- instead of every entry's count.
+constexpr int LC_MAX_CAND = 64;
+struct LcRecord {
+    int ready;       // entry id + 1 once the record is complete (released at system scope)
+    int nq;          // query descriptors
+    int last_count;  // count against entry id - 1
+    int n_cand;
+    int cand_id[LC_MAX_CAND], cand_count[LC_MAX_CAND];
+};
+
+__global__ __launch_bounds__(256) void lc_topk_kernel(const int *__restrict__ counts, int max_id, int k_want,
+                                                      const int *__restrict__ d_nq, int entry_id, int nf, LcRecord *rec)
+{
+    __shared__ int s_hist[2049], s_cut, s_above, s_n, s_wave[4], s_run;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    for (int i = t; i <= nf; i += 256)
+        s_hist[i] = 0;
+    if (t == 0) {
+        s_n = 0;
+        s_run = 0;
+    }
+    __syncthreads();
+    for (int e = t; e < max_id; e += 256) {
+        const int c = min(counts[e], nf);
+        if (c > 0)
+            atomicAdd(&s_hist[c], 1);
+    }
+    __syncthreads();
+    if (t == 0) {  // the count value at which the k_want-th best entry sits
+        int cum = 0, cut = 1;
+        for (int c = nf; c >= 1; c--) {
+            if (cum + s_hist[c] >= k_want) {
+                cut = c;
+                break;
+            }
+            cum += s_hist[c];
+        }
+        // entries with a count above `cut` all take part (`above` of them); of those AT the cut the lowest ids fill up
+        int above = 0;
+        for (int c = nf; c > cut; c--)
+            above += s_hist[c];
+        s_cut = cut;
+        s_above = above;
+    }
+    __syncthreads();
+    const int cut = s_cut, need = max(0, min(k_want, LC_MAX_CAND) - s_above);
+    for (int base = 0; base < max_id; base += 256) {
+        const int e = base + t;
+        const int c = e < max_id ? min(counts[e], nf) : 0;
+        if (c > cut) {
+            const int slot = atomicAdd(&s_n, 1);
+            if (slot < LC_MAX_CAND) {
+                rec->cand_id[slot] = e;
+                rec->cand_count[slot] = c;
+            }
+        }
+        // ties at the cut, in entry order
+        const bool tie = c == cut && c > 0;
+        const unsigned long long bal = __ballot(tie);
+        if (lane == 0)
+            s_wave[wave] = __popcll(bal);
+        __syncthreads();
+        int before = s_run;
+        for (int w2 = 0; w2 < wave; w2++)
+            before += s_wave[w2];
+        const int pos = before + __popcll(bal & ((1ull << lane) - 1ull));
+        if (tie && pos < need) {
+            const int slot = atomicAdd(&s_n, 1);
+            if (slot < LC_MAX_CAND) {
+                rec->cand_id[slot] = e;
+                rec->cand_count[slot] = c;
+            }
+        }
+        __syncthreads();
+        if (t == 0)
+            s_run += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        __syncthreads();
+    }
+    if (t == 0) {
+        rec->nq = *d_nq;
+        rec->last_count = entry_id > 0 ? counts[entry_id - 1] : 0;
+        rec->n_cand = min(s_n, LC_MAX_CAND);
+        __threadfence_system();
+        __hip_atomic_store(&rec->ready, entry_id + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 struct Island {  // tIsland, :268-330
     int first, last;
     double score;
@@ -119,8 +209,9 @@ struct svo_lc {
     svo_orb *orb = nullptr;
     int w = 0, h = 0, c = 0, nf = 0, capacity = 0;
     DevBuf db_desc, db_xy, db_n, q, counts, nn, img;
-    std::vector<int> n_host;                 // descriptors per entry
-    std::vector<std::vector<float>> xy_host; // m_image_keys (positions only)
+    std::vector<int> n_host;                 // descriptors per COLLECTED entry
+    LcRecord *rec = nullptr;                 // pinned: one record per entry, filled by lc_topk_kernel
+    int submitted = 0;                       // entries queued (svo_lc_submit); n_host.size() of them are collected
     int window_n = 0, window_first = 0, window_last = 0, window_query = -1;
     bool have_last = false;                  // m_last_bowvec's stand-in: the previous entry is the reference
 };
@@ -182,6 +273,12 @@ int svo_lc_create(svo_ctx *ctx, const svo_lc_params *params, int width, int heig
         svo_lc_destroy(l);
         return rc;
     }
+    if (hipHostMalloc(reinterpret_cast<void **>(&l->rec), sizeof(LcRecord) * cap, hipHostMallocDefault) != hipSuccess) {
+        svo_set_error("svo_lc_create: cannot pin %zu bytes for the per-frame records", sizeof(LcRecord) * cap);
+        svo_lc_destroy(l);
+        return SVO_ERR_HIP;
+    }
+    memset(l->rec, 0, sizeof(LcRecord) * cap);
     *out = l;
     return SVO_OK;
 }
@@ -193,6 +290,8 @@ int svo_lc_destroy(svo_lc *l)
     (void)hipStreamSynchronize(l->ctx->stream);
     if (l->orb)
         svo_orb_destroy(l->orb);
+    if (l->rec)
+        (void)hipHostFree(l->rec);
     DevBuf *bufs[] = {&l->db_desc, &l->db_xy, &l->db_n, &l->q, &l->counts, &l->nn, &l->img};
     for (DevBuf *b : bufs)
         b->release();
@@ -200,16 +299,20 @@ int svo_lc_destroy(svo_lc *l)
     return SVO_OK;
 }
 
-int svo_lc_size(const svo_lc *l) { return l ? (int)l->n_host.size() : 0; }
+int svo_lc_size(const svo_lc *l) { return l ? l->submitted : 0; }
 
-int svo_lc_detect(svo_lc *l, const uint8_t *image, int mem, int *status, int *query, int *match)
+// Queue one frame: features, similarity against every stored entry, the frame's own entry, the reduction of the
+// scores to what the host logic reads (LcRecord).  Nothing is waited for: the work runs on the detector's context --
+// give the detector a context of its own and it runs beside the front-end's streams.
+int svo_lc_submit(svo_lc *l, const uint8_t *image, int mem)
 {
-    SVO_CHECK_ARG(l && image && status);
+    SVO_CHECK_ARG(l && image);
     SVO_CHECK_ARG(mem == SVO_MEM_HOST || mem == SVO_MEM_DEVICE);
     svo_ctx *ctx = l->ctx;
     const svo_lc_params &p = l->prm;
+    SVO_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    const int entry_id = (int)l->n_host.size();
+    const int entry_id = l->submitted;
     if (entry_id >= l->capacity) {
         svo_set_error("loop detector database is full (%d entries)", l->capacity);
         return SVO_ERR_STATE;
@@ -230,8 +333,6 @@ int svo_lc_detect(svo_lc *l, const uint8_t *image, int mem, int *status, int *qu
     if (rc)
         return rc;
     // ---- similarity of the query to every stored entry (one workgroup per entry) ----
-    std::vector<int> counts((size_t)entry_id, 0);
-    int nq = 0;
     if (entry_id > 0)
         hipLaunchKernelGGL(lc_score_kernel, dim3(entry_id), dim3(256), nf * 32, st, qdesc, d_nq,
                            l->db_desc.as<uint32_t>(), l->db_n.as<int>(), l->nf, p.hamming_threshold,
@@ -241,29 +342,63 @@ int svo_lc_detect(svo_lc *l, const uint8_t *image, int mem, int *status, int *qu
                            hipMemcpyDeviceToDevice, st));
     SVO_HIP(hipMemcpyAsync(l->db_xy.as<float>() + (size_t)entry_id * nf * 2, qxy, nf * 8, hipMemcpyDeviceToDevice, st));
     SVO_HIP(hipMemcpyAsync(l->db_n.as<int>() + entry_id, d_nq, 4, hipMemcpyDeviceToDevice, st));
-    SVO_HIP(hipMemcpyAsync(&nq, d_nq, 4, hipMemcpyDeviceToHost, st));
-    if (entry_id > 0)
-        SVO_HIP(hipMemcpyAsync(counts.data(), l->counts.p, (size_t)entry_id * 4, hipMemcpyDeviceToHost, st));
-    std::vector<float> kxy(nf * 2, 0.f);
-    SVO_HIP(hipMemcpyAsync(kxy.data(), qxy, nf * 8, hipMemcpyDeviceToHost, st));
-    SVO_HIP(hipStreamSynchronize(st));
-    kxy.resize((size_t)nq * 2);
-    auto score = [&](int e) { return nq > 0 ? (double)counts[e] / (double)nq : 0.; };
+    // ---- the <= max_db_results best entries below `dislocal`, the normalisation count, the feature count ----
+    const int max_id = entry_id > p.dislocal ? entry_id - p.dislocal : 0;
+    const int k_want = p.max_db_results < LC_MAX_CAND ? p.max_db_results : LC_MAX_CAND;
+    l->rec[entry_id].ready = 0;
+    hipLaunchKernelGGL(lc_topk_kernel, dim3(1), dim3(256), 0, st, l->counts.as<int>(), max_id, k_want, d_nq, entry_id,
+                       l->nf, l->rec + entry_id);
+    SVO_HIP(hipGetLastError());
+    l->submitted = entry_id + 1;
+    return SVO_OK;
+}
+
+int svo_lc_pending(const svo_lc *l) { return l ? l->submitted - (int)l->n_host.size() : 0; }
+
+// The oldest queued frame's verdict: waits (on the DETECTOR's stream only) until its record has landed, then the
+// host logic of detectLoop.  Frames are collected in the order they were submitted.
+int svo_lc_collect(svo_lc *l, int *status, int *query, int *match)
+{
+    SVO_CHECK_ARG(l && status);
+    svo_ctx *ctx = l->ctx;
+    const svo_lc_params &p = l->prm;
+    const int entry_id = (int)l->n_host.size();
+    if (entry_id >= l->submitted) {
+        svo_set_error("svo_lc_collect: no frame is queued");
+        return SVO_ERR_STATE;
+    }
+    SVO_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const size_t nf = (size_t)l->nf;
+    const LcRecord &rec = l->rec[entry_id];
+    if (__atomic_load_n(&rec.ready, __ATOMIC_ACQUIRE) != entry_id + 1) {
+        SVO_HIP(hipStreamSynchronize(st));
+        if (__atomic_load_n(&rec.ready, __ATOMIC_ACQUIRE) != entry_id + 1) {
+            svo_set_error("svo_lc_collect: the record of entry %d did not arrive", entry_id);
+            return SVO_ERR_HIP;
+        }
+    }
+    const int nq = rec.nq;
+    const uint32_t *qdesc = l->db_desc.as<uint32_t>() + (size_t)entry_id * nf * 8;  // the query IS entry `entry_id` now
+    const int *d_nq = l->db_n.as<int>() + entry_id;
+    int rc;
+    auto score_of = [&](int count) { return nq > 0 ? (double)count / (double)nq : 0.; };
 
     int st_out = SVO_LC_CLOSE_MATCHES_ONLY, match_out = -1;
     if (entry_id > p.dislocal) {  // :714-722
-        const int max_id = entry_id - p.dislocal;
+        // the record holds the best entries in no particular order: score descending, entry id ascending on ties is
+        // what the stable sort of the id-ordered full list gave
         std::vector<Result> qret;
-        for (int e = 0; e < max_id; e++)
-            if (score(e) > 0)
-                qret.push_back({e, score(e)});
-        std::stable_sort(qret.begin(), qret.end(), [](const Result &a, const Result &b) { return a.score > b.score; });
+        for (int k = 0; k < rec.n_cand; k++)
+            qret.push_back({rec.cand_id[k], score_of(rec.cand_count[k])});
+        std::sort(qret.begin(), qret.end(),
+                  [](const Result &a, const Result &b) { return a.score > b.score || (a.score == b.score && a.id < b.id); });
         if ((int)qret.size() > p.max_db_results)
             qret.resize(p.max_db_results);
         if (!qret.empty()) {
             double ns = 1.0;
             if (p.use_nss)
-                ns = l->have_last ? score(entry_id - 1) : 0.;  // :736-739
+                ns = l->have_last ? score_of(rec.last_count) : 0.;  // :736-739
             if (!p.use_nss || ns >= p.min_nss_factor) {
                 const double cut = (double)p.alpha * ns;  // removeLowScores, :1320-1338
                 size_t keep = 0;
@@ -360,7 +495,13 @@ int svo_lc_detect(svo_lc *l, const uint8_t *image, int mem, int *status, int *qu
                                 }
                                 if ((int)mA.size() >= p.min_Fpoints) {
                                     std::vector<float> po(mA.size() * 2), pc(mA.size() * 2);
-                                    const std::vector<float> &ko = l->xy_host[old];
+                                    // m_image_keys of the two entries: fetched from the database in HBM only here
+                                    std::vector<float> ko(nf * 2), kxy(nf * 2);
+                                    SVO_HIP(hipMemcpyAsync(ko.data(), l->db_xy.as<float>() + (size_t)old * nf * 2, nf * 8,
+                                                           hipMemcpyDeviceToHost, st));
+                                    SVO_HIP(hipMemcpyAsync(kxy.data(), l->db_xy.as<float>() + (size_t)entry_id * nf * 2, nf * 8,
+                                                           hipMemcpyDeviceToHost, st));
+                                    SVO_HIP(hipStreamSynchronize(st));
                                     for (size_t i = 0; i < mA.size(); i++) {
                                         po[2 * i] = ko[2 * mA[i]];
                                         po[2 * i + 1] = ko[2 * mA[i] + 1];
@@ -391,7 +532,6 @@ int svo_lc_detect(svo_lc *l, const uint8_t *image, int mem, int *status, int *qu
             st_out = SVO_LC_NO_DB_RESULTS;
     }
     l->n_host.push_back(nq);
-    l->xy_host.push_back(kxy);
     if (p.use_nss && entry_id + 1 > p.dislocal)  // :855-858
         l->have_last = true;
     *status = st_out;
@@ -400,6 +540,21 @@ int svo_lc_detect(svo_lc *l, const uint8_t *image, int mem, int *status, int *qu
     if (match)
         *match = match_out;
     return SVO_OK;
+}
+
+// submit + collect: the synchronous form, one call per frame, in order (checkLoopDetectorStatus as the reference
+// calls it, src/optimizationStuff.cpp:49-64)
+int svo_lc_detect(svo_lc *l, const uint8_t *image, int mem, int *status, int *query, int *match)
+{
+    SVO_CHECK_ARG(l && image && status);
+    if (svo_lc_pending(l) != 0) {
+        svo_set_error("svo_lc_detect: %d queued frames are not collected yet", svo_lc_pending(l));
+        return SVO_ERR_STATE;
+    }
+    int rc = svo_lc_submit(l, image, mem);
+    if (rc)
+        return rc;
+    return svo_lc_collect(l, status, query, match);
 }
 
 }  // extern "C"

@@ -50,14 +50,21 @@ class StereoSlam:
         """One frame.  Returns (ok, R, t, info)."""
         if self.shutdown:
             return False, None, None, {}
+        # a detector with a queue (capi.LoopDetector on a context of its own) works on this frame BESIDE the
+        # front-end's localisation: queued here, its verdict collected once the pose is there
+        queued = self.detector is not None and hasattr(self.detector, "submit")
+        if queued:
+            self.detector.submit(left)
         res = self.vo.localize(left)
         rc, R, t, n_inl, n_trk = res
         self.frame += 1
         if rc:
             self.shutdown = True  # SHUTDOWN_FLAG, src/VisualSLAM.cpp:65-67
+            if queued:
+                self.detector.collect()
             return False, R, t, {"inliers": n_inl, "tracked": n_trk}
         if self.detector is not None:
-            r = self.detector.detect(left)
+            r = self.detector.collect() if queued else self.detector.detect(left)
             loop_match = r["match"] if r["status"] == 0 else -1
         lc = False
         if loop_match >= 0 and (self.frame - loop_match) > self.min_gap and self.cooldown == 0:

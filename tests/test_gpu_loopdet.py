@@ -54,3 +54,45 @@ def test_device_images_and_capacity(ctx):
         a.detect(imgs[26])                                       # database full
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("max_db_results", [50, 4])
+def test_queued_detector_on_a_context_of_its_own_equals_the_synchronous_one(ctx, max_db_results):
+    """svo_lc_submit / svo_lc_collect: every frame queued on the detector's own context before anything is collected
+    (the scores reduced on the device to the max_db_results candidates the host logic reads -- with 4 the cut falls
+    inside runs of equal scores), then frames two deep in flight: the verdicts of the synchronous calls, and the
+    oracle's."""
+    import torch
+    poses, imgs = _loop_images()
+    dev = [torch.from_numpy(i).cuda() for i in imgs]
+    torch.cuda.synchronize()
+    own = capi.Context(0)
+    a = capi.LoopDetector(ctx, SIZE[0], SIZE[1], 3, seed=5, max_db_results=max_db_results)
+    b = capi.LoopDetector(own, SIZE[0], SIZE[1], 3, seed=5, max_db_results=max_db_results)
+    c = capi.LoopDetector(own, SIZE[0], SIZE[1], 3, seed=5, max_db_results=max_db_results)
+    o = OracleDetector(Params(seed=5, max_db_results=max_db_results))
+    ref = [a.detect(d) for d in dev]
+    for i, (r, img) in enumerate(zip(ref, imgs)):
+        ro = o.detect(img)
+        assert (r["status"], r["match"]) == (ro["status"], ro["match"]), i
+    for d in dev:
+        b.submit(d)
+    assert b.pending() == len(dev) and len(b) == len(dev)
+    assert [b.collect() for _ in dev] == ref
+    assert b.pending() == 0
+    got = []
+    c.submit(dev[0])
+    for d in dev[1:]:
+        c.submit(d)                      # frame i + 1 is queued ...
+        got.append(c.collect())          # ... before frame i is collected
+    got.append(c.collect())
+    assert got == ref
+    with pytest.raises(capi.SvoError):
+        c.collect()                      # nothing queued
+    c.submit(dev[0])
+    with pytest.raises(capi.SvoError):
+        c.detect(dev[1])                 # the synchronous call refuses to overtake a queued frame
+    assert any(r["status"] == 0 for r in ref)
+    for x in (a, b, c):
+        x.close()
+    own.close()

@@ -76,6 +76,29 @@ def test_64_chunks_against_the_sequential_run_at_full_size(ctx, stream):
     assert chi2[-1] <= chi2[0] and np.abs(est[0] - [0, 0, 0, 0, 0, 0, 1]).max() == 0
     assert ate_after <= ate_sh * 1.02
 
+    # ---- the same with the library's OWN detector (svo_lc_*): every frame's left image queued on a context of its own,
+    # entry id = GLOBAL frame id of the stitched stream (the chunks never see the detector), the reference's gating
+    # (src/optimizationStuff.cpp:58-63) on the verdicts, one global solve ----
+    own = capi.Context(0)
+    det = capi.LoopDetector(own, W, H, C, seed=5)
+    for img in lefts:
+        det.submit(img)
+    verdicts = [det.collect() for _ in lefts]
+    det.close()
+    own.close()
+    det_closures = chunked.gate_closures([v["match"] if v["status"] == 0 and v["match"] >= 1 else -1 for v in verdicts])
+    assert len(det_closures) >= 1
+    for q, m in det_closures.items():       # every accepted closure is a true revisit: within 2 m on the generator's path
+        assert np.linalg.norm(truth[q] - truth[m]) < 2.0, (q, m)
+    pg = capi.PoseGraph(ctx)
+    est_d, chi2_d = chunked.global_solve(pg, traj, det_closures, iters=10)
+    pg.close()
+    ate_det = chunked.ate_rmse(est_d[:, :3], truth)
+    print(f"detector: {sum(v['status'] == 0 for v in verdicts)} detections, accepted {det_closures}; "
+          f"chi2 {chi2_d[0]:.4g} -> {chi2_d[-1]:.4g}, ATE {ate_sh:.3f} -> {ate_det:.3f} m")
+    assert chi2_d[-1] <= chi2_d[0]
+    assert ate_det <= ate_sh                 # ATE after <= ATE before with the detector's closures
+
 
 def test_init_inside_run_chunks_equals_init_then_run(ctx, stream):
     """svo_chunk_job.init_left / init_right: the chunk's stereo initialisation inside the call (one
