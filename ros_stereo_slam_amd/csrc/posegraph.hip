@@ -332,22 +332,32 @@ __global__ __launch_bounds__(64) void pg_segment_kernel(int nb, const int *__res
     const bool act = lane < 36;
     const bool has_l = a > 0, has_r = z < nb - 1;
     // ---- forward: factorisation and L^-1 [r | E_a C_l] (7 columns; column layout [6][7]) ----
+    // The rows of a segment are a serial chain: the next row's blocks are requested while this row is worked on (their
+    // load latency was a third of a row's 2 us).
+    const int r7 = lane / 7, c7 = lane - 7 * r7;
+    double nDg = act ? Dg[(size_t)a * 36 + lane] : 0., nCc = act && a < z ? Cc[(size_t)a * 36 + lane] : 0.;
+    double nr = lane < 42 ? (c7 == 0 ? rneg[(size_t)a * 6 + r7] : (has_l ? Cc[(size_t)(a - 1) * 36 + 6 * r7 + (c7 - 1)] : 0.)) : 0.;
     for (int b = a; b <= z; b++) {
+        const double cDg = nDg, cCc = nCc, cr = nr;
+        if (b < z) {
+            nDg = act ? Dg[(size_t)(b + 1) * 36 + lane] : 0.;
+            nCc = act && b + 1 < z ? Cc[(size_t)(b + 1) * 36 + lane] : 0.;
+            nr = lane < 42 && c7 == 0 ? rneg[(size_t)(b + 1) * 6 + r7] : 0.;
+        }
         if (act) {
-            double sv = Dg[(size_t)b * 36 + lane];
+            double sv = cDg;
             if (b > a) {
 #pragma unroll
                 for (int t = 0; t < 6; t++)
                     sv -= sSub[6 * i + t] * sSub[6 * j + t];
             }
             sS[lane] = sv;
-            sC[lane] = b < z ? Cc[(size_t)b * 36 + lane] : 0.;
+            sC[lane] = cCc;
         }
         // right-hand side block of this row: [rneg_b | C_l (first row only)]
         if (lane < 42) {
-            const int r = lane / 7, c = lane - 7 * r;
-            double v = c == 0 ? rneg[(size_t)b * 6 + r]
-                              : (b == a && has_l ? Cc[(size_t)(a - 1) * 36 + 6 * r + (c - 1)] : 0.);
+            const int r = r7, c = c7;
+            double v = cr;
             if (b > a) {
 #pragma unroll
                 for (int t = 0; t < 6; t++)
@@ -391,18 +401,30 @@ __global__ __launch_bounds__(64) void pg_segment_kernel(int nb, const int *__res
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     // ---- backward: x = L^-T z for 13 columns [y | Wl (6) | Wr (6)], layout [6][13] in sX ----
+    // (the same here: Li / Lsub / Z7 of the row below are in flight while this row is combined)
+    const int e1 = lane + 64, r13a = lane / 13, c13a = lane - 13 * r13a, r13b = e1 / 13, c13b = e1 - 13 * r13b;
+    double nLi = act ? Li[(size_t)z * 36 + lane] : 0., nSub = 0.;
+    double nZa = c13a < 7 ? Z7[(size_t)z * 42 + 7 * r13a + c13a] : 0.;
+    double nZb = e1 < 78 && c13b < 7 ? Z7[(size_t)z * 42 + 7 * r13b + c13b] : 0.;
     for (int b = z; b >= a; b--) {
+        const double cZa = nZa, cZb = nZb;
         if (act) {
-            sLi[lane] = Li[(size_t)b * 36 + lane];
+            sLi[lane] = nLi;
             if (b < z)
-                sSub[lane] = Lsub[(size_t)(b + 1) * 36 + lane];
+                sSub[lane] = nSub;
+        }
+        if (b > a) {
+            nLi = act ? Li[(size_t)(b - 1) * 36 + lane] : 0.;
+            nSub = act ? Lsub[(size_t)b * 36 + lane] : 0.;
+            nZa = c13a < 7 ? Z7[(size_t)(b - 1) * 42 + 7 * r13a + c13a] : 0.;
+            nZb = e1 < 78 && c13b < 7 ? Z7[(size_t)(b - 1) * 42 + 7 * r13b + c13b] : 0.;
         }
         wave_sync();
         for (int e = lane; e < 78; e += 64) {
             const int r = e / 13, c = e - 13 * r;
             double v;
             if (c < 7)
-                v = Z7[(size_t)b * 42 + 7 * r + c];
+                v = e == lane ? cZa : cZb;
             else if (b == z && has_r) {  // z-value of the Wr columns: L_zz^-1 C_z^T, nonzero in the last row only
                 v = 0;
 #pragma unroll
@@ -540,58 +562,123 @@ __global__ __launch_bounds__(256) void pg_dense_potf2_kernel(const double *__res
                                                              double *__restrict__ Tinv, int ldr, int kb,
                                                              int *__restrict__ status, int status_base)
 {
-    __shared__ double sA[TB * (TB + 1)], sI[TB * (TB + 1)];
+    // The lower triangle of the 48 x 48 tile lives in REGISTERS: 1176 entries dealt out to 256 threads (entry e of
+    // the row-major triangle to thread e mod 256, <= 5 each), their (row, column) worked out once.  Right-looking with
+    // ONE barrier per column: the owners of column k publish it (unscaled) to LDS, then every thread updates the
+    // entries it owns, a_ij -= a_ik a_jk / a_kk; the columns are scaled by 1 / sqrt(pivot) at the end.  (With the
+    // tile in LDS, an integer division per entry and step, a square root + division + three barriers per column and
+    // the inverse by a thread per column through LDS this kernel took 94 us per tile: half of a solve.)
+    constexpr int NTRI = TB * (TB + 1) / 2, OWN = (NTRI + 255) / 256;
+    __shared__ double sCol2[2][TB], sPiv[TB], sL[TB * (TB + 1)];
     __shared__ int s_bad;
     const int tid = threadIdx.x;
     constexpr int LD = TB + 1;
+    double a[OWN];
+    int ri[OWN], ci[OWN];
+#pragma unroll
+    for (int q = 0; q < OWN; q++) {
+        const int e = tid + 256 * q;
+        int r = 0;
+        if (e < NTRI) {
+            r = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+            while ((r + 1) * (r + 2) / 2 <= e)
+                r++;
+            while (r * (r + 1) / 2 > e)
+                r--;
+        }
+        ri[q] = e < NTRI ? r : -1;
+        ci[q] = e < NTRI ? e - r * (r + 1) / 2 : -1;
+        a[q] = e < NTRI ? A[(size_t)(kb * TB + ri[q]) * ldr + kb * TB + ci[q]] : 0.;
+    }
     if (tid == 0)
         s_bad = 0;
-    for (int e = tid; e < TB * TB; e += 256) {
-        const int r = e / TB, c = e - TB * r;
-        sA[r * LD + c] = c <= r ? A[(size_t)(kb * TB + r) * ldr + kb * TB + c] : 0.;
-    }
-    __syncthreads();
     for (int k = 0; k < TB; k++) {
-        const double piv = sA[k * LD + k];
-        if (!(piv > 0)) {
-            if (tid == 0)
+        double *sCol = sCol2[k & 1];  // two buffers take turns: the step after next rewrites this one, a barrier later
+#pragma unroll
+        for (int q = 0; q < OWN; q++)
+            if (ci[q] == k)
+                sCol[ri[q]] = a[q];  // column k, rows k .. TB-1 (final: every earlier step has been applied)
+        __syncthreads();
+        const double piv = sCol[k];
+        if (tid == 0) {
+            sPiv[k] = piv;
+            if (!(piv > 0))
                 s_bad = 1 + k;
         }
-        const double d = sqrt(piv), inv = 1. / d;
-        __syncthreads();
-        if (tid < TB && tid >= k)
-            sA[tid * LD + k] = tid == k ? d : sA[tid * LD + k] * inv;
-        __syncthreads();
-        // trailing update of the lower triangle: pairs (i, j), k < j <= i
-        const int rem = TB - 1 - k;
-        for (int e = tid; e < rem * rem; e += 256) {
-            const int ii = e / rem, jj = e - rem * ii;
-            if (jj <= ii) {
-                const int i = k + 1 + ii, j = k + 1 + jj;
-                sA[i * LD + j] -= sA[i * LD + k] * sA[j * LD + k];
-            }
-        }
-        __syncthreads();
+        double rp = __builtin_amdgcn_rcp(piv);  // v_rcp_f64 + one Newton step: the update's scale, not a result
+        rp = rp * (2. - piv * rp);
+#pragma unroll
+        for (int q = 0; q < OWN; q++)
+            if (ci[q] > k)
+                a[q] -= sCol[ri[q]] * sCol[ci[q]] * rp;
     }
+    __syncthreads();
+    // L = columns scaled by 1 / sqrt(pivot), into LDS for the inverse and out to the factor
+#pragma unroll
+    for (int q = 0; q < OWN; q++)
+        if (ri[q] >= 0)
+            sL[ri[q] * LD + ci[q]] = a[q] * (1. / sqrt(sPiv[ci[q]]));
+    __syncthreads();
     if (s_bad) {
         if (tid == 0)
             atomicMax(status, status_base + kb * TB + s_bad);
         // keep going with whatever is there: the host reports the failure
     }
-    if (tid < TB) {  // column tid of the inverse by forward substitution
-        const int c = tid;
-        for (int r = 0; r < TB; r++) {
-            double acc = r == c ? 1. : 0.;
-            for (int k = c; k < r; k++)
-                acc -= sA[r * LD + k] * sI[k * LD + c];
-            sI[r * LD + c] = r < c ? 0. : acc / sA[r * LD + r];
-        }
-    }
-    __syncthreads();
     for (int e = tid; e < TB * TB; e += 256) {
         const int r = e / TB, c = e - TB * r;
-        Lo[(size_t)(kb * TB + r) * ldr + kb * TB + c] = sA[r * LD + c];
-        Tinv[(size_t)kb * TB * TB + e] = sI[r * LD + c];
+        Lo[(size_t)(kb * TB + r) * ldr + kb * TB + c] = c <= r ? sL[r * LD + c] : 0.;
+    }
+    // L^-1: column c by forward substitution, FOUR lanes per column (192 busy): lane `part` adds the terms k = part mod 4
+    // of every row's dot product, two shuffles combine the four shares; the column lives in LDS (sX), written and read
+    // by lanes of the same wave.  (One thread per column was a dependent chain of 1152 multiply-subtracts: 20 us.)
+    __shared__ double sX[TB * (TB + 1)], sRd[TB];
+    if (tid < TB)
+        sRd[tid] = 1. / sL[tid * LD + tid];  // 48 divisions side by side, not one at the end of every row's chain
+    __syncthreads();
+    if (tid < 4 * TB) {
+        const int c = tid >> 2, part = tid & 3;
+        for (int r = 0; r < TB; r++) {
+            double acc = 0.;
+            for (int k = c + part; k < r; k += 4)  // entries above the diagonal of the inverse are zero: start at k = c
+                acc -= sL[r * LD + k] * sX[c * LD + k];
+            acc = acc + __shfl_xor(acc, 1, 64);
+            acc = acc + __shfl_xor(acc, 2, 64);
+            const double xr = r < c ? 0. : ((r == c ? 1. : 0.) + acc) * sRd[r];
+            if (part == 0) {
+                sX[c * LD + r] = xr;
+                Tinv[(size_t)kb * TB * TB + r * TB + c] = xr;
+            }
+            wave_sync();
+        }
+    }
+}
+
+// out[r][c] (-)= sum_k X[r][k] Y[c][k], k < kmax(c): a 3 x 3 block of the 48 x 48 result per thread (16 x 16 threads), so
+// that six LDS reads feed nine multiply-adds (one entry per thread and two reads per multiply-add made this kernel
+// LDS-bound at 35 us per tile)
+template <bool TRI>
+__device__ __forceinline__ void pg_tile_mult(const double *sX, const double *sY, int tr, int tc, double (&acc)[3][3])
+{
+    constexpr int LD = TB + 1;
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b2 = 0; b2 < 3; b2++)
+            acc[a][b2] = 0;
+    // TRI: Y is lower triangular (Y[c][k] = 0 for k > c): columns 3 tc .. 3 tc + 2 need k <= 3 tc + 2 only
+    const int kend = TRI ? 3 * tc + 3 : TB;
+    for (int k = 0; k < kend; k++) {
+        const double x0 = sX[(3 * tr) * LD + k], x1 = sX[(3 * tr + 1) * LD + k], x2 = sX[(3 * tr + 2) * LD + k];
+        const double y0 = sY[(3 * tc) * LD + k], y1 = sY[(3 * tc + 1) * LD + k], y2 = sY[(3 * tc + 2) * LD + k];
+        acc[0][0] += x0 * y0;
+        acc[0][1] += x0 * y1;
+        acc[0][2] += x0 * y2;
+        acc[1][0] += x1 * y0;
+        acc[1][1] += x1 * y1;
+        acc[1][2] += x1 * y2;
+        acc[2][0] += x2 * y0;
+        acc[2][1] += x2 * y1;
+        acc[2][2] += x2 * y2;
     }
 }
 
@@ -600,7 +687,7 @@ __global__ __launch_bounds__(256) void pg_dense_update_kernel(double *__restrict
 {
     __shared__ double sI[TB * (TB + 1)], sPi[TB * (TB + 1)], sPj[TB * (TB + 1)], sA[TB * (TB + 1)];
     constexpr int LD = TB + 1;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, tr = tid >> 4, tc = tid & 15;
     // linear tile index -> (i, j) with kb < j <= i < T
     int t = blockIdx.x, i = kb + 1;
     while (t >= i - kb) {
@@ -611,17 +698,17 @@ __global__ __launch_bounds__(256) void pg_dense_update_kernel(double *__restrict
     (void)T;
     for (int e = tid; e < TB * TB; e += 256) {
         const int r = e / TB, c = e - TB * r;
-        sI[r * LD + c] = Tinv[(size_t)kb * TB * TB + e];
+        sI[r * LD + c] = c <= r ? Tinv[(size_t)kb * TB * TB + e] : 0.;  // lower triangular
         sA[r * LD + c] = A[(size_t)(i * TB + r) * ldr + kb * TB + c];
     }
     __syncthreads();
-    for (int e = tid; e < TB * TB; e += 256) {  // P_i = A_i,kb * Tinv^T
-        const int r = e / TB, c = e - TB * r;
-        double acc = 0;
-        for (int k = 0; k <= c; k++)
-            acc += sA[r * LD + k] * sI[c * LD + k];
-        sPi[r * LD + c] = acc;
-    }
+    double acc[3][3];
+    pg_tile_mult<true>(sA, sI, tr, tc, acc);  // P_i = A_i,kb * Tinv^T
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b2 = 0; b2 < 3; b2++)
+            sPi[(3 * tr + a) * LD + 3 * tc + b2] = acc[a][b2];
     __syncthreads();
     if (i != j) {
         for (int e = tid; e < TB * TB; e += 256) {
@@ -629,24 +716,26 @@ __global__ __launch_bounds__(256) void pg_dense_update_kernel(double *__restrict
             sA[r * LD + c] = A[(size_t)(j * TB + r) * ldr + kb * TB + c];
         }
         __syncthreads();
-        for (int e = tid; e < TB * TB; e += 256) {
-            const int r = e / TB, c = e - TB * r;
-            double acc = 0;
-            for (int k = 0; k <= c; k++)
-                acc += sA[r * LD + k] * sI[c * LD + k];
-            sPj[r * LD + c] = acc;
-        }
+        pg_tile_mult<true>(sA, sI, tr, tc, acc);
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b2 = 0; b2 < 3; b2++)
+                sPj[(3 * tr + a) * LD + 3 * tc + b2] = acc[a][b2];
         __syncthreads();
     }
     const double *Pj = i == j ? sPi : sPj;
-    for (int e = tid; e < TB * TB; e += 256) {
-        const int r = e / TB, c = e - TB * r;
-        if (i == j && c > r)
-            continue;
-        double acc = 0;
-        for (int k = 0; k < TB; k++)
-            acc += sPi[r * LD + k] * Pj[c * LD + k];
-        A[(size_t)(i * TB + r) * ldr + j * TB + c] -= acc;
+    if (!(i == j && tc > tr)) {  // a diagonal tile keeps its lower triangle only (whole 3 x 3 blocks above it are skipped)
+        pg_tile_mult<false>(sPi, Pj, tr, tc, acc);
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b2 = 0; b2 < 3; b2++) {
+                const int r = 3 * tr + a, c = 3 * tc + b2;
+                if (i == j && c > r)
+                    continue;
+                A[(size_t)(i * TB + r) * ldr + j * TB + c] -= acc[a][b2];
+            }
     }
     if (j == kb + 1)
         for (int e = tid; e < TB * TB; e += 256) {
@@ -655,62 +744,66 @@ __global__ __launch_bounds__(256) void pg_dense_update_kernel(double *__restrict
         }
 }
 
-// L y = b, L^T x = y with the tiles' inverses; one workgroup, the vector lives in LDS
-__global__ __launch_bounds__(256) void pg_dense_solve_kernel(const double *__restrict__ Lo,
-                                                             const double *__restrict__ Tinv, int ldr, int T,
-                                                             const double *__restrict__ rhs, double *__restrict__ x)
+// L y = b, L^T x = y with the tiles' inverses; one workgroup of 384 threads = 48 rows x 8 column parts (the eight
+// lanes of a row read 64 contiguous bytes of the factor per step and combine their partial sums with three shuffles),
+// the vector lives in LDS; two barriers per tile step
+constexpr int PG_SOLVE_THREADS = TB * 8;
+__device__ __forceinline__ double pg_sum8(double v)
 {
-    extern __shared__ double sv[];  // ldr entries + TB * 8 partials + TB
-    double *sp = sv + ldr, *st = sp + TB * 8;
+    v = v + __shfl_xor(v, 1, 64);
+    v = v + __shfl_xor(v, 2, 64);
+    v = v + __shfl_xor(v, 4, 64);
+    return v;
+}
+__global__ __launch_bounds__(PG_SOLVE_THREADS) void pg_dense_solve_kernel(const double *__restrict__ Lo,
+                                                                          const double *__restrict__ Tinv, int ldr, int T,
+                                                                          const double *__restrict__ rhs,
+                                                                          double *__restrict__ x)
+{
+    extern __shared__ double sv[];  // ldr entries + TB
+    double *st = sv + ldr;
     const int tid = threadIdx.x;
-    const int r = tid % TB, part = tid / TB;  // 48 rows x 5 column parts (240 threads busy)
-    for (int e = tid; e < ldr; e += 256)
+    const int r = tid >> 3, part = tid & 7;
+    for (int e = tid; e < ldr; e += PG_SOLVE_THREADS)
         sv[e] = rhs[e];
     __syncthreads();
-    for (int kb = 0; kb < T; kb++) {  // forward
+    for (int kb = 0; kb < T; kb++) {  // forward: y_kb = Tinv (b_kb - L_kb,:kb y_:kb)
         double acc = 0;
-        if (part < 5) {
-            const double *row = Lo + (size_t)(kb * TB + r) * ldr;
-            for (int c = part; c < kb * TB; c += 5)
-                acc += row[c] * sv[c];
-            sp[part * TB + r] = acc;
-        }
+        const double *row = Lo + (size_t)(kb * TB + r) * ldr;
+        for (int c = part; c < kb * TB; c += 8)
+            acc += row[c] * sv[c];
+        acc = pg_sum8(acc);
+        if (part == 0)
+            st[r] = sv[kb * TB + r] - acc;
         __syncthreads();
-        if (tid < TB)
-            st[tid] = sv[kb * TB + tid] - ((((sp[tid] + sp[TB + tid]) + sp[2 * TB + tid]) + sp[3 * TB + tid]) +
-                                           sp[4 * TB + tid]);
-        __syncthreads();
-        if (tid < TB) {
-            double a2 = 0;
-            const double *ti = Tinv + (size_t)kb * TB * TB + tid * TB;
-            for (int c = 0; c <= tid; c++)
-                a2 += ti[c] * st[c];
-            sv[kb * TB + tid] = a2;
-        }
+        double a2 = 0;
+        const double *ti = Tinv + (size_t)kb * TB * TB + r * TB;
+        for (int c = part; c <= r; c += 8)
+            a2 += ti[c] * st[c];
+        a2 = pg_sum8(a2);
+        if (part == 0)
+            sv[kb * TB + r] = a2;
         __syncthreads();
     }
     for (int kb = T - 1; kb >= 0; kb--) {  // backward: x_kb = Tinv^T (y_kb - sum_{i>kb} L_i,kb^T x_i)
+        // column r of the panel below the tile: rows (kb+1) TB .. T TB; the eight parts take every eighth row
         double acc = 0;
-        if (part < 5) {
-            for (int rr = (kb + 1) * TB + part; rr < T * TB; rr += 5)
-                acc += Lo[(size_t)rr * ldr + kb * TB + r] * sv[rr];
-            sp[part * TB + r] = acc;
-        }
+        for (int rr = (kb + 1) * TB + part; rr < T * TB; rr += 8)
+            acc += Lo[(size_t)rr * ldr + kb * TB + r] * sv[rr];
+        acc = pg_sum8(acc);
+        if (part == 0)
+            st[r] = sv[kb * TB + r] - acc;
         __syncthreads();
-        if (tid < TB)
-            st[tid] = sv[kb * TB + tid] - ((((sp[tid] + sp[TB + tid]) + sp[2 * TB + tid]) + sp[3 * TB + tid]) +
-                                           sp[4 * TB + tid]);
-        __syncthreads();
-        if (tid < TB) {
-            double a2 = 0;
-            const double *ti = Tinv + (size_t)kb * TB * TB;
-            for (int c = tid; c < TB; c++)
-                a2 += ti[c * TB + tid] * st[c];
-            sv[kb * TB + tid] = a2;
-        }
+        double a2 = 0;
+        const double *ti = Tinv + (size_t)kb * TB * TB;
+        for (int c = r + part; c < TB; c += 8)
+            a2 += ti[c * TB + r] * st[c];
+        a2 = pg_sum8(a2);
+        if (part == 0)
+            sv[kb * TB + r] = a2;
         __syncthreads();
     }
-    for (int e = tid; e < ldr; e += 256)
+    for (int e = tid; e < ldr; e += PG_SOLVE_THREADS)
         x[e] = sv[e];
 }
 
@@ -957,14 +1050,25 @@ int svo_pg_optimize(svo_posegraph *g, int iters, double *chi2)
         // separators: both ends of every chord (edge between non-neighbouring unknowns) + every SEG_L-th row
         std::vector<int> sepidx(nb, -1);
         std::vector<char> is_sep(nb, 0);
-        for (int b = SEG_L - 1; b < nb - 1; b += SEG_L)
-            is_sep[b] = 1;
         for (int e = 0; e < ne; e++) {
             const int i = g->efrom[e] - 1, j = g->eto[e] - 1;
             if (i < 0 || j < 0 || i == j || i - j == 1 || j - i == 1)
                 continue;
             is_sep[i] = 1;
             is_sep[j] = 1;
+        }
+        // regular separators only where the chord endpoints leave a run longer than SEG_L rows: every separator adds six
+        // rows to the dense reduced system, whose cost is what a solve's time is made of (a fixed grid of every 128th row
+        // gave 115 separators at 4541 vertices / 40 closures, the endpoints alone cut that chain into runs of ~100 rows)
+        for (int b = 0, run = 0; b < nb - 1; b++) {
+            if (is_sep[b]) {
+                run = 0;
+                continue;
+            }
+            if (++run >= SEG_L) {
+                is_sep[b] = 1;
+                run = 0;
+            }
         }
         std::vector<int> seps;
         for (int b = 0; b < nb; b++)
@@ -1147,7 +1251,7 @@ int svo_pg_optimize(svo_posegraph *g, int iters, double *chi2)
                     hipLaunchKernelGGL(pg_dense_update_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, st, R, Lo, Tinv,
                                        ldr, kb, T);
             }
-            hipLaunchKernelGGL(pg_dense_solve_kernel, dim3(1), dim3(256), (size_t)(ldr + TB * 9) * 8, st, Lo, Tinv, ldr,
+            hipLaunchKernelGGL(pg_dense_solve_kernel, dim3(1), dim3(PG_SOLVE_THREADS), (size_t)(ldr + TB) * 8, st, Lo, Tinv, ldr,
                                T, rR, xR);
         }
         hipLaunchKernelGGL(pg_backsub_kernel, dim3((nb * 6 + 255) / 256), dim3(256), 0, st, nb, ds + o_sepidx,
