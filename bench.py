@@ -48,7 +48,7 @@ sys.path.insert(0, ROOT)
 
 W, H, C = 1241, 376, 3
 PYR_BYTES = 619930 * C    # sum of the 4 level sizes
-LK_PMC_JSON = os.path.join(ROOT, "profiles", "r02_lk_pmc.json")
+LK_PMC_JSON = os.path.join(ROOT, "profiles", "r03_lk_pmc_{kpts}.json")   # one per keypoint count (4096, 8192)
 
 
 def lk_algorithmic_bytes(n_pts: int) -> int:
@@ -67,7 +67,7 @@ def lk_pmc_constants(n_kpts: int):
     build and workload they were taken on: the file names the sha256 of lk.hip and the keypoint
     count, anything else gives None."""
     try:
-        with open(LK_PMC_JSON) as f:
+        with open(LK_PMC_JSON.format(kpts=n_kpts)) as f:
             d = json.load(f)
         with open(os.path.join(ROOT, "ros_stereo_slam_amd", "csrc", "lk.hip"), "rb") as f:
             sha = hashlib.sha256(f.read()).hexdigest()
@@ -252,18 +252,46 @@ def main():
     # INTEGRATION.md section 4 uses); the 128-byte id travels through torch.distributed here.  Any failure falls back
     # to torch.distributed's all-gather (also RCCL) and says so in the line.
     comm, collective = None, None
-    if not rehearsal:
-        try:
-            ident_bytes = [capi.shard_unique_id() if rank == 0 else None]
-            if dist is not None:
-                dist.broadcast_object_list(ident_bytes, src=0)
-            comm = capi.ShardComm(sh.ctxs[0], rank, world, ident_bytes[0])
-            collective = f"ncclAllGather through svo_shard_allgather_boundaries (C ABI, librccl), {world} rank(s)"
-        except Exception as e:   # noqa: BLE001 -- the bench must not die on the optional path
-            comm = None
-            collective = f"torch.distributed all_gather (C-ABI communicator unavailable: {type(e).__name__}: {e})"
+    # (a live RCCL communicator holds hardware queues: with one it is -2 % on the batched figure and -27 % on the
+    # three-stream single-chunk run, A/B on one box -- so none is made where there is nothing to exchange, at N = 1)
+    if not rehearsal and world > 1 and os.environ.get("SVO_BENCH_NO_CABI") != "1":
+        ident, why = None, ""
+        if rank == 0:
+            try:
+                ident = capi.shard_unique_id()
+            except Exception as e:   # noqa: BLE001 -- the bench must not die on the optional path
+                why = f"{type(e).__name__}: {e}"
+        if dist is not None:         # every rank learns whether there is an id (None = none), so nobody waits alone
+            box = [ident]
+            dist.broadcast_object_list(box, src=0)
+            ident = box[0]
+        if ident is not None:
+            # ncclCommInitRank is itself a rendezvous of all ranks: it runs in a helper thread with a deadline, so
+            # that a rank which cannot join falls back instead of hanging the run
+            import threading
+
+            made = {}
+
+            def _make():
+                try:
+                    made["comm"] = capi.ShardComm(sh.ctxs[0], rank, world, ident)
+                except Exception as e:   # noqa: BLE001
+                    made["err"] = f"{type(e).__name__}: {e}"
+
+            th = threading.Thread(target=_make, daemon=True)
+            th.start()
+            th.join(timeout=120.0)
+            if "comm" in made:
+                comm = made["comm"]
+                collective = f"ncclAllGather through svo_shard_allgather_boundaries (C ABI, librccl), {world} rank(s)"
+            else:
+                why = made.get("err", "ncclCommInitRank did not return within 120 s")
+        if comm is None:
+            collective = f"torch.distributed all_gather (C-ABI communicator unavailable: {why or 'no unique id'})"
     if collective is None:
-        collective = "gloo rehearsal on one GPU"
+        collective = ("gloo rehearsal on one GPU" if rehearsal else
+                      "none: one rank (tests/test_gpu_sharded.py runs svo_shard_allgather_boundaries on a one-rank communicator)"
+                      if world == 1 else "torch.distributed all_gather (SVO_BENCH_NO_CABI=1)")
     if dist is not None:
         ok = torch.tensor([1 if comm is not None else 0], device=coll_dev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)      # every rank takes the same path
@@ -403,6 +431,10 @@ def main():
         path_len = float(np.sum(np.linalg.norm(np.diff(t_truth, axis=0), axis=1)))
         fps = world * n_frames / elapsed
         lk_ms, lk_launches = times.get("lk", (0.0, 0))
+        if not lk_launches and M > 1:
+            # no instrumented pass: a lock-step group step queues two tracking launches per context (the frame's pass of
+            # all its chunks, the stereo pass of those that keyframe)
+            lk_launches = 2 * K * len(sh.ctxs)
         lk_avg_s = lk_ms / max(lk_launches, 1) * 1e-3
         # passes carried by the LK launches of the timed region: one tracking pass per frame + one
         # stereo pass per keyframe
@@ -428,7 +460,7 @@ def main():
             "frac": achieved / 8000.0 if achieved is not None else None,
             "traffic": pmc["hbm_bytes_per_pass"] * passes_per_launch if pmc else None,
             "traffic_source": (pmc["source"] + " x passes per launch") if pmc else
-                              f"null: {os.path.basename(LK_PMC_JSON)} absent or taken on another lk.hip / keypoint count",
+                              f"null: {os.path.basename(LK_PMC_JSON.format(kpts=n_kpts))} absent or taken on another lk.hip / keypoint count",
             "avg_launch_us": lk_avg_s * 1e6 if lk_launches else None,
             "avg_launch_source": "HIP events on each context's stream in a SEPARATE instrumented pass over the same "
                                  "frames (the timed region carries no event records); launches of several "

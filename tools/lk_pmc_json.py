@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Writes profiles/r02_lk_pmc.json: the per-pass counter figures of lk_track_kernel<3> that bench.py's
+"""Writes profiles/rNN_lk_pmc_<kpts>.json (r02: profiles/r02_lk_pmc.json): the per-pass counter figures of lk_track_kernel<3> that bench.py's
 roofline object quotes, from the committed per-kernel summaries of the rocprofv3 --pmc passes
 (tools/pmc_summary.py), the bench line those passes printed (passes per tracking launch in the timed region)
 and the VALU-rate microbenchmark (tools/valu_rate.hip).  The file names the sha256 of lk.hip: bench.py
@@ -34,11 +34,18 @@ def main():
     ap.add_argument("--lk-alone-us", type=float, required=True,
                     help="mean duration of a tracking launch in the SQ pass (kernels run one at a time there)")
     ap.add_argument("--kpts", type=int, default=4096)
+    ap.add_argument("--lk-launches", type=int, default=0,
+                    help="tracking launches of the timed region (the dispatches the --pmc summaries average over), when the "
+                         "bench line was printed with --no-kernel-timing")
+    ap.add_argument("--source", default=None, help="text of the `source` field (the committed files the figures come from)")
     a = ap.parse_args()
     sq = row_of(a.sq, "lk_track_kernel<3>")
     hbm = row_of(a.hbm, "lk_track_kernel<3>")
     bench = json.loads(open(a.bench_line).read().strip().splitlines()[-1])
     passes = bench["roofline"]["lk_passes_per_launch"]
+    if a.lk_launches:   # a bench line printed without its instrumented pass carries the passes of the whole region
+        passes = bench["roofline"]["lk_passes_per_launch"] * bench["roofline"].get("launches_per_step", 0) * bench["steps"] / a.lk_launches \
+            if bench["roofline"].get("launches_per_step") else bench["roofline"]["lk_passes_per_launch"] / a.lk_launches
     rates = [json.loads(l) for l in open(a.valu_rate) if l.startswith("{") and '"mix"' in l]
     mix4 = next(r for r in rates if r["mix"].startswith("lk_mix") and r["waves_per_simd"] == 4)
     fma4 = next(r for r in rates if r["mix"] == "v_fma_f32" and r["waves_per_simd"] == 4)
@@ -64,8 +71,8 @@ def main():
         "valu_cycles_per_wave_inst_v_fma_f32": fma4["kernel_ms"] * 1e6 / (fma4["insts_per_wave"] * 4) * 1e-9 * sclk,
         "lk_launch_alone_us": a.lk_alone_us,
         "valu_issue_share_of_a_launch_alone": valu * ns_per_inst * 1e-9 / 1024.0 / (a.lk_alone_us * 1e-6),
-        "source": "profiles/r02_pmc_hbm_traffic.csv, profiles/r02_pmc_sq.csv (rocprofv3 --pmc, timed region, "
-                  "(2*FETCH_SIZE+WRITE_SIZE)*1024 per tracking pass), profiles/r02_valu_rate.jsonl",
+        "source": a.source or (f"{a.hbm}, {a.sq} (rocprofv3 --pmc, timed region, (2*FETCH_SIZE+WRITE_SIZE)*1024 per "
+                               f"tracking pass), {a.valu_rate}"),
     }
     print(json.dumps(out, indent=1))
 
