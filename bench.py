@@ -643,7 +643,12 @@ def main():
         dts = [float(np.linalg.norm(tg - to)) for (Rg, tg), (Ro, to) in zip(g_poses, o_poses)]
         dRs = [rot_angle(Rg, Ro) for (Rg, tg), (Ro, to) in zip(g_poses, o_poses)]
         result["ate_rmse_vs_oracle"] = chunked.ate_rmse([t for _, t in g_poses], [t for _, t in o_poses])
-        result["max_frame_delta_vs_oracle"] = {"translation_m": max(dts), "rotation_rad": max(dRs), "frames": len(dts)}
+        result["max_frame_delta_vs_oracle"] = {
+            "translation_m": max(dts), "rotation_rad": max(dRs), "frames": len(dts),
+            # arccos of a trace resolves 1e-8 rad at best: the entries themselves say whether the rotations are EQUAL
+            "rotation_matrix_max_abs_diff": max(float(np.abs(Rg - Ro).max()) for (Rg, _), (Ro, _) in zip(g_poses, o_poses)),
+            "bit_identical": all(np.array_equal(Rg, Ro) and np.array_equal(tg, to)
+                                 for (Rg, tg), (Ro, to) in zip(g_poses, o_poses))}
         result["cpu_baseline"] = {
             "value": multi,
             "unit": "frames/s",

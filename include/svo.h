@@ -321,9 +321,12 @@ int svo_vo_track(svo_vo *vo, const uint8_t *left, const uint8_t *right, int mem,
  * all HOST or all DEVICE per `mem`) through the front-end without returning to the caller in
  * between -- exactly the result of n_frames calls of svo_vo_track(force_keyframe = 0).
  * Outputs per frame (host arrays, any may be NULL except R_out/t_out): R_out n*9, t_out n*3,
- * inliers_out, tracked_out, keyframe_out.  pipeline != 0 (device images only) overlaps the
- * PnP-RANSAC of frame t with the pyramid + LK of frame t+1 on a second HIP stream; results
- * are identical.  Stops at tracking loss (SVO_ERR_TRACKING_LOST, *n_done frames completed).    */
+ * inliers_out, tracked_out, keyframe_out.  The frame policy (retry / lost thresholds, keyframe rule,
+ * reference hand-over, pose composition) runs on the device; the host enqueues the whole chunk and
+ * reads the per-frame records once.  pipeline != 0 (device images only) runs the chunk on three
+ * HIP streams: filters + LK + triangulation, PnP's decision + refinement, and the pose-free stereo
+ * half of a possible keyframe; results are identical.  Stops at tracking loss
+ * (SVO_ERR_TRACKING_LOST, *n_done frames completed).                                            */
 int svo_vo_run_chunk(svo_vo *vo, const uint8_t *const *lefts, const uint8_t *const *rights, int n_frames,
                      int mem, int pipeline, double *R_out, double *t_out, int *inliers_out,
                      int *tracked_out, uint8_t *keyframe_out, int *n_done);

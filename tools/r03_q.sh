@@ -1,11 +1,14 @@
 #!/bin/bash
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-export GPU_MAX_HW_QUEUES=8
 OUT=gpurun_out/r03; mkdir -p $OUT
-for r in 1 2; do
-timeout -k 10 400 python3 bench.py --no-cpu-baseline > $OUT/bench_default.json 2> $OUT/bench_default.err || exit 7
-python3 -c "
-import json; d=json.loads(open('$OUT/bench_default.json').read().strip().splitlines()[-1])
-print('value', round(d['value']), 'events', d['event_records'], 'inits', round(d['value_including_chunk_inits']), 'single', round(d.get('single_chunk_frames_per_s')))"
-done
+S0=$(date +%s); timeout -k 10 600 python3 bench.py > $OUT/bench_full.json 2> $OUT/bench_full.err || { tail -5 $OUT/bench_full.err; exit 7; }
+echo "default bench wall: $(( $(date +%s) - S0 )) s"
+timeout -k 10 600 python3 bench.py --steps 20 --warmup 5 > $OUT/bench_20_5.json 2> $OUT/bench_20_5.err || exit 8
+timeout -k 10 600 python3 bench.py --kpts 8192 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_8192.json 2> $OUT/bench_8192.err || exit 9
+python3 - <<'PY'
+import json
+for f in ('bench_full','bench_20_5','bench_8192'):
+    d=json.loads(open('gpurun_out/r03/'+f+'.json').read().strip().splitlines()[-1])
+    print(f, round(d['value']), 'single', round(d['single_chunk_frames_per_s']), 'inits', round(d['value_including_chunk_inits']), 'ate', round(d['ate_rmse_vs_truth'],3), 'seq', round(d['ate_rmse_sequential_vs_truth'],3), 'sh-vs-seq', round(d['ate_rmse_sharded_vs_sequential'],3), 'frac', d['roofline']['frac'], 'lk_us', round(d['roofline']['avg_launch_us']), 'traffic', d['roofline']['traffic'], 'pg', d['posegraph']['posegraph_ms_per_iter'], d['posegraph']['ate_rmse_vs_truth_after'], 'cpu', d.get('cpu_baseline',{}).get('value'), d.get('cpu_baseline',{}).get('single_thread_value'), d.get('max_frame_delta_vs_oracle'))
+PY
