@@ -44,6 +44,8 @@ struct svo_vo {
     svo_ctx *ctx_s = nullptr;
     hipEvent_t ev_pyr = nullptr, ev_p1 = nullptr, ev_tri = nullptr, ev_end = nullptr;
     float *s_a2 = nullptr, *s_b2 = nullptr, *s_c2 = nullptr, *s_d2 = nullptr, *s_x1 = nullptr, *s_x2 = nullptr, *s_resp = nullptr;
+    // what the stereo stream hands over, per frame parity: x1 and the camera-frame points (count: s_cnt[4 + parity])
+    float *s_x1b = nullptr, *s_xyz = nullptr, *s_xyzb = nullptr;
     uint8_t *s_status = nullptr, *s_st2 = nullptr, *s_mask = nullptr;
     int *s_idx = nullptr, *s_cnt = nullptr;
     // second set of tracked points / inlier list: frame t's refinement reads its set while frame t+1's filters write theirs
@@ -217,9 +219,11 @@ int stereo_triangulate_batch(int k, svo_vo *const *vs, svo_pyramid *const *lefts
 
 // The stereo half of the keyframe path for ONE pipelined chunk, on the front-end's third stream (v->ctx_s) and its
 // own buffers: LK left -> right from the lattice (src/tracking.cpp:18), ANMS, status filter (:20-27), F-RANSAC at 3 px
-// with its mask filter (:30-43) -- everything of stereoTriangulate that does not need the frame's pose.  Leaves
-// x1 / x2 / count in s_x1 / s_x2 / s_cnt[4].  `frame_no`: the frame the pass belongs to (its seed).
-int stereo_part1_spec(svo_vo *v, svo_pyramid *left, svo_pyramid *right, int frame_no)
+// with its mask filter (:30-43), the DLT triangulation in the camera frame (src/triangulation.cpp:142-160) --
+// everything of stereoTriangulate, none of which needs the frame's pose.  Leaves x1 / camera-frame points / count in
+// s_x1 / s_xyz / s_cnt[4] (s_x1b / s_xyzb / s_cnt[5] for odd `par`: the main stream reads one frame's set while the
+// next frame's is written).  `frame_no`: the frame the pass belongs to (its seed).
+int stereo_part1_spec(svo_vo *v, svo_pyramid *left, svo_pyramid *right, int frame_no, int par)
 {
     svo_ctx *cs = v->ctx_s;
     int rc;
@@ -254,29 +258,28 @@ int stereo_part1_spec(svo_vo *v, svo_pyramid *left, svo_pyramid *right, int fram
         d_n = v->s_cnt + 2;
     }
     float *o1 = pts == v->grid_xy ? v->s_c2 : v->s_a2, *o2 = pts == v->grid_xy ? v->s_d2 : v->s_b2;
+    float *x1 = par ? v->s_x1b : v->s_x1;
+    int *cnt = v->s_cnt + 4 + (par ? 1 : 0);
     const svo_compact_job c1 = {stt, n, d_n, {pts, trk, nullptr}, {o1, o2, nullptr}, {2, 2, 0}, v->s_cnt + 3, run};
-    const svo_compact_job c2 = {v->s_mask, n, v->s_cnt + 3, {o1, o2, nullptr}, {v->s_x1, v->s_x2, nullptr}, {2, 2, 0},
-                                v->s_cnt + 4};
+    const svo_compact_job c2 = {v->s_mask, n, v->s_cnt + 3, {o1, o2, nullptr}, {x1, v->s_x2, nullptr}, {2, 2, 0}, cnt};
     const uint64_t seed = v->prm.seed + 8ull * (uint64_t)frame_no + 3;  // stage_seed(frame_no, 3)
     const svo_fransac_job fj = {o1, o2, n, v->s_cnt + 3, v->prm.f_thr_stereo, 0.99, 1000, seed, v->s_mask, nullptr, nullptr,
                                 nullptr, &c2, run};
     if ((rc = svo_launch_compact_batch(cs, 1, &c1)) || (rc = svo_launch_fransac_batch(cs, 1, &fj)))
         return rc;
-    return SVO_OK;
-}
-
-// ... and the half that does: DLT triangulation of the filtered pairs and the cloud's placement with the frame's refined
-// pose (src/triangulation.cpp:142-160, src/keyFrameManagement.cpp:20-30), on the main stream, only when the device flag
-// says keyframe.  The keyframe's 2-D set is copied from the staging buffer by the same kernel.
-int stereo_part2_spec(svo_vo *v, const svo_pyramid *left)
-{
-    const int n = grid_axis(v->w, v->prm.grid_step) * grid_axis(v->h, v->prm.grid_step);
-    svo_tri_job tj = {v->s_x1, v->s_x2, n, v->s_cnt + 4, v->b3, nullptr, nullptr, v->ref3d, nullptr, v->d_chain, v->ref2d};
-    tj.color_src = left;
-    tj.color_out = v->kf_col;
+    const svo_tri_job tj = {x1, v->s_x2, n, cnt, par ? v->s_xyzb : v->s_xyz, nullptr, nullptr, nullptr, nullptr};
     double P1[12], P2[12];
     svo_stereo_projections(v->prm.fx, v->prm.fy, v->prm.cx, v->prm.cy, v->prm.baseline, P1, P2);
-    return svo_launch_triangulate_batch(v->ctx, P1, P2, 1, &tj);
+    return svo_launch_triangulate_batch(cs, P1, P2, 1, &tj);
+}
+
+// ... and the rest, which does: the cloud's placement with the frame's refined pose and the hand-over of the keyframe's
+// sets (src/keyFrameManagement.cpp:18-30), on the main stream, only when the device flag says keyframe.
+int stereo_part2_spec(svo_vo *v, const svo_pyramid *left, int par)
+{
+    const int n = grid_axis(v->w, v->prm.grid_step) * grid_axis(v->h, v->prm.grid_step);
+    return svo_launch_keyframe_place(v->ctx, v->d_chain, par ? v->s_x1b : v->s_x1, par ? v->s_xyzb : v->s_xyz, n,
+                                     v->s_cnt + 4 + (par ? 1 : 0), v->ref2d, v->b3, v->ref3d, left, v->kf_col);
 }
 
 // the PnP-RANSAC problem of a localisation as the chain runner queues it: solvePnPRansac(100, 1 px, 0.99) over the
@@ -466,7 +469,7 @@ int svo_vo_destroy(svo_vo *v)
     }
     {
         void *sb[] = {v->s_a2, v->s_b2, v->s_c2, v->s_d2, v->s_x1, v->s_x2, v->s_resp, v->s_status, v->s_st2, v->s_mask,
-                      v->s_idx, v->s_cnt, v->trk2d_b, v->trk3d_b, v->idx_b};
+                      v->s_idx, v->s_cnt, v->trk2d_b, v->trk3d_b, v->idx_b, v->s_x1b, v->s_xyz, v->s_xyzb};
         for (void *b : sb)
             if (b)
                 (void)hipFree(b);
@@ -875,7 +878,7 @@ static int chain_enqueue(ChainRun *const *runs, int k, bool pipeline)
             if ((rc = chain_lk(ctx, 1, vs, &ref, &cur, pts, dn, gates)))
                 return rc;
             SVO_HIP(hipStreamWaitEvent(sC, v->ev_pyr, 0));
-            if ((rc = stereo_part1_spec(v, cur, right[0], frame0 + 1)))
+            if ((rc = stereo_part1_spec(v, cur, right[0], frame0 + 1, 0)))
                 return rc;
             SVO_HIP(hipEventRecord(v->ev_p1, sC));
         }
@@ -911,19 +914,18 @@ static int chain_enqueue(ChainRun *const *runs, int k, bool pipeline)
             // the frame is decided (and, a keyframe, refined); its stereo half has long been ready
             SVO_HIP(hipStreamWaitEvent(sA, v->ev_b, 0));
             SVO_HIP(hipStreamWaitEvent(sA, v->ev_p1, 0));
-            if ((rc = stereo_part2_spec(v, cur)))
+            if ((rc = stereo_part2_spec(v, cur, f & 1)))
                 return rc;
-            SVO_HIP(hipEventRecord(v->ev_tri, sA));
             if (more) {
                 pts[0] = v->ref2d;  // a keyframe: the next frame is tracked from its points
                 dn[0] = &v->d_chain->nref;
                 gates[0] = kf;
                 if ((rc = chain_lk(ctx, 1, vs, &cur, &nxt, pts, dn, gates)))
                     return rc;
-                // the stereo half of the next frame: its pyramids are built, this frame's staging buffers are free
+                // the stereo half of the next frame: its pyramids are built; it writes the other hand-over set than the
+                // one this frame's placement reads (and the set it writes was read a frame ago on A, before ev_pyr)
                 SVO_HIP(hipStreamWaitEvent(sC, v->ev_pyr, 0));
-                SVO_HIP(hipStreamWaitEvent(sC, v->ev_tri, 0));
-                if ((rc = stereo_part1_spec(v, nxt, right[(f + 1) & 1], frame0 + f + 2)))
+                if ((rc = stereo_part1_spec(v, nxt, right[(f + 1) & 1], frame0 + f + 2, (f + 1) & 1)))
                     return rc;
                 SVO_HIP(hipEventRecord(v->ev_p1, sC));
             }
@@ -1180,7 +1182,8 @@ int svo_vo_run_chunk(svo_vo *v, const uint8_t *const *lefts, const uint8_t *cons
             (rc = dev_alloc(&v->s_x1, n * 2)) || (rc = dev_alloc(&v->s_x2, n * 2)) || (rc = dev_alloc(&v->s_resp, n)) ||
             (rc = dev_alloc(&v->s_status, n)) || (rc = dev_alloc(&v->s_st2, n)) || (rc = dev_alloc(&v->s_mask, n)) ||
             (rc = dev_alloc(&v->s_idx, n)) || (rc = dev_alloc(&v->s_cnt, 16)) || (rc = dev_alloc(&v->trk2d_b, n * 2)) ||
-            (rc = dev_alloc(&v->trk3d_b, n * 3)) || (rc = dev_alloc(&v->idx_b, n)))
+            (rc = dev_alloc(&v->trk3d_b, n * 3)) || (rc = dev_alloc(&v->idx_b, n)) || (rc = dev_alloc(&v->s_x1b, n * 2)) ||
+            (rc = dev_alloc(&v->s_xyz, n * 3)) || (rc = dev_alloc(&v->s_xyzb, n * 3)))
             return rc;
         for (hipEvent_t *e : {&v->ev_pyr, &v->ev_p1, &v->ev_tri, &v->ev_end})
             SVO_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));

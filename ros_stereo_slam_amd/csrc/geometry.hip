@@ -174,6 +174,61 @@ __global__ __launch_bounds__(128) void triangulate_kernel(Mat34 P1, Mat34 P2, Tr
     }
 }
 
+// The pose-dependent rest of a keyframe whose triangulation ran ahead of the decision (the pipelined chunk's stereo
+// stream): exactly what triangulate_kernel does in chain mode after its DLT -- reference-set size and halt rule, the
+// keyframe's 2-D set, `colors`, the camera-frame cloud, and the cloud placed with the pose the frame was localised at
+// (src/keyFrameManagement.cpp:18-30) -- reading the camera-frame points instead of solving for them.
+struct PlaceArgs {
+    VoChain *chain;
+    const float2 *x1;
+    const float *xyz;
+    int n_host;
+    const int *d_n;
+    float2 *out_x1;
+    float *out_cam, *out_world;
+    const uint8_t *cimg;
+    int cpitch, cw, chh, cc;
+    float *cout;
+};
+__global__ __launch_bounds__(64) void keyframe_place_kernel(PlaceArgs a)
+{
+    svo_chain_priority();
+    VoChain *chain = a.chain;
+    if (chain->kf == 0)
+        return;
+    const int n = min(*a.d_n, a.n_host);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {
+        chain->nref = n;
+        chain->kf_n = n;
+        if (n < 5) {
+            chain->run = 0;
+            chain->halt_code = SVO_HALT_FEW_REF;
+        }
+    }
+    if (i >= n)
+        return;
+    const float2 p = a.x1[i];
+    a.out_x1[i] = p;
+    if (a.cout) {
+        int cx = (int)p.x, cy = (int)p.y;
+        cx = cx < 0 ? 0 : (cx >= a.cw ? a.cw - 1 : cx);
+        cy = cy < 0 ? 0 : (cy >= a.chh ? a.chh - 1 : cy);
+        const uint8_t *px = a.cimg + (size_t)cy * a.cpitch + cx * a.cc;
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+            a.cout[3 * i + k] = (float)px[a.cc >= 3 ? k : 0];
+    }
+    const float x = a.xyz[3 * i], y = a.xyz[3 * i + 1], z = a.xyz[3 * i + 2];
+    a.out_cam[3 * i] = x;
+    a.out_cam[3 * i + 1] = y;
+    a.out_cam[3 * i + 2] = z;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+        a.out_world[3 * i + r] =
+            (float)(chain->R[3 * r] * x + chain->R[3 * r + 1] * y + chain->R[3 * r + 2] * z + chain->t[r]);
+}
+
 __global__ __launch_bounds__(256) void transform_kernel(Mat34 Rt, const float *__restrict__ in, int n_host,
                                                         const int *__restrict__ d_n, float *__restrict__ out)
 {
@@ -340,6 +395,36 @@ int svo_launch_triangulate_batch(svo_ctx *ctx, const double *P1, const double *P
     ScopedKernelTime tm(ctx, SVO_K_TRIANGULATE);
     hipLaunchKernelGGL(triangulate_kernel, dim3((cap_max + 63) / 64, k), dim3(64), 0, ctx->stream, to_mat34(P1),
                        to_mat34(P2), batch);
+    SVO_HIP(hipGetLastError());
+    return SVO_OK;
+}
+
+int svo_launch_keyframe_place(svo_ctx *ctx, VoChain *chain, const float *x1, const float *xyz, int cap, const int *d_n,
+                              float *out_x1, float *out_cam, float *out_world, const svo_pyramid *color_src, float *color_out)
+{
+    if (cap <= 0)
+        return SVO_OK;
+    if (!chain || !x1 || !xyz || !d_n || !out_x1 || !out_cam || !out_world) {
+        svo_set_error("keyframe_place: null argument");
+        return SVO_ERR_ARG;
+    }
+    PlaceArgs a;
+    a.chain = chain;
+    a.x1 = reinterpret_cast<const float2 *>(x1);
+    a.xyz = xyz;
+    a.n_host = cap;
+    a.d_n = d_n;
+    a.out_x1 = reinterpret_cast<float2 *>(out_x1);
+    a.out_cam = out_cam;
+    a.out_world = out_world;
+    a.cimg = color_src && color_out ? color_src->dev.lvl[0] : nullptr;
+    a.cpitch = color_src ? color_src->dev.pitch[0] : 0;
+    a.cw = color_src ? color_src->w : 0;
+    a.chh = color_src ? color_src->h : 0;
+    a.cc = color_src ? color_src->c : 0;
+    a.cout = color_src ? color_out : nullptr;
+    ScopedKernelTime tm(ctx, SVO_K_TRIANGULATE);
+    hipLaunchKernelGGL(keyframe_place_kernel, dim3((cap + 63) / 64), dim3(64), 0, ctx->stream, a);
     SVO_HIP(hipGetLastError());
     return SVO_OK;
 }

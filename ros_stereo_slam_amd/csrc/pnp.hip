@@ -794,7 +794,10 @@ __device__ __forceinline__ void pnp_hypothesis(const PnpJob &job, int it, int n,
 // hypotheses were 6 % of the vector instructions of a bench run).  pnp_finish_kernel replays the whole loop
 // itself, reads only iterations below the bound, and so never sees a skipped one.
 constexpr int PNP_PHASE_A = 32;
-__global__ __launch_bounds__(64, 4) void pnp_solve_kernel(PnpBatch batch, int it0, int it1_cap)
+// LEAN (several jobs per launch, beside tracking launches): 128 VGPRs, four waves per SIMD, 172 spilled registers -- the
+// launch is wide enough to hide them.  !LEAN (one job: a chunk on its own, where the launch is a chain of ONE wave's
+// latency and every scratch access is on it): the whole register file, nothing spilled.  Same arithmetic either way.
+template <bool LEAN> __global__ __launch_bounds__(64, LEAN ? 4 : 1) void pnp_solve_kernel(PnpBatch batch, int it0, int it1_cap)
 {
     svo_chain_priority();
     const PnpJob &job = batch.j[blockIdx.y];
@@ -1713,9 +1716,14 @@ int svo_launch_pnp_ransac_batch(svo_ctx *ctx, int n_jobs, const svo_pnp_job *job
     // single-wave workgroups: they get wave slots beside a tracking launch as soon as one frees
     const int bounds[3] = {0, it_max < PNP_PHASE_A ? it_max : PNP_PHASE_A, it_max};
     for (int ph = 0; ph < 2; ph++)
-        if (bounds[ph + 1] > bounds[ph])  // solves AND scores; the second phase usually leaves at once
-            hipLaunchKernelGGL(pnp_solve_kernel, dim3(bounds[ph + 1] - bounds[ph], nb), dim3(64), 0, ctx->stream, batch,
-                               bounds[ph], bounds[ph + 1]);
+        if (bounds[ph + 1] > bounds[ph]) {  // solves AND scores; the second phase usually leaves at once
+            if (nb > 1)
+                hipLaunchKernelGGL(pnp_solve_kernel<true>, dim3(bounds[ph + 1] - bounds[ph], nb), dim3(64), 0, ctx->stream,
+                                   batch, bounds[ph], bounds[ph + 1]);
+            else
+                hipLaunchKernelGGL(pnp_solve_kernel<false>, dim3(bounds[ph + 1] - bounds[ph], nb), dim3(64), 0, ctx->stream,
+                                   batch, bounds[ph], bounds[ph + 1]);
+        }
     const int mode = split ? PNP_FINISH_DECIDE : PNP_FINISH_ALL;
     if (nb > 1)
         hipLaunchKernelGGL(pnp_finish_kernel<true>, dim3(nb), dim3(256), 0, ctx->stream, batch, mode);

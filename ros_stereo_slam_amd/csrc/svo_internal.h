@@ -233,6 +233,10 @@ struct svo_tri_job {  // one stereo DLT triangulation (device pointers; Rt: host
     float *color_out = nullptr;
 };
 int svo_launch_triangulate_batch(svo_ctx *ctx, const double *P1, const double *P2, int k, const svo_tri_job *jobs);
+// a keyframe whose camera-frame points were triangulated ahead of the decision: the chain-mode tail of the triangulation
+// launch alone (runs only when chain->kf is set; [R|t] from the chain state)
+int svo_launch_keyframe_place(svo_ctx *ctx, VoChain *chain, const float *x1, const float *xyz, int cap, const int *d_n,
+                              float *out_x1, float *out_cam, float *out_world, const svo_pyramid *color_src, float *color_out);
 int svo_launch_transform(svo_ctx *ctx, const double *Rt, const float *in, int cap, const int *d_n, float *out);
 int svo_launch_colors(svo_ctx *ctx, const svo_pyramid *pyr, const float *xy, int cap, const int *d_n, float *out);
 int svo_launch_compact_batch(svo_ctx *ctx, int n_jobs, const svo_compact_job *jobs);
