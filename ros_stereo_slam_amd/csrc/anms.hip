@@ -45,9 +45,10 @@ struct AnmsJob {
     uint8_t *out_s;
     const int *gate;  // optional: the job's workgroups leave at once when *gate == 0 (chain runner: no keyframe)
 };
-struct AnmsBatch {
-    AnmsJob j[SVO_LK_MAX_JOBS];
+template <int NJ> struct AnmsBatchN {  // NJ = 1: a chunk on its own (a sixteenth of the kernel arguments per launch)
+    AnmsJob j[NJ];
 };
+using AnmsBatch = AnmsBatchN<SVO_LK_MAX_JOBS>;
 
 // KPW keypoints per wavefront in the all-pairs passes: a stripe of the other keypoints is loaded once
 // and compared against all KPW of them (an eighth of the loads), and a launch has an eighth of the
@@ -58,7 +59,7 @@ constexpr int KPW_LONE = 2;   // a lone problem has the chip to itself: four tim
 
 // order[rank] = i, rank = #keypoints sorting before i (response descending, index ascending);
 // also emits the sorted (x, y, response) triples the radius pass streams through.
-template <int KPW> __global__ __launch_bounds__(64) void anms_rank_kernel(AnmsBatch batch, int n)
+template <int KPW> __global__ __launch_bounds__(64) void anms_rank_kernel(AnmsBatchN<KPW == KPW_LONE ? 1 : SVO_LK_MAX_JOBS> batch, int n)
 {
     svo_chain_priority();
     const AnmsJob &job = batch.j[blockIdx.y];
@@ -126,7 +127,7 @@ template <int KPW> __global__ __launch_bounds__(64) void anms_rank_kernel(AnmsBa
 }
 
 // squared suppression radius of the s-th sorted keypoint (DBL_MAX when nothing dominates it)
-template <int KPW> __global__ __launch_bounds__(64) void anms_radius_kernel(AnmsBatch batch, int n)
+template <int KPW> __global__ __launch_bounds__(64) void anms_radius_kernel(AnmsBatchN<KPW == KPW_LONE ? 1 : SVO_LK_MAX_JOBS> batch, int n)
 {
     svo_chain_priority();
     if (batch.j[blockIdx.y].gate && *batch.j[blockIdx.y].gate == 0)
@@ -186,7 +187,7 @@ template <int KPW> __global__ __launch_bounds__(64) void anms_radius_kernel(Anms
 }
 
 // decision radius = the (keep+1)-th largest radius
-template <int KPW> __global__ __launch_bounds__(64) void anms_decide_kernel(AnmsBatch batch, int n, int keep)
+template <int KPW> __global__ __launch_bounds__(64) void anms_decide_kernel(AnmsBatchN<KPW == KPW_LONE ? 1 : SVO_LK_MAX_JOBS> batch, int n, int keep)
 {
     svo_chain_priority();
     if (batch.j[blockIdx.y].gate && *batch.j[blockIdx.y].gate == 0)
@@ -234,7 +235,7 @@ template <int KPW> __global__ __launch_bounds__(64) void anms_decide_kernel(Anms
 
 // kept[] = order[s] for every s with radius[s] >= decision radius, in sorted order (single workgroup scan);
 // the payload arrays of the kept keypoints are gathered in the same pass
-__global__ __launch_bounds__(1024) void anms_gather_kernel(AnmsBatch batch, int n)
+template <int NJ> __global__ __launch_bounds__(1024) void anms_gather_kernel(AnmsBatchN<NJ> batch, int n)
 {
     svo_chain_priority();
     const AnmsJob &job = batch.j[blockIdx.x];  // one workgroup per job
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(1024) void anms_gather_kernel(AnmsBatch batch, int 
 }
 
 // everything is kept (n <= numToKeep): the index list, its count and the payload in sorted order
-__global__ __launch_bounds__(64) void anms_payload_kernel(AnmsBatch batch, int n)
+template <int NJ> __global__ __launch_bounds__(64) void anms_payload_kernel(AnmsBatchN<NJ> batch, int n)
 {
     const AnmsJob &job = batch.j[blockIdx.y];
     if (job.gate && *job.gate == 0)
@@ -341,24 +342,30 @@ int svo_launch_anms_batch(svo_ctx *ctx, int k, const float *const *xy, const flo
     const bool lone = k == 1;
     const int kpw = lone ? KPW_LONE : KPW_GROUP;
     const dim3 wgrid((n + kpw - 1) / kpw, k), block(64);
+    AnmsBatchN<1> one;
+    one.j[0] = batch.j[0];
     if (lone)
-        hipLaunchKernelGGL(anms_rank_kernel<KPW_LONE>, wgrid, block, 0, ctx->stream, batch, n);
+        hipLaunchKernelGGL(anms_rank_kernel<KPW_LONE>, wgrid, block, 0, ctx->stream, one, n);
     else
         hipLaunchKernelGGL(anms_rank_kernel<KPW_GROUP>, wgrid, block, 0, ctx->stream, batch, n);
     if (n <= keep) {
         // everything is kept, in sorted order (one launch: index list, count, payload)
-        hipLaunchKernelGGL(anms_payload_kernel, dim3((n + 63) / 64, k), dim3(64), 0, ctx->stream, batch, n);
+        if (lone)
+            hipLaunchKernelGGL(anms_payload_kernel<1>, dim3((n + 63) / 64, k), dim3(64), 0, ctx->stream, one, n);
+        else
+            hipLaunchKernelGGL(anms_payload_kernel<SVO_LK_MAX_JOBS>, dim3((n + 63) / 64, k), dim3(64), 0, ctx->stream, batch, n);
         SVO_HIP(hipGetLastError());
         return SVO_OK;
     }
     if (lone) {
-        hipLaunchKernelGGL(anms_radius_kernel<KPW_LONE>, wgrid, block, 0, ctx->stream, batch, n);
-        hipLaunchKernelGGL(anms_decide_kernel<KPW_LONE>, wgrid, block, 0, ctx->stream, batch, n, keep);
+        hipLaunchKernelGGL(anms_radius_kernel<KPW_LONE>, wgrid, block, 0, ctx->stream, one, n);
+        hipLaunchKernelGGL(anms_decide_kernel<KPW_LONE>, wgrid, block, 0, ctx->stream, one, n, keep);
+        hipLaunchKernelGGL(anms_gather_kernel<1>, dim3(k), dim3(1024), 0, ctx->stream, one, n);
     } else {
         hipLaunchKernelGGL(anms_radius_kernel<KPW_GROUP>, wgrid, block, 0, ctx->stream, batch, n);
         hipLaunchKernelGGL(anms_decide_kernel<KPW_GROUP>, wgrid, block, 0, ctx->stream, batch, n, keep);
+        hipLaunchKernelGGL(anms_gather_kernel<SVO_LK_MAX_JOBS>, dim3(k), dim3(1024), 0, ctx->stream, batch, n);
     }
-    hipLaunchKernelGGL(anms_gather_kernel, dim3(k), dim3(1024), 0, ctx->stream, batch, n);
     SVO_HIP(hipGetLastError());
     return SVO_OK;
 }

@@ -53,9 +53,10 @@ struct FrJob {
     int *c_count;
     const int *gate;  // optional: every wave of the job leaves at once when *gate == 0 (chain runner)
 };
-struct FrBatch {
-    FrJob j[SVO_LK_MAX_JOBS];
+template <int NJ> struct FrBatchN {  // NJ = 1: a chunk on its own (a sixteenth of the kernel arguments per launch)
+    FrJob j[NJ];
 };
+using FrBatch = FrBatchN<SVO_LK_MAX_JOBS>;
 static_assert(sizeof(FrBatch) + 16 <= 4096, "kernel arguments are limited to 4 KB");
 
 __device__ __forceinline__ double det3(const double *m)
@@ -377,7 +378,7 @@ __device__ __forceinline__ float f_error(const double (&F)[9], float x1, float y
 // iterations would leave 15 of 16 SIMDs idle: FOUR waves per iteration (wave 0 solves, all four share the scoring
 // pass, and the finishing workgroup's four waves share the mask / compaction pass), 128-VGPR build.
 template <bool LEAN>
-__global__ __launch_bounds__(LEAN ? 64 : 256, LEAN ? 5 : 4) void fr_ransac_kernel(FrBatch batch, int it0, int it1_cap,
+__global__ __launch_bounds__(LEAN ? 64 : 256, LEAN ? 5 : 4) void fr_ransac_kernel(FrBatchN<LEAN ? SVO_LK_MAX_JOBS : 1> batch, int it0, int it1_cap,
                                                                                    int final_phase)
 {
     constexpr int NW = LEAN ? 1 : 4;  // waves per workgroup
@@ -639,9 +640,12 @@ int svo_launch_fransac_batch(svo_ctx *ctx, int n_jobs, const svo_fransac_job *jo
         if (nb > 1)
             hipLaunchKernelGGL(fr_ransac_kernel<true>, dim3(iters < PHASE_WAVES ? iters : PHASE_WAVES, nb), dim3(64), 0,
                                ctx->stream, batch, it0, it1, it1 >= it_max ? 1 : 0);
-        else
+        else {
+            FrBatchN<1> one;
+            one.j[0] = batch.j[0];
             hipLaunchKernelGGL(fr_ransac_kernel<false>, dim3(iters < PHASE_WAVES ? iters : PHASE_WAVES, nb), dim3(256), 0,
-                               ctx->stream, batch, it0, it1, it1 >= it_max ? 1 : 0);
+                               ctx->stream, one, it0, it1, it1 >= it_max ? 1 : 0);
+        }
     }
     SVO_HIP(hipGetLastError());
     return SVO_OK;

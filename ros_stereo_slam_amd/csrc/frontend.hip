@@ -35,19 +35,28 @@ struct svo_vo {
     svo_vo_params prm;
     int w = 0, h = 0, c = 0, cap = 0;
     svo_pyramid *pyr_ref = nullptr, *pyr_cur = nullptr, *pyr_right = nullptr, *pyr_next = nullptr, *pyr_right2 = nullptr;
-    hipStream_t stream_b = nullptr;          // second stream: PnP of frame t beside pyramid + LK of frame t+1
-    hipEvent_t ev_a = nullptr;               // "tracked sets of frame t are ready" (stream A -> B)
-    hipEvent_t ev_b = nullptr;               // "frame t's policy is decided" (stream B -> A)
-    // one chunk per GPU, pipelined: the stereo half of the keyframe path (LK left -> right, ANMS, filters) does not
-    // depend on the frame's pose, so it runs for EVERY frame on a third stream with its own context (stream, scratch,
-    // tickets) and its own point buffers, a frame ahead; only the triangulation waits for the keyframe decision
-    svo_ctx *ctx_s = nullptr;
-    hipEvent_t ev_pyr = nullptr, ev_p1 = nullptr, ev_tri = nullptr, ev_end = nullptr;
-    float *s_a2 = nullptr, *s_b2 = nullptr, *s_c2 = nullptr, *s_d2 = nullptr, *s_x1 = nullptr, *s_x2 = nullptr, *s_resp = nullptr;
-    // what the stereo stream hands over, per frame parity: x1 and the camera-frame points (count: s_cnt[4 + parity])
-    float *s_x1b = nullptr, *s_xyz = nullptr, *s_xyzb = nullptr;
-    uint8_t *s_status = nullptr, *s_st2 = nullptr, *s_mask = nullptr;
-    int *s_idx = nullptr, *s_cnt = nullptr;
+    // One chunk per GPU, pipelined (svo_vo_run_chunk, pipeline != 0): three streams.
+    //   A   the context's stream: the frame's filters, the next frame's pyramids and its tracking pass from the tracked
+    //       set, then -- once B has decided the frame -- a keyframe's pose-free hand-over and the tracking pass again
+    //       from its points
+    //   B   stream_b: PnP hypotheses, the decision, the refinement (a keyframe's first, then the placement of its cloud)
+    //   C   lane.ctx: the whole stereo path of EVERY frame (LK left -> right, ANMS, filters, DLT triangulation in the
+    //       camera frame: none of it needs the frame's pose), a frame ahead, on a context of its own (stream, scratch,
+    //       tickets) with its own staging buffers
+    hipStream_t stream_b = nullptr;
+    struct StereoLane {
+        svo_ctx *ctx = nullptr;
+        float *a2 = nullptr, *b2 = nullptr, *c2 = nullptr, *d2 = nullptr, *x2 = nullptr, *resp = nullptr;
+        uint8_t *status = nullptr, *st2 = nullptr, *mask = nullptr;
+        int *idx = nullptr, *cnt = nullptr;
+    } lane;
+    // what the lane hands to A and B, by frame parity: the keyframe candidate's 2-D points, camera-frame points, count
+    float *h_x1[2] = {nullptr, nullptr}, *h_xyz[2] = {nullptr, nullptr};
+    int *h_cnt = nullptr;
+    // tracked sets ready (A), decided (B), cloud placed (B), refined (B: end of a run), pyramids built (A), stereo path
+    // done (C)
+    hipEvent_t ev_flt = nullptr, ev_dec = nullptr, ev_p3 = nullptr, ev_ref = nullptr, ev_pyr = nullptr, ev_p1 = nullptr;
+    bool pipe_ready = false;
     // second set of tracked points / inlier list: frame t's refinement reads its set while frame t+1's filters write theirs
     float *trk2d_b = nullptr, *trk3d_b = nullptr;
     int *idx_b = nullptr;
@@ -217,15 +226,14 @@ int stereo_triangulate_batch(int k, svo_vo *const *vs, svo_pyramid *const *lefts
     return SVO_OK;
 }
 
-// The stereo half of the keyframe path for ONE pipelined chunk, on the front-end's third stream (v->ctx_s) and its
-// own buffers: LK left -> right from the lattice (src/tracking.cpp:18), ANMS, status filter (:20-27), F-RANSAC at 3 px
-// with its mask filter (:30-43), the DLT triangulation in the camera frame (src/triangulation.cpp:142-160) --
-// everything of stereoTriangulate, none of which needs the frame's pose.  Leaves x1 / camera-frame points / count in
-// s_x1 / s_xyz / s_cnt[4] (s_x1b / s_xyzb / s_cnt[5] for odd `par`: the main stream reads one frame's set while the
-// next frame's is written).  `frame_no`: the frame the pass belongs to (its seed).
-int stereo_part1_spec(svo_vo *v, svo_pyramid *left, svo_pyramid *right, int frame_no, int par)
+// The stereo path of a keyframe candidate for ONE pipelined chunk, on a lane's stream and buffers: LK left -> right from
+// the lattice (src/tracking.cpp:18), ANMS, status filter (:20-27), F-RANSAC at 3 px with its mask filter (:30-43), the
+// DLT triangulation in the camera frame (src/triangulation.cpp:142-160) -- all of stereoTriangulate, none of which
+// needs the frame's pose.  Leaves x1 / camera-frame points / count in h_x1 / h_xyz / h_cnt[slot].
+// `frame_no`: the frame the pass belongs to (its seed).
+int stereo_part1_spec(svo_vo *v, svo_vo::StereoLane &L, svo_pyramid *left, svo_pyramid *right, int frame_no, int slot)
 {
-    svo_ctx *cs = v->ctx_s;
+    svo_ctx *cs = L.ctx;
     int rc;
     const int n = grid_axis(v->w, v->prm.grid_step) * grid_axis(v->h, v->prm.grid_step);
     const int *run = &v->d_chain->run;
@@ -236,50 +244,51 @@ int stereo_part1_spec(svo_vo *v, svo_pyramid *left, svo_pyramid *right, int fram
     q.prev_pts = v->grid_xy;
     q.n_cap = n;
     q.d_n = nullptr;
-    q.next_pts = v->s_b2;
-    q.status = v->s_status;
+    q.next_pts = L.b2;
+    q.status = L.status;
     q.err = nullptr;
-    q.min_eig = v->s_resp;
+    q.min_eig = L.resp;
     q.gate = run;
     if ((rc = svo_launch_lk_batch(cs, 1, &q, left)))
         return rc;
-    const float *pts = v->grid_xy, *trk = v->s_b2;
-    const uint8_t *stt = v->s_status;
+    const float *pts = v->grid_xy, *trk = L.b2;
+    const uint8_t *stt = L.status;
     const int *d_n = nullptr;
     if (v->prm.anms_keep > 0) {
-        const float *xy = v->grid_xy, *resp = v->s_resp;
-        int *oidx = v->s_idx, *ocnt = v->s_cnt + 2;
-        const svo_anms_gather ga = {v->grid_xy, v->s_b2, v->s_c2, v->s_d2, v->s_status, v->s_st2};
+        const float *xy = v->grid_xy, *resp = L.resp;
+        int *oidx = L.idx, *ocnt = L.cnt + 2;
+        const svo_anms_gather ga = {v->grid_xy, L.b2, L.c2, L.d2, L.status, L.st2};
         if ((rc = svo_launch_anms_batch(cs, 1, &xy, &resp, n, v->prm.anms_keep, &oidx, &ocnt, &ga, &run)))
             return rc;
-        pts = v->s_c2;
-        trk = v->s_d2;
-        stt = v->s_st2;
-        d_n = v->s_cnt + 2;
+        pts = L.c2;
+        trk = L.d2;
+        stt = L.st2;
+        d_n = L.cnt + 2;
     }
-    float *o1 = pts == v->grid_xy ? v->s_c2 : v->s_a2, *o2 = pts == v->grid_xy ? v->s_d2 : v->s_b2;
-    float *x1 = par ? v->s_x1b : v->s_x1;
-    int *cnt = v->s_cnt + 4 + (par ? 1 : 0);
-    const svo_compact_job c1 = {stt, n, d_n, {pts, trk, nullptr}, {o1, o2, nullptr}, {2, 2, 0}, v->s_cnt + 3, run};
-    const svo_compact_job c2 = {v->s_mask, n, v->s_cnt + 3, {o1, o2, nullptr}, {x1, v->s_x2, nullptr}, {2, 2, 0}, cnt};
+    float *o1 = pts == v->grid_xy ? L.c2 : L.a2, *o2 = pts == v->grid_xy ? L.d2 : L.b2;
+    float *x1 = v->h_x1[slot];
+    int *cnt = v->h_cnt + slot;
+    const svo_compact_job c1 = {stt, n, d_n, {pts, trk, nullptr}, {o1, o2, nullptr}, {2, 2, 0}, L.cnt + 3, run};
+    const svo_compact_job c2 = {L.mask, n, L.cnt + 3, {o1, o2, nullptr}, {x1, L.x2, nullptr}, {2, 2, 0}, cnt};
     const uint64_t seed = v->prm.seed + 8ull * (uint64_t)frame_no + 3;  // stage_seed(frame_no, 3)
-    const svo_fransac_job fj = {o1, o2, n, v->s_cnt + 3, v->prm.f_thr_stereo, 0.99, 1000, seed, v->s_mask, nullptr, nullptr,
+    const svo_fransac_job fj = {o1, o2, n, L.cnt + 3, v->prm.f_thr_stereo, 0.99, 1000, seed, L.mask, nullptr, nullptr,
                                 nullptr, &c2, run};
     if ((rc = svo_launch_compact_batch(cs, 1, &c1)) || (rc = svo_launch_fransac_batch(cs, 1, &fj)))
         return rc;
-    const svo_tri_job tj = {x1, v->s_x2, n, cnt, par ? v->s_xyzb : v->s_xyz, nullptr, nullptr, nullptr, nullptr};
+    const svo_tri_job tj = {x1, L.x2, n, cnt, v->h_xyz[slot], nullptr, nullptr, nullptr, nullptr};
     double P1[12], P2[12];
     svo_stereo_projections(v->prm.fx, v->prm.fy, v->prm.cx, v->prm.cy, v->prm.baseline, P1, P2);
     return svo_launch_triangulate_batch(cs, P1, P2, 1, &tj);
 }
 
-// ... and the rest, which does: the cloud's placement with the frame's refined pose and the hand-over of the keyframe's
-// sets (src/keyFrameManagement.cpp:18-30), on the main stream, only when the device flag says keyframe.
-int stereo_part2_spec(svo_vo *v, const svo_pyramid *left, int par)
+// ... and what is left once the frame is decided, only when the device flag says keyframe: what = 1, the hand-over of
+// the 2-D set (all the next tracking pass needs); what = 2, the cloud placed with the frame's refined pose
+// (src/keyFrameManagement.cpp:18-30).  On the context's current stream.
+int stereo_part2_spec(svo_vo *v, const svo_pyramid *left, int slot, int what)
 {
     const int n = grid_axis(v->w, v->prm.grid_step) * grid_axis(v->h, v->prm.grid_step);
-    return svo_launch_keyframe_place(v->ctx, v->d_chain, par ? v->s_x1b : v->s_x1, par ? v->s_xyzb : v->s_xyz, n,
-                                     v->s_cnt + 4 + (par ? 1 : 0), v->ref2d, v->b3, v->ref3d, left, v->kf_col);
+    return svo_launch_keyframe_place(v->ctx, v->d_chain, v->h_x1[slot], v->h_xyz[slot], n, v->h_cnt + slot, v->ref2d, v->b3,
+                                     v->ref3d, left, v->kf_col, what);
 }
 
 // the PnP-RANSAC problem of a localisation as the chain runner queues it: solvePnPRansac(100, 1 px, 0.99) over the
@@ -427,10 +436,8 @@ int svo_vo_create(svo_ctx *ctx, const svo_vo_params *params, int width, int heig
         svo_vo_destroy(v);
         return rc;
     }
-    if (hipEventCreateWithFlags(&v->ev_a, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&v->ev_b, hipEventDisableTiming) != hipSuccess ||
-        hipHostMalloc(reinterpret_cast<void **>(&v->h_chain), sizeof(VoChain), hipHostMallocDefault) != hipSuccess) {
-        svo_set_error("front-end: cannot create the events / the pinned state block");
+    if (hipHostMalloc(reinterpret_cast<void **>(&v->h_chain), sizeof(VoChain), hipHostMallocDefault) != hipSuccess) {
+        svo_set_error("front-end: cannot allocate the pinned state block");
         svo_vo_destroy(v);
         return SVO_ERR_HIP;
     }
@@ -456,20 +463,18 @@ int svo_vo_destroy(svo_vo *v)
         (void)hipStreamSynchronize(v->stream_b);
         (void)hipStreamDestroy(v->stream_b);
     }
-    if (v->ev_a)
-        (void)hipEventDestroy(v->ev_a);
-    if (v->ev_b)
-        (void)hipEventDestroy(v->ev_b);
-    for (hipEvent_t e : {v->ev_pyr, v->ev_p1, v->ev_tri, v->ev_end})
+    for (hipEvent_t e : {v->ev_flt, v->ev_dec, v->ev_p3, v->ev_ref, v->ev_pyr, v->ev_p1})
         if (e)
             (void)hipEventDestroy(e);
-    if (v->ctx_s) {
-        (void)hipStreamSynchronize(v->ctx_s->stream);
-        (void)svo_ctx_destroy(v->ctx_s);
-    }
     {
-        void *sb[] = {v->s_a2, v->s_b2, v->s_c2, v->s_d2, v->s_x1, v->s_x2, v->s_resp, v->s_status, v->s_st2, v->s_mask,
-                      v->s_idx, v->s_cnt, v->trk2d_b, v->trk3d_b, v->idx_b, v->s_x1b, v->s_xyz, v->s_xyzb};
+        svo_vo::StereoLane &L = v->lane;
+        if (L.ctx) {
+            (void)hipStreamSynchronize(L.ctx->stream);
+            (void)svo_ctx_destroy(L.ctx);
+        }
+        void *sb[] = {L.a2,        L.b2,        L.c2,        L.d2,         L.x2,         L.resp,   L.status,   L.st2,      L.mask,
+                      L.idx,       L.cnt,       v->h_x1[0],  v->h_x1[1],   v->h_xyz[0],  v->h_xyz[1], v->h_cnt, v->trk2d_b, v->trk3d_b,
+                      v->idx_b};
         for (void *b : sb)
             if (b)
                 (void)hipFree(b);
@@ -681,10 +686,11 @@ int svo_vo_track(svo_vo *v, const uint8_t *left, const uint8_t *right, int mem, 
 // Results: exactly those of n_frames calls of svo_vo_track(..., force_keyframe = 0) -- every stage sees the same
 // inputs and seeds (tests/test_gpu_frontend.py::test_run_chunk_*).
 //
-// pipeline (one chunk, device images): two HIP streams.  Stream A carries a frame's filters and the keyframe path;
-// the PnP-RANSAC of frame t runs on stream B while stream A builds the pyramid of frame t+1 and tracks into it from
-// the points frame t kept -- which is what frame t+1 does unless frame t turns out to be a keyframe, in which case a
-// second tracking launch (gated on the keyframe flag) redoes it from the new keyframe's points.
+// pipeline (one chunk, device images): three HIP streams, see svo_vo and chain_enqueue.  The PnP of frame t runs on a
+// stream of its own while the context's stream builds the pyramids of frame t+1 and tracks into them from the points
+// frame t kept -- which is what frame t+1 does unless frame t turns out to be a keyframe, in which case a second tracking
+// launch (gated on the keyframe flag) redoes it from the new keyframe's points; the stereo path of every frame runs a
+// frame ahead on a third stream.
 struct ChainRun {            // one chunk of a lock-step set
     svo_vo *v;
     const uint8_t *const *lefts, *const *rights;
@@ -717,7 +723,8 @@ static int chain_prepare(ChainRun &r)
     }
     VoChain *c = v->h_chain;
     memset(c, 0, sizeof(*c));
-    c->run = 1;
+    static const bool dry = getenv("SVO_CHAIN_DRY") != nullptr;  // experiment: every kernel leaves at once -> the host's own cost
+    c->run = dry ? 0 : 1;
     c->kf = 0;
     c->nref = v->nref;
     c->frame = 0;
@@ -798,14 +805,19 @@ static int chain_filters(svo_ctx *ctx, int k, svo_vo *const *vs, int set = 0)
     return SVO_OK;
 }
 
-static int chain_pnp(svo_ctx *ctx, int k, svo_vo *const *vs, int set = 0, bool split = false, bool refine_only = false)
+static int chain_pnp(svo_ctx *ctx, int k, svo_vo *const *vs, int set = 0, bool split = false)
 {
     svo_pnp_job pj[SVO_LK_MAX_JOBS];
     for (int a = 0; a < k; a++)
         pj[a] = pnp_job(vs[a], vs[a]->d_cnt + (set ? 9 : 1), stage_seed(vs[a], 1), set);
-    if (refine_only)
-        return svo_launch_pnp_refine(ctx, k, pj);
     return svo_launch_pnp_ransac_batch(ctx, k, pj, split);
+}
+
+// the refinement a split chain_pnp left undone, for the frame if it is a keyframe / if it is none
+static int chain_pnp_refine(svo_ctx *ctx, svo_vo *const *vs, int set, bool keyframes)
+{
+    const svo_pnp_job pj = pnp_job(vs[0], vs[0]->d_cnt + (set ? 9 : 1), stage_seed(vs[0], 1), set);
+    return svo_launch_pnp_refine(ctx, 1, &pj, keyframes);
 }
 
 // Queue frames [0, n) of k chunks that share a context (lock step: every stage one set of launches for all of them;
@@ -814,7 +826,6 @@ static int chain_enqueue(ChainRun *const *runs, int k, bool pipeline)
 {
     svo_vo *v0 = runs[0]->v;
     svo_ctx *ctx = v0->ctx;
-    hipStream_t sA = ctx->stream;
     int n_max = 0, rc;
     for (int a = 0; a < k; a++)
         n_max = runs[a]->n_frames > n_max ? runs[a]->n_frames : n_max;
@@ -853,20 +864,35 @@ static int chain_enqueue(ChainRun *const *runs, int k, bool pipeline)
         return svo_build_pyramids_from_device(ctx, 2 * na, pyrs, imgs, g);
     };
     if (pipeline) {
-        // Three streams.  A (the context's): the frame's filters, the next frame's pyramids and its tracking pass from
-        // the tracked set, then -- once B has decided the frame -- the keyframe's triangulation and the tracking pass
-        // again from its points (both leave at once unless the frame is a keyframe).  B: PnP-RANSAC, the policy,
-        // the refinement (a keyframe is refined before A goes on; any other frame beside the next frame's filters).
-        // C: the pose-free half of the stereo path of EVERY frame, a frame ahead.
+        // Three streams (see svo_vo).  A: the frame's filters, the next frame's pyramids and its tracking pass from the
+        // tracked set -- what frame f+1 uses unless f turns out to be a keyframe --, then, once B has decided the frame,
+        // a keyframe's pose-free hand-over and the tracking pass again from its points (both leave at once otherwise).
+        // B: PnP hypotheses and the decision (A goes on from here), then the refinement: a keyframe's first, and the
+        // placement of its cloud with that pose, which A waits for only before the next filters read the 3-D set (the
+        // second tracking pass runs beside it); any other frame's after that, beside the next frame's filters.
+        // C: the stereo path of EVERY frame, a frame ahead.
+        static const bool dbg = getenv("SVO_CHAIN_DEBUG") != nullptr;
+        double us_cat[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // host time by category (debug): see the print below
+        auto tick = [&]() { return dbg ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point(); };
+        auto tock = [&](int cat, std::chrono::steady_clock::time_point t0) {
+            if (dbg)
+                us_cat[cat] += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        };
         ChainRun &r = *runs[0];
         svo_vo *v = r.v;
-        hipStream_t sB = v->stream_b, sC = v->ctx_s->stream;
+        hipStream_t sA = ctx->stream, sB = v->stream_b, sC = v->lane.ctx->stream;
         svo_pyramid *ref = v->pyr_ref, *cur = v->pyr_cur, *nxt = v->pyr_next;
         svo_pyramid *right[2] = {v->pyr_right, v->pyr_right2};
         const int *run = &v->d_chain->run, *kf = &v->d_chain->kf;
         vs[0] = v;
-        const int frame0 = v->frame;
-        // prologue: the pyramids of frame 0, its tracking pass, the stereo half of frame 0
+        const int frame0 = v->frame, nf = r.n_frames;
+        struct OnStream {  // the launch helpers take the stream from the context
+            svo_ctx *c;
+            hipStream_t keep;
+            OnStream(svo_ctx *cc, hipStream_t st) : c(cc), keep(cc->stream) { c->stream = st; }
+            ~OnStream() { c->stream = keep; }
+        };
+        // prologue: the pyramids of frame 0, its tracking pass, the stereo path of frame 0
         {
             const uint8_t *li = r.lefts[0], *ri = r.rights[0];
             if ((rc = build(1, vs, &cur, &right[0], &li, &ri, r.mem)))
@@ -878,29 +904,41 @@ static int chain_enqueue(ChainRun *const *runs, int k, bool pipeline)
             if ((rc = chain_lk(ctx, 1, vs, &ref, &cur, pts, dn, gates)))
                 return rc;
             SVO_HIP(hipStreamWaitEvent(sC, v->ev_pyr, 0));
-            if ((rc = stereo_part1_spec(v, cur, right[0], frame0 + 1, 0)))
+            if ((rc = stereo_part1_spec(v, v->lane, cur, right[0], frame0 + 1, 0)))
                 return rc;
             SVO_HIP(hipEventRecord(v->ev_p1, sC));
         }
-        for (int f = 0; f < r.n_frames; f++) {
+        for (int f = 0; f < nf; f++) {
             v->frame++;
             const int set = f & 1;
+            const bool more = f + 1 < nf;
+            auto t0 = tick();
             if ((rc = chain_filters(ctx, 1, vs, set)))
                 return rc;
-            // PnP of this frame on stream B: solve, decide (A goes on from here), refine
-            SVO_HIP(hipEventRecord(v->ev_a, sA));
-            SVO_HIP(hipStreamWaitEvent(sB, v->ev_a, 0));
-            ctx->stream = sB;
-            rc = chain_pnp(ctx, 1, vs, set, true);
-            if (!rc) {
-                SVO_HIP(hipEventRecord(v->ev_b, sB));
-                rc = chain_pnp(ctx, 1, vs, set, true, true);
+            tock(0, t0);
+            t0 = tick();
+            SVO_HIP(hipEventRecord(v->ev_flt, sA));
+            tock(1, t0);
+            t0 = tick();
+            // B: hypotheses and the decision; then a keyframe is refined and its cloud placed with that pose; any other
+            // frame is refined after that.  (In order on B: the next frame's hypotheses follow this frame's refinement,
+            // which reads the workspace they are written to.)
+            SVO_HIP(hipStreamWaitEvent(sB, v->ev_flt, 0));
+            {
+                OnStream on(ctx, sB);
+                if ((rc = chain_pnp(ctx, 1, vs, set, true)))
+                    return rc;
+                SVO_HIP(hipEventRecord(v->ev_dec, sB));
+                SVO_HIP(hipStreamWaitEvent(sB, v->ev_p1, 0));  // the stereo path of this frame: long done
+                if ((rc = chain_pnp_refine(ctx, vs, set, true)) || (rc = stereo_part2_spec(v, cur, set, 2)))
+                    return rc;
+                SVO_HIP(hipEventRecord(v->ev_p3, sB));
+                if ((rc = chain_pnp_refine(ctx, vs, set, false)))
+                    return rc;
             }
-            ctx->stream = sA;
-            if (rc)
-                return rc;
-            const bool more = f + 1 < r.n_frames;
-            if (more) {  // beside it on stream A: the next frame's pyramids and its tracking pass from the tracked set
+            tock(2, t0);
+            t0 = tick();
+            if (more) {  // beside it on A: the next frame's pyramids and its tracking pass from the tracked set
                 const uint8_t *li = r.lefts[f + 1], *ri = r.rights[f + 1];
                 if ((rc = build(1, vs, &nxt, &right[(f + 1) & 1], &li, &ri, r.mem)))
                     return rc;
@@ -911,10 +949,12 @@ static int chain_enqueue(ChainRun *const *runs, int k, bool pipeline)
                 if ((rc = chain_lk(ctx, 1, vs, &cur, &nxt, pts, dn, gates)))
                     return rc;
             }
-            // the frame is decided (and, a keyframe, refined); its stereo half has long been ready
-            SVO_HIP(hipStreamWaitEvent(sA, v->ev_b, 0));
+            tock(3, t0);
+            t0 = tick();
+            // the frame is decided; its stereo path has long been ready
+            SVO_HIP(hipStreamWaitEvent(sA, v->ev_dec, 0));
             SVO_HIP(hipStreamWaitEvent(sA, v->ev_p1, 0));
-            if ((rc = stereo_part2_spec(v, cur, f & 1)))
+            if ((rc = stereo_part2_spec(v, cur, set, 1)))
                 return rc;
             if (more) {
                 pts[0] = v->ref2d;  // a keyframe: the next frame is tracked from its points
@@ -922,21 +962,30 @@ static int chain_enqueue(ChainRun *const *runs, int k, bool pipeline)
                 gates[0] = kf;
                 if ((rc = chain_lk(ctx, 1, vs, &cur, &nxt, pts, dn, gates)))
                     return rc;
-                // the stereo half of the next frame: its pyramids are built; it writes the other hand-over set than the
-                // one this frame's placement reads (and the set it writes was read a frame ago on A, before ev_pyr)
+                tock(4, t0);
+                t0 = tick();
+                // the stereo path of the next frame: its pyramids are built; it writes the other hand-over set than the
+                // one this frame's placements read (and the set it writes was read a frame ago, before ev_pyr on A and
+                // before the ev_p3 A waited for)
                 SVO_HIP(hipStreamWaitEvent(sC, v->ev_pyr, 0));
-                if ((rc = stereo_part1_spec(v, nxt, right[(f + 1) & 1], frame0 + f + 2, (f + 1) & 1)))
+                if ((rc = stereo_part1_spec(v, v->lane, nxt, right[(f + 1) & 1], frame0 + f + 2, (f + 1) & 1)))
                     return rc;
                 SVO_HIP(hipEventRecord(v->ev_p1, sC));
             }
+            tock(5, t0);
+            SVO_HIP(hipStreamWaitEvent(sA, v->ev_p3, 0));  // the next filters read the 3-D reference set
             svo_pyramid *t = ref;  // referenceImg = currentImage (src/VisualSLAM.cpp:151)
             ref = cur;
             cur = nxt;
             nxt = t;
         }
         // the last frame's refinement runs on B: the caller's wait on A covers it
-        SVO_HIP(hipEventRecord(v->ev_end, sB));
-        SVO_HIP(hipStreamWaitEvent(sA, v->ev_end, 0));
+        SVO_HIP(hipEventRecord(v->ev_ref, sB));
+        SVO_HIP(hipStreamWaitEvent(sA, v->ev_ref, 0));
+        if (dbg)
+            fprintf(stderr, "[svo chain] host us per frame: filters %.1f, record %.1f, B (3 waits/records + 6 launches) %.1f, "
+                            "pyramids + LK on A %.1f, waits + place + LK2 on A %.1f, C %.1f\n", us_cat[0] / nf, us_cat[1] / nf,
+                    us_cat[2] / nf, us_cat[3] / nf, us_cat[4] / nf, us_cat[5] / nf);
         return SVO_OK;
     }
     // lock step on one stream
@@ -1089,13 +1138,25 @@ static int chain_run(ChainRun *const *runs, int k, bool pipeline)
     for (int a = 0; a < k; a++)
         if ((rc = chain_prepare(*runs[a])))
             return rc;
+    static const bool debug = getenv("SVO_CHAIN_DEBUG") != nullptr;  // host time of the enqueue against the device's
+    const auto t0 = std::chrono::steady_clock::now();
     if ((rc = chain_enqueue(runs, k, pipeline)))
         return rc;
+    const auto t1 = std::chrono::steady_clock::now();
     if ((rc = svo_wait(ctx)))
         return rc;
+    if (debug) {
+        const auto t2 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[svo chain] %d chunk(s) x %d frames, pipeline %d: enqueue %.1f us, then waited %.1f us\n", k,
+                runs[0]->n_frames, (int)pipeline, std::chrono::duration<double, std::micro>(t1 - t0).count(),
+                std::chrono::duration<double, std::micro>(t2 - t1).count());
+    }
     for (int a = 0; a < k; a++)
         if ((rc = chain_collect(*runs[a], pipeline)))
             return rc;
+    if (getenv("SVO_CHAIN_DRY"))  // experiment (see chain_prepare): nothing ran, report the frames as done
+        for (int a = 0; a < k; a++)
+            runs[a]->n_done = runs[a]->n_frames;
     for (int a = 0; a < k; a++) {
         ChainRun &r = *runs[a];
         svo_vo *v = r.v;
@@ -1164,29 +1225,37 @@ int svo_vo_run_chunk(svo_vo *v, const uint8_t *const *lefts, const uint8_t *cons
     SVO_HIP(hipSetDevice(v->ctx->device));
     if (mem == SVO_MEM_HOST)
         pipeline = 0;  // host images go through one staging buffer; keep them strictly in order
-    if (pipeline && !v->stream_b) {
-        // The PnP stream exists only once pipelining is asked for, and in the high-priority class:
-        // HIP keeps a separate pool of hardware queues per priority class, so the two streams of
-        // a chunk never land on one queue (with both in the default class the runtime was seen to
-        // put them on the same queue, which serialises the overlap away), and creating it does not
-        // disturb the stream -> queue assignment of serial chunks running side by side.
-        int prio_lo = 0, prio_hi = 0;
+    if (pipeline && !v->pipe_ready) {
+        // The pipeline's streams exist only once pipelining is asked for.  The PnP stream is in the high-priority class:
+        // HIP keeps a separate pool of hardware queues per priority class, so the streams of a chunk never land on one
+        // queue (with all in the default class the runtime was seen to put two of them on the same queue, which
+        // serialises the overlap away), and creating it does not disturb the stream -> queue assignment of serial chunks
+        // running side by side.
+        int rc, prio_lo = 0, prio_hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-        SVO_HIP(hipStreamCreateWithPriority(&v->stream_b, hipStreamNonBlocking, prio_hi));
-    }
-    if (pipeline && !v->ctx_s) {  // the stereo stream: a context of its own (stream, scratch, tickets) + staging buffers
-        int rc;
+        if (!v->stream_b)
+            SVO_HIP(hipStreamCreateWithPriority(&v->stream_b, hipStreamNonBlocking, prio_hi));
         const size_t n = (size_t)v->cap;
-        if ((rc = svo_ctx_create(v->ctx->device, &v->ctx_s)) || (rc = dev_alloc(&v->s_a2, n * 2)) ||
-            (rc = dev_alloc(&v->s_b2, n * 2)) || (rc = dev_alloc(&v->s_c2, n * 2)) || (rc = dev_alloc(&v->s_d2, n * 2)) ||
-            (rc = dev_alloc(&v->s_x1, n * 2)) || (rc = dev_alloc(&v->s_x2, n * 2)) || (rc = dev_alloc(&v->s_resp, n)) ||
-            (rc = dev_alloc(&v->s_status, n)) || (rc = dev_alloc(&v->s_st2, n)) || (rc = dev_alloc(&v->s_mask, n)) ||
-            (rc = dev_alloc(&v->s_idx, n)) || (rc = dev_alloc(&v->s_cnt, 16)) || (rc = dev_alloc(&v->trk2d_b, n * 2)) ||
-            (rc = dev_alloc(&v->trk3d_b, n * 3)) || (rc = dev_alloc(&v->idx_b, n)) || (rc = dev_alloc(&v->s_x1b, n * 2)) ||
-            (rc = dev_alloc(&v->s_xyz, n * 3)) || (rc = dev_alloc(&v->s_xyzb, n * 3)))
+        svo_vo::StereoLane &L = v->lane;
+        if (!L.ctx && (rc = svo_ctx_create(v->ctx->device, &L.ctx)))
             return rc;
-        for (hipEvent_t *e : {&v->ev_pyr, &v->ev_p1, &v->ev_tri, &v->ev_end})
-            SVO_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        if ((!L.a2 && (rc = dev_alloc(&L.a2, n * 2))) || (!L.b2 && (rc = dev_alloc(&L.b2, n * 2))) ||
+            (!L.c2 && (rc = dev_alloc(&L.c2, n * 2))) || (!L.d2 && (rc = dev_alloc(&L.d2, n * 2))) ||
+            (!L.x2 && (rc = dev_alloc(&L.x2, n * 2))) || (!L.resp && (rc = dev_alloc(&L.resp, n))) ||
+            (!L.status && (rc = dev_alloc(&L.status, n))) || (!L.st2 && (rc = dev_alloc(&L.st2, n))) ||
+            (!L.mask && (rc = dev_alloc(&L.mask, n))) || (!L.idx && (rc = dev_alloc(&L.idx, n))) ||
+            (!L.cnt && (rc = dev_alloc(&L.cnt, 16))))
+            return rc;
+        for (int k = 0; k < 2; k++)
+            if ((!v->h_x1[k] && (rc = dev_alloc(&v->h_x1[k], n * 2))) || (!v->h_xyz[k] && (rc = dev_alloc(&v->h_xyz[k], n * 3))))
+                return rc;
+        if ((!v->h_cnt && (rc = dev_alloc(&v->h_cnt, 16))) || (!v->trk2d_b && (rc = dev_alloc(&v->trk2d_b, n * 2))) ||
+            (!v->trk3d_b && (rc = dev_alloc(&v->trk3d_b, n * 3))) || (!v->idx_b && (rc = dev_alloc(&v->idx_b, n))))
+            return rc;
+        for (hipEvent_t *e : {&v->ev_flt, &v->ev_dec, &v->ev_p3, &v->ev_ref, &v->ev_pyr, &v->ev_p1})
+            if (!*e)
+                SVO_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        v->pipe_ready = true;
     }
     if (v->nref < 5) {
         svo_set_error("tracking lost: %d reference points", v->nref);

@@ -93,11 +93,12 @@ struct TriJob {
     int cpitch, cw, chh, cc;
     float *cout;
 };
-struct TriBatch {  // blockIdx.y picks the job
-    TriJob j[SVO_LK_MAX_JOBS];
+template <int NJ> struct TriBatchN {  // blockIdx.y picks the job; NJ = 1: a lone problem (a sixteenth of the kernel arguments)
+    TriJob j[NJ];
 };
+using TriBatch = TriBatchN<SVO_LK_MAX_JOBS>;
 
-__global__ __launch_bounds__(128) void triangulate_kernel(Mat34 P1, Mat34 P2, TriBatch batch)
+template <int NJ> __global__ __launch_bounds__(128) void triangulate_kernel(Mat34 P1, Mat34 P2, TriBatchN<NJ> batch)
 {
     svo_chain_priority();
     const TriJob &job = batch.j[blockIdx.y];
@@ -190,7 +191,9 @@ struct PlaceArgs {
     int cpitch, cw, chh, cc;
     float *cout;
 };
-__global__ __launch_bounds__(64) void keyframe_place_kernel(PlaceArgs a)
+// what: 1 = the pose-free part (reference-set size and halt rule, the 2-D set, colours: all the next tracking pass
+// needs), 2 = the clouds (camera frame and placed with the refined pose), 3 = both.
+__global__ __launch_bounds__(64) void keyframe_place_kernel(PlaceArgs a, int what)
 {
     svo_chain_priority();
     VoChain *chain = a.chain;
@@ -198,7 +201,7 @@ __global__ __launch_bounds__(64) void keyframe_place_kernel(PlaceArgs a)
         return;
     const int n = min(*a.d_n, a.n_host);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) {
+    if (i == 0 && (what & 1)) {
         chain->nref = n;
         chain->kf_n = n;
         if (n < 5) {
@@ -208,25 +211,29 @@ __global__ __launch_bounds__(64) void keyframe_place_kernel(PlaceArgs a)
     }
     if (i >= n)
         return;
-    const float2 p = a.x1[i];
-    a.out_x1[i] = p;
-    if (a.cout) {
-        int cx = (int)p.x, cy = (int)p.y;
-        cx = cx < 0 ? 0 : (cx >= a.cw ? a.cw - 1 : cx);
-        cy = cy < 0 ? 0 : (cy >= a.chh ? a.chh - 1 : cy);
-        const uint8_t *px = a.cimg + (size_t)cy * a.cpitch + cx * a.cc;
+    if (what & 1) {
+        const float2 p = a.x1[i];
+        a.out_x1[i] = p;
+        if (a.cout) {
+            int cx = (int)p.x, cy = (int)p.y;
+            cx = cx < 0 ? 0 : (cx >= a.cw ? a.cw - 1 : cx);
+            cy = cy < 0 ? 0 : (cy >= a.chh ? a.chh - 1 : cy);
+            const uint8_t *px = a.cimg + (size_t)cy * a.cpitch + cx * a.cc;
 #pragma unroll
-        for (int k = 0; k < 3; k++)
-            a.cout[3 * i + k] = (float)px[a.cc >= 3 ? k : 0];
+            for (int k = 0; k < 3; k++)
+                a.cout[3 * i + k] = (float)px[a.cc >= 3 ? k : 0];
+        }
     }
-    const float x = a.xyz[3 * i], y = a.xyz[3 * i + 1], z = a.xyz[3 * i + 2];
-    a.out_cam[3 * i] = x;
-    a.out_cam[3 * i + 1] = y;
-    a.out_cam[3 * i + 2] = z;
+    if (what & 2) {
+        const float x = a.xyz[3 * i], y = a.xyz[3 * i + 1], z = a.xyz[3 * i + 2];
+        a.out_cam[3 * i] = x;
+        a.out_cam[3 * i + 1] = y;
+        a.out_cam[3 * i + 2] = z;
 #pragma unroll
-    for (int r = 0; r < 3; r++)
-        a.out_world[3 * i + r] =
-            (float)(chain->R[3 * r] * x + chain->R[3 * r + 1] * y + chain->R[3 * r + 2] * z + chain->t[r]);
+        for (int r = 0; r < 3; r++)
+            a.out_world[3 * i + r] =
+                (float)(chain->R[3 * r] * x + chain->R[3 * r + 1] * y + chain->R[3 * r + 2] * z + chain->t[r]);
+    }
 }
 
 __global__ __launch_bounds__(256) void transform_kernel(Mat34 Rt, const float *__restrict__ in, int n_host,
@@ -276,9 +283,10 @@ struct CompactArgs {
     int *d_count;
     const int *gate;
 };
-struct CompactBatch {  // one workgroup per job
-    CompactArgs j[SVO_LK_MAX_JOBS];
+template <int NJ> struct CompactBatchN {  // blockIdx.y picks the job; NJ = 1: a lone problem
+    CompactArgs j[NJ];
 };
+using CompactBatch = CompactBatchN<SVO_LK_MAX_JOBS>;
 
 __device__ __forceinline__ int wave_sum_int(int v)
 {
@@ -296,7 +304,7 @@ __device__ __forceinline__ int count_ones_bytes(uint32_t x)
     return __popc(t);
 }
 
-__global__ __launch_bounds__(64) void compact_kernel(CompactBatch batch, int seg)
+template <int NJ> __global__ __launch_bounds__(64) void compact_kernel(CompactBatchN<NJ> batch, int seg)
 {
     svo_chain_priority();
     const CompactArgs &args = batch.j[blockIdx.y];
@@ -393,14 +401,22 @@ int svo_launch_triangulate_batch(svo_ctx *ctx, const double *P1, const double *P
     if (cap_max <= 0)
         return SVO_OK;
     ScopedKernelTime tm(ctx, SVO_K_TRIANGULATE);
-    hipLaunchKernelGGL(triangulate_kernel, dim3((cap_max + 63) / 64, k), dim3(64), 0, ctx->stream, to_mat34(P1),
-                       to_mat34(P2), batch);
+    if (k == 1) {
+        TriBatchN<1> one;
+        one.j[0] = batch.j[0];
+        hipLaunchKernelGGL(triangulate_kernel<1>, dim3((cap_max + 63) / 64, k), dim3(64), 0, ctx->stream, to_mat34(P1),
+                           to_mat34(P2), one);
+    } else {
+        hipLaunchKernelGGL(triangulate_kernel<SVO_LK_MAX_JOBS>, dim3((cap_max + 63) / 64, k), dim3(64), 0, ctx->stream,
+                           to_mat34(P1), to_mat34(P2), batch);
+    }
     SVO_HIP(hipGetLastError());
     return SVO_OK;
 }
 
 int svo_launch_keyframe_place(svo_ctx *ctx, VoChain *chain, const float *x1, const float *xyz, int cap, const int *d_n,
-                              float *out_x1, float *out_cam, float *out_world, const svo_pyramid *color_src, float *color_out)
+                              float *out_x1, float *out_cam, float *out_world, const svo_pyramid *color_src, float *color_out,
+                              int what)
 {
     if (cap <= 0)
         return SVO_OK;
@@ -424,7 +440,7 @@ int svo_launch_keyframe_place(svo_ctx *ctx, VoChain *chain, const float *x1, con
     a.cc = color_src ? color_src->c : 0;
     a.cout = color_src ? color_out : nullptr;
     ScopedKernelTime tm(ctx, SVO_K_TRIANGULATE);
-    hipLaunchKernelGGL(keyframe_place_kernel, dim3((cap + 63) / 64), dim3(64), 0, ctx->stream, a);
+    hipLaunchKernelGGL(keyframe_place_kernel, dim3((cap + 63) / 64), dim3(64), 0, ctx->stream, a, what);
     SVO_HIP(hipGetLastError());
     return SVO_OK;
 }
@@ -485,8 +501,15 @@ int svo_launch_compact_batch(svo_ctx *ctx, int n_jobs, const svo_compact_job *jo
     for (int k = 0; k < n_jobs; k++)
         cap_max = jobs[k].cap > cap_max ? jobs[k].cap : cap_max;
     const int seg = ((cap_max + 15) / 16 + 63) / 64 * 64;  // 16 segments, whole 64-element strips
-    hipLaunchKernelGGL(compact_kernel, dim3(seg > 0 ? (cap_max + seg - 1) / seg : 1, n_jobs), dim3(64), 0, ctx->stream,
-                       batch, seg > 0 ? seg : 64);
+    if (n_jobs == 1) {
+        CompactBatchN<1> one;
+        one.j[0] = batch.j[0];
+        hipLaunchKernelGGL(compact_kernel<1>, dim3(seg > 0 ? (cap_max + seg - 1) / seg : 1, n_jobs), dim3(64), 0, ctx->stream,
+                           one, seg > 0 ? seg : 64);
+    } else {
+        hipLaunchKernelGGL(compact_kernel<SVO_LK_MAX_JOBS>, dim3(seg > 0 ? (cap_max + seg - 1) / seg : 1, n_jobs), dim3(64), 0,
+                           ctx->stream, batch, seg > 0 ? seg : 64);
+    }
     SVO_HIP(hipGetLastError());
     return SVO_OK;
 }

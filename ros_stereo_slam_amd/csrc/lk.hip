@@ -500,8 +500,8 @@ __device__ __forceinline__ void lane_mismatch(const uint8_t *lds, int off, int w
 // One launch may carry the LK passes of several independent chunks of the stream (blockIdx.y picks
 // the job): the launch lasts as long as the slowest keypoint of ANY job, so two jobs cost little
 // more than one (svo_vo_run_chunks, chunks that share a context).
-template <int C>
-__global__ __launch_bounds__(64 * WAVES, 4) void lk_track_kernel(LkBatch batch, LkParams prm)
+template <int C, int NJ>
+__global__ __launch_bounds__(64 * WAVES, 4) void lk_track_kernel(LkBatchN<NJ> batch, LkParams prm)
 {
     const LkJob &job = batch.j[blockIdx.y];
     if (job.gate && *job.gate == 0)
@@ -832,6 +832,8 @@ int svo_launch_lk_batch(svo_ctx *ctx, int n_jobs, const LkJob *jobs, const svo_p
         batch.j[k] = jobs[0];
     if (n_max == 0)
         return SVO_OK;
+    LkBatchN<1> one;
+    one.j[0] = jobs[0];
     LkParams prm;
     prm.max_level = levels - 1;
     prm.max_count = 30;
@@ -846,16 +848,22 @@ int svo_launch_lk_batch(svo_ctx *ctx, int n_jobs, const LkJob *jobs, const svo_p
     prm.interleave = n_jobs == 1 ? lone_interleave : 0;
     dim3 grid(((n_max + 7) / 8 + WAVES - 1) / WAVES * 8, n_jobs), block(64 * WAVES);  // x: a multiple of 8, every XCD band has all its slots
     ScopedKernelTime t(ctx, SVO_K_LK);
-    switch (c) {
-    case 1:
-        hipLaunchKernelGGL(lk_track_kernel<1>, grid, block, WAVES * Lds<1>::WAVE_BYTES, ctx->stream, batch, prm);
-        break;
-    case 3:
-        hipLaunchKernelGGL(lk_track_kernel<3>, grid, block, WAVES * Lds<3>::WAVE_BYTES, ctx->stream, batch, prm);
-        break;
-    default:
+    if (c != 1 && c != 3) {
         svo_set_error("lk: unsupported channel count %d (1 or 3)", c);
         return SVO_ERR_ARG;
+    }
+    if (n_jobs == 1) {
+        if (c == 1)
+            hipLaunchKernelGGL((lk_track_kernel<1, 1>), grid, block, WAVES * Lds<1>::WAVE_BYTES, ctx->stream, one, prm);
+        else
+            hipLaunchKernelGGL((lk_track_kernel<3, 1>), grid, block, WAVES * Lds<3>::WAVE_BYTES, ctx->stream, one, prm);
+    } else {
+        if (c == 1)
+            hipLaunchKernelGGL((lk_track_kernel<1, SVO_LK_MAX_JOBS>), grid, block, WAVES * Lds<1>::WAVE_BYTES, ctx->stream,
+                               batch, prm);
+        else
+            hipLaunchKernelGGL((lk_track_kernel<3, SVO_LK_MAX_JOBS>), grid, block, WAVES * Lds<3>::WAVE_BYTES, ctx->stream,
+                               batch, prm);
     }
     SVO_HIP(hipGetLastError());
     return SVO_OK;

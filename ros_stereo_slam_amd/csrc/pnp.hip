@@ -58,9 +58,10 @@ struct PnpJob {
     const int *cnt_trk;
     unsigned *ticket;  // "last wave of a phase" counter (self-resetting)
 };
-struct PnpBatch {
-    PnpJob j[SVO_LK_MAX_JOBS];
+template <int NJ> struct PnpBatchN {  // NJ = 1: a chunk on its own (a sixteenth of the kernel arguments per launch)
+    PnpJob j[NJ];
 };
+using PnpBatch = PnpBatchN<SVO_LK_MAX_JOBS>;
 static_assert(sizeof(PnpBatch) + 16 <= 4096, "kernel arguments are limited to 4 KB");
 
 // ---- small dense helpers (registers, static indexing) --------------------------------------
@@ -797,7 +798,7 @@ constexpr int PNP_PHASE_A = 32;
 // LEAN (several jobs per launch, beside tracking launches): 128 VGPRs, four waves per SIMD, 172 spilled registers -- the
 // launch is wide enough to hide them.  !LEAN (one job: a chunk on its own, where the launch is a chain of ONE wave's
 // latency and every scratch access is on it): the whole register file, nothing spilled.  Same arithmetic either way.
-template <bool LEAN> __global__ __launch_bounds__(64, LEAN ? 4 : 1) void pnp_solve_kernel(PnpBatch batch, int it0, int it1_cap)
+template <bool LEAN> __global__ __launch_bounds__(64, LEAN ? 4 : 1) void pnp_solve_kernel(PnpBatchN<LEAN ? SVO_LK_MAX_JOBS : 1> batch, int it0, int it1_cap)
 {
     svo_chain_priority();
     const PnpJob &job = batch.j[blockIdx.y];
@@ -1344,11 +1345,12 @@ __device__ void publish_record(const PnpJob &job, const PnpResult &r, PnpResult 
 // of another context -- the lock-step groups; a lone chunk has the chip to itself between its tracking
 // launches and takes the 128-VGPR build without spills (45 us faster alone).
 // mode (chain runner, one chunk per GPU): PNP_FINISH_ALL does everything; PNP_FINISH_DECIDE stops after the frame's
-// policy, the inlier list and the hand-over when the frame is NO keyframe -- what the next frame's filters wait for --
-// and leaves the refinement to a PNP_FINISH_REFINE launch that runs beside them (a keyframe is refined at once: its
-// stereo path needs the pose).
-enum { PNP_FINISH_ALL = 0, PNP_FINISH_DECIDE = 1, PNP_FINISH_REFINE = 2 };
-template <bool LEAN> __global__ __launch_bounds__(256, LEAN ? 5 : 4) void pnp_finish_kernel(PnpBatch batch, int mode)
+// policy, the inlier list and the hand-over -- what the next frame's tracking pass and filters wait for -- and leaves
+// the refinement to a later launch on another stream: PNP_FINISH_REFINE_KF runs only for a keyframe (the placement of
+// its cloud waits for that pose, nothing else does), PNP_FINISH_REFINE_PLAIN only for any other frame (nothing in the
+// next frame waits for it).
+enum { PNP_FINISH_ALL = 0, PNP_FINISH_DECIDE = 1, PNP_FINISH_REFINE_KF = 2, PNP_FINISH_REFINE_PLAIN = 3 };
+template <bool LEAN> __global__ __launch_bounds__(256, LEAN ? 5 : 4) void pnp_finish_kernel(PnpBatchN<LEAN ? SVO_LK_MAX_JOBS : 1> batch, int mode)
 {
     svo_chain_priority();
     const PnpJob &job = batch.j[blockIdx.x];  // one workgroup per job
@@ -1370,9 +1372,10 @@ template <bool LEAN> __global__ __launch_bounds__(256, LEAN ? 5 : 4) void pnp_fi
     const int max_iters = job.max_lm_iters;
     PnpResult *__restrict__ out = job.out;
     VoChain *chain = job.chain;
-    if (mode == PNP_FINISH_REFINE) {
-        if (!chain || chain->refine_due == 0)
-            return;  // refined by the deciding launch (a keyframe), or the frame never got that far
+    const bool refine_only = mode == PNP_FINISH_REFINE_KF || mode == PNP_FINISH_REFINE_PLAIN;
+    if (refine_only) {
+        if (!chain || chain->refine_due == 0 || (chain->kf != 0) != (mode == PNP_FINISH_REFINE_KF))
+            return;  // the frame never got that far, or it is the other launch's
     } else if (chain && chain->run == 0) {
         return;  // the chain halted at an earlier frame
     }
@@ -1382,7 +1385,7 @@ template <bool LEAN> __global__ __launch_bounds__(256, LEAN ? 5 : 4) void pnp_fi
     __shared__ RansacState s_state;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = d_n ? min(*d_n, n_host) : n_host;
-    if (tid == 0 && mode != PNP_FINISH_REFINE) {
+    if (tid == 0 && !refine_only) {
         RansacState r;
         if (job.direct) {  // cv::solvePnP: every point takes part, the start is the DLT pose
             r.niters = r.next_iter = r.iters_run = 0;
@@ -1414,7 +1417,7 @@ template <bool LEAN> __global__ __launch_bounds__(256, LEAN ? 5 : 4) void pnp_fi
             }
         }
     }
-    if (tid == 0 && mode == PNP_FINISH_REFINE) {
+    if (tid == 0 && refine_only) {
         s_state = *st;  // what the deciding launch left
         s_base = *d_m;
         s_flag = 0;
@@ -1424,7 +1427,7 @@ template <bool LEAN> __global__ __launch_bounds__(256, LEAN ? 5 : 4) void pnp_fi
         return;  // halted: the host takes over at this frame
     const RansacState s = s_state;
     const bool have_model = s.best_iter >= 0 && s.best_count > 0;
-    if (mode != PNP_FINISH_REFINE) {
+    if (!refine_only) {
         double P[12];
 #pragma unroll
         for (int k = 0; k < 12; k++)
@@ -1461,9 +1464,9 @@ template <bool LEAN> __global__ __launch_bounds__(256, LEAN ? 5 : 4) void pnp_fi
         }
     }
     const int m = s_base;
-    if (tid == 0 && mode != PNP_FINISH_REFINE)
+    if (tid == 0 && !refine_only)
         *d_m = m;
-    if (chain && mode != PNP_FINISH_REFINE) {
+    if (chain && !refine_only) {
         // The frame's policy is known: its counts go to the per-frame record; no keyframe -> the tracked sets become
         // the reference sets (src/VisualSLAM.cpp:143-146; a keyframe's sets are written by the stereo path that
         // follows).  The refinement below reads the tracked sets and the inlier list, not the reference sets.
@@ -1491,10 +1494,10 @@ template <bool LEAN> __global__ __launch_bounds__(256, LEAN ? 5 : 4) void pnp_fi
                     chain->halt_code = SVO_HALT_FEW_REF;
                 }
             }
-            chain->refine_due = (mode == PNP_FINISH_DECIDE && kf == 0) ? 1 : 0;
+            chain->refine_due = mode == PNP_FINISH_DECIDE ? 1 : 0;
         }
-        if (mode == PNP_FINISH_DECIDE && kf == 0)
-            return;  // PNP_FINISH_REFINE finishes the frame beside the next frame's filters
+        if (mode == PNP_FINISH_DECIDE)
+            return;  // a refining launch finishes the frame beside what follows
     }
     if (!have_model || m <= 0) {
         if (tid == 0) {
@@ -1712,6 +1715,8 @@ int svo_launch_pnp_ransac_batch(svo_ctx *ctx, int n_jobs, const svo_pnp_job *job
     const int nb = pnp_fill_batch(ctx, n_jobs, jobs, batch, &it_max);
     if (nb <= 0)
         return nb;
+    PnpBatchN<1> one;
+    one.j[0] = batch.j[0];
     ScopedKernelTime tm(ctx, SVO_K_PNP);
     // single-wave workgroups: they get wave slots beside a tracking launch as soon as one frees
     const int bounds[3] = {0, it_max < PNP_PHASE_A ? it_max : PNP_PHASE_A, it_max};
@@ -1722,13 +1727,13 @@ int svo_launch_pnp_ransac_batch(svo_ctx *ctx, int n_jobs, const svo_pnp_job *job
                                    batch, bounds[ph], bounds[ph + 1]);
             else
                 hipLaunchKernelGGL(pnp_solve_kernel<false>, dim3(bounds[ph + 1] - bounds[ph], nb), dim3(64), 0, ctx->stream,
-                                   batch, bounds[ph], bounds[ph + 1]);
+                                   one, bounds[ph], bounds[ph + 1]);
         }
     const int mode = split ? PNP_FINISH_DECIDE : PNP_FINISH_ALL;
     if (nb > 1)
         hipLaunchKernelGGL(pnp_finish_kernel<true>, dim3(nb), dim3(256), 0, ctx->stream, batch, mode);
     else
-        hipLaunchKernelGGL(pnp_finish_kernel<false>, dim3(nb), dim3(256), 0, ctx->stream, batch, mode);
+        hipLaunchKernelGGL(pnp_finish_kernel<false>, dim3(nb), dim3(256), 0, ctx->stream, one, mode);
     SVO_HIP(hipGetLastError());
     return SVO_OK;
 }
@@ -1738,8 +1743,9 @@ int svo_launch_pnp_ransac_batch(svo_ctx *ctx, int n_jobs, const svo_pnp_job *job
     return svo_launch_pnp_ransac_batch(ctx, n_jobs, jobs, false);
 }
 
-// the refinement a split launch left undone (frames that are no keyframes); same jobs, same workspace
-int svo_launch_pnp_refine(svo_ctx *ctx, int n_jobs, const svo_pnp_job *jobs)
+// the refinement a split launch left undone; same jobs, same workspace.  keyframes: refine only the frames that turned
+// out to be keyframes / only those that did not (the two go to different places in the caller's streams)
+int svo_launch_pnp_refine(svo_ctx *ctx, int n_jobs, const svo_pnp_job *jobs, bool keyframes)
 {
     if (n_jobs <= 0)
         return SVO_OK;
@@ -1749,10 +1755,14 @@ int svo_launch_pnp_refine(svo_ctx *ctx, int n_jobs, const svo_pnp_job *jobs)
     if (nb <= 0)
         return nb;
     ScopedKernelTime tm(ctx, SVO_K_PNP);
+    const int mode = keyframes ? PNP_FINISH_REFINE_KF : PNP_FINISH_REFINE_PLAIN;
     if (nb > 1)
-        hipLaunchKernelGGL(pnp_finish_kernel<true>, dim3(nb), dim3(256), 0, ctx->stream, batch, (int)PNP_FINISH_REFINE);
-    else
-        hipLaunchKernelGGL(pnp_finish_kernel<false>, dim3(nb), dim3(256), 0, ctx->stream, batch, (int)PNP_FINISH_REFINE);
+        hipLaunchKernelGGL(pnp_finish_kernel<true>, dim3(nb), dim3(256), 0, ctx->stream, batch, mode);
+    else {
+        PnpBatchN<1> one;
+        one.j[0] = batch.j[0];
+        hipLaunchKernelGGL(pnp_finish_kernel<false>, dim3(nb), dim3(256), 0, ctx->stream, one, mode);
+    }
     SVO_HIP(hipGetLastError());
     return SVO_OK;
 }
@@ -1800,7 +1810,7 @@ int svo_launch_solve_pnp(svo_ctx *ctx, const float *obj, const float *img, int c
     d.K = {K4h[0], K4h[1], K4h[2], K4h[3]};
     d.hyp = ctx->w_c.as<double>();
     d.status = ib + 12;
-    PnpBatch batch;
+    PnpBatchN<1> batch;
     PnpJob &j = batch.j[0];
     j.obj = obj;
     j.img = img;
@@ -1824,8 +1834,6 @@ int svo_launch_solve_pnp(svo_ctx *ctx, const float *obj, const float *img, int c
     j.dlt_status = d.status;
     j.chain = nullptr;
     j.cnt_trk = nullptr;
-    for (int k = 1; k < SVO_LK_MAX_JOBS; k++)
-        batch.j[k] = batch.j[0];
     ScopedKernelTime tm(ctx, SVO_K_PNP);
     hipLaunchKernelGGL(pnp_dlt_kernel, dim3(1), dim3(256), 0, ctx->stream, d);
     hipLaunchKernelGGL(pnp_finish_kernel<false>, dim3(1), dim3(256), 0, ctx->stream, batch, (int)PNP_FINISH_ALL);

@@ -47,15 +47,39 @@ constexpr int ROWS_PER_BLOCK = 8;
 constexpr int PYR_JOBS = 2 * SVO_LK_MAX_JOBS;
 
 // everything the four launches need, by value (2.4 KB of the 4 KB kernel-argument space)
-struct PyrBuild {
-    const uint8_t *img[PYR_JOBS];                 // raw images, row stride w[0] * C
-    uint8_t *lvl[PYR_JOBS][SVO_MAX_LEVELS];       // pixel (0, 0) of the padded levels
-    int *dlvl[PYR_JOBS];                          // derivative levels (svo_pyramid::dbase) or null
-    const int *gate[PYR_JOBS];                    // optional: the pyramid is left untouched when *gate == 0 (chain runner)
-    int doff[SVO_MAX_LEVELS];                     // element (0, 0) of each derivative level, in ints
+// NJ: PYR_JOBS for the lock-step groups; 2 for a chunk on its own (its left and right image): a sixteenth of the kernel
+// arguments per launch
+template <int NJ> struct PyrBuildN {
+    const uint8_t *img[NJ];                 // raw images, row stride w[0] * C
+    uint8_t *lvl[NJ][SVO_MAX_LEVELS];       // pixel (0, 0) of the padded levels
+    int *dlvl[NJ];                          // derivative levels (svo_pyramid::dbase) or null
+    const int *gate[NJ];                    // optional: the pyramid is left untouched when *gate == 0 (chain runner)
+    int doff[SVO_MAX_LEVELS];               // element (0, 0) of each derivative level, in ints
     int pitch[SVO_MAX_LEVELS], dpitch[SVO_MAX_LEVELS], w[SVO_MAX_LEVELS], h[SVO_MAX_LEVELS];
     int levels;
 };
+using PyrBuild = PyrBuildN<PYR_JOBS>;
+constexpr int PYR_FEW = 2;
+inline PyrBuildN<PYR_FEW> pyr_few(const PyrBuild &b)
+{
+    PyrBuildN<PYR_FEW> f;
+    for (int a = 0; a < PYR_FEW; a++) {
+        f.img[a] = b.img[a];
+        for (int l = 0; l < SVO_MAX_LEVELS; l++)
+            f.lvl[a][l] = b.lvl[a][l];
+        f.dlvl[a] = b.dlvl[a];
+        f.gate[a] = b.gate[a];
+    }
+    for (int l = 0; l < SVO_MAX_LEVELS; l++) {
+        f.doff[l] = b.doff[l];
+        f.pitch[l] = b.pitch[l];
+        f.dpitch[l] = b.dpitch[l];
+        f.w[l] = b.w[l];
+        f.h[l] = b.h[l];
+    }
+    f.levels = b.levels;
+    return f;
+}
 static_assert(sizeof(PyrBuild) <= 3072, "kernel arguments are limited to 4 KB");
 
 // One 32x8 output tile of level l from level l-1 (RAW = false: the padded level; RAW = true: the raw
@@ -203,7 +227,7 @@ __device__ __forceinline__ void pad_copy_row(const uint8_t *__restrict__ src, ui
 }
 
 // launch 1: workgroups [0, n_tiles) build level 1 from the raw image, the rest the padded level 0
-template <int C> __global__ __launch_bounds__(PB) void pyr_base_kernel(PyrBuild b, int tiles_x, int n_tiles, int pad_x)
+template <int C, int NJ> __global__ __launch_bounds__(PB) void pyr_base_kernel(PyrBuildN<NJ> b, int tiles_x, int n_tiles, int pad_x)
 {
     svo_chain_priority();
     const int job = blockIdx.y;
@@ -225,7 +249,7 @@ template <int C> __global__ __launch_bounds__(PB) void pyr_base_kernel(PyrBuild 
 }
 
 // launches 2 and 3: level l from level l - 1
-template <int C> __global__ __launch_bounds__(PB) void pyr_down_kernel(PyrBuild b, int l)
+template <int C, int NJ> __global__ __launch_bounds__(PB) void pyr_down_kernel(PyrBuildN<NJ> b, int l)
 {
     svo_chain_priority();
     if (b.gate[blockIdx.z] && *b.gate[blockIdx.z] == 0)
@@ -356,7 +380,7 @@ struct FinishPlan {
     int border_y0[SVO_MAX_LEVELS + 1];  // first blockIdx.y of level l's border role (l >= 1); [levels] = end
     int scharr_y0[SVO_MAX_LEVELS + 1];  // first blockIdx.y of level l's Scharr role; [levels] = end
 };
-template <int C> __global__ __launch_bounds__(PB) void pyr_finish_kernel(PyrBuild b, FinishPlan plan)
+template <int C, int NJ> __global__ __launch_bounds__(PB) void pyr_finish_kernel(PyrBuildN<NJ> b, FinishPlan plan)
 {
     svo_chain_priority();
     const int job = blockIdx.z, by = blockIdx.y;
@@ -450,7 +474,10 @@ template <int C> static int launch_finish(svo_ctx *ctx, int k, const PyrBuild &b
     plan.scharr_y0[b.levels] = y;
     if (y == 0)
         return SVO_OK;
-    hipLaunchKernelGGL(pyr_finish_kernel<C>, dim3(xmax, y, k), dim3(PB), 0, ctx->stream, b, plan);
+    if (k <= PYR_FEW)
+        hipLaunchKernelGGL((pyr_finish_kernel<C, PYR_FEW>), dim3(xmax, y, k), dim3(PB), 0, ctx->stream, pyr_few(b), plan);
+    else
+        hipLaunchKernelGGL((pyr_finish_kernel<C, PYR_JOBS>), dim3(xmax, y, k), dim3(PB), 0, ctx->stream, b, plan);
     SVO_HIP(hipGetLastError());
     return SVO_OK;
 }
@@ -488,12 +515,21 @@ static int build_levels(svo_ctx *ctx, int k, svo_pyramid *const *pyrs, const uin
         const int n_tiles = tiles_x * tiles_y;
         const int pad_x = ((b.pitch[0] >> 2) + PB - 1) / PB,
                   pad_y = (b.h[0] + 2 * SVO_PYR_PAD + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
-        hipLaunchKernelGGL(pyr_base_kernel<C>, dim3(n_tiles + pad_x * pad_y, k), dim3(PB), 0, ctx->stream, b,
-                           tiles_x > 0 ? tiles_x : 1, n_tiles, pad_x);
+        if (k <= PYR_FEW)
+            hipLaunchKernelGGL((pyr_base_kernel<C, PYR_FEW>), dim3(n_tiles + pad_x * pad_y, k), dim3(PB), 0, ctx->stream,
+                               pyr_few(b), tiles_x > 0 ? tiles_x : 1, n_tiles, pad_x);
+        else
+            hipLaunchKernelGGL((pyr_base_kernel<C, PYR_JOBS>), dim3(n_tiles + pad_x * pad_y, k), dim3(PB), 0, ctx->stream, b,
+                               tiles_x > 0 ? tiles_x : 1, n_tiles, pad_x);
     }
-    for (int l = 2; l < b.levels; l++)
-        hipLaunchKernelGGL(pyr_down_kernel<C>, dim3((b.w[l] + TW - 1) / TW, (b.h[l] + TH - 1) / TH, k), dim3(PB), 0,
-                           ctx->stream, b, l);
+    for (int l = 2; l < b.levels; l++) {
+        if (k <= PYR_FEW)
+            hipLaunchKernelGGL((pyr_down_kernel<C, PYR_FEW>), dim3((b.w[l] + TW - 1) / TW, (b.h[l] + TH - 1) / TH, k),
+                               dim3(PB), 0, ctx->stream, pyr_few(b), l);
+        else
+            hipLaunchKernelGGL((pyr_down_kernel<C, PYR_JOBS>), dim3((b.w[l] + TW - 1) / TW, (b.h[l] + TH - 1) / TH, k),
+                               dim3(PB), 0, ctx->stream, b, l);
+    }
     SVO_HIP(hipGetLastError());
     int rc = SVO_OK;
     if constexpr (C == 1 || C == 3)

@@ -171,9 +171,12 @@ struct LkJob {  // one pyramidal-LK pass: prev/next pyramids, points in, points 
     float *err, *min_eig;  // optional
     const int *gate = nullptr;  // optional: the job's workgroups leave at once when *gate == 0 (VoChain::run / ::kf)
 };
-struct LkBatch {
-    LkJob j[SVO_LK_MAX_JOBS];
+// NJ: SVO_LK_MAX_JOBS for the lock-step groups, 1 for a chunk on its own -- a launch of one job carries a sixteenth of the
+// kernel arguments (the runtime stalls the launching thread for tens of microseconds per few hundred KB of them)
+template <int NJ> struct LkBatchN {
+    LkJob j[NJ];
 };
+using LkBatch = LkBatchN<SVO_LK_MAX_JOBS>;
 // `geom`: any pyramid with the geometry of the jobs' prev pyramids (derivative level offsets / pitches)
 int svo_launch_lk_batch(svo_ctx *ctx, int n_jobs, const LkJob *jobs, const svo_pyramid *geom);
 int svo_launch_lk(svo_ctx *ctx, svo_pyramid *prev, const svo_pyramid *next, const float *prev_pts,
@@ -234,9 +237,11 @@ struct svo_tri_job {  // one stereo DLT triangulation (device pointers; Rt: host
 };
 int svo_launch_triangulate_batch(svo_ctx *ctx, const double *P1, const double *P2, int k, const svo_tri_job *jobs);
 // a keyframe whose camera-frame points were triangulated ahead of the decision: the chain-mode tail of the triangulation
-// launch alone (runs only when chain->kf is set; [R|t] from the chain state)
+// launch alone (runs only when chain->kf is set; [R|t] from the chain state).  what: 1 = the pose-free part (set size,
+// 2-D set, colours), 2 = the clouds (camera frame, and placed with the pose), 3 = both
 int svo_launch_keyframe_place(svo_ctx *ctx, VoChain *chain, const float *x1, const float *xyz, int cap, const int *d_n,
-                              float *out_x1, float *out_cam, float *out_world, const svo_pyramid *color_src, float *color_out);
+                              float *out_x1, float *out_cam, float *out_world, const svo_pyramid *color_src, float *color_out,
+                              int what);
 int svo_launch_transform(svo_ctx *ctx, const double *Rt, const float *in, int cap, const int *d_n, float *out);
 int svo_launch_colors(svo_ctx *ctx, const svo_pyramid *pyr, const float *xy, int cap, const int *d_n, float *out);
 int svo_launch_compact_batch(svo_ctx *ctx, int n_jobs, const svo_compact_job *jobs);
@@ -272,10 +277,11 @@ struct svo_pnp_job {  // host-side description of one PnP-RANSAC problem (device
     VoChain *chain = nullptr;
     const int *cnt_trk;
 };
-// split: the finishing launch is queued as PNP_FINISH_DECIDE, the refinement of a frame that is no keyframe is left to
-// svo_launch_pnp_refine (chain jobs only; the caller queues it where it runs beside the next frame's filters)
+// split: the finishing launch is queued as PNP_FINISH_DECIDE, the refinement is left to svo_launch_pnp_refine (chain
+// jobs only; the caller queues it on another stream: once for keyframes, before their cloud is placed, once for the
+// other frames, beside whatever follows)
 int svo_launch_pnp_ransac_batch(svo_ctx *ctx, int n_jobs, const svo_pnp_job *jobs, bool split);
-int svo_launch_pnp_refine(svo_ctx *ctx, int n_jobs, const svo_pnp_job *jobs);
+int svo_launch_pnp_refine(svo_ctx *ctx, int n_jobs, const svo_pnp_job *jobs, bool keyframes);
 int svo_launch_pnp_ransac_batch(svo_ctx *ctx, int n_jobs, const svo_pnp_job *jobs);
 int svo_launch_pnp_ransac(svo_ctx *ctx, const float *obj, const float *img, int cap, const int *d_n,
                           const double *K4h, int iterations, double reproj_err, double confidence, uint64_t seed,

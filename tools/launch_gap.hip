@@ -111,6 +111,32 @@ int main()
         CK(hipGraphExecDestroy(ge));
         CK(hipGraphDestroy(g));
     }
+    // host-side stalls: per-launch host time, small against 4 KB arguments (how often does a launch take > 20 us?)
+    for (int variant = 0; variant < 2; variant++) {
+        CK(hipStreamSynchronize(st));
+        std::vector<double> dt(4000);
+        for (int i = 0; i < 4000; i++) {
+            const double a = now();
+            if (variant == 0)
+                hipLaunchKernelGGL(k_small, dim3(64), dim3(64), 0, st, d);
+            else
+                hipLaunchKernelGGL(k_big, dim3(64), dim3(64), 0, st, big, d);
+            dt[i] = now() - a;
+        }
+        CK(hipStreamSynchronize(st));
+        int n_long = 0, first = -1, last = -1;
+        double sum_long = 0;
+        for (int i = 0; i < 4000; i++)
+            if (dt[i] > 20e-6) {
+                n_long++;
+                sum_long += dt[i];
+                if (first < 0) first = i;
+                last = i;
+            }
+        printf("{\"case\": \"host stalls, %s arguments\", \"launches\": 4000, \"launches_over_20us\": %d, \"mean_stall_us\": %.1f, "
+               "\"mean_spacing_launches\": %.1f}\n", variant ? "3.8 KB" : "8 B", n_long, n_long ? sum_long / n_long * 1e6 : 0.,
+               n_long > 1 ? (double)(last - first) / (n_long - 1) : 0.);
+    }
     // two streams, cross-stream event dependency per launch pair (the PnP stream hand-off)
     {
         hipStream_t sb;
