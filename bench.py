@@ -316,6 +316,8 @@ def main():
                 raise SystemExit(f"bench: chunk {rank * M + m} lost tracking at local frame {a + done + 1} (rc {rc})")
             out[m].extend((Rs[i].copy(), ts[i].copy()) for i in range(done))
             if stats is not None:
+                if m == 0 and os.environ.get("SVO_BENCH_DUMP_FRAMES"):  # per-frame record of chunk 0, for offline study
+                    np.savez(os.environ["SVO_BENCH_DUMP_FRAMES"], inliers=inl, tracked=trk, keyframe=kf)
                 stats["keyframes"] += int(kf.sum())
                 stats["inliers"] += int(inl.sum())
                 stats["tracked"] += int(trk.sum())

@@ -35,27 +35,34 @@ struct svo_vo {
     svo_vo_params prm;
     int w = 0, h = 0, c = 0, cap = 0;
     svo_pyramid *pyr_ref = nullptr, *pyr_cur = nullptr, *pyr_right = nullptr, *pyr_next = nullptr, *pyr_right2 = nullptr;
-    // One chunk per GPU, pipelined (svo_vo_run_chunk, pipeline != 0): three streams.
-    //   A   the context's stream: the frame's filters, the next frame's pyramids and its tracking pass from the tracked
-    //       set, then -- once B has decided the frame -- a keyframe's pose-free hand-over and the tracking pass again
-    //       from its points
-    //   B   stream_b: PnP hypotheses, the decision, the refinement (a keyframe's first, then the placement of its cloud)
+    // One chunk per GPU, pipelined (svo_vo_run_chunk, pipeline != 0): four streams.
+    //   A   the context's stream: the frame's filters, then BOTH tracking passes frame f+1 can start from -- from the
+    //       tracked set (f is no keyframe) and from the 2-D points the stereo path of f has left (f is a keyframe) -- as one
+    //       launch; the next filters take the one the decision points to
+    //   B   stream_b: PnP hypotheses, the decision, the refinement (a keyframe's first, then the hand-over of its sets)
     //   C   lane.ctx: the whole stereo path of EVERY frame (LK left -> right, ANMS, filters, DLT triangulation in the
     //       camera frame: none of it needs the frame's pose), a frame ahead, on a context of its own (stream, scratch,
     //       tickets) with its own staging buffers
-    hipStream_t stream_b = nullptr;
+    //   D   stream_p: the pyramids, two frames ahead
+    hipStream_t stream_b = nullptr, stream_p = nullptr;
     struct StereoLane {
         svo_ctx *ctx = nullptr;
         float *a2 = nullptr, *b2 = nullptr, *c2 = nullptr, *d2 = nullptr, *x2 = nullptr, *resp = nullptr;
         uint8_t *status = nullptr, *st2 = nullptr, *mask = nullptr;
         int *idx = nullptr, *cnt = nullptr;
     } lane;
-    // what the lane hands to A and B, by frame parity: the keyframe candidate's 2-D points, camera-frame points, count
-    float *h_x1[2] = {nullptr, nullptr}, *h_xyz[2] = {nullptr, nullptr};
+    // what the lane hands to A and B, by frame % 3: the keyframe candidate's 2-D points, camera-frame points, count
+    float *h_x1[3] = {nullptr, nullptr, nullptr}, *h_xyz[3] = {nullptr, nullptr, nullptr};
     int *h_cnt = nullptr;
-    // tracked sets ready (A), decided (B), cloud placed (B), refined (B: end of a run), pyramids built (A), stereo path
-    // done (C)
-    hipEvent_t ev_flt = nullptr, ev_dec = nullptr, ev_p3 = nullptr, ev_ref = nullptr, ev_pyr = nullptr, ev_p1 = nullptr;
+    // output of the tracking pass from the keyframe candidate's points (beside a2 / status of the pass from the tracked set)
+    float *a2k = nullptr;
+    // status bytes of both passes by frame parity: the PnP stream reads a frame's while A's next launch writes the next frame's
+    uint8_t *statusk = nullptr, *status_b = nullptr, *statusk_b = nullptr;
+    // tracked sets ready (A), tracking launch ended (A), cloud placed (B), refined (B: end of a run); by frame & 3: pyramids
+    // built (D), stereo path done (C)
+    hipEvent_t ev_flt = nullptr, ev_lk = nullptr, ev_dec = nullptr, ev_ref = nullptr;
+    hipEvent_t ev_pyr[4] = {nullptr, nullptr, nullptr, nullptr}, ev_p1[4] = {nullptr, nullptr, nullptr, nullptr},
+               ev_p3[4] = {nullptr, nullptr, nullptr, nullptr};
     bool pipe_ready = false;
     // second set of tracked points / inlier list: frame t's refinement reads its set while frame t+1's filters write theirs
     float *trk2d_b = nullptr, *trk3d_b = nullptr;
@@ -104,6 +111,9 @@ int grid_axis(int dim, int step)
 uint64_t stage_seed(const svo_vo *v, int stage) { return v->prm.seed + 8ull * (uint64_t)v->frame + stage; }
 
 __global__ void store_count_kernel(const int *__restrict__ src, int *__restrict__ dst) { *dst = *src; }
+
+// debug (SVO_CHAIN_STAMPS): the constant 100 MHz clock, written by a one-lane launch between the stages of a stream
+__global__ void stamp_kernel(unsigned long long *dst) { *dst = wall_clock64(); }
 
 const uint8_t *stage_image(svo_vo *v, const uint8_t *img, int mem, int *rc)
 {
@@ -459,11 +469,13 @@ int svo_vo_destroy(svo_vo *v)
     svo_pyramid_destroy(v->ctx, v->pyr_right);
     svo_pyramid_destroy(v->ctx, v->pyr_next);
     svo_pyramid_destroy(v->ctx, v->pyr_right2);
-    if (v->stream_b) {
-        (void)hipStreamSynchronize(v->stream_b);
-        (void)hipStreamDestroy(v->stream_b);
-    }
-    for (hipEvent_t e : {v->ev_flt, v->ev_dec, v->ev_p3, v->ev_ref, v->ev_pyr, v->ev_p1})
+    for (hipStream_t st : {v->stream_b, v->stream_p})
+        if (st) {
+            (void)hipStreamSynchronize(st);
+            (void)hipStreamDestroy(st);
+        }
+    for (hipEvent_t e : {v->ev_flt, v->ev_lk, v->ev_dec, v->ev_ref, v->ev_pyr[0], v->ev_pyr[1], v->ev_pyr[2], v->ev_pyr[3], v->ev_p1[0],
+                         v->ev_p1[1], v->ev_p1[2], v->ev_p1[3], v->ev_p3[0], v->ev_p3[1], v->ev_p3[2], v->ev_p3[3]})
         if (e)
             (void)hipEventDestroy(e);
     {
@@ -474,7 +486,7 @@ int svo_vo_destroy(svo_vo *v)
         }
         void *sb[] = {L.a2,        L.b2,        L.c2,        L.d2,         L.x2,         L.resp,   L.status,   L.st2,      L.mask,
                       L.idx,       L.cnt,       v->h_x1[0],  v->h_x1[1],   v->h_xyz[0],  v->h_xyz[1], v->h_cnt, v->trk2d_b, v->trk3d_b,
-                      v->idx_b};
+                      v->idx_b,    v->a2k,      v->statusk,  v->h_x1[2],   v->h_xyz[2], v->status_b, v->statusk_b};
         for (void *b : sb)
             if (b)
                 (void)hipFree(b);
@@ -772,17 +784,33 @@ static int chain_lk(svo_ctx *ctx, int k, svo_vo *const *vs, svo_pyramid *const *
 
 // status filter (src/tracking.cpp:54-64), F-RANSAC at 1 px + its mask filter (:75-88): the tracked sets and their count
 // set: which of the two tracked sets / count slots the frame writes (pipelined chunks alternate)
-static int chain_filters(svo_ctx *ctx, int k, svo_vo *const *vs, int set = 0)
+// st_par: which of the two status-byte buffers the frame's tracking passes wrote (pipelined chunk).
+// kf_slot >= 0 (pipelined chunk, one front-end): the 2-D half only -- the 3-D column follows on the PnP stream,
+// chain_filters_3d -- and, when the previous frame was a keyframe (the device flag), from the sets of the tracking pass
+// that started at its points: reference points = hand-over set kf_slot, tracked points / status bytes = a2k / statusk.
+static int chain_filters(svo_ctx *ctx, int k, svo_vo *const *vs, int set = 0, int kf_slot = -1, int st_par = 0)
 {
     svo_compact_job c1[SVO_LK_MAX_JOBS], c2[SVO_LK_MAX_JOBS];
     svo_fransac_job fj[SVO_LK_MAX_JOBS];
     for (int a = 0; a < k; a++) {
         svo_vo *v = vs[a];
         const int *run = &v->d_chain->run;
-        c1[a] = {v->status, v->cap, &v->d_chain->nref, {v->ref2d, v->a2, v->ref3d}, {v->b2, v->c2, v->a3}, {2, 2, 3},
-                 v->d_cnt, run};
-        c2[a] = {v->mask, v->cap, v->d_cnt, {v->c2, v->a3, nullptr},
-                 {set ? v->trk2d_b : v->trk2d, set ? v->trk3d_b : v->trk3d, nullptr}, {2, 3, 0}, v->d_cnt + (set ? 9 : 1)};
+        if (kf_slot >= 0) {
+            c1[a] = {st_par ? v->status_b : v->status, v->cap, &v->d_chain->nref, {v->ref2d, v->a2, nullptr},
+                     {v->b2, v->c2, nullptr}, {2, 2, 0}, v->d_cnt, run};
+            c1[a].alt_sel = &v->d_chain->kf;
+            c1[a].alt_mask = st_par ? v->statusk_b : v->statusk;
+            c1[a].alt_in[0] = v->h_x1[kf_slot];
+            c1[a].alt_in[1] = v->a2k;
+            c1[a].alt_d_n = v->h_cnt + kf_slot;
+            c2[a] = {v->mask, v->cap, v->d_cnt, {v->c2, nullptr, nullptr}, {set ? v->trk2d_b : v->trk2d, nullptr, nullptr},
+                     {2, 0, 0}, v->d_cnt + (set ? 9 : 1)};
+        } else {
+            c1[a] = {v->status, v->cap, &v->d_chain->nref, {v->ref2d, v->a2, v->ref3d}, {v->b2, v->c2, v->a3}, {2, 2, 3},
+                     v->d_cnt, run};
+            c2[a] = {v->mask, v->cap, v->d_cnt, {v->c2, v->a3, nullptr},
+                     {set ? v->trk2d_b : v->trk2d, set ? v->trk3d_b : v->trk3d, nullptr}, {2, 3, 0}, v->d_cnt + (set ? 9 : 1)};
+        }
         svo_fransac_job &q = fj[a];
         q.p1 = v->b2;
         q.p2 = v->c2;
@@ -801,6 +829,25 @@ static int chain_filters(svo_ctx *ctx, int k, svo_vo *const *vs, int set = 0)
     }
     int rc;
     if ((rc = svo_launch_compact_batch(ctx, k, c1)) || (rc = svo_launch_fransac_batch(ctx, k, fj)))
+        return rc;
+    return SVO_OK;
+}
+
+// The 3-D column of the two filters above, for a pipelined chunk, on the PnP stream once the frame's status bytes and
+// F-RANSAC mask exist: reference points (by then the keyframe's cloud has been placed, if the previous frame was one)
+// -> status filter -> mask filter -> the tracked 3-D set the PnP reads.
+static int chain_filters_3d(svo_ctx *ctx, svo_vo *v, int set, int st_par)
+{
+    const int *run = &v->d_chain->run;
+    svo_compact_job c[2];
+    c[0] = {st_par ? v->status_b : v->status, v->cap, &v->d_chain->nref, {v->ref3d, nullptr, nullptr}, {v->a3, nullptr, nullptr},
+            {3, 0, 0}, v->d_cnt + 10, run};
+    c[0].alt_sel = &v->d_chain->kf;  // still the previous frame's decision
+    c[0].alt_mask = st_par ? v->statusk_b : v->statusk;
+    c[1] = {v->mask, v->cap, v->d_cnt + 10, {v->a3, nullptr, nullptr}, {set ? v->trk3d_b : v->trk3d, nullptr, nullptr},
+            {3, 0, 0}, v->d_cnt + 11, run};
+    int rc;
+    if ((rc = svo_launch_compact_batch(ctx, 1, &c[0])) || (rc = svo_launch_compact_batch(ctx, 1, &c[1])))
         return rc;
     return SVO_OK;
 }
@@ -864,13 +911,15 @@ static int chain_enqueue(ChainRun *const *runs, int k, bool pipeline)
         return svo_build_pyramids_from_device(ctx, 2 * na, pyrs, imgs, g);
     };
     if (pipeline) {
-        // Three streams (see svo_vo).  A: the frame's filters, the next frame's pyramids and its tracking pass from the
-        // tracked set -- what frame f+1 uses unless f turns out to be a keyframe --, then, once B has decided the frame,
-        // a keyframe's pose-free hand-over and the tracking pass again from its points (both leave at once otherwise).
-        // B: PnP hypotheses and the decision (A goes on from here), then the refinement: a keyframe's first, and the
-        // placement of its cloud with that pose, which A waits for only before the next filters read the 3-D set (the
-        // second tracking pass runs beside it); any other frame's after that, beside the next frame's filters.
-        // C: the stereo path of EVERY frame, a frame ahead.
+        // Four streams (see svo_vo).  Nothing on A waits for the frame's decision: after the filters of frame f it runs
+        // BOTH tracking passes into frame f+1 -- from the tracked set and from the 2-D points the stereo path of f has
+        // left -- as one launch (the launch lasts as long as its slowest keypoint: two passes cost less than two
+        // launches), and the filters of f+1 take the status bytes and points of the one the decision points to (the
+        // compaction selects by the keyframe flag on the device).  B: PnP hypotheses, the decision, then a keyframe's
+        // refinement and the hand-over of its sets (the 2-D points become the reference set, the cloud is placed with
+        // the refined pose), which A waits for before the next filters; any other frame's refinement after that.
+        // C: the stereo path of EVERY frame, two frames ahead, started when A's tracking launch has ended (its own
+        // tracking pass then runs beside A's filters instead of beside A's launch).  D: the pyramids, two frames ahead.
         static const bool dbg = getenv("SVO_CHAIN_DEBUG") != nullptr;
         double us_cat[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // host time by category (debug): see the print below
         auto tick = [&]() { return dbg ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point(); };
@@ -880,10 +929,21 @@ static int chain_enqueue(ChainRun *const *runs, int k, bool pipeline)
         };
         ChainRun &r = *runs[0];
         svo_vo *v = r.v;
-        hipStream_t sA = ctx->stream, sB = v->stream_b, sC = v->lane.ctx->stream;
+        hipStream_t sA = ctx->stream, sB = v->stream_b, sC = v->lane.ctx->stream, sD = v->stream_p;
+        // debug: device time stamps between the stages (8 per frame: A0 before filters, A1 after, A2 after the tracking
+        // launch, B0 before hypotheses, B1 decided, B2 handed over, C0 / C1 around the stereo path)
+        static const bool stamps = getenv("SVO_CHAIN_STAMPS") != nullptr;
+        static unsigned long long *d_stamps = nullptr;
+        const int max_stamp_frames = 4096;
+        if (stamps && !d_stamps)
+            SVO_HIP(hipMalloc(reinterpret_cast<void **>(&d_stamps), sizeof(unsigned long long) * 8 * max_stamp_frames));
+        auto stamp = [&](hipStream_t st, int frame, int slot) {
+            if (stamps && frame < max_stamp_frames)
+                hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, st, d_stamps + 8 * frame + slot);
+        };
         svo_pyramid *ref = v->pyr_ref, *cur = v->pyr_cur, *nxt = v->pyr_next;
         svo_pyramid *right[2] = {v->pyr_right, v->pyr_right2};
-        const int *run = &v->d_chain->run, *kf = &v->d_chain->kf;
+        const int *run = &v->d_chain->run;
         vs[0] = v;
         const int frame0 = v->frame, nf = r.n_frames;
         struct OnStream {  // the launch helpers take the stream from the context
@@ -892,88 +952,133 @@ static int chain_enqueue(ChainRun *const *runs, int k, bool pipeline)
             OnStream(svo_ctx *cc, hipStream_t st) : c(cc), keep(cc->stream) { c->stream = st; }
             ~OnStream() { c->stream = keep; }
         };
-        // prologue: the pyramids of frame 0, its tracking pass, the stereo path of frame 0
-        {
-            const uint8_t *li = r.lefts[0], *ri = r.rights[0];
-            if ((rc = build(1, vs, &cur, &right[0], &li, &ri, r.mem)))
+        // pyramids of frame g of the run on D (the left one into `left`)
+        auto pyramids = [&](int g, svo_pyramid *left) -> int {
+            const uint8_t *li = r.lefts[g], *ri = r.rights[g];
+            svo_pyramid *rp = right[g & 1];
+            OnStream on(ctx, sD);
+            if ((rc = build(1, vs, &left, &rp, &li, &ri, r.mem)))
                 return rc;
-            SVO_HIP(hipEventRecord(v->ev_pyr, sA));
+            SVO_HIP(hipEventRecord(v->ev_pyr[g & 3], sD));
+            return SVO_OK;
+        };
+        // the stereo path of frame g on C, from the pyramids D has built
+        auto stereo = [&](int g, svo_pyramid *left) -> int {
+            SVO_HIP(hipStreamWaitEvent(sC, v->ev_pyr[g & 3], 0));
+            if ((rc = stereo_part1_spec(v, v->lane, left, right[g & 1], frame0 + g + 1, g % 3)))
+                return rc;
+            SVO_HIP(hipEventRecord(v->ev_p1[g & 3], sC));
+            return SVO_OK;
+        };
+        // prologue: the chain state is on its way (chain_prepare, on A); the pyramids of frames 0 and 1, the tracking
+        // pass into frame 0 from the reference set, the stereo paths of frames 0 and 1
+        SVO_HIP(hipEventRecord(v->ev_flt, sA));
+        SVO_HIP(hipStreamWaitEvent(sD, v->ev_flt, 0));
+        if ((rc = pyramids(0, cur)) || (nf > 1 && (rc = pyramids(1, nxt))))
+            return rc;
+        {
+            SVO_HIP(hipStreamWaitEvent(sA, v->ev_pyr[0], 0));
             pts[0] = v->ref2d;
             dn[0] = &v->d_chain->nref;
             gates[0] = run;
             if ((rc = chain_lk(ctx, 1, vs, &ref, &cur, pts, dn, gates)))
                 return rc;
-            SVO_HIP(hipStreamWaitEvent(sC, v->ev_pyr, 0));
-            if ((rc = stereo_part1_spec(v, v->lane, cur, right[0], frame0 + 1, 0)))
+            if ((rc = stereo(0, cur)) || (nf > 1 && (rc = stereo(1, nxt))))
                 return rc;
-            SVO_HIP(hipEventRecord(v->ev_p1, sC));
         }
         for (int f = 0; f < nf; f++) {
             v->frame++;
-            const int set = f & 1;
+            const int set = f & 1, slot = f % 3;
             const bool more = f + 1 < nf;
             auto t0 = tick();
-            if ((rc = chain_filters(ctx, 1, vs, set)))
+            if (more) {  // what the tracking launch below waits for, asked for here: both have long happened
+                SVO_HIP(hipStreamWaitEvent(sA, v->ev_pyr[(f + 1) & 3], 0));
+                SVO_HIP(hipStreamWaitEvent(sA, v->ev_p1[f & 3], 0));  // the 2-D points of this frame's stereo path
+            }
+            stamp(sA, f, 0);
+            // the 2-D half of the filters; the previous frame a keyframe: from the sets of the pass that started at its points
+            if ((rc = chain_filters(ctx, 1, vs, set, (f + 2) % 3, f & 1)))
                 return rc;
+            SVO_HIP(hipEventRecord(v->ev_flt, sA));
+            stamp(sA, f, 1);
             tock(0, t0);
             t0 = tick();
-            SVO_HIP(hipEventRecord(v->ev_flt, sA));
-            tock(1, t0);
-            t0 = tick();
-            // B: hypotheses and the decision; then a keyframe is refined and its cloud placed with that pose; any other
-            // frame is refined after that.  (In order on B: the next frame's hypotheses follow this frame's refinement,
-            // which reads the workspace they are written to.)
+            // B: the 3-D column of the filters, hypotheses, the decision (all A waits for); then a keyframe is refined and
+            // its sets handed over; any other frame is refined after that.  (In order on B: the next frame's 3-D column
+            // follows the hand-over it reads, its hypotheses follow this frame's refinement, which reads the workspace
+            // they are written to.)
             SVO_HIP(hipStreamWaitEvent(sB, v->ev_flt, 0));
             {
                 OnStream on(ctx, sB);
-                if ((rc = chain_pnp(ctx, 1, vs, set, true)))
+                stamp(sB, f, 3);
+                if ((rc = chain_filters_3d(ctx, v, set, f & 1)) || (rc = chain_pnp(ctx, 1, vs, set, true)))
                     return rc;
                 SVO_HIP(hipEventRecord(v->ev_dec, sB));
-                SVO_HIP(hipStreamWaitEvent(sB, v->ev_p1, 0));  // the stereo path of this frame: long done
-                if ((rc = chain_pnp_refine(ctx, vs, set, true)) || (rc = stereo_part2_spec(v, cur, set, 2)))
+                stamp(sB, f, 4);
+                SVO_HIP(hipStreamWaitEvent(sB, v->ev_p1[f & 3], 0));  // the stereo path of this frame: long done
+                if ((rc = chain_pnp_refine(ctx, vs, set, true)) || (rc = stereo_part2_spec(v, cur, slot, 3)))
                     return rc;
-                SVO_HIP(hipEventRecord(v->ev_p3, sB));
+                stamp(sB, f, 5);
+                SVO_HIP(hipEventRecord(v->ev_p3[f & 3], sB));
                 if ((rc = chain_pnp_refine(ctx, vs, set, false)))
+                    return rc;
+            }
+            tock(1, t0);
+            t0 = tick();
+            // D: the pyramids of frame f+2 into the buffer of frame f-1, whose last readers were the tracking launch of
+            // the previous iteration (before these filters on A), the stereo path of frame f-1 (C is in order: frame f's
+            // is done) and the colours of keyframe f-1 (its hand-over on B); the right pyramid it overwrites is the one
+            // the stereo path of frame f has read
+            if (f + 2 < nf) {
+                SVO_HIP(hipStreamWaitEvent(sD, v->ev_flt, 0));
+                SVO_HIP(hipStreamWaitEvent(sD, v->ev_p1[f & 3], 0));
+                if (f > 0)
+                    SVO_HIP(hipStreamWaitEvent(sD, v->ev_p3[(f - 1) & 3], 0));
+                if ((rc = pyramids(f + 2, ref)))
                     return rc;
             }
             tock(2, t0);
             t0 = tick();
-            if (more) {  // beside it on A: the next frame's pyramids and its tracking pass from the tracked set
-                const uint8_t *li = r.lefts[f + 1], *ri = r.rights[f + 1];
-                if ((rc = build(1, vs, &nxt, &right[(f + 1) & 1], &li, &ri, r.mem)))
+            if (more) {  // A: both tracking passes into frame f+1
+                LkJob lk2[2];
+                for (int a = 0; a < 2; a++) {
+                    LkJob &q = lk2[a];
+                    q.prev = cur->dev;
+                    q.next = nxt->dev;
+                    q.dprev = cur->dbase;
+                    q.n_cap = v->cap;
+                    q.err = nullptr;
+                    q.min_eig = nullptr;
+                    q.gate = run;
+                }
+                lk2[0].prev_pts = set ? v->trk2d_b : v->trk2d;
+                lk2[0].d_n = v->d_cnt + (set ? 9 : 1);
+                lk2[0].next_pts = v->a2;
+                lk2[0].status = (f + 1) & 1 ? v->status_b : v->status;
+                lk2[1].prev_pts = v->h_x1[slot];
+                lk2[1].d_n = v->h_cnt + slot;
+                lk2[1].next_pts = v->a2k;
+                lk2[1].status = (f + 1) & 1 ? v->statusk_b : v->statusk;
+                if ((rc = svo_launch_lk_batch(ctx, 2, lk2, cur)))
                     return rc;
-                SVO_HIP(hipEventRecord(v->ev_pyr, sA));
-                pts[0] = set ? v->trk2d_b : v->trk2d;
-                dn[0] = v->d_cnt + (set ? 9 : 1);
-                gates[0] = run;
-                if ((rc = chain_lk(ctx, 1, vs, &cur, &nxt, pts, dn, gates)))
-                    return rc;
-            }
-            tock(3, t0);
-            t0 = tick();
-            // the frame is decided; its stereo path has long been ready
-            SVO_HIP(hipStreamWaitEvent(sA, v->ev_dec, 0));
-            SVO_HIP(hipStreamWaitEvent(sA, v->ev_p1, 0));
-            if ((rc = stereo_part2_spec(v, cur, set, 1)))
-                return rc;
-            if (more) {
-                pts[0] = v->ref2d;  // a keyframe: the next frame is tracked from its points
-                dn[0] = &v->d_chain->nref;
-                gates[0] = kf;
-                if ((rc = chain_lk(ctx, 1, vs, &cur, &nxt, pts, dn, gates)))
-                    return rc;
-                tock(4, t0);
+                stamp(sA, f, 2);
+                SVO_HIP(hipEventRecord(v->ev_lk, sA));
+                tock(3, t0);
                 t0 = tick();
-                // the stereo path of the next frame: its pyramids are built; it writes the other hand-over set than the
-                // one this frame's placements read (and the set it writes was read a frame ago, before ev_pyr on A and
-                // before the ev_p3 A waited for)
-                SVO_HIP(hipStreamWaitEvent(sC, v->ev_pyr, 0));
-                if ((rc = stereo_part1_spec(v, v->lane, nxt, right[(f + 1) & 1], frame0 + f + 2, (f + 1) & 1)))
-                    return rc;
-                SVO_HIP(hipEventRecord(v->ev_p1, sC));
+                // C: the stereo path of frame f+2 once this launch has ended.  It writes the hand-over set of frame f-1,
+                // whose readers were the previous iteration's launch and that frame's hand-over on B.
+                if (f + 2 < nf) {
+                    SVO_HIP(hipStreamWaitEvent(sC, v->ev_lk, 0));
+                    if (f > 0)
+                        SVO_HIP(hipStreamWaitEvent(sC, v->ev_p3[(f - 1) & 3], 0));
+                    stamp(sC, f, 6);
+                    if ((rc = stereo(f + 2, ref)))  // `ref`: where D has just been told to build frame f+2
+                        return rc;
+                    stamp(sC, f, 7);
+                }
+                tock(4, t0);
             }
-            tock(5, t0);
-            SVO_HIP(hipStreamWaitEvent(sA, v->ev_p3, 0));  // the next filters read the 3-D reference set
+            SVO_HIP(hipStreamWaitEvent(sA, v->ev_dec, 0));  // the next filters: the keyframe flag, a plain frame's 2-D set
             svo_pyramid *t = ref;  // referenceImg = currentImage (src/VisualSLAM.cpp:151)
             ref = cur;
             cur = nxt;
@@ -983,9 +1088,34 @@ static int chain_enqueue(ChainRun *const *runs, int k, bool pipeline)
         SVO_HIP(hipEventRecord(v->ev_ref, sB));
         SVO_HIP(hipStreamWaitEvent(sA, v->ev_ref, 0));
         if (dbg)
-            fprintf(stderr, "[svo chain] host us per frame: filters %.1f, record %.1f, B (3 waits/records + 6 launches) %.1f, "
-                            "pyramids + LK on A %.1f, waits + place + LK2 on A %.1f, C %.1f\n", us_cat[0] / nf, us_cat[1] / nf,
-                    us_cat[2] / nf, us_cat[3] / nf, us_cat[4] / nf, us_cat[5] / nf);
+            fprintf(stderr, "[svo chain] host us per frame: filters + record %.1f, B %.1f, D %.1f, tracking launch on A %.1f, C %.1f\n",
+                    us_cat[0] / nf, us_cat[1] / nf, us_cat[2] / nf, us_cat[3] / nf, us_cat[4] / nf);
+        if (stamps && nf > 40) {  // debug: wait, read, print the mean intervals over the middle of the run
+            SVO_HIP(hipStreamSynchronize(sA));
+            SVO_HIP(hipStreamSynchronize(sC));
+            const int n = nf < max_stamp_frames ? nf : max_stamp_frames;
+            std::vector<unsigned long long> h((size_t)8 * n);
+            SVO_HIP(hipMemcpy(h.data(), d_stamps, h.size() * sizeof(h[0]), hipMemcpyDeviceToHost));
+            auto T = [&](int f, int k) { return (double)h[(size_t)8 * f + k] * 0.01; };  // 100 MHz -> us
+            double cyc = 0, filt = 0, a_gap = 0, lk = 0, a_wait = 0, b_lag = 0, pnp = 0, hand = 0, c_lag = 0, c_len = 0;
+            int m = 0;
+            for (int f = 20; f + 3 < n; f++, m++) {
+                cyc += T(f + 1, 0) - T(f, 0);
+                filt += T(f, 1) - T(f, 0);
+                lk += T(f, 2) - T(f, 1);
+                a_wait += T(f + 1, 0) - T(f, 2);
+                b_lag += T(f, 3) - T(f, 1);
+                pnp += T(f, 4) - T(f, 3);
+                hand += T(f, 5) - T(f, 4);
+                c_lag += T(f, 6) - T(f, 2);
+                c_len += T(f, 7) - T(f, 6);
+            }
+            (void)a_gap;
+            fprintf(stderr, "[svo chain] device us per frame (stamps): cycle %.1f = filters %.1f + tracking launch %.1f + wait for B %.1f | "
+                            "B starts %.1f after the filters, PnP to decision %.1f, refine + hand-over of a keyframe %.1f | C starts %.1f "
+                            "after the launch, stereo path %.1f\n", cyc / m, filt / m, lk / m, a_wait / m, b_lag / m, pnp / m, hand / m,
+                    c_lag / m, c_len / m);
+        }
         return SVO_OK;
     }
     // lock step on one stream
@@ -1235,6 +1365,8 @@ int svo_vo_run_chunk(svo_vo *v, const uint8_t *const *lefts, const uint8_t *cons
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
         if (!v->stream_b)
             SVO_HIP(hipStreamCreateWithPriority(&v->stream_b, hipStreamNonBlocking, prio_hi));
+        if (!v->stream_p)
+            SVO_HIP(hipStreamCreateWithFlags(&v->stream_p, hipStreamNonBlocking));
         const size_t n = (size_t)v->cap;
         svo_vo::StereoLane &L = v->lane;
         if (!L.ctx && (rc = svo_ctx_create(v->ctx->device, &L.ctx)))
@@ -1246,13 +1378,17 @@ int svo_vo_run_chunk(svo_vo *v, const uint8_t *const *lefts, const uint8_t *cons
             (!L.mask && (rc = dev_alloc(&L.mask, n))) || (!L.idx && (rc = dev_alloc(&L.idx, n))) ||
             (!L.cnt && (rc = dev_alloc(&L.cnt, 16))))
             return rc;
-        for (int k = 0; k < 2; k++)
+        for (int k = 0; k < 3; k++)
             if ((!v->h_x1[k] && (rc = dev_alloc(&v->h_x1[k], n * 2))) || (!v->h_xyz[k] && (rc = dev_alloc(&v->h_xyz[k], n * 3))))
                 return rc;
         if ((!v->h_cnt && (rc = dev_alloc(&v->h_cnt, 16))) || (!v->trk2d_b && (rc = dev_alloc(&v->trk2d_b, n * 2))) ||
-            (!v->trk3d_b && (rc = dev_alloc(&v->trk3d_b, n * 3))) || (!v->idx_b && (rc = dev_alloc(&v->idx_b, n))))
+            (!v->trk3d_b && (rc = dev_alloc(&v->trk3d_b, n * 3))) || (!v->idx_b && (rc = dev_alloc(&v->idx_b, n))) ||
+            (!v->a2k && (rc = dev_alloc(&v->a2k, n * 2))) || (!v->statusk && (rc = dev_alloc(&v->statusk, n))) ||
+            (!v->status_b && (rc = dev_alloc(&v->status_b, n))) || (!v->statusk_b && (rc = dev_alloc(&v->statusk_b, n))))
             return rc;
-        for (hipEvent_t *e : {&v->ev_flt, &v->ev_dec, &v->ev_p3, &v->ev_ref, &v->ev_pyr, &v->ev_p1})
+        for (hipEvent_t *e : {&v->ev_flt, &v->ev_lk, &v->ev_dec, &v->ev_ref, &v->ev_pyr[0], &v->ev_pyr[1], &v->ev_pyr[2], &v->ev_pyr[3],
+                              &v->ev_p1[0], &v->ev_p1[1], &v->ev_p1[2], &v->ev_p1[3], &v->ev_p3[0], &v->ev_p3[1], &v->ev_p3[2],
+                              &v->ev_p3[3]})
             if (!*e)
                 SVO_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
         v->pipe_ready = true;

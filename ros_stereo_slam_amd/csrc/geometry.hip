@@ -282,6 +282,10 @@ struct CompactArgs {
     const int *d_n;
     int *d_count;
     const int *gate;
+    const int *alt_sel;
+    const uint8_t *alt_mask;
+    const float *alt_in[3];
+    const int *alt_d_n;
 };
 template <int NJ> struct CompactBatchN {  // blockIdx.y picks the job; NJ = 1: a lone problem
     CompactArgs j[NJ];
@@ -310,8 +314,14 @@ template <int NJ> __global__ __launch_bounds__(64) void compact_kernel(CompactBa
     const CompactArgs &args = batch.j[blockIdx.y];
     if (args.gate && *args.gate == 0)
         return;
-    const uint8_t *__restrict__ mask = args.mask;
-    const int n = args.d_n ? min(*args.d_n, args.n_host) : args.n_host;
+    const bool alt = args.alt_sel && *args.alt_sel != 0;  // wave-uniform
+    const uint8_t *__restrict__ mask = alt && args.alt_mask ? args.alt_mask : args.mask;
+    const float *src_of[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+        src_of[a] = alt && args.alt_in[a] ? args.alt_in[a] : args.in[a];
+    const int *d_n = alt && args.alt_d_n ? args.alt_d_n : args.d_n;
+    const int n = d_n ? min(*d_n, args.n_host) : args.n_host;
     const int lane = threadIdx.x;
     const int first = blockIdx.x * seg;  // this wave's segment: [first, last)
     if (first >= n && !(n <= 0 && blockIdx.x == 0))
@@ -342,8 +352,9 @@ template <int NJ> __global__ __launch_bounds__(64) void compact_kernel(CompactBa
             for (int a = 0; a < 3; a++)
                 if (args.in[a]) {
                     const int st = args.stride[a];
+                    const float *__restrict__ src = src_of[a];
                     for (int k = 0; k < st; k++)
-                        args.out[a][(size_t)pos * st + k] = args.in[a][(size_t)i * st + k];
+                        args.out[a][(size_t)pos * st + k] = src[(size_t)i * st + k];
                 }
         }
         pos0 += __popcll(bal);
@@ -496,6 +507,11 @@ int svo_launch_compact_batch(svo_ctx *ctx, int n_jobs, const svo_compact_job *jo
         a.d_n = h.d_n;
         a.d_count = h.d_count;
         a.gate = h.gate;
+        a.alt_sel = h.alt_sel;
+        a.alt_mask = h.alt_mask;
+        for (int q = 0; q < 3; q++)
+            a.alt_in[q] = h.alt_in[q];
+        a.alt_d_n = h.alt_d_n;
     }
     int cap_max = 0;
     for (int k = 0; k < n_jobs; k++)

@@ -845,7 +845,7 @@ int svo_launch_lk_batch(svo_ctx *ctx, int n_jobs, const LkJob *jobs, const svo_p
         prm.dpitch[l] = geom->dpitch[l];
     }
     static const int lone_interleave = getenv("SVO_LK_INTERLEAVE") ? atoi(getenv("SVO_LK_INTERLEAVE")) : 1;  // A/B: +2.8 % frames/s for one chunk per GPU
-    prm.interleave = n_jobs == 1 ? lone_interleave : 0;
+    prm.interleave = n_jobs <= 2 ? lone_interleave : 0;  // two jobs: the two candidate passes of a pipelined chunk
     dim3 grid(((n_max + 7) / 8 + WAVES - 1) / WAVES * 8, n_jobs), block(64 * WAVES);  // x: a multiple of 8, every XCD band has all its slots
     ScopedKernelTime t(ctx, SVO_K_LK);
     if (c != 1 && c != 3) {

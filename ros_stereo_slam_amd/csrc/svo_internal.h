@@ -194,6 +194,13 @@ struct svo_compact_job {  // order-preserving compaction of up to three float ar
     int stride[3];
     int *d_count;
     const int *gate = nullptr;  // optional: leave at once when *gate == 0
+    // optional: when *alt_sel != 0 the mask, the count and the input arrays given here replace the ones above (pipelined
+    // chunk: the sets of the tracking pass from a keyframe's points rather than of the pass from the tracked set);
+    // a null alt_in[k] / alt_d_n keeps the regular one
+    const int *alt_sel = nullptr;
+    const uint8_t *alt_mask = nullptr;
+    const float *alt_in[3] = {nullptr, nullptr, nullptr};
+    const int *alt_d_n = nullptr;
 };
 struct svo_fransac_job {  // host-side description of one F-matrix RANSAC problem (device pointers)
     const float *p1, *p2;

@@ -61,6 +61,7 @@ def regs_of(text):
 
 LABEL = re.compile(r"^(?:[0-9a-f]+ )?(\.LBB\S*|<L\d+>):")
 KERNEL = re.compile(r"^(?:[0-9a-f]+ <)?(_ZN\S*lk_track_kernel[^>:\s]*)>?:")
+SYMBOL = re.compile(r"^(?:[0-9a-f]+ <[^>]+>|[A-Za-z_$][\w$.]*):")
 
 
 def check(path):
@@ -77,7 +78,8 @@ def check(path):
             continue
         kernels += 1
         name = m.group(1)
-        end = next(j for j in range(i, len(lines)) if "s_endpgm" in lines[j])
+        # the kernel ends where the next symbol begins (an early exit puts an s_endpgm in the middle of it)
+        end = next((j for j in range(i + 1, len(lines)) if SYMBOL.match(lines[j]) and not LABEL.match(lines[j])), len(lines))
         body = [(j, lines[j].strip()) for j in range(i + 1, end)]
         body = [(j, l) for j, l in body if l and not l.startswith(";") and not l.startswith(".") or LABEL.match(l)]
         # outstanding hand-issued loads, oldest first: (line, dest registers)
@@ -106,7 +108,7 @@ def check(path):
                     if keep == 0:
                         pending = []
                 continue
-            if op.startswith("s_cbranch") or op == "s_branch":
+            if op.startswith("s_cbranch") or op == "s_branch" or op == "s_endpgm":
                 if pending:
                     problems.append(f"{name}: branch at line {j + 1} inside an in-flight window (loads from line {pending[0][0] + 1})")
                     pending = []
@@ -116,7 +118,7 @@ def check(path):
                 for lj, d in pending:
                     if touched & d:
                         problems.append(f"{name}: line {j + 1} touches v{sorted(touched & d)} in flight since line {lj + 1}: {l}")
-        i = end + 1
+        i = end  # the next symbol's own line (it may be the next tracking kernel)
     return kernels, loads_seen, problems
 
 
