@@ -254,7 +254,10 @@ def main():
     comm, collective = None, None
     # (a live RCCL communicator holds hardware queues: with one it is -2 % on the batched figure and -27 % on the
     # three-stream single-chunk run, A/B on one box -- so none is made where there is nothing to exchange, at N = 1)
-    if not rehearsal and world > 1 and os.environ.get("SVO_BENCH_NO_CABI") != "1":
+    # (SVO_BENCH_REHEARSE_CABI=1: a rehearsal tries it too -- two ranks on one GPU are refused by RCCL, which exercises the
+    # fall-back and the agreement between the ranks)
+    try_cabi = (not rehearsal or os.environ.get("SVO_BENCH_REHEARSE_CABI") == "1")
+    if try_cabi and world > 1 and os.environ.get("SVO_BENCH_NO_CABI") != "1":
         ident, why = None, ""
         if rank == 0:
             try:
@@ -274,7 +277,13 @@ def main():
 
             def _make():
                 try:
-                    made["comm"] = capi.ShardComm(sh.ctxs[0], rank, world, ident)
+                    c = capi.ShardComm(sh.ctxs[0], rank, world, ident)
+                    # a first all-gather of the size the run will do, still under the deadline and outside the clock: a
+                    # collective that cannot complete on this node is found here, not in the timed region
+                    trial = c.allgather_boundaries([(np.eye(3), np.full(3, float(rank)))] * M)
+                    if len(trial) != M * world or any(abs(float(trial[r * M][1][0]) - r) > 0 for r in range(world)):
+                        raise RuntimeError("trial all-gather returned the wrong boundaries")
+                    made["comm"] = c
                 except Exception as e:   # noqa: BLE001
                     made["err"] = f"{type(e).__name__}: {e}"
 
@@ -285,7 +294,7 @@ def main():
                 comm = made["comm"]
                 collective = f"ncclAllGather through svo_shard_allgather_boundaries (C ABI, librccl), {world} rank(s)"
             else:
-                why = made.get("err", "ncclCommInitRank did not return within 120 s")
+                why = made.get("err", "ncclCommInitRank / the trial all-gather did not return within 120 s")
         if comm is None:
             collective = f"torch.distributed all_gather (C-ABI communicator unavailable: {why or 'no unique id'})"
     if collective is None:
@@ -513,7 +522,8 @@ def main():
                 "chunks_per_gpu": M,
                 "chunks_per_context": G,
                 "frames_per_chunk": L,
-                "pipeline": "two HIP streams per chunk: PnP(t) beside pyramid+LK(t+1)" if pipeline
+                "pipeline": "four HIP streams per chunk: filters + both candidate tracking passes | PnP, decision, refinement, "
+                            "keyframe hand-over | stereo path two frames ahead | pyramids two frames ahead" if pipeline
                             else "one in-order HIP stream per context",
                 "keyframe_rate": kf_rate,
                 "frames_per_step": M * world,
