@@ -628,28 +628,57 @@ __global__ __launch_bounds__(256) void pg_dense_potf2_kernel(const double *__res
         const int r = e / TB, c = e - TB * r;
         Lo[(size_t)(kb * TB + r) * ldr + kb * TB + c] = c <= r ? sL[r * LD + c] : 0.;
     }
-    // L^-1: column c by forward substitution, FOUR lanes per column (192 busy): lane `part` adds the terms k = part mod 4
-    // of every row's dot product, two shuffles combine the four shares; the column lives in LDS (sX), written and read
-    // by lanes of the same wave.  (One thread per column was a dependent chain of 1152 multiply-subtracts: 20 us.)
-    __shared__ double sX[TB * (TB + 1)], sRd[TB];
+    // L^-1 by halves: the eight 6 x 6 diagonal blocks are inverted side by side (a thread per column, six steps), then
+    // three levels put pairs of inverted halves together, X21 = -X22 (L21 X11), every entry of a product a thread's own
+    // dot product: two barriers per level, about sixty dependent multiply-adds in all.  (Forward substitution over the
+    // 48 rows -- four lanes per column, a hand-off per row -- was a chain of 48 x 12 steps: 20 of this kernel's 45 us.)
+    __shared__ double sX[TB * (TB + 1)], sRd[TB], sT[TB * TB / 4];
     if (tid < TB)
         sRd[tid] = 1. / sL[tid * LD + tid];  // 48 divisions side by side, not one at the end of every row's chain
+    for (int e = tid; e < TB * TB; e += 256) {
+        const int r = e / TB, c = e - TB * r;
+        sX[r * LD + c] = 0.;
+    }
     __syncthreads();
-    if (tid < 4 * TB) {
-        const int c = tid >> 2, part = tid & 3;
-        for (int r = 0; r < TB; r++) {
-            double acc = 0.;
-            for (int k = c + part; k < r; k += 4)  // entries above the diagonal of the inverse are zero: start at k = c
-                acc -= sL[r * LD + k] * sX[c * LD + k];
-            acc = acc + __shfl_xor(acc, 1, 64);
-            acc = acc + __shfl_xor(acc, 2, 64);
-            const double xr = r < c ? 0. : ((r == c ? 1. : 0.) + acc) * sRd[r];
-            if (part == 0) {
-                sX[c * LD + r] = xr;
-                Tinv[(size_t)kb * TB * TB + r * TB + c] = xr;
-            }
-            wave_sync();
+    if (tid < TB) {  // column c of diagonal block blk, kept in registers
+        const int blk = tid / 6, c = tid - 6 * blk, o = 6 * blk;
+        double x[6];
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+            double acc = r == c ? 1. : 0.;
+#pragma unroll
+            for (int k = 0; k < 6; k++)
+                if (k < r)
+                    acc -= sL[(o + r) * LD + o + k] * (k >= c ? x[k] : 0.);
+            x[r] = r < c ? 0. : acc * sRd[o + r];
         }
+#pragma unroll
+        for (int r = 0; r < 6; r++)
+            sX[(o + r) * LD + o + c] = x[r];
+    }
+    __syncthreads();
+    for (int h = 6; h < TB; h *= 2) {  // halves of h rows -> inverted blocks of 2 h rows
+        const int pairs = TB / (2 * h), per = h * h;
+        for (int e = tid; e < pairs * per; e += 256) {  // T = L21 X11 (X11 lower triangular: k >= j)
+            const int pr = e / per, ij = e - pr * per, i = ij / h, j = ij - i * h, o = 2 * h * pr;
+            double acc = 0.;
+            for (int k = j; k < h; k++)
+                acc += sL[(o + h + i) * LD + o + k] * sX[(o + k) * LD + o + j];
+            sT[e] = acc;
+        }
+        __syncthreads();
+        for (int e = tid; e < pairs * per; e += 256) {  // X21 = -X22 T (X22 lower triangular: k <= i)
+            const int pr = e / per, ij = e - pr * per, i = ij / h, j = ij - i * h, o = 2 * h * pr;
+            double acc = 0.;
+            for (int k = 0; k <= i; k++)
+                acc -= sX[(o + h + i) * LD + o + h + k] * sT[pr * per + k * h + j];
+            sX[(o + h + i) * LD + o + j] = acc;
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < TB * TB; e += 256) {
+        const int r = e / TB, c = e - TB * r;
+        Tinv[(size_t)kb * TB * TB + e] = c <= r ? sX[r * LD + c] : 0.;
     }
 }
 
