@@ -314,145 +314,273 @@ __device__ inline bool wave_chol6_inv(double *sS, double *sL, double *sLi, int l
     return ok;
 }
 
-// One wavefront per segment: block-tridiagonal Cholesky of the segment, then y, Wl, Wr for all
-// its rows.  Scratch Li (L_bb^-1), Lsub (L_{b,b-1}) and Z7 (the forward-substituted right-hand
-// sides) are written in the forward sweep and read back by the same wave in the backward sweep.
-// status[0] != 0 marks a non-positive pivot (1 + block row).
-__global__ __launch_bounds__(64) void pg_segment_kernel(int nb, const int *__restrict__ seg_start,
-                                                        const int *__restrict__ seg_len,
-                                                        const double *__restrict__ Dg, const double *__restrict__ Cc,
-                                                        const double *__restrict__ rneg, double *Li, double *Lsub,
-                                                        double *Z7, double *__restrict__ Y, double *__restrict__ Wl,
-                                                        double *__restrict__ Wr, int *__restrict__ status)
+// Two wavefronts per segment, one from each end (a "twisted" factorisation): wave 0 eliminates rows a .. m-1 downwards,
+// wave 1 rows z .. m+1 upwards -- the same block-tridiagonal Cholesky on the reversed chain --, both meet at the middle
+// row m, whose Schur complement takes a term from either side; then both substitute back outwards from m.  The serial
+// chain of a segment is half as long as with one wave walking all of it.  Outputs as before: y, Wl, Wr of every row,
+//   x_b = y_b - Wl_b x_l - Wr_b x_r.
+// Per row b of a half with direction d (+1 / -1): N_b = H[b+d][b] L_bb^-T (the coupling to the next row of the half, for
+// the last row: to m), z_b = L_bb^-1 (rhs_b - N_{b-d} z_{b-d}) for 7 columns [r | coupling to the half's own separator].
+// Scratch Li (L_bb^-1), Lsub (N_b) and Z7 (z_b) are written in the forward sweep and read back by the same wave in the
+// backward sweep.  status[0] != 0 marks a non-positive pivot (1 + block row).
+struct PgHalfLds {
+    double sS[36], sL[36], sLi[36], sSub[36], sC[36], sT[80], sZ[80], sX[80];
+};
+__global__ __launch_bounds__(128) void pg_segment_kernel(int nb, const int *__restrict__ seg_start,
+                                                         const int *__restrict__ seg_len,
+                                                         const double *__restrict__ Dg, const double *__restrict__ Cc,
+                                                         const double *__restrict__ rneg, double *Li, double *Lsub,
+                                                         double *Z7, double *__restrict__ Y, double *__restrict__ Wl,
+                                                         double *__restrict__ Wr, int *__restrict__ status)
 {
-    __shared__ double sS[36], sL[36], sLi[36], sSub[36], sC[36], sT[80], sZ[80], sX[80];
-    const int lane = threadIdx.x;
+    __shared__ PgHalfLds sH[2];
+    __shared__ double sXm[80];  // x of the middle row, 13 columns [y | Wl | Wr], layout [6][13]
+    __shared__ int s_fail;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    PgHalfLds &S = sH[wave];
     const int a = seg_start[blockIdx.x], n = seg_len[blockIdx.x], z = a + n - 1;
+    const int m = a + n / 2;                      // the middle row: halves a .. m-1 and m+1 .. z
+    const int d = wave == 0 ? 1 : -1;
+    const int first = wave == 0 ? a : z;          // the half's first row (next to its separator)
+    const int cnt = wave == 0 ? m - a : z - m;    // its rows
     const int i = lane / 6, j = lane - 6 * i;
     const bool act = lane < 36;
-    const bool has_l = a > 0, has_r = z < nb - 1;
-    // ---- forward: factorisation and L^-1 [r | E_a C_l] (7 columns; column layout [6][7]) ----
-    // The rows of a segment are a serial chain: the next row's blocks are requested while this row is worked on (their
-    // load latency was a third of a row's 2 us).
+    const bool has_sep = wave == 0 ? a > 0 : z < nb - 1;  // the separator beside the half's first row exists
     const int r7 = lane / 7, c7 = lane - 7 * r7;
-    double nDg = act ? Dg[(size_t)a * 36 + lane] : 0., nCc = act && a < z ? Cc[(size_t)a * 36 + lane] : 0.;
-    double nr = lane < 42 ? (c7 == 0 ? rneg[(size_t)a * 6 + r7] : (has_l ? Cc[(size_t)(a - 1) * 36 + 6 * r7 + (c7 - 1)] : 0.)) : 0.;
-    for (int b = a; b <= z; b++) {
-        const double cDg = nDg, cCc = nCc, cr = nr;
-        if (b < z) {
-            nDg = act ? Dg[(size_t)(b + 1) * 36 + lane] : 0.;
-            nCc = act && b + 1 < z ? Cc[(size_t)(b + 1) * 36 + lane] : 0.;
-            nr = lane < 42 && c7 == 0 ? rneg[(size_t)(b + 1) * 6 + r7] : 0.;
+    if (threadIdx.x == 0)
+        s_fail = 0;
+    __syncthreads();
+    // H[p][q] for |p - q| = 1, entry (i, j): Cc[q] (p = q + 1) or Cc[p]^T (q = p + 1)
+    auto Hoff = [&](int p, int q, int ii, int jj) -> double {
+        return p > q ? Cc[(size_t)q * 36 + 6 * ii + jj] : Cc[(size_t)p * 36 + 6 * jj + ii];
+    };
+    // ---- forward sweep of this wave's half: 7 columns [r | coupling to the half's separator (first row only)] ----
+    // The rows of a half are a serial chain: the next row's blocks are requested while this row is worked on (their load
+    // latency was a third of a row's time).
+    bool failed = false;
+    double nDg = 0., nC = 0., nR = 0.;
+    if (cnt > 0) {
+        nDg = act ? Dg[(size_t)first * 36 + lane] : 0.;
+        nC = act ? Hoff(first + d, first, i, j) : 0.;
+        nR = lane < 42 ? (c7 == 0 ? rneg[(size_t)first * 6 + r7] : (has_sep ? Hoff(first, first - d, r7, c7 - 1) : 0.)) : 0.;
+    }
+    for (int k = 0; k < cnt; k++) {
+        const int b = first + d * k;
+        const double cDg = nDg, cC = nC, cR = nR;
+        if (k + 1 < cnt) {
+            const int bn = b + d;
+            nDg = act ? Dg[(size_t)bn * 36 + lane] : 0.;
+            nC = act ? Hoff(bn + d, bn, i, j) : 0.;
+            nR = lane < 42 && c7 == 0 ? rneg[(size_t)bn * 6 + r7] : 0.;
         }
         if (act) {
             double sv = cDg;
-            if (b > a) {
+            if (k > 0) {
 #pragma unroll
                 for (int t = 0; t < 6; t++)
-                    sv -= sSub[6 * i + t] * sSub[6 * j + t];
+                    sv -= S.sSub[6 * i + t] * S.sSub[6 * j + t];
             }
-            sS[lane] = sv;
-            sC[lane] = cCc;
+            S.sS[lane] = sv;
+            S.sC[lane] = cC;  // the coupling to the next row of the half (the last row's: to m)
         }
-        // right-hand side block of this row: [rneg_b | C_l (first row only)]
         if (lane < 42) {
-            const int r = r7, c = c7;
-            double v = cr;
-            if (b > a) {
+            double v = cR;
+            if (k > 0) {
 #pragma unroll
                 for (int t = 0; t < 6; t++)
-                    v -= sSub[6 * r + t] * sZ[7 * t + c];
+                    v -= S.sSub[6 * r7 + t] * S.sZ[7 * t + c7];
             }
-            sT[lane] = v;
+            S.sT[lane] = v;
         }
         wave_sync();
-        if (!wave_chol6_inv(sS, sL, sLi, lane)) {
-            if (lane == 0)
+        if (!wave_chol6_inv(S.sS, S.sL, S.sLi, lane)) {
+            if (lane == 0) {
                 atomicMax(status, 1 + b);
-            return;
+                s_fail = 1;
+            }
+            failed = true;
+            break;
         }
         if (act) {
-            Li[(size_t)b * 36 + lane] = sLi[lane];
-            // L_{b+1,b} = C_b L_bb^-T
-            double v = 0;
+            Li[(size_t)b * 36 + lane] = S.sLi[lane];
+            double v = 0;  // N_b = H[b+d][b] L_bb^-T
 #pragma unroll
             for (int t = 0; t < 6; t++)
-                v += sC[6 * i + t] * sLi[6 * j + t];
-            if (b < z)
-                Lsub[(size_t)(b + 1) * 36 + lane] = v;
-            sS[lane] = v;  // parked; becomes sSub after the z update below has read the old sSub
+                v += S.sC[6 * i + t] * S.sLi[6 * j + t];
+            Lsub[(size_t)b * 36 + lane] = v;
+            S.sS[lane] = v;  // parked; becomes sSub after the z update below has read the old sSub
         }
         double zv = 0;
         if (lane < 42) {
-            const int r = lane / 7, c = lane - 7 * r;
 #pragma unroll
             for (int t = 0; t < 6; t++)
-                zv += sLi[6 * r + t] * sT[7 * t + c];
+                zv += S.sLi[6 * r7 + t] * S.sT[7 * t + c7];
             Z7[(size_t)b * 42 + lane] = zv;
         }
         wave_sync();
         if (lane < 42)
-            sZ[lane] = zv;
+            S.sZ[lane] = zv;
         if (act)
-            sSub[lane] = sS[lane];
+            S.sSub[lane] = S.sS[lane];
         wave_sync();
     }
-    // the scratch written above is read back below by other lanes of this wave
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    // ---- backward: x = L^-T z for 13 columns [y | Wl (6) | Wr (6)], layout [6][13] in sX ----
-    // (the same here: Li / Lsub / Z7 of the row below are in flight while this row is combined)
-    const int e1 = lane + 64, r13a = lane / 13, c13a = lane - 13 * r13a, r13b = e1 / 13, c13b = e1 - 13 * r13b;
-    double nLi = act ? Li[(size_t)z * 36 + lane] : 0., nSub = 0.;
-    double nZa = c13a < 7 ? Z7[(size_t)z * 42 + 7 * r13a + c13a] : 0.;
-    double nZb = e1 < 78 && c13b < 7 ? Z7[(size_t)z * 42 + 7 * r13b + c13b] : 0.;
-    for (int b = z; b >= a; b--) {
-        const double cZa = nZa, cZb = nZb;
+    (void)failed;
+    __syncthreads();  // both halves are factorised (or one has failed): sSub = N of the row beside m, sZ = its z
+    if (s_fail)
+        return;
+    // ---- the middle row, by wave 0: Schur complement with a term from either side, 13 right-hand sides ----
+    if (wave == 0) {
+        const PgHalfLds &U = sH[0], &D = sH[1];
+        const bool hu = m > a, hd = z > m;
         if (act) {
-            sLi[lane] = nLi;
-            if (b < z)
-                sSub[lane] = nSub;
+            double sv = Dg[(size_t)m * 36 + lane];
+#pragma unroll
+            for (int t = 0; t < 6; t++) {
+                if (hu)
+                    sv -= U.sSub[6 * i + t] * U.sSub[6 * j + t];
+                if (hd)
+                    sv -= D.sSub[6 * i + t] * D.sSub[6 * j + t];
+            }
+            S.sS[lane] = sv;
         }
-        if (b > a) {
-            nLi = act ? Li[(size_t)(b - 1) * 36 + lane] : 0.;
-            nSub = act ? Lsub[(size_t)b * 36 + lane] : 0.;
-            nZa = c13a < 7 ? Z7[(size_t)(b - 1) * 42 + 7 * r13a + c13a] : 0.;
-            nZb = e1 < 78 && c13b < 7 ? Z7[(size_t)(b - 1) * 42 + 7 * r13b + c13b] : 0.;
-        }
-        wave_sync();
         for (int e = lane; e < 78; e += 64) {
             const int r = e / 13, c = e - 13 * r;
             double v;
-            if (c < 7)
-                v = e == lane ? cZa : cZb;
-            else if (b == z && has_r) {  // z-value of the Wr columns: L_zz^-1 C_z^T, nonzero in the last row only
-                v = 0;
+            if (c == 0) {
+                v = rneg[(size_t)m * 6 + r];
 #pragma unroll
-                for (int t = 0; t < 6; t++)
-                    v += sLi[6 * r + t] * Cc[(size_t)z * 36 + 6 * (c - 7) + t];
-            } else
-                v = 0;
-            if (b < z) {  // - L_{b+1,b}^T x_{b+1}
+                for (int t = 0; t < 6; t++) {
+                    if (hu)
+                        v -= U.sSub[6 * r + t] * U.sZ[7 * t];
+                    if (hd)
+                        v -= D.sSub[6 * r + t] * D.sZ[7 * t];
+                }
+            } else if (c < 7) {  // Wl: the left separator's coupling, directly (m == a) or through the upper half
+                v = !hu && a > 0 ? Hoff(m, m - 1, r, c - 1) : 0.;
+                if (hu) {
 #pragma unroll
-                for (int t = 0; t < 6; t++)
-                    v -= sSub[6 * t + r] * sX[13 * t + c];
+                    for (int t = 0; t < 6; t++)
+                        v -= U.sSub[6 * r + t] * U.sZ[7 * t + c];
+                }
+            } else {             // Wr: the right separator's, directly (m == z) or through the lower half
+                v = !hd && z < nb - 1 ? Hoff(m, m + 1, r, c - 7) : 0.;
+                if (hd) {
+#pragma unroll
+                    for (int t = 0; t < 6; t++)
+                        v -= D.sSub[6 * r + t] * D.sZ[7 * t + (c - 6)];
+                }
             }
-            sT[e] = v;
+            sXm[e] = v;  // right-hand sides for now
         }
         wave_sync();
-        for (int e = lane; e < 78; e += 64) {
+        if (!wave_chol6_inv(S.sS, S.sL, S.sLi, lane)) {
+            if (lane == 0) {
+                atomicMax(status, 1 + m);
+                s_fail = 1;
+            }
+        } else {
+            double t1[2];
+            for (int q = 0, e = lane; e < 78; e += 64, q++) {  // L^-1 rhs
+                const int r = e / 13, c = e - 13 * r;
+                double v = 0;
+#pragma unroll
+                for (int t = 0; t < 6; t++)
+                    v += S.sLi[6 * r + t] * sXm[13 * t + c];
+                t1[q] = v;
+            }
+            wave_sync();
+            for (int q = 0, e = lane; e < 78; e += 64, q++)
+                S.sT[e] = t1[q];
+            wave_sync();
+            for (int q = 0, e = lane; e < 78; e += 64, q++) {  // L^-T (L^-1 rhs)
+                const int r = e / 13, c = e - 13 * r;
+                double v = 0;
+#pragma unroll
+                for (int t = 0; t < 6; t++)
+                    v += S.sLi[6 * t + r] * S.sT[13 * t + c];
+                t1[q] = v;
+            }
+            wave_sync();
+            for (int q = 0, e = lane; e < 78; e += 64, q++) {
+                const int r = e / 13, c = e - 13 * r;
+                const double v = t1[q];
+                sXm[e] = v;
+                if (c == 0)
+                    Y[(size_t)m * 6 + r] = v;
+                else if (c < 7)
+                    Wl[(size_t)m * 36 + 6 * r + (c - 1)] = v;
+                else
+                    Wr[(size_t)m * 36 + 6 * r + (c - 7)] = v;
+            }
+        }
+    }
+    // the scratch written in the forward sweep is read back below by other lanes of the same wave
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    if (s_fail)
+        return;
+    // ---- backward sweep of this wave's half, outwards from m: x_b = L_bb^-T (z_b - N_b^T x_{b+d}), 13 columns ----
+    for (int e = lane; e < 78; e += 64)
+        S.sX[e] = sXm[e];
+    wave_sync();
+    // z of the 13 columns of row b: [r | this half's separator columns]; the other separator's columns start from zero
+    auto zval = [&](int b, int e) -> double {
+        const int r = e / 13, c = e - 13 * r;
+        if (e >= 78)
+            return 0.;
+        if (c == 0)
+            return Z7[(size_t)b * 42 + 7 * r];
+        if (c < 7)
+            return wave == 0 ? Z7[(size_t)b * 42 + 7 * r + c] : 0.;
+        return wave == 1 ? Z7[(size_t)b * 42 + 7 * r + (c - 6)] : 0.;
+    };
+    double nLi = 0., nSub = 0., nZa = 0., nZb = 0.;
+    if (cnt > 0) {
+        const int bl = first + d * (cnt - 1);
+        nLi = act ? Li[(size_t)bl * 36 + lane] : 0.;
+        nSub = act ? Lsub[(size_t)bl * 36 + lane] : 0.;
+        nZa = zval(bl, lane);
+        nZb = zval(bl, lane + 64);
+    }
+    for (int k = cnt - 1; k >= 0; k--) {
+        const int b = first + d * k;
+        const double cZ[2] = {nZa, nZb};
+        if (act) {
+            S.sLi[lane] = nLi;
+            S.sSub[lane] = nSub;
+        }
+        if (k > 0) {  // the row after this one, in flight while this one is combined
+            const int bn = b - d;
+            nLi = act ? Li[(size_t)bn * 36 + lane] : 0.;
+            nSub = act ? Lsub[(size_t)bn * 36 + lane] : 0.;
+            nZa = zval(bn, lane);
+            nZb = zval(bn, lane + 64);
+        }
+        wave_sync();
+        for (int q = 0, e = lane; e < 78; e += 64, q++) {
+            const int r = e / 13, c = e - 13 * r;
+            double v = cZ[q];
+#pragma unroll
+            for (int t = 0; t < 6; t++)
+                v -= S.sSub[6 * t + r] * S.sX[13 * t + c];  // - N_b^T x_{b+d}
+            S.sT[e] = v;
+        }
+        wave_sync();
+        double xv[2];
+        for (int q = 0, e = lane; e < 78; e += 64, q++) {
             const int r = e / 13, c = e - 13 * r;
             double v = 0;
 #pragma unroll
             for (int t = 0; t < 6; t++)
-                v += sLi[6 * t + r] * sT[13 * t + c];  // L^-T
-            sZ[e] = v;
+                v += S.sLi[6 * t + r] * S.sT[13 * t + c];  // L^-T
+            xv[q] = v;
         }
         wave_sync();
-        for (int e = lane; e < 78; e += 64) {
+        for (int q = 0, e = lane; e < 78; e += 64, q++) {
             const int r = e / 13, c = e - 13 * r;
-            const double v = sZ[e];
-            sX[e] = v;
+            const double v = xv[q];
+            S.sX[e] = v;
             if (c == 0)
                 Y[(size_t)b * 6 + r] = v;
             else if (c < 7)
@@ -1262,7 +1390,7 @@ int svo_pg_optimize(svo_posegraph *g, int iters, double *chi2)
         hipLaunchKernelGGL(pg_assemble_kernel, dim3((nb + 127) / 128), dim3(128), 0, st, nb, g->d_incptr.as<int>(),
                            g->d_inc.as<int>(), g->d_from.as<int>(), g->d_to.as<int>(), eo, Dg, Cc, rneg);
         if (nseg > 0)
-            hipLaunchKernelGGL(pg_segment_kernel, dim3(nseg), dim3(64), 0, st, nb, ds + o_seg_start, ds + o_seg_len, Dg,
+            hipLaunchKernelGGL(pg_segment_kernel, dim3(nseg), dim3(128), 0, st, nb, ds + o_seg_start, ds + o_seg_len, Dg,
                                Cc, rneg, g->d_Li.as<double>(), g->d_Lsub.as<double>(), g->d_Z7.as<double>(), Y, Wl, Wr,
                                d_status);
         if (m > 0) {
