@@ -275,37 +275,59 @@ __global__ __launch_bounds__(128) void pg_assemble_kernel(int nb, const int *__r
 
 // 6x6 Cholesky S = L L^T and the inverse of L, by the 64 lanes of one wave on LDS arrays
 // (sS is destroyed).  Returns false (wave-uniform) at a non-positive pivot.
+// The pivots' reciprocal square roots come from v_rsq_f64 and two Newton steps (to the last bits of a double) and
+// are kept: L_kk = pivot * rsqrt, the column scales and the forward substitution of the inverse multiply by them.  A
+// square root and a division per pivot and a division per row of the inverse were two thirds of this routine, and this
+// routine is the serial chain of the segments (a call per block row) and of the separator tiles (eight per tile).
+__device__ __forceinline__ double pg_readlane(double v, int src)  // src: a compile-time constant after unrolling
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+// Row r of the matrix lives in the registers of lane r (six lanes work, the others shadow lane 0); what a lane needs of
+// another row arrives through v_readlane, so the six pivot steps and the forward substitution of the inverse touch
+// neither LDS nor a barrier.
 __device__ inline bool wave_chol6_inv(double *sS, double *sL, double *sLi, int lane)
 {
-    const int i = lane / 6, j = lane - 6 * i;
-    const bool act = lane < 36;
+    const int row = lane < 6 ? lane : 0;
+    double a[6], rinv[6];
+#pragma unroll
+    for (int c = 0; c < 6; c++)
+        a[c] = sS[6 * row + c];
     bool ok = true;
 #pragma unroll
     for (int k = 0; k < 6; k++) {
-        const double piv = sS[7 * k];
+        const double piv = pg_readlane(a[k], k);
         if (!(piv > 0))
             ok = false;
-        const double d = sqrt(piv), inv = 1. / d;
-        if (lane < 6) {
-            // column k of L: zero above the diagonal, d on it, scaled entries below
-            sL[6 * lane + k] = lane < k ? 0. : (lane == k ? d : sS[6 * lane + k] * inv);
-        }
-        wave_sync();
-        if (act && j > k && i >= j)
-            sS[6 * i + j] -= sL[6 * i + k] * sL[6 * j + k];
-        wave_sync();
+        double y = __builtin_amdgcn_rsq(piv);
+        const double hp = 0.5 * piv;
+        y = y * (1.5 - hp * y * y);
+        y = y * (1.5 - hp * y * y);
+        rinv[k] = y;
+        const double lk = row == k ? piv * y : a[k] * y;  // L[row][k] (rows >= k)
+        a[k] = lk;
+#pragma unroll
+        for (int j = 0; j < 6; j++)
+            if (j > k)
+                a[j] -= lk * pg_readlane(lk, j);  // S[row][j] -= L[row][k] L[j][k]; used for j <= row only
     }
-    if (lane < 6) {  // column `lane` of L^-1 by forward substitution, kept in registers
-        double x[6];
+    // column `row` of L^-1 by forward substitution
+    double x[6];
 #pragma unroll
-        for (int r = 0; r < 6; r++) {
-            double sacc = r == lane ? 1. : 0.;
+    for (int r = 0; r < 6; r++) {
+        double sacc = r == row ? 1. : 0.;
 #pragma unroll
-            for (int k = 0; k < 6; k++)
-                if (k < r)
-                    sacc -= sL[6 * r + k] * (k >= lane ? x[k] : 0.);
-            x[r] = r < lane ? 0. : sacc / sL[7 * r];
-        }
+        for (int k = 0; k < 6; k++)
+            if (k < r)
+                sacc -= pg_readlane(a[k], r) * (k >= row ? x[k] : 0.);
+        x[r] = r < row ? 0. : sacc * rinv[r];
+    }
+    if (lane < 6) {
+#pragma unroll
+        for (int c = 0; c < 6; c++)
+            sL[6 * lane + c] = c <= lane ? a[c] : 0.;
 #pragma unroll
         for (int r = 0; r < 6; r++)
             sLi[6 * r + lane] = x[r];
@@ -690,63 +712,72 @@ __global__ __launch_bounds__(256) void pg_dense_potf2_kernel(const double *__res
                                                              double *__restrict__ Tinv, int ldr, int kb,
                                                              int *__restrict__ status, int status_base)
 {
-    // The lower triangle of the 48 x 48 tile lives in REGISTERS: 1176 entries dealt out to 256 threads (entry e of
-    // the row-major triangle to thread e mod 256, <= 5 each), their (row, column) worked out once.  Right-looking with
-    // ONE barrier per column: the owners of column k publish it (unscaled) to LDS, then every thread updates the
-    // entries it owns, a_ij -= a_ik a_jk / a_kk; the columns are scaled by 1 / sqrt(pivot) at the end.  (With the
-    // tile in LDS, an integer division per entry and step, a square root + division + three barriers per column and
-    // the inverse by a thread per column through LDS this kernel took 94 us per tile: half of a solve.)
-    constexpr int NTRI = TB * (TB + 1) / 2, OWN = (NTRI + 255) / 256;
-    __shared__ double sCol2[2][TB], sPiv[TB], sL[TB * (TB + 1)];
+    // Blocked by 6 inside the 48 x 48 tile (LDS): eight steps of  (1) Cholesky + inverse of the 6 x 6 diagonal block by
+    // one wave (wave_chol6_inv, the segments' routine), (2) the panel below it, L21 = A21 L11^-T, an entry per thread,
+    // (3) the trailing update A22 -= L21 L21^T, six multiply-adds per entry.  Three barriers per step, 24 in all.
+    // (Right-looking by single columns -- the triangle in registers, a barrier per column -- was a chain of 48 steps of
+    // half a microsecond: 24 of this kernel's 35 us; with the tile in LDS and a square root + division + three barriers per
+    // column it had been 94 us.)
+    constexpr int LD = TB + 1, NB6 = TB / 6;
+    __shared__ double sL[TB * LD], sX[TB * LD], sRd[TB], sT[TB * TB / 4];
+    __shared__ double sS6[36], sL6[36], sLi6[36];
     __shared__ int s_bad;
     const int tid = threadIdx.x;
-    constexpr int LD = TB + 1;
-    double a[OWN];
-    int ri[OWN], ci[OWN];
+    for (int e = tid; e < TB * TB; e += 256) {
+        const int r = e / TB, c = e - TB * r;
+        sL[r * LD + c] = c <= r ? A[(size_t)(kb * TB + r) * ldr + kb * TB + c] : 0.;
+        sX[r * LD + c] = 0.;
+    }
+    if (tid == 0)
+        s_bad = 0;
+    __syncthreads();
+    for (int blk = 0; blk < NB6; blk++) {
+        const int o = 6 * blk;
+        if (tid < 64) {  // (1) the diagonal block: L11 into the tile, L11^-1 into the inverse's diagonal block
+            if (tid < 36) {
+                const int i = tid / 6, j = tid - 6 * i;
+                sS6[tid] = sL[(o + (i > j ? i : j)) * LD + o + (i > j ? j : i)];  // symmetric from the lower triangle
+            }
+            wave_sync();
+            if (!wave_chol6_inv(sS6, sL6, sLi6, tid) && tid == 0 && s_bad == 0)
+                s_bad = 1 + o;
+            if (tid < 36) {
+                const int i = tid / 6, j = tid - 6 * i;
+                sL[(o + i) * LD + o + j] = sL6[tid];  // zero above the diagonal
+                sX[(o + i) * LD + o + j] = sLi6[tid];
+            }
+        }
+        __syncthreads();
+        const int below = TB - o - 6;  // rows under the diagonal block
+        if (tid < below * 6) {         // (2) panel: (A21 L11^-T)[r][c] = sum_t A21[r][t] Li[c][t], t <= c
+            const int r = o + 6 + tid / 6, c = tid % 6;
+            double acc = 0.;
 #pragma unroll
-    for (int q = 0; q < OWN; q++) {
-        const int e = tid + 256 * q;
-        int r = 0;
-        if (e < NTRI) {
-            r = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+            for (int t = 0; t < 6; t++)
+                acc += t <= c ? sL[r * LD + o + t] * sLi6[6 * c + t] : 0.;
+            sT[tid] = acc;
+        }
+        __syncthreads();
+        if (tid < below * 6)
+            sL[(o + 6 + tid / 6) * LD + o + tid % 6] = sT[tid];
+        __syncthreads();
+        const int ntri = below * (below + 1) / 2;
+        for (int e = tid; e < ntri; e += 256) {  // (3) trailing update, lower triangle of the rest
+            int r = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
             while ((r + 1) * (r + 2) / 2 <= e)
                 r++;
             while (r * (r + 1) / 2 > e)
                 r--;
-        }
-        ri[q] = e < NTRI ? r : -1;
-        ci[q] = e < NTRI ? e - r * (r + 1) / 2 : -1;
-        a[q] = e < NTRI ? A[(size_t)(kb * TB + ri[q]) * ldr + kb * TB + ci[q]] : 0.;
-    }
-    if (tid == 0)
-        s_bad = 0;
-    for (int k = 0; k < TB; k++) {
-        double *sCol = sCol2[k & 1];  // two buffers take turns: the step after next rewrites this one, a barrier later
+            const int c = e - r * (r + 1) / 2;
+            const double *pr = sL + (o + 6 + r) * LD + o, *pc = sL + (o + 6 + c) * LD + o;
+            double acc = 0.;
 #pragma unroll
-        for (int q = 0; q < OWN; q++)
-            if (ci[q] == k)
-                sCol[ri[q]] = a[q];  // column k, rows k .. TB-1 (final: every earlier step has been applied)
+            for (int t = 0; t < 6; t++)
+                acc += pr[t] * pc[t];
+            sL[(o + 6 + r) * LD + o + 6 + c] -= acc;
+        }
         __syncthreads();
-        const double piv = sCol[k];
-        if (tid == 0) {
-            sPiv[k] = piv;
-            if (!(piv > 0))
-                s_bad = 1 + k;
-        }
-        double rp = __builtin_amdgcn_rcp(piv);  // v_rcp_f64 + one Newton step: the update's scale, not a result
-        rp = rp * (2. - piv * rp);
-#pragma unroll
-        for (int q = 0; q < OWN; q++)
-            if (ci[q] > k)
-                a[q] -= sCol[ri[q]] * sCol[ci[q]] * rp;
     }
-    __syncthreads();
-    // L = columns scaled by 1 / sqrt(pivot), into LDS for the inverse and out to the factor
-#pragma unroll
-    for (int q = 0; q < OWN; q++)
-        if (ri[q] >= 0)
-            sL[ri[q] * LD + ci[q]] = a[q] * (1. / sqrt(sPiv[ci[q]]));
-    __syncthreads();
     if (s_bad) {
         if (tid == 0)
             atomicMax(status, status_base + kb * TB + s_bad);
@@ -756,35 +787,11 @@ __global__ __launch_bounds__(256) void pg_dense_potf2_kernel(const double *__res
         const int r = e / TB, c = e - TB * r;
         Lo[(size_t)(kb * TB + r) * ldr + kb * TB + c] = c <= r ? sL[r * LD + c] : 0.;
     }
-    // L^-1 by halves: the eight 6 x 6 diagonal blocks are inverted side by side (a thread per column, six steps), then
-    // three levels put pairs of inverted halves together, X21 = -X22 (L21 X11), every entry of a product a thread's own
-    // dot product: two barriers per level, about sixty dependent multiply-adds in all.  (Forward substitution over the
-    // 48 rows -- four lanes per column, a hand-off per row -- was a chain of 48 x 12 steps: 20 of this kernel's 45 us.)
-    __shared__ double sX[TB * (TB + 1)], sRd[TB], sT[TB * TB / 4];
-    if (tid < TB)
-        sRd[tid] = 1. / sL[tid * LD + tid];  // 48 divisions side by side, not one at the end of every row's chain
-    for (int e = tid; e < TB * TB; e += 256) {
-        const int r = e / TB, c = e - TB * r;
-        sX[r * LD + c] = 0.;
-    }
-    __syncthreads();
-    if (tid < TB) {  // column c of diagonal block blk, kept in registers
-        const int blk = tid / 6, c = tid - 6 * blk, o = 6 * blk;
-        double x[6];
-#pragma unroll
-        for (int r = 0; r < 6; r++) {
-            double acc = r == c ? 1. : 0.;
-#pragma unroll
-            for (int k = 0; k < 6; k++)
-                if (k < r)
-                    acc -= sL[(o + r) * LD + o + k] * (k >= c ? x[k] : 0.);
-            x[r] = r < c ? 0. : acc * sRd[o + r];
-        }
-#pragma unroll
-        for (int r = 0; r < 6; r++)
-            sX[(o + r) * LD + o + c] = x[r];
-    }
-    __syncthreads();
+    // L^-1 by halves: the eight 6 x 6 diagonal blocks are inverted already (step 1 above), three levels put pairs of
+    // inverted halves together, X21 = -X22 (L21 X11), every entry of a product a thread's own dot product: two barriers
+    // per level.  (Forward substitution over the 48 rows -- four lanes per column, a hand-off per row -- was a chain of
+    // 48 x 12 steps: 20 us.)
+    (void)sRd;
     for (int h = 6; h < TB; h *= 2) {  // halves of h rows -> inverted blocks of 2 h rows
         const int pairs = TB / (2 * h), per = h * h;
         for (int e = tid; e < pairs * per; e += 256) {  // T = L21 X11 (X11 lower triangular: k >= j)
