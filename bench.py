@@ -456,7 +456,7 @@ def main():
         kf_rate = stats["keyframes"] / n_frames
         pmc = lk_pmc_constants(n_kpts)
         roof = {
-            "kernel": "lk_track_kernel<3>",
+            "kernel": "lk_track_kernel<3, 16>",
             # achieved / peak / frac price the kernel against the HBM roofline, the one the contract and
             # SURVEY.md 8d name; what LIMITS the kernel is vector-instruction issue (valu_* keys below)
             "bound": "valu",

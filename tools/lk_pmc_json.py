@@ -39,8 +39,8 @@ def main():
                          "bench line was printed with --no-kernel-timing")
     ap.add_argument("--source", default=None, help="text of the `source` field (the committed files the figures come from)")
     a = ap.parse_args()
-    sq = row_of(a.sq, "lk_track_kernel<3>")
-    hbm = row_of(a.hbm, "lk_track_kernel<3>")
+    sq = row_of(a.sq, "lk_track_kernel<3")   # <3> (rounds 1-2) or <3, 16> (jobs per launch as a template parameter)
+    hbm = row_of(a.hbm, "lk_track_kernel<3")
     bench = json.loads(open(a.bench_line).read().strip().splitlines()[-1])
     passes = bench["roofline"]["lk_passes_per_launch"]
     if a.lk_launches:   # a bench line printed without its instrumented pass carries the passes of the whole region
@@ -57,7 +57,7 @@ def main():
     # tracking launch itself
     ns_per_inst = mix4["kernel_ms"] * 1e6 / (mix4["insts_per_wave"] * mix4["waves_per_simd"])
     out = {
-        "kernel": "lk_track_kernel<3>",
+        "kernel": sq["kernel"],
         "kpts": a.kpts,
         "lk_hip_sha256": hashlib.sha256(open(os.path.join(ROOT, "ros_stereo_slam_amd", "csrc", "lk.hip"), "rb").read()).hexdigest(),
         "passes_per_launch_in_the_pmc_runs": passes,

@@ -33,6 +33,9 @@ done
 timeout -k 10 300 python3 bench.py --chunks-per-gpu 1 --steps 100 --warmup 5 --no-cpu-baseline --no-extras --no-kernel-timing > $OUT/one_plain.json 2> $OUT/one_plain.err || exit 5
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/r03_one -o one -- python3 bench.py --chunks-per-gpu 1 --steps 100 --warmup 5 --no-cpu-baseline --no-extras --no-kernel-timing > $OUT/one_bench.json 2> $OUT/one.err || exit 6
 keep $(find /tmp/r03_one -name "one_kernel_trace.csv") $OUT/one_trace.csv
+# the one-chunk stages from device time stamps (no profiler in the way: its interception makes the host the bottleneck of this run)
+SVO_CHAIN_STAMPS=1 timeout -k 10 300 python3 bench.py --chunks-per-gpu 1 --steps 200 --warmup 10 --no-cpu-baseline --no-extras --no-kernel-timing > $OUT/one_stamps.json 2> $OUT/one_stamps.err || exit 11
+grep "svo chain" $OUT/one_stamps.err > $OUT/one_stamps.txt
 timeout -k 10 300 python3 tools/pg_profile.py 4541 40 3 > $OUT/pg_plain.log 2>&1 || exit 7
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/r03_pg -o pg -- python3 tools/pg_profile.py 4541 40 1 > $OUT/pg_prof.log 2>&1 || exit 8
 grep "pg_\|Name" $(find /tmp/r03_pg -name "pg_kernel_stats.csv") > $OUT/pg_kernel_stats.csv
