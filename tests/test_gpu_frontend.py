@@ -167,6 +167,40 @@ def test_run_chunk_equals_frame_by_frame(ctx, pipeline):
     b.close()
 
 
+def test_pipelined_chunk_in_pieces_of_every_short_length(ctx):
+    """The four-stream pipeline runs its pyramids and the stereo path two frames ahead and rotates buffers by frame index:
+    runs of 1, 2, 3, 4 and 5 frames, one after the other on the same front-end, must hand their state over exactly --
+    every pose, count and keyframe decision equal to frame-by-frame svo_vo_track, and the reference set at the end."""
+    import torch
+    poses, frames = _frames(17)
+    dev = [(torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()) for l, r in frames]
+    torch.cuda.synchronize()
+    kw = dict(grid_step=30, keyframe_min_inliers=200, seed=11)
+    a = capi.VisualOdometry(ctx, 1241, 376, 3, **kw)
+    b = capi.VisualOdometry(ctx, 1241, 376, 3, **kw)
+    assert a.init(*dev[0]) == b.init(*dev[0])
+    pieces = [1, 2, 3, 4, 5, 1]
+    assert sum(pieces) == len(dev) - 1
+    ref = [a.track(*dev[i]) for i in range(1, len(dev))]
+    at = 1
+    kf_all = []
+    for n in pieces:
+        rc, done, R, t, inl, trk, kf = b.run_chunk([d[0] for d in dev[at:at + n]], [d[1] for d in dev[at:at + n]], pipeline=True)
+        assert rc == 0 and done == n
+        for i in range(n):
+            rc_i, R_i, t_i, inl_i, kf_i, trk_i = ref[at - 1 + i]
+            assert np.array_equal(R[i], R_i) and np.array_equal(t[i], t_i), f"frame {at + i}"
+            assert inl[i] == inl_i and trk[i] == trk_i and bool(kf[i]) == kf_i
+        kf_all.extend(bool(x) for x in kf)
+        at += n
+    assert any(kf_all) and not all(kf_all)
+    a2, a3 = a.reference()
+    b2, b3 = b.reference()
+    assert np.array_equal(a2, b2) and np.array_equal(a3, b3)
+    a.close()
+    b.close()
+
+
 def test_run_chunks_side_by_side_equals_one_by_one(ctx):
     """svo_vo_run_chunks (several chunks of the stream at once on one GPU, one context and one
     host thread each) must give every chunk exactly what svo_vo_run_chunk gives it alone."""
