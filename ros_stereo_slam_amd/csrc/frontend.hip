@@ -52,17 +52,21 @@ struct svo_vo {
         int *idx = nullptr, *cnt = nullptr;
     } lane;
     // what the lane hands to A and B, by frame % 3: the keyframe candidate's 2-D points, camera-frame points, count
-    float *h_x1[3] = {nullptr, nullptr, nullptr}, *h_xyz[3] = {nullptr, nullptr, nullptr};
+    float *h_x1[3] = {nullptr, nullptr, nullptr}, *h_xyz[3] = {nullptr, nullptr, nullptr}, *h_x2[3] = {nullptr, nullptr, nullptr};
     int *h_cnt = nullptr;
     // output of the tracking pass from the keyframe candidate's points (beside a2 / status of the pass from the tracked set)
-    float *a2k = nullptr;
+    float *a2k[3] = {nullptr, nullptr, nullptr};  // by target frame % 3 (stream E writes a frame's two frames ahead)
     // status bytes of both passes by frame parity: the PnP stream reads a frame's while A's next launch writes the next frame's
-    uint8_t *statusk = nullptr, *status_b = nullptr, *statusk_b = nullptr;
+    uint8_t *statusk[3] = {nullptr, nullptr, nullptr}, *status_b = nullptr;
     // tracked sets ready (A), tracking launch ended (A), cloud placed (B), refined (B: end of a run); by frame & 3: pyramids
     // built (D), stereo path done (C)
     hipEvent_t ev_flt = nullptr, ev_lk = nullptr, ev_dec = nullptr, ev_ref = nullptr;
     hipEvent_t ev_pyr[4] = {nullptr, nullptr, nullptr, nullptr}, ev_p1[4] = {nullptr, nullptr, nullptr, nullptr},
-               ev_p3[4] = {nullptr, nullptr, nullptr, nullptr};
+               ev_p3[4] = {nullptr, nullptr, nullptr, nullptr}, ev_e[4] = {nullptr, nullptr, nullptr, nullptr}, ev_c[4] = {nullptr, nullptr, nullptr, nullptr};
+    // the two hand-overs on a frame's critical path (tracked sets ready: A -> B; decided: B -> A) as stream memory
+    // operations on signal memory (hipStreamWriteValue32 / hipStreamWaitValue32: half the latency of an event), values count up
+    uint64_t *sig_flt = nullptr, *sig_dec = nullptr;
+    uint32_t sig_n = 0;
     bool pipe_ready = false;
     // second set of tracked points / inlier list: frame t's refinement reads its set while frame t+1's filters write theirs
     float *trk2d_b = nullptr, *trk3d_b = nullptr;
@@ -279,16 +283,24 @@ int stereo_part1_spec(svo_vo *v, svo_vo::StereoLane &L, svo_pyramid *left, svo_p
     float *x1 = v->h_x1[slot];
     int *cnt = v->h_cnt + slot;
     const svo_compact_job c1 = {stt, n, d_n, {pts, trk, nullptr}, {o1, o2, nullptr}, {2, 2, 0}, L.cnt + 3, run};
-    const svo_compact_job c2 = {L.mask, n, L.cnt + 3, {o1, o2, nullptr}, {x1, L.x2, nullptr}, {2, 2, 0}, cnt};
+    const svo_compact_job c2 = {L.mask, n, L.cnt + 3, {o1, o2, nullptr}, {x1, v->h_x2[slot], nullptr}, {2, 2, 0}, cnt};
     const uint64_t seed = v->prm.seed + 8ull * (uint64_t)frame_no + 3;  // stage_seed(frame_no, 3)
     const svo_fransac_job fj = {o1, o2, n, L.cnt + 3, v->prm.f_thr_stereo, 0.99, 1000, seed, L.mask, nullptr, nullptr,
                                 nullptr, &c2, run};
     if ((rc = svo_launch_compact_batch(cs, 1, &c1)) || (rc = svo_launch_fransac_batch(cs, 1, &fj)))
         return rc;
-    const svo_tri_job tj = {x1, L.x2, n, cnt, v->h_xyz[slot], nullptr, nullptr, nullptr, nullptr};
+    return SVO_OK;
+}
+
+// ... its last stage, the DLT triangulation of the filtered pairs in the camera frame (src/triangulation.cpp:142-160), on
+// the context's current stream (the pipelined chunk runs it on the pyramid stream: the stereo stream is the busiest)
+int stereo_tri_spec(svo_vo *v, int slot)
+{
+    const int n = grid_axis(v->w, v->prm.grid_step) * grid_axis(v->h, v->prm.grid_step);
+    const svo_tri_job tj = {v->h_x1[slot], v->h_x2[slot], n, v->h_cnt + slot, v->h_xyz[slot], nullptr, nullptr, nullptr, nullptr};
     double P1[12], P2[12];
     svo_stereo_projections(v->prm.fx, v->prm.fy, v->prm.cx, v->prm.cy, v->prm.baseline, P1, P2);
-    return svo_launch_triangulate_batch(cs, P1, P2, 1, &tj);
+    return svo_launch_triangulate_batch(v->ctx, P1, P2, 1, &tj);
 }
 
 // ... and what is left once the frame is decided, only when the device flag says keyframe: what = 1, the hand-over of
@@ -469,13 +481,17 @@ int svo_vo_destroy(svo_vo *v)
     svo_pyramid_destroy(v->ctx, v->pyr_right);
     svo_pyramid_destroy(v->ctx, v->pyr_next);
     svo_pyramid_destroy(v->ctx, v->pyr_right2);
+    for (void *sg : {(void *)v->sig_flt, (void *)v->sig_dec})
+        if (sg)
+            (void)hipFree(sg);
     for (hipStream_t st : {v->stream_b, v->stream_p})
         if (st) {
             (void)hipStreamSynchronize(st);
             (void)hipStreamDestroy(st);
         }
     for (hipEvent_t e : {v->ev_flt, v->ev_lk, v->ev_dec, v->ev_ref, v->ev_pyr[0], v->ev_pyr[1], v->ev_pyr[2], v->ev_pyr[3], v->ev_p1[0],
-                         v->ev_p1[1], v->ev_p1[2], v->ev_p1[3], v->ev_p3[0], v->ev_p3[1], v->ev_p3[2], v->ev_p3[3]})
+                         v->ev_p1[1], v->ev_p1[2], v->ev_p1[3], v->ev_p3[0], v->ev_p3[1], v->ev_p3[2], v->ev_p3[3], v->ev_e[0], v->ev_e[1],
+                         v->ev_e[2], v->ev_e[3], v->ev_c[0], v->ev_c[1], v->ev_c[2], v->ev_c[3]})
         if (e)
             (void)hipEventDestroy(e);
     {
@@ -486,7 +502,8 @@ int svo_vo_destroy(svo_vo *v)
         }
         void *sb[] = {L.a2,        L.b2,        L.c2,        L.d2,         L.x2,         L.resp,   L.status,   L.st2,      L.mask,
                       L.idx,       L.cnt,       v->h_x1[0],  v->h_x1[1],   v->h_xyz[0],  v->h_xyz[1], v->h_cnt, v->trk2d_b, v->trk3d_b,
-                      v->idx_b,    v->a2k,      v->statusk,  v->h_x1[2],   v->h_xyz[2], v->status_b, v->statusk_b};
+                      v->idx_b,    v->a2k[0],   v->statusk[0], v->h_x1[2],  v->h_xyz[2], v->status_b, v->a2k[1],  v->a2k[2],
+                      v->statusk[1], v->statusk[2], v->h_x2[0], v->h_x2[1], v->h_x2[2]};
         for (void *b : sb)
             if (b)
                 (void)hipFree(b);
@@ -787,8 +804,8 @@ static int chain_lk(svo_ctx *ctx, int k, svo_vo *const *vs, svo_pyramid *const *
 // st_par: which of the two status-byte buffers the frame's tracking passes wrote (pipelined chunk).
 // kf_slot >= 0 (pipelined chunk, one front-end): the 2-D half only -- the 3-D column follows on the PnP stream,
 // chain_filters_3d -- and, when the previous frame was a keyframe (the device flag), from the sets of the tracking pass
-// that started at its points: reference points = hand-over set kf_slot, tracked points / status bytes = a2k / statusk.
-static int chain_filters(svo_ctx *ctx, int k, svo_vo *const *vs, int set = 0, int kf_slot = -1, int st_par = 0)
+// that started at its points: reference points = hand-over set kf_slot, tracked points / status bytes = a2k / statusk [kbuf].
+static int chain_filters(svo_ctx *ctx, int k, svo_vo *const *vs, int set = 0, int kf_slot = -1, int st_par = 0, int kbuf = 0)
 {
     svo_compact_job c1[SVO_LK_MAX_JOBS], c2[SVO_LK_MAX_JOBS];
     svo_fransac_job fj[SVO_LK_MAX_JOBS];
@@ -799,9 +816,9 @@ static int chain_filters(svo_ctx *ctx, int k, svo_vo *const *vs, int set = 0, in
             c1[a] = {st_par ? v->status_b : v->status, v->cap, &v->d_chain->nref, {v->ref2d, v->a2, nullptr},
                      {v->b2, v->c2, nullptr}, {2, 2, 0}, v->d_cnt, run};
             c1[a].alt_sel = &v->d_chain->kf;
-            c1[a].alt_mask = st_par ? v->statusk_b : v->statusk;
+            c1[a].alt_mask = v->statusk[kbuf];
             c1[a].alt_in[0] = v->h_x1[kf_slot];
-            c1[a].alt_in[1] = v->a2k;
+            c1[a].alt_in[1] = v->a2k[kbuf];
             c1[a].alt_d_n = v->h_cnt + kf_slot;
             c2[a] = {v->mask, v->cap, v->d_cnt, {v->c2, nullptr, nullptr}, {set ? v->trk2d_b : v->trk2d, nullptr, nullptr},
                      {2, 0, 0}, v->d_cnt + (set ? 9 : 1)};
@@ -836,14 +853,14 @@ static int chain_filters(svo_ctx *ctx, int k, svo_vo *const *vs, int set = 0, in
 // The 3-D column of the two filters above, for a pipelined chunk, on the PnP stream once the frame's status bytes and
 // F-RANSAC mask exist: reference points (by then the keyframe's cloud has been placed, if the previous frame was one)
 // -> status filter -> mask filter -> the tracked 3-D set the PnP reads.
-static int chain_filters_3d(svo_ctx *ctx, svo_vo *v, int set, int st_par)
+static int chain_filters_3d(svo_ctx *ctx, svo_vo *v, int set, int st_par, int kbuf)
 {
     const int *run = &v->d_chain->run;
     svo_compact_job c[2];
     c[0] = {st_par ? v->status_b : v->status, v->cap, &v->d_chain->nref, {v->ref3d, nullptr, nullptr}, {v->a3, nullptr, nullptr},
             {3, 0, 0}, v->d_cnt + 10, run};
     c[0].alt_sel = &v->d_chain->kf;  // still the previous frame's decision
-    c[0].alt_mask = st_par ? v->statusk_b : v->statusk;
+    c[0].alt_mask = v->statusk[kbuf];
     c[1] = {v->mask, v->cap, v->d_cnt + 10, {v->a3, nullptr, nullptr}, {set ? v->trk3d_b : v->trk3d, nullptr, nullptr},
             {3, 0, 0}, v->d_cnt + 11, run};
     int rc;
@@ -930,8 +947,13 @@ static int chain_enqueue(ChainRun *const *runs, int k, bool pipeline)
         ChainRun &r = *runs[0];
         svo_vo *v = r.v;
         hipStream_t sA = ctx->stream, sB = v->stream_b, sC = v->lane.ctx->stream, sD = v->stream_p;
+        hipStream_t sE = sD;  // the keyframe passes share the pyramids' stream: a fifth busy queue costs more than it brings
         // debug: device time stamps between the stages (8 per frame: A0 before filters, A1 after, A2 after the tracking
         // launch, B0 before hypotheses, B1 decided, B2 handed over, C0 / C1 around the stereo path)
+        // SVO_PIPE_MEMOPS=1: the two hand-overs as stream memory operations instead of events.  Measured: B starts 5 us after
+        // the filters instead of 11-17, frames/s unchanged (3 071 against 3 084) -- the hops are not what limits a frame; the
+        // API is marked beta, so events stay the default.
+        static const bool memops = getenv("SVO_PIPE_MEMOPS") ? atoi(getenv("SVO_PIPE_MEMOPS")) != 0 : false;
         static const bool stamps = getenv("SVO_CHAIN_STAMPS") != nullptr;
         static unsigned long long *d_stamps = nullptr;
         const int max_stamp_frames = 4096;
@@ -967,11 +989,48 @@ static int chain_enqueue(ChainRun *const *runs, int k, bool pipeline)
             SVO_HIP(hipStreamWaitEvent(sC, v->ev_pyr[g & 3], 0));
             if ((rc = stereo_part1_spec(v, v->lane, left, right[g & 1], frame0 + g + 1, g % 3)))
                 return rc;
-            SVO_HIP(hipEventRecord(v->ev_p1[g & 3], sC));
+            SVO_HIP(hipEventRecord(v->ev_c[g & 3], sC));
+            return SVO_OK;
+        };
+        // ... and its triangulation, on D
+        auto triangulate = [&](int g) -> int {
+            SVO_HIP(hipStreamWaitEvent(sD, v->ev_c[g & 3], 0));
+            {
+                OnStream on(ctx, sD);
+                if ((rc = stereo_tri_spec(v, g % 3)))
+                    return rc;
+            }
+            SVO_HIP(hipEventRecord(v->ev_p1[g & 3], sD));
+            return SVO_OK;
+        };
+        // E: the tracking pass into frame g from the 2-D points the stereo path of frame g-1 has left -- what frame g starts
+        // from if g-1 turns out to be a keyframe.  Nothing in it depends on a decision or a tracked set: it runs as soon as
+        // that stereo path and the pyramids of g exist, a frame and a half before the filters that may read it.
+        auto kf_pass = [&](int g, svo_pyramid *from, svo_pyramid *into) -> int {
+            SVO_HIP(hipStreamWaitEvent(sE, v->ev_c[(g - 1) & 3], 0));  // the 2-D points of that stereo path
+            SVO_HIP(hipStreamWaitEvent(sE, v->ev_pyr[g & 3], 0));
+            LkJob q;
+            q.prev = from->dev;
+            q.next = into->dev;
+            q.dprev = from->dbase;
+            q.prev_pts = v->h_x1[(g - 1) % 3];
+            q.n_cap = v->cap;
+            q.d_n = v->h_cnt + (g - 1) % 3;
+            q.next_pts = v->a2k[g % 3];
+            q.status = v->statusk[g % 3];
+            q.err = nullptr;
+            q.min_eig = nullptr;
+            q.gate = run;
+            {
+                OnStream on(ctx, sE);
+                if ((rc = svo_launch_lk_batch(ctx, 1, &q, from)))
+                    return rc;
+            }
+            SVO_HIP(hipEventRecord(v->ev_e[g & 3], sE));
             return SVO_OK;
         };
         // prologue: the chain state is on its way (chain_prepare, on A); the pyramids of frames 0 and 1, the tracking
-        // pass into frame 0 from the reference set, the stereo paths of frames 0 and 1
+        // pass into frame 0 from the reference set, the stereo paths of frames 0 and 1, the keyframe pass into frame 1
         SVO_HIP(hipEventRecord(v->ev_flt, sA));
         SVO_HIP(hipStreamWaitEvent(sD, v->ev_flt, 0));
         if ((rc = pyramids(0, cur)) || (nf > 1 && (rc = pyramids(1, nxt))))
@@ -983,22 +1042,24 @@ static int chain_enqueue(ChainRun *const *runs, int k, bool pipeline)
             gates[0] = run;
             if ((rc = chain_lk(ctx, 1, vs, &ref, &cur, pts, dn, gates)))
                 return rc;
-            if ((rc = stereo(0, cur)) || (nf > 1 && (rc = stereo(1, nxt))))
+            if ((rc = stereo(0, cur)) || (nf > 1 && (rc = stereo(1, nxt))) || (rc = triangulate(0)) ||
+                (nf > 1 && (rc = kf_pass(1, cur, nxt))))
                 return rc;
         }
+        if (nf > 1)
+            SVO_HIP(hipStreamWaitEvent(sA, v->ev_pyr[1], 0));  // the first tracking launch's target
         for (int f = 0; f < nf; f++) {
             v->frame++;
             const int set = f & 1, slot = f % 3;
             const bool more = f + 1 < nf;
             auto t0 = tick();
-            if (more) {  // what the tracking launch below waits for, asked for here: both have long happened
-                SVO_HIP(hipStreamWaitEvent(sA, v->ev_pyr[(f + 1) & 3], 0));
-                SVO_HIP(hipStreamWaitEvent(sA, v->ev_p1[f & 3], 0));  // the 2-D points of this frame's stereo path
-            }
             stamp(sA, f, 0);
             // the 2-D half of the filters; the previous frame a keyframe: from the sets of the pass that started at its points
-            if ((rc = chain_filters(ctx, 1, vs, set, (f + 2) % 3, f & 1)))
+            if ((rc = chain_filters(ctx, 1, vs, set, (f + 2) % 3, f & 1, f % 3)))
                 return rc;
+            const uint32_t tick_no = ++v->sig_n;  // this frame's value of the two signals
+            if (memops)
+                SVO_HIP(hipStreamWriteValue32(sA, v->sig_flt, tick_no, 0));
             SVO_HIP(hipEventRecord(v->ev_flt, sA));
             stamp(sA, f, 1);
             tock(0, t0);
@@ -1007,13 +1068,19 @@ static int chain_enqueue(ChainRun *const *runs, int k, bool pipeline)
             // its sets handed over; any other frame is refined after that.  (In order on B: the next frame's 3-D column
             // follows the hand-over it reads, its hypotheses follow this frame's refinement, which reads the workspace
             // they are written to.)
-            SVO_HIP(hipStreamWaitEvent(sB, v->ev_flt, 0));
+            if (memops)
+                SVO_HIP(hipStreamWaitValue32(sB, v->sig_flt, tick_no, hipStreamWaitValueGte, 0xffffffffu));
+            else
+                SVO_HIP(hipStreamWaitEvent(sB, v->ev_flt, 0));
             {
                 OnStream on(ctx, sB);
                 stamp(sB, f, 3);
-                if ((rc = chain_filters_3d(ctx, v, set, f & 1)) || (rc = chain_pnp(ctx, 1, vs, set, true)))
+                if ((rc = chain_filters_3d(ctx, v, set, f & 1, f % 3)) || (rc = chain_pnp(ctx, 1, vs, set, true)))
                     return rc;
-                SVO_HIP(hipEventRecord(v->ev_dec, sB));
+                if (memops)
+                    SVO_HIP(hipStreamWriteValue32(sB, v->sig_dec, tick_no, 0));
+                else
+                    SVO_HIP(hipEventRecord(v->ev_dec, sB));
                 stamp(sB, f, 4);
                 SVO_HIP(hipStreamWaitEvent(sB, v->ev_p1[f & 3], 0));  // the stereo path of this frame: long done
                 if ((rc = chain_pnp_refine(ctx, vs, set, true)) || (rc = stereo_part2_spec(v, cur, slot, 3)))
@@ -1029,37 +1096,35 @@ static int chain_enqueue(ChainRun *const *runs, int k, bool pipeline)
             // the previous iteration (before these filters on A), the stereo path of frame f-1 (C is in order: frame f's
             // is done) and the colours of keyframe f-1 (its hand-over on B); the right pyramid it overwrites is the one
             // the stereo path of frame f has read
-            if (f + 2 < nf) {
+            if (more) {
                 SVO_HIP(hipStreamWaitEvent(sD, v->ev_flt, 0));
-                SVO_HIP(hipStreamWaitEvent(sD, v->ev_p1[f & 3], 0));
-                if (f > 0)
+                SVO_HIP(hipStreamWaitEvent(sD, v->ev_c[f & 3], 0));
+                if (f > 0)  // ... and the hand-over of keyframe f-2 (B is in order), whose cloud's buffer the triangulation below writes
                     SVO_HIP(hipStreamWaitEvent(sD, v->ev_p3[(f - 1) & 3], 0));
-                if ((rc = pyramids(f + 2, ref)))
+                if (f + 2 < nf && (rc = pyramids(f + 2, ref)))
+                    return rc;
+                if ((rc = triangulate(f + 1)))  // the stereo path of the next frame ends here (its 2-D part is long done)
                     return rc;
             }
             tock(2, t0);
             t0 = tick();
-            if (more) {  // A: both tracking passes into frame f+1
-                LkJob lk2[2];
-                for (int a = 0; a < 2; a++) {
-                    LkJob &q = lk2[a];
-                    q.prev = cur->dev;
-                    q.next = nxt->dev;
-                    q.dprev = cur->dbase;
-                    q.n_cap = v->cap;
-                    q.err = nullptr;
-                    q.min_eig = nullptr;
-                    q.gate = run;
-                }
-                lk2[0].prev_pts = set ? v->trk2d_b : v->trk2d;
-                lk2[0].d_n = v->d_cnt + (set ? 9 : 1);
-                lk2[0].next_pts = v->a2;
-                lk2[0].status = (f + 1) & 1 ? v->status_b : v->status;
-                lk2[1].prev_pts = v->h_x1[slot];
-                lk2[1].d_n = v->h_cnt + slot;
-                lk2[1].next_pts = v->a2k;
-                lk2[1].status = (f + 1) & 1 ? v->statusk_b : v->statusk;
-                if ((rc = svo_launch_lk_batch(ctx, 2, lk2, cur)))
+            if (more) {  // A: the tracking pass into frame f+1 from the tracked set
+                pts[0] = set ? v->trk2d_b : v->trk2d;
+                dn[0] = v->d_cnt + (set ? 9 : 1);
+                gates[0] = run;
+                LkJob q;
+                q.prev = cur->dev;
+                q.next = nxt->dev;
+                q.dprev = cur->dbase;
+                q.prev_pts = pts[0];
+                q.n_cap = v->cap;
+                q.d_n = dn[0];
+                q.next_pts = v->a2;
+                q.status = (f + 1) & 1 ? v->status_b : v->status;
+                q.err = nullptr;
+                q.min_eig = nullptr;
+                q.gate = run;
+                if ((rc = svo_launch_lk_batch(ctx, 1, &q, cur)))
                     return rc;
                 stamp(sA, f, 2);
                 SVO_HIP(hipEventRecord(v->ev_lk, sA));
@@ -1075,10 +1140,26 @@ static int chain_enqueue(ChainRun *const *runs, int k, bool pipeline)
                     if ((rc = stereo(f + 2, ref)))  // `ref`: where D has just been told to build frame f+2
                         return rc;
                     stamp(sC, f, 7);
+                    // E: the keyframe pass from frame f+1 into frame f+2, when A's launch has ended too.  Its output
+                    // buffer (target % 3) was last read by the filters of frame f-1 on A and B, before the decision A
+                    // waited for at the end of the previous iteration.
+                    SVO_HIP(hipStreamWaitEvent(sE, v->ev_lk, 0));
+                    if ((rc = kf_pass(f + 2, nxt, ref)))
+                        return rc;
                 }
                 tock(4, t0);
             }
-            SVO_HIP(hipStreamWaitEvent(sA, v->ev_dec, 0));  // the next filters: the keyframe flag, a plain frame's 2-D set
+            // What the next iteration needs of the streams that run ahead is waited for HERE, before the wait for the
+            // decision: every wait is a barrier packet of ~7 us on the stream, and while B decides this stream is idle
+            // anyway -- after the decision nothing but the filters' launches is left.
+            if (f + 2 < nf)
+                SVO_HIP(hipStreamWaitEvent(sA, v->ev_pyr[(f + 2) & 3], 0));  // the next tracking launch's target
+            if (more)
+                SVO_HIP(hipStreamWaitEvent(sA, v->ev_e[(f + 1) & 3], 0));    // the keyframe pass the next filters may read
+            if (memops)  // the next filters: the keyframe flag, a plain frame's 2-D set
+                SVO_HIP(hipStreamWaitValue32(sA, v->sig_dec, tick_no, hipStreamWaitValueGte, 0xffffffffu));
+            else
+                SVO_HIP(hipStreamWaitEvent(sA, v->ev_dec, 0));
             svo_pyramid *t = ref;  // referenceImg = currentImage (src/VisualSLAM.cpp:151)
             ref = cur;
             cur = nxt;
@@ -1379,18 +1460,27 @@ int svo_vo_run_chunk(svo_vo *v, const uint8_t *const *lefts, const uint8_t *cons
             (!L.cnt && (rc = dev_alloc(&L.cnt, 16))))
             return rc;
         for (int k = 0; k < 3; k++)
-            if ((!v->h_x1[k] && (rc = dev_alloc(&v->h_x1[k], n * 2))) || (!v->h_xyz[k] && (rc = dev_alloc(&v->h_xyz[k], n * 3))))
+            if ((!v->h_x2[k] && (rc = dev_alloc(&v->h_x2[k], n * 2))) || (!v->h_x1[k] && (rc = dev_alloc(&v->h_x1[k], n * 2))) || (!v->h_xyz[k] && (rc = dev_alloc(&v->h_xyz[k], n * 3))))
                 return rc;
         if ((!v->h_cnt && (rc = dev_alloc(&v->h_cnt, 16))) || (!v->trk2d_b && (rc = dev_alloc(&v->trk2d_b, n * 2))) ||
             (!v->trk3d_b && (rc = dev_alloc(&v->trk3d_b, n * 3))) || (!v->idx_b && (rc = dev_alloc(&v->idx_b, n))) ||
-            (!v->a2k && (rc = dev_alloc(&v->a2k, n * 2))) || (!v->statusk && (rc = dev_alloc(&v->statusk, n))) ||
-            (!v->status_b && (rc = dev_alloc(&v->status_b, n))) || (!v->statusk_b && (rc = dev_alloc(&v->statusk_b, n))))
+            (!v->status_b && (rc = dev_alloc(&v->status_b, n))))
             return rc;
+        for (int k = 0; k < 3; k++)
+            if ((!v->a2k[k] && (rc = dev_alloc(&v->a2k[k], n * 2))) || (!v->statusk[k] && (rc = dev_alloc(&v->statusk[k], n))))
+                return rc;
         for (hipEvent_t *e : {&v->ev_flt, &v->ev_lk, &v->ev_dec, &v->ev_ref, &v->ev_pyr[0], &v->ev_pyr[1], &v->ev_pyr[2], &v->ev_pyr[3],
                               &v->ev_p1[0], &v->ev_p1[1], &v->ev_p1[2], &v->ev_p1[3], &v->ev_p3[0], &v->ev_p3[1], &v->ev_p3[2],
-                              &v->ev_p3[3]})
+                              &v->ev_p3[3], &v->ev_e[0], &v->ev_e[1], &v->ev_e[2], &v->ev_e[3], &v->ev_c[0], &v->ev_c[1],
+                              &v->ev_c[2], &v->ev_c[3]})
             if (!*e)
                 SVO_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        if (!v->sig_flt) {
+            SVO_HIP(hipExtMallocWithFlags(reinterpret_cast<void **>(&v->sig_flt), 8, hipMallocSignalMemory));
+            SVO_HIP(hipExtMallocWithFlags(reinterpret_cast<void **>(&v->sig_dec), 8, hipMallocSignalMemory));
+            SVO_HIP(hipMemset(v->sig_flt, 0, 8));
+            SVO_HIP(hipMemset(v->sig_dec, 0, 8));
+        }
         v->pipe_ready = true;
     }
     if (v->nref < 5) {

@@ -161,6 +161,40 @@ int main()
         CK(hipEventElapsedTime(&ms, e0, e1));
         report("eager ping-pong across two streams (event each way)", 1, t1 - t0, ms, 1000);
     }
+    // the same ping-pong with stream memory operations instead of events: hipStreamWriteValue32 after the kernel on one
+    // stream, hipStreamWaitValue32 before the kernel on the other (signal memory, values counting up)
+    {
+        int can = 0;
+        CK(hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, 0));
+        printf("{\"case\": \"hipDeviceAttributeCanUseStreamWaitValue\", \"value\": %d}\n", can);
+        if (can) {
+            hipStream_t sb;
+            CK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
+            uint64_t *sig = nullptr, *sig2 = nullptr;  // signal memory comes in single 8-byte objects
+            CK(hipExtMallocWithFlags((void **)&sig, 8, hipMallocSignalMemory));
+            CK(hipExtMallocWithFlags((void **)&sig2, 8, hipMallocSignalMemory));
+            CK(hipMemset(sig, 0, 8));
+            CK(hipMemset(sig2, 0, 8));
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0, st));
+            const double t0 = now();
+            for (uint32_t i = 1; i <= 500; i++) {
+                hipLaunchKernelGGL(k_small, dim3(1), dim3(64), 0, st, d);
+                CK(hipStreamWriteValue32(st, sig, i, 0));
+                CK(hipStreamWaitValue32(sb, sig, i, hipStreamWaitValueGte, 0xffffffffu));
+                hipLaunchKernelGGL(k_small, dim3(1), dim3(64), 0, sb, d + 1);
+                CK(hipStreamWriteValue32(sb, sig2, i, 0));
+                CK(hipStreamWaitValue32(st, sig2, i, hipStreamWaitValueGte, 0xffffffffu));
+            }
+            const double t1 = now();
+            CK(hipEventRecord(e1, st));
+            CK(hipStreamSynchronize(st));
+            CK(hipStreamSynchronize(sb));
+            float ms = 0;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            report("eager ping-pong across two streams (write value / wait value each way)", 1, t1 - t0, ms, 1000);
+        }
+    }
     // host round trip: kernel -> system-scope tag -> host spin -> next launch
     {
         CK(hipStreamSynchronize(st));
