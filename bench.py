@@ -522,8 +522,9 @@ def main():
                 "chunks_per_gpu": M,
                 "chunks_per_context": G,
                 "frames_per_chunk": L,
-                "pipeline": "four HIP streams per chunk: filters + both candidate tracking passes | PnP, decision, refinement, "
-                            "keyframe hand-over | stereo path two frames ahead | pyramids two frames ahead" if pipeline
+                "pipeline": "four HIP streams per chunk: filters + tracking pass from the tracked set | PnP, decision, refinement, "
+                            "keyframe hand-over | stereo path two frames ahead | pyramids, triangulation, tracking pass from the "
+                            "keyframe candidate, ahead" if pipeline
                             else "one in-order HIP stream per context",
                 "keyframe_rate": kf_rate,
                 "frames_per_step": M * world,

@@ -324,9 +324,10 @@ int svo_vo_track(svo_vo *vo, const uint8_t *left, const uint8_t *right, int mem,
  * inliers_out, tracked_out, keyframe_out.  The frame policy (retry / lost thresholds, keyframe rule,
  * reference hand-over, pose composition) runs on the device; the host enqueues the whole chunk and
  * reads the per-frame records once.  pipeline != 0 (device images only) runs the chunk on four HIP
- * streams: filters + both candidate tracking passes into the next frame | PnP, the decision, the
- * refinement and a keyframe's hand-over | the stereo path of every frame, two frames ahead | the
- * pyramids, two frames ahead (the process needs a hardware queue per stream: GPU_MAX_HW_QUEUES >= 5);
+ * streams: filters + the tracking pass from the tracked set | PnP, the decision, the refinement and
+ * a keyframe's hand-over | the stereo path of every frame, two frames ahead | pyramids, triangulation
+ * and the tracking pass from the keyframe candidate's points, ahead as well (the process needs a
+ * hardware queue per stream: GPU_MAX_HW_QUEUES >= 5);
  * results are identical.  Stops at tracking loss (SVO_ERR_TRACKING_LOST, *n_done frames completed).  */
 int svo_vo_run_chunk(svo_vo *vo, const uint8_t *const *lefts, const uint8_t *const *rights, int n_frames,
                      int mem, int pipeline, double *R_out, double *t_out, int *inliers_out,
