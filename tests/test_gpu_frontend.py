@@ -167,15 +167,17 @@ def test_run_chunk_equals_frame_by_frame(ctx, pipeline):
     b.close()
 
 
-def test_pipelined_chunk_in_pieces_of_every_short_length(ctx):
+@pytest.mark.parametrize("grid_step,anms_keep,kf_min", [(30, 0, 200), (10, 4096, 2000), (7, 8192, 4000)])
+def test_pipelined_chunk_in_pieces_of_every_short_length(ctx, grid_step, anms_keep, kf_min):
     """The four-stream pipeline runs its pyramids and the stereo path two frames ahead and rotates buffers by frame index:
     runs of 1, 2, 3, 4 and 5 frames, one after the other on the same front-end, must hand their state over exactly --
-    every pose, count and keyframe decision equal to frame-by-frame svo_vo_track, and the reference set at the end."""
+    every pose, count and keyframe decision equal to frame-by-frame svo_vo_track, and the reference set at the end.
+    At a coarse lattice and at the benchmarked shapes (4096 keypoints: the metric; 8192: configs[4])."""
     import torch
     poses, frames = _frames(17)
     dev = [(torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda()) for l, r in frames]
     torch.cuda.synchronize()
-    kw = dict(grid_step=30, keyframe_min_inliers=200, seed=11)
+    kw = dict(grid_step=grid_step, anms_keep=anms_keep, keyframe_min_inliers=kf_min, seed=11)
     a = capi.VisualOdometry(ctx, 1241, 376, 3, **kw)
     b = capi.VisualOdometry(ctx, 1241, 376, 3, **kw)
     assert a.init(*dev[0]) == b.init(*dev[0])
