@@ -195,6 +195,41 @@ int main()
             report("eager ping-pong across two streams (write value / wait value each way)", 1, t1 - t0, ms, 1000);
         }
     }
+    // the event ping-pong captured once as a hipGraph (fork / join through captured events) and replayed: what a graph of a
+    // multi-stream frame would make of the cross-stream hand-overs
+    {
+        hipStream_t sb;
+        CK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
+        hipEvent_t ev, ev2;
+        CK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        CK(hipEventCreateWithFlags(&ev2, hipEventDisableTiming));
+        hipGraph_t g;
+        hipGraphExec_t ge;
+        CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        for (int i = 0; i < 20; i++) {
+            hipLaunchKernelGGL(k_small, dim3(1), dim3(64), 0, st, d);
+            CK(hipEventRecord(ev, st));
+            CK(hipStreamWaitEvent(sb, ev, 0));
+            hipLaunchKernelGGL(k_small, dim3(1), dim3(64), 0, sb, d + 1);
+            CK(hipEventRecord(ev2, sb));
+            CK(hipStreamWaitEvent(st, ev2, 0));
+        }
+        CK(hipStreamEndCapture(st, &g));
+        CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        for (int i = 0; i < 5; i++) CK(hipGraphLaunch(ge, st));
+        CK(hipStreamSynchronize(st));
+        CK(hipEventRecord(e0, st));
+        const double t0 = now();
+        for (int i = 0; i < 25; i++) CK(hipGraphLaunch(ge, st));
+        const double t1 = now();
+        CK(hipEventRecord(e1, st));
+        CK(hipStreamSynchronize(st));
+        float ms = 0;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        report("graph of the two-stream ping-pong (20 pairs), replayed", 1, t1 - t0, ms, 1000);
+        CK(hipGraphExecDestroy(ge));
+        CK(hipGraphDestroy(g));
+    }
     // host round trip: kernel -> system-scope tag -> host spin -> next launch
     {
         CK(hipStreamSynchronize(st));
