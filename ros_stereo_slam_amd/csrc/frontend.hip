@@ -1350,52 +1350,12 @@ static int chain_run(ChainRun *const *runs, int k, bool pipeline)
         if ((rc = chain_prepare(*runs[a])))
             return rc;
     static const bool debug = getenv("SVO_CHAIN_DEBUG") != nullptr;  // host time of the enqueue against the device's
-    auto t0 = std::chrono::steady_clock::now();
-    // Experiment (SVO_CHAIN_GRAPH=1, one pipelined chunk): the whole chunk's launches and events captured as ONE hipGraph
-    // and launched once -- every parameter is baked for exactly these frames, so the results are the eager run's; what it
-    // measures is what the graph executor makes of the four streams.  Capture failure: eager, with a note.
-    static const bool as_graph = getenv("SVO_CHAIN_GRAPH") != nullptr;
-    bool launched_graph = false;
-    static int pipelined_runs = 0;  // the first one allocates work buffers (not allowed inside a capture): eager
-    if (as_graph && pipeline && k == 1 && pipelined_runs++ > 0) {
-        hipGraph_t g = nullptr;
-        hipGraphExec_t ge = nullptr;
-        hipError_t e = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed);
-        if (e == hipSuccess) {
-            rc = chain_enqueue(runs, k, pipeline);
-            e = hipStreamEndCapture(ctx->stream, &g);
-            if (rc == SVO_OK && e == hipSuccess && g) {
-                const auto tc = std::chrono::steady_clock::now();
-                e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
-                const auto ti = std::chrono::steady_clock::now();
-                if (e == hipSuccess) {
-                    t0 = std::chrono::steady_clock::now();
-                    e = hipGraphLaunch(ge, ctx->stream);
-                    launched_graph = e == hipSuccess;
-                    fprintf(stderr, "[svo chain] graph of %d frames: instantiate %.1f ms\n", runs[0]->n_frames,
-                            std::chrono::duration<double, std::milli>(ti - tc).count());
-                }
-            }
-            if (!launched_graph)
-                fprintf(stderr, "[svo chain] graph experiment failed (%s, rc %d): %s\n", hipGetErrorString(e), rc,
-                        "the chunk was NOT run");
-        }
-        if (!launched_graph)
-            return SVO_ERR_HIP;
-        // the host mirror chain_enqueue advanced (v->frame) is what the eager path leaves too
-        (void)g;
-        (void)ge;  // leaked on purpose: an experiment, destroyed with the process
-    } else if ((rc = chain_enqueue(runs, k, pipeline)))
+    const auto t0 = std::chrono::steady_clock::now();
+    if ((rc = chain_enqueue(runs, k, pipeline)))
         return rc;
     const auto t1 = std::chrono::steady_clock::now();
     if ((rc = svo_wait(ctx)))
         return rc;
-    if (launched_graph) {
-        const auto t2 = std::chrono::steady_clock::now();
-        fprintf(stderr, "[svo chain] graph launch -> done: %.1f us for %d frames = %.1f us per frame\n",
-                std::chrono::duration<double, std::micro>(t2 - t0).count(), runs[0]->n_frames,
-                std::chrono::duration<double, std::micro>(t2 - t0).count() / runs[0]->n_frames);
-    }
     if (debug) {
         const auto t2 = std::chrono::steady_clock::now();
         fprintf(stderr, "[svo chain] %d chunk(s) x %d frames, pipeline %d: enqueue %.1f us, then waited %.1f us\n", k,
