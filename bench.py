@@ -549,136 +549,145 @@ def main():
 
     # ---- one contiguous chunk per GPU (the north-star's partitioning), measured, rank 0's share ----
     if rank == 0 and not args.no_extras:
-        ctx1 = capi.Context(local_rank)
-        one = capi.VisualOdometry(ctx1, W, H, C, seed=20261003, **vo_kw)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        one.init(lefts[0], rights[0])
-        rc, done, R1, t1, inl1, trk1, kf1 = one.run_chunk(lefts[1:], rights[1:], pipeline=True)
-        ctx1.sync()
-        dt = time.perf_counter() - t0
-        if rc or done != share:
-            result["single_chunk_frames_per_s"] = None
-            result["single_chunk_note"] = f"tracking lost after {done} frames"
-        else:
-            t_seq = np.vstack([np.zeros((1, 3)), t1])
-            result["single_chunk_frames_per_s"] = share / dt
-            result["single_chunk_frames"] = share
-            result["single_chunk_keyframe_rate"] = float(kf1.mean())
-            n1 = share + 1
-            result["ate_rmse_sequential_vs_truth"] = chunked.ate_rmse(t_seq, t_truth[:n1])
-            result["ate_rmse_sharded_vs_sequential"] = chunked.ate_rmse(t_sh[:n1], t_seq)
-            result["ate_rmse_sharded_vs_truth_same_frames"] = chunked.ate_rmse(t_sh[:n1], t_truth[:n1])
-            result["ate_sharded_vs_sequential_over_path_length"] = (
-                result["ate_rmse_sharded_vs_sequential"] / (path_len * share / (world * share)))
-        one.close()
-        ctx1.close()
+        try:   # an extra leg must not cost the run its line
+            ctx1 = capi.Context(local_rank)
+            one = capi.VisualOdometry(ctx1, W, H, C, seed=20261003, **vo_kw)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            one.init(lefts[0], rights[0])
+            rc, done, R1, t1, inl1, trk1, kf1 = one.run_chunk(lefts[1:], rights[1:], pipeline=True)
+            ctx1.sync()
+            dt = time.perf_counter() - t0
+            if rc or done != share:
+                result["single_chunk_frames_per_s"] = None
+                result["single_chunk_note"] = f"tracking lost after {done} frames"
+            else:
+                t_seq = np.vstack([np.zeros((1, 3)), t1])
+                result["single_chunk_frames_per_s"] = share / dt
+                result["single_chunk_frames"] = share
+                result["single_chunk_keyframe_rate"] = float(kf1.mean())
+                n1 = share + 1
+                result["ate_rmse_sequential_vs_truth"] = chunked.ate_rmse(t_seq, t_truth[:n1])
+                result["ate_rmse_sharded_vs_sequential"] = chunked.ate_rmse(t_sh[:n1], t_seq)
+                result["ate_rmse_sharded_vs_truth_same_frames"] = chunked.ate_rmse(t_sh[:n1], t_truth[:n1])
+                result["ate_sharded_vs_sequential_over_path_length"] = (
+                    result["ate_rmse_sharded_vs_sequential"] / (path_len * share / (world * share)))
+            one.close()
+            ctx1.close()
+        except Exception as e:   # noqa: BLE001
+            result["single_chunk_error"] = f"{type(e).__name__}: {e}"
 
     # ---- configs[3]'s global solve on the stitched trajectory (rank 0; also configs[2]'s figure) ----
     if rank == 0 and not args.no_extras:
-        matches = synth.loop_closures(poses_all, max_dist=0.3, max_angle_deg=10.0, min_gap=100, pick="nearest")
-        closures = chunked.gate_closures([m if m >= 1 else -1 for m in matches])  # LCidx = match - 1 must exist
-        closure_source = "generator (frame pairs within 0.3 m / 10 deg, SURVEY.md 8d)"
-        det_info = None
-        if world == 1 and not args.no_detector:
-            # configs[2] / [3]: the closures come from the library's own detector (ORB features + database + geometric
-            # check, svo_lc_*), run over the left image of EVERY frame of the stitched stream on a context of its own:
-            # all frames are queued (svo_lc_submit), then collected; entry id = global frame id
-            ctxd = capi.Context(local_rank)
-            det = capi.LoopDetector(ctxd, W, H, C, seed=5, max_entries=len(lefts) + 8)
+        try:   # an extra leg must not cost the run its line
+            matches = synth.loop_closures(poses_all, max_dist=0.3, max_angle_deg=10.0, min_gap=100, pick="nearest")
+            closures = chunked.gate_closures([m if m >= 1 else -1 for m in matches])  # LCidx = match - 1 must exist
+            closure_source = "generator (frame pairs within 0.3 m / 10 deg, SURVEY.md 8d)"
+            det_info = None
+            if world == 1 and not args.no_detector:
+                # configs[2] / [3]: the closures come from the library's own detector (ORB features + database + geometric
+                # check, svo_lc_*), run over the left image of EVERY frame of the stitched stream on a context of its own:
+                # all frames are queued (svo_lc_submit), then collected; entry id = global frame id
+                ctxd = capi.Context(local_rank)
+                det = capi.LoopDetector(ctxd, W, H, C, seed=5, max_entries=len(lefts) + 8)
+                t0 = time.perf_counter()
+                for img in lefts:
+                    det.submit(img)
+                t_submit = time.perf_counter() - t0
+                verdicts = [det.collect() for _ in lefts]
+                t_det = time.perf_counter() - t0
+                det_matches = [v["match"] if v["status"] == 0 and v["match"] >= 1 else -1 for v in verdicts]
+                det_closures = chunked.gate_closures(det_matches)
+                det_info = {"frames": len(lefts), "ms_per_frame": t_det / len(lefts) * 1e3,
+                            "host_submit_ms_per_frame": t_submit / len(lefts) * 1e3,
+                            "detections": int(sum(v["status"] == 0 for v in verdicts)),
+                            "accepted_closures": len(det_closures), "generator_closures": len(closures),
+                            # an accepted closure is TRUE when the two frames' generator poses are within 2 m
+                            "accepted_true": int(sum(np.linalg.norm(poses_all[q][1] - poses_all[m][1]) < 2.0
+                                                     for q, m in det_closures.items()))}
+                det.close()
+                ctxd.close()
+                if det_closures:
+                    closures = det_closures
+                    closure_source = "svo_lc detector on the stitched stream's left images (global frame ids)"
+            ctxg = capi.Context(local_rank)
+            pg = capi.PoseGraph(ctxg)
+            ctxg.enable_kernel_timing(True)
             t0 = time.perf_counter()
-            for img in lefts:
-                det.submit(img)
-            t_submit = time.perf_counter() - t0
-            verdicts = [det.collect() for _ in lefts]
-            t_det = time.perf_counter() - t0
-            det_matches = [v["match"] if v["status"] == 0 and v["match"] >= 1 else -1 for v in verdicts]
-            det_closures = chunked.gate_closures(det_matches)
-            det_info = {"frames": len(lefts), "ms_per_frame": t_det / len(lefts) * 1e3,
-                        "host_submit_ms_per_frame": t_submit / len(lefts) * 1e3,
-                        "detections": int(sum(v["status"] == 0 for v in verdicts)),
-                        "accepted_closures": len(det_closures), "generator_closures": len(closures),
-                        # an accepted closure is TRUE when the two frames' generator poses are within 2 m
-                        "accepted_true": int(sum(np.linalg.norm(poses_all[q][1] - poses_all[m][1]) < 2.0
-                                                 for q, m in det_closures.items()))}
-            det.close()
-            ctxd.close()
-            if det_closures:
-                closures = det_closures
-                closure_source = "svo_lc detector on the stitched stream's left images (global frame ids)"
-        ctxg = capi.Context(local_rank)
-        pg = capi.PoseGraph(ctxg)
-        ctxg.enable_kernel_timing(True)
-        t0 = time.perf_counter()
-        est, chi2 = chunked.global_solve(pg, traj, closures, iters=10)
-        dt = time.perf_counter() - t0
-        pg_ms, _ = ctxg.kernel_time(capi.K_POSEGRAPH)
-        # the same solve once more on a fresh graph: the first one of a process pays for the lazy loading of its kernels
-        pg2 = capi.PoseGraph(ctxg)
-        chunked.global_solve(pg2, traj, closures, iters=10)
-        pg_ms_total, _ = ctxg.kernel_time(capi.K_POSEGRAPH)
-        pg2.close()
-        result["posegraph"] = {
-            "vertices": len(traj), "loop_closures": len(closures), "closure_source": closure_source,
-            "detector": det_info, "gn_iterations": 10,
-            "posegraph_ms_per_iter": pg_ms / 10.0,
-            "posegraph_ms_per_iter_second_solve": (pg_ms_total - pg_ms) / 10.0,
-            "solve_wall_ms_incl_graph_build": dt * 1e3,
-            "chi2_first": float(chi2[0]), "chi2_last": float(chi2[-1]),
-            "ate_rmse_vs_truth_before": ate_sh,
-            "ate_rmse_vs_truth_after": chunked.ate_rmse(est[:, :3], t_truth),
-        }
-        pg.close()
-        ctxg.close()
+            est, chi2 = chunked.global_solve(pg, traj, closures, iters=10)
+            dt = time.perf_counter() - t0
+            pg_ms, _ = ctxg.kernel_time(capi.K_POSEGRAPH)
+            # the same solve once more on a fresh graph: the first one of a process pays for the lazy loading of its kernels
+            pg2 = capi.PoseGraph(ctxg)
+            chunked.global_solve(pg2, traj, closures, iters=10)
+            pg_ms_total, _ = ctxg.kernel_time(capi.K_POSEGRAPH)
+            pg2.close()
+            result["posegraph"] = {
+                "vertices": len(traj), "loop_closures": len(closures), "closure_source": closure_source,
+                "detector": det_info, "gn_iterations": 10,
+                "posegraph_ms_per_iter": pg_ms / 10.0,
+                "posegraph_ms_per_iter_second_solve": (pg_ms_total - pg_ms) / 10.0,
+                "solve_wall_ms_incl_graph_build": dt * 1e3,
+                "chi2_first": float(chi2[0]), "chi2_last": float(chi2[-1]),
+                "ate_rmse_vs_truth_before": ate_sh,
+                "ate_rmse_vs_truth_after": chunked.ate_rmse(est[:, :3], t_truth),
+            }
+            pg.close()
+            ctxg.close()
+        except Exception as e:   # noqa: BLE001
+            result["posegraph_error"] = f"{type(e).__name__}: {e}"
 
     # ---- CPU baseline: the oracle on the node's own cores, a bounded sample of the same stream ----
     if rank == 0 and not args.no_cpu_baseline:
-        from oracle import orc  # the checker, timed as the CPU baseline ("port")
+        try:   # an extra leg must not cost the run its line
+            from oracle import orc  # the checker, timed as the CPU baseline ("port")
 
-        native = orc.use_native_build()
-        nf = min(max(2, args.cpu_frames), L)
-        host = [(lefts[i].cpu().numpy(), rights[i].cpu().numpy()) for i in range(nf + 1)]
+            native = orc.use_native_build()
+            nf = min(max(2, args.cpu_frames), L)
+            host = [(lefts[i].cpu().numpy(), rights[i].cpu().numpy()) for i in range(nf + 1)]
 
-        def oracle_run(threads: int, frames: int):
-            orc.set_num_threads(threads)
-            o = orc.VO(W, H, C, grid_step=grid_step, anms_keep=n_kpts, keyframe_min_inliers=kf_min, seed=20261003)
-            c0 = time.perf_counter()
-            o.init(*host[0])
-            out = []
-            for i in range(1, frames + 1):
-                rc, R, t, *_ = o.track(*host[i])
-                if rc:
-                    break
-                out.append((R.copy(), t.copy()))
-            dt = time.perf_counter() - c0
-            o.close()
-            return (len(out) + 1) / dt, out
+            def oracle_run(threads: int, frames: int):
+                orc.set_num_threads(threads)
+                o = orc.VO(W, H, C, grid_step=grid_step, anms_keep=n_kpts, keyframe_min_inliers=kf_min, seed=20261003)
+                c0 = time.perf_counter()
+                o.init(*host[0])
+                out = []
+                for i in range(1, frames + 1):
+                    rc, R, t, *_ = o.track(*host[i])
+                    if rc:
+                        break
+                    out.append((R.copy(), t.copy()))
+                dt = time.perf_counter() - c0
+                o.close()
+                return (len(out) + 1) / dt, out
 
-        cores = os.cpu_count() or 1
-        threads = min(cores, 32)
-        multi, o_poses = oracle_run(threads, nf)
-        single, _ = oracle_run(1, max(3, nf // 4))
-        g_poses = local[0][1:1 + len(o_poses)]   # chunk 0 of rank 0 started on the same frame with the same seed
-        dts = [float(np.linalg.norm(tg - to)) for (Rg, tg), (Ro, to) in zip(g_poses, o_poses)]
-        dRs = [rot_angle(Rg, Ro) for (Rg, tg), (Ro, to) in zip(g_poses, o_poses)]
-        result["ate_rmse_vs_oracle"] = chunked.ate_rmse([t for _, t in g_poses], [t for _, t in o_poses])
-        result["max_frame_delta_vs_oracle"] = {
-            "translation_m": max(dts), "rotation_rad": max(dRs), "frames": len(dts),
-            # arccos of a trace resolves 1e-8 rad at best: the entries themselves say whether the rotations are EQUAL
-            "rotation_matrix_max_abs_diff": max(float(np.abs(Rg - Ro).max()) for (Rg, _), (Ro, _) in zip(g_poses, o_poses)),
-            "bit_identical": all(np.array_equal(Rg, Ro) and np.array_equal(tg, to)
-                                 for (Rg, tg), (Ro, to) in zip(g_poses, o_poses))}
-        result["cpu_baseline"] = {
-            "value": multi,
-            "unit": "frames/s",
-            "cores": threads,
-            "host_cpu_count": cores,
-            "kind": "port",
-            "sample": f"chunk 0 of the same stream: stereo initialisation + {nf} frames, same stages, oracle C "
-                      f"({'-O3 -march=native, built on this host' if native else '-O3 -march=x86-64-v3 (prebuilt)'}, "
-                      f"OpenMP over keypoints in LK and ANMS, RANSAC stages scalar), {threads} threads",
-            "single_thread_value": single,
-        }
+            cores = os.cpu_count() or 1
+            threads = min(cores, 32)
+            multi, o_poses = oracle_run(threads, nf)
+            single, _ = oracle_run(1, max(3, nf // 4))
+            g_poses = local[0][1:1 + len(o_poses)]   # chunk 0 of rank 0 started on the same frame with the same seed
+            dts = [float(np.linalg.norm(tg - to)) for (Rg, tg), (Ro, to) in zip(g_poses, o_poses)]
+            dRs = [rot_angle(Rg, Ro) for (Rg, tg), (Ro, to) in zip(g_poses, o_poses)]
+            result["ate_rmse_vs_oracle"] = chunked.ate_rmse([t for _, t in g_poses], [t for _, t in o_poses])
+            result["max_frame_delta_vs_oracle"] = {
+                "translation_m": max(dts), "rotation_rad": max(dRs), "frames": len(dts),
+                # arccos of a trace resolves 1e-8 rad at best: the entries themselves say whether the rotations are EQUAL
+                "rotation_matrix_max_abs_diff": max(float(np.abs(Rg - Ro).max()) for (Rg, _), (Ro, _) in zip(g_poses, o_poses)),
+                "bit_identical": all(np.array_equal(Rg, Ro) and np.array_equal(tg, to)
+                                     for (Rg, tg), (Ro, to) in zip(g_poses, o_poses))}
+            result["cpu_baseline"] = {
+                "value": multi,
+                "unit": "frames/s",
+                "cores": threads,
+                "host_cpu_count": cores,
+                "kind": "port",
+                "sample": f"chunk 0 of the same stream: stereo initialisation + {nf} frames, same stages, oracle C "
+                          f"({'-O3 -march=native, built on this host' if native else '-O3 -march=x86-64-v3 (prebuilt)'}, "
+                          f"OpenMP over keypoints in LK and ANMS, RANSAC stages scalar), {threads} threads",
+                "single_thread_value": single,
+            }
+        except Exception as e:   # noqa: BLE001
+            result["cpu_baseline_error"] = f"{type(e).__name__}: {e}"
 
     if rank == 0:
         print(json.dumps(result))
