@@ -846,10 +846,15 @@ __device__ __forceinline__ void pg_tile_mult(const double *sX, const double *sY,
     }
 }
 
+// The forward substitution of the solve rides along: the workgroup of a diagonal tile (j, j) has the factor's block
+// L_j,kb = P_j at hand, forms y_kb = Tinv_kb b_kb (48 x 48, every such workgroup for itself) and takes L_j,kb y_kb off
+// b_j; the first of them leaves y_kb in `yout`.  The solve kernel is left with the last tile's y and the backward sweep.
 __global__ __launch_bounds__(256) void pg_dense_update_kernel(double *__restrict__ A, double *__restrict__ Lo,
-                                                              const double *__restrict__ Tinv, int ldr, int kb, int T)
+                                                              const double *__restrict__ Tinv, int ldr, int kb, int T,
+                                                              double *__restrict__ rhs, double *__restrict__ yout)
 {
     __shared__ double sI[TB * (TB + 1)], sPi[TB * (TB + 1)], sPj[TB * (TB + 1)], sA[TB * (TB + 1)];
+    __shared__ double s_y[TB];
     constexpr int LD = TB + 1;
     const int tid = threadIdx.x, tr = tid >> 4, tc = tid & 15;
     // linear tile index -> (i, j) with kb < j <= i < T
@@ -874,6 +879,23 @@ __global__ __launch_bounds__(256) void pg_dense_update_kernel(double *__restrict
         for (int b2 = 0; b2 < 3; b2++)
             sPi[(3 * tr + a) * LD + 3 * tc + b2] = acc[a][b2];
     __syncthreads();
+    if (i == j) {  // the right-hand side of block row j (see above); sI is the lower-triangular Tinv_kb
+        if (tid < TB) {
+            double a = 0;
+            for (int c = 0; c <= tid; c++)
+                a += sI[tid * LD + c] * rhs[kb * TB + c];
+            s_y[tid] = a;
+            if (blockIdx.x == 0)
+                yout[kb * TB + tid] = a;
+        }
+        __syncthreads();
+        if (tid < TB) {
+            double a = 0;
+            for (int c = 0; c < TB; c++)
+                a += sPi[tid * LD + c] * s_y[c];
+            rhs[j * TB + tid] -= a;
+        }
+    }
     if (i != j) {
         for (int e = tid; e < TB * TB; e += 256) {
             const int r = e / TB, c = e - TB * r;
@@ -921,24 +943,21 @@ __device__ __forceinline__ double pg_sum8(double v)
 }
 __global__ __launch_bounds__(PG_SOLVE_THREADS) void pg_dense_solve_kernel(const double *__restrict__ Lo,
                                                                           const double *__restrict__ Tinv, int ldr, int T,
-                                                                          const double *__restrict__ rhs,
-                                                                          double *__restrict__ x)
+                                                                          const double *__restrict__ rhs, double *x)
 {
     extern __shared__ double sv[];  // ldr entries + TB
     double *st = sv + ldr;
     const int tid = threadIdx.x;
     const int r = tid >> 3, part = tid & 7;
+    // forward: y of the tiles 0 .. T-2 came with the factorisation (pg_dense_update_kernel left them in x, and took their
+    // terms off the later blocks of rhs); the last tile's y = Tinv (its block of rhs) here
     for (int e = tid; e < ldr; e += PG_SOLVE_THREADS)
-        sv[e] = rhs[e];
+        sv[e] = e < (T - 1) * TB ? x[e] : rhs[e];
     __syncthreads();
-    for (int kb = 0; kb < T; kb++) {  // forward: y_kb = Tinv (b_kb - L_kb,:kb y_:kb)
-        double acc = 0;
-        const double *row = Lo + (size_t)(kb * TB + r) * ldr;
-        for (int c = part; c < kb * TB; c += 8)
-            acc += row[c] * sv[c];
-        acc = pg_sum8(acc);
+    {
+        const int kb = T - 1;
         if (part == 0)
-            st[r] = sv[kb * TB + r] - acc;
+            st[r] = sv[kb * TB + r];
         __syncthreads();
         double a2 = 0;
         const double *ti = Tinv + (size_t)kb * TB * TB + r * TB;
@@ -1413,7 +1432,7 @@ int svo_pg_optimize(svo_posegraph *g, int iters, double *chi2)
                 const int nt = T - 1 - kb;
                 if (nt > 0)
                     hipLaunchKernelGGL(pg_dense_update_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, st, R, Lo, Tinv,
-                                       ldr, kb, T);
+                                       ldr, kb, T, rR, xR);
             }
             hipLaunchKernelGGL(pg_dense_solve_kernel, dim3(1), dim3(PG_SOLVE_THREADS), (size_t)(ldr + TB) * 8, st, Lo, Tinv, ldr,
                                T, rR, xR);
