@@ -88,6 +88,16 @@ int svo_ctx_reset_kernel_time(svo_ctx *ctx);
 enum { SVO_MATH_SIN = 0, SVO_MATH_COS = 1, SVO_MATH_ACOS = 2, SVO_MATH_CBRT = 3, SVO_MATH_LOG = 4 };
 int svo_math_eval(svo_ctx *ctx, int fn, const double *x, int n, double *y, int mem);
 
+/* ---- diagnostics ---------------------------------------------------------------------------
+ * svo_selftest_fransac_gate: ONE findFundamentalMat launch sequence (src/tracking.cpp:34) in which the workgroups of
+ * every launch DISAGREE about the chunk runner's launch gate (even workgroups see it open, odd ones closed) -- the view
+ * a pipelined chunk can produce when the PnP stream halts the chain under a launch another stream is dispatching.
+ * tickets_after[0..1] receive the "last workgroup finishes" counters of the context afterwards; they must be 0, and the
+ * next ordinary svo_fransac on the context must give its usual answer.  Device pointers; lean != 0: the single-wave
+ * build the lock-step groups use (two jobs), else the lone-chunk build.  The mask's contents are unspecified. */
+int svo_selftest_fransac_gate(svo_ctx *ctx, const float *d_p1, const float *d_p2, int n, double threshold,
+                              uint64_t seed, int lean, uint8_t *d_mask, unsigned *tickets_after);
+
 /* ---- image pyramid ----------------------------------------------------------------------- */
 /* Replaces the pyramid cv::calcOpticalFlowPyrLK rebuilds on every call
  * (src/tracking.cpp:18,52).  A pyramid is built once per image and reused for the

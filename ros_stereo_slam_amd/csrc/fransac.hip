@@ -52,6 +52,8 @@ struct FrJob {
     int c_stride[3];
     int *c_count;
     const int *gate;  // optional: every wave of the job leaves at once when *gate == 0 (chain runner)
+    int gate_stride;  // 0 in the product; svo_selftest_fransac_gate: workgroup b reads gate[b * gate_stride], so that ONE
+                      // launch sees the gate both open and closed -- deterministically, not by a race between streams
 };
 template <int NJ> struct FrBatchN {  // NJ = 1: a chunk on its own (a sixteenth of the kernel arguments per launch)
     FrJob j[NJ];
@@ -384,8 +386,17 @@ __global__ __launch_bounds__(LEAN ? 64 : 256, LEAN ? 5 : 4) void fr_ransac_kerne
     constexpr int NW = LEAN ? 1 : 4;  // waves per workgroup
     svo_chain_priority();
     const FrJob &job = batch.j[blockIdx.y];
-    if (job.gate && *job.gate == 0)
-        return;  // not due (the frame is no keyframe / the chain halted): no ticket is taken, the counters stay at rest
+    // The gate (VoChain::kf / ::run) may be cleared on ANOTHER stream while this launch is being dispatched (the pipelined
+    // chunk: the PnP stream halts the chain while the stereo stream's launch of a frame ahead starts), so the workgroups of
+    // one launch need not agree on it.  A workgroup that finds it closed does no work but STILL takes its ticket: the
+    // self-resetting counter then always reaches gridDim.x and returns to zero, whatever mixture of views the launch saw
+    // (a skipped ticket left it at a partial count for every later launch on the context).  One read per
+    // workgroup, shared through LDS: the scoring loop holds workgroup barriers.
+    __shared__ int s_due;
+    if (threadIdx.x == 0)
+        s_due = !(job.gate && __hip_atomic_load(job.gate + (size_t)blockIdx.x * job.gate_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0);
+    __syncthreads();
+    const bool due = s_due != 0;
     const float2 *__restrict__ p1 = reinterpret_cast<const float2 *>(job.p1);
     const float2 *__restrict__ p2 = reinterpret_cast<const float2 *>(job.p2);
     const int n_host = job.n_host;
@@ -402,12 +413,12 @@ __global__ __launch_bounds__(LEAN ? 64 : 256, LEAN ? 5 : 4) void fr_ransac_kerne
     const int pt0 = 4 * (int)threadIdx.x;  // this thread's first pair of a step; a step covers 256 * NW pairs
     constexpr int STEP = 256 * NW;
     __shared__ double sA[63], sV[18], sF[27];
-    __shared__ int sPerm[9], s_nm, s_cnt[NW][3], s_last;
+    __shared__ int sPerm[9], s_nm, s_cnt[NW][3], s_last, s_all_due;
     if (it0 > 0 && st->done)  // the loop ended in an earlier phase (the same answer in every wave of the launch)
         return;
     const int n = d_n ? min(*d_n, n_host) : n_host;  // a live count never exceeds the capacity the buffers were sized for
     const bool vec_ok = ((reinterpret_cast<uintptr_t>(p1) | reinterpret_cast<uintptr_t>(p2)) & 15) == 0;
-    for (int it = it0 + (int)blockIdx.x; it < it1; it += gridDim.x) {
+    for (int it = it0 + (int)blockIdx.x; due && it < it1; it += gridDim.x) {
         if (wave == 0) {
             const int nm_l0 = fr_solve_wave(job.p1, job.p2, n, job.seed, it, sA, sV, sPerm, sF, lane);
             if (lane == 0) {
@@ -475,17 +486,32 @@ __global__ __launch_bounds__(LEAN ? 64 : 256, LEAN ? 5 : 4) void fr_ransac_kerne
         __syncthreads();  // sF / s_nm / s_cnt are rewritten by the next iteration of this workgroup
     }
     // every workgroup takes a ticket once its counts are out; the holder of the last one sees them all
+    // (low half: workgroups that have arrived; high half: how many of them found the gate closed)
     if (threadIdx.x == 0) {
         __threadfence();
-        const unsigned t = atomicAdd(ticket, 1u);
-        s_last = t == gridDim.x - 1;
+        const unsigned t = atomicAdd(ticket, due ? 1u : 0x10001u);
+        s_last = (t & 0xffffu) == gridDim.x - 1;
+        s_all_due = due && (t >> 16) == 0;
     }
     __syncthreads();
     if (!s_last)
         return;
     __shared__ RansacState s_state;
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0)
         *ticket = 0;  // ready for the next launch
+    if (!s_all_due) {
+        // some workgroup found the gate closed: its iteration slots hold whatever the workspace held before (it is
+        // shared with other stages), so there is nothing to replay.  The state says "ended, no model": a phase that
+        // follows leaves at once.  What the launch leaves behind belongs to a frame the halted chain discards and
+        // the host queues again.
+        if (threadIdx.x == 0) {
+            RansacState r;
+            r.niters = 0, r.next_iter = 0, r.best_iter = -1, r.best_model = 0, r.best_count = 0, r.done = 1, r.iters_run = 0, r.pad = 0;
+            *st = r;
+        }
+        return;
+    }
+    if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // other waves' counts, not this CU's stale lines
         const RansacState r = ransac_replay<3>(st, it0 == 0 ? 1 : 0, it1, max_iters, n, job.confidence, nmodels, counts, M);
         *st = r;
@@ -624,6 +650,7 @@ int svo_launch_fransac_batch(svo_ctx *ctx, int n_jobs, const svo_fransac_job *jo
         }
         j.c_count = h.then_compact ? h.then_compact->d_count : nullptr;
         j.gate = h.gate;
+        j.gate_stride = h.gate_stride;
         nb++;
     }
     if (nb == 0)
@@ -670,6 +697,47 @@ int svo_launch_fransac(svo_ctx *ctx, const float *p1, const float *p2, int cap, 
     j.d_count = d_count;
     j.d_iters = d_iters;
     return svo_launch_fransac_batch(ctx, 1, &j);
+}
+
+// Diagnostics (fransac.hip gate / ticket): ONE launch of each phase in which the workgroups disagree about
+// the gate -- even workgroups find it open, odd ones closed -- as the pipelined chunk can produce when the PnP stream
+// halts the chain under a launch the stereo stream is dispatching.  Reports the value the self-resetting ticket counter
+// is left at (must be 0) so that the caller can check that the NEXT ordinary call on the context is unaffected.
+// Device pointers; `lean`: the single-wave build the lock-step groups use (two identical jobs) instead of the lone one.
+extern "C" int svo_selftest_fransac_gate(svo_ctx *ctx, const float *d_p1, const float *d_p2, int n, double threshold,
+                                         uint64_t seed, int lean, uint8_t *d_mask, unsigned *tickets_after)
+{
+    SVO_CHECK_ARG(ctx && d_p1 && d_p2 && n > 0 && d_mask && tickets_after);
+    int rc;
+    if ((rc = ctx->s_g.ensure(sizeof(int) * PHASE_WAVES)))
+        return rc;
+    int h_gate[PHASE_WAVES];
+    for (int b = 0; b < PHASE_WAVES; b++)
+        h_gate[b] = (b & 1) ? 0 : 1;
+    SVO_HIP(hipMemcpyAsync(ctx->s_g.p, h_gate, sizeof(h_gate), hipMemcpyHostToDevice, ctx->stream));
+    SVO_HIP(hipStreamSynchronize(ctx->stream));
+    svo_fransac_job j[2];
+    for (int a = 0; a < 2; a++) {
+        j[a].p1 = d_p1;
+        j[a].p2 = d_p2;
+        j[a].cap = n;
+        j[a].d_n = nullptr;
+        j[a].threshold = threshold;
+        j[a].confidence = 0.99;
+        j[a].max_iters = 1000;
+        j[a].seed = seed;
+        j[a].mask = d_mask;
+        j[a].d_F = nullptr;
+        j[a].d_count = nullptr;
+        j[a].d_iters = nullptr;
+        j[a].gate = ctx->s_g.as<int>();
+        j[a].gate_stride = 1;
+    }
+    if ((rc = svo_launch_fransac_batch(ctx, lean ? 2 : 1, j)))
+        return rc;
+    SVO_HIP(hipMemcpyAsync(tickets_after, ctx->d_tickets, sizeof(unsigned) * 2, hipMemcpyDeviceToHost, ctx->stream));
+    SVO_HIP(hipStreamSynchronize(ctx->stream));
+    return SVO_OK;
 }
 
 extern "C" int svo_fransac(svo_ctx *ctx, const float *p1, const float *p2, int n, double threshold,

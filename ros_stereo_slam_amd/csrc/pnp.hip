@@ -802,28 +802,41 @@ template <bool LEAN> __global__ __launch_bounds__(64, LEAN ? 4 : 1) void pnp_sol
 {
     svo_chain_priority();
     const PnpJob &job = batch.j[blockIdx.y];
-    if (job.chain && job.chain->run == 0)
-        return;  // the chain halted at an earlier frame: nothing of this chunk runs any more
+    // the chain halted at an earlier frame: nothing of this chunk runs any more.  A wave that finds the chain halted does
+    // no work but still takes its ticket below (as fr_ransac_kernel: the flag may change under a launch that another
+    // stream dispatches, and a skipped ticket would leave the self-resetting counter at a partial count for good).
+    const bool due = !(job.chain && __builtin_amdgcn_readfirstlane(__hip_atomic_load(&job.chain->run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0);
     const int it1 = it1_cap < job.iterations ? it1_cap : job.iterations;
     if (it0 > 0 && job.st->done)
-        return;  // the same answer in every wave of the launch
+        return;  // the same answer in every wave of the launch (written by the previous launch of this stream)
     __shared__ WaveLds s_lds[1];
     const int lane = threadIdx.x & 63;
     const int it = __builtin_amdgcn_readfirstlane(it0 + blockIdx.x);
     const int n = job.d_n ? min(*job.d_n, job.n_host) : job.n_host;  // as pnp_finish: never past the capacity
-    if (it < it1)
+    if (due && it < it1)
         pnp_hypothesis(job, it, n, s_lds[0], lane);
     if (it1 >= job.iterations)
         return;  // no phase follows: pnp_finish_kernel replays
-    int last = 0;
+    int last = 0;  // bit 0: this wave holds the last ticket; bit 1: every wave of the launch found the chain live
     if (lane == 0) {
         __threadfence();
-        last = atomicAdd(job.ticket, 1u) == gridDim.x - 1;
+        const unsigned t = atomicAdd(job.ticket, due ? 1u : 0x10001u);  // low half: arrivals; high half: of them, halted views
+        last = ((t & 0xffffu) == gridDim.x - 1 ? 1 : 0) | (due && (t >> 16) == 0 ? 2 : 0);
     }
-    if (!__builtin_amdgcn_readfirstlane(last))
+    last = __builtin_amdgcn_readfirstlane(last);
+    if (!(last & 1))
         return;
-    if (lane == 0) {
+    if (lane == 0)
         *job.ticket = 0;  // ready for the next launch
+    if (!(last & 2)) {  // a halted view: slots of this phase were not written -- nothing to replay; "ended" for the next phase
+        if (lane == 0) {
+            RansacState r;
+            r.niters = 0, r.next_iter = 0, r.best_iter = -1, r.best_model = 0, r.best_count = 0, r.done = 1, r.iters_run = 0, r.pad = 0;
+            *job.st = r;
+        }
+        return;
+    }
+    if (lane == 0) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // other waves' counts, not this CU's stale lines
         *job.st = ransac_replay<1>(job.st, it0 == 0 ? 1 : 0, it1, job.iterations, n, job.confidence, job.nmodels,
                                    job.counts, MP);

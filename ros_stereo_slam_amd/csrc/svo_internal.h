@@ -216,6 +216,7 @@ struct svo_fransac_job {  // host-side description of one F-matrix RANSAC proble
     // ignored), done by the wave that writes the mask -- no launch of its own
     const svo_compact_job *then_compact = nullptr;
     const int *gate = nullptr;  // optional: every wave leaves at once when *gate == 0
+    int gate_stride = 0;        // diagnostics only (svo_selftest_fransac_gate): workgroup b reads gate[b * gate_stride]
 };
 int svo_launch_fransac_batch(svo_ctx *ctx, int n_jobs, const svo_fransac_job *jobs);
 int svo_launch_fransac(svo_ctx *ctx, const float *p1, const float *p2, int cap, const int *d_n,

@@ -23,6 +23,10 @@ KITTI_K = (718.856, 718.856, 607.1928, 185.2157)
 KITTI_BASELINE = 0.54
 KITTI_SIZE = (1241, 376)
 DEFAULT_SEED = 20261003
+# colour mode of Scene / textured_pair: seed offset, amplitude share and sky tint of a channel's own texture
+CHANNEL_SEED = 15485863
+COLOUR_MIX = 0.45
+SKY_TINT = (38, -9, -52)          # B, G, R
 
 
 def _hash2(ix: np.ndarray, iy: np.ndarray, seed: int) -> np.ndarray:
@@ -63,15 +67,24 @@ class Scene:
     z_max: float | None = None
     wavelengths: tuple = (1.2, 0.45, 0.15)
     sky: int = 128
+    # colour=False: R = G = B (every channel is the grey albedo).  colour=True: a hue-varying albedo -- channel c
+    # (memory order B, G, R as cv::imread delivers KITTI's image_2/3, src/keyFrameManagement.cpp:52-54) mixes the
+    # shared texture with a texture of its own (COLOUR_MIX of the amplitude) and the sky gets a tint, so that no two
+    # channels of any pixel neighbourhood agree and a channel-stride or channel-order slip shows in the results.
+    colour: bool = False
 
-    def albedo(self, u, v, footprint, surface_id):
-        """Value-noise albedo in [0,255]; octaves fade out when the pixel footprint nears them."""
+    def albedo(self, u, v, footprint, surface_id, channel=None):
+        """Value-noise albedo in [0,255]; octaves fade out when the pixel footprint nears them.
+        ``channel`` (colour mode): the channel's own texture is mixed in."""
         acc = np.zeros_like(u)
         wsum = np.zeros_like(u)
         amp = 1.0
         for k, wl in enumerate(self.wavelengths):
             fade = np.clip(1.5 - 2.0 * footprint / wl, 0.0, 1.0)
             n = _value_noise(u / wl, v / wl, self.seed + 7919 * surface_id + 104729 * k)
+            if channel is not None:
+                own = _value_noise(u / wl, v / wl, self.seed + 7919 * surface_id + 104729 * k + CHANNEL_SEED * (channel + 1))
+                n = (1.0 - COLOUR_MIX) * n + COLOUR_MIX * own
             acc += amp * fade * (n - 0.5)
             wsum += amp
             amp *= 0.7
@@ -117,14 +130,20 @@ class Scene:
         found = np.isfinite(best_t)
         depth = np.where(found, best_t, 0.0)  # dc has z = 1, so ray parameter == camera depth
         footprint = depth / fx * 1.5
-        grey = np.zeros((h, w))
-        for sid in (1, 2, 3, 4, 5):
-            m = surf == sid
-            if m.any():
-                grey = np.where(m, self.albedo(tex_u, tex_v, footprint, sid), grey)
-        grey = np.where(found, grey, float(self.sky))
-        img = np.rint(grey).astype(np.uint8)
-        img = np.repeat(img[..., None], channels, axis=2)
+
+        def shade(channel):
+            grey = np.zeros((h, w))
+            for sid in (1, 2, 3, 4, 5):
+                m = surf == sid
+                if m.any():
+                    grey = np.where(m, self.albedo(tex_u, tex_v, footprint, sid, channel), grey)
+            sky = float(self.sky) if channel is None else float(np.clip(self.sky + SKY_TINT[channel % 3], 0, 255))
+            return np.rint(np.where(found, grey, sky)).astype(np.uint8)
+
+        if self.colour and channels > 1:
+            img = np.stack([shade(c) for c in range(channels)], axis=2)
+        else:
+            img = np.repeat(shade(None)[..., None], channels, axis=2)
         return np.ascontiguousarray(img), depth
 
     def stereo(self, R, t, K=KITTI_K, size=KITTI_SIZE, channels=3, baseline=KITTI_BASELINE):
@@ -213,23 +232,33 @@ def render_torch(scene: "Scene", R, t, K=KITTI_K, size=KITTI_SIZE, channels=3, d
     found = torch.isfinite(best_t)
     depth = torch.where(found, best_t, torch.zeros_like(best_t))
     footprint = depth / fx * 1.5
-    grey = torch.zeros_like(depth)
-    for sid in (1, 2, 3, 4, 5):
-        m = surf == sid
-        acc = torch.zeros_like(depth)
-        wsum = 0.0
-        amp = 1.0
-        for k, wl in enumerate(scene.wavelengths):
-            fade = torch.clamp(1.5 - 2.0 * footprint / wl, 0.0, 1.0)
-            n = _t_value_noise(tex_u / wl, tex_v / wl, scene.seed + 7919 * sid + 104729 * k)
-            acc = acc + amp * fade * (n - 0.5)
-            wsum += amp
-            amp *= 0.7
-        alb = torch.clamp(128.0 + 230.0 * acc / wsum * 1.6, 0, 255)
-        grey = torch.where(m, alb, grey)
-    grey = torch.where(found, grey, torch.full_like(grey, float(scene.sky)))
-    img = torch.round(grey).to(torch.uint8)  # round half to even, as np.rint
-    return img[..., None].expand(B, h, w, channels).contiguous()
+
+    def shade(channel):
+        grey = torch.zeros_like(depth)
+        for sid in (1, 2, 3, 4, 5):
+            m = surf == sid
+            acc = torch.zeros_like(depth)
+            wsum = 0.0
+            amp = 1.0
+            for k, wl in enumerate(scene.wavelengths):
+                fade = torch.clamp(1.5 - 2.0 * footprint / wl, 0.0, 1.0)
+                n = _t_value_noise(tex_u / wl, tex_v / wl, scene.seed + 7919 * sid + 104729 * k)
+                if channel is not None:
+                    own = _t_value_noise(tex_u / wl, tex_v / wl,
+                                         scene.seed + 7919 * sid + 104729 * k + CHANNEL_SEED * (channel + 1))
+                    n = (1.0 - COLOUR_MIX) * n + COLOUR_MIX * own
+                acc = acc + amp * fade * (n - 0.5)
+                wsum += amp
+                amp *= 0.7
+            alb = torch.clamp(128.0 + 230.0 * acc / wsum * 1.6, 0, 255)
+            grey = torch.where(m, alb, grey)
+        sky = float(scene.sky) if channel is None else float(min(255, max(0, scene.sky + SKY_TINT[channel % 3])))
+        grey = torch.where(found, grey, torch.full_like(grey, sky))
+        return torch.round(grey).to(torch.uint8)  # round half to even, as np.rint
+
+    if scene.colour and channels > 1:
+        return torch.stack([shade(c) for c in range(channels)], dim=3).contiguous()
+    return shade(None)[..., None].expand(B, h, w, channels).contiguous()
 
 
 def stereo_torch(scene: "Scene", poses, K=KITTI_K, size=KITTI_SIZE, channels=3, baseline=KITTI_BASELINE,
@@ -308,20 +337,30 @@ def loop_trajectory(n: int, half_x: float = 14.0, half_z: float = 30.0, radius: 
     return poses
 
 
-def textured_pair(w: int, h: int, c: int, shift=(0.0, 0.0), seed: int = 1, wavelength: float = 9.0):
+def textured_pair(w: int, h: int, c: int, shift=(0.0, 0.0), seed: int = 1, wavelength: float = 9.0,
+                  colour: bool = False):
     """Two images of one band-limited texture, the second shifted by ``shift`` pixels
-    (image2(x, y) = image1(x - dx, y - dy)); the analytic flow is ``shift`` everywhere."""
+    (image2(x, y) = image1(x - dx, y - dy)); the analytic flow is ``shift`` everywhere.
+    ``colour``: every channel mixes the shared texture with one of its own (see ``Scene.colour``)."""
     uu, vv = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
 
-    def tex(u, v):
+    def tex(u, v, channel=None):
         acc = 0.0
         amp, wl = 1.0, wavelength * 4
         for k in range(3):
-            acc = acc + amp * (_value_noise(u / wl, v / wl, seed + 31 * k) - 0.5)
+            n = _value_noise(u / wl, v / wl, seed + 31 * k)
+            if channel is not None:
+                n = (1.0 - COLOUR_MIX) * n + COLOUR_MIX * _value_noise(u / wl, v / wl,
+                                                                        seed + 31 * k + CHANNEL_SEED * (channel + 1))
+            acc = acc + amp * (n - 0.5)
             amp *= 0.6
             wl *= 0.5
         return np.clip(128 + 200 * acc / 1.96, 0, 255)
 
+    if colour and c > 1:
+        a = np.stack([np.rint(tex(uu, vv, ch)).astype(np.uint8) for ch in range(c)], 2)
+        b = np.stack([np.rint(tex(uu - shift[0], vv - shift[1], ch)).astype(np.uint8) for ch in range(c)], 2)
+        return np.ascontiguousarray(a), np.ascontiguousarray(b)
     a = np.rint(tex(uu, vv)).astype(np.uint8)
     b = np.rint(tex(uu - shift[0], vv - shift[1])).astype(np.uint8)
     a = np.ascontiguousarray(np.repeat(a[..., None], c, 2))
@@ -362,6 +401,6 @@ def loop_closures(poses, max_dist: float = 2.0, max_angle_deg: float = 10.0, min
 BENCH_LOOP = dict(half_x=50.0, half_z=80.0, radius=45.0, step=0.9, closed=True)
 
 
-def bench_scene(seed: int = DEFAULT_SEED) -> Scene:
+def bench_scene(seed: int = DEFAULT_SEED, colour: bool = False) -> Scene:
     return Scene(seed=seed, wall_x=BENCH_LOOP["half_x"] + 8, z_min=-BENCH_LOOP["half_z"] - 8,
-                 z_max=BENCH_LOOP["half_z"] + 8)
+                 z_max=BENCH_LOOP["half_z"] + 8, colour=colour)

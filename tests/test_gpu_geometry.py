@@ -145,3 +145,34 @@ def test_get_colors(ctx, orc, c):
     xy = rng.uniform([0, 0], [159.99, 119.99], (500, 2)).astype(np.float32)
     assert np.array_equal(ctx.get_colors(pyr, xy), orc.get_colors(img, xy))
     pyr.close()
+
+
+@pytest.mark.parametrize("lean", [0, 1])
+def test_fransac_ticket_survives_a_launch_with_a_mixed_view_of_the_gate(ctx, lean):
+    """ADVICE r3 (medium): in the four-stream pipeline VoChain::run is cleared on the PnP stream while the stereo
+    stream's F-RANSAC launch of a later frame is being dispatched, so the workgroups of ONE launch can disagree about
+    the gate.  A workgroup that left without its ticket used to leave the self-resetting "last workgroup finishes"
+    counter at a partial count -- silently wrong masks for the rest of the context's life.  svo_selftest_fransac_gate
+    produces exactly that launch (even workgroups: gate open, odd ones: closed) deterministically; afterwards the
+    counters must be at rest and the next ordinary call must give the answer it gave before."""
+    import ctypes as C
+
+    import torch
+
+    n = 2400
+    x1, x2, gt, *_ = two_view(n=n, n_out=900, seed=17, noise=0.15)      # low inlier ratio: both phases run
+    before = ctx.fransac(x1, x2, 1.0, seed=9)
+    assert before[3] > 64
+    d1 = torch.from_numpy(np.ascontiguousarray(x1, np.float32)).cuda()
+    d2 = torch.from_numpy(np.ascontiguousarray(x2, np.float32)).cuda()
+    dmask = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    tickets = (C.c_uint * 2)(7, 7)
+    for _ in range(3):
+        rc = ctx.lib.svo_selftest_fransac_gate(ctx._h, C.c_void_p(d1.data_ptr()), C.c_void_p(d2.data_ptr()), n,
+                                               C.c_double(1.0), C.c_uint64(9), lean, C.c_void_p(dmask.data_ptr()), tickets)
+        assert rc == 0
+        assert tickets[0] == 0 and tickets[1] == 0, f"ticket counters left at {tickets[0]}, {tickets[1]}"
+    after = ctx.fransac(x1, x2, 1.0, seed=9)
+    assert after[0] == before[0] and after[3] == before[3]
+    assert np.array_equal(after[1], before[1]) and np.array_equal(after[2], before[2])

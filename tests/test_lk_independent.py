@@ -68,3 +68,37 @@ def test_the_restatement_reproduces_the_building_blocks(orc):
     dx, dy = L.scharr(img)
     got = orc.scharr(img)
     assert np.array_equal(got[..., 0], dx) and np.array_equal(got[..., 1], dy)
+
+
+def test_the_oracles_channel_loops_on_colour_images(orc):
+    """every 3-channel parity image used to have R = G = B, so the oracle's own channel loops
+    (interleaved BGR rows, sums over the channels, minEig not divided by C) were checked by nothing but the oracle.
+    Colour textures (three different channels) and a colour stereo / temporal pair of the benchmark's scene: the numpy
+    restatement of appendix A.1 against oracle/lk.c -- status identical, positions inside upstream's cross-build
+    spread -- and the building blocks (pyrDown, Scharr) channel by channel."""
+    a, b = synth.textured_pair(320, 200, 3, shift=(2.3, -1.4), seed=3, colour=True)
+    assert min(np.abs(a[..., i].astype(int) - a[..., j].astype(int)).mean() for i, j in ((0, 1), (0, 2), (1, 2))) > 5
+    pts = orc.grid_keypoints(200, 320, 20)
+    o, r, ok, d_oracle, d_builds, d_err = _compare(orc, a, b, pts)
+    assert d_oracle < 0.02 and d_builds < 0.02 and d_oracle <= 2.0 * d_builds + 3e-3 and d_err < 0.01
+    inner = ok & (pts[:, 0] > 45) & (pts[:, 0] < 275) & (pts[:, 1] > 45) & (pts[:, 1] < 155)
+    assert np.abs((o - pts)[inner] - np.array((2.3, -1.4), np.float32)).max() < 0.12
+    # a channel permutation of ONE image must change the answer of both implementations alike
+    b_rot = np.ascontiguousarray(b[..., [1, 2, 0]])
+    o2, r2, ok2, d2, _, _ = _compare(orc, a, b_rot, pts)
+    assert d2 < 0.05
+    assert (ok != ok2).any() or np.abs(o - o2)[ok & ok2].max() > 0.05
+    assert np.array_equal(L.pyr_down(a), orc.pyr_down(a))
+    dx, dy = L.scharr(a)
+    got = orc.scharr(a)
+    assert np.array_equal(got[..., 0], dx) and np.array_equal(got[..., 1], dy)
+    scene = synth.bench_scene(colour=True)
+    poses = synth.loop_trajectory(2, **synth.BENCH_LOOP)
+    (l0, r0), (l1, _) = scene.stereo(*poses[0])[:2], scene.stereo(*poses[1])[:2]
+    pts = orc.grid_keypoints(376, 1241, 40)
+    for x, y, name in ((l0, l1, "t -> t+1"), (l0, r0, "left -> right")):
+        o, r, ok, d_oracle, d_builds, d_err = _compare(orc, x, y, pts)
+        assert ok.sum() > 120, name
+        assert d_oracle < 0.03 and d_builds < 0.03 and d_oracle <= 2.0 * d_builds + 3e-3, (name, d_oracle, d_builds)
+        print(f"\ncolour {name}: {int(ok.sum())} of {len(pts)} tracked, oracle vs upstream builds {d_oracle:.4f} px, "
+              f"builds among themselves {d_builds:.4f} px, status identical")
