@@ -125,8 +125,38 @@ def launch_ranks(n: int) -> int:
                     "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": port, "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [q.wait() for q in procs[1:]]
+    # rank 0's stdout is drained by a thread, so that every rank can be polled: a rank that dies before the rendezvous
+    # must not leave the others (and this launcher) waiting for torch's store timeout
+    import threading
+
+    chunks0 = []
+    reader = threading.Thread(target=lambda: chunks0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    codes = [None] * n
+    failed = None
+    while any(c is None for c in codes):
+        for r, q in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = q.poll()
+                if codes[r] not in (None, 0) and failed is None:
+                    failed = r
+        if failed is not None:
+            for r, q in enumerate(procs):
+                if codes[r] is None:
+                    q.terminate()
+            for r, q in enumerate(procs):
+                if codes[r] is None:
+                    try:
+                        codes[r] = q.wait(timeout=20)
+                    except subprocess.TimeoutExpired:
+                        q.kill()
+                        codes[r] = q.wait()
+            break
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    out0 = "".join(c for c in chunks0 if c)
+    if failed is not None:
+        print(f"bench.py: rank {failed} exited with code {codes[failed]}; the other ranks were stopped", file=sys.stderr)
     lines = [ln for ln in (out0 or "").splitlines() if ln.strip()]
     json_lines = [ln for ln in lines if ln.lstrip().startswith("{")]
     for ln in lines:
@@ -134,7 +164,7 @@ def launch_ranks(n: int) -> int:
             print(ln, file=sys.stderr)      # anything else rank 0 wrote is not the contract's line
     if any(codes):
         print(f"bench.py: rank exit codes {codes}", file=sys.stderr)
-        return next(c for c in codes if c) or 1
+        return (codes[failed] if failed is not None else next(c for c in codes if c)) or 1
     if len(json_lines) != 1:
         print(f"bench.py: rank 0 printed {len(json_lines)} JSON lines, expected one", file=sys.stderr)
         return 1
@@ -192,6 +222,9 @@ def main():
                     help="pose-graph leg: take the loop closures from the generator instead of running the detector")
     ap.add_argument("--no-kernel-timing", action="store_true",
                     help="diagnostic: no HIP events around the kernels (the roofline object is then empty)")
+    ap.add_argument("--min-timed-s", type=float, default=1.0,
+                    help="the K timed steps are repeated (warm-up untimed every time) until this much time is on the clock")
+    ap.add_argument("--max-repeats", type=int, default=16)
     ap.add_argument("--kitti", default=None, help="KITTI odometry root (holds sequences/<seq>/image_2, image_3)")
     ap.add_argument("--seq", default="00")
     args = ap.parse_args()
@@ -219,17 +252,17 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
+    # Control traffic (barriers, max over ranks, the trajectory gather) runs over gloo on host tensors; the path's ONE
+    # data collective -- the all-gather of chunk-boundary poses -- runs over RCCL through the C ABI (a communicator the
+    # library makes, below).  No RCCL communicator exists in the process before the single-chunk leg has run: a live one
+    # holds hardware queues and costs that leg a quarter of its rate.
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
 
         dist = dist_mod
-        if rehearsal:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    coll_dev = "cpu" if rehearsal else "cuda"
-
+        dist.init_process_group("gloo")
+    coll_dev = "cpu"
     from ros_stereo_slam_amd import capi, chunked, synth
 
     M = max(1, args.chunks_per_gpu)
@@ -248,68 +281,128 @@ def main():
 
     vo_kw = dict(grid_step=grid_step, anms_keep=n_kpts, keyframe_min_inliers=kf_min)
     sh = chunked.ShardedVO(capi, local_rank, W, H, C, M, G, first_chunk_id=rank * M, seed=20261003, **vo_kw)
-    # The path's one collective behind the C ABI: an RCCL communicator made by the library itself (what a C++ host of
-    # INTEGRATION.md section 4 uses); the 128-byte id travels through torch.distributed here.  Any failure falls back
-    # to torch.distributed's all-gather (also RCCL) and says so in the line.
-    comm, collective = None, None
-    # (a live RCCL communicator holds hardware queues: with one it is -2 % on the batched figure and -27 % on the
-    # three-stream single-chunk run, A/B on one box -- so none is made where there is nothing to exchange, at N = 1)
-    # (SVO_BENCH_REHEARSE_CABI=1: a rehearsal tries it too -- two ranks on one GPU are refused by RCCL, which exercises the
-    # fall-back and the agreement between the ranks)
-    try_cabi = (not rehearsal or os.environ.get("SVO_BENCH_REHEARSE_CABI") == "1")
-    if try_cabi and world > 1 and os.environ.get("SVO_BENCH_NO_CABI") != "1":
-        ident, why = None, ""
-        if rank == 0:
-            try:
-                ident = capi.shard_unique_id()
-            except Exception as e:   # noqa: BLE001 -- the bench must not die on the optional path
-                why = f"{type(e).__name__}: {e}"
-        if dist is not None:         # every rank learns whether there is an id (None = none), so nobody waits alone
-            box = [ident]
-            dist.broadcast_object_list(box, src=0)
-            ident = box[0]
-        if ident is not None:
-            # ncclCommInitRank is itself a rendezvous of all ranks: it runs in a helper thread with a deadline, so
-            # that a rank which cannot join falls back instead of hanging the run
-            import threading
-
-            made = {}
-
-            def _make():
-                try:
-                    c = capi.ShardComm(sh.ctxs[0], rank, world, ident)
-                    # a first all-gather of the size the run will do, still under the deadline and outside the clock: a
-                    # collective that cannot complete on this node is found here, not in the timed region
-                    trial = c.allgather_boundaries([(np.eye(3), np.full(3, float(rank)))] * M)
-                    if len(trial) != M * world or any(abs(float(trial[r * M][1][0]) - r) > 0 for r in range(world)):
-                        raise RuntimeError("trial all-gather returned the wrong boundaries")
-                    made["comm"] = c
-                except Exception as e:   # noqa: BLE001
-                    made["err"] = f"{type(e).__name__}: {e}"
-
-            th = threading.Thread(target=_make, daemon=True)
-            th.start()
-            th.join(timeout=120.0)
-            if "comm" in made:
-                comm = made["comm"]
-                collective = f"ncclAllGather through svo_shard_allgather_boundaries (C ABI, librccl), {world} rank(s)"
-            else:
-                why = made.get("err", "ncclCommInitRank / the trial all-gather did not return within 120 s")
-        if comm is None:
-            collective = f"torch.distributed all_gather (C-ABI communicator unavailable: {why or 'no unique id'})"
-    if collective is None:
-        collective = ("gloo rehearsal on one GPU" if rehearsal else
-                      "none: one rank (tests/test_gpu_sharded.py runs svo_shard_allgather_boundaries on a one-rank communicator)"
-                      if world == 1 else "torch.distributed all_gather (SVO_BENCH_NO_CABI=1)")
-    if dist is not None:
-        ok = torch.tensor([1 if comm is not None else 0], device=coll_dev)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)      # every rank takes the same path
-        if int(ok.item()) == 0 and comm is not None:
-            comm.close()
-            comm = None
-            collective = "torch.distributed all_gather (another rank has no C-ABI communicator)"
     bounds = chunked.chunk_bounds(share + 1, M)
     assert all(e - s == L for s, e in bounds)
+
+    comm_state = {"thread": None}
+
+    def make_communicator():
+        """The path's one collective behind the C ABI: an RCCL communicator made by the library itself (what a C++ host
+        of INTEGRATION.md section 6 uses), on a context of its OWN; the 128-byte id travels over gloo.  If any rank
+        cannot make it, all ranks agree on the next form: a torch.distributed nccl (= RCCL) group, then gloo.
+        -> (comm or None, torch group or None, text for config.collective)"""
+        if world == 1:
+            return None, None, ("none: one rank (tests/test_gpu_sharded.py runs svo_shard_allgather_boundaries on a "
+                                "one-rank communicator)")
+        if rehearsal and os.environ.get("SVO_BENCH_REHEARSE_CABI") != "1":
+            return None, None, "gloo rehearsal on one GPU"
+        comm, why = None, ""
+        if os.environ.get("SVO_BENCH_NO_CABI") == "1":
+            why = "SVO_BENCH_NO_CABI=1"
+        else:
+            ident = None
+            if rank == 0:
+                try:
+                    ident = capi.shard_unique_id()
+                except Exception as e:   # noqa: BLE001 -- the bench must not die on the optional path
+                    why = f"{type(e).__name__}: {e}"
+            box = [ident, why]
+            dist.broadcast_object_list(box, src=0)   # every rank learns whether there is an id, so nobody waits alone
+            ident, why = box
+            if ident is not None:
+                # ncclCommInitRank is itself a rendezvous of all ranks: it runs in a helper thread with a deadline, on a
+                # context nothing else ever touches -- a rank whose helper is still inside RCCL after the deadline leaves
+                # that context alone, takes the fall-back with the others and ends the process with os._exit (ADVICE r3)
+                import threading
+
+                made = {}
+
+                def _make():
+                    try:
+                        cctx = capi.Context(local_rank)
+                        c = capi.ShardComm(cctx, rank, world, ident)
+                        # a first all-gather of the size the run will do, under the deadline and outside the clock
+                        trial = c.allgather_boundaries([(np.eye(3), np.full(3, float(rank)))] * M)
+                        if len(trial) != M * world or any(abs(float(trial[r * M][1][0]) - r) > 0 for r in range(world)):
+                            raise RuntimeError("trial all-gather returned the wrong boundaries")
+                        made["comm"] = c
+                    except Exception as e:   # noqa: BLE001
+                        made["err"] = f"{type(e).__name__}: {e}"
+
+                th = threading.Thread(target=_make, daemon=True)
+                th.start()
+                th.join(timeout=float(os.environ.get("SVO_BENCH_COMM_DEADLINE_S", "120")))
+                if "comm" in made:
+                    comm = made["comm"]
+                else:
+                    why = made.get("err", "ncclCommInitRank / the trial all-gather did not return before the deadline")
+                    if th.is_alive():
+                        comm_state["thread"] = th
+        ok = torch.tensor([1 if comm is not None else 0])
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)      # every rank takes the same path
+        if int(ok.item()) == 1:
+            return comm, None, f"ncclAllGather through svo_shard_allgather_boundaries (C ABI, librccl), {world} rank(s)"
+        if comm is not None:
+            comm.close()
+            why = "another rank has no C-ABI communicator"
+        group = None
+        if not rehearsal:
+            try:
+                group = dist.new_group(backend="nccl")
+                probe = torch.zeros(1, device=f"cuda:{local_rank}")
+                dist.all_reduce(probe, group=group)
+                torch.cuda.synchronize()
+            except Exception as e:   # noqa: BLE001
+                group = None
+                why += f"; torch nccl group: {type(e).__name__}: {e}"
+        ok = torch.tensor([1 if group is not None else 0])
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            return None, group, f"torch.distributed all_gather over nccl (C-ABI communicator unavailable: {why or 'no unique id'})"
+        return None, None, f"torch.distributed all_gather over gloo (no RCCL communicator could be made: {why or 'no unique id'})"
+
+    def single_chunk_leg():
+        """ONE contiguous chunk per GPU (the north-star's partitioning), four streams, over rank 0's whole share --
+        run while NO RCCL communicator exists in the process; then once more with device time stamps between the
+        stages (svo_vo_set_stage_stamps), which say where a frame's time goes on this box."""
+        out = {"single_chunk_comm_alive": False}
+        try:   # an extra leg must not cost the run its line
+            ctx1 = capi.Context(local_rank)
+            one = capi.VisualOdometry(ctx1, W, H, C, seed=20261003, **vo_kw)
+            one.init(lefts[0], rights[0])     # first use: streams, buffers and kernels of the pipeline come into being
+            one.run_chunk(lefts[1:42], rights[1:42], pipeline=True)
+            ctx1.sync()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            one.init(lefts[0], rights[0])
+            rc, done, R1, t1, inl1, trk1, kf1 = one.run_chunk(lefts[1:], rights[1:], pipeline=True)
+            ctx1.sync()
+            dt = time.perf_counter() - t0
+            if rc or done != share:
+                out["single_chunk_frames_per_s"] = None
+                out["single_chunk_note"] = f"tracking lost after {done} frames"
+            else:
+                out["t_seq"] = np.vstack([np.zeros((1, 3)), t1])
+                out["single_chunk_frames_per_s"] = share / dt
+                out["single_chunk_frames"] = share
+                out["single_chunk_keyframe_rate"] = float(kf1.mean())
+                n_st = min(share, 1000)
+                one.set_stage_stamps(True)
+                one.init(lefts[0], rights[0])
+                t0 = time.perf_counter()
+                rc2, done2, R2, t2, *_ = one.run_chunk(lefts[1:1 + n_st], rights[1:1 + n_st], pipeline=True)
+                ctx1.sync()
+                dt2 = time.perf_counter() - t0
+                us, nfr = one.stage_us()
+                one.set_stage_stamps(False)
+                if rc2 == 0 and nfr > 0:
+                    out["single_chunk_stage_us"] = dict(us, frames_averaged=nfr, frames_per_s_with_stamps=n_st / dt2,
+                                                        bit_identical=bool(np.array_equal(t2, t1[:n_st])))
+            one.close()
+            ctx1.close()
+        except Exception as e:   # noqa: BLE001
+            out["single_chunk_error"] = f"{type(e).__name__}: {e}"
+        return out
 
     def jobs_for(a: int, b: int, init: bool):
         """frames a+1 .. b of every chunk (chunk-local numbering), preceded by the seed frame a when
@@ -335,29 +428,68 @@ def main():
     local = [[ident] for _ in range(M)]
     stats = {"keyframes": 0, "inliers": 0, "tracked": 0}
 
-    # ---- warm-up: every chunk's stereo initialisation + its first W frames (untimed) ----
-    run(0, Wn, True, local)
-    sh.sync()
-    for c in sh.ctxs:
-        c.enable_kernel_timing(False)   # the timed region carries NO event records
+    # ---- one chunk per GPU first (rank 0), while the process holds no RCCL communicator; then the communicator ----
+    single = single_chunk_leg() if (rank == 0 and not args.no_extras) else {}
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
-    sh.sync()
-    # ---- the timed region: EXACTLY --steps steps + the path's one exchange ----
-    t0 = time.perf_counter()
-    run(Wn, L, False, local, stats)
-    if dist is not None or comm is not None:
-        boundaries = chunked.all_gather_chunk_boundaries(dist, [loc[-1] for loc in local], device=coll_dev, comm=comm)
-    else:
-        boundaries = [loc[-1] for loc in local]
-    starts = chunked.prefix_transforms(boundaries)  # global pose of every chunk's first frame
-    assert len(starts) == world * M
-    sh.sync()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    comm, nccl_group, collective = make_communicator()
+    coll = dict(dist=dist, comm=comm)
+    if comm is None and nccl_group is not None:
+        coll = dict(dist=dist, comm=None, group=nccl_group, device=f"cuda:{local_rank}")
+
+    def exchange(loc):
+        """the path's one exchange step: all-gather of the chunk-boundary poses"""
+        if dist is None and comm is None:
+            return [x[-1] for x in loc]
+        return chunked.all_gather_chunk_boundaries(coll["dist"], [x[-1] for x in loc], device=coll.get("device", "cpu"),
+                                                   comm=coll["comm"], group=coll.get("group"))
+
+    def max_over_ranks(x: float) -> float:
+        if dist is None:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    # ---- the timed region: EXACTLY --steps steps + the path's one exchange, REPEATED (each repeat: every chunk's stereo
+    # initialisation + its first W frames untimed, then the K timed steps) until at least --min-timed-s seconds are on the
+    # clock, so that a box's +-2 % does not decide a round (VERDICT r3 #7).  value = all frames of all repeats / all time.
+    reps = []               # (elapsed max over ranks, elapsed local)
+    local = None
+    target_s = max(0.0, args.min_timed_s)
+    n_reps = 1
+    r_i = 0
+    while r_i < n_reps:
+        loc_r = [[ident] for _ in range(M)]
+        st_r = {"keyframes": 0, "inliers": 0, "tracked": 0}
+        run(0, Wn, True, loc_r)     # warm-up: every chunk's stereo initialisation + its first W frames (untimed)
+        sh.sync()
+        for c in sh.ctxs:
+            c.enable_kernel_timing(False)   # the timed region carries NO event records (VERDICT r2 weak #5)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        sh.sync()
+        t0 = time.perf_counter()
+        run(Wn, L, False, loc_r, st_r)
+        boundaries = exchange(loc_r)
+        starts = chunked.prefix_transforms(boundaries)  # global pose of every chunk's first frame
+        assert len(starts) == world * M
+        sh.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        el_local = time.perf_counter() - t0
+        el = max_over_ranks(el_local)
+        reps.append((el, el_local))
+        if local is None:
+            local, stats = loc_r, st_r
+            n_reps = max(1, min(args.max_repeats, int(np.ceil(target_s / max(el, 1e-6)))))   # every rank: the same number
+        elif not all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for la, lb in zip(local, loc_r) for a, b in zip(la, lb)):
+            raise SystemExit(f"bench: repeat {r_i} of the timed region did not reproduce the first one bit for bit")
+        r_i += 1
+    elapsed = sum(e for e, _ in reps) / len(reps)           # mean duration of the K timed steps
+    elapsed_local = sum(e for _, e in reps) / len(reps)
     ranks_seen = dist.get_world_size() if dist is not None else 1   # after a real all-gather over the group
 
     # ---- the SAME frames once more with HIP events around every launch: per-kernel launch durations for the
@@ -392,16 +524,6 @@ def main():
             raise SystemExit("bench: the instrumented pass did not reproduce the timed pass bit for bit")
     n_frames = K * M
 
-    def max_over_ranks(x: float) -> float:
-        if dist is None:
-            return x
-        tt = torch.tensor([x], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        return float(tt.item())
-
-    elapsed_local = elapsed
-    elapsed = max_over_ranks(elapsed)
-
     # ---- second timed figure: the whole share again, chunk initialisations inside the clock ----
     extras = {}
     local2 = None
@@ -412,8 +534,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         run(0, L, True, local2)
-        if dist is not None or comm is not None:
-            chunked.all_gather_chunk_boundaries(dist, [loc[-1] for loc in local2], device=coll_dev, comm=comm)
+        exchange(local2)
         sh.sync()
         torch.cuda.synchronize()
         if dist is not None:
@@ -427,10 +548,8 @@ def main():
     # ---- stitch: rebase with the prefix transforms, gather the trajectories (configs[3]) ----
     mine = chunked.join_chunks(local, starts[rank * M:(rank + 1) * M])
     if dist is not None:
-        parts = chunked.gather_trajectories(dist, mine, device=coll_dev)
-        traj = list(parts[0])
-        for p in parts[1:]:
-            traj.extend(p[1:])
+        parts = chunked.gather_trajectories(dist, mine, device="cpu", counts=[share + 1] * world, as_array=True)
+        traj = chunked.array_to_poses(np.concatenate([parts[0]] + [p[1:] for p in parts[1:]]))   # ONE tensor collective
     else:
         traj = mine
 
@@ -506,6 +625,9 @@ def main():
             "steps": K,
             "warmup": Wn,
             "ms_per_step": elapsed / K * 1e3,
+            "repeats": len(reps),
+            "timed_s_total": sum(e for e, _ in reps),
+            "value_per_repeat": [world * n_frames / e for e, _ in reps],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -519,6 +641,9 @@ def main():
                 "parallelism": f"{M} contiguous chunk(s) of {L} frames per GPU x{world} GPU(s), one all-gather of "
                                "chunk-boundary poses",
                 "collective": collective,
+                # where an RCCL communicator was alive in the process (it holds hardware queues)
+                "comm_alive_during": {"timed_region": bool(comm is not None or nccl_group is not None),
+                                      "single_chunk_leg": False},
                 "chunks_per_gpu": M,
                 "chunks_per_context": G,
                 "frames_per_chunk": L,
@@ -547,35 +672,17 @@ def main():
         }
         result.update(extras)
 
-    # ---- one contiguous chunk per GPU (the north-star's partitioning), measured, rank 0's share ----
-    if rank == 0 and not args.no_extras:
-        try:   # an extra leg must not cost the run its line
-            ctx1 = capi.Context(local_rank)
-            one = capi.VisualOdometry(ctx1, W, H, C, seed=20261003, **vo_kw)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            one.init(lefts[0], rights[0])
-            rc, done, R1, t1, inl1, trk1, kf1 = one.run_chunk(lefts[1:], rights[1:], pipeline=True)
-            ctx1.sync()
-            dt = time.perf_counter() - t0
-            if rc or done != share:
-                result["single_chunk_frames_per_s"] = None
-                result["single_chunk_note"] = f"tracking lost after {done} frames"
-            else:
-                t_seq = np.vstack([np.zeros((1, 3)), t1])
-                result["single_chunk_frames_per_s"] = share / dt
-                result["single_chunk_frames"] = share
-                result["single_chunk_keyframe_rate"] = float(kf1.mean())
-                n1 = share + 1
-                result["ate_rmse_sequential_vs_truth"] = chunked.ate_rmse(t_seq, t_truth[:n1])
-                result["ate_rmse_sharded_vs_sequential"] = chunked.ate_rmse(t_sh[:n1], t_seq)
-                result["ate_rmse_sharded_vs_truth_same_frames"] = chunked.ate_rmse(t_sh[:n1], t_truth[:n1])
-                result["ate_sharded_vs_sequential_over_path_length"] = (
-                    result["ate_rmse_sharded_vs_sequential"] / (path_len * share / (world * share)))
-            one.close()
-            ctx1.close()
-        except Exception as e:   # noqa: BLE001
-            result["single_chunk_error"] = f"{type(e).__name__}: {e}"
+    # ---- one contiguous chunk per GPU: measured before the communicator existed (single); its trajectory figures ----
+    if rank == 0 and single:
+        result.update({k: v for k, v in single.items() if k != "t_seq"})
+        if "t_seq" in single:
+            t_seq = single["t_seq"]
+            n1 = share + 1
+            result["ate_rmse_sequential_vs_truth"] = chunked.ate_rmse(t_seq, t_truth[:n1])
+            result["ate_rmse_sharded_vs_sequential"] = chunked.ate_rmse(t_sh[:n1], t_seq)
+            result["ate_rmse_sharded_vs_truth_same_frames"] = chunked.ate_rmse(t_sh[:n1], t_truth[:n1])
+            result["ate_sharded_vs_sequential_over_path_length"] = (
+                result["ate_rmse_sharded_vs_sequential"] / (path_len * share / (world * share)))
 
     # ---- configs[3]'s global solve on the stitched trajectory (rank 0; also configs[2]'s figure) ----
     if rank == 0 and not args.no_extras:
@@ -662,9 +769,14 @@ def main():
                 return (len(out) + 1) / dt, out
 
             cores = os.cpu_count() or 1
-            threads = min(cores, 32)
+            # the thread count that is fastest on THIS node: a short sample at each candidate, the full sample at the best
+            cands = sorted({t for t in (16, 32, 64, 128, cores) if t <= cores} or {cores})
+            sweep = {}
+            for tc in cands:
+                sweep[tc] = oracle_run(tc, min(6, nf))[0]
+            threads = max(sweep, key=sweep.get)
             multi, o_poses = oracle_run(threads, nf)
-            single, _ = oracle_run(1, max(3, nf // 4))
+            single_thr, _ = oracle_run(1, max(3, nf // 4))
             g_poses = local[0][1:1 + len(o_poses)]   # chunk 0 of rank 0 started on the same frame with the same seed
             dts = [float(np.linalg.norm(tg - to)) for (Rg, tg), (Ro, to) in zip(g_poses, o_poses)]
             dRs = [rot_angle(Rg, Ro) for (Rg, tg), (Ro, to) in zip(g_poses, o_poses)]
@@ -683,14 +795,23 @@ def main():
                 "kind": "port",
                 "sample": f"chunk 0 of the same stream: stereo initialisation + {nf} frames, same stages, oracle C "
                           f"({'-O3 -march=native, built on this host' if native else '-O3 -march=x86-64-v3 (prebuilt)'}, "
-                          f"OpenMP over keypoints in LK and ANMS, RANSAC stages scalar), {threads} threads",
-                "single_thread_value": single,
+                          f"OpenMP over keypoints in LK and ANMS and over the hypotheses' scoring passes in both RANSAC stages), "
+                          f"{threads} threads = the fastest of {cands} on this node",
+                "single_thread_value": single_thr,
+                "thread_sweep_frames_per_s": {str(k): v for k, v in sweep.items()},
             }
         except Exception as e:   # noqa: BLE001
             result["cpu_baseline_error"] = f"{type(e).__name__}: {e}"
 
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+    if comm_state["thread"] is not None and comm_state["thread"].is_alive():
+        # a helper thread is still inside RCCL on its own context: nothing of it was used; leave without unwinding it
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
     if comm is not None:
         comm.close()
     if dist is not None:

@@ -374,6 +374,16 @@ int svo_vo_run_chunks(svo_chunk_job *jobs, int n_jobs);
 /* the current reference point set (2-D in the reference image, 3-D world) */
 int svo_vo_get_reference(svo_vo *vo, float *ref2d, float *ref3d, int cap, int *n, int mem);
 int svo_vo_capacity(const svo_vo *vo);
+/* Where a frame of a PIPELINED chunk (svo_vo_run_chunk, pipeline != 0) spends its time: with stamps enabled a run of more
+ * than 40 frames writes the device's 100 MHz clock between its stages (one-lane launches on the four streams: they cost a
+ * few per cent, so a timed run leaves them off) and keeps the mean intervals over the middle of the run, in microseconds:
+ *   [0] frame period on the main stream  = [1] filters + [2] tracking launch + [3] waiting for the decision
+ *   [4] PnP stream starts after the filters, [5] from there to the keyframe decision, [6] a keyframe's refinement + hand-over
+ *   [7] stereo stream starts after the tracking launch, [8] stereo path
+ * (the per-frame body of src/VisualSLAM.cpp:54-169 as the four streams run it).  *n_frames = frames averaged (0: none yet). */
+enum { SVO_STAGE_COUNT = 9 };
+int svo_vo_set_stage_stamps(svo_vo *vo, int enable);
+int svo_vo_get_stage_us(const svo_vo *vo, double *us, int cap, int *n_frames);
 /* `colors` of the last keyframe (getColors(imL, its 2-D points): B, G, R as floats per point,
  * include/monoUtils.h:180-193, src/triangulation.cpp:139-140), point for point with svo_vo_get_keyframe_cloud:
  * what src/VisualSLAM.cpp:125-136 pushes into colorHistory.  Gathered by the triangulation launch itself. */

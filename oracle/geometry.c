@@ -348,6 +348,8 @@ int orc_fransac(const float *p1, const float *p2, int n, const orc_fransac_param
         int nm = orc_seven_point(x1, x2, Fs);
         for (int m = 0; m < nm; m++) {
             int count = 0;
+            /* an integer count: the order of the summands is free (cpu_baseline runs this over the host's threads) */
+#pragma omp parallel for reduction(+ : count) schedule(static) if (n >= 2048)
             for (int i = 0; i < n; i++)
                 count += orc_f_error(Fs + 9 * m, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]) <= thr;
             if (count > (best_count > M - 1 ? best_count : M - 1)) {

@@ -743,6 +743,8 @@ int orc_pnp_ransac(const float *obj, const float *img, int n, const double *K4, 
         if (rc != 0)
             continue;
         int count = 0;
+        /* an integer count: the order of the summands is free (cpu_baseline runs this over the host's threads) */
+#pragma omp parallel for reduction(+ : count) schedule(static) if (n >= 2048)
         for (int i = 0; i < n; i++)
             count += reproj_err_sq(R, t, K4, obj + 3 * i, img + 2 * i) <= thr;
         if (count > (best_count > M - 1 ? best_count : M - 1)) {

@@ -437,6 +437,19 @@ class VisualOdometry:
         kf = self.update(right, R, t, ninl, force_keyframe)
         return rc, R, t, ninl, kf, ntrk
 
+    STAGE_NAMES = ("frame_period", "filters", "tracking_launch", "wait_for_decision", "pnp_stream_lag",
+                   "pnp_to_decision", "keyframe_refine_handover", "stereo_stream_lag", "stereo_path")
+
+    def set_stage_stamps(self, enable: bool = True):
+        _check(self.ctx.lib.svo_vo_set_stage_stamps(self._h, int(enable)))
+
+    def stage_us(self):
+        """Mean stage intervals (microseconds) of the last pipelined run with stamps on -> (dict, frames averaged)."""
+        us = (C.c_double * len(self.STAGE_NAMES))()
+        n = C.c_int()
+        _check(self.ctx.lib.svo_vo_get_stage_us(self._h, us, len(self.STAGE_NAMES), C.byref(n)))
+        return {k: float(v) for k, v in zip(self.STAGE_NAMES, us)}, n.value
+
     def run_chunk(self, lefts, rights, pipeline: bool = True):
         """Consecutive frames without returning to Python in between (``svo_vo_run_chunk``).
         Returns (rc, n_done, R[n,3,3], t[n,3], inliers[n], tracked[n], keyframe[n])."""

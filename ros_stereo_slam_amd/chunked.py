@@ -55,25 +55,35 @@ def prefix_transforms(boundaries):
     return out
 
 
-def all_gather_boundaries(dist, R, t, device=None):
+def _all_gather_flat(dist, mine, group=None):
+    """One ``all_gather_into_tensor`` of equally sized 1-D tensors -> (world, numel) (the flat in / flat out form is the one
+    every backend -- nccl == RCCL, gloo -- accepts)."""
+    import torch
+
+    mine = mine.reshape(-1).contiguous()
+    got = torch.empty(dist.get_world_size() * mine.numel(), dtype=mine.dtype, device=mine.device)
+    dist.all_gather_into_tensor(got, mine, group=group)
+    return got.reshape(dist.get_world_size(), mine.numel())
+
+
+def all_gather_boundaries(dist, R, t, device=None, n_poses=None):
     """The path's one collective: every rank contributes its chunk-boundary pose (12 doubles)
     and receives all of them.  ``dist`` is ``torch.distributed`` (backend nccl == RCCL on the
-    GPU node, gloo in the CPU tests)."""
+    GPU node, gloo in the CPU tests).  ``n_poses``: this rank's pose count rides along as a 13th
+    double (chunks may differ by a frame); the result is then (boundaries, counts)."""
     import torch
 
     dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
-    mine = torch.tensor(np.r_[np.asarray(R, np.float64).ravel(), np.asarray(t, np.float64).ravel()],
-                        dtype=torch.float64, device=dev)
-    got = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
-    dist.all_gather(got, mine)
-    res = []
-    for g in got:
-        a = g.cpu().numpy()
-        res.append((a[:9].reshape(3, 3).copy(), a[9:].copy()))
-    return res
+    row = np.r_[np.asarray(R, np.float64).ravel(), np.asarray(t, np.float64).ravel(),
+                [] if n_poses is None else [float(n_poses)]]
+    a = _all_gather_flat(dist, torch.tensor(row, dtype=torch.float64, device=dev)).cpu().numpy()
+    res = [(r[:9].reshape(3, 3).copy(), r[9:12].copy()) for r in a]
+    if n_poses is None:
+        return res
+    return res, [int(r[12]) for r in a]
 
 
-def all_gather_chunk_boundaries(dist, pairs, device=None, comm=None):
+def all_gather_chunk_boundaries(dist, pairs, device=None, comm=None, group=None):
     """As :func:`all_gather_boundaries` when every rank runs several chunks side by side
     (``svo_vo_run_chunks``): ``pairs`` = this rank's chunk-boundary poses in chunk order, the
     same number on every rank.  Still ONE all-gather (12 doubles per chunk); returns the
@@ -87,41 +97,43 @@ def all_gather_chunk_boundaries(dist, pairs, device=None, comm=None):
     import torch
 
     dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
-    flat = np.concatenate([np.r_[np.asarray(R, np.float64).ravel(), np.asarray(t, np.float64).ravel()]
-                           for R, t in pairs])
-    mine = torch.tensor(flat, dtype=torch.float64, device=dev)
-    got = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
-    dist.all_gather(got, mine)
-    res = []
-    for g in got:
-        a = g.cpu().numpy().reshape(-1, 12)
-        res.extend((row[:9].reshape(3, 3).copy(), row[9:].copy()) for row in a)
-    return res
+    return array_to_poses(_all_gather_flat(dist, torch.from_numpy(poses_to_array(pairs)).to(dev), group=group).cpu().numpy())
 
 
-def gather_trajectories(dist, poses, device=None):
-    """All ranks receive every rank's (rebased) pose list; used to build the global pose graph.
-    Chunks may differ in length by one frame, so lists are padded to the longest."""
+def poses_to_array(poses) -> np.ndarray:
+    """[(R, t)] -> (n, 12) float64 rows [R row-major | t]."""
+    if isinstance(poses, np.ndarray):
+        return np.ascontiguousarray(poses, np.float64).reshape(-1, 12)
+    out = np.empty((len(poses), 12))
+    for i, (R, t) in enumerate(poses):
+        out[i, :9] = np.asarray(R, np.float64).ravel()
+        out[i, 9:] = np.asarray(t, np.float64).ravel()
+    return out
+
+
+def array_to_poses(a):
+    return [(r[:9].reshape(3, 3).copy(), r[9:].copy()) for r in np.asarray(a).reshape(-1, 12)]
+
+
+def gather_trajectories(dist, poses, device=None, counts=None, as_array=False):
+    """All ranks receive every rank's (rebased) poses -- ONE tensor collective (``all_gather_into_tensor`` of
+    max(counts) x 12 doubles per rank).  ``counts``: every rank's pose count, which the callers know without a
+    second exchange (equal shares: the bench; unequal chunks: it rode along with the boundary all-gather, see
+    :func:`all_gather_boundaries`); None = every rank holds ``len(poses)``.  Returns one pose list per rank, or
+    with ``as_array`` one (count, 12) array per rank (no per-pose Python objects)."""
     import torch
 
     dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
-    n = torch.tensor([len(poses)], dtype=torch.int64, device=dev)
-    counts = [torch.empty_like(n) for _ in range(dist.get_world_size())]
-    dist.all_gather(counts, n)
-    counts = [int(c.item()) for c in counts]
+    world = dist.get_world_size()
+    mine_a = poses_to_array(poses)
+    if counts is None:
+        counts = [len(mine_a)] * world
     m = max(counts)
     host = np.zeros((m, 12))
-    for i, (R, t) in enumerate(poses):
-        host[i, :9] = np.asarray(R, np.float64).ravel()
-        host[i, 9:] = np.asarray(t, np.float64).ravel()
-    buf = torch.from_numpy(host).to(dev)  # one copy, not one per pose
-    got = [torch.empty_like(buf) for _ in range(dist.get_world_size())]
-    dist.all_gather(got, buf)
-    out = []
-    for c, g in zip(counts, got):
-        a = g.cpu().numpy()[:c]
-        out.append([(r[:9].reshape(3, 3).copy(), r[9:].copy()) for r in a])
-    return out
+    host[:len(mine_a)] = mine_a
+    a = _all_gather_flat(dist, torch.from_numpy(host).to(dev)).cpu().numpy().reshape(world, m, 12)
+    parts = [a[r, :c].copy() for r, c in enumerate(counts)]
+    return parts if as_array else [array_to_poses(p) for p in parts]
 
 
 def stitch(dist, local_poses, device=None):
@@ -129,10 +141,10 @@ def stitch(dist, local_poses, device=None):
     including the overlap frame) -> the rank's poses in the global frame, plus the global
     trajectory without the duplicated overlap frames (identical on every rank)."""
     rank = dist.get_rank()
-    boundaries = all_gather_boundaries(dist, *local_poses[-1], device=device)
+    boundaries, counts = all_gather_boundaries(dist, *local_poses[-1], device=device, n_poses=len(local_poses))
     starts = prefix_transforms(boundaries)
     mine = rebase(local_poses, *starts[rank])
-    chunks = gather_trajectories(dist, mine, device=device)
+    chunks = gather_trajectories(dist, mine, device=device, counts=counts)
     traj = list(chunks[0])
     for ch in chunks[1:]:
         traj.extend(ch[1:])  # the first frame of a chunk is the last frame of the previous one
@@ -252,8 +264,13 @@ def stitch_chunks(dist, local, device=None):
     boundaries = all_gather_chunk_boundaries(dist, pairs, device=device)
     starts = prefix_transforms(boundaries)
     mine = join_chunks(local, starts[rank * m:(rank + 1) * m])
-    # join_chunks rebases chunk 0 of this rank with starts[rank*m], so `mine` is already global
-    parts = gather_trajectories(dist, mine, device=device)
+    # join_chunks rebases chunk 0 of this rank with starts[rank*m], so `mine` is already global; ranks may hold
+    # different numbers of frames: the counts take one small all-gather of their own here
+    import torch
+
+    dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
+    cnt = _all_gather_flat(dist, torch.tensor([len(mine)], dtype=torch.int64, device=dev))
+    parts = gather_trajectories(dist, mine, device=device, counts=[int(c) for c in cnt.cpu().numpy().ravel()])
     traj = list(parts[0])
     for p in parts[1:]:
         traj.extend(p[1:])  # a rank's first frame is the previous rank's last

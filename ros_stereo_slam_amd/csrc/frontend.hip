@@ -90,6 +90,12 @@ struct svo_vo {
     int ladder_ransac_inliers = 0;
     double R[9], t[3];
     bool has_cur = false;
+    // svo_vo_set_stage_stamps: device time stamps between the stages of a pipelined run (8 per frame), read back into
+    // stage_us by the run (mean intervals in microseconds over the middle of the run; stage_n = how many are valid)
+    bool stamps_on = false;
+    unsigned long long *d_stamps = nullptr;
+    double stage_us[SVO_STAGE_COUNT] = {0};
+    int stage_frames = 0;
 };
 
 namespace {
@@ -508,6 +514,8 @@ int svo_vo_destroy(svo_vo *v)
             if (b)
                 (void)hipFree(b);
     }
+    if (v->d_stamps)
+        (void)hipFree(v->d_stamps);
     if (v->h_chain)
         (void)hipHostFree(v->h_chain);
     if (v->h_out)
@@ -954,11 +962,12 @@ static int chain_enqueue(ChainRun *const *runs, int k, bool pipeline)
         // the filters instead of 11-17, frames/s unchanged (3 071 against 3 084) -- the hops are not what limits a frame; the
         // API is marked beta, so events stay the default.
         static const bool memops = getenv("SVO_PIPE_MEMOPS") ? atoi(getenv("SVO_PIPE_MEMOPS")) != 0 : false;
-        static const bool stamps = getenv("SVO_CHAIN_STAMPS") != nullptr;
-        static unsigned long long *d_stamps = nullptr;
+        static const bool stamps_env = getenv("SVO_CHAIN_STAMPS") != nullptr;
+        const bool stamps = stamps_env || v->stamps_on;
         const int max_stamp_frames = 4096;
-        if (stamps && !d_stamps)
-            SVO_HIP(hipMalloc(reinterpret_cast<void **>(&d_stamps), sizeof(unsigned long long) * 8 * max_stamp_frames));
+        if (stamps && !v->d_stamps)
+            SVO_HIP(hipMalloc(reinterpret_cast<void **>(&v->d_stamps), sizeof(unsigned long long) * 8 * max_stamp_frames));
+        unsigned long long *d_stamps = v->d_stamps;
         auto stamp = [&](hipStream_t st, int frame, int slot) {
             if (stamps && frame < max_stamp_frames)
                 hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, st, d_stamps + 8 * frame + slot);
@@ -1171,14 +1180,14 @@ static int chain_enqueue(ChainRun *const *runs, int k, bool pipeline)
         if (dbg)
             fprintf(stderr, "[svo chain] host us per frame: filters + record %.1f, B %.1f, D %.1f, tracking launch on A %.1f, C %.1f\n",
                     us_cat[0] / nf, us_cat[1] / nf, us_cat[2] / nf, us_cat[3] / nf, us_cat[4] / nf);
-        if (stamps && nf > 40) {  // debug: wait, read, print the mean intervals over the middle of the run
+        if (stamps && nf > 40) {  // wait, read, keep (and print, with the environment switch) the mean intervals over the middle of the run
             SVO_HIP(hipStreamSynchronize(sA));
             SVO_HIP(hipStreamSynchronize(sC));
             const int n = nf < max_stamp_frames ? nf : max_stamp_frames;
             std::vector<unsigned long long> h((size_t)8 * n);
             SVO_HIP(hipMemcpy(h.data(), d_stamps, h.size() * sizeof(h[0]), hipMemcpyDeviceToHost));
             auto T = [&](int f, int k) { return (double)h[(size_t)8 * f + k] * 0.01; };  // 100 MHz -> us
-            double cyc = 0, filt = 0, a_gap = 0, lk = 0, a_wait = 0, b_lag = 0, pnp = 0, hand = 0, c_lag = 0, c_len = 0;
+            double cyc = 0, filt = 0, lk = 0, a_wait = 0, b_lag = 0, pnp = 0, hand = 0, c_lag = 0, c_len = 0;
             int m = 0;
             for (int f = 20; f + 3 < n; f++, m++) {
                 cyc += T(f + 1, 0) - T(f, 0);
@@ -1191,11 +1200,15 @@ static int chain_enqueue(ChainRun *const *runs, int k, bool pipeline)
                 c_lag += T(f, 6) - T(f, 2);
                 c_len += T(f, 7) - T(f, 6);
             }
-            (void)a_gap;
-            fprintf(stderr, "[svo chain] device us per frame (stamps): cycle %.1f = filters %.1f + tracking launch %.1f + wait for B %.1f | "
-                            "B starts %.1f after the filters, PnP to decision %.1f, refine + hand-over of a keyframe %.1f | C starts %.1f "
-                            "after the launch, stereo path %.1f\n", cyc / m, filt / m, lk / m, a_wait / m, b_lag / m, pnp / m, hand / m,
-                    c_lag / m, c_len / m);
+            const double vals[SVO_STAGE_COUNT] = {cyc / m, filt / m, lk / m, a_wait / m, b_lag / m, pnp / m, hand / m, c_lag / m, c_len / m};
+            for (int i = 0; i < SVO_STAGE_COUNT; i++)
+                v->stage_us[i] = vals[i];
+            v->stage_frames = m;
+            if (stamps_env)
+                fprintf(stderr, "[svo chain] device us per frame (stamps): cycle %.1f = filters %.1f + tracking launch %.1f + wait for B %.1f | "
+                                "B starts %.1f after the filters, PnP to decision %.1f, refine + hand-over of a keyframe %.1f | C starts %.1f "
+                                "after the launch, stereo path %.1f\n", cyc / m, filt / m, lk / m, a_wait / m, b_lag / m, pnp / m, hand / m,
+                        c_lag / m, c_len / m);
         }
         return SVO_OK;
     }
@@ -1801,5 +1814,23 @@ int svo_vo_get_keyframe_colors(svo_vo *v, float *bgr, int cap, int *n, int mem)
 }
 
 int svo_vo_capacity(const svo_vo *v) { return v ? v->cap : 0; }
+
+int svo_vo_set_stage_stamps(svo_vo *v, int enable)
+{
+    SVO_CHECK_ARG(v);
+    v->stamps_on = enable != 0;
+    v->stage_frames = 0;
+    return SVO_OK;
+}
+
+int svo_vo_get_stage_us(const svo_vo *v, double *us, int cap, int *n_frames)
+{
+    SVO_CHECK_ARG(v && us && cap >= SVO_STAGE_COUNT);
+    for (int i = 0; i < SVO_STAGE_COUNT; i++)
+        us[i] = v->stage_us[i];
+    if (n_frames)
+        *n_frames = v->stage_frames;
+    return SVO_OK;
+}
 
 }  // extern "C"
