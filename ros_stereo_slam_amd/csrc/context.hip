@@ -1,6 +1,7 @@
 // context.hip -- svo_ctx: device, stream, scratch, kernel timers, error text.
 #include <cstdarg>
 
+#include <cstdlib>
 #include "svo_internal.h"
 
 static thread_local char g_err[512] = "";
@@ -106,6 +107,12 @@ const char *svo_last_error(void) { return g_err; }
 
 int svo_ctx_create(int device, svo_ctx **out)
 {
+    static const int prio = getenv("SVO_CTX_PRIO") ? atoi(getenv("SVO_CTX_PRIO")) : 0;  // A/B experiments only
+    return svo_ctx_create_prio(device, prio, out);
+}
+
+int svo_ctx_create_prio(int device, int priority_class, svo_ctx **out)
+{
     SVO_CHECK_ARG(out != nullptr);
     *out = nullptr;
     int count = 0;
@@ -126,7 +133,13 @@ int svo_ctx_create(int device, svo_ctx **out)
     }
     svo_ctx *ctx = new svo_ctx();
     ctx->device = device;
-    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (priority_class == 0)
+        e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    else {
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        e = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, priority_class < 0 ? prio_hi : prio_lo);
+    }
     if (e != hipSuccess) {
         delete ctx;
         svo_set_error("hipStreamCreate -> %s", hipGetErrorString(e));

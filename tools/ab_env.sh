@@ -1,5 +1,6 @@
 #!/bin/bash
 # A/B of environment settings on ONE GPU box: tools/ab_env.sh ROUNDS "VAR=a" "VAR=b" ...  (BENCH_FLAGS as in ab.sh)
+# BENCH_KEY: the key of the JSON line to print (default value; e.g. single_chunk_frames_per_s)
 set -u
 cd "$GRAFT_REPO_ROOT" || exit 1
 ROUNDS=$1; shift
@@ -12,6 +13,6 @@ for r in $(seq 1 "$ROUNDS"); do
     python3 -c "
 import json
 d=json.loads(open('gpurun_out/abenv/${i}_$r.json').read().strip().splitlines()[-1])
-print('$v', $r, round(d['value']), flush=True)" || exit 1
+print('$v', $r, round(d['${BENCH_KEY:-value}']), flush=True)" || exit 1
   done
 done
