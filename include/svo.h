@@ -231,6 +231,40 @@ int svo_lc_submit(svo_lc *lc, const uint8_t *image, int mem);
 int svo_lc_collect(svo_lc *lc, int *status, int *query, int *match);
 int svo_lc_pending(const svo_lc *lc);
 
+/* ---- the vocabulary: OrbVocabulary of DBoW2 (include/visualSLAM.h:115-137 loads orb_voc00.yml.gz; the reference's own
+ * trainer: src/bagOfWordsDetector.cpp:46-56, OrbVocabulary(k = 9, L = 6, TF_IDF, L1_NORM).create(features)) ------------
+ * A tree of 256-bit centres: node 0 is the root, the children of a node have consecutive ids, the leaves are the words
+ * (numbered in node order), every word carries its idf weight.  svo_voc_create takes the arrays of a vocabulary that was
+ * loaded from a file (ros_stereo_slam_amd/vocabulary.py reads DBoW2's .yml / .yml.gz); svo_voc_train builds one on the GPU
+ * by hierarchical k-medians++ in Hamming space from host descriptors (8 words each; image i owns
+ * [img_off[i], img_off[i + 1])).  svo_voc_transform: per feature the word, its weight and the ancestor `levelsup` levels
+ * above the leaf (the direct index's node).  svo_voc_bow: an image's BowVector -- TF-IDF, L1-normalised, ascending word
+ * order -- and per feature its direct-index node (-1: weight 0, the feature is in neither).                              */
+typedef struct svo_voc svo_voc;
+int svo_voc_create(svo_ctx *ctx, int k, int L, int n_nodes, const int *parent, const uint32_t *desc, const double *weight,
+                   svo_voc **out);
+int svo_voc_train(svo_ctx *ctx, const uint32_t *desc, const int *img_off, int n_images, int k, int L, uint64_t seed,
+                  svo_voc **out);
+int svo_voc_destroy(svo_voc *voc);
+int svo_voc_info(const svo_voc *voc, int *k, int *L, int *n_nodes, int *n_words);
+int svo_voc_export(const svo_voc *voc, int *parent, uint32_t *desc, double *weight, int *word_id);
+int svo_voc_transform(svo_voc *voc, const uint32_t *desc, int n, int levelsup, int *word, double *weight, int *node, int mem);
+int svo_voc_bow(svo_voc *voc, const uint32_t *desc, int n, int levelsup, int *words, double *values, int *n_words,
+                int *node_per_feature);
+/* The detector with the reference's scoring: once a vocabulary is set (before the first frame), entries are scored as
+ * DBoW2 does -- BowVector per frame, inverted-file query with the L1 score (TemplatedDatabase::queryL1), normalisation by
+ * the score against the previous frame (use_nss), alpha, islands, temporal window -- and the geometric check matches
+ * through the direct index at di_levels (GEOM_DI, include/TemplatedLoopDetector.h:1005-1087).  The vocabulary must
+ * outlive the detector.  Without one the detector keeps its vocabulary-free similarity (svo_lc_params.hamming_threshold). */
+int svo_lc_set_vocabulary(svo_lc *lc, svo_voc *voc, int di_levels);
+/* a frame given by its FEATURES instead of its image (a chunk-sharded run: every rank extracts svo_orb_extract on its own
+ * frames, the 20 KB per frame travel to the rank that holds the database): xy n*2 floats, desc n*8 words               */
+int svo_lc_submit_features(svo_lc *lc, const float *xy, const uint32_t *desc, int n, int mem);
+/* svo_lc_collect that also hands out what the verdict was formed from: the candidates of the database query in score
+ * order (before removeLowScores) and the normalisation score; any pointer may be NULL                                    */
+int svo_lc_collect_ex(svo_lc *lc, int *status, int *query, int *match, int *cand_id, double *cand_score, int cap,
+                      int *n_cand, double *ns_factor);
+
 /* ---- ANMS: adaptiveNonMaximalSuppresion(keypoints, numToKeep), src/ANMS.cpp:18-67 ------------ */
 /* xy: n*2 floats, response: n floats (the reference's grid keypoints carry response 0; the
  * front-end passes the level-0 LK minimum eigenvalue).  out_idx: n ints capacity, receives the

@@ -34,11 +34,20 @@ class Params:
 
 
 class LoopDetector:
-    def __init__(self, params: Params | None = None):
+    """``voc`` (an ``orc.Vocabulary``): DBoW2's scoring -- BowVector per frame (TF-IDF, L1-normalised), the database query
+    with the L1 score (TemplatedDatabase::queryL1), the normalisation by the score against the previous frame's vector
+    (:733) -- and the geometric check through the direct index at ``di_levels`` (isGeometricallyConsistent_DI, :1005-1087).
+    Without a vocabulary: the vocabulary-free similarity of loopdet.c and the exhaustive matching (rounds 2-3)."""
+
+    def __init__(self, params: Params | None = None, voc=None, di_levels: int = 2):
         self.p = params or Params()
         self.keys, self.descs = [], []          # m_image_keys / m_image_descriptors
         self.window = dict(nentries=0, last_island=None, last_query=-1)
         self.last_desc = None                    # m_last_bowvec's stand-in
+        self.voc, self.di_levels = voc, di_levels
+        self.bows, self.nodes = [], []           # per entry: (words, values), direct-index node per feature
+        self.last_bow = None
+        self.last_query = None                   # (candidate ids, scores, ns factor) of the last frame, for the tests
 
     def _scores(self, desc, entries):
         if len(entries) == 0 or len(desc) == 0:
@@ -55,21 +64,48 @@ class LoopDetector:
         xy, octv, resp, d, desc = orc.orb_extract(image, self.p.n_features, self.p.fast_threshold)
         return self.detect_features(xy, desc)
 
+    def _bow_query(self, bow, max_id):
+        """TemplatedDatabase::queryL1 below max_id: [(id, score)] best first, cut to max_db_results"""
+        if max_id <= 0:
+            return []
+        stride = max(max(len(self.bows[e][0]) for e in range(max_id)), 1)
+        dbw, dbv = np.zeros((max_id, stride), np.int32), np.zeros((max_id, stride))
+        dbn = np.zeros(max_id, np.int32)
+        for e in range(max_id):
+            w, v = self.bows[e]
+            dbn[e] = len(w)
+            dbw[e, :len(w)], dbv[e, :len(w)] = w, v
+        sums, common = orc.bow_query(bow[0], bow[1], dbw, dbv, dbn)
+        order = sorted((e for e in range(max_id) if common[e] > 0), key=lambda e: (sums[e], e))[:self.p.max_db_results]
+        return [(int(e), float(-sums[e] / 2.0)) for e in order]
+
     def detect_features(self, xy, desc):
         p = self.p
         entry_id = len(self.keys)
         res = dict(query=entry_id, match=-1, status=CLOSE_MATCHES_ONLY)
+        bow = node = None
+        if self.voc is not None:
+            w, v, node = self.voc.bow(desc, self.di_levels)
+            bow = (w, v)
+        self.last_query = ([], [], 0.0)
         if entry_id > p.dislocal:
             max_id = entry_id - p.dislocal
             # m_database->query(bowvec, qret, max_db_results, max_id): ids < max_id, positive score, best first
-            ids = np.arange(max_id)
-            sc = self._scores(desc, list(ids))
-            order = sorted((i for i in ids if sc[i] > 0), key=lambda i: (-sc[i], i))[:p.max_db_results]
-            qret = [(int(i), float(sc[i])) for i in order]
+            if bow is not None:
+                qret = self._bow_query(bow, max_id)
+            else:
+                ids = np.arange(max_id)
+                sc = self._scores(desc, list(ids))
+                order = sorted((i for i in ids if sc[i] > 0), key=lambda i: (-sc[i], i))[:p.max_db_results]
+                qret = [(int(i), float(sc[i])) for i in order]
             if qret:
                 ns = 1.0
                 if p.use_nss:
-                    ns = float(self._scores(desc, [entry_id - 1])[0]) if self.last_desc is not None else 0.0
+                    if bow is not None:
+                        ns = -orc.bow_l1_sum(bow[0], bow[1], *self.last_bow)[0] / 2.0 if self.last_bow is not None else 0.0
+                    else:
+                        ns = float(self._scores(desc, [entry_id - 1])[0]) if self.last_desc is not None else 0.0
+                self.last_query = ([r[0] for r in qret], [r[1] for r in qret], ns)
                 if not p.use_nss or ns >= p.min_nss_factor:
                     qret = [r for r in qret if r[1] >= p.alpha * ns]          # removeLowScores
                     if qret:
@@ -80,7 +116,7 @@ class LoopDetector:
                             self._update_window(best, entry_id)
                             res["match"] = best["best_entry"]
                             if self.window["nentries"] > p.k:
-                                ok = self._geometric(best["best_entry"], xy, desc)
+                                ok = self._geometric(best["best_entry"], xy, desc, node)
                                 res["status"] = LOOP_DETECTED if ok else NO_GEOMETRICAL_CONSISTENCY
                             else:
                                 res["status"] = NO_TEMPORAL_CONSISTENCY
@@ -94,8 +130,12 @@ class LoopDetector:
                 res["status"] = NO_DB_RESULTS
         self.keys.append(np.asarray(xy, np.float32))
         self.descs.append(np.asarray(desc, np.uint32))
+        if bow is not None:
+            self.bows.append(bow)
+            self.nodes.append(node)
         if p.use_nss and entry_id + 1 > p.dislocal:
             self.last_desc = desc
+            self.last_bow = bow
         return res
 
     def _islands(self, q):
@@ -140,23 +180,26 @@ class LoopDetector:
             w["nentries"] = w["nentries"] + 1 if fit else 1
         w["last_island"], w["last_query"] = island, entry_id
 
-    def _geometric(self, old_entry, xy, desc):
+    def _geometric(self, old_entry, xy, desc, node=None):
         p = self.p
         A, B = self.descs[old_entry], desc
         if len(A) == 0 or len(B) == 0:
             return False
-        bj, d1, d2 = orc.lc_nearest2(A, B)
-        match_A, match_B = [], []
-        for i in range(len(A)):
-            if float(d1[i]) / float(d2[i]) <= p.max_neighbor_ratio:
-                jb = int(bj[i])
-                if jb not in match_B:
-                    match_B.append(jb)
-                    match_A.append(i)
-                else:
-                    k = match_B.index(jb)
-                    if d1[i] < d1[match_A[k]]:
-                        match_A[k] = i
+        if node is not None:   # GEOM_DI: only features under a common direct-index node are compared
+            match_A, match_B = (list(map(int, m)) for m in orc.di_matches(A, self.nodes[old_entry], B, node, p.max_neighbor_ratio))
+        else:
+            bj, d1, d2 = orc.lc_nearest2(A, B)
+            match_A, match_B = [], []
+            for i in range(len(A)):
+                if float(d1[i]) / float(d2[i]) <= p.max_neighbor_ratio:
+                    jb = int(bj[i])
+                    if jb not in match_B:
+                        match_B.append(jb)
+                        match_A.append(i)
+                    else:
+                        k = match_B.index(jb)
+                        if d1[i] < d1[match_A[k]]:
+                            match_A[k] = i
         if len(match_A) < p.min_Fpoints:
             return False
         old = self.keys[old_entry][match_A]

@@ -357,6 +357,141 @@ def lc_nearest2(A, B):
     return bj[:len(A)], d1[:len(A)], d2[:len(A)]
 
 
+# ---- bag of words (bow.c): DBoW2's vocabulary tree / BowVector / L1 score / direct index -----------------
+class Vocabulary:
+    """orc_voc: train(descs per image, k, L, seed) or from arrays; transform / bow vectors / scores."""
+
+    def __init__(self, handle):
+        self._h = handle
+        lib = load()
+        self.k, self.L = lib.orc_voc_k(handle), lib.orc_voc_levels(handle)
+        self.n_nodes, self.n_words = lib.orc_voc_nodes(handle), lib.orc_voc_words(handle)
+
+    @staticmethod
+    def _setup(lib):
+        lib.orc_voc_train.restype = C.c_void_p
+        lib.orc_voc_train.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint64]
+        lib.orc_voc_import.restype = C.c_void_p
+        lib.orc_voc_import.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        for f in ("orc_voc_free", "orc_voc_nodes", "orc_voc_words", "orc_voc_k", "orc_voc_levels", "orc_voc_export",
+                  "orc_voc_transform"):
+            getattr(lib, f).argtypes = [C.c_void_p] + [C.c_void_p] * {"orc_voc_export": 6}.get(f, 0) + \
+                ([C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p] if f == "orc_voc_transform" else [])
+        lib.orc_bow_l1_sum.restype = C.c_double
+
+    @classmethod
+    def train(cls, descs_per_image, k=9, L=6, seed=0):
+        lib = load()
+        cls._setup(lib)
+        off = np.zeros(len(descs_per_image) + 1, np.int32)
+        off[1:] = np.cumsum([len(d) for d in descs_per_image])
+        D = np.ascontiguousarray(np.concatenate([np.asarray(d, np.uint32).reshape(-1, 8) for d in descs_per_image]), np.uint32)
+        h = lib.orc_voc_train(_p(D), _p(off), len(descs_per_image), k, L, seed)
+        if not h:
+            raise ValueError("orc_voc_train refused its arguments")
+        return cls(h)
+
+    @classmethod
+    def from_arrays(cls, k, L, parent, desc, weight):
+        lib = load()
+        cls._setup(lib)
+        parent = np.ascontiguousarray(parent, np.int32)
+        desc = np.ascontiguousarray(desc, np.uint32).reshape(-1, 8)
+        weight = np.ascontiguousarray(weight, np.float64)
+        h = lib.orc_voc_import(k, L, len(parent), _p(parent), _p(desc), _p(weight))
+        if not h:
+            raise ValueError("orc_voc_import: the children of a node must be consecutive, parents before children")
+        return cls(h)
+
+    def arrays(self):
+        """-> dict(parent, first_child, n_children, desc [n,8], weight, word_id) in node order."""
+        n = self.n_nodes
+        out = dict(parent=np.zeros(n, np.int32), first_child=np.zeros(n, np.int32), n_children=np.zeros(n, np.int32),
+                   desc=np.zeros((n, 8), np.uint32), weight=np.zeros(n), word_id=np.zeros(n, np.int32))
+        load().orc_voc_export(self._h, _p(out["parent"]), _p(out["first_child"]), _p(out["n_children"]), _p(out["desc"]),
+                              _p(out["weight"]), _p(out["word_id"]))
+        return out
+
+    def transform(self, desc, levelsup=0):
+        """-> (word [n], weight [n], direct-index node [n])"""
+        desc = np.ascontiguousarray(desc, np.uint32).reshape(-1, 8)
+        n = len(desc)
+        word, node, weight = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1))
+        load().orc_voc_transform(self._h, _p(desc), n, levelsup, _p(word), _p(weight), _p(node))
+        return word[:n], weight[:n], node[:n]
+
+    def bow(self, desc, levelsup=0):
+        """-> (words [m] ascending, values [m] L1-normalised, node per feature [-1 where the feature's weight is 0])"""
+        word, weight, node = self.transform(desc, levelsup)
+        return bow_vector(word, weight) + (np.where(weight > 0, node, -1).astype(np.int32),)
+
+    def close(self):
+        if self._h:
+            load().orc_voc_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def voc_cluster(D, idx, k, seed, key):
+    """one node's clustering (HKmeansStep): -> (centres [nc,8], assoc [n], lloyd steps)"""
+    lib = load()
+    D = np.ascontiguousarray(D, np.uint32).reshape(-1, 8)
+    idx = np.ascontiguousarray(idx, np.int32)
+    cen, assoc, steps = np.zeros((16, 8), np.uint32), np.zeros(max(len(idx), 1), np.int32), C.c_int()
+    lib.orc_voc_cluster.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p,
+                                    C.c_void_p]
+    nc = lib.orc_voc_cluster(_p(D), _p(idx), len(idx), k, seed, key, _p(cen), _p(assoc), C.byref(steps))
+    return cen[:nc].copy(), assoc[:len(idx)].copy(), steps.value
+
+
+def bow_vector(word, weight):
+    word = np.ascontiguousarray(word, np.int32)
+    weight = np.ascontiguousarray(weight, np.float64)
+    ow, ov = np.zeros(max(len(word), 1), np.int32), np.zeros(max(len(word), 1))
+    m = load().orc_bow_vector(_p(word), _p(weight), len(word), _p(ow), _p(ov))
+    return ow[:m].copy(), ov[:m].copy()
+
+
+def bow_l1_sum(w1, v1, w2, v2):
+    """raw L1 sum over the common words and their number; the score is -sum / 2"""
+    lib = load()
+    lib.orc_bow_l1_sum.restype = C.c_double
+    w1, w2 = np.ascontiguousarray(w1, np.int32), np.ascontiguousarray(w2, np.int32)
+    v1, v2 = np.ascontiguousarray(v1, np.float64), np.ascontiguousarray(v2, np.float64)
+    c = C.c_int()
+    s = lib.orc_bow_l1_sum(_p(w1), _p(v1), len(w1), _p(w2), _p(v2), len(w2), C.byref(c))
+    return float(s), c.value
+
+
+def bow_query(qw, qv, db_w, db_v, db_n):
+    """query against a database stored as [n_entries, stride] (word, value) rows -> (sums, common)"""
+    qw, qv = np.ascontiguousarray(qw, np.int32), np.ascontiguousarray(qv, np.float64)
+    db_w, db_v = np.ascontiguousarray(db_w, np.int32), np.ascontiguousarray(db_v, np.float64)
+    db_n = np.ascontiguousarray(db_n, np.int32)
+    ne = len(db_n)
+    sums, common = np.zeros(max(ne, 1)), np.zeros(max(ne, 1), np.int32)
+    if ne:
+        load().orc_bow_query(_p(qw), _p(qv), len(qw), _p(db_w), _p(db_v), _p(db_n), db_w.shape[1], ne, _p(sums), _p(common))
+    return sums[:ne], common[:ne]
+
+
+def di_matches(A, node_a, B, node_b, max_ratio=0.6):
+    A = np.ascontiguousarray(A, np.uint32).reshape(-1, 8)
+    B = np.ascontiguousarray(B, np.uint32).reshape(-1, 8)
+    node_a, node_b = np.ascontiguousarray(node_a, np.int32), np.ascontiguousarray(node_b, np.int32)
+    io, ic = np.zeros(max(len(A), 1), np.int32), np.zeros(max(len(A), 1), np.int32)
+    lib = load()
+    lib.orc_di_matches.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p,
+                                   C.c_void_p]
+    n = lib.orc_di_matches(_p(A), _p(node_a), len(A), _p(B), _p(node_b), len(B), float(max_ratio), _p(io), _p(ic))
+    return io[:n].copy(), ic[:n].copy()
+
+
 # ---- front-end frame loop -----------------------------------------------------------------
 
 def solve_pnp(obj, img, K4):

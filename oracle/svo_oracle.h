@@ -240,6 +240,30 @@ void orc_lc_scores(const uint32_t *q, int nq, const uint32_t *db, const int *db_
                    int hamming_thr, int *counts);
 void orc_lc_nearest2(const uint32_t *A, int na, const uint32_t *B, int nb, int *best_j, int *d1, int *d2);
 
+/* ---- bag of words: DBoW2's vocabulary tree, BowVector, L1 score, direct index (bow.c) ---------------- */
+/* stands in for OrbVocabulary / OrbDatabase behind DLoopDetector (include/visualSLAM.h:115-137,
+ * include/TemplatedLoopDetector.h:696-861) and for the trainer src/bagOfWordsDetector.cpp:46-56 (k 9, L 6, TF_IDF, L1). */
+typedef struct orc_voc orc_voc;
+/* desc: all training descriptors (8 words each), image i owns [img_off[i], img_off[i+1]) */
+orc_voc *orc_voc_train(const uint32_t *desc, const int *img_off, int n_images, int k, int L, uint64_t seed);
+orc_voc *orc_voc_import(int k, int L, int n_nodes, const int *parent, const uint32_t *desc, const double *weight);
+void orc_voc_free(orc_voc *v);
+int orc_voc_nodes(const orc_voc *v);
+int orc_voc_words(const orc_voc *v);
+int orc_voc_k(const orc_voc *v);
+int orc_voc_levels(const orc_voc *v);
+void orc_voc_export(const orc_voc *v, int *parent, int *first_child, int *n_children, uint32_t *desc, double *weight,
+                    int *word_id);
+int orc_voc_cluster(const uint32_t *D, const int *idx, int n, int k, uint64_t seed, uint64_t key, uint32_t *centres,
+                    int *assoc, int *lloyd_steps);
+void orc_voc_transform(const orc_voc *v, const uint32_t *desc, int n, int levelsup, int *word, double *weight, int *node);
+int orc_bow_vector(const int *word, const double *weight, int n, int *out_words, double *out_vals);
+double orc_bow_l1_sum(const int *w1, const double *v1, int n1, const int *w2, const double *v2, int n2, int *common);
+void orc_bow_query(const int *qw, const double *qv, int nq, const int *db_w, const double *db_v, const int *db_n, int stride,
+                   int n_entries, double *sums, int *common);
+int orc_di_matches(const uint32_t *A, const int *node_a, int na, const uint32_t *B, const int *node_b, int nb,
+                   double max_ratio, int *i_old, int *i_cur);
+
 /* cv::solvePnP (SOLVEPNP_ITERATIVE, no guess): DLT over all n >= 6 points + LM; the last rung of the
  * older VO ladder, src/bundleAdjust.cpp:470-477.  0 ok, -1 bad arguments, -2 planar points (upstream's
  * homography branch is not built), -3 degenerate.                                                   */

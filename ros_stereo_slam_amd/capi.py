@@ -706,12 +706,99 @@ class LoopDetector:
     def pending(self) -> int:
         return self.ctx.lib.svo_lc_pending(self._h)
 
+    def set_vocabulary(self, voc: "Vocabulary", di_levels: int = 2):
+        """DBoW2's scoring and the direct-index geometric check (``svo_lc_set_vocabulary``); before the first frame."""
+        _check(self.ctx.lib.svo_lc_set_vocabulary(self._h, voc._h, int(di_levels)))
+        self._voc = voc      # the vocabulary must outlive the detector
+
+    def submit_features(self, xy, desc):
+        """Queue a frame given by its features (``svo_lc_submit_features``): xy [n, 2] float32, desc [n, 8] uint32."""
+        xy = np.ascontiguousarray(xy, np.float32).reshape(-1, 2)
+        desc = np.ascontiguousarray(desc, np.uint32).reshape(-1, 8)
+        _check(self.ctx.lib.svo_lc_submit_features(self._h, _ptr(xy), _ptr(desc), len(xy), MEM_HOST))
+
+    def collect_ex(self):
+        """``svo_lc_collect_ex`` -> dict(status, query, match, cand_id, cand_score, ns_factor)."""
+        st, q, m, n, ns = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_double()
+        ids, sc = np.zeros(64, np.int32), np.zeros(64)
+        _check(self.ctx.lib.svo_lc_collect_ex(self._h, C.byref(st), C.byref(q), C.byref(m), _ptr(ids), _ptr(sc), 64,
+                                              C.byref(n), C.byref(ns)))
+        k = min(n.value, 64)
+        return dict(status=st.value, query=q.value, match=m.value, cand_id=ids[:k].copy(), cand_score=sc[:k].copy(),
+                    ns_factor=ns.value)
+
     def __len__(self):
         return self.ctx.lib.svo_lc_size(self._h)
 
     def close(self):
         if self._h and self.ctx._h:
             self.ctx.lib.svo_lc_destroy(self._h)
+        self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Vocabulary:
+    """DBoW2's OrbVocabulary on the GPU (``svo_voc``): ``train`` (src/bagOfWordsDetector.cpp:46-56) or ``from_arrays``
+    (a vocabulary read from a file, ros_stereo_slam_amd/vocabulary.py)."""
+
+    def __init__(self, ctx: "Context", handle):
+        self.ctx, self._h = ctx, handle
+        k, L, nn, nw = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        _check(ctx.lib.svo_voc_info(handle, C.byref(k), C.byref(L), C.byref(nn), C.byref(nw)))
+        self.k, self.L, self.n_nodes, self.n_words = k.value, L.value, nn.value, nw.value
+        ctx._children.add(self)
+
+    @classmethod
+    def train(cls, ctx: "Context", descs_per_image, k=9, L=6, seed=0):
+        off = np.zeros(len(descs_per_image) + 1, np.int32)
+        off[1:] = np.cumsum([len(d) for d in descs_per_image])
+        D = np.ascontiguousarray(np.concatenate([np.asarray(d, np.uint32).reshape(-1, 8) for d in descs_per_image]), np.uint32)
+        h = C.c_void_p()
+        _check(ctx.lib.svo_voc_train(ctx._h, _ptr(D), _ptr(off), len(descs_per_image), int(k), int(L), C.c_uint64(seed),
+                                     C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def from_arrays(cls, ctx: "Context", k, L, parent, desc, weight):
+        parent = np.ascontiguousarray(parent, np.int32)
+        desc = np.ascontiguousarray(desc, np.uint32).reshape(-1, 8)
+        weight = np.ascontiguousarray(weight, np.float64)
+        h = C.c_void_p()
+        _check(ctx.lib.svo_voc_create(ctx._h, int(k), int(L), len(parent), _ptr(parent), _ptr(desc), _ptr(weight), C.byref(h)))
+        return cls(ctx, h)
+
+    def arrays(self):
+        n = self.n_nodes
+        out = dict(parent=np.zeros(n, np.int32), desc=np.zeros((n, 8), np.uint32), weight=np.zeros(n),
+                   word_id=np.zeros(n, np.int32))
+        _check(self.ctx.lib.svo_voc_export(self._h, _ptr(out["parent"]), _ptr(out["desc"]), _ptr(out["weight"]),
+                                           _ptr(out["word_id"])))
+        return out
+
+    def transform(self, desc, levelsup=0):
+        desc = np.ascontiguousarray(desc, np.uint32).reshape(-1, 8)
+        n = len(desc)
+        word, node, weight = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1))
+        _check(self.ctx.lib.svo_voc_transform(self._h, _ptr(desc), n, int(levelsup), _ptr(word), _ptr(weight), _ptr(node),
+                                              MEM_HOST))
+        return word[:n], weight[:n], node[:n]
+
+    def bow(self, desc, levelsup=0):
+        """-> (words ascending, values L1-normalised, direct-index node per feature, -1 = not indexed)"""
+        desc = np.ascontiguousarray(desc, np.uint32).reshape(-1, 8)
+        n = len(desc)
+        w, v, node, m = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1)), np.zeros(max(n, 1), np.int32), C.c_int()
+        _check(self.ctx.lib.svo_voc_bow(self._h, _ptr(desc), n, int(levelsup), _ptr(w), _ptr(v), C.byref(m), _ptr(node)))
+        return w[:m.value].copy(), v[:m.value].copy(), node[:n].copy()
+
+    def close(self):
+        if self._h and self.ctx._h:
+            self.ctx.lib.svo_voc_destroy(self._h)
         self._h = C.c_void_p()
 
     def __del__(self):

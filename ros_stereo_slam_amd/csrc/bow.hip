@@ -1,0 +1,981 @@
+// bow.hip -- the bag-of-words side of the loop detector on gfx950: a Hamming vocabulary tree, its training, the
+// BowVector / direct index of a frame, and the database query with DBoW2's L1 score.
+//
+// Replaces what visualSLAM reaches through DLoopDetector (include/visualSLAM.h:115-137: OrbVocabulary(orb_voc00.yml.gz),
+// OrbLoopDetector(voc, params), GEOM_DI with di_levels 2; detectLoop, include/TemplatedLoopDetector.h:696-861:
+// vocabulary->transform :709-713, database->query :722, ->add :725, vocabulary->score :733, the direct index :1005-1054)
+// and the reference's own trainer (src/bagOfWordsDetector.cpp:46-56: OrbVocabulary(k 9, L 6, TF_IDF, L1_NORM).create()).
+// DBoW2 / DLib and the vocabulary files were stripped from the checkout; the algorithm restated is DBoW2's published
+// one, and oracle/bow.c is its CPU twin (every integer and every double of it is compared bit for bit).
+//
+// Mapping
+//   training      one workgroup per tree node and level: kmeans++ seeding (block scans over the node's Hamming
+//                 distances), Lloyd steps with the majority vote per bit (FORB::meanValue) -- a wave holds 64 descriptors
+//                 in registers and broadcasts them lane by lane, thread t owns bit t of every cluster's counters --,
+//                 assignment by v_xor + v_bcnt, a stable partition of the node's descriptors into its children.  All of
+//                 it is integer arithmetic: the tree equals the oracle's bit for bit.  The host only walks the levels.
+//   transform     a thread per feature descends the tree (first minimum of <= k Hamming distances per level)
+//   bow vector    one workgroup: rank the (word, feature) keys, add weights per word in feature order, L1-normalise in
+//                 word order -- the order std::map gives DBoW2, so every double equals the oracle's
+//   query         inverted file as linked lists through the database rows (head per word, next per row slot): a thread
+//                 per query word walks its list and drops |q-d|-|q|-|d| into a (query word x entry) plane; a thread per
+//                 entry then adds its column IN WORD ORDER (the order queryL1's map accumulates); one workgroup selects
+//                 the max_db_results best.  The Hamming work per frame no longer grows with the database.
+#include <algorithm>
+#include <vector>
+
+#include "svo_internal.h"
+#include "ransac_common.hip.h"
+
+using svo::rng_u32;
+
+namespace {
+
+constexpr int VOC_MAX_K = 12;      // 4 waves x 12 clusters x 256 bit counters = 48 KB of LDS
+constexpr int VOC_MAX_LLOYD = 64;  // oracle/bow.c: ORC_VOC_MAX_LLOYD
+
+__device__ __forceinline__ int ham8(const uint32_t (&a)[8], const uint32_t *b)
+{
+    int d = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        d += __popc(a[k] ^ b[k]);
+    return d;
+}
+
+// ---- training: one node's clustering (oracle/bow.c: orc_voc_cluster) + the stable partition into its children ----
+struct ClusterTask {
+    int start, n;         // the node's descriptors: idx_in[start .. start + n)
+    unsigned long long key;  // path key: root 1, child c of K: 16 K + c + 1
+};
+struct ClusterOut {
+    int nc, steps;
+    int size[VOC_MAX_K];
+    uint32_t centre[VOC_MAX_K][8];
+};
+
+__device__ __forceinline__ long long block_sum_ll(long long v, long long *s_red, int t)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((t & 63) == 0)
+        s_red[t >> 6] = v;
+    __syncthreads();
+    return s_red[0] + s_red[1] + s_red[2] + s_red[3];
+}
+
+__global__ __launch_bounds__(256) void voc_cluster_kernel(const uint32_t *__restrict__ D, const int *__restrict__ idx_in,
+                                                          int *__restrict__ idx_out, int *__restrict__ assoc,
+                                                          int *__restrict__ min_d, const ClusterTask *__restrict__ tasks,
+                                                          ClusterOut *__restrict__ outs, int k, unsigned long long seed)
+{
+    const ClusterTask task = tasks[blockIdx.x];
+    ClusterOut *out = outs + blockIdx.x;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int n = task.n;
+    const int *__restrict__ idx = idx_in + task.start;
+    int *__restrict__ as = assoc + task.start;
+    int *__restrict__ md = min_d + task.start;
+    __shared__ uint32_t s_c[VOC_MAX_K][8];
+    __shared__ int s_cnt[4][VOC_MAX_K][256];  // per wave: members of cluster c that have bit b
+    __shared__ int s_size[VOC_MAX_K], s_changed, s_pick, s_wtot[4][VOC_MAX_K], s_base[VOC_MAX_K];
+    __shared__ long long s_red[4], s_wsum[4];
+    const unsigned long long rkey = seed ^ (task.key * 0x9E3779B97F4A7C15ull);
+    int nc = 0, steps = 0;
+    if (n <= k) {  // trivial case: one cluster per feature
+        if (t < n) {
+#pragma unroll
+            for (int w = 0; w < 8; w++)
+                s_c[t][w] = D[(size_t)8 * idx[t] + w];
+            as[t] = t;
+            s_size[t] = 1;
+        }
+        nc = n;
+        __syncthreads();
+    } else {
+        // ---- initiateClustersKMpp ----
+        unsigned draw = 0;
+        {
+            const int f = (int)(rng_u32(rkey, 0, draw++) % (unsigned)n);
+            if (t < 8)
+                s_c[0][t] = D[(size_t)8 * idx[f] + t];
+            __syncthreads();
+            for (int i = t; i < n; i += 256) {
+                uint32_t a[8];
+#pragma unroll
+                for (int w = 0; w < 8; w++)
+                    a[w] = D[(size_t)8 * idx[i] + w];
+                md[i] = ham8(a, s_c[0]);
+            }
+            nc = 1;
+        }
+        while (nc < k) {
+            long long part = 0;
+            for (int i = t; i < n; i += 256)
+                part += md[i];
+            __syncthreads();  // (the writes of min_d above are this thread's own: no fence needed for its reads)
+            const long long sum = block_sum_ll(part, s_red, t);
+            if (sum <= 0)
+                break;  // every descriptor coincides with a centre (uniform: every thread sees the same sum)
+            const unsigned long long hi = rng_u32(rkey, 0, draw++), lo = rng_u32(rkey, 0, draw++);
+            const long long cut = 1 + (long long)(((hi << 32) | lo) % (unsigned long long)sum);
+            // the first i whose running sum reaches the cut: block scans over chunks of 256, in order
+            long long running = 0;
+            int f = n - 1;
+            for (int base = 0; base < n; base += 256) {
+                const int i = base + t;
+                long long v = i < n ? md[i] : 0, incl = v;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const long long u = __shfl_up(incl, o, 64);
+                    if (lane >= o)
+                        incl += u;
+                }
+                if (lane == 63)
+                    s_wsum[wave] = incl;
+                if (t == 0)
+                    s_pick = 1 << 30;
+                __syncthreads();
+                long long before = running;
+                for (int w = 0; w < wave; w++)
+                    before += s_wsum[w];
+                if (i < n && before + incl >= cut)
+                    atomicMin(&s_pick, i);
+                const long long total = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+                __syncthreads();
+                const int pick = s_pick;
+                __syncthreads();
+                if (pick < (1 << 30)) {
+                    f = pick;
+                    break;
+                }
+                running += total;
+            }
+            if (t < 8)
+                s_c[nc][t] = D[(size_t)8 * idx[f] + t];
+            __syncthreads();
+            for (int i = t; i < n; i += 256) {
+                uint32_t a[8];
+#pragma unroll
+                for (int w = 0; w < 8; w++)
+                    a[w] = D[(size_t)8 * idx[i] + w];
+                const int d = ham8(a, s_c[nc]);
+                if (d < md[i])
+                    md[i] = d;
+            }
+            nc++;
+        }
+        // ---- Lloyd: associate / majority vote until the associations stop changing ----
+        bool first = true;
+        for (;;) {
+            if (!first) {
+                // the centres: thread t owns bit t; a wave keeps 64 descriptors in registers and broadcasts them lane by lane
+                for (int c = 0; c < nc; c++)
+#pragma unroll
+                    for (int w4 = 0; w4 < 4; w4++)
+                        s_cnt[w4][c][t] = 0;
+                __syncthreads();
+                for (int base = wave * 64; base < n; base += 256) {
+                    const int i = base + lane;
+                    uint32_t a[8];
+                    int ca = -1;
+                    if (i < n) {
+                        ca = as[i];
+#pragma unroll
+                        for (int w = 0; w < 8; w++)
+                            a[w] = D[(size_t)8 * idx[i] + w];
+                    } else {
+#pragma unroll
+                        for (int w = 0; w < 8; w++)
+                            a[w] = 0;
+                    }
+                    const int m = min(64, n - base);
+                    for (int l = 0; l < m; l++) {
+                        const int c = __builtin_amdgcn_readlane(ca, l);
+#pragma unroll
+                        for (int wp = 0; wp < 4; wp++) {
+                            const uint32_t x0 = __builtin_amdgcn_readlane(a[2 * wp], l), x1 = __builtin_amdgcn_readlane(a[2 * wp + 1], l);
+                            const uint32_t x = lane < 32 ? x0 : x1;
+                            s_cnt[wave][c][wp * 64 + lane] += (x >> (lane & 31)) & 1u;
+                        }
+                    }
+                }
+                __syncthreads();
+                for (int c = 0; c < nc; c++) {
+                    const int sz = s_size[c];
+                    const int tot = s_cnt[0][c][t] + s_cnt[1][c][t] + s_cnt[2][c][t] + s_cnt[3][c][t];
+                    const unsigned long long bal = __ballot(tot >= sz / 2 + (sz & 1));  // bits 64 wave .. 64 wave + 63
+                    if (sz > 0 && lane == 0) {  // an empty cluster keeps its centre (oracle/bow.c, deviation 2)
+                        s_c[c][2 * wave] = (uint32_t)bal;
+                        s_c[c][2 * wave + 1] = (uint32_t)(bal >> 32);
+                    }
+                }
+                __syncthreads();
+            }
+            if (t < VOC_MAX_K)
+                s_size[t] = 0;
+            if (t == 0)
+                s_changed = 0;
+            __syncthreads();
+            int changed = 0;
+            for (int i = t; i < n; i += 256) {
+                uint32_t a[8];
+#pragma unroll
+                for (int w = 0; w < 8; w++)
+                    a[w] = D[(size_t)8 * idx[i] + w];
+                int best = ham8(a, s_c[0]), bc = 0;
+                for (int c = 1; c < nc; c++) {
+                    const int d = ham8(a, s_c[c]);
+                    if (d < best) {
+                        best = d;
+                        bc = c;
+                    }
+                }
+                if (first || as[i] != bc)
+                    changed = 1;
+                as[i] = bc;
+                atomicAdd(&s_size[bc], 1);
+            }
+            if (changed)
+                s_changed = 1;
+            __syncthreads();
+            const int any = s_changed;
+            __syncthreads();
+            if (first) {
+                first = false;
+                steps = 1;
+                continue;
+            }
+            if (!any || steps >= VOC_MAX_LLOYD)
+                break;
+            steps++;
+        }
+    }
+    // ---- the children's segments: a stable partition of the node's descriptors by cluster ----
+    if (t < VOC_MAX_K)
+        s_base[t] = 0;
+    __syncthreads();
+    if (t == 0) {
+        int acc = 0;
+        for (int c = 0; c < nc; c++) {
+            s_base[c] = acc;
+            acc += s_size[c];
+        }
+    }
+    __syncthreads();
+    for (int base = 0; base < n; base += 256) {
+        const int i = base + t;
+        const int a = i < n ? as[i] : -1;
+        int before = 0;
+        for (int c = 0; c < nc; c++) {
+            const unsigned long long bal = __ballot(a == c);
+            if (lane == 0)
+                s_wtot[wave][c] = __popcll(bal);
+            if (a == c)
+                before = __popcll(bal & ((1ull << lane) - 1ull));
+        }
+        __syncthreads();
+        if (a >= 0) {
+            int pos = s_base[a] + before;
+            for (int w = 0; w < wave; w++)
+                pos += s_wtot[w][a];
+            idx_out[task.start + pos] = idx[i];
+        }
+        __syncthreads();
+        if (t < nc)
+            s_base[t] += s_wtot[0][t] + s_wtot[1][t] + s_wtot[2][t] + s_wtot[3][t];
+        __syncthreads();
+    }
+    if (t == 0) {
+        out->nc = nc;
+        out->steps = steps;
+    }
+    if (t < VOC_MAX_K)
+        out->size[t] = t < nc ? s_size[t] : 0;
+    if (t < nc * 8)
+        out->centre[t >> 3][t & 7] = s_c[t >> 3][t & 7];
+}
+
+// ---- transform: a thread per feature descends the tree (TemplatedVocabulary::transform) ----
+__global__ __launch_bounds__(256) void voc_transform_kernel(const int *__restrict__ first_child, const int *__restrict__ n_children,
+                                                            const int *__restrict__ word_id, const uint32_t *__restrict__ ndesc,
+                                                            const double *__restrict__ nweight, const uint32_t *__restrict__ q,
+                                                            int n_host, const int *__restrict__ d_n, int nid_level,
+                                                            int *__restrict__ word, double *__restrict__ weight,
+                                                            int *__restrict__ node)
+{
+    const int n = d_n ? min(*d_n, n_host) : n_host;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n)
+        return;
+    uint32_t a[8];
+#pragma unroll
+    for (int w = 0; w < 8; w++)
+        a[w] = q[(size_t)8 * i + w];
+    int cur = 0, level = 0, nid = 0;
+    while (n_children[cur] > 0) {
+        level++;
+        const int c0 = first_child[cur], nch = n_children[cur];
+        int best = ham8(a, ndesc + (size_t)8 * c0), bi = c0;
+        for (int c = 1; c < nch; c++) {
+            const int d = ham8(a, ndesc + (size_t)8 * (c0 + c));
+            if (d < best) {
+                best = d;
+                bi = c0 + c;
+            }
+        }
+        cur = bi;
+        if (level == nid_level)
+            nid = cur;
+    }
+    word[i] = word_id[cur];
+    weight[i] = nweight[cur];
+    if (node)
+        node[i] = nid_level <= 0 ? 0 : nid;
+}
+
+// ---- BowVector of one image (orc_bow_vector) + the direct-index node per feature; writes database row `row` ----
+constexpr int BOW_MAX_F = 2048;
+__global__ __launch_bounds__(512) void bow_vector_kernel(const int *__restrict__ word, const double *__restrict__ weight,
+                                                         const int *__restrict__ node, int n_host, const int *__restrict__ d_n,
+                                                         int *__restrict__ row_w, double *__restrict__ row_v,
+                                                         int *__restrict__ row_n, int *__restrict__ row_node)
+{
+    __shared__ int s_w[BOW_MAX_F], s_i[BOW_MAX_F], s_nv, s_m;
+    __shared__ double s_norm;
+    const int t = threadIdx.x;
+    const int n = min(d_n ? min(*d_n, n_host) : n_host, BOW_MAX_F);
+    if (t == 0)
+        s_nv = 0;
+    __syncthreads();
+    // rank of (word, feature) among the features with a positive weight
+    for (int i = t; i < n; i += 512) {
+        const bool ok = weight[i] > 0;
+        if (row_node)
+            row_node[i] = ok ? node[i] : -1;  // a feature with weight 0 is not in the FeatureVector either
+        if (!ok)
+            continue;
+        const int wi = word[i];
+        int r = 0;
+        for (int j = 0; j < n; j++) {
+            if (!(weight[j] > 0))
+                continue;
+            const int wj = word[j];
+            r += (wj < wi || (wj == wi && j < i)) ? 1 : 0;
+        }
+        s_w[r] = wi;
+        s_i[r] = i;
+        atomicAdd(&s_nv, 1);
+    }
+    __syncthreads();
+    const int nv = s_nv;
+    if (t == 0) {  // weights added per word in feature order, as BowVector::addWeight sees them
+        int m = -1;
+        double acc = 0;
+        for (int r = 0; r < nv; r++) {
+            const double wgt = weight[s_i[r]];
+            if (r == 0 || s_w[r] != s_w[r - 1]) {
+                if (m >= 0)
+                    row_v[m] = acc;
+                m++;
+                row_w[m] = s_w[r];
+                acc = wgt;
+            } else
+                acc += wgt;
+        }
+        if (m >= 0)
+            row_v[m] = acc;
+        m++;
+        double norm = 0;
+        for (int u = 0; u < m; u++)
+            norm += fabs(row_v[u]);  // the thread's own writes
+        s_norm = norm;
+        s_m = m;
+        *row_n = m;
+    }
+    __syncthreads();
+    const double norm = s_norm;
+    if (norm > 0)
+        for (int u = t; u < s_m; u += 512)
+            row_v[u] = row_v[u] / norm;
+}
+
+// ---- the database query (TemplatedDatabase::queryL1) ----
+// a thread per query word walks the word's list through the database rows and drops its term into plane[r][entry]
+__global__ __launch_bounds__(256) void bow_contrib_kernel(const int *__restrict__ qw, const double *__restrict__ qv,
+                                                          const int *__restrict__ d_nq, const int *__restrict__ head,
+                                                          const int *__restrict__ next, const double *__restrict__ db_v,
+                                                          int stride, int n_entries, double *__restrict__ plane, int pitch)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= *d_nq)
+        return;
+    const double q = qv[r];
+    int slot = head[qw[r]];
+    while (slot >= 0) {
+        const int e = slot / stride;
+        if (e < n_entries) {
+            const double d = db_v[slot];
+            plane[(size_t)r * pitch + e] = fabs(q - d) - fabs(q) - fabs(d);
+        }
+        slot = next[slot];
+    }
+}
+
+// a thread per entry adds its column in word order: the sum queryL1's map holds for the entry (0: no common word)
+__global__ __launch_bounds__(256) void bow_sum_kernel(const double *__restrict__ plane, int pitch, const int *__restrict__ d_nq,
+                                                      int n_entries, double *__restrict__ sums)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_entries)
+        return;
+    const int nq = *d_nq;
+    double s = 0;
+    for (int r = 0; r < nq; r++)
+        s += plane[(size_t)r * pitch + e];
+    sums[e] = s;
+}
+
+// the frame's row enters the inverted file (TemplatedDatabase::add)
+__global__ __launch_bounds__(256) void bow_link_kernel(const int *__restrict__ row_w, const int *__restrict__ row_n, int slot0,
+                                                       int *__restrict__ head, int *__restrict__ next)
+{
+    const int u = blockIdx.x * 256 + threadIdx.x;
+    if (u >= *row_n)
+        return;
+    const int w = row_w[u];  // the words of a row are distinct: no two threads touch the same head
+    next[slot0 + u] = head[w];
+    head[w] = slot0 + u;
+}
+
+// the max_db_results entries below max_id with the most negative sums (ties: the lower id), the previous entry's sum,
+// the word count -- what the host logic of detectLoop reads, into pinned memory
+__global__ __launch_bounds__(1024) void bow_topk_kernel(const double *__restrict__ sums, int max_id, int k_want,
+                                                        const int *__restrict__ row_n, int entry_id, svo_lc_bow_record *rec)
+{
+    constexpr int PER = 8;  // 8192 entries at most
+    __shared__ double s_v[16];
+    __shared__ int s_id[16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    double v[PER];
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+        const int e = u * 1024 + t;
+        v[u] = e < max_id ? sums[e] : 0.;
+    }
+    int n_out = 0;
+    for (int round = 0; round < k_want; round++) {
+        double bv = 0.;
+        int be = 1 << 30;
+#pragma unroll
+        for (int u = 0; u < PER; u++) {
+            const int e = u * 1024 + t;
+            if (v[u] < bv || (v[u] == bv && v[u] < 0. && e < be)) {
+                bv = v[u];
+                be = e;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double ov = __shfl_xor(bv, o, 64);
+            const int oe = __shfl_xor(be, o, 64);
+            if (ov < bv || (ov == bv && oe < be)) {
+                bv = ov;
+                be = oe;
+            }
+        }
+        if (lane == 0) {
+            s_v[wave] = bv;
+            s_id[wave] = be;
+        }
+        __syncthreads();
+        bv = s_v[0];
+        be = s_id[0];
+#pragma unroll
+        for (int w = 1; w < 16; w++)
+            if (s_v[w] < bv || (s_v[w] == bv && s_id[w] < be)) {
+                bv = s_v[w];
+                be = s_id[w];
+            }
+        __syncthreads();
+        if (!(bv < 0.))
+            break;  // no entry with a common word is left
+        if (t == 0) {
+            rec->cand_id[n_out] = be;
+            rec->cand_sum[n_out] = bv;
+        }
+        n_out++;
+        if ((be & 1023) == t) {  // taken
+#pragma unroll
+            for (int u = 0; u < PER; u++)
+                if (u == (be >> 10))
+                    v[u] = 0.;
+        }
+    }
+    if (t == 0) {
+        rec->nq = *row_n;
+        rec->last_sum = entry_id > 0 ? sums[entry_id - 1] : 0.;
+        rec->n_cand = n_out;
+        __threadfence_system();
+        __hip_atomic_store(&rec->ready, entry_id + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// direct-index matching (getMatches_neighratio restricted to the features under the same node): for every feature of the
+// OLD image its nearest / second-nearest feature of the current image under the same direct-index node
+__global__ __launch_bounds__(256) void bow_di_nearest_kernel(const uint32_t *__restrict__ A, const int *__restrict__ node_a,
+                                                             int na, const uint32_t *__restrict__ B,
+                                                             const int *__restrict__ node_b, const int *__restrict__ d_nb,
+                                                             int *__restrict__ best_j, int *__restrict__ d1, int *__restrict__ d2)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= na)
+        return;
+    const int nb = *d_nb, node = node_a[i];
+    int bj = -1, b1 = 1000000000, b2 = 1000000000;
+    if (node >= 0) {
+        uint32_t a[8];
+#pragma unroll
+        for (int w = 0; w < 8; w++)
+            a[w] = A[(size_t)8 * i + w];
+        for (int j = 0; j < nb; j++) {
+            if (node_b[j] != node)
+                continue;
+            const int d = ham8(a, B + (size_t)8 * j);
+            if (d < b1) {
+                bj = j;
+                b2 = b1;
+                b1 = d;
+            } else if (d < b2)
+                b2 = d;
+        }
+    }
+    best_j[i] = bj;
+    d1[i] = b1;
+    d2[i] = b2;
+}
+
+}  // namespace
+
+// ---- the vocabulary object ----------------------------------------------------------------------------------------------
+struct svo_voc {
+    svo_ctx *ctx = nullptr;
+    int k = 0, L = 0, n_nodes = 0, n_words = 0;
+    std::vector<int> parent, first_child, n_children, word_id, level;
+    std::vector<uint32_t> desc;
+    std::vector<double> weight;
+    DevBuf d_first_child, d_n_children, d_word_id, d_desc, d_weight;
+    int train_lloyd_steps = 0;  // of the root's clustering (diagnostics)
+};
+
+static int voc_upload(svo_voc *v)
+{
+    int rc;
+    const size_t n = (size_t)v->n_nodes;
+    if ((rc = v->d_first_child.ensure(n * 4)) || (rc = v->d_n_children.ensure(n * 4)) || (rc = v->d_word_id.ensure(n * 4)) ||
+        (rc = v->d_desc.ensure(n * 32)) || (rc = v->d_weight.ensure(n * 8)))
+        return rc;
+    SVO_HIP(hipMemcpy(v->d_first_child.p, v->first_child.data(), n * 4, hipMemcpyHostToDevice));
+    SVO_HIP(hipMemcpy(v->d_n_children.p, v->n_children.data(), n * 4, hipMemcpyHostToDevice));
+    SVO_HIP(hipMemcpy(v->d_word_id.p, v->word_id.data(), n * 4, hipMemcpyHostToDevice));
+    SVO_HIP(hipMemcpy(v->d_desc.p, v->desc.data(), n * 32, hipMemcpyHostToDevice));
+    SVO_HIP(hipMemcpy(v->d_weight.p, v->weight.data(), n * 8, hipMemcpyHostToDevice));
+    return SVO_OK;
+}
+
+// nodes in id order with parents before children and the children of a node consecutive -> links, levels, words
+static int voc_link(svo_voc *v)
+{
+    const int n = v->n_nodes;
+    v->first_child.assign(n, -1);
+    v->n_children.assign(n, 0);
+    v->word_id.assign(n, -1);
+    v->level.assign(n, 0);
+    for (int i = 1; i < n; i++) {
+        const int p = v->parent[i];
+        if (p < 0 || p >= i) {
+            svo_set_error("vocabulary: node %d has parent %d (parents come first, node 0 is the root)", i, p);
+            return SVO_ERR_ARG;
+        }
+        if (v->n_children[p] == 0)
+            v->first_child[p] = i;
+        else if (v->first_child[p] + v->n_children[p] != i) {
+            svo_set_error("vocabulary: the children of node %d are not consecutive (node %d)", p, i);
+            return SVO_ERR_ARG;
+        }
+        v->n_children[p]++;
+        v->level[i] = v->level[p] + 1;
+    }
+    v->n_words = 0;
+    for (int i = 1; i < n; i++)
+        if (v->n_children[i] == 0)
+            v->word_id[i] = v->n_words++;  // createWords: the leaves in node order
+    return SVO_OK;
+}
+
+int svo_voc_launch_transform(svo_voc *v, hipStream_t st, const uint32_t *d_desc, int cap, const int *d_n, int levelsup,
+                             int *d_word, double *d_weight, int *d_node)
+{
+    if (cap <= 0)
+        return SVO_OK;
+    hipLaunchKernelGGL(voc_transform_kernel, dim3((cap + 255) / 256), dim3(256), 0, st, v->d_first_child.as<int>(),
+                       v->d_n_children.as<int>(), v->d_word_id.as<int>(), v->d_desc.as<uint32_t>(), v->d_weight.as<double>(),
+                       d_desc, cap, d_n, v->L - levelsup, d_word, d_weight, d_node);
+    SVO_HIP(hipGetLastError());
+    return SVO_OK;
+}
+
+int svo_bow_launch_vector(hipStream_t st, const int *d_word, const double *d_weight, const int *d_node, int cap, const int *d_n,
+                          int *row_w, double *row_v, int *row_n, int *row_node)
+{
+    if (cap > BOW_MAX_F) {
+        svo_set_error("bow vector: at most %d features per image", BOW_MAX_F);
+        return SVO_ERR_ARG;
+    }
+    hipLaunchKernelGGL(bow_vector_kernel, dim3(1), dim3(512), 0, st, d_word, d_weight, d_node, cap, d_n, row_w, row_v, row_n,
+                       row_node);
+    SVO_HIP(hipGetLastError());
+    return SVO_OK;
+}
+
+int svo_bow_launch_query(hipStream_t st, const int *qw, const double *qv, const int *d_nq, int nf, const int *head,
+                         const int *next, const double *db_v, int stride, int n_entries, double *plane, int pitch, double *sums,
+                         int max_id, int k_want, int entry_id, svo_lc_bow_record *rec)
+{
+    if (n_entries > 0) {
+        SVO_HIP(hipMemset2DAsync(plane, (size_t)pitch * 8, 0, (size_t)n_entries * 8, (size_t)nf, st));
+        hipLaunchKernelGGL(bow_contrib_kernel, dim3((nf + 255) / 256), dim3(256), 0, st, qw, qv, d_nq, head, next, db_v, stride,
+                           n_entries, plane, pitch);
+        hipLaunchKernelGGL(bow_sum_kernel, dim3((n_entries + 255) / 256), dim3(256), 0, st, plane, pitch, d_nq, n_entries, sums);
+    }
+    hipLaunchKernelGGL(bow_topk_kernel, dim3(1), dim3(1024), 0, st, sums, max_id, k_want, d_nq, entry_id, rec);
+    SVO_HIP(hipGetLastError());
+    return SVO_OK;
+}
+
+int svo_bow_launch_link(hipStream_t st, const int *row_w, const int *row_n, int nf, int slot0, int *head, int *next)
+{
+    hipLaunchKernelGGL(bow_link_kernel, dim3((nf + 255) / 256), dim3(256), 0, st, row_w, row_n, slot0, head, next);
+    SVO_HIP(hipGetLastError());
+    return SVO_OK;
+}
+
+int svo_bow_launch_di_nearest(hipStream_t st, const uint32_t *A, const int *node_a, int na, const uint32_t *B, const int *node_b,
+                              const int *d_nb, int *best_j, int *d1, int *d2)
+{
+    if (na <= 0)
+        return SVO_OK;
+    hipLaunchKernelGGL(bow_di_nearest_kernel, dim3((na + 255) / 256), dim3(256), 0, st, A, node_a, na, B, node_b, d_nb, best_j, d1,
+                       d2);
+    SVO_HIP(hipGetLastError());
+    return SVO_OK;
+}
+
+int svo_voc_words_internal(const svo_voc *v) { return v->n_words; }
+int svo_voc_levels_internal(const svo_voc *v) { return v->L; }
+
+extern "C" {
+
+int svo_voc_create(svo_ctx *ctx, int k, int L, int n_nodes, const int *parent, const uint32_t *desc, const double *weight,
+                   svo_voc **out)
+{
+    SVO_CHECK_ARG(ctx && out && parent && desc && weight && n_nodes >= 1 && k >= 2 && k <= VOC_MAX_K && L >= 1 && L <= 10);
+    *out = nullptr;
+    SVO_HIP(hipSetDevice(ctx->device));
+    svo_voc *v = new svo_voc();
+    v->ctx = ctx;
+    v->k = k;
+    v->L = L;
+    v->n_nodes = n_nodes;
+    v->parent.assign(parent, parent + n_nodes);
+    v->desc.assign(desc, desc + (size_t)8 * n_nodes);
+    v->weight.assign(weight, weight + n_nodes);
+    int rc = voc_link(v);
+    if (rc || (rc = voc_upload(v))) {
+        svo_voc_destroy(v);
+        return rc;
+    }
+    *out = v;
+    return SVO_OK;
+}
+
+int svo_voc_destroy(svo_voc *v)
+{
+    if (!v)
+        return SVO_OK;
+    DevBuf *bufs[] = {&v->d_first_child, &v->d_n_children, &v->d_word_id, &v->d_desc, &v->d_weight};
+    for (DevBuf *b : bufs)
+        b->release();
+    delete v;
+    return SVO_OK;
+}
+
+int svo_voc_info(const svo_voc *v, int *k, int *L, int *n_nodes, int *n_words)
+{
+    SVO_CHECK_ARG(v);
+    if (k)
+        *k = v->k;
+    if (L)
+        *L = v->L;
+    if (n_nodes)
+        *n_nodes = v->n_nodes;
+    if (n_words)
+        *n_words = v->n_words;
+    return SVO_OK;
+}
+
+int svo_voc_export(const svo_voc *v, int *parent, uint32_t *desc, double *weight, int *word_id)
+{
+    SVO_CHECK_ARG(v);
+    if (parent)
+        memcpy(parent, v->parent.data(), sizeof(int) * (size_t)v->n_nodes);
+    if (desc)
+        memcpy(desc, v->desc.data(), (size_t)32 * v->n_nodes);
+    if (weight)
+        memcpy(weight, v->weight.data(), sizeof(double) * (size_t)v->n_nodes);
+    if (word_id)
+        memcpy(word_id, v->word_id.data(), sizeof(int) * (size_t)v->n_nodes);
+    return SVO_OK;
+}
+
+// OrbVocabulary(k, L, TF_IDF, L1_NORM).create(features), src/bagOfWordsDetector.cpp:46-56.  Host descriptors.
+int svo_voc_train(svo_ctx *ctx, const uint32_t *desc, const int *img_off, int n_images, int k, int L, uint64_t seed,
+                  svo_voc **out)
+{
+    SVO_CHECK_ARG(ctx && desc && img_off && out && n_images >= 1 && k >= 2 && k <= VOC_MAX_K && L >= 1 && L <= 10);
+    *out = nullptr;
+    const int n = img_off[n_images];
+    SVO_CHECK_ARG(n >= 1);
+    SVO_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    int rc;
+    DevBuf dD, dIdx[2], dAssoc, dMin, dTasks, dOuts;
+    auto cleanup = [&]() {
+        for (DevBuf *b : {&dD, &dIdx[0], &dIdx[1], &dAssoc, &dMin, &dTasks, &dOuts})
+            b->release();
+    };
+    if ((rc = dD.ensure((size_t)n * 32)) || (rc = dIdx[0].ensure((size_t)n * 4)) || (rc = dIdx[1].ensure((size_t)n * 4)) ||
+        (rc = dAssoc.ensure((size_t)n * 4)) || (rc = dMin.ensure((size_t)n * 4))) {
+        cleanup();
+        return rc;
+    }
+    std::vector<int> iota((size_t)n);
+    for (int i = 0; i < n; i++)
+        iota[i] = i;
+    SVO_HIP(hipMemcpyAsync(dD.p, desc, (size_t)n * 32, hipMemcpyHostToDevice, st));
+    SVO_HIP(hipMemcpyAsync(dIdx[0].p, iota.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+    SVO_HIP(hipMemcpyAsync(dIdx[1].p, iota.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+    SVO_HIP(hipStreamSynchronize(st));
+    // breadth-first: the nodes of a level are clustered by one launch (a workgroup each)
+    struct BNode {
+        int parent;                // breadth-first id of the parent
+        int start, n;              // its descriptors
+        unsigned long long key;
+        uint32_t d[8];
+        int first_child = -1, n_children = 0;
+    };
+    std::vector<BNode> nodes;
+    {
+        BNode root{};
+        root.parent = -1;
+        root.start = 0;
+        root.n = n;
+        root.key = 1;
+        nodes.push_back(root);
+    }
+    std::vector<int> frontier = {0};
+    int cur = 0, root_steps = 0;
+    for (int level = 1; level <= L && !frontier.empty(); level++) {
+        std::vector<ClusterTask> tasks;
+        for (int b : frontier)
+            tasks.push_back({nodes[b].start, nodes[b].n, nodes[b].key});
+        if ((rc = dTasks.ensure(tasks.size() * sizeof(ClusterTask))) || (rc = dOuts.ensure(tasks.size() * sizeof(ClusterOut)))) {
+            cleanup();
+            return rc;
+        }
+        SVO_HIP(hipMemcpyAsync(dTasks.p, tasks.data(), tasks.size() * sizeof(ClusterTask), hipMemcpyHostToDevice, st));
+        // segments that are not clustered at this level keep their order in the other buffer: copy it over first
+        SVO_HIP(hipMemcpyAsync(dIdx[cur ^ 1].p, dIdx[cur].p, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(voc_cluster_kernel, dim3((unsigned)tasks.size()), dim3(256), 0, st, dD.as<uint32_t>(), dIdx[cur].as<int>(),
+                           dIdx[cur ^ 1].as<int>(), dAssoc.as<int>(), dMin.as<int>(), dTasks.as<ClusterTask>(),
+                           dOuts.as<ClusterOut>(), k, (unsigned long long)seed);
+        std::vector<ClusterOut> outs(tasks.size());
+        SVO_HIP(hipMemcpyAsync(outs.data(), dOuts.p, tasks.size() * sizeof(ClusterOut), hipMemcpyDeviceToHost, st));
+        SVO_HIP(hipStreamSynchronize(st));
+        cur ^= 1;
+        std::vector<int> next_frontier;
+        for (size_t ti = 0; ti < tasks.size(); ti++) {
+            const int b = frontier[ti];
+            const ClusterOut &o = outs[ti];
+            if (level == 1)
+                root_steps = o.steps;
+            int at = nodes[b].start;
+            nodes[b].first_child = (int)nodes.size();
+            nodes[b].n_children = o.nc;
+            for (int c = 0; c < o.nc; c++) {
+                BNode ch{};
+                ch.parent = b;
+                ch.start = at;
+                ch.n = o.size[c];
+                ch.key = nodes[b].key * 16 + (unsigned long long)c + 1;
+                memcpy(ch.d, o.centre[c], 32);
+                at += o.size[c];
+                if (level < L && ch.n > 1)
+                    next_frontier.push_back((int)nodes.size());
+                nodes.push_back(ch);
+            }
+        }
+        frontier.swap(next_frontier);
+    }
+    // DBoW2's node ids: all children of a node consecutively, then depth first (oracle/bow.c: hkmeans_step)
+    svo_voc *v = new svo_voc();
+    v->ctx = ctx;
+    v->k = k;
+    v->L = L;
+    v->train_lloyd_steps = root_steps;
+    std::vector<int> new_id(nodes.size(), -1);
+    {
+        int next = 1;
+        new_id[0] = 0;
+        std::vector<int> stack = {0};
+        // iterative form of: visit(b): number b's children; then visit each child that has children, in order
+        std::vector<std::pair<int, int>> work;  // (node, next child to descend into)
+        auto number_children = [&](int b) {
+            for (int c = 0; c < nodes[b].n_children; c++)
+                new_id[nodes[b].first_child + c] = next++;
+        };
+        number_children(0);
+        work.push_back({0, 0});
+        while (!work.empty()) {
+            auto &top = work.back();
+            const int b = top.first;
+            if (top.second >= nodes[b].n_children) {
+                work.pop_back();
+                continue;
+            }
+            const int ch = nodes[b].first_child + top.second++;
+            if (nodes[ch].n_children > 0) {
+                number_children(ch);
+                work.push_back({ch, 0});
+            }
+        }
+        v->n_nodes = next;
+    }
+    v->parent.assign(v->n_nodes, -1);
+    v->desc.assign((size_t)8 * v->n_nodes, 0);
+    v->weight.assign(v->n_nodes, 0.);
+    for (size_t b = 1; b < nodes.size(); b++) {
+        const int id = new_id[b];
+        v->parent[id] = new_id[nodes[b].parent];
+        memcpy(&v->desc[(size_t)8 * id], nodes[b].d, 32);
+    }
+    rc = voc_link(v);
+    if (rc || (rc = voc_upload(v))) {
+        cleanup();
+        svo_voc_destroy(v);
+        return rc;
+    }
+    // setNodeWeights, TF_IDF: idf = log(N / Ni) with Ni = images that contain the word (svo_log: shared with the oracle)
+    {
+        DevBuf dW, dWt;
+        if ((rc = dW.ensure((size_t)n * 4)) || (rc = dWt.ensure((size_t)n * 8)) ||
+            (rc = svo_voc_launch_transform(v, st, dD.as<uint32_t>(), n, nullptr, 0, dW.as<int>(), dWt.as<double>(), nullptr))) {
+            dW.release();
+            dWt.release();
+            cleanup();
+            svo_voc_destroy(v);
+            return rc;
+        }
+        std::vector<int> words((size_t)n);
+        SVO_HIP(hipMemcpyAsync(words.data(), dW.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+        SVO_HIP(hipStreamSynchronize(st));
+        dW.release();
+        dWt.release();
+        std::vector<int> ni(v->n_words, 0), last(v->n_words, -1), word_node(v->n_words, 0);
+        for (int i = 1; i < v->n_nodes; i++)
+            if (v->word_id[i] >= 0)
+                word_node[v->word_id[i]] = i;
+        for (int im = 0; im < n_images; im++)
+            for (int f = img_off[im]; f < img_off[im + 1]; f++) {
+                const int w = words[f];
+                if (last[w] != im) {
+                    last[w] = im;
+                    ni[w]++;
+                }
+            }
+        for (int w = 0; w < v->n_words; w++)
+            if (ni[w] > 0)
+                v->weight[word_node[w]] = svo_log((double)n_images / (double)ni[w]);
+        SVO_HIP(hipMemcpy(v->d_weight.p, v->weight.data(), (size_t)v->n_nodes * 8, hipMemcpyHostToDevice));
+    }
+    cleanup();
+    *out = v;
+    return SVO_OK;
+}
+
+int svo_voc_transform(svo_voc *v, const uint32_t *desc, int n, int levelsup, int *word, double *weight, int *node, int mem)
+{
+    SVO_CHECK_ARG(v && n >= 0 && levelsup >= 0);
+    SVO_CHECK_ARG(mem == SVO_MEM_HOST || mem == SVO_MEM_DEVICE);
+    if (n == 0)
+        return SVO_OK;
+    SVO_CHECK_ARG(desc && word && weight);
+    svo_ctx *ctx = v->ctx;
+    SVO_HIP(hipSetDevice(ctx->device));
+    if (mem == SVO_MEM_DEVICE)
+        return svo_voc_launch_transform(v, ctx->stream, desc, n, nullptr, levelsup, word, weight, node);
+    int rc;
+    if ((rc = ctx->s_a.ensure((size_t)n * 32)) || (rc = ctx->s_b.ensure((size_t)n * 4)) || (rc = ctx->s_c.ensure((size_t)n * 8)) ||
+        (rc = ctx->s_d.ensure((size_t)n * 4)))
+        return rc;
+    SVO_HIP(hipMemcpyAsync(ctx->s_a.p, desc, (size_t)n * 32, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = svo_voc_launch_transform(v, ctx->stream, ctx->s_a.as<uint32_t>(), n, nullptr, levelsup, ctx->s_b.as<int>(),
+                                       ctx->s_c.as<double>(), ctx->s_d.as<int>())))
+        return rc;
+    SVO_HIP(hipMemcpyAsync(word, ctx->s_b.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SVO_HIP(hipMemcpyAsync(weight, ctx->s_c.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (node)
+        SVO_HIP(hipMemcpyAsync(node, ctx->s_d.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SVO_HIP(hipStreamSynchronize(ctx->stream));
+    return SVO_OK;
+}
+
+// the BowVector and the direct-index nodes of one image's descriptors (host arrays; what svo_lc keeps per entry)
+int svo_voc_bow(svo_voc *v, const uint32_t *desc, int n, int levelsup, int *words, double *values, int *n_words,
+                int *node_per_feature)
+{
+    SVO_CHECK_ARG(v && n >= 0 && n <= BOW_MAX_F && words && values && n_words);
+    *n_words = 0;
+    if (n == 0)
+        return SVO_OK;
+    SVO_CHECK_ARG(desc != nullptr);
+    svo_ctx *ctx = v->ctx;
+    SVO_HIP(hipSetDevice(ctx->device));
+    int rc;
+    if ((rc = ctx->s_a.ensure((size_t)n * 32)) || (rc = ctx->s_b.ensure((size_t)n * 4)) || (rc = ctx->s_c.ensure((size_t)n * 8)) ||
+        (rc = ctx->s_d.ensure((size_t)n * 4)) || (rc = ctx->s_e.ensure((size_t)n * 4 + 16)) || (rc = ctx->s_f.ensure((size_t)n * 8)) ||
+        (rc = ctx->s_g.ensure((size_t)n * 4)))
+        return rc;
+    hipStream_t st = ctx->stream;
+    SVO_HIP(hipMemcpyAsync(ctx->s_a.p, desc, (size_t)n * 32, hipMemcpyHostToDevice, st));
+    int *row_w = ctx->s_e.as<int>(), *row_n = row_w + n;
+    if ((rc = svo_voc_launch_transform(v, st, ctx->s_a.as<uint32_t>(), n, nullptr, levelsup, ctx->s_b.as<int>(), ctx->s_c.as<double>(),
+                                       ctx->s_d.as<int>())) ||
+        (rc = svo_bow_launch_vector(st, ctx->s_b.as<int>(), ctx->s_c.as<double>(), ctx->s_d.as<int>(), n, nullptr, row_w,
+                                    ctx->s_f.as<double>(), row_n, ctx->s_g.as<int>())))
+        return rc;
+    SVO_HIP(hipMemcpyAsync(ctx->pinned, row_n, 4, hipMemcpyDeviceToHost, st));
+    SVO_HIP(hipStreamSynchronize(st));
+    const int m = *reinterpret_cast<const int *>(ctx->pinned);
+    *n_words = m;
+    SVO_HIP(hipMemcpyAsync(words, row_w, (size_t)m * 4, hipMemcpyDeviceToHost, st));
+    SVO_HIP(hipMemcpyAsync(values, ctx->s_f.p, (size_t)m * 8, hipMemcpyDeviceToHost, st));
+    if (node_per_feature)
+        SVO_HIP(hipMemcpyAsync(node_per_feature, ctx->s_g.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    SVO_HIP(hipStreamSynchronize(st));
+    return SVO_OK;
+}
+
+}  // extern "C"

@@ -190,6 +190,8 @@ __global__ __launch_bounds__(256) void lc_topk_kernel(const int *__restrict__ co
     }
 }
 
+__global__ void lc_store_int_kernel(int *dst, int v) { *dst = v; }
+
 struct Island {  // tIsland, :268-330
     int first, last;
     double score;
@@ -214,6 +216,17 @@ struct svo_lc {
     int submitted = 0;                       // entries queued (svo_lc_submit); n_host.size() of them are collected
     int window_n = 0, window_first = 0, window_last = 0, window_query = -1;
     bool have_last = false;                  // m_last_bowvec's stand-in: the previous entry is the reference
+    // bag-of-words mode (svo_lc_set_vocabulary): DBoW2's database.  Row e of bw_w / bw_v is entry e's BowVector (ascending
+    // words, nf slots), bw_node its direct index (node per feature, -1: not indexed); the inverted file is a linked list per
+    // word THROUGH the rows (bw_head per word, bw_next per row slot); bw_plane / bw_sums are the query's workspace
+    svo_voc *voc = nullptr;
+    int di_levels = 2;
+    DevBuf bw_w, bw_v, bw_nw, bw_node, bw_head, bw_next, bw_plane, bw_sums, q_word, q_weight, q_node;
+    svo_lc_bow_record *rec_bow = nullptr;    // pinned: one record per entry, filled by bow_topk_kernel
+    // what the last collected verdict was formed from (svo_lc_collect_ex)
+    std::vector<int> last_cand_id;
+    std::vector<double> last_cand_score;
+    double last_ns = 0;
 };
 
 extern "C" {
@@ -254,9 +267,11 @@ int svo_lc_create(svo_ctx *ctx, const svo_lc_params *params, int width, int heig
     else
         svo_lc_default_params(&l->prm);
     const svo_lc_params &p = l->prm;
-    if (p.n_features < 8 || p.n_features > 2048 || p.max_entries < 2 || p.dislocal < 0) {
+    if (p.n_features < 8 || p.n_features > 2048 || p.max_entries < 2 || p.dislocal < 0 || p.max_db_results < 1 ||
+        p.max_db_results > LC_MAX_CAND) {
         delete l;
-        svo_set_error("svo_lc_create: n_features in 8..2048, max_entries >= 2");
+        svo_set_error("svo_lc_create: n_features in 8..2048, max_entries >= 2, max_db_results in 1..%d (the candidate list "
+                      "of a query is cut there BEFORE removeLowScores and the islands)", LC_MAX_CAND);
         return SVO_ERR_ARG;
     }
     l->w = width;
@@ -292,7 +307,10 @@ int svo_lc_destroy(svo_lc *l)
         svo_orb_destroy(l->orb);
     if (l->rec)
         (void)hipHostFree(l->rec);
-    DevBuf *bufs[] = {&l->db_desc, &l->db_xy, &l->db_n, &l->q, &l->counts, &l->nn, &l->img};
+    if (l->rec_bow)
+        (void)hipHostFree(l->rec_bow);
+    DevBuf *bufs[] = {&l->db_desc, &l->db_xy, &l->db_n, &l->q, &l->counts, &l->nn, &l->img, &l->bw_w, &l->bw_v, &l->bw_nw, &l->bw_node,
+                      &l->bw_head, &l->bw_next, &l->bw_plane, &l->bw_sums, &l->q_word, &l->q_weight, &l->q_node};
     for (DevBuf *b : bufs)
         b->release();
     delete l;
@@ -301,55 +319,165 @@ int svo_lc_destroy(svo_lc *l)
 
 int svo_lc_size(const svo_lc *l) { return l ? l->submitted : 0; }
 
-// Queue one frame: features, similarity against every stored entry, the frame's own entry, the reduction of the
-// scores to what the host logic reads (LcRecord).  Nothing is waited for: the work runs on the detector's context --
-// give the detector a context of its own and it runs beside the front-end's streams.
+// the query buffers of a frame: key points, octaves, responses, orientation vectors, descriptors, the live count
+struct LcQuery {
+    float *xy;
+    int *oct;
+    float *resp, *dir;
+    uint32_t *desc;
+    int *d_n;
+};
+static LcQuery lc_query(svo_lc *l)
+{
+    const size_t nf = (size_t)l->nf;
+    LcQuery q;
+    q.xy = l->q.as<float>();
+    q.oct = reinterpret_cast<int *>(q.xy + 2 * nf);
+    q.resp = reinterpret_cast<float *>(q.oct + nf);
+    q.dir = q.resp + nf;
+    q.desc = reinterpret_cast<uint32_t *>(q.dir + 2 * nf);
+    q.d_n = reinterpret_cast<int *>(q.desc + 8 * nf);
+    return q;
+}
+
+// The frame's features are in the query buffers (on the detector's stream): scoring against the database, the frame's own
+// entry, the reduction of the scores to what the host logic reads.  Nothing is waited for.
+static int lc_enqueue(svo_lc *l)
+{
+    svo_ctx *ctx = l->ctx;
+    const svo_lc_params &p = l->prm;
+    hipStream_t st = ctx->stream;
+    const int entry_id = l->submitted;
+    const size_t nf = (size_t)l->nf;
+    const LcQuery q = lc_query(l);
+    const int max_id = entry_id > p.dislocal ? entry_id - p.dislocal : 0;
+    const int k_want = p.max_db_results < LC_MAX_CAND ? p.max_db_results : LC_MAX_CAND;
+    int rc;
+    if (l->voc) {
+        // ---- DBoW2's way: BowVector + direct index of the frame (its database row), query through the inverted file ----
+        int *row_w = l->bw_w.as<int>() + (size_t)entry_id * nf, *row_n = l->bw_nw.as<int>() + entry_id;
+        double *row_v = l->bw_v.as<double>() + (size_t)entry_id * nf;
+        int *row_node = l->bw_node.as<int>() + (size_t)entry_id * nf;
+        l->rec_bow[entry_id].ready = 0;
+        if ((rc = svo_voc_launch_transform(l->voc, st, q.desc, l->nf, q.d_n, l->di_levels, l->q_word.as<int>(),
+                                           l->q_weight.as<double>(), l->q_node.as<int>())) ||
+            (rc = svo_bow_launch_vector(st, l->q_word.as<int>(), l->q_weight.as<double>(), l->q_node.as<int>(), l->nf, q.d_n, row_w,
+                                        row_v, row_n, row_node)) ||
+            (rc = svo_bow_launch_query(st, row_w, row_v, row_n, l->nf, l->bw_head.as<int>(), l->bw_next.as<int>(),
+                                       l->bw_v.as<double>(), l->nf, entry_id, l->bw_plane.as<double>(), l->capacity,
+                                       l->bw_sums.as<double>(), max_id, k_want, entry_id, l->rec_bow + entry_id)) ||
+            (rc = svo_bow_launch_link(st, row_w, row_n, l->nf, entry_id * l->nf, l->bw_head.as<int>(), l->bw_next.as<int>())))
+            return rc;
+    } else if (entry_id > 0) {
+        // ---- similarity of the query to every stored entry (one workgroup per entry) ----
+        hipLaunchKernelGGL(lc_score_kernel, dim3(entry_id), dim3(256), nf * 32, st, q.desc, q.d_n, l->db_desc.as<uint32_t>(),
+                           l->db_n.as<int>(), l->nf, p.hamming_threshold, l->counts.as<int>());
+    }
+    // ---- the query becomes entry `entry_id` (m_database->add + m_image_keys/descriptors, :728,:842-851) ----
+    SVO_HIP(hipMemcpyAsync(l->db_desc.as<uint32_t>() + (size_t)entry_id * nf * 8, q.desc, nf * 32, hipMemcpyDeviceToDevice, st));
+    SVO_HIP(hipMemcpyAsync(l->db_xy.as<float>() + (size_t)entry_id * nf * 2, q.xy, nf * 8, hipMemcpyDeviceToDevice, st));
+    SVO_HIP(hipMemcpyAsync(l->db_n.as<int>() + entry_id, q.d_n, 4, hipMemcpyDeviceToDevice, st));
+    if (!l->voc) {
+        // ---- the <= max_db_results best entries below `dislocal`, the normalisation count, the feature count ----
+        l->rec[entry_id].ready = 0;
+        hipLaunchKernelGGL(lc_topk_kernel, dim3(1), dim3(256), 0, st, l->counts.as<int>(), max_id, k_want, q.d_n, entry_id, l->nf,
+                           l->rec + entry_id);
+    }
+    SVO_HIP(hipGetLastError());
+    l->submitted = entry_id + 1;
+    return SVO_OK;
+}
+
+static int lc_check_room(svo_lc *l)
+{
+    if (l->submitted >= l->capacity) {
+        svo_set_error("loop detector database is full (%d entries)", l->capacity);
+        return SVO_ERR_STATE;
+    }
+    return SVO_OK;
+}
+
+// Queue one frame: features, scoring against the database, the frame's own entry, the reduction of the scores to what the
+// host logic reads.  Nothing is waited for: the work runs on the detector's context -- give the detector a context of its
+// own and it runs beside the front-end's streams.  With SVO_MEM_DEVICE the image is read by that queued work: it must
+// stay valid until svo_lc_collect of this frame has returned.
 int svo_lc_submit(svo_lc *l, const uint8_t *image, int mem)
 {
     SVO_CHECK_ARG(l && image);
     SVO_CHECK_ARG(mem == SVO_MEM_HOST || mem == SVO_MEM_DEVICE);
     svo_ctx *ctx = l->ctx;
-    const svo_lc_params &p = l->prm;
     SVO_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    const int entry_id = l->submitted;
-    if (entry_id >= l->capacity) {
-        svo_set_error("loop detector database is full (%d entries)", l->capacity);
-        return SVO_ERR_STATE;
-    }
-    const size_t nf = (size_t)l->nf;
-    // ---- features of this frame ----
+    int rc = lc_check_room(l);
+    if (rc)
+        return rc;
     const uint8_t *d_img = image;
     if (mem == SVO_MEM_HOST) {
         SVO_HIP(hipMemcpyAsync(l->img.p, image, (size_t)l->w * l->h * l->c, hipMemcpyHostToDevice, st));
         d_img = l->img.as<uint8_t>();
     }
-    float *qxy = l->q.as<float>();
-    int *qoct = reinterpret_cast<int *>(qxy + 2 * nf);
-    float *qresp = reinterpret_cast<float *>(qoct + nf), *qdir = qresp + nf;
-    uint32_t *qdesc = reinterpret_cast<uint32_t *>(qdir + 2 * nf);
-    int *d_nq = reinterpret_cast<int *>(qdesc + 8 * nf);
-    int rc = svo_orb_launch(l->orb, d_img, qxy, qoct, qresp, qdir, qdesc, d_nq);
+    const LcQuery q = lc_query(l);
+    if ((rc = svo_orb_launch(l->orb, d_img, q.xy, q.oct, q.resp, q.dir, q.desc, q.d_n)))
+        return rc;
+    return lc_enqueue(l);
+}
+
+// the same for a frame whose features were extracted elsewhere (svo_orb_extract on another rank of a chunk-sharded run)
+int svo_lc_submit_features(svo_lc *l, const float *xy, const uint32_t *desc, int n, int mem)
+{
+    SVO_CHECK_ARG(l && n >= 0 && n <= l->nf && (n == 0 || (xy && desc)));
+    SVO_CHECK_ARG(mem == SVO_MEM_HOST || mem == SVO_MEM_DEVICE);
+    svo_ctx *ctx = l->ctx;
+    SVO_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    int rc = lc_check_room(l);
     if (rc)
         return rc;
-    // ---- similarity of the query to every stored entry (one workgroup per entry) ----
-    if (entry_id > 0)
-        hipLaunchKernelGGL(lc_score_kernel, dim3(entry_id), dim3(256), nf * 32, st, qdesc, d_nq,
-                           l->db_desc.as<uint32_t>(), l->db_n.as<int>(), l->nf, p.hamming_threshold,
-                           l->counts.as<int>());
-    // ---- the query becomes entry `entry_id` (m_database->add + m_image_keys/descriptors, :728,:842-851) ----
-    SVO_HIP(hipMemcpyAsync(l->db_desc.as<uint32_t>() + (size_t)entry_id * nf * 8, qdesc, nf * 32,
-                           hipMemcpyDeviceToDevice, st));
-    SVO_HIP(hipMemcpyAsync(l->db_xy.as<float>() + (size_t)entry_id * nf * 2, qxy, nf * 8, hipMemcpyDeviceToDevice, st));
-    SVO_HIP(hipMemcpyAsync(l->db_n.as<int>() + entry_id, d_nq, 4, hipMemcpyDeviceToDevice, st));
-    // ---- the <= max_db_results best entries below `dislocal`, the normalisation count, the feature count ----
-    const int max_id = entry_id > p.dislocal ? entry_id - p.dislocal : 0;
-    const int k_want = p.max_db_results < LC_MAX_CAND ? p.max_db_results : LC_MAX_CAND;
-    l->rec[entry_id].ready = 0;
-    hipLaunchKernelGGL(lc_topk_kernel, dim3(1), dim3(256), 0, st, l->counts.as<int>(), max_id, k_want, d_nq, entry_id,
-                       l->nf, l->rec + entry_id);
-    SVO_HIP(hipGetLastError());
-    l->submitted = entry_id + 1;
+    const LcQuery q = lc_query(l);
+    const hipMemcpyKind kind = mem == SVO_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+    SVO_HIP(hipMemsetAsync(q.xy, 0, (size_t)l->nf * 8, st));
+    SVO_HIP(hipMemsetAsync(q.desc, 0, (size_t)l->nf * 32, st));
+    if (n > 0) {
+        SVO_HIP(hipMemcpyAsync(q.xy, xy, (size_t)n * 8, kind, st));
+        SVO_HIP(hipMemcpyAsync(q.desc, desc, (size_t)n * 32, kind, st));
+    }
+    hipLaunchKernelGGL(lc_store_int_kernel, dim3(1), dim3(1), 0, st, q.d_n, n);  // the count travels as a kernel argument
+    if (mem == SVO_MEM_HOST)
+        SVO_HIP(hipStreamSynchronize(st));  // the caller's arrays are pageable: they are read by now
+    return lc_enqueue(l);
+}
+
+int svo_lc_set_vocabulary(svo_lc *l, svo_voc *voc, int di_levels)
+{
+    SVO_CHECK_ARG(l && voc && di_levels >= 0);
+    if (l->submitted != 0) {
+        svo_set_error("svo_lc_set_vocabulary: the database already holds %d entries", l->submitted);
+        return SVO_ERR_STATE;
+    }
+    SVO_HIP(hipSetDevice(l->ctx->device));
+    const size_t nf = (size_t)l->nf, cap = (size_t)l->capacity, nw = (size_t)svo_voc_words_internal(voc);
+    if (cap > 8192) {
+        svo_set_error("svo_lc_set_vocabulary: the candidate selection holds at most 8192 entries (max_entries %zu)", cap);
+        return SVO_ERR_ARG;
+    }
+    int rc;
+    if ((rc = l->bw_w.ensure(cap * nf * 4)) || (rc = l->bw_v.ensure(cap * nf * 8)) || (rc = l->bw_nw.ensure(cap * 4)) ||
+        (rc = l->bw_node.ensure(cap * nf * 4)) || (rc = l->bw_head.ensure((nw + 1) * 4)) || (rc = l->bw_next.ensure(cap * nf * 4)) ||
+        (rc = l->bw_plane.ensure(nf * cap * 8)) || (rc = l->bw_sums.ensure(cap * 8)) || (rc = l->q_word.ensure(nf * 4)) ||
+        (rc = l->q_weight.ensure(nf * 8)) || (rc = l->q_node.ensure(nf * 4)))
+        return rc;
+    SVO_HIP(hipMemset(l->bw_head.p, 0xff, (nw + 1) * 4));
+    SVO_HIP(hipMemset(l->bw_next.p, 0xff, cap * nf * 4));
+    SVO_HIP(hipMemset(l->bw_sums.p, 0, cap * 8));
+    if (!l->rec_bow) {
+        if (hipHostMalloc(reinterpret_cast<void **>(&l->rec_bow), sizeof(svo_lc_bow_record) * cap, hipHostMallocDefault) != hipSuccess) {
+            svo_set_error("svo_lc_set_vocabulary: cannot pin %zu bytes for the per-frame records", sizeof(svo_lc_bow_record) * cap);
+            return SVO_ERR_HIP;
+        }
+        memset(l->rec_bow, 0, sizeof(svo_lc_bow_record) * cap);
+    }
+    l->voc = voc;
+    l->di_levels = di_levels;
     return SVO_OK;
 }
 
@@ -357,7 +485,8 @@ int svo_lc_pending(const svo_lc *l) { return l ? l->submitted - (int)l->n_host.s
 
 // The oldest queued frame's verdict: waits (on the DETECTOR's stream only) until its record has landed, then the
 // host logic of detectLoop.  Frames are collected in the order they were submitted.
-int svo_lc_collect(svo_lc *l, int *status, int *query, int *match)
+int svo_lc_collect_ex(svo_lc *l, int *status, int *query, int *match, int *cand_id, double *cand_score, int cap_out,
+                      int *n_cand_out, double *ns_factor)
 {
     SVO_CHECK_ARG(l && status);
     svo_ctx *ctx = l->ctx;
@@ -370,35 +499,62 @@ int svo_lc_collect(svo_lc *l, int *status, int *query, int *match)
     SVO_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const size_t nf = (size_t)l->nf;
-    const LcRecord &rec = l->rec[entry_id];
-    if (__atomic_load_n(&rec.ready, __ATOMIC_ACQUIRE) != entry_id + 1) {
+    const bool bow = l->voc != nullptr;
+    const int *ready = bow ? &l->rec_bow[entry_id].ready : &l->rec[entry_id].ready;
+    if (__atomic_load_n(ready, __ATOMIC_ACQUIRE) != entry_id + 1) {
         SVO_HIP(hipStreamSynchronize(st));
-        if (__atomic_load_n(&rec.ready, __ATOMIC_ACQUIRE) != entry_id + 1) {
+        if (__atomic_load_n(ready, __ATOMIC_ACQUIRE) != entry_id + 1) {
             svo_set_error("svo_lc_collect: the record of entry %d did not arrive", entry_id);
             return SVO_ERR_HIP;
         }
     }
-    const int nq = rec.nq;
+    // the candidates of the database query (score descending, entry id ascending on ties -- what the sort of the
+    // id-ordered result list gives) and the normalisation score
+    std::vector<Result> qret;
+    double ns_have = 0.;
+    int nq = 0;  // features of the query (0 features: no geometric check possible)
+    if (bow) {
+        // DBoW2: score = -(sum over the common words of |v - w| - |v| - |w|) / 2 (TemplatedDatabase::queryL1,
+        // L1Scoring::score for the normalisation against the previous frame's vector, :733)
+        const svo_lc_bow_record &rec = l->rec_bow[entry_id];
+        for (int k = 0; k < rec.n_cand; k++)
+            qret.push_back({rec.cand_id[k], -rec.cand_sum[k] / 2.0});
+        ns_have = -rec.last_sum / 2.0;
+    } else {
+        const LcRecord &rec = l->rec[entry_id];
+        nq = rec.nq;
+        auto score_of = [&](int count) { return nq > 0 ? (double)count / (double)nq : 0.; };
+        for (int k = 0; k < rec.n_cand; k++)
+            qret.push_back({rec.cand_id[k], score_of(rec.cand_count[k])});
+        ns_have = score_of(rec.last_count);
+    }
+    std::sort(qret.begin(), qret.end(),
+              [](const Result &a, const Result &b) { return a.score > b.score || (a.score == b.score && a.id < b.id); });
+    if ((int)qret.size() > p.max_db_results)
+        qret.resize(p.max_db_results);
     const uint32_t *qdesc = l->db_desc.as<uint32_t>() + (size_t)entry_id * nf * 8;  // the query IS entry `entry_id` now
     const int *d_nq = l->db_n.as<int>() + entry_id;
     int rc;
-    auto score_of = [&](int count) { return nq > 0 ? (double)count / (double)nq : 0.; };
+    if (bow) {  // the feature count of the frame (the record carries the WORD count)
+        SVO_HIP(hipMemcpyAsync(ctx->pinned, d_nq, 4, hipMemcpyDeviceToHost, st));
+        SVO_HIP(hipStreamSynchronize(st));
+        nq = *reinterpret_cast<const int *>(ctx->pinned);
+    }
+    l->last_cand_id.clear();
+    l->last_cand_score.clear();
+    for (const Result &r : qret) {
+        l->last_cand_id.push_back(r.id);
+        l->last_cand_score.push_back(r.score);
+    }
+    l->last_ns = 0.;
 
     int st_out = SVO_LC_CLOSE_MATCHES_ONLY, match_out = -1;
     if (entry_id > p.dislocal) {  // :714-722
-        // the record holds the best entries in no particular order: score descending, entry id ascending on ties is
-        // what the stable sort of the id-ordered full list gave
-        std::vector<Result> qret;
-        for (int k = 0; k < rec.n_cand; k++)
-            qret.push_back({rec.cand_id[k], score_of(rec.cand_count[k])});
-        std::sort(qret.begin(), qret.end(),
-                  [](const Result &a, const Result &b) { return a.score > b.score || (a.score == b.score && a.id < b.id); });
-        if ((int)qret.size() > p.max_db_results)
-            qret.resize(p.max_db_results);
         if (!qret.empty()) {
             double ns = 1.0;
             if (p.use_nss)
-                ns = l->have_last ? score_of(rec.last_count) : 0.;  // :736-739
+                ns = l->have_last ? ns_have : 0.;  // :736-739
+            l->last_ns = ns;
             if (!p.use_nss || ns >= p.min_nss_factor) {
                 const double cut = (double)p.alpha * ns;  // removeLowScores, :1320-1338
                 size_t keep = 0;
@@ -466,23 +622,48 @@ int svo_lc_collect(svo_lc *l, int *status, int *query, int *match)
                         l->window_query = entry_id;
                         match_out = isl.best_entry;
                         if (l->window_n > p.k) {
-                            // ---- geometric check: neighbour-ratio matches + RANSAC F (:1101-1160) ----
+                            // ---- geometric check: neighbour-ratio matches + RANSAC F.  With a vocabulary through the direct
+                            // index (isGeometricallyConsistent_DI, :1005-1087: only features under a common node at di_levels
+                            // are compared, nodes ascending); without, the exhaustive form (:1101-1160) ----
                             bool detection = false;
                             const int old = isl.best_entry, na = l->n_host[old];
                             if (na > 0 && nq > 0) {
                                 int *bj = l->nn.as<int>(), *dd1 = bj + nf, *dd2 = dd1 + nf;
-                                hipLaunchKernelGGL(lc_nearest2_kernel, dim3((na + 255) / 256), dim3(256), nf * 32, st,
-                                                   l->db_desc.as<uint32_t>() + (size_t)old * nf * 8, na, qdesc, d_nq, bj,
-                                                   dd1, dd2);
+                                const uint32_t *odesc = l->db_desc.as<uint32_t>() + (size_t)old * nf * 8;
+                                std::vector<int> hnode;
+                                if (bow) {
+                                    if ((rc = svo_bow_launch_di_nearest(st, odesc, l->bw_node.as<int>() + (size_t)old * nf, na, qdesc,
+                                                                        l->bw_node.as<int>() + (size_t)entry_id * nf, d_nq, bj, dd1, dd2)))
+                                        return rc;
+                                    hnode.resize(nf);
+                                    SVO_HIP(hipMemcpyAsync(hnode.data(), l->bw_node.as<int>() + (size_t)old * nf, nf * 4,
+                                                           hipMemcpyDeviceToHost, st));
+                                } else
+                                    hipLaunchKernelGGL(lc_nearest2_kernel, dim3((na + 255) / 256), dim3(256), nf * 32, st, odesc, na, qdesc,
+                                                       d_nq, bj, dd1, dd2);
                                 std::vector<int> h((size_t)3 * nf);
                                 SVO_HIP(hipMemcpyAsync(h.data(), bj, nf * 12, hipMemcpyDeviceToHost, st));
                                 SVO_HIP(hipStreamSynchronize(st));
                                 const int *hbj = h.data(), *hd1 = hbj + nf, *hd2 = hd1 + nf;
+                                // the order the old image's features are visited in: by feature (exhaustive), or by direct-index
+                                // node and then by feature, a fresh conflict table per node (one getMatches_neighratio call each)
+                                std::vector<int> order;
+                                for (int i = 0; i < na; i++)
+                                    if (!bow || (hnode[i] >= 0 && hbj[i] >= 0))
+                                        order.push_back(i);
+                                if (bow)
+                                    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return hnode[a] < hnode[b]; });
                                 std::vector<int> mA, mB;
-                                for (int i = 0; i < na; i++) {
+                                size_t base = 0;
+                                int cur_node = -2;
+                                for (int i : order) {
+                                    if (bow && hnode[i] != cur_node) {
+                                        cur_node = hnode[i];
+                                        base = mA.size();
+                                    }
                                     if ((double)hd1[i] / (double)hd2[i] <= p.max_neighbor_ratio) {  // :1293
                                         const int jb = hbj[i];
-                                        auto it = std::find(mB.begin(), mB.end(), jb);
+                                        auto it = std::find(mB.begin() + base, mB.end(), jb);
                                         if (it == mB.end()) {
                                             mB.push_back(jb);
                                             mA.push_back(i);
@@ -539,7 +720,22 @@ int svo_lc_collect(svo_lc *l, int *status, int *query, int *match)
         *query = entry_id;
     if (match)
         *match = match_out;
+    if (n_cand_out)
+        *n_cand_out = (int)l->last_cand_id.size();
+    for (int k = 0; k < (int)l->last_cand_id.size() && k < cap_out; k++) {
+        if (cand_id)
+            cand_id[k] = l->last_cand_id[k];
+        if (cand_score)
+            cand_score[k] = l->last_cand_score[k];
+    }
+    if (ns_factor)
+        *ns_factor = l->last_ns;
     return SVO_OK;
+}
+
+int svo_lc_collect(svo_lc *l, int *status, int *query, int *match)
+{
+    return svo_lc_collect_ex(l, status, query, match, nullptr, nullptr, 0, nullptr, nullptr);
 }
 
 // submit + collect: the synchronous form, one call per frame, in order (checkLoopDetectorStatus as the reference

@@ -1,0 +1,123 @@
+"""DBoW2 vocabulary files: what ``OrbVocabulary::load`` / ``save`` read and write (the reference loads
+``orb_voc00.yml.gz`` at include/visualSLAM.h:131-134 and its trainer saves ``orb_voc.yml.gz``,
+src/bagOfWordsDetector.cpp:95-98).  The vocabularies were stripped from the reference checkout
+(``.MISSING_LARGE_BLOBS``); a user who has one reads it here and hands the arrays to ``svo_voc_create``
+(``capi.Vocabulary.from_arrays``), and a vocabulary trained with ``svo_voc_train`` is written in the same format.
+
+Format (cv::FileStorage YAML, DBoW2's TemplatedVocabulary::save as recalled -- the library is not in the checkout)::
+
+    %YAML:1.0
+    vocabulary:
+       k: 9
+       L: 6
+       scoringType: 0          # L1_NORM
+       weightingType: 0        # TF_IDF
+       nodes:
+          - { nodeId:1, parentId:0, weight:0., descriptor:"b0 b1 ... b31 " }
+       words:
+          - { wordId:0, nodeId:19 }
+
+Node 0 (the root) is not listed.  An ORB descriptor is written by FORB::toString as its 32 bytes in decimal; the
+library packs bytes 4i .. 4i+3 into word i of its 8 x uint32 layout (little endian: what a memcpy of cv::Mat row
+gives).  Files whose nodes are not in id order, or whose children are not consecutive, are renumbered on reading
+(``svo_voc_create`` wants the children of a node consecutive; DBoW2 writes them so)."""
+from __future__ import annotations
+
+import gzip
+import re
+
+import numpy as np
+
+L1_NORM, TF_IDF = 0, 0
+
+
+def _open(path, mode):
+    return gzip.open(path, mode + "t") if str(path).endswith(".gz") else open(path, mode)
+
+
+def save_dbow2(path, k: int, L: int, parent, desc, weight, word_id=None):
+    """Write a vocabulary (arrays in node order, node 0 = root) as DBoW2 does."""
+    parent = np.asarray(parent, np.int64)
+    desc = np.ascontiguousarray(desc, np.uint32).reshape(-1, 8)
+    weight = np.asarray(weight, np.float64)
+    n = len(parent)
+    byts = desc.view(np.uint8).reshape(n, 32)
+    if word_id is None:
+        has_child = np.zeros(n, bool)
+        has_child[parent[1:]] = True
+        word_id = np.full(n, -1, np.int64)
+        leaves = [i for i in range(1, n) if not has_child[i]]
+        word_id[leaves] = np.arange(len(leaves))
+    with _open(path, "w") as f:
+        f.write("%YAML:1.0\n---\nvocabulary:\n")
+        f.write(f"   k: {int(k)}\n   L: {int(L)}\n   scoringType: {L1_NORM}\n   weightingType: {TF_IDF}\n   nodes:\n")
+        for i in range(1, n):
+            d = " ".join(str(int(b)) for b in byts[i])
+            f.write(f"      - {{ nodeId:{i}, parentId:{int(parent[i])}, weight:{float(weight[i])!r},\n"
+                    f"          descriptor:\"{d} \" }}\n")
+        f.write("   words:\n")
+        for i in range(1, n):
+            if word_id[i] >= 0:
+                f.write(f"      - {{ wordId:{int(word_id[i])}, nodeId:{i} }}\n")
+
+
+_NODE = re.compile(r"nodeId:\s*(\d+)\s*,\s*parentId:\s*(\d+)\s*,\s*weight:\s*([-+0-9.eEinfa]+)\s*,\s*descriptor:\s*\"([^\"]*)\"", re.S)
+_WORD = re.compile(r"wordId:\s*(\d+)\s*,\s*nodeId:\s*(\d+)")
+
+
+def load_dbow2(path):
+    """-> dict(k, L, scoring, weighting, parent, desc [n, 8] uint32, weight, word_id) in the library's node order."""
+    with _open(path, "r") as f:
+        text = f.read()
+
+    def scalar(name):
+        m = re.search(rf"\b{name}:\s*(-?\d+)", text)
+        if not m:
+            raise ValueError(f"{path}: no '{name}' entry -- not a DBoW2 vocabulary")
+        return int(m.group(1))
+
+    k, L = scalar("k"), scalar("L")
+    scoring, weighting = scalar("scoringType"), scalar("weightingType")
+    nodes = [(int(a), int(b), float(c.rstrip(".") if c.endswith(".") else c), d) for a, b, c, d in _NODE.findall(text)]
+    if not nodes:
+        raise ValueError(f"{path}: no nodes")
+    ids = [a for a, *_ in nodes]
+    if sorted(ids) != list(range(1, len(nodes) + 1)):
+        raise ValueError(f"{path}: node ids are not 1..{len(nodes)}")
+    n = len(nodes) + 1
+    parent = np.full(n, -1, np.int64)
+    weight = np.zeros(n)
+    byts = np.zeros((n, 32), np.uint8)
+    for a, b, c, d in nodes:
+        vals = d.split()
+        if len(vals) != 32:
+            raise ValueError(f"{path}: node {a} has {len(vals)} descriptor bytes, ORB needs 32")
+        parent[a], weight[a] = b, c
+        byts[a] = [int(v) for v in vals]
+    desc = byts.view(np.uint32).reshape(n, 8)
+    # library order: parents before children, the children of a node consecutive (renumber if the file's are not)
+    children = [[] for _ in range(n)]
+    for i in range(1, n):
+        children[parent[i]].append(i)
+    order = [0]
+    stack = [0]
+    # all children of a node consecutively, then depth first -- DBoW2's own creation order
+    def visit(b):
+        order.extend(children[b])
+        for c in children[b]:
+            if children[c]:
+                visit(c)
+    import sys
+    sys.setrecursionlimit(max(10000, sys.getrecursionlimit()))
+    visit(0)
+    new = np.empty(n, np.int64)
+    new[order] = np.arange(n)
+    out_parent = np.full(n, -1, np.int64)
+    out_parent[new[1:]] = new[parent[1:]]
+    out_desc, out_weight = np.zeros_like(desc), np.zeros(n)
+    out_desc[new], out_weight[new] = desc, weight
+    word_id = np.full(n, -1, np.int64)
+    for w, node in _WORD.findall(text):
+        word_id[new[int(node)]] = int(w)
+    return dict(k=k, L=L, scoring=scoring, weighting=weighting, parent=out_parent.astype(np.int32), desc=out_desc,
+                weight=out_weight, word_id=word_id.astype(np.int32), renumbered=bool((new != np.arange(n)).any()))

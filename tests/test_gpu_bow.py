@@ -1,0 +1,162 @@
+"""The bag-of-words side of the loop detector on the GPU (bow.hip, loopdet.hip in vocabulary mode) against its oracle
+(oracle/bow.c, oracle/loop_detector.py): the trained tree node for node, words / weights / BowVectors bit for bit, and the
+detector frame by frame -- the candidates of the database query, their L1 scores, the normalisation score and the verdict
+of DLoopDetector::detectLoop (include/TemplatedLoopDetector.h:696-861) with the reference's parameters
+(include/visualSLAM.h:120-127: use_nss, alpha 0.9, k 1, GEOM_DI, di_levels 2) and the reference trainer's shape
+(src/bagOfWordsDetector.cpp:46-56: k 9, L 6, TF_IDF, L1_NORM)."""
+import numpy as np
+import pytest
+
+from bow_fixtures import noisy_descriptor_images
+from oracle import orc
+from oracle.loop_detector import LoopDetector as OracleDetector, Params
+from ros_stereo_slam_amd import capi, synth, vocabulary
+
+pytestmark = pytest.mark.gpu
+SIZE, K4 = (480, 160), (270.0, 270.0, 240.0, 80.0)
+
+
+def _same_tree(g, o):
+    ga, oa = g.arrays(), o.arrays()
+    assert g.n_nodes == o.n_nodes and g.n_words == o.n_words, (g.n_nodes, o.n_nodes, g.n_words, o.n_words)
+    assert np.array_equal(ga["parent"], oa["parent"])
+    assert np.array_equal(ga["desc"], oa["desc"])
+    assert np.array_equal(ga["word_id"], oa["word_id"])
+    assert np.array_equal(ga["weight"], oa["weight"])          # idf through the shared svo_log: the same bits
+
+
+@pytest.mark.parametrize("k,L,seed", [(9, 4, 3), (9, 6, 11), (4, 3, 0), (10, 2, 7)])
+def test_training_builds_the_oracles_tree_node_for_node(ctx, k, L, seed):
+    imgs = noisy_descriptor_images(n_images=30, per_image=260, n_proto=150, seed=seed)
+    g = capi.Vocabulary.train(ctx, imgs, k=k, L=L, seed=seed)
+    o = orc.Vocabulary.train(imgs, k=k, L=L, seed=seed)
+    assert g.k == k and g.L == L
+    _same_tree(g, o)
+    for im in imgs[:4]:
+        for levelsup in (0, 2):
+            for a, b in zip(g.transform(im, levelsup), o.transform(im, levelsup)):
+                assert np.array_equal(a, b)
+            for a, b in zip(g.bow(im, levelsup), o.bow(im, levelsup)):
+                assert np.array_equal(a, b)
+    g.close()
+
+
+def test_training_edge_cases(ctx):
+    rng = np.random.default_rng(1)
+    one = [rng.integers(0, 2 ** 32, (1, 8), dtype=np.uint64).astype(np.uint32)]                 # a single descriptor
+    same = [np.repeat(one[0], 40, axis=0), np.repeat(one[0], 25, axis=0)]                         # all identical: kmeans++ stops at one centre
+    few = [rng.integers(0, 2 ** 32, (5, 8), dtype=np.uint64).astype(np.uint32)]                  # fewer than k
+    for imgs in (one, same, few):
+        g = capi.Vocabulary.train(ctx, imgs, k=9, L=3, seed=2)
+        o = orc.Vocabulary.train(imgs, k=9, L=3, seed=2)
+        _same_tree(g, o)
+        for a, b in zip(g.bow(imgs[0], 1), o.bow(imgs[0], 1)):
+            assert np.array_equal(a, b)
+        g.close()
+    with pytest.raises(capi.SvoError):
+        capi.Vocabulary.train(ctx, few, k=40, L=3)
+
+
+def _loop_images(n=134):
+    poses = synth.loop_trajectory(n, half_x=6, half_z=10, radius=4, step=0.5)
+    sc = synth.Scene(wall_x=14, z_min=-18, z_max=18)
+    return poses, [sc.stereo(R, t, K=K4, size=SIZE)[0] for R, t in poses]
+
+
+def _features(ctx, imgs):
+    return [ctx.orb_extract(im, 500, 20) for im in imgs]
+
+
+@pytest.fixture(scope="module")
+def loop_setup(ctx):
+    poses, imgs = _loop_images()
+    feats = _features(ctx, imgs)
+    train = [f[4] for f in feats[::2]]                       # every second frame trains the vocabulary (k 9, L 6)
+    g = capi.Vocabulary.train(ctx, train, k=9, L=6, seed=20261003)
+    o = orc.Vocabulary.train(train, k=9, L=6, seed=20261003)
+    return poses, imgs, feats, g, o
+
+
+def test_vocabulary_of_real_orb_descriptors_and_the_file_format(ctx, loop_setup, tmp_path):
+    poses, imgs, feats, g, o = loop_setup
+    _same_tree(g, o)
+    assert g.n_words > 5000
+    a = g.arrays()
+    vocabulary.save_dbow2(tmp_path / "orb_voc.yml.gz", g.k, g.L, a["parent"], a["desc"], a["weight"], a["word_id"])
+    f = vocabulary.load_dbow2(tmp_path / "orb_voc.yml.gz")
+    g2 = capi.Vocabulary.from_arrays(ctx, f["k"], f["L"], f["parent"], f["desc"], f["weight"])
+    assert g2.n_words == g.n_words
+    for xy, octv, resp, d, desc in feats[1:6]:
+        for x, y in zip(g2.bow(desc, 2), o.bow(desc, 2)):
+            assert np.array_equal(x, y)
+    g2.close()
+
+
+@pytest.mark.parametrize("alpha", [0.9, 0.3])
+def test_bow_detector_matches_oracle_frame_by_frame(ctx, loop_setup, alpha):
+    """Every frame: the candidates of the database query (ids in order), their scores, the normalisation score, the status
+    and the matched entry.  Scores are compared to 1e-12 -- and found EQUAL: the GPU adds an entry's terms in
+    word order, as queryL1's map does."""
+    poses, imgs, feats, gv, ov = loop_setup
+    g = capi.LoopDetector(ctx, SIZE[0], SIZE[1], 3, alpha=alpha, seed=5)
+    g.set_vocabulary(gv, 2)
+    o = OracleDetector(Params(alpha=alpha, seed=5), voc=ov, di_levels=2)
+    accepted_g, accepted_o, worst, n_equal, n_cmp = [], [], 0.0, 0, 0
+    for i, img in enumerate(imgs):
+        g.submit(img)
+        rg = g.collect_ex()
+        ro = o.detect(img)
+        ids_o, sc_o, ns_o = o.last_query
+        assert rg["query"] == ro["query"] == i
+        assert rg["cand_id"].tolist() == ids_o, (i, rg["cand_id"].tolist(), ids_o)
+        if len(ids_o):
+            worst = max(worst, float(np.abs(rg["cand_score"] - np.array(sc_o)).max()), abs(rg["ns_factor"] - ns_o))
+            n_equal += int(np.array_equal(rg["cand_score"], np.array(sc_o)) and rg["ns_factor"] == ns_o)
+            n_cmp += 1
+            assert (np.diff(rg["cand_score"]) <= 0).all() and 0.0 <= rg["cand_score"].min() and rg["cand_score"].max() <= 1.0 + 1e-12
+        assert rg["status"] == ro["status"], (i, capi.LC_STATUS[rg["status"]], capi.LC_STATUS[ro["status"]])
+        assert rg["match"] == ro["match"], i
+        for r, acc in ((rg, accepted_g), (ro, accepted_o)):
+            if r["status"] == 0 and r["query"] - r["match"] > 100:      # src/optimizationStuff.cpp:58
+                acc.append((r["query"], r["match"]))
+    assert worst <= 1e-12 and n_cmp > 80
+    assert n_equal == n_cmp, f"{n_equal} of {n_cmp} frames bit-equal, worst difference {worst:.2e}"
+    assert accepted_g == accepted_o and accepted_g
+    gt = synth.loop_closures(poses, min_gap=100)
+    first_true = next(i for i, m in enumerate(gt) if m >= 0)
+    q, m = accepted_g[0]
+    assert abs(q - first_true) <= 8 and m <= 8
+    g.close()
+
+
+def test_features_submitted_from_elsewhere_and_queued(ctx, loop_setup):
+    """svo_lc_submit_features (a chunk-sharded run: ORB on the rank that holds the images, the database on rank 0): the
+    verdicts of the image form; all frames queued before the first is collected."""
+    poses, imgs, feats, gv, ov = loop_setup
+    own = capi.Context(0)
+    a = capi.LoopDetector(ctx, SIZE[0], SIZE[1], 3, seed=5)
+    b = capi.LoopDetector(own, SIZE[0], SIZE[1], 3, seed=5)
+    a.set_vocabulary(gv, 2)
+    b.set_vocabulary(gv, 2)
+    ref = []
+    for img in imgs:
+        a.submit(img)
+        ref.append(a.collect())
+    for xy, octv, resp, d, desc in feats:
+        b.submit_features(xy, desc)
+    assert b.pending() == len(feats)
+    assert [b.collect() for _ in feats] == ref
+    assert any(r["status"] == 0 for r in ref)
+    # and without a vocabulary (the vocabulary-free similarity of rounds 2-3)
+    c = capi.LoopDetector(ctx, SIZE[0], SIZE[1], 3, seed=5)
+    d_ = capi.LoopDetector(own, SIZE[0], SIZE[1], 3, seed=5)
+    for img, f in zip(imgs[:60], feats[:60]):
+        d_.submit_features(f[0], f[4])
+        assert c.detect(img) == d_.collect()
+    with pytest.raises(capi.SvoError):
+        c.set_vocabulary(gv, 2)                                  # the database already holds entries
+    with pytest.raises(capi.SvoError):
+        capi.LoopDetector(ctx, SIZE[0], SIZE[1], 3, max_db_results=100)   # rejected, not silently clamped
+    for x in (a, b, c, d_):
+        x.close()
+    own.close()
