@@ -684,6 +684,35 @@ def main():
             result["ate_sharded_vs_sequential_over_path_length"] = (
                 result["ate_rmse_sharded_vs_sequential"] / (path_len * share / (world * share)))
 
+    # ---- the loop detector's input: every rank extracts the ORB features of ITS frames (500 x 40 B per frame), rank 0
+    # receives them in global frame order (one gather of tensors; outside every clock) ----
+    feats_all, feat_s = None, 0.0
+    if not args.no_extras and not args.no_detector:
+        try:
+            ctxf = capi.Context(local_rank)
+            t0 = time.perf_counter()
+            mine_n = share + (1 if rank == world - 1 else 0)       # the overlap frame belongs to the next rank
+            fxy = np.zeros((mine_n, 500, 2), np.float32)
+            fdesc = np.zeros((mine_n, 500, 8), np.uint32)
+            fn = np.zeros(mine_n, np.int32)
+            for i in range(mine_n):
+                xy_i, _, _, _, desc_i = ctxf.orb_extract(lefts[i], 500, 20)
+                fn[i] = len(xy_i)
+                fxy[i, :fn[i]], fdesc[i, :fn[i]] = xy_i, desc_i
+            feat_s = time.perf_counter() - t0
+            ctxf.close()
+            if dist is not None:
+                parts = chunked.gather_frame_features(dist, fn, fxy, fdesc, counts=[share + (1 if r == world - 1 else 0) for r in range(world)])
+            else:
+                parts = [(fn, fxy, fdesc)]
+            if rank == 0:
+                feats_all = [(pxy[i, :pn[i]], pdesc[i, :pn[i]]) for pn, pxy, pdesc in parts for i in range(len(pn))]
+                assert len(feats_all) == world * share + 1
+        except Exception as e:   # noqa: BLE001 -- the detector leg must not cost the run its line
+            feats_all = None
+            if rank == 0 and result is not None:
+                result["detector_features_error"] = f"{type(e).__name__}: {e}"
+
     # ---- configs[3]'s global solve on the stitched trajectory (rank 0; also configs[2]'s figure) ----
     if rank == 0 and not args.no_extras:
         try:   # an extra leg must not cost the run its line
@@ -691,32 +720,47 @@ def main():
             closures = chunked.gate_closures([m if m >= 1 else -1 for m in matches])  # LCidx = match - 1 must exist
             closure_source = "generator (frame pairs within 0.3 m / 10 deg, SURVEY.md 8d)"
             det_info = None
-            if world == 1 and not args.no_detector:
-                # configs[2] / [3]: the closures come from the library's own detector (ORB features + database + geometric
-                # check, svo_lc_*), run over the left image of EVERY frame of the stitched stream on a context of its own:
-                # all frames are queued (svo_lc_submit), then collected; entry id = global frame id
+            if feats_all is not None:
+                # configs[2] / [3]: the closures come from the library's own detector with the reference's scoring --
+                # a Hamming vocabulary tree (k 9, L 6: src/bagOfWordsDetector.cpp:46-56) trained on the GPU on every
+                # fourth frame of the first lap, DBoW2's TF-IDF / L1 score through the inverted file, GEOM_DI at
+                # di_levels 2 (include/visualSLAM.h:120-127) -- over the ORB features of EVERY frame of the stitched
+                # stream.  Every rank extracted the features of its own frames (svo_orb_extract); 20 KB per frame came to
+                # this rank; the database is filled by global frame id (svo_lc_submit_features), then all collected.
                 ctxd = capi.Context(local_rank)
-                det = capi.LoopDetector(ctxd, W, H, C, seed=5, max_entries=len(lefts) + 8)
+                n_all = len(feats_all)
                 t0 = time.perf_counter()
-                for img in lefts:
-                    det.submit(img)
+                train = [f[1] for f in feats_all[0:min(n_all, 492):4]]
+                voc = capi.Vocabulary.train(ctxd, train, k=9, L=6, seed=20261003)
+                t_train = time.perf_counter() - t0
+                det = capi.LoopDetector(ctxd, W, H, C, seed=5, max_entries=n_all + 8)
+                det.set_vocabulary(voc, 2)
+                t0 = time.perf_counter()
+                for xy, desc in feats_all:
+                    det.submit_features(xy, desc)
                 t_submit = time.perf_counter() - t0
-                verdicts = [det.collect() for _ in lefts]
+                verdicts = [det.collect() for _ in feats_all]
                 t_det = time.perf_counter() - t0
                 det_matches = [v["match"] if v["status"] == 0 and v["match"] >= 1 else -1 for v in verdicts]
                 det_closures = chunked.gate_closures(det_matches)
-                det_info = {"frames": len(lefts), "ms_per_frame": t_det / len(lefts) * 1e3,
-                            "host_submit_ms_per_frame": t_submit / len(lefts) * 1e3,
+                det_info = {"frames": n_all, "ms_per_frame": t_det / n_all * 1e3,
+                            "host_submit_ms_per_frame": t_submit / n_all * 1e3,
+                            "feature_extraction_ms_per_frame": feat_s / max(1, len(lefts) - 1) * 1e3,
+                            "scoring": "DBoW2 TF-IDF / L1 through an inverted file, GEOM_DI at di_levels 2",
+                            "vocabulary": {"k": voc.k, "L": voc.L, "nodes": voc.n_nodes, "words": voc.n_words,
+                                           "training_images": len(train), "train_s": t_train},
                             "detections": int(sum(v["status"] == 0 for v in verdicts)),
                             "accepted_closures": len(det_closures), "generator_closures": len(closures),
                             # an accepted closure is TRUE when the two frames' generator poses are within 2 m
                             "accepted_true": int(sum(np.linalg.norm(poses_all[q][1] - poses_all[m][1]) < 2.0
                                                      for q, m in det_closures.items()))}
                 det.close()
+                voc.close()
                 ctxd.close()
                 if det_closures:
                     closures = det_closures
-                    closure_source = "svo_lc detector on the stitched stream's left images (global frame ids)"
+                    closure_source = (f"svo_lc detector (vocabulary mode) on the ORB features of the stitched stream, extracted "
+                                      f"by {world} rank(s) on their own frames (global frame ids)")
             ctxg = capi.Context(local_rank)
             pg = capi.PoseGraph(ctxg)
             ctxg.enable_kernel_timing(True)

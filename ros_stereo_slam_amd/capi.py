@@ -276,13 +276,31 @@ def anms(self, xy, response, num_to_keep):
 def orb_extract(self, img, n_features=500, fast_threshold=20):
     """cv::ORB stand-in of the loop detector (src/optimizationStuff.cpp:49-56) ->
     (xy [n,2], octave [n], response [n], dir [n,2], desc [n,8] uint32)."""
+    n = C.c_int()
+    if not isinstance(img, np.ndarray):      # a device tensor (H, W[, C]) uint8: the outputs come back through device buffers
+        import torch
+
+        h, w = img.shape[:2]
+        c = 1 if img.ndim == 2 else img.shape[2]
+        dev = img.device
+        t_xy = torch.zeros((n_features, 2), dtype=torch.float32, device=dev)
+        t_oct = torch.zeros(n_features, dtype=torch.int32, device=dev)
+        t_resp = torch.zeros(n_features, dtype=torch.float32, device=dev)
+        t_d = torch.zeros((n_features, 2), dtype=torch.float32, device=dev)
+        t_desc = torch.zeros((n_features, 8), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize(dev)
+        _check(self.lib.svo_orb_extract(self._h, _ptr(img), w, h, c, n_features, fast_threshold, _ptr(t_xy), _ptr(t_oct),
+                                        _ptr(t_resp), _ptr(t_d), _ptr(t_desc), C.byref(n), MEM_DEVICE))
+        self.sync()
+        k = n.value
+        return (t_xy[:k].cpu().numpy(), t_oct[:k].cpu().numpy(), t_resp[:k].cpu().numpy(), t_d[:k].cpu().numpy(),
+                t_desc[:k].cpu().numpy().view(np.uint32))
     img = np.ascontiguousarray(img, np.uint8)
     h, w = img.shape[:2]
     c = 1 if img.ndim == 2 else img.shape[2]
     xy, octv = np.zeros((n_features, 2), np.float32), np.zeros(n_features, np.int32)
     resp, d = np.zeros(n_features, np.float32), np.zeros((n_features, 2), np.float32)
     desc = np.zeros((n_features, 8), np.uint32)
-    n = C.c_int()
     _check(self.lib.svo_orb_extract(self._h, _ptr(img), w, h, c, n_features, fast_threshold, _ptr(xy), _ptr(octv),
                                     _ptr(resp), _ptr(d), _ptr(desc), C.byref(n), MEM_HOST))
     k = n.value

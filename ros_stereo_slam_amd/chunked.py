@@ -136,6 +136,37 @@ def gather_trajectories(dist, poses, device=None, counts=None, as_array=False):
     return parts if as_array else [array_to_poses(p) for p in parts]
 
 
+def gather_frame_features(dist, n, xy, desc, counts=None, dst: int = 0):
+    """The loop detector's input in a chunk-sharded run: every rank holds the ORB features of ITS frames -- ``n`` [F]
+    feature counts, ``xy`` [F, nf, 2] float32, ``desc`` [F, nf, 8] uint32 (500 x 40 B per frame) -- and rank ``dst``,
+    which keeps the database, receives them in rank order (global frame order).  ``counts``: frames per rank.  One
+    gather per array; returns [(n, xy, desc)] per rank on ``dst``, None elsewhere."""
+    import torch
+
+    world, rank = dist.get_world_size(), dist.get_rank()
+    n = np.ascontiguousarray(n, np.int32)
+    xy = np.ascontiguousarray(xy, np.float32)
+    desc = np.ascontiguousarray(desc, np.uint32)
+    if counts is None:
+        counts = [len(n)] * world
+    m, nf = max(counts), xy.shape[1]
+
+    def pad(a, shape, dtype):
+        out = np.zeros(shape, dtype)
+        out[:len(a)] = a
+        return torch.from_numpy(out.view(np.uint8).reshape(-1))
+
+    out = []
+    for a, shape, dtype in ((n, (m,), np.int32), (xy, (m, nf, 2), np.float32), (desc, (m, nf, 8), np.uint32)):
+        mine = pad(a, shape, dtype)
+        got = [torch.empty_like(mine) for _ in range(world)] if rank == dst else None
+        dist.gather(mine, got, dst=dst)
+        out.append(None if got is None else [g.numpy().view(dtype).reshape(shape) for g in got])
+    if rank != dst:
+        return None
+    return [(out[0][r][:counts[r]], out[1][r][:counts[r]], out[2][r][:counts[r]]) for r in range(world)]
+
+
 def stitch(dist, local_poses, device=None):
     """Rank-local poses (relative to the chunk's first frame, one per frame of the chunk
     including the overlap frame) -> the rank's poses in the global frame, plus the global

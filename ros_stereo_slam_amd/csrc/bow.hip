@@ -17,7 +17,7 @@
 //   transform     a thread per feature descends the tree (first minimum of <= k Hamming distances per level)
 //   bow vector    one workgroup: rank the (word, feature) keys, add weights per word in feature order, L1-normalise in
 //                 word order -- the order std::map gives DBoW2, so every double equals the oracle's
-//   query         inverted file as linked lists through the database rows (head per word, next per row slot): a thread
+//   query         inverted file as linked lists through the database rows (head per word, skip pointers per row slot): a wave
 //                 per query word walks its list and drops |q-d|-|q|-|d| into a (query word x entry) plane; a thread per
 //                 entry then adds its column IN WORD ORDER (the order queryL1's map accumulates); one workgroup selects
 //                 the max_db_results best.  The Hamming work per frame no longer grows with the database.
@@ -343,84 +343,103 @@ __global__ __launch_bounds__(512) void bow_vector_kernel(const int *__restrict__
                                                          int *__restrict__ row_w, double *__restrict__ row_v,
                                                          int *__restrict__ row_n, int *__restrict__ row_node)
 {
-    __shared__ int s_w[BOW_MAX_F], s_i[BOW_MAX_F], s_nv, s_m;
+    // s_w / s_x: the features' words and weights as loaded; s_sw / s_sx: the same sorted by (word, feature);
+    // s_acc: the weight sums of the distinct words in word order
+    __shared__ int s_w[BOW_MAX_F], s_sw[BOW_MAX_F], s_nv, s_m;
+    __shared__ double s_x[BOW_MAX_F], s_sx[BOW_MAX_F], s_acc[BOW_MAX_F];
     __shared__ double s_norm;
     const int t = threadIdx.x;
     const int n = min(d_n ? min(*d_n, n_host) : n_host, BOW_MAX_F);
-    if (t == 0)
+    if (t == 0) {
         s_nv = 0;
-    __syncthreads();
-    // rank of (word, feature) among the features with a positive weight
+        s_m = 0;
+    }
     for (int i = t; i < n; i += 512) {
-        const bool ok = weight[i] > 0;
+        const double x = weight[i];
+        s_w[i] = word[i];
+        s_x[i] = x;
         if (row_node)
-            row_node[i] = ok ? node[i] : -1;  // a feature with weight 0 is not in the FeatureVector either
-        if (!ok)
+            row_node[i] = x > 0 ? node[i] : -1;  // a feature with weight 0 is not in the FeatureVector either
+    }
+    __syncthreads();
+    // rank of (word, feature) among the features with a positive weight (LDS broadcasts)
+    for (int i = t; i < n; i += 512) {
+        if (!(s_x[i] > 0))
             continue;
-        const int wi = word[i];
+        const int wi = s_w[i];
         int r = 0;
         for (int j = 0; j < n; j++) {
-            if (!(weight[j] > 0))
-                continue;
-            const int wj = word[j];
-            r += (wj < wi || (wj == wi && j < i)) ? 1 : 0;
+            const int wj = s_w[j];
+            r += (s_x[j] > 0 && (wj < wi || (wj == wi && j < i))) ? 1 : 0;
         }
-        s_w[r] = wi;
-        s_i[r] = i;
+        s_sw[r] = wi;
+        s_sx[r] = s_x[i];
         atomicAdd(&s_nv, 1);
     }
     __syncthreads();
     const int nv = s_nv;
-    if (t == 0) {  // weights added per word in feature order, as BowVector::addWeight sees them
-        int m = -1;
-        double acc = 0;
-        for (int r = 0; r < nv; r++) {
-            const double wgt = weight[s_i[r]];
-            if (r == 0 || s_w[r] != s_w[r - 1]) {
-                if (m >= 0)
-                    row_v[m] = acc;
-                m++;
-                row_w[m] = s_w[r];
-                acc = wgt;
-            } else
-                acc += wgt;
-        }
-        if (m >= 0)
-            row_v[m] = acc;
-        m++;
+    // a thread per distinct word: its place among the distinct words, its weights added in feature order
+    // (BowVector::addWeight sees the features in that order)
+    for (int r = t; r < nv; r += 512) {
+        if (r > 0 && s_sw[r] == s_sw[r - 1])
+            continue;
+        int u = 0;
+        for (int j = 1; j <= r; j++)
+            u += s_sw[j] != s_sw[j - 1] ? 1 : 0;
+        double acc = s_sx[r];
+        for (int q = r + 1; q < nv && s_sw[q] == s_sw[r]; q++)
+            acc += s_sx[q];
+        row_w[u] = s_sw[r];
+        s_acc[u] = acc;
+        atomicAdd(&s_m, 1);
+    }
+    __syncthreads();
+    const int m = s_m;
+    if (t == 0) {  // the L1 norm in word order
         double norm = 0;
         for (int u = 0; u < m; u++)
-            norm += fabs(row_v[u]);  // the thread's own writes
+            norm += fabs(s_acc[u]);
         s_norm = norm;
-        s_m = m;
         *row_n = m;
     }
     __syncthreads();
     const double norm = s_norm;
-    if (norm > 0)
-        for (int u = t; u < s_m; u += 512)
-            row_v[u] = row_v[u] / norm;
+    for (int u = t; u < m; u += 512)
+        row_v[u] = norm > 0 ? s_acc[u] / norm : s_acc[u];
 }
 
 // ---- the database query (TemplatedDatabase::queryL1) ----
-// a thread per query word walks the word's list through the database rows and drops its term into plane[r][entry]
-__global__ __launch_bounds__(256) void bow_contrib_kernel(const int *__restrict__ qw, const double *__restrict__ qv,
-                                                          const int *__restrict__ d_nq, const int *__restrict__ head,
-                                                          const int *__restrict__ next, const double *__restrict__ db_v,
-                                                          int stride, int n_entries, double *__restrict__ plane, int pitch)
+// A wave per query word walks the word's list through the database rows and drops its terms into plane[r][entry].  The list
+// is linked newest-first; beside `next` every slot carries skip pointers to its 2nd, 4th, ... 32nd successor (written when
+// the slot is linked, bow_link_kernel), so lane l reaches the l-th element in at most six dependent loads and a list of
+// n elements costs ~6 n / 64 hops instead of n: the words every image has (long lists, small weights) no longer set the
+// kernel's duration.
+constexpr int BOW_SKIPS = 6;  // jump[slot][j] = the 2^j-th successor
+__global__ __launch_bounds__(64) void bow_contrib_kernel(const int *__restrict__ qw, const double *__restrict__ qv,
+                                                         const int *__restrict__ d_nq, const int *__restrict__ head,
+                                                         const int *__restrict__ jump, const double *__restrict__ db_v,
+                                                         int stride, int n_entries, double *__restrict__ plane, int pitch)
 {
-    const int r = blockIdx.x * 256 + threadIdx.x;
+    const int r = blockIdx.x, lane = threadIdx.x;
     if (r >= *d_nq)
         return;
     const double q = qv[r];
-    int slot = head[qw[r]];
-    while (slot >= 0) {
-        const int e = slot / stride;
-        if (e < n_entries) {
-            const double d = db_v[slot];
-            plane[(size_t)r * pitch + e] = fabs(q - d) - fabs(q) - fabs(d);
+    int base = head[qw[r]];  // element 0 of the part of the list not visited yet
+    while (base >= 0) {
+        int cur = base;
+#pragma unroll
+        for (int j = 0; j < BOW_SKIPS; j++)
+            if (((lane >> j) & 1) && cur >= 0)
+                cur = jump[(size_t)cur * BOW_SKIPS + j];
+        if (cur >= 0) {
+            const int e = cur / stride;
+            if (e < n_entries) {
+                const double d = db_v[cur];
+                plane[(size_t)r * pitch + e] = fabs(q - d) - fabs(q) - fabs(d);
+            }
         }
-        slot = next[slot];
+        const int last = __shfl(cur, 63, 64);  // element 63 of this stretch, or -1: the list has ended
+        base = last >= 0 ? jump[(size_t)last * BOW_SKIPS] : -1;
     }
 }
 
@@ -433,89 +452,142 @@ __global__ __launch_bounds__(256) void bow_sum_kernel(const double *__restrict__
         return;
     const int nq = *d_nq;
     double s = 0;
-    for (int r = 0; r < nq; r++)
+    int r = 0;
+    for (; r + 16 <= nq; r += 16) {  // sixteen loads in flight, the additions in word order
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++)
+            v[u] = plane[(size_t)(r + u) * pitch + e];
+#pragma unroll
+        for (int u = 0; u < 16; u++)
+            s += v[u];
+    }
+    for (; r < nq; r++)
         s += plane[(size_t)r * pitch + e];
     sums[e] = s;
 }
 
 // the frame's row enters the inverted file (TemplatedDatabase::add)
 __global__ __launch_bounds__(256) void bow_link_kernel(const int *__restrict__ row_w, const int *__restrict__ row_n, int slot0,
-                                                       int *__restrict__ head, int *__restrict__ next)
+                                                       int *__restrict__ head, int *__restrict__ jump)
 {
     const int u = blockIdx.x * 256 + threadIdx.x;
     if (u >= *row_n)
         return;
-    const int w = row_w[u];  // the words of a row are distinct: no two threads touch the same head
-    next[slot0 + u] = head[w];
+    const int w = row_w[u];  // the words of a row are distinct: no two threads touch the same head or list
+    const size_t s = (size_t)(slot0 + u);
+    int to = head[w];        // successor 1
+    jump[s * BOW_SKIPS] = to;
+    for (int j = 1; j < BOW_SKIPS; j++) {  // successor 2^j = the 2^(j-1)-th successor of successor 2^(j-1)
+        to = to >= 0 ? jump[(size_t)to * BOW_SKIPS + (j - 1)] : -1;
+        jump[s * BOW_SKIPS + j] = to;
+    }
     head[w] = slot0 + u;
 }
 
 // the max_db_results entries below max_id with the most negative sums (ties: the lower id), the previous entry's sum,
 // the word count -- what the host logic of detectLoop reads, into pinned memory
 __global__ __launch_bounds__(1024) void bow_topk_kernel(const double *__restrict__ sums, int max_id, int k_want,
-                                                        const int *__restrict__ row_n, int entry_id, svo_lc_bow_record *rec)
+                                                        const int *__restrict__ row_n, const int *__restrict__ d_nfeat,
+                                                        int entry_id, svo_lc_bow_record *rec)
 {
-    constexpr int PER = 8;  // 8192 entries at most
+    constexpr int PER = 8;      // 8192 entries at most
+    constexpr int LIST = 4096;  // entries with a common word that fit the rank-counting path
+    __shared__ double s_s[LIST];
+    __shared__ int s_e[LIST];
     __shared__ double s_v[16];
-    __shared__ int s_id[16];
+    __shared__ int s_id[16], s_c;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     double v[PER];
+    if (t == 0)
+        s_c = 0;
+    __syncthreads();
 #pragma unroll
     for (int u = 0; u < PER; u++) {
         const int e = u * 1024 + t;
         v[u] = e < max_id ? sums[e] : 0.;
+        if (v[u] < 0.) {  // the entry shares a word with the query
+            const int slot = atomicAdd(&s_c, 1);
+            if (slot < LIST) {
+                s_s[slot] = v[u];
+                s_e[slot] = e;
+            }
+        }
     }
+    __syncthreads();
+    const int c = s_c;
     int n_out = 0;
-    for (int round = 0; round < k_want; round++) {
-        double bv = 0.;
-        int be = 1 << 30;
-#pragma unroll
-        for (int u = 0; u < PER; u++) {
-            const int e = u * 1024 + t;
-            if (v[u] < bv || (v[u] == bv && v[u] < 0. && e < be)) {
-                bv = v[u];
-                be = e;
+    if (c <= LIST) {
+        // the usual case: few entries share a word.  Rank of an entry = how many come before it in (sum ascending, id ascending)
+        for (int a = t; a < c; a += 1024) {
+            const double sa = s_s[a];
+            const int ea = s_e[a];
+            int rank = 0;
+            for (int b = 0; b < c; b++) {
+                const double sb = s_s[b];
+                rank += (sb < sa || (sb == sa && s_e[b] < ea)) ? 1 : 0;
+            }
+            if (rank < k_want) {
+                rec->cand_id[rank] = ea;
+                rec->cand_sum[rank] = sa;
+                __threadfence_system();  // before the barrier that precedes the record's release
             }
         }
+        n_out = c < k_want ? c : k_want;
+    } else {
+        for (int round = 0; round < k_want; round++) {  // more than LIST: k_want rounds of a block-wide minimum
+            double bv = 0.;
+            int be = 1 << 30;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const double ov = __shfl_xor(bv, o, 64);
-            const int oe = __shfl_xor(be, o, 64);
-            if (ov < bv || (ov == bv && oe < be)) {
-                bv = ov;
-                be = oe;
+            for (int u = 0; u < PER; u++) {
+                const int e = u * 1024 + t;
+                if (v[u] < bv || (v[u] == bv && v[u] < 0. && e < be)) {
+                    bv = v[u];
+                    be = e;
+                }
             }
-        }
-        if (lane == 0) {
-            s_v[wave] = bv;
-            s_id[wave] = be;
-        }
-        __syncthreads();
-        bv = s_v[0];
-        be = s_id[0];
 #pragma unroll
-        for (int w = 1; w < 16; w++)
-            if (s_v[w] < bv || (s_v[w] == bv && s_id[w] < be)) {
-                bv = s_v[w];
-                be = s_id[w];
+            for (int o = 32; o > 0; o >>= 1) {
+                const double ov = __shfl_xor(bv, o, 64);
+                const int oe = __shfl_xor(be, o, 64);
+                if (ov < bv || (ov == bv && oe < be)) {
+                    bv = ov;
+                    be = oe;
+                }
             }
-        __syncthreads();
-        if (!(bv < 0.))
-            break;  // no entry with a common word is left
-        if (t == 0) {
-            rec->cand_id[n_out] = be;
-            rec->cand_sum[n_out] = bv;
-        }
-        n_out++;
-        if ((be & 1023) == t) {  // taken
+            if (lane == 0) {
+                s_v[wave] = bv;
+                s_id[wave] = be;
+            }
+            __syncthreads();
+            bv = s_v[0];
+            be = s_id[0];
 #pragma unroll
-            for (int u = 0; u < PER; u++)
-                if (u == (be >> 10))
-                    v[u] = 0.;
+            for (int w = 1; w < 16; w++)
+                if (s_v[w] < bv || (s_v[w] == bv && s_id[w] < be)) {
+                    bv = s_v[w];
+                    be = s_id[w];
+                }
+            __syncthreads();
+            if (!(bv < 0.))
+                break;  // no entry with a common word is left
+            if (t == 0) {
+                rec->cand_id[n_out] = be;
+                rec->cand_sum[n_out] = bv;
+            }
+            n_out++;
+            if ((be & 1023) == t) {  // taken
+#pragma unroll
+                for (int u = 0; u < PER; u++)
+                    if (u == (be >> 10))
+                        v[u] = 0.;
+            }
         }
     }
+    __syncthreads();
     if (t == 0) {
         rec->nq = *row_n;
+        rec->n_feat = *d_nfeat;
         rec->last_sum = entry_id > 0 ? sums[entry_id - 1] : 0.;
         rec->n_cand = n_out;
         __threadfence_system();
@@ -642,15 +714,15 @@ int svo_bow_launch_vector(hipStream_t st, const int *d_word, const double *d_wei
 
 int svo_bow_launch_query(hipStream_t st, const int *qw, const double *qv, const int *d_nq, int nf, const int *head,
                          const int *next, const double *db_v, int stride, int n_entries, double *plane, int pitch, double *sums,
-                         int max_id, int k_want, int entry_id, svo_lc_bow_record *rec)
+                         int max_id, int k_want, int entry_id, const int *d_nfeat, svo_lc_bow_record *rec)
 {
     if (n_entries > 0) {
         SVO_HIP(hipMemset2DAsync(plane, (size_t)pitch * 8, 0, (size_t)n_entries * 8, (size_t)nf, st));
-        hipLaunchKernelGGL(bow_contrib_kernel, dim3((nf + 255) / 256), dim3(256), 0, st, qw, qv, d_nq, head, next, db_v, stride,
-                           n_entries, plane, pitch);
+        hipLaunchKernelGGL(bow_contrib_kernel, dim3(nf), dim3(64), 0, st, qw, qv, d_nq, head, next, db_v, stride, n_entries, plane,
+                           pitch);
         hipLaunchKernelGGL(bow_sum_kernel, dim3((n_entries + 255) / 256), dim3(256), 0, st, plane, pitch, d_nq, n_entries, sums);
     }
-    hipLaunchKernelGGL(bow_topk_kernel, dim3(1), dim3(1024), 0, st, sums, max_id, k_want, d_nq, entry_id, rec);
+    hipLaunchKernelGGL(bow_topk_kernel, dim3(1), dim3(1024), 0, st, sums, max_id, k_want, d_nq, d_nfeat, entry_id, rec);
     SVO_HIP(hipGetLastError());
     return SVO_OK;
 }

@@ -223,6 +223,9 @@ struct svo_lc {
     int di_levels = 2;
     DevBuf bw_w, bw_v, bw_nw, bw_node, bw_head, bw_next, bw_plane, bw_sums, q_word, q_weight, q_node;
     svo_lc_bow_record *rec_bow = nullptr;    // pinned: one record per entry, filled by bow_topk_kernel
+    uint8_t *stage = nullptr;                // pinned ring for svo_lc_submit_features with host arrays
+    std::vector<hipEvent_t> stage_ev;
+    long stage_next = 0;
     // what the last collected verdict was formed from (svo_lc_collect_ex)
     std::vector<int> last_cand_id;
     std::vector<double> last_cand_score;
@@ -309,6 +312,11 @@ int svo_lc_destroy(svo_lc *l)
         (void)hipHostFree(l->rec);
     if (l->rec_bow)
         (void)hipHostFree(l->rec_bow);
+    if (l->stage)
+        (void)hipHostFree(l->stage);
+    for (hipEvent_t e : l->stage_ev)
+        if (e)
+            (void)hipEventDestroy(e);
     DevBuf *bufs[] = {&l->db_desc, &l->db_xy, &l->db_n, &l->q, &l->counts, &l->nn, &l->img, &l->bw_w, &l->bw_v, &l->bw_nw, &l->bw_node,
                       &l->bw_head, &l->bw_next, &l->bw_plane, &l->bw_sums, &l->q_word, &l->q_weight, &l->q_node};
     for (DevBuf *b : bufs)
@@ -365,7 +373,7 @@ static int lc_enqueue(svo_lc *l)
                                         row_v, row_n, row_node)) ||
             (rc = svo_bow_launch_query(st, row_w, row_v, row_n, l->nf, l->bw_head.as<int>(), l->bw_next.as<int>(),
                                        l->bw_v.as<double>(), l->nf, entry_id, l->bw_plane.as<double>(), l->capacity,
-                                       l->bw_sums.as<double>(), max_id, k_want, entry_id, l->rec_bow + entry_id)) ||
+                                       l->bw_sums.as<double>(), max_id, k_want, entry_id, q.d_n, l->rec_bow + entry_id)) ||
             (rc = svo_bow_launch_link(st, row_w, row_n, l->nf, entry_id * l->nf, l->bw_head.as<int>(), l->bw_next.as<int>())))
             return rc;
     } else if (entry_id > 0) {
@@ -434,16 +442,33 @@ int svo_lc_submit_features(svo_lc *l, const float *xy, const uint32_t *desc, int
     if (rc)
         return rc;
     const LcQuery q = lc_query(l);
-    const hipMemcpyKind kind = mem == SVO_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
     SVO_HIP(hipMemsetAsync(q.xy, 0, (size_t)l->nf * 8, st));
     SVO_HIP(hipMemsetAsync(q.desc, 0, (size_t)l->nf * 32, st));
-    if (n > 0) {
-        SVO_HIP(hipMemcpyAsync(q.xy, xy, (size_t)n * 8, kind, st));
-        SVO_HIP(hipMemcpyAsync(q.desc, desc, (size_t)n * 32, kind, st));
+    if (n > 0 && mem == SVO_MEM_DEVICE) {
+        SVO_HIP(hipMemcpyAsync(q.xy, xy, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+        SVO_HIP(hipMemcpyAsync(q.desc, desc, (size_t)n * 32, hipMemcpyDeviceToDevice, st));
+    } else if (n > 0) {
+        // host arrays go through a ring of pinned slots, so that the call returns without waiting for the stream: a slot is
+        // reused only when the copy that read it has run (its event)
+        constexpr int SLOTS = 32;
+        const size_t slot_bytes = (size_t)l->nf * 40;
+        if (!l->stage) {
+            SVO_HIP(hipHostMalloc(reinterpret_cast<void **>(&l->stage), slot_bytes * SLOTS, hipHostMallocDefault));
+            l->stage_ev.assign(SLOTS, nullptr);
+            for (hipEvent_t &e : l->stage_ev)
+                SVO_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        }
+        const int slot = l->stage_next++ % SLOTS;
+        if (l->stage_next > SLOTS)
+            SVO_HIP(hipEventSynchronize(l->stage_ev[slot]));
+        uint8_t *h = l->stage + slot_bytes * slot;
+        memcpy(h, xy, (size_t)n * 8);
+        memcpy(h + (size_t)l->nf * 8, desc, (size_t)n * 32);
+        SVO_HIP(hipMemcpyAsync(q.xy, h, (size_t)n * 8, hipMemcpyHostToDevice, st));
+        SVO_HIP(hipMemcpyAsync(q.desc, h + (size_t)l->nf * 8, (size_t)n * 32, hipMemcpyHostToDevice, st));
+        SVO_HIP(hipEventRecord(l->stage_ev[slot], st));
     }
     hipLaunchKernelGGL(lc_store_int_kernel, dim3(1), dim3(1), 0, st, q.d_n, n);  // the count travels as a kernel argument
-    if (mem == SVO_MEM_HOST)
-        SVO_HIP(hipStreamSynchronize(st));  // the caller's arrays are pageable: they are read by now
     return lc_enqueue(l);
 }
 
@@ -462,12 +487,12 @@ int svo_lc_set_vocabulary(svo_lc *l, svo_voc *voc, int di_levels)
     }
     int rc;
     if ((rc = l->bw_w.ensure(cap * nf * 4)) || (rc = l->bw_v.ensure(cap * nf * 8)) || (rc = l->bw_nw.ensure(cap * 4)) ||
-        (rc = l->bw_node.ensure(cap * nf * 4)) || (rc = l->bw_head.ensure((nw + 1) * 4)) || (rc = l->bw_next.ensure(cap * nf * 4)) ||
+        (rc = l->bw_node.ensure(cap * nf * 4)) || (rc = l->bw_head.ensure((nw + 1) * 4)) || (rc = l->bw_next.ensure(cap * nf * 4 * 6)) ||
         (rc = l->bw_plane.ensure(nf * cap * 8)) || (rc = l->bw_sums.ensure(cap * 8)) || (rc = l->q_word.ensure(nf * 4)) ||
         (rc = l->q_weight.ensure(nf * 8)) || (rc = l->q_node.ensure(nf * 4)))
         return rc;
     SVO_HIP(hipMemset(l->bw_head.p, 0xff, (nw + 1) * 4));
-    SVO_HIP(hipMemset(l->bw_next.p, 0xff, cap * nf * 4));
+    SVO_HIP(hipMemset(l->bw_next.p, 0xff, cap * nf * 4 * 6));  // six skip pointers per row slot (bow.hip: BOW_SKIPS)
     SVO_HIP(hipMemset(l->bw_sums.p, 0, cap * 8));
     if (!l->rec_bow) {
         if (hipHostMalloc(reinterpret_cast<void **>(&l->rec_bow), sizeof(svo_lc_bow_record) * cap, hipHostMallocDefault) != hipSuccess) {
@@ -520,6 +545,7 @@ int svo_lc_collect_ex(svo_lc *l, int *status, int *query, int *match, int *cand_
         for (int k = 0; k < rec.n_cand; k++)
             qret.push_back({rec.cand_id[k], -rec.cand_sum[k] / 2.0});
         ns_have = -rec.last_sum / 2.0;
+        nq = rec.n_feat;
     } else {
         const LcRecord &rec = l->rec[entry_id];
         nq = rec.nq;
@@ -535,11 +561,6 @@ int svo_lc_collect_ex(svo_lc *l, int *status, int *query, int *match, int *cand_
     const uint32_t *qdesc = l->db_desc.as<uint32_t>() + (size_t)entry_id * nf * 8;  // the query IS entry `entry_id` now
     const int *d_nq = l->db_n.as<int>() + entry_id;
     int rc;
-    if (bow) {  // the feature count of the frame (the record carries the WORD count)
-        SVO_HIP(hipMemcpyAsync(ctx->pinned, d_nq, 4, hipMemcpyDeviceToHost, st));
-        SVO_HIP(hipStreamSynchronize(st));
-        nq = *reinterpret_cast<const int *>(ctx->pinned);
-    }
     l->last_cand_id.clear();
     l->last_cand_score.clear();
     for (const Result &r : qret) {

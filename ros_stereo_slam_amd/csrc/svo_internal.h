@@ -324,7 +324,7 @@ constexpr int SVO_LC_MAX_CAND = 64;
 struct svo_lc_bow_record {  // what the host logic of detectLoop reads for one frame, in pinned memory
     int ready;       // entry id + 1 once the record is complete (released at system scope)
     int nq;          // words of the query's BowVector
-    int n_cand, pad;
+    int n_cand, n_feat;  // n_feat: features of the frame
     double last_sum;                      // raw L1 sum against entry id - 1 (the normalisation score is -last_sum / 2)
     int cand_id[SVO_LC_MAX_CAND];         // best first: sum ascending (= score descending), entry id ascending on ties
     double cand_sum[SVO_LC_MAX_CAND];
@@ -335,7 +335,7 @@ int svo_bow_launch_vector(hipStream_t st, const int *d_word, const double *d_wei
                           int *row_w, double *row_v, int *row_n, int *row_node);
 int svo_bow_launch_query(hipStream_t st, const int *qw, const double *qv, const int *d_nq, int nf, const int *head,
                          const int *next, const double *db_v, int stride, int n_entries, double *plane, int pitch, double *sums,
-                         int max_id, int k_want, int entry_id, svo_lc_bow_record *rec);
+                         int max_id, int k_want, int entry_id, const int *d_nfeat, svo_lc_bow_record *rec);
 int svo_bow_launch_link(hipStream_t st, const int *row_w, const int *row_n, int nf, int slot0, int *head, int *next);
 int svo_bow_launch_di_nearest(hipStream_t st, const uint32_t *A, const int *node_a, int na, const uint32_t *B, const int *node_b,
                               const int *d_nb, int *best_j, int *d1, int *d2);

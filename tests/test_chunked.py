@@ -233,3 +233,83 @@ def test_configs3_flow_single_process_matches_two_ranks_over_gloo():
         # the same chunks in the same order, whoever ran them: identical trajectory and solve
         assert before == pytest.approx(one[2], rel=1e-12) and after == pytest.approx(one[3], rel=1e-9)
         assert checksum == pytest.approx(float(np.abs(one[6]).sum()), rel=1e-9)
+
+
+# ---- detector-driven closures at N > 1 (VERDICT r3 missing #2): every rank extracts the features of its own frames, rank 0
+# keeps the database by global frame id -- over gloo with the ORACLE's extractor and detector (the GPU twins are compared
+# with them in tests/test_gpu_orb.py / test_gpu_bow.py) ----
+def _loop_images_small(n):
+    from ros_stereo_slam_amd import synth
+
+    size, K4 = (320, 120), (180.0, 180.0, 160.0, 60.0)
+    poses = synth.loop_trajectory(n, half_x=6, half_z=10, radius=4, step=0.5)
+    sc = synth.Scene(wall_x=14, z_min=-18, z_max=18)
+    return [sc.stereo(R, t, K=K4, size=size)[0] for R, t in poses]
+
+
+def _closures_of(feats):
+    """train the vocabulary on every second frame, run the detector over all, gate as the reference does"""
+    from oracle import orc
+    from oracle.loop_detector import LoopDetector, Params
+
+    voc = orc.Vocabulary.train([d for _, d in feats[::2]], k=9, L=4, seed=1)
+    det = LoopDetector(Params(seed=5, n_features=200), voc=voc, di_levels=2)
+    verdicts = [det.detect_features(xy, d) for xy, d in feats]
+    matches = [v["match"] if v["status"] == 0 and v["match"] >= 1 else -1 for v in verdicts]
+    return chunked.gate_closures(matches), [v["status"] for v in verdicts]
+
+
+def _detector_worker(rank, world, port, n, q):
+    import torch.distributed as dist
+
+    from oracle import orc
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        imgs = _loop_images_small(n)
+        share = (n - 1) // world
+        lo, hi = rank * share, (rank + 1) * share + (1 if rank == world - 1 else 0)   # the overlap frame is the next rank's
+        counts = [share + (1 if r == world - 1 else 0) for r in range(world)]
+        nf = 200
+        fn, fxy, fdesc = np.zeros(hi - lo, np.int32), np.zeros((hi - lo, nf, 2), np.float32), np.zeros((hi - lo, nf, 8), np.uint32)
+        for i in range(lo, hi):
+            xy, _, _, _, desc = orc.orb_extract(imgs[i], nf, 20)
+            fn[i - lo] = len(xy)
+            fxy[i - lo, :len(xy)], fdesc[i - lo, :len(xy)] = xy, desc
+        parts = chunked.gather_frame_features(dist, fn, fxy, fdesc, counts=counts)
+        if rank == 0:
+            feats = [(pxy[i, :pn[i]], pd[i, :pn[i]]) for pn, pxy, pd in parts for i in range(len(pn))]
+            q.put(("sharded", len(feats), _closures_of(feats)))
+        else:
+            assert parts is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_detector_closures_from_features_gathered_over_gloo():
+    import torch.multiprocessing as mp
+
+    from oracle import orc
+
+    n, world = 141, 2
+    imgs = _loop_images_small(n)
+    single = [(xy, desc) for xy, _, _, _, desc in (orc.orb_extract(im, 200, 20) for im in imgs)]
+    want_closures, want_status = _closures_of(single)
+    assert want_closures, "the loop must close for the test to mean something"
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_detector_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    tag, n_feats, (closures, status) = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert tag == "sharded" and n_feats == n
+    assert closures == want_closures and status == want_status        # the two-rank flow gives the one-process verdicts
