@@ -320,6 +320,95 @@ int orc_fransac_draw(const float *p1, const float *p2, int n, uint64_t seed, uin
     return draw_subset(seed, iter, n, 7, idx7, f_subset_ok, &u);
 }
 
+/* cv::findFundamentalMat below 15 correspondences (upstream fundam.cpp, recalled -- OpenCV is not in the checkout):
+ *   n == 7      the 7-point solver runs once on the seven pairs, the mask is set to all ones
+ *   8 <= n < 15 `(method & ~3) == FM_RANSAC && npoints >= 15` fails, so the call goes to the LEAST-MEDIAN estimator
+ *               (createLMeDSPointSetRegistrator(cb, 7, confidence)): RANSACUpdateNumIters(confidence, 0.45, 7, 1000)
+ *               = 300 iterations of 7-point samples; per model the MEDIAN of the float errors ((a + b) * 0.5 of the two
+ *               middle ones for an even count); the first model with the smallest median wins; then
+ *               sigma = max(2.5 * 1.4826 * (1 + 5 / (n - 7)) * sqrt(median), 0.001) and the inliers are err <= sigma^2;
+ *               the result stands if at least 7 are inliers (else the mask is cleared).
+ * The threshold argument is not used on this branch.  Reached when tracking is nearly lost -- exactly where
+ * PerspectiveNpointEstimation's 8 px retry fires (src/keyFrameManagement.cpp:85-92; call sites src/tracking.cpp:34,75). */
+static int cmp_float(const void *a, const void *b)
+{
+    const float x = *(const float *)a, y = *(const float *)b;
+    return x < y ? -1 : (x > y ? 1 : 0);
+}
+
+int orc_f_small(const float *p1, const float *p2, int n, const orc_fransac_params *prm, uint8_t *mask, double *F,
+                int *iters_run)
+{
+    const int M = 7;
+    fsub_t u = {p1, p2};
+    if (n == M) {
+        double x1[14], x2[14], Fs[27];
+        for (int k = 0; k < M; k++) {
+            x1[2 * k] = p1[2 * k];
+            x1[2 * k + 1] = p1[2 * k + 1];
+            x2[2 * k] = p2[2 * k];
+            x2[2 * k + 1] = p2[2 * k + 1];
+        }
+        const int nm = orc_seven_point(x1, x2, Fs);
+        if (iters_run)
+            *iters_run = 0;
+        if (nm <= 0)
+            return 0; /* runKernel found nothing: an empty matrix, the mask is not touched upstream (cleared here) */
+        memset(mask, 1, (size_t)n);
+        if (F)
+            memcpy(F, Fs, 9 * sizeof(double));
+        return n;
+    }
+    const int niters = update_num_iters(prm->confidence, 0.45, M, 1000);
+    double min_median = DBL_MAX, bestF[9] = {0};
+    float err[16], sorted[16];
+    int it;
+    for (it = 0; it < niters; it++) {
+        int idx[7];
+        if (!draw_subset(prm->seed, (uint32_t)it, n, M, idx, f_subset_ok, &u))
+            break;
+        double x1[14], x2[14], Fs[27];
+        for (int k = 0; k < M; k++) {
+            x1[2 * k] = p1[2 * idx[k]];
+            x1[2 * k + 1] = p1[2 * idx[k] + 1];
+            x2[2 * k] = p2[2 * idx[k]];
+            x2[2 * k + 1] = p2[2 * idx[k] + 1];
+        }
+        const int nm = orc_seven_point(x1, x2, Fs);
+        for (int m = 0; m < nm; m++) {
+            for (int i = 0; i < n; i++)
+                sorted[i] = orc_f_error(Fs + 9 * m, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]);
+            qsort(sorted, (size_t)n, sizeof(float), cmp_float);
+            const double median = (n & 1) ? (double)sorted[n / 2] : (double)(sorted[n / 2 - 1] + sorted[n / 2]) * 0.5;
+            if (median < min_median) {
+                min_median = median;
+                memcpy(bestF, Fs + 9 * m, sizeof(bestF));
+            }
+        }
+    }
+    if (iters_run)
+        *iters_run = it;
+    if (!(min_median < DBL_MAX))
+        return 0;
+    double sigma = 2.5 * 1.4826 * (1. + 5. / (n - M)) * sqrt(min_median);
+    if (sigma < 0.001)
+        sigma = 0.001;
+    const float t = (float)(sigma * sigma);
+    int count = 0;
+    for (int i = 0; i < n; i++) {
+        err[i] = orc_f_error(bestF, p1[2 * i], p1[2 * i + 1], p2[2 * i], p2[2 * i + 1]);
+        mask[i] = err[i] <= t;
+        count += mask[i];
+    }
+    if (count < M) { /* result = count >= modelPoints: no model */
+        memset(mask, 0, (size_t)n);
+        return 0;
+    }
+    if (F)
+        memcpy(F, bestF, sizeof(bestF));
+    return count;
+}
+
 int orc_fransac(const float *p1, const float *p2, int n, const orc_fransac_params *prm,
                 uint8_t *mask, double *F, int *iters_run)
 {
@@ -329,6 +418,8 @@ int orc_fransac(const float *p1, const float *p2, int n, const orc_fransac_param
         *iters_run = 0;
     if (n < M)
         return 0;
+    if (n < 15 && !prm->ransac_below_15) /* upstream: RANSAC only from 15 correspondences on */
+        return orc_f_small(p1, p2, n, prm, mask, F, iters_run);
     const float thr = (float)(prm->threshold * prm->threshold);
     int niters = prm->max_iters, best_count = 0;
     double bestF[9] = {0};

@@ -205,5 +205,5 @@ class LoopDetector:
         old = self.keys[old_entry][match_A]
         cur = np.asarray(xy, np.float32)[match_B]
         cnt, mask, F, iters = orc.fransac(old, cur, p.max_reprojection_error, p.ransac_probability,
-                                          p.max_ransac_iterations, p.seed + len(self.keys))
+                                          p.max_ransac_iterations, p.seed + len(self.keys), ransac_below_15=True)
         return cnt >= p.min_Fpoints

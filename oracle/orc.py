@@ -110,7 +110,7 @@ def grid_keypoints(rows, cols, step) -> np.ndarray:
 # ---- two-view geometry -------------------------------------------------------------------
 class FransacParams(C.Structure):
     _fields_ = [("threshold", C.c_double), ("confidence", C.c_double), ("max_iters", C.c_int),
-                ("seed", C.c_uint64)]
+                ("seed", C.c_uint64), ("ransac_below_15", C.c_int)]
 
 
 def rng_u32(seed, it, draw):
@@ -128,14 +128,34 @@ def seven_point(x1, x2):
     return F[:n].reshape(n, 3, 3)
 
 
-def fransac(p1, p2, threshold, confidence=0.99, max_iters=1000, seed=0):
+def fransac_draw(p1, p2, seed, it):
+    """the 7-sample of RANSAC iteration `it` (collinearity-checked, re-drawn) -> (ok, indices)"""
+    p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2)
+    p2 = np.ascontiguousarray(p2, np.float32).reshape(-1, 2)
+    idx = np.zeros(7, np.int32)
+    f = load().orc_fransac_draw
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint64, C.c_uint32, C.c_void_p]
+    ok = f(_p(p1), _p(p2), len(p1), seed, it, _p(idx))
+    return bool(ok), idx.copy()
+
+
+def pnp_draw(n, seed, it):
+    """the 5-sample of PnP-RANSAC iteration `it` -> (ok, indices)"""
+    idx = np.zeros(5, np.int32)
+    f = load().orc_draw_subset_plain
+    f.argtypes = [C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.c_void_p]
+    ok = f(seed, it, n, 5, _p(idx))
+    return bool(ok), idx.copy()
+
+
+def fransac(p1, p2, threshold, confidence=0.99, max_iters=1000, seed=0, ransac_below_15=False):
     p1 = np.ascontiguousarray(p1, np.float32).reshape(-1, 2)
     p2 = np.ascontiguousarray(p2, np.float32).reshape(-1, 2)
     n = len(p1)
     mask = np.zeros(n, np.uint8)
     F = np.zeros(9)
     iters = C.c_int()
-    prm = FransacParams(threshold, confidence, max_iters, seed)
+    prm = FransacParams(threshold, confidence, max_iters, seed, int(bool(ransac_below_15)))
     cnt = load().orc_fransac(_p(p1), _p(p2), n, C.byref(prm), _p(mask), _p(F), C.byref(iters))
     return cnt, mask, F.reshape(3, 3), iters.value
 

@@ -96,7 +96,12 @@ typedef struct {
     double confidence;  /* 0.99                                                           */
     int max_iters;      /* 1000                                                           */
     uint64_t seed;
+    int ransac_below_15; /* 0: cv::findFundamentalMat -- 7 pairs: the 7-point solver once, mask all ones; 8..14 pairs: the
+                          * least-median estimator (orc_f_small).  1: RANSAC at any count >= 7 (the loop detector's check,
+                          * DVision::FSolver in the reference, is a RANSAC of its own)                                    */
 } orc_fransac_params;
+int orc_f_small(const float *p1, const float *p2, int n, const orc_fransac_params *prm, uint8_t *mask, double *F,
+                int *iters_run);
 
 int orc_fransac(const float *p1, const float *p2, int n, const orc_fransac_params *prm,
                 uint8_t *mask, double *F, int *iters_run);

@@ -144,7 +144,7 @@ static int stereo_triangulate(orc_vo *v, const uint8_t *left, const uint8_t *rig
             m++;
         }
     /* FmatThresholding (src/tracking.cpp:30-43) */
-    orc_fransac_params fp = {v->prm.f_thr_stereo, 0.99, 1000, stage_seed(v, 3)};
+    orc_fransac_params fp = {v->prm.f_thr_stereo, 0.99, 1000, stage_seed(v, 3), 0};
     orc_fransac(pts, trk, m, &fp, v->mask, 0, 0);
     int k = 0;
     for (int i = 0; i < m; i++)
@@ -232,7 +232,7 @@ int orc_vo_localize(orc_vo *v, const uint8_t *left, double *R, double *t, int *n
             memcpy(r3 + 3 * m, v->ref3d + 3 * i, 12);
             m++;
         }
-    orc_fransac_params fp = {v->prm.f_thr_temporal, 0.99, 1000, stage_seed(v, 0)};
+    orc_fransac_params fp = {v->prm.f_thr_temporal, 0.99, 1000, stage_seed(v, 0), 0};
     orc_fransac(r2, t2, m, &fp, v->mask, 0, 0);
     int k = 0;
     for (int i = 0; i < m; i++) /* over the mask length (reference bug: tracking.cpp:78) */

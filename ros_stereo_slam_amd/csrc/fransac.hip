@@ -52,6 +52,8 @@ struct FrJob {
     int c_stride[3];
     int *c_count;
     const int *gate;  // optional: every wave of the job leaves at once when *gate == 0 (chain runner)
+    double *med;      // 3 doubles per iteration: the models' median errors (the least-median branch below 15 pairs)
+    int cv_small;     // 1: cv::findFundamentalMat's small-sample behaviour (7 pairs: direct; 8..14: least median)
     int gate_stride;  // 0 in the product; svo_selftest_fransac_gate: workgroup b reads gate[b * gate_stride], so that ONE
                       // launch sees the gate both open and closed -- deterministically, not by a race between streams
 };
@@ -163,15 +165,19 @@ __device__ __forceinline__ double wave_max_f64(double v)
 // was 1300 dependent LDS round trips, most of the kernel's time): every entry sees exactly the operations of
 // the sequential elimination, in its order, so the result is the same bit for bit; the null-space tail (cubic,
 // models) is lane 0's.  sA / sV / sPerm: LDS scratch (63 + 18 doubles, 9 ints).
+// identity_sample: the sample is pairs 0..6 as they stand (findFundamentalMat on exactly seven pairs: no subset is drawn)
 __device__ int fr_solve_wave(const float *__restrict__ p1, const float *__restrict__ p2, int n, uint64_t seed, int it,
-                             double *sA, double *sV, int *sPerm, double *Fk_out, int lane)
+                             double *sA, double *sV, int *sPerm, double *Fk_out, int lane, bool identity_sample = false)
 {
     if (n < M)
         return -1;
     // ---- sample: M distinct indices, degenerate samples re-drawn ----
     int idx[M];
-    bool ok = false;
+    bool ok = identity_sample;
     uint32_t draw = 0;
+#pragma unroll
+    for (int slot = 0; slot < M; slot++)
+        idx[slot] = slot;
     for (int attempt = 0; attempt < kMaxAttempts && !ok; attempt++) {
         int guard = 0;
         bool filled = true;
@@ -373,13 +379,150 @@ __device__ __forceinline__ float f_error(const double (&F)[9], float x1, float y
     return (float)(e1 > e2 ? e1 : e2);
 }
 
+// cv::findFundamentalMat below 15 pairs (oracle/geometry.c: orc_f_small has the statement and its source): seven pairs -- the
+// 7-point solver once, the mask all ones; 8 .. 14 -- the least-median estimator: 300 iterations of 7-point samples
+// (RANSACUpdateNumIters(confidence, 0.45, 7, 1000)), per model the median of the float errors, the first model with the
+// smallest median wins, sigma = max(2.5 * 1.4826 * (1 + 5 / (n - 7)) * sqrt(median), 0.001), inliers err <= sigma^2, the
+// result stands with at least seven.  Runs in the LAST launch of a call: every workgroup takes the iterations
+// blockIdx.x, + gridDim.x, ... (wave 0 solves and takes the medians: n <= 14 lanes), the workgroup with the last ticket
+// replays them in order and writes mask, model, counts and the compaction.  The threshold argument plays no part.
+template <int NW>
+__device__ void fr_small_case(const FrJob &job, int n, bool due, double *sA, double *sV, int *sPerm, double *sF, int *s_last,
+                              int *s_all_due)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float2 *__restrict__ p1 = reinterpret_cast<const float2 *>(job.p1);
+    const float2 *__restrict__ p2 = reinterpret_cast<const float2 *>(job.p2);
+    const int niters = n == M ? 1 : update_num_iters(job.confidence, 0.45, M, 1000);
+    float2 a1 = {0.f, 0.f}, a2 = {0.f, 0.f};
+    if (lane < n) {
+        a1 = p1[lane];
+        a2 = p2[lane];
+    }
+    if (due && wave == 0)
+        for (int it = blockIdx.x; it < niters; it += gridDim.x) {
+            const int nm0 = fr_solve_wave(job.p1, job.p2, n, job.seed, it, sA, sV, sPerm, sF, lane, n == M);
+            const int nm = __builtin_amdgcn_readfirstlane(nm0);
+            wave_lds_fence();  // lane 0's models, read by every lane below
+            for (int k = 0; k < 3; k++) {
+                if (k >= nm)
+                    break;
+                double F[9];
+#pragma unroll
+                for (int i = 0; i < 9; i++)
+                    F[i] = sF[k * 9 + i];
+                const float e = lane < n ? f_error(F, a1.x, a1.y, a2.x, a2.y) : 0.f;
+                int rank = 0;  // place of this lane's error among the n (ties in lane order)
+                for (int j = 0; j < n; j++) {
+                    const float ej = __shfl(e, j, 64);
+                    rank += (lane < n && (ej < e || (ej == e && j < lane))) ? 1 : 0;
+                }
+                const int hi = __ffsll((unsigned long long)__ballot(lane < n && rank == n / 2)) - 1;
+                const int lo = __ffsll((unsigned long long)__ballot(lane < n && rank == n / 2 - 1)) - 1;
+                const float eh = __shfl(e, hi, 64), el = __shfl(e, lo < 0 ? hi : lo, 64);
+                const double median = (n & 1) ? (double)eh : (double)(el + eh) * 0.5;
+                if (lane == 0) {
+                    job.med[it * 3 + k] = median;
+                    for (int i = 0; i < 9; i++)
+                        job.Fm[((size_t)it * 3 + k) * 9 + i] = sF[k * 9 + i];
+                }
+            }
+            if (lane == 0)
+                job.nmodels[it] = nm;
+            wave_lds_fence();  // sF is rewritten by the next iteration
+        }
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned t = atomicAdd(job.ticket, due ? 1u : 0x10001u);
+        *s_last = (t & 0xffffu) == gridDim.x - 1;
+        *s_all_due = due && (t >> 16) == 0;
+    }
+    __syncthreads();
+    if (!*s_last)
+        return;
+    if (threadIdx.x == 0)
+        *job.ticket = 0;
+    if (!*s_all_due || wave != 0)
+        return;
+    __shared__ double s_best[12];
+    if (lane == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        double best = 1.7976931348623157e308;
+        int bi = -1, bk = 0, it = 0;
+        for (; it < niters; it++) {
+            const int nm = job.nmodels[it];
+            if (nm < 0)
+                break;  // getSubset failed: the loop stops
+            for (int k = 0; k < nm; k++)
+                if (job.med[it * 3 + k] < best) {
+                    best = job.med[it * 3 + k];
+                    bi = it;
+                    bk = k;
+                }
+        }
+        s_best[9] = bi >= 0 ? 1. : 0.;
+        s_best[10] = best;
+        s_best[11] = (double)(n == M ? 0 : it);
+        for (int i = 0; i < 9; i++)
+            s_best[i] = bi >= 0 ? job.Fm[((size_t)bi * 3 + bk) * 9 + i] : 0.;
+    }
+    wave_lds_fence();
+    const bool have = s_best[9] != 0.;
+    double F[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+        F[i] = s_best[i];
+    bool keep = false;
+    if (have && lane < n) {
+        if (n == M)
+            keep = true;  // seven pairs: the mask is all ones
+        else {
+            double sigma = 2.5 * 1.4826 * (1. + 5. / (n - M)) * sqrt(s_best[10]);
+            sigma = sigma < 0.001 ? 0.001 : sigma;
+            keep = f_error(F, a1.x, a1.y, a2.x, a2.y) <= (float)(sigma * sigma);
+        }
+    }
+    unsigned long long bal = __ballot(keep);
+    int count = __popcll(bal);
+    if (count < M) {  // result = count >= modelPoints: no model
+        keep = false;
+        bal = 0;
+        count = 0;
+    }
+    for (int i = lane; i < job.n_host; i += 64)  // the capacity of the mask
+        job.mask[i] = (i == lane && keep) ? 1 : 0;
+    if (job.c_in[0] && keep) {  // the compaction by the fresh mask, order kept
+        const int pos = __popcll(bal & ((1ull << lane) - 1ull));
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+            if (job.c_in[r]) {
+                const int stn = job.c_stride[r];
+                for (int k = 0; k < stn; k++)
+                    job.c_out[r][(size_t)pos * stn + k] = job.c_in[r][(size_t)lane * stn + k];
+            }
+    }
+    if (lane == 0) {
+        if (job.c_in[0] && job.c_count)
+            *job.c_count = count;
+        if (job.out_count)
+            *job.out_count = count;
+        if (job.out_iters)
+            *job.out_iters = (int)s_best[11];
+        if (job.Fbest)
+            for (int k = 0; k < 9; k++)
+                job.Fbest[k] = count > 0 ? F[k] : 0.;
+    }
+}
+
 // One phase of the RANSAC loop: iterations [it0, min(it1_cap, max_iters)), one wave per iteration (see the
 // file header).  `final_phase`: no launch follows, so the last wave finishes the problem whatever the state.
 // LEAN: the lock-step groups -- single-wave workgroups capped at 96 VGPRs (with spills), so that a wave starts beside
 // four tracking waves of another context on its SIMD.  !LEAN: a lone problem has the chip to itself, its 64
 // iterations would leave 15 of 16 SIMDs idle: FOUR waves per iteration (wave 0 solves, all four share the scoring
 // pass, and the finishing workgroup's four waves share the mask / compaction pass), 128-VGPR build.
-template <bool LEAN>
+// TAIL: the instantiation the LAST launch of a call uses.  It also carries cv::findFundamentalMat's behaviour below 15
+// pairs (fr_small_case), so that the kernel of the first 64 iterations -- the one on every frame's path -- stays as it was.
+template <bool LEAN, bool TAIL>
 __global__ __launch_bounds__(LEAN ? 64 : 256, LEAN ? 5 : 4) void fr_ransac_kernel(FrBatchN<LEAN ? SVO_LK_MAX_JOBS : 1> batch, int it0, int it1_cap,
                                                                                    int final_phase)
 {
@@ -414,9 +557,14 @@ __global__ __launch_bounds__(LEAN ? 64 : 256, LEAN ? 5 : 4) void fr_ransac_kerne
     constexpr int STEP = 256 * NW;
     __shared__ double sA[63], sV[18], sF[27];
     __shared__ int sPerm[9], s_nm, s_cnt[NW][3], s_last, s_all_due;
+    const int n = d_n ? min(*d_n, n_host) : n_host;  // a live count never exceeds the capacity the buffers were sized for
+    if (job.cv_small && n >= M && n < 15) {  // findFundamentalMat below 15 pairs is not a RANSAC (the same n in every workgroup)
+        if (TAIL)
+            fr_small_case<NW>(job, n, due, sA, sV, sPerm, sF, &s_last, &s_all_due);
+        return;
+    }
     if (it0 > 0 && st->done)  // the loop ended in an earlier phase (the same answer in every wave of the launch)
         return;
-    const int n = d_n ? min(*d_n, n_host) : n_host;  // a live count never exceeds the capacity the buffers were sized for
     const bool vec_ok = ((reinterpret_cast<uintptr_t>(p1) | reinterpret_cast<uintptr_t>(p2)) & 15) == 0;
     for (int it = it0 + (int)blockIdx.x; due && it < it1; it += gridDim.x) {
         if (wave == 0) {
@@ -612,7 +760,8 @@ int svo_launch_fransac_batch(svo_ctx *ctx, int n_jobs, const svo_fransac_job *jo
         it_max = mi > it_max ? mi : it_max;
         cap_max = jobs[k].cap > cap_max ? jobs[k].cap : cap_max;
     }
-    const size_t f_stride = (size_t)it_max * 27, i_stride = ((size_t)it_max * 4 + 32 + 15) / 16 * 16;
+    const int it_ws = it_max < 304 ? 304 : it_max;  // the least-median branch runs 300 iterations whatever max_iters says
+    const size_t f_stride = (size_t)it_ws * 30, i_stride = ((size_t)it_ws * 4 + 32 + 15) / 16 * 16;
     int rc;
     if ((rc = ctx->w_a.ensure(f_stride * sizeof(double) * n_jobs)) || (rc = ctx->w_b.ensure(i_stride * sizeof(int) * n_jobs)))
         return rc;
@@ -635,8 +784,10 @@ int svo_launch_fransac_batch(svo_ctx *ctx, int n_jobs, const svo_fransac_job *jo
         j.thr = (float)(h.threshold * h.threshold);
         j.st = reinterpret_cast<RansacState *>(ib);
         j.nmodels = ib + 16;
-        j.counts = j.nmodels + mi;
+        j.counts = j.nmodels + it_ws;
         j.Fm = ctx->w_a.as<double>() + f_stride * nb;
+        j.med = j.Fm + (size_t)it_ws * 27;
+        j.cv_small = h.cv_small ? 1 : 0;
         j.ticket = ctx->d_tickets + nb;  // slots 0..15 (16..31: pnp.hip)
         j.mask = h.mask;
         j.Fbest = h.d_F;
@@ -659,30 +810,43 @@ int svo_launch_fransac_batch(svo_ctx *ctx, int n_jobs, const svo_fransac_job *jo
         batch.j[k] = batch.j[0];
     ScopedKernelTime tm(ctx, SVO_K_FRANSAC);
     const int bounds[3] = {0, it_max < PHASE_A ? it_max : PHASE_A, it_max};
-    for (int ph = 0; ph < 2; ph++) {
-        const int it0 = bounds[ph], it1 = bounds[ph + 1];
-        if (it1 <= it0)
-            continue;
-        const int iters = it1 - it0;
-        if (nb > 1)
-            hipLaunchKernelGGL(fr_ransac_kernel<true>, dim3(iters < PHASE_WAVES ? iters : PHASE_WAVES, nb), dim3(64), 0,
-                               ctx->stream, batch, it0, it1, it1 >= it_max ? 1 : 0);
-        else {
-            FrBatchN<1> one;
-            one.j[0] = batch.j[0];
-            hipLaunchKernelGGL(fr_ransac_kernel<false>, dim3(iters < PHASE_WAVES ? iters : PHASE_WAVES, nb), dim3(256), 0,
-                               ctx->stream, one, it0, it1, it1 >= it_max ? 1 : 0);
+    bool any_small = false;
+    for (int k = 0; k < nb; k++)
+        any_small |= batch.j[k].cv_small != 0;
+    FrBatchN<1> one;
+    one.j[0] = batch.j[0];
+    auto launch = [&](int it0, int it1, int waves, bool tail) {
+        const int fin = it1 >= it_max ? 1 : 0;
+        if (nb > 1) {
+            if (tail)
+                hipLaunchKernelGGL((fr_ransac_kernel<true, true>), dim3(waves, nb), dim3(64), 0, ctx->stream, batch, it0, it1, fin);
+            else
+                hipLaunchKernelGGL((fr_ransac_kernel<true, false>), dim3(waves, nb), dim3(64), 0, ctx->stream, batch, it0, it1, fin);
+        } else {
+            if (tail)
+                hipLaunchKernelGGL((fr_ransac_kernel<false, true>), dim3(waves, nb), dim3(256), 0, ctx->stream, one, it0, it1, fin);
+            else
+                hipLaunchKernelGGL((fr_ransac_kernel<false, false>), dim3(waves, nb), dim3(256), 0, ctx->stream, one, it0, it1, fin);
         }
-    }
+    };
+    // two phases (iterations 0..63, 64..max); the LAST launch of the call is the TAIL instantiation, which also carries the
+    // small-sample branch.  A call of at most 64 iterations whose jobs want that branch gets an (empty) tail launch for it.
+    const bool two = bounds[2] > bounds[1];
+    launch(bounds[0], bounds[1], bounds[1] - bounds[0] < PHASE_WAVES ? bounds[1] - bounds[0] : PHASE_WAVES, !two && !any_small);
+    if (two)
+        launch(bounds[1], bounds[2], bounds[2] - bounds[1] < PHASE_WAVES ? bounds[2] - bounds[1] : PHASE_WAVES, true);
+    else if (any_small)
+        launch(bounds[2], bounds[2], PHASE_WAVES, true);
     SVO_HIP(hipGetLastError());
     return SVO_OK;
 }
 
 int svo_launch_fransac(svo_ctx *ctx, const float *p1, const float *p2, int cap, const int *d_n,
                        double threshold, double confidence, int max_iters, uint64_t seed, uint8_t *mask,
-                       double *d_F, int *d_count, int *d_iters, const svo_compact_job *then_compact)
+                       double *d_F, int *d_count, int *d_iters, const svo_compact_job *then_compact, bool cv_small)
 {
     svo_fransac_job j;
+    j.cv_small = cv_small;
     j.then_compact = then_compact;
     j.p1 = p1;
     j.p2 = p2;
@@ -744,6 +908,13 @@ extern "C" int svo_fransac(svo_ctx *ctx, const float *p1, const float *p2, int n
                            double confidence, int max_iters, uint64_t seed, uint8_t *mask, double *F9,
                            int *inlier_count, int *iters_run, int mem)
 {
+    return svo_fransac_ex(ctx, p1, p2, n, threshold, confidence, max_iters, seed, mask, F9, inlier_count, iters_run, mem, true);
+}
+
+// cv_small = false: a RANSAC at any count >= 7 (the loop detector's geometric check)
+int svo_fransac_ex(svo_ctx *ctx, const float *p1, const float *p2, int n, double threshold, double confidence, int max_iters,
+                   uint64_t seed, uint8_t *mask, double *F9, int *inlier_count, int *iters_run, int mem, bool cv_small)
+{
     SVO_CHECK_ARG(ctx && n >= 0 && threshold > 0 && max_iters > 0);
     SVO_CHECK_ARG(mem == SVO_MEM_HOST || mem == SVO_MEM_DEVICE);
     if (n == 0) {
@@ -758,7 +929,7 @@ extern "C" int svo_fransac(svo_ctx *ctx, const float *p1, const float *p2, int n
     SVO_CHECK_ARG(p1 && p2 && mask);
     if (mem == SVO_MEM_DEVICE)
         return svo_launch_fransac(ctx, p1, p2, n, nullptr, threshold, confidence, max_iters, seed, mask, F9,
-                                  inlier_count, iters_run);
+                                  inlier_count, iters_run, nullptr, cv_small);
     int rc;
     if ((rc = ctx->s_a.ensure((size_t)n * 8)) || (rc = ctx->s_b.ensure((size_t)n * 8)) ||
         (rc = ctx->s_c.ensure((size_t)n)) || (rc = ctx->s_d.ensure(256)))
@@ -768,7 +939,7 @@ extern "C" int svo_fransac(svo_ctx *ctx, const float *p1, const float *p2, int n
     double *dF = ctx->s_d.as<double>();
     int *dcnt = reinterpret_cast<int *>(dF + 9), *dit = dcnt + 1;
     rc = svo_launch_fransac(ctx, ctx->s_a.as<float>(), ctx->s_b.as<float>(), n, nullptr, threshold, confidence,
-                            max_iters, seed, ctx->s_c.as<uint8_t>(), dF, dcnt, dit);
+                            max_iters, seed, ctx->s_c.as<uint8_t>(), dF, dcnt, dit, nullptr, cv_small);
     if (rc)
         return rc;
     SVO_HIP(hipMemcpyAsync(mask, ctx->s_c.p, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));

@@ -712,10 +712,12 @@ int svo_lc_collect_ex(svo_lc *l, int *status, int *query, int *match, int *cand_
                                     }
                                     std::vector<uint8_t> mask(mA.size());
                                     int cnt = 0;
-                                    rc = svo_fransac(ctx, po.data(), pc.data(), (int)mA.size(), p.max_reprojection_error,
-                                                     p.ransac_probability, p.max_ransac_iterations,
-                                                     p.seed + (uint64_t)entry_id, mask.data(), nullptr, &cnt, nullptr,
-                                                     SVO_MEM_HOST);
+                                    // (DVision::FSolver::checkFundamentalMat is a RANSAC at any count: not findFundamentalMat's
+                                    // least-median branch below 15 pairs)
+                                    rc = svo_fransac_ex(ctx, po.data(), pc.data(), (int)mA.size(), p.max_reprojection_error,
+                                                        p.ransac_probability, p.max_ransac_iterations,
+                                                        p.seed + (uint64_t)entry_id, mask.data(), nullptr, &cnt, nullptr,
+                                                        SVO_MEM_HOST, false);
                                     if (rc)
                                         return rc;
                                     detection = cnt >= p.min_Fpoints;

@@ -225,11 +225,17 @@ struct svo_fransac_job {  // host-side description of one F-matrix RANSAC proble
     const svo_compact_job *then_compact = nullptr;
     const int *gate = nullptr;  // optional: every wave leaves at once when *gate == 0
     int gate_stride = 0;        // diagnostics only (svo_selftest_fransac_gate): workgroup b reads gate[b * gate_stride]
+    // cv::findFundamentalMat's behaviour below 15 pairs (7: the solver once, mask all ones; 8..14: least median).  Off for the
+    // loop detector's geometric check, whose upstream (DVision::FSolver) is a RANSAC at any count.
+    bool cv_small = true;
 };
 int svo_launch_fransac_batch(svo_ctx *ctx, int n_jobs, const svo_fransac_job *jobs);
 int svo_launch_fransac(svo_ctx *ctx, const float *p1, const float *p2, int cap, const int *d_n,
                        double threshold, double confidence, int max_iters, uint64_t seed, uint8_t *mask,
-                       double *d_F, int *d_count, int *d_iters, const svo_compact_job *then_compact = nullptr);
+                       double *d_F, int *d_count, int *d_iters, const svo_compact_job *then_compact = nullptr,
+                       bool cv_small = true);
+int svo_fransac_ex(svo_ctx *ctx, const float *p1, const float *p2, int n, double threshold, double confidence, int max_iters,
+                   uint64_t seed, uint8_t *mask, double *F9, int *inlier_count, int *iters_run, int mem, bool cv_small);
 // geometry.hip
 int svo_launch_triangulate(svo_ctx *ctx, const double *P1, const double *P2, const float *x1, const float *x2,
                            int cap, const int *d_n, float *out_xyz, float *out_h, const double *Rt,

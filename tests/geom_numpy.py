@@ -1,0 +1,255 @@
+"""BLIND restatements of the two geometric solvers, written from SURVEY.md appendix A.2 / A.4 and the published algorithms
+ALONE -- not from oracle/geometry.c, oracle/pnp.c or the HIP kernels (what tests/lk_numpy.py is for LK):
+
+  * cv::findFundamentalMat(FM_RANSAC): the 7-point solver as upstream does it -- null space of the 7 x 9 epipolar system by
+    SVD, det(lambda F1 + (1 - lambda) F2) = 0 as a cubic solved by numpy.roots, up to three real models -- the error
+    max(d1^2, d2^2) rounded to float, and the SEQUENTIAL loop (first-best-wins, adaptive bound log(1 - conf) /
+    log(1 - w^7)).  Below 15 pairs the least-median estimator.  The loop is fed the oracle's index samples (the one
+    stated deviation they share: counter-based draws), so the comparison isolates the solver + the loop.
+  * cv::solvePnPRansac: EPnP (Lepetit, Moreno-Noguer, Fua, IJCV 2009) on 5-point samples -- control points from the PCA of
+    the object points, barycentric coordinates, the 12 x 12 M^T M by numpy.linalg.eigh, betas from the N = 1, 2, 3
+    linearisations by least squares + Gauss-Newton, pose by Procrustes (SVD), the smallest reprojection error wins --, the
+    inlier test, the sequential loop, and the final Levenberg-Marquardt over (rvec, tvec) THROUGH Rodrigues on the inliers
+    (scipy.optimize.least_squares, method "lm").
+Where these disagree with the oracle is the band of doubt of "parity"; tests/test_solvers_independent.py states it."""
+import numpy as np
+from scipy.optimize import least_squares
+from scipy.spatial.transform import Rotation as Rot
+
+
+# ---------------------------------------------------------------------------------------------- fundamental matrix
+def seven_point(x1, x2):
+    """7 pairs -> up to 3 fundamental matrices (x2^T F x1 = 0), unit Frobenius norm."""
+    x1, x2 = np.asarray(x1, np.float64), np.asarray(x2, np.float64)
+    A = np.stack([x2[:, 0] * x1[:, 0], x2[:, 0] * x1[:, 1], x2[:, 0], x2[:, 1] * x1[:, 0], x2[:, 1] * x1[:, 1], x2[:, 1],
+                  x1[:, 0], x1[:, 1], np.ones(7)], axis=1)
+    _, _, vt = np.linalg.svd(A)
+    F1, F2 = vt[-1].reshape(3, 3), vt[-2].reshape(3, 3)
+    # det(l F1 + (1 - l) F2) is a cubic in l: sample it at four points and interpolate exactly
+    ls = np.array([-1.0, 0.0, 1.0, 2.0])
+    dets = [np.linalg.det(l * F1 + (1 - l) * F2) for l in ls]
+    coef = np.polyfit(ls, dets, 3)
+    out = []
+    for r in np.roots(coef):
+        if abs(r.imag) > 1e-9 * max(1.0, abs(r.real)):
+            continue
+        F = r.real * F1 + (1 - r.real) * F2
+        nrm = np.linalg.norm(F)
+        if nrm > 0 and np.isfinite(nrm):
+            out.append(F / nrm)
+    return out
+
+
+def f_error(F, p1, p2):
+    """FMEstimatorCallback::computeError: max of the two squared point-to-epipolar-line distances, float."""
+    p1, p2 = np.asarray(p1, np.float32).astype(np.float64), np.asarray(p2, np.float32).astype(np.float64)
+    h1 = np.c_[p1, np.ones(len(p1))]
+    h2 = np.c_[p2, np.ones(len(p2))]
+    l2 = h1 @ F.T          # F x1: line in image 2
+    l1 = h2 @ F            # F^T x2: line in image 1
+    d2 = np.sum(l2 * h2, axis=1) ** 2 / (l2[:, 0] ** 2 + l2[:, 1] ** 2)
+    d1 = np.sum(l1 * h1, axis=1) ** 2 / (l1[:, 0] ** 2 + l1[:, 1] ** 2)
+    return np.maximum(d1, d2).astype(np.float32)
+
+
+def update_num_iters(p, ep, model_points, max_iters):
+    p, ep = min(max(p, 0.0), 1.0), min(max(ep, 0.0), 1.0)
+    num = max(1.0 - p, np.finfo(np.float64).tiny)
+    denom = 1.0 - (1.0 - ep) ** model_points
+    if denom < np.finfo(np.float64).tiny:
+        return 0
+    num, denom = np.log(num), np.log(denom)
+    return max_iters if denom >= 0 or -num >= max_iters * (-denom) else int(np.rint(num / denom))
+
+
+def fransac_replay(p1, p2, samples, thr, conf=0.99, max_iters=1000):
+    """The sequential RANSAC loop over given 7-samples (None = the draw failed: the loop stops).
+    -> (inlier count, mask, F, iterations run)"""
+    p1, p2 = np.asarray(p1, np.float32), np.asarray(p2, np.float32)
+    n = len(p1)
+    t = np.float32(thr * thr)
+    niters, best, bestF, it = max_iters, 0, None, 0
+    while it < niters:
+        if it >= len(samples) or samples[it] is None:
+            break
+        idx = samples[it]
+        for F in seven_point(p1[idx], p2[idx]):
+            c = int(np.sum(f_error(F, p1, p2) <= t))
+            if c > max(best, 6):
+                best, bestF = c, F
+                niters = update_num_iters(conf, (n - c) / n, 7, niters)
+        it += 1
+    if bestF is None:
+        return 0, np.zeros(n, np.uint8), None, it
+    mask = (f_error(bestF, p1, p2) <= t).astype(np.uint8)
+    return best, mask, bestF, it
+
+
+def lmeds_replay(p1, p2, samples, conf=0.99):
+    """findFundamentalMat on 8..14 pairs: the least-median estimator over given samples."""
+    p1, p2 = np.asarray(p1, np.float32), np.asarray(p2, np.float32)
+    n = len(p1)
+    niters = update_num_iters(conf, 0.45, 7, 1000)
+    best, bestF = np.inf, None
+    for it in range(niters):
+        if it >= len(samples) or samples[it] is None:
+            break
+        for F in seven_point(p1[samples[it]], p2[samples[it]]):
+            e = np.sort(f_error(F, p1, p2))
+            med = float(e[n // 2]) if n % 2 else float(np.float32(e[n // 2 - 1] + e[n // 2])) * 0.5
+            if med < best:
+                best, bestF = med, F
+    if bestF is None:
+        return 0, np.zeros(n, np.uint8), None
+    sigma = max(2.5 * 1.4826 * (1 + 5.0 / (n - 7)) * np.sqrt(best), 0.001)
+    mask = (f_error(bestF, p1, p2) <= np.float32(sigma * sigma)).astype(np.uint8)
+    if mask.sum() < 7:
+        return 0, np.zeros(n, np.uint8), None
+    return int(mask.sum()), mask, bestF
+
+
+# ---------------------------------------------------------------------------------------------------------- EPnP
+def _procrustes(pw, pc):
+    """R, t with pc ~ R pw + t (Horn / Umeyama without scale)."""
+    cw, cc = pw.mean(0), pc.mean(0)
+    H = (pc - cc).T @ (pw - cw)
+    U, _, Vt = np.linalg.svd(H)
+    R = U @ Vt
+    if np.linalg.det(R) < 0:
+        U[:, 2] *= -1
+        R = U @ Vt
+    return R, cc - R @ cw
+
+
+def epnp(obj, img, K4):
+    """EPnP on n >= 4 points -> (R, t) of the candidate (N = 1, 2, 3) with the smallest mean reprojection error."""
+    fx, fy, cx, cy = K4
+    pw = np.asarray(obj, np.float64)
+    uv = np.asarray(img, np.float64)
+    n = len(pw)
+    # control points: the centroid and the principal directions scaled by sqrt(eigenvalue / n)
+    c0 = pw.mean(0)
+    q = pw - c0
+    w, V = np.linalg.eigh(q.T @ q)
+    cws = np.vstack([c0] + [c0 + np.sqrt(max(w[i], 0) / n) * V[:, i] for i in range(3)])
+    # barycentric coordinates
+    C = (cws[1:] - cws[0]).T
+    al = np.linalg.solve(C, (pw - cws[0]).T).T
+    alphas = np.c_[1 - al.sum(1), al]
+    M = np.zeros((2 * n, 12))
+    for i in range(n):
+        for j in range(4):
+            M[2 * i, 3 * j:3 * j + 3] = [alphas[i, j] * fx, 0, alphas[i, j] * (cx - uv[i, 0])]
+            M[2 * i + 1, 3 * j:3 * j + 3] = [0, alphas[i, j] * fy, alphas[i, j] * (cy - uv[i, 1])]
+    ew, ev = np.linalg.eigh(M.T @ M)
+    v = [ev[:, k] for k in range(4)]                           # the four smallest
+    pairs = [(0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3)]
+    rho = np.array([np.sum((cws[a] - cws[b]) ** 2) for a, b in pairs])
+    dv = [[v[k][3 * a:3 * a + 3] - v[k][3 * b:3 * b + 3] for a, b in pairs] for k in range(4)]
+    # L (6 x 10): coefficients of b11 b12 b22 b13 b23 b33 b14 b24 b34 b44
+    L = np.zeros((6, 10))
+    for r in range(6):
+        d = [dv[k][r] for k in range(4)]
+        L[r] = [d[0] @ d[0], 2 * d[0] @ d[1], d[1] @ d[1], 2 * d[0] @ d[2], 2 * d[1] @ d[2], d[2] @ d[2],
+                2 * d[0] @ d[3], 2 * d[1] @ d[3], 2 * d[2] @ d[3], d[3] @ d[3]]
+
+    def ccs_of(b):
+        return sum(b[k] * v[k] for k in range(4)).reshape(4, 3)
+
+    def gauss_newton(b):
+        b = np.array(b, np.float64)
+        for _ in range(5):
+            bb = np.array([b[0] * b[0], b[0] * b[1], b[1] * b[1], b[0] * b[2], b[1] * b[2], b[2] * b[2], b[0] * b[3],
+                           b[1] * b[3], b[2] * b[3], b[3] * b[3]])
+            res = rho - L @ bb
+            J = np.stack([2 * L[:, 0] * b[0] + L[:, 1] * b[1] + L[:, 3] * b[2] + L[:, 6] * b[3],
+                          L[:, 1] * b[0] + 2 * L[:, 2] * b[1] + L[:, 4] * b[2] + L[:, 7] * b[3],
+                          L[:, 3] * b[0] + L[:, 4] * b[1] + 2 * L[:, 5] * b[2] + L[:, 8] * b[3],
+                          L[:, 6] * b[0] + L[:, 7] * b[1] + L[:, 8] * b[2] + 2 * L[:, 9] * b[3]], axis=1)
+            b = b + np.linalg.lstsq(J, res, rcond=None)[0]
+        return b
+
+    cands = []
+    # N = 1 (the paper's "approx 1": unknowns b11 b12 b13 b14), N = 2 (b11 b12 b22), N = 3 (b11 b12 b22 b13 b23)
+    x = np.linalg.lstsq(L[:, [0, 1, 3, 6]], rho, rcond=None)[0]
+    b = np.zeros(4)
+    if x[0] < 0:
+        x = -x
+    b[0] = np.sqrt(x[0])
+    b[1:] = x[1:] / b[0] if b[0] != 0 else 0
+    cands.append(b)
+    x = np.linalg.lstsq(L[:, [0, 1, 2]], rho, rcond=None)[0]
+    b = np.zeros(4)
+    if x[0] < 0:
+        b[0], b[1] = np.sqrt(-x[0]), np.sqrt(-x[2]) if x[2] < 0 else 0.0
+    else:
+        b[0], b[1] = np.sqrt(x[0]), np.sqrt(x[2]) if x[2] > 0 else 0.0
+    if x[1] < 0:
+        b[0] = -b[0]
+    cands.append(b)
+    x = np.linalg.lstsq(L[:, [0, 1, 2, 3, 4]], rho, rcond=None)[0]
+    b = np.zeros(4)
+    if x[0] < 0:
+        b[0], b[1] = np.sqrt(-x[0]), np.sqrt(-x[2]) if x[2] < 0 else 0.0
+    else:
+        b[0], b[1] = np.sqrt(x[0]), np.sqrt(x[2]) if x[2] > 0 else 0.0
+    if x[1] < 0:
+        b[0] = -b[0]
+    b[2] = x[3] / b[0] if b[0] != 0 else 0.0
+    cands.append(b)
+    best = None
+    for b0 in cands:
+        b = gauss_newton(b0)
+        ccs = ccs_of(b)
+        pc = alphas @ ccs
+        if pc[0, 2] < 0:
+            pc = -pc
+        R, t = _procrustes(pw, pc)
+        Xc = pw @ R.T + t
+        err = np.mean(np.hypot(cx + fx * Xc[:, 0] / Xc[:, 2] - uv[:, 0], cy + fy * Xc[:, 1] / Xc[:, 2] - uv[:, 1]))
+        if np.isfinite(err) and (best is None or err < best[0]):
+            best = (err, R, t)
+    return (best[1], best[2]) if best else (None, None)
+
+
+def reproj_err_sq(R, t, K4, obj, img):
+    fx, fy, cx, cy = K4
+    Xc = np.asarray(obj, np.float64) @ R.T + t
+    z = np.where(Xc[:, 2] != 0, 1.0 / np.where(Xc[:, 2] != 0, Xc[:, 2], 1.0), 1.0)
+    du = cx + fx * Xc[:, 0] * z - np.asarray(img, np.float64)[:, 0]
+    dv = cy + fy * Xc[:, 1] * z - np.asarray(img, np.float64)[:, 1]
+    return (du * du + dv * dv).astype(np.float32)
+
+
+def pnp_ransac_replay(obj, img, K4, samples, thr=1.0, conf=0.99, iterations=100, refine=True):
+    """solvePnPRansac over given 5-samples -> (inlier indices, rvec, tvec, iterations run)."""
+    obj, img = np.asarray(obj, np.float32), np.asarray(img, np.float32)
+    n = len(obj)
+    t2 = np.float32(thr * thr)
+    niters, best, bestRt, it = iterations, 0, None, 0
+    while it < niters:
+        if it >= len(samples) or samples[it] is None:
+            break
+        R, t = epnp(obj[samples[it]], img[samples[it]], K4)
+        if R is not None:
+            c = int(np.sum(reproj_err_sq(R, t, K4, obj, img) <= t2))
+            if c > max(best, 4):
+                best, bestRt = c, (R, t)
+                niters = update_num_iters(conf, (n - c) / n, 5, niters)
+        it += 1
+    if bestRt is None:
+        return np.zeros(0, int), None, None, it
+    R, t = bestRt
+    inl = np.nonzero(reproj_err_sq(R, t, K4, obj, img) <= t2)[0]
+    rvec = Rot.from_matrix(R).as_rotvec()
+    if refine:
+        fx, fy, cx, cy = K4
+        P, U = obj[inl].astype(np.float64), img[inl].astype(np.float64)
+
+        def res(x):
+            Xc = P @ Rot.from_rotvec(x[:3]).as_matrix().T + x[3:]
+            return np.r_[cx + fx * Xc[:, 0] / Xc[:, 2] - U[:, 0], cy + fy * Xc[:, 1] / Xc[:, 2] - U[:, 1]]
+
+        sol = least_squares(res, np.r_[rvec, t], method="lm", xtol=1e-15, ftol=1e-15, gtol=1e-15)
+        rvec, t = sol.x[:3], sol.x[3:]
+    return inl, rvec, t, it

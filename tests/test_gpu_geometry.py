@@ -176,3 +176,49 @@ def test_fransac_ticket_survives_a_launch_with_a_mixed_view_of_the_gate(ctx, lea
     after = ctx.fransac(x1, x2, 1.0, seed=9)
     assert after[0] == before[0] and after[3] == before[3]
     assert np.array_equal(after[1], before[1]) and np.array_equal(after[2], before[2])
+
+
+@pytest.mark.parametrize("n", [6, 7, 8, 9, 12, 13, 14, 15, 16])
+def test_find_fundamental_mat_below_15_pairs(ctx, orc, n):
+    """cv::findFundamentalMat is a RANSAC only from 15 pairs on (src/tracking.cpp:34,75 reach it with whatever the tracker
+    kept): 7 pairs -- the 7-point solver once, the mask all ones; 8 .. 14 -- the least-median estimator (300 iterations, the
+    first model with the smallest median, sigma from it, floor 0.001); fewer than 7 -- no model.  GPU == oracle bit for
+    bit: count, iterations, mask, model."""
+    for seed in range(3):
+        x1, x2, gt, *_ = two_view(n=n, n_out=2 if n > 9 else 0, seed=60 + seed, noise=0.2)
+        gc, gmask, gF, git = ctx.fransac(x1, x2, 1.0, seed=seed)
+        oc, omask, oF, oit = orc.fransac(x1, x2, 1.0, seed=seed)
+        assert (gc, git) == (oc, oit), (n, seed, gc, oc, git, oit)
+        assert np.array_equal(gmask, omask)
+        assert np.array_equal(gF, oF), (n, seed)
+        if n == 7:
+            assert gc == 7 and gmask.all()
+        if 8 <= n < 15:
+            assert git == 300 and (gc == 0 or gc >= 7)
+        if n < 7:
+            assert gc == 0 and not gmask.any()
+
+
+def test_the_small_sample_branch_inside_the_front_end_filters(ctx, orc):
+    """The front-end's filters reach findFundamentalMat through device counts (the host does not know n).  A lattice of 15
+    points: frame 1 filters 15 pairs (RANSAC), frame 2 fewer than 15 (least median), frame 3 exactly 7 (the solver once) --
+    poses, counts and keyframe decisions equal the oracle's frame loop bit for bit."""
+    sc = synth.Scene()
+    poses = synth.corridor_trajectory(4)
+    frames = [sc.stereo(R, t)[:2] for R, t in poses]
+    kw = dict(grid_step=110, keyframe_min_inliers=5, seed=3, pnp_retry_below=3, pnp_lost_below=3)
+    g = capi.VisualOdometry(ctx, 1241, 376, 3, **kw)
+    o = orc.VO(1241, 376, 3, **kw)
+    ng, no = g.init(*frames[0]), o.init(*frames[0])
+    assert ng == no == 15
+    tracked = []
+    for i in (1, 2, 3):
+        rg, Rg, tg, ig, kg, trg = g.track(*frames[i])
+        ro, Ro, to, io, ko, tro = o.track(*frames[i])
+        assert rg == 0 and ro == 0
+        assert (ig, kg, trg) == (io, ko, tro), (i, ig, trg, io, tro)
+        assert np.array_equal(Rg, Ro) and np.array_equal(tg, to), i
+        tracked.append(trg)
+    assert tracked[0] >= 15 > tracked[1] > 7 >= tracked[2], tracked      # RANSAC, then least median, then seven pairs
+    g.close()
+    o.close()
