@@ -845,7 +845,13 @@ int svo_launch_lk_batch(svo_ctx *ctx, int n_jobs, const LkJob *jobs, const svo_p
         prm.dpitch[l] = geom->dpitch[l];
     }
     static const int lone_interleave = getenv("SVO_LK_INTERLEAVE") ? atoi(getenv("SVO_LK_INTERLEAVE")) : 1;  // A/B: +2.8 % frames/s for one chunk per GPU
-    prm.interleave = n_jobs <= 2 ? lone_interleave : 0;  // two jobs: the two candidate passes of a pipelined chunk
+    // Round 4: the launches of the lock-step groups deal their keypoints round-robin too.  Until then XCD x was given the
+    // x-th eighth of every job's list ("one band of the image per L2"): +11 % frames/s for dropping that (11.17 k -> 12.4 k, three
+    // alternating runs on one box) -- the L2-miss bytes a spatial order saves cost the kernel no time, the imbalance between
+    // the bands does (profiles/r04_lk_locality.txt: the order that fetches 5 x the bytes is the fastest).  SVO_LK_INTERLEAVE_BATCH=0
+    // restores the bands for an A/B.
+    static const int batch_interleave = getenv("SVO_LK_INTERLEAVE_BATCH") ? atoi(getenv("SVO_LK_INTERLEAVE_BATCH")) : 1;
+    prm.interleave = n_jobs <= 2 ? lone_interleave : batch_interleave;  // two jobs: the two candidate passes of a pipelined chunk
     dim3 grid(((n_max + 7) / 8 + WAVES - 1) / WAVES * 8, n_jobs), block(64 * WAVES);  // x: a multiple of 8, every XCD band has all its slots
     ScopedKernelTime t(ctx, SVO_K_LK);
     const int pad = ctx->lk_lds_pad;
