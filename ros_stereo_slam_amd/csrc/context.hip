@@ -107,12 +107,6 @@ const char *svo_last_error(void) { return g_err; }
 
 int svo_ctx_create(int device, svo_ctx **out)
 {
-    static const int prio = getenv("SVO_CTX_PRIO") ? atoi(getenv("SVO_CTX_PRIO")) : 0;  // A/B experiments only
-    return svo_ctx_create_prio(device, prio, out);
-}
-
-int svo_ctx_create_prio(int device, int priority_class, svo_ctx **out)
-{
     SVO_CHECK_ARG(out != nullptr);
     *out = nullptr;
     int count = 0;
@@ -133,13 +127,7 @@ int svo_ctx_create_prio(int device, int priority_class, svo_ctx **out)
     }
     svo_ctx *ctx = new svo_ctx();
     ctx->device = device;
-    if (priority_class == 0)
-        e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-    else {
-        int prio_lo = 0, prio_hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-        e = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, priority_class < 0 ? prio_hi : prio_lo);
-    }
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
         delete ctx;
         svo_set_error("hipStreamCreate -> %s", hipGetErrorString(e));

@@ -68,20 +68,6 @@ struct svo_vo {
     uint64_t *sig_flt = nullptr, *sig_dec = nullptr;
     uint32_t sig_n = 0;
     bool pipe_ready = false;
-    // Round 4: the keyframe decision is OFF the main stream's recurrence.  The filters of frame f+1 (status filter +
-    // F-RANSAC at 1 px) run for BOTH tracking passes frame f+1 can come from, without waiting for the decision of frame f:
-    // the pass from the tracked set on A ("P", buffers by frame parity), the pass from the keyframe candidate's points on the
-    // stream that runs ahead ("K", buffers by frame % 3, a context of its own for the RANSAC workspace and tickets).
-    // Everything downstream picks one of the two by the per-frame decision slots VoChain::kfs / nkfs.
-    float *trk2dP[2] = {nullptr, nullptr}, *c2P[2] = {nullptr, nullptr};
-    uint8_t *maskP[2] = {nullptr, nullptr};
-    float *b2K = nullptr, *c2K[3] = {nullptr, nullptr, nullptr}, *trk2dK[3] = {nullptr, nullptr, nullptr};
-    uint8_t *maskK[3] = {nullptr, nullptr, nullptr};
-    int *d_cntx = nullptr;  // [0..1] cntP by parity, [2] the status-filtered count on A, [4..6] the same on K by % 3, [8..10] cntK
-    svo_ctx *ctxK = nullptr;
-    int pad_ahead = 0;  // LDS pad of the tracking launches the pyramid stream carries (see svo_ctx::lk_lds_pad)
-    hipEvent_t ev_fltN[4] = {nullptr, nullptr, nullptr, nullptr}, ev_lkN[4] = {nullptr, nullptr, nullptr, nullptr},
-               ev_decN[4] = {nullptr, nullptr, nullptr, nullptr}, ev_fk[4] = {nullptr, nullptr, nullptr, nullptr};
     // second set of tracked points / inlier list: frame t's refinement reads its set while frame t+1's filters write theirs
     float *trk2d_b = nullptr, *trk3d_b = nullptr;
     int *idx_b = nullptr;
@@ -528,19 +514,6 @@ int svo_vo_destroy(svo_vo *v)
             if (b)
                 (void)hipFree(b);
     }
-    for (hipEvent_t e : {v->ev_fltN[0], v->ev_fltN[1], v->ev_fltN[2], v->ev_fltN[3], v->ev_lkN[0], v->ev_lkN[1], v->ev_lkN[2], v->ev_lkN[3],
-                         v->ev_decN[0], v->ev_decN[1], v->ev_decN[2], v->ev_decN[3], v->ev_fk[0], v->ev_fk[1], v->ev_fk[2], v->ev_fk[3]})
-        if (e)
-            (void)hipEventDestroy(e);
-    if (v->ctxK) {
-        (void)hipStreamSynchronize(v->ctxK->stream);
-        (void)svo_ctx_destroy(v->ctxK);
-    }
-    for (void *b : {(void *)v->trk2dP[0], (void *)v->trk2dP[1], (void *)v->c2P[0], (void *)v->c2P[1], (void *)v->maskP[0], (void *)v->maskP[1],
-                    (void *)v->b2K, (void *)v->c2K[0], (void *)v->c2K[1], (void *)v->c2K[2], (void *)v->trk2dK[0], (void *)v->trk2dK[1],
-                    (void *)v->trk2dK[2], (void *)v->maskK[0], (void *)v->maskK[1], (void *)v->maskK[2], (void *)v->d_cntx})
-        if (b)
-            (void)hipFree(b);
     if (v->d_stamps)
         (void)hipFree(v->d_stamps);
     if (v->h_chain)
@@ -919,366 +892,6 @@ static int chain_pnp_refine(svo_ctx *ctx, svo_vo *const *vs, int set, bool keyfr
     return svo_launch_pnp_refine(ctx, 1, &pj, keyframes);
 }
 
-// ---- the pipelined chunk, round 4: the keyframe decision is off the main stream's recurrence -------------------------
-// Round 3's main stream ran  filters(f) -> tracking launch(f -> f+1) -> WAIT for the decision of f -> filters(f+1): the
-// filters of f+1 pick, by the decision, the output of the pass from the tracked set or of the pass from the keyframe's
-// points, and the decision arrives 180 us after the filters of f (3-D column, PnP hypotheses, replay) -- a frame was
-// filters + PnP + the hop back = 314 us.  Here the filters run for BOTH passes before the decision exists:
-//   A   filtersP(f): the pass from the tracked set -- reference points = the filtered tracked set of f-1 of whichever
-//       branch f-1 took (selected on the device by the decision slot of f-2), output by frame parity; then, once frame
-//       f-1 is decided, ONE launch with both candidate passes into f+1 (from filtersP(f)'s and from filtersK(f)'s output),
-//       each gated on its decision slot: only the one that is due runs
-//   D   (beside pyramids, triangulation and the pass from the keyframe candidate, all ahead): filtersK(g), the filters of the
-//       pass from keyframe candidate g-1's points, two frames ahead, on a context of its own (RANSAC workspace, tickets)
-//   B   3-D column (status part as soon as the tracking launch has ended), then the mask part -- which now also writes the
-//       2-D set the PnP reads, from the chosen branch --, hypotheses, decision, refinement, hand-over as before
-//   C   the stereo path two frames ahead, as before.
-// The recurrence of the main stream is filters + tracking launch; the decision of f-1 must arrive before the launch of f
-// (it has a whole frame for that).  Results: bit-identical to round 3's pipeline and to the frame-by-frame loop.
-static int chain_enqueue_pipe4(ChainRun &r)
-{
-    svo_vo *v = r.v;
-    svo_ctx *ctx = v->ctx;
-    int rc = SVO_OK;
-    static const bool stamps_env = getenv("SVO_CHAIN_STAMPS") != nullptr;
-    const bool stamps = stamps_env || v->stamps_on;
-    const int max_stamp_frames = 4096;
-    constexpr int NS = 12;  // stamps per frame
-    if (stamps && !v->d_stamps)
-        SVO_HIP(hipMalloc(reinterpret_cast<void **>(&v->d_stamps), sizeof(unsigned long long) * NS * max_stamp_frames));
-    unsigned long long *d_stamps = v->d_stamps;
-    auto stamp = [&](hipStream_t st, int frame, int slot) {
-        if (stamps && frame < max_stamp_frames)
-            hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, st, d_stamps + NS * frame + slot);
-    };
-    hipStream_t sA = ctx->stream, sB = v->stream_b, sC = v->lane.ctx->stream, sD = v->stream_p;
-    svo_pyramid *ref = v->pyr_ref, *cur = v->pyr_cur, *nxt = v->pyr_next;
-    svo_pyramid *right[2] = {v->pyr_right, v->pyr_right2};
-    VoChain *ch = v->d_chain;
-    const int *run = &ch->run;
-    svo_vo *vs[1] = {v};
-    const int frame0 = v->frame, nf = r.n_frames, cap = v->cap;
-    int *cntP = v->d_cntx, *cA1 = v->d_cntx + 2, *cK1 = v->d_cntx + 4, *cntK = v->d_cntx + 8;
-    struct OnStream {  // the launch helpers take the stream from the context
-        svo_ctx *c;
-        hipStream_t keep;
-        OnStream(svo_ctx *cc, hipStream_t st) : c(cc), keep(cc->stream) { c->stream = st; }
-        ~OnStream() { c->stream = keep; }
-    };
-    auto seed_of = [&](int g, int stage) { return v->prm.seed + 8ull * (uint64_t)(frame0 + g + 1) + (uint64_t)stage; };
-    // pyramids of frame g of the run on D (the left one into `left`)
-    auto pyramids = [&](int g, svo_pyramid *left) -> int {
-        const uint8_t *li = r.lefts[g], *ri = r.rights[g];
-        svo_pyramid *rp = right[g & 1];
-        svo_pyramid *pyrs[2] = {left, rp};
-        const uint8_t *imgs[2] = {li, ri};
-        const int *g2[2] = {run, run};
-        OnStream on(ctx, sD);
-        if ((rc = svo_build_pyramids_from_device(ctx, 2, pyrs, imgs, g2)))
-            return rc;
-        SVO_HIP(hipEventRecord(v->ev_pyr[g & 3], sD));
-        return SVO_OK;
-    };
-    auto stereo = [&](int g, svo_pyramid *left) -> int {  // the stereo path of frame g on C, from the pyramids D has built
-        SVO_HIP(hipStreamWaitEvent(sC, v->ev_pyr[g & 3], 0));
-        if ((rc = stereo_part1_spec(v, v->lane, left, right[g & 1], frame0 + g + 1, g % 3)))
-            return rc;
-        SVO_HIP(hipEventRecord(v->ev_c[g & 3], sC));
-        return SVO_OK;
-    };
-    auto triangulate = [&](int g) -> int {  // ... and its triangulation, on D
-        SVO_HIP(hipStreamWaitEvent(sD, v->ev_c[g & 3], 0));
-        {
-            OnStream on(ctx, sD);
-            if ((rc = stereo_tri_spec(v, g % 3)))
-                return rc;
-        }
-        SVO_HIP(hipEventRecord(v->ev_p1[g & 3], sD));
-        return SVO_OK;
-    };
-    // D: the tracking pass into frame g from the 2-D points the stereo path of frame g-1 has left, then ITS filters
-    // (status filter, F-RANSAC at 1 px with the mask filter riding along): the K candidate of frame g's tracked 2-D set
-    auto kf_pass = [&](int g, svo_pyramid *from, svo_pyramid *into) -> int {
-        SVO_HIP(hipStreamWaitEvent(sD, v->ev_c[(g - 1) & 3], 0));  // the 2-D points of that stereo path
-        SVO_HIP(hipStreamWaitEvent(sD, v->ev_pyr[g & 3], 0));
-        LkJob q;
-        q.prev = from->dev;
-        q.next = into->dev;
-        q.dprev = from->dbase;
-        q.prev_pts = v->h_x1[(g - 1) % 3];
-        q.n_cap = cap;
-        q.d_n = v->h_cnt + (g - 1) % 3;
-        q.next_pts = v->a2k[g % 3];
-        q.status = v->statusk[g % 3];
-        q.err = nullptr;
-        q.min_eig = nullptr;
-        q.gate = run;
-        {
-            OnStream on(ctx, sD);
-            ctx->lk_lds_pad = v->pad_ahead;
-            rc = svo_launch_lk_batch(ctx, 1, &q, from);
-            ctx->lk_lds_pad = 0;
-            if (rc)
-                return rc;
-        }
-        SVO_HIP(hipEventRecord(v->ev_e[g & 3], sD));
-        return SVO_OK;
-    };
-    // K: the filters of that pass (status filter, F-RANSAC at 1 px with the mask filter riding along) -- the K candidate of
-    // frame g's tracked 2-D set -- on a FIFTH stream with a context of its own, once frame g-1 is decided and only if it is
-    // a keyframe (gated on its decision slot): queued for every frame, 84 us of work for the frames that need it.  Called
-    // when the decision of g-1 has been queued on B (the event wait takes the event's latest record).
-    auto filtersK = [&](int g) -> int {
-        hipStream_t sK = v->ctxK->stream;
-        const int k3 = g % 3;
-        const int *gate = &ch->kfs[(g - 1) & 3];
-        SVO_HIP(hipStreamWaitEvent(sK, v->ev_e[g & 3], 0));
-        SVO_HIP(hipStreamWaitEvent(sK, v->ev_decN[(g - 1) & 3], 0));
-        svo_compact_job c1 = {v->statusk[k3], cap, v->h_cnt + (g - 1) % 3, {v->h_x1[(g - 1) % 3], v->a2k[k3], nullptr},
-                              {v->b2K, v->c2K[k3], nullptr}, {2, 2, 0}, cK1 + k3, gate};
-        svo_compact_job c2 = {v->maskK[k3], cap, cK1 + k3, {v->c2K[k3], nullptr, nullptr}, {v->trk2dK[k3], nullptr, nullptr},
-                              {2, 0, 0}, cntK + k3};
-        svo_fransac_job fj;
-        fj.p1 = v->b2K;
-        fj.p2 = v->c2K[k3];
-        fj.cap = cap;
-        fj.d_n = cK1 + k3;
-        fj.threshold = v->prm.f_thr_temporal;
-        fj.confidence = 0.99;
-        fj.max_iters = 1000;
-        fj.seed = seed_of(g, 0);
-        fj.mask = v->maskK[k3];
-        fj.d_F = nullptr;
-        fj.d_count = nullptr;
-        fj.d_iters = nullptr;
-        fj.then_compact = &c2;
-        fj.gate = gate;
-        if ((rc = svo_launch_compact_batch(v->ctxK, 1, &c1)) || (rc = svo_launch_fransac_batch(v->ctxK, 1, &fj)))
-            return rc;
-        SVO_HIP(hipEventRecord(v->ev_fk[g & 3], sK));
-        return SVO_OK;
-    };
-    // A: the filters of the pass from the tracked set into frame f.  Reference points: the run's reference set (f == 0),
-    // else the filtered tracked set of f-1 of the branch f-1 took (by the decision slot of f-2; f == 1: always P).
-    auto filtersP = [&](int f) -> int {
-        const int par = f & 1;
-        svo_compact_job c1;
-        if (f == 0)
-            c1 = {v->status, cap, &ch->nref, {v->ref2d, v->a2, nullptr}, {v->b2, v->c2P[par], nullptr}, {2, 2, 0}, cA1, run};
-        else {
-            c1 = {par ? v->status_b : v->status, cap, cntP + ((f - 1) & 1), {v->trk2dP[(f - 1) & 1], v->a2, nullptr},
-                  {v->b2, v->c2P[par], nullptr}, {2, 2, 0}, cA1, run};
-            if (f >= 2) {
-                c1.alt_sel = &ch->kfs[(f - 2) & 3];
-                c1.alt_in[0] = v->trk2dK[(f - 1) % 3];
-                c1.alt_d_n = cntK + (f - 1) % 3;
-            }
-        }
-        svo_compact_job c2 = {v->maskP[par], cap, cA1, {v->c2P[par], nullptr, nullptr}, {v->trk2dP[par], nullptr, nullptr}, {2, 0, 0},
-                              cntP + par};
-        svo_fransac_job fj;
-        fj.p1 = v->b2;
-        fj.p2 = v->c2P[par];
-        fj.cap = cap;
-        fj.d_n = cA1;
-        fj.threshold = v->prm.f_thr_temporal;
-        fj.confidence = 0.99;
-        fj.max_iters = 1000;
-        fj.seed = seed_of(f, 0);
-        fj.mask = v->maskP[par];
-        fj.d_F = nullptr;
-        fj.d_count = nullptr;
-        fj.d_iters = nullptr;
-        fj.then_compact = &c2;
-        fj.gate = run;
-        if ((rc = svo_launch_compact_batch(ctx, 1, &c1)) || (rc = svo_launch_fransac_batch(ctx, 1, &fj)))
-            return rc;
-        return SVO_OK;
-    };
-    // A: both candidate passes from frame f into frame f+1 as ONE launch, each gated on its decision slot
-    auto track_next = [&](int f) -> int {
-        LkJob q[2];
-        for (int k = 0; k < 2; k++) {
-            q[k].prev = cur->dev;
-            q[k].next = nxt->dev;
-            q[k].dprev = cur->dbase;
-            q[k].n_cap = cap;
-            q[k].next_pts = v->a2;
-            q[k].status = (f + 1) & 1 ? v->status_b : v->status;
-            q[k].err = nullptr;
-            q[k].min_eig = nullptr;
-        }
-        q[0].prev_pts = v->trk2dP[f & 1];
-        q[0].d_n = cntP + (f & 1);
-        q[0].gate = f >= 1 ? &ch->nkfs[(f - 1) & 3] : run;  // frame f-1 no keyframe: frame f came from the tracked set
-        q[1].prev_pts = v->trk2dK[f % 3];
-        q[1].d_n = cntK + f % 3;
-        q[1].gate = f >= 1 ? &ch->kfs[(f - 1) & 3] : run;
-        return svo_launch_lk_batch(ctx, f >= 1 ? 2 : 1, q, cur);
-    };
-    // ---- prologue: the chain state is on its way (chain_prepare, on A) ----
-    SVO_HIP(hipEventRecord(v->ev_flt, sA));
-    SVO_HIP(hipStreamWaitEvent(sD, v->ev_flt, 0));
-    SVO_HIP(hipStreamWaitEvent(sB, v->ev_flt, 0));
-    if ((rc = pyramids(0, cur)) || (nf > 1 && (rc = pyramids(1, nxt))))
-        return rc;
-    {
-        SVO_HIP(hipStreamWaitEvent(sA, v->ev_pyr[0], 0));
-        LkJob q;  // the tracking pass into frame 0 from the run's reference set
-        q.prev = ref->dev;
-        q.next = cur->dev;
-        q.dprev = ref->dbase;
-        q.prev_pts = v->ref2d;
-        q.n_cap = cap;
-        q.d_n = &ch->nref;
-        q.next_pts = v->a2;
-        q.status = v->status;
-        q.err = nullptr;
-        q.min_eig = nullptr;
-        q.gate = run;
-        if ((rc = svo_launch_lk_batch(ctx, 1, &q, ref)))
-            return rc;
-        SVO_HIP(hipEventRecord(v->ev_lkN[3], sA));  // "frame -1"
-        SVO_HIP(hipEventRecord(v->ev_lk, sA));
-        if ((rc = stereo(0, cur)) || (nf > 1 && (rc = stereo(1, nxt))) || (rc = triangulate(0)) || (nf > 1 && (rc = kf_pass(1, cur, nxt))))
-            return rc;
-    }
-    if (nf > 1)
-        SVO_HIP(hipStreamWaitEvent(sA, v->ev_pyr[1], 0));  // the first tracking launch's target
-    for (int f = 0; f < nf; f++) {
-        v->frame++;
-        const int set = f & 1, slot = f % 3;
-        const bool more = f + 1 < nf;
-        stamp(sA, f, 0);
-        if ((rc = filtersP(f)))
-            return rc;
-        SVO_HIP(hipEventRecord(v->ev_fltN[f & 3], sA));
-        stamp(sA, f, 1);
-        // ---- B: the frame's 3-D column, PnP, decision; then refinement and hand-over ----
-        SVO_HIP(hipStreamWaitEvent(sB, v->ev_lkN[(f + 3) & 3], 0));  // the tracking launch into frame f has ended (status bytes)
-        if (f >= 1)
-            SVO_HIP(hipStreamWaitEvent(sB, v->ev_e[f & 3], 0));       // ... and the pass from the keyframe candidate (ahead)
-        {
-            OnStream on(ctx, sB);
-            svo_compact_job c0 = {set ? v->status_b : v->status, cap, &ch->nref, {v->ref3d, nullptr, nullptr}, {v->a3, nullptr, nullptr},
-                                  {3, 0, 0}, v->d_cnt + 10, run};
-            c0.alt_sel = &ch->kf;  // still the previous frame's decision (this stream took it)
-            c0.alt_mask = v->statusk[slot];
-            if ((rc = svo_launch_compact_batch(ctx, 1, &c0)))
-                return rc;
-            SVO_HIP(hipStreamWaitEvent(sB, v->ev_fltN[f & 3], 0));
-            if (f >= 1)
-                SVO_HIP(hipStreamWaitEvent(sB, v->ev_fk[f & 3], 0));
-            stamp(sB, f, 3);
-            // the mask part: the tracked 3-D set AND the tracked 2-D set the PnP reads, from the chosen branch
-            svo_compact_job c1 = {v->maskP[set], cap, v->d_cnt + 10, {v->a3, v->c2P[set], nullptr},
-                                  {set ? v->trk3d_b : v->trk3d, set ? v->trk2d_b : v->trk2d, nullptr}, {3, 2, 0}, v->d_cnt + (set ? 9 : 1), run};
-            c1.alt_sel = &ch->kf;
-            c1.alt_mask = v->maskK[slot];
-            c1.alt_in[1] = v->c2K[slot];
-            if ((rc = svo_launch_compact_batch(ctx, 1, &c1)) || (rc = chain_pnp(ctx, 1, vs, set, true)))
-                return rc;
-            SVO_HIP(hipEventRecord(v->ev_decN[f & 3], sB));
-            stamp(sB, f, 4);
-            SVO_HIP(hipStreamWaitEvent(sB, v->ev_p1[f & 3], 0));  // the stereo path of this frame: long done
-            if ((rc = chain_pnp_refine(ctx, vs, set, true)) || (rc = stereo_part2_spec(v, cur, slot, 3)))
-                return rc;
-            stamp(sB, f, 5);
-            SVO_HIP(hipEventRecord(v->ev_p3[f & 3], sB));
-            if ((rc = chain_pnp_refine(ctx, vs, set, false)))
-                return rc;
-        }
-        if (more && (rc = filtersK(f + 1)))  // K: the filters of the pass from keyframe candidate f into f+1, if f is a keyframe
-            return rc;
-        // ---- D: the pyramids of frame f+2 into the buffer of frame f-1 (last readers: the tracking launch into f, before
-        // these filters on A; the stereo path of f-1 on C; the colours of keyframe f-1, its hand-over on B), then the
-        // triangulation of the stereo path of f+1 ----
-        if (more) {
-            SVO_HIP(hipStreamWaitEvent(sD, v->ev_fltN[f & 3], 0));
-            SVO_HIP(hipStreamWaitEvent(sD, v->ev_c[f & 3], 0));
-            if (f > 0)
-                SVO_HIP(hipStreamWaitEvent(sD, v->ev_p3[(f - 1) & 3], 0));
-            if (f + 2 < nf && (rc = pyramids(f + 2, ref)))
-                return rc;
-            if ((rc = triangulate(f + 1)))
-                return rc;
-        }
-        if (more) {
-            // ---- A: once frame f-1 is decided, both candidate passes into frame f+1 as one launch ----
-            if (f >= 1) {
-                SVO_HIP(hipStreamWaitEvent(sA, v->ev_fk[f & 3], 0));  // the decision of frame f-1 and, if it is a keyframe, filtersK(f)
-            }
-            stamp(sA, f, 8);
-            if ((rc = track_next(f)))
-                return rc;
-            stamp(sA, f, 2);
-            SVO_HIP(hipEventRecord(v->ev_lkN[f & 3], sA));
-            // ---- C: the stereo path of frame f+2 once this launch has ended; D: the pass from keyframe candidate f+1 into
-            // f+2 and its filters.  (Hand-over set (f+2) % 3 was last read by frame f-1: its hand-over on B.) ----
-            if (f + 2 < nf) {
-                SVO_HIP(hipStreamWaitEvent(sC, v->ev_lkN[f & 3], 0));
-                if (f > 0)
-                    SVO_HIP(hipStreamWaitEvent(sC, v->ev_p3[(f - 1) & 3], 0));
-                stamp(sC, f, 6);
-                if ((rc = stereo(f + 2, ref)))  // `ref`: where D has just been told to build frame f+2
-                    return rc;
-                stamp(sC, f, 7);
-                // the K buffers of slot (f+2) % 3 were last read by frame f-1: its mask part on B (before its decision) and
-                // the launch from it on A (before this one); both are behind the event below
-                SVO_HIP(hipStreamWaitEvent(sD, v->ev_lkN[f & 3], 0));
-                if (f > 0)
-                    SVO_HIP(hipStreamWaitEvent(sD, v->ev_decN[(f - 1) & 3], 0));
-                if ((rc = kf_pass(f + 2, nxt, ref)))
-                    return rc;
-            }
-            if (f + 2 < nf)
-                SVO_HIP(hipStreamWaitEvent(sA, v->ev_pyr[(f + 2) & 3], 0));  // the next tracking launch's target
-        }
-        svo_pyramid *t = ref;  // referenceImg = currentImage (src/VisualSLAM.cpp:151)
-        ref = cur;
-        cur = nxt;
-        nxt = t;
-    }
-    // the last frame's refinement runs on B: the caller's wait on A covers it; D and C are ahead of nothing any more
-    SVO_HIP(hipEventRecord(v->ev_ref, sB));
-    SVO_HIP(hipStreamWaitEvent(sA, v->ev_ref, 0));
-    SVO_HIP(hipEventRecord(v->ev_flt, sD));
-    SVO_HIP(hipStreamWaitEvent(sA, v->ev_flt, 0));
-    SVO_HIP(hipEventRecord(v->ev_lk, sC));
-    SVO_HIP(hipStreamWaitEvent(sA, v->ev_lk, 0));
-    SVO_HIP(hipEventRecord(v->ev_dec, v->ctxK->stream));
-    SVO_HIP(hipStreamWaitEvent(sA, v->ev_dec, 0));
-    if (stamps && nf > 40) {
-        SVO_HIP(hipStreamSynchronize(sA));
-        const int n = nf < max_stamp_frames ? nf : max_stamp_frames;
-        std::vector<unsigned long long> h((size_t)NS * n);
-        SVO_HIP(hipMemcpy(h.data(), d_stamps, h.size() * sizeof(h[0]), hipMemcpyDeviceToHost));
-        auto T = [&](int f, int k) { return (double)h[(size_t)NS * f + k] * 0.01; };  // 100 MHz -> us
-        double cyc = 0, filt = 0, lk = 0, a_wait = 0, b_lag = 0, pnp = 0, hand = 0, c_lag = 0, c_len = 0;
-        int m = 0;
-        for (int f = 20; f + 3 < n; f++, m++) {
-            cyc += T(f + 1, 0) - T(f, 0);
-            filt += T(f, 1) - T(f, 0);
-            a_wait += T(f, 8) - T(f, 1);   // after the filters: waiting for the decision of f-1 (and the events ahead)
-            lk += T(f, 2) - T(f, 8);
-            b_lag += T(f, 3) - T(f, 1);
-            pnp += T(f, 4) - T(f, 3);
-            hand += T(f, 5) - T(f, 4);
-            c_lag += T(f, 6) - T(f, 2);
-            c_len += T(f, 7) - T(f, 6);
-        }
-        const double vals[SVO_STAGE_COUNT] = {cyc / m, filt / m, lk / m, a_wait / m, b_lag / m, pnp / m, hand / m, c_lag / m, c_len / m};
-        for (int i = 0; i < SVO_STAGE_COUNT; i++)
-            v->stage_us[i] = vals[i];
-        v->stage_frames = m;
-        if (stamps_env)
-            fprintf(stderr, "[svo chain 4] device us per frame: period %.1f = filters %.1f + wait for the decision of f-1 %.1f + tracking launch %.1f | "
-                            "B mask part starts %.1f after the filters, to the decision %.1f, refine + hand-over of a keyframe %.1f | C starts %.1f "
-                            "after the launch, stereo path %.1f\n", cyc / m, filt / m, a_wait / m, lk / m, b_lag / m, pnp / m, hand / m, c_lag / m, c_len / m);
-    }
-    return SVO_OK;
-}
-
 // Queue frames [0, n) of k chunks that share a context (lock step: every stage one set of launches for all of them;
 // chunks may differ in length).  pipeline: k == 1, device images.
 static int chain_enqueue(ChainRun *const *runs, int k, bool pipeline)
@@ -1322,12 +935,6 @@ static int chain_enqueue(ChainRun *const *runs, int k, bool pipeline)
         }
         return svo_build_pyramids_from_device(ctx, 2 * na, pyrs, imgs, g);
     };
-    // SVO_PIPE4=1: the experimental five-stream form with the decision off the main stream's recurrence (chain_enqueue_pipe4;
-    // bit-identical, measured SLOWER in round 4 -- 2 690 against 3 060 frames/s: the main stream's filters then start together
-    // with the two tracking launches that run ahead and wait for wave slots)
-    static const bool pipe4 = getenv("SVO_PIPE4") != nullptr && atoi(getenv("SVO_PIPE4")) != 0;
-    if (pipeline && pipe4)
-        return chain_enqueue_pipe4(*runs[0]);
     if (pipeline) {
         // Four streams (see svo_vo).  Nothing on A waits for the frame's decision: after the filters of frame f it runs
         // BOTH tracking passes into frame f+1 -- from the tracked set and from the 2-D points the stereo path of f has
@@ -1852,19 +1459,12 @@ int svo_vo_run_chunk(svo_vo *v, const uint8_t *const *lefts, const uint8_t *cons
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
         if (!v->stream_b)
             SVO_HIP(hipStreamCreateWithPriority(&v->stream_b, hipStreamNonBlocking, prio_hi));
-        static const int ahead_low = getenv("SVO_PIPE_AHEAD_LOW") ? atoi(getenv("SVO_PIPE_AHEAD_LOW")) : 0;  // A/B: the streams that run ahead in the low priority class
-        static const int ahead_pad = getenv("SVO_PIPE_AHEAD_PAD") ? atoi(getenv("SVO_PIPE_AHEAD_PAD")) : 0;  // A/B: LDS pad of their tracking launches
-        if (!v->stream_p) {
-            if (ahead_low)
-                SVO_HIP(hipStreamCreateWithPriority(&v->stream_p, hipStreamNonBlocking, prio_lo));
-            else
-                SVO_HIP(hipStreamCreateWithFlags(&v->stream_p, hipStreamNonBlocking));
-        }
+        if (!v->stream_p)
+            SVO_HIP(hipStreamCreateWithFlags(&v->stream_p, hipStreamNonBlocking));
         const size_t n = (size_t)v->cap;
         svo_vo::StereoLane &L = v->lane;
-        if (!L.ctx && (rc = svo_ctx_create_prio(v->ctx->device, ahead_low ? 1 : 0, &L.ctx)))
+        if (!L.ctx && (rc = svo_ctx_create(v->ctx->device, &L.ctx)))
             return rc;
-        L.ctx->lk_lds_pad = ahead_pad;
         if ((!L.a2 && (rc = dev_alloc(&L.a2, n * 2))) || (!L.b2 && (rc = dev_alloc(&L.b2, n * 2))) ||
             (!L.c2 && (rc = dev_alloc(&L.c2, n * 2))) || (!L.d2 && (rc = dev_alloc(&L.d2, n * 2))) ||
             (!L.x2 && (rc = dev_alloc(&L.x2, n * 2))) || (!L.resp && (rc = dev_alloc(&L.resp, n))) ||
@@ -1886,24 +1486,6 @@ int svo_vo_run_chunk(svo_vo *v, const uint8_t *const *lefts, const uint8_t *cons
                               &v->ev_p1[0], &v->ev_p1[1], &v->ev_p1[2], &v->ev_p1[3], &v->ev_p3[0], &v->ev_p3[1], &v->ev_p3[2],
                               &v->ev_p3[3], &v->ev_e[0], &v->ev_e[1], &v->ev_e[2], &v->ev_e[3], &v->ev_c[0], &v->ev_c[1],
                               &v->ev_c[2], &v->ev_c[3]})
-            if (!*e)
-                SVO_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
-        for (int k = 0; k < 2; k++)
-            if ((!v->trk2dP[k] && (rc = dev_alloc(&v->trk2dP[k], n * 2))) || (!v->c2P[k] && (rc = dev_alloc(&v->c2P[k], n * 2))) ||
-                (!v->maskP[k] && (rc = dev_alloc(&v->maskP[k], n))))
-                return rc;
-        for (int k = 0; k < 3; k++)
-            if ((!v->c2K[k] && (rc = dev_alloc(&v->c2K[k], n * 2))) || (!v->trk2dK[k] && (rc = dev_alloc(&v->trk2dK[k], n * 2))) ||
-                (!v->maskK[k] && (rc = dev_alloc(&v->maskK[k], n))))
-                return rc;
-        if ((!v->b2K && (rc = dev_alloc(&v->b2K, n * 2))) || (!v->d_cntx && (rc = dev_alloc(&v->d_cntx, 32))))
-            return rc;
-        if (!v->ctxK && (rc = svo_ctx_create_prio(v->ctx->device, ahead_low ? 1 : 0, &v->ctxK)))
-            return rc;
-        v->pad_ahead = ahead_pad;
-        for (hipEvent_t *e : {&v->ev_fltN[0], &v->ev_fltN[1], &v->ev_fltN[2], &v->ev_fltN[3], &v->ev_lkN[0], &v->ev_lkN[1], &v->ev_lkN[2],
-                              &v->ev_lkN[3], &v->ev_decN[0], &v->ev_decN[1], &v->ev_decN[2], &v->ev_decN[3], &v->ev_fk[0], &v->ev_fk[1],
-                              &v->ev_fk[2], &v->ev_fk[3]})
             if (!*e)
                 SVO_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
         if (!v->sig_flt) {

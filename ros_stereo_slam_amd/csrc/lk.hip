@@ -854,22 +854,21 @@ int svo_launch_lk_batch(svo_ctx *ctx, int n_jobs, const LkJob *jobs, const svo_p
     prm.interleave = n_jobs <= 2 ? lone_interleave : batch_interleave;  // two jobs: the two candidate passes of a pipelined chunk
     dim3 grid(((n_max + 7) / 8 + WAVES - 1) / WAVES * 8, n_jobs), block(64 * WAVES);  // x: a multiple of 8, every XCD band has all its slots
     ScopedKernelTime t(ctx, SVO_K_LK);
-    const int pad = ctx->lk_lds_pad;
     if (c != 1 && c != 3) {
         svo_set_error("lk: unsupported channel count %d (1 or 3)", c);
         return SVO_ERR_ARG;
     }
     if (n_jobs == 1) {
         if (c == 1)
-            hipLaunchKernelGGL((lk_track_kernel<1, 1>), grid, block, WAVES * Lds<1>::WAVE_BYTES + pad, ctx->stream, one, prm);
+            hipLaunchKernelGGL((lk_track_kernel<1, 1>), grid, block, WAVES * Lds<1>::WAVE_BYTES, ctx->stream, one, prm);
         else
-            hipLaunchKernelGGL((lk_track_kernel<3, 1>), grid, block, WAVES * Lds<3>::WAVE_BYTES + pad, ctx->stream, one, prm);
+            hipLaunchKernelGGL((lk_track_kernel<3, 1>), grid, block, WAVES * Lds<3>::WAVE_BYTES, ctx->stream, one, prm);
     } else {
         if (c == 1)
-            hipLaunchKernelGGL((lk_track_kernel<1, SVO_LK_MAX_JOBS>), grid, block, WAVES * Lds<1>::WAVE_BYTES + pad, ctx->stream,
+            hipLaunchKernelGGL((lk_track_kernel<1, SVO_LK_MAX_JOBS>), grid, block, WAVES * Lds<1>::WAVE_BYTES, ctx->stream,
                                batch, prm);
         else
-            hipLaunchKernelGGL((lk_track_kernel<3, SVO_LK_MAX_JOBS>), grid, block, WAVES * Lds<3>::WAVE_BYTES + pad, ctx->stream,
+            hipLaunchKernelGGL((lk_track_kernel<3, SVO_LK_MAX_JOBS>), grid, block, WAVES * Lds<3>::WAVE_BYTES, ctx->stream,
                                batch, prm);
     }
     SVO_HIP(hipGetLastError());

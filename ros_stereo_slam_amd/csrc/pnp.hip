@@ -1420,19 +1420,13 @@ template <bool LEAN> __global__ __launch_bounds__(256, LEAN ? 5 : 4) void pnp_fi
             // this frame in place and the host runs the retry.  Otherwise: keyframe iff fewer than 200 inliers
             // (src/VisualSLAM.cpp:120).
             const int ninl = r.best_iter >= 0 ? r.best_count : 0;
-            const int slot = chain->frame & 3;  // this frame's index in the run (it advances when the frame is finished)
             if (ninl < chain->retry_below) {
                 chain->run = 0;
                 chain->kf = 0;
-                chain->kfs[slot] = 0;
-                chain->nkfs[slot] = 0;
                 chain->halt_code = SVO_HALT_RETRY;
                 s_flag = 3;
             } else {
-                const int kf_now = ninl < chain->kf_min ? 1 : 0;
-                chain->kf = kf_now;
-                chain->kfs[slot] = kf_now;
-                chain->nkfs[slot] = 1 - kf_now;
+                chain->kf = ninl < chain->kf_min ? 1 : 0;
             }
         }
     }

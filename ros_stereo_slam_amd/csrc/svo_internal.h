@@ -109,11 +109,7 @@ struct svo_ctx {
     void *pinned = nullptr;  // small pinned host block for scalar read-backs
     size_t pinned_bytes = 0;
     hipEvent_t wait_ev = nullptr;  // svo_wait(): event polled by the host
-    // extra dynamic LDS (bytes per workgroup) requested by tracking launches of this context: caps how many of a launch's
-    // waves are resident per CU (a launch that runs AHEAD of the frame then leaves wave slots to the frame's short kernels)
-    int lk_lds_pad = 0;
 };
-extern "C" int svo_ctx_create_prio(int device, int priority_class, svo_ctx **out);  // -1 high, 0 default, 1 low (internal)
 
 // Low-latency host wait for everything queued on the context's stream: records an event and
 // polls it (hipStreamSynchronize parks the thread and costs tens of microseconds to wake).
@@ -151,10 +147,6 @@ struct VoChain {
     int kf_n;       // points of the last keyframe's camera-frame cloud
     int refine_due; // 1: the frame's policy is decided, its refinement is left to a PNP_FINISH_REFINE launch
     int pad;
-    // the keyframe decision of the frame with index f of the run, by f & 3, and its complement (both 0 after a halt):
-    // launch gates / selectors for kernels of OTHER streams that must not read `kf` while the next decision may land
-    // (the pipelined chunk: the main stream runs the next frame's filters before this frame is decided)
-    int kfs[4], nkfs[4];
     double R[9], t[3];  // pose of the frame just localised, camera in world: the keyframe's [R|t]
     // configuration, written by the host before a run
     int kf_min, retry_below;

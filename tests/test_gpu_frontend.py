@@ -501,3 +501,41 @@ def test_keyframe_colors_on_the_fused_path(ctx, orc):
     else:           # colours are pixel values of that keyframe's left image
         assert set(np.unique(col)).issubset(set(np.unique(frames[last_kf][0]).astype(np.float32)))
     g.close()
+
+
+def test_pipeline_soak_600_frames_in_pieces_of_random_length(ctx):
+    """the four-stream pipeline's hazards are timing-dependent (buffers and events indexed by f & 1, f % 3,
+    g & 3, shared by streams that run two frames ahead), so its race coverage must not live in a tool only.  One round of
+    tools/pipeline_soak.py: 600 frames of the benchmark stream at the benchmarked shape through the pipelined runner in
+    pieces of random length (1 .. 89) against the one-stream runner on a second context -- every pose, count and
+    keyframe decision and the final reference sets bit for bit.  A later edit that breaks a buffer rotation shows here."""
+    import torch
+
+    n = 600
+    rng = np.random.default_rng(1)
+    poses = synth.loop_trajectory(n + 1, **synth.BENCH_LOOP)
+    lefts, rights = synth.stereo_torch(synth.bench_scene(), poses, device="cuda", batch=8)
+    torch.cuda.synchronize()
+    kw = dict(grid_step=10, anms_keep=4096, keyframe_min_inliers=2000, seed=20261003)
+    other = capi.Context(0)
+    a = capi.VisualOdometry(ctx, 1241, 376, 3, **kw)
+    b = capi.VisualOdometry(other, 1241, 376, 3, **kw)
+    assert a.init(lefts[0], rights[0]) == b.init(lefts[0], rights[0])
+    at, kfs, pieces = 1, 0, 0
+    while at <= n:
+        m = int(min(n + 1 - at, rng.integers(1, 90)))
+        ra = a.run_chunk(list(lefts[at:at + m]), list(rights[at:at + m]), pipeline=True)
+        rb = b.run_chunk(list(lefts[at:at + m]), list(rights[at:at + m]), pipeline=False)
+        assert ra[0] == rb[0] == 0 and ra[1] == rb[1] == m, (ra[0], rb[0], ra[1], rb[1], at)
+        for k in range(2, 7):
+            assert np.array_equal(ra[k], rb[k]), f"output {k} differs in the piece of {m} frames from frame {at}"
+        kfs += int(ra[6].sum())
+        at += m
+        pieces += 1
+    a2, a3 = a.reference()
+    b2, b3 = b.reference()
+    assert np.array_equal(a2, b2) and np.array_equal(a3, b3)
+    assert 100 < kfs < n - 100 and pieces > 8
+    a.close()
+    b.close()
+    other.close()
