@@ -48,7 +48,7 @@ sys.path.insert(0, ROOT)
 
 W, H, C = 1241, 376, 3
 PYR_BYTES = 619930 * C    # sum of the 4 level sizes
-LK_PMC_JSON = os.path.join(ROOT, "profiles", "r03_lk_pmc_{kpts}.json")   # one per keypoint count (4096, 8192)
+LK_PMC_JSON = os.path.join(ROOT, "profiles", "r04_lk_pmc_{kpts}.json")   # one per keypoint count (4096, 8192)
 
 
 def lk_algorithmic_bytes(n_pts: int) -> int:
