@@ -173,9 +173,12 @@ int svo_ctx_destroy(svo_ctx *ctx)
             (void)hipEventDestroy(pr.first);
             (void)hipEventDestroy(pr.second);
         }
+    if (ctx->orb_cache)
+        svo_orb_destroy(ctx->orb_cache);  // svo_orb_extract's cached extractor
+    ctx->orb_cache = nullptr;
     DevBuf *bufs[] = {&ctx->s_img, &ctx->s_a, &ctx->s_b, &ctx->s_c, &ctx->s_d, &ctx->s_e,
                       &ctx->s_f,   &ctx->s_g, &ctx->w_a, &ctx->w_b, &ctx->w_c, &ctx->w_d,
-                      &ctx->w_e};
+                      &ctx->w_e,   &ctx->orb_out};
     for (DevBuf *b : bufs)
         b->release();
     if (ctx->d_tickets)

@@ -498,18 +498,24 @@ extern "C" int svo_orb_extract(svo_ctx *ctx, const uint8_t *image, int w, int h,
 {
     SVO_CHECK_ARG(ctx && image && xy && desc && n && n_features > 0);
     SVO_CHECK_ARG(mem == SVO_MEM_HOST || mem == SVO_MEM_DEVICE);
-    svo_orb *o = nullptr;
-    int rc = svo_orb_create(ctx, w, h, c, n_features, fast_threshold, &o);
-    if (rc)
-        return rc;
+    SVO_HIP(hipSetDevice(ctx->device));
+    int rc;
+    const int key[5] = {w, h, c, n_features, fast_threshold};
+    if (!ctx->orb_cache || memcmp(key, ctx->orb_key, sizeof(key)) != 0) {  // the context keeps one extractor: rebuilt on a new shape
+        if (ctx->orb_cache)
+            svo_orb_destroy(ctx->orb_cache);
+        ctx->orb_cache = nullptr;
+        if ((rc = svo_orb_create(ctx, w, h, c, n_features, fast_threshold, &ctx->orb_cache)))
+            return rc;
+        memcpy(ctx->orb_key, key, sizeof(key));
+    }
+    svo_orb *o = ctx->orb_cache;
     const size_t nf = (size_t)n_features;
-    DevBuf out;
+    DevBuf &out = ctx->orb_out;
     const uint8_t *d_img = image;
     if ((rc = out.ensure(nf * (8 + 4 + 4 + 8 + 32) + 64)) ||
-        (mem == SVO_MEM_HOST && (rc = ctx->s_img.ensure((size_t)w * h * c)))) {
-        svo_orb_destroy(o);
+        (mem == SVO_MEM_HOST && (rc = ctx->s_img.ensure((size_t)w * h * c))))
         return rc;
-    }
     float *dxy = out.as<float>();
     int *doct = reinterpret_cast<int *>(dxy + 2 * nf);
     float *dresp = reinterpret_cast<float *>(doct + nf), *ddir = dresp + nf;
@@ -540,8 +546,6 @@ extern "C" int svo_orb_extract(svo_ctx *ctx, const uint8_t *image, int w, int h,
         (void)hipMemcpyAsync(desc, ddesc, (size_t)hn * 32, k, ctx->stream);
         e = hipStreamSynchronize(ctx->stream);
     }
-    out.release();
-    svo_orb_destroy(o);
     if (e != hipSuccess) {
         svo_set_error("svo_orb_extract -> %s", hipGetErrorString(e));
         return SVO_ERR_HIP;

@@ -15,6 +15,8 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <string>
+
 #include "svo_internal.h"
 
 namespace {
@@ -28,31 +30,41 @@ struct Rccl {
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 
+// the loader's message when librccl could not be brought in (dlerror() clears itself when read: kept here, read once)
+std::string &rccl_why()
+{
+    static std::string why;
+    return why;
+}
+
+// loaded once, whichever thread asks first (bench.py asks from a helper thread): a function-local static's initialiser is
+// thread-safe
 Rccl *rccl()
 {
-    static Rccl r;
-    static bool tried = false;
-    if (tried)
-        return r.handle ? &r : nullptr;
-    tried = true;
-    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-        r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-        if (r.handle)
-            break;
-    }
-    if (!r.handle)
-        return nullptr;
-    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.handle, "ncclGetUniqueId"));
-    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.handle, "ncclCommInitRank"));
-    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.handle, "ncclCommDestroy"));
-    r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.handle, "ncclAllGather"));
-    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.handle, "ncclGetErrorString"));
-    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather || !r.GetErrorString) {
-        dlclose(r.handle);
-        r.handle = nullptr;
-        return nullptr;
-    }
-    return &r;
+    static Rccl r = [] {
+        Rccl x;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            x.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (x.handle)
+                break;
+            const char *m = dlerror();
+            rccl_why() = m ? m : "no loader message";
+        }
+        if (!x.handle)
+            return x;
+        x.GetUniqueId = reinterpret_cast<decltype(x.GetUniqueId)>(dlsym(x.handle, "ncclGetUniqueId"));
+        x.CommInitRank = reinterpret_cast<decltype(x.CommInitRank)>(dlsym(x.handle, "ncclCommInitRank"));
+        x.CommDestroy = reinterpret_cast<decltype(x.CommDestroy)>(dlsym(x.handle, "ncclCommDestroy"));
+        x.AllGather = reinterpret_cast<decltype(x.AllGather)>(dlsym(x.handle, "ncclAllGather"));
+        x.GetErrorString = reinterpret_cast<decltype(x.GetErrorString)>(dlsym(x.handle, "ncclGetErrorString"));
+        if (!x.GetUniqueId || !x.CommInitRank || !x.CommDestroy || !x.AllGather || !x.GetErrorString) {
+            dlclose(x.handle);
+            x.handle = nullptr;
+            rccl_why() = "librccl lacks one of ncclGetUniqueId / CommInitRank / CommDestroy / AllGather / GetErrorString";
+        }
+        return x;
+    }();
+    return r.handle ? &r : nullptr;
 }
 
 #define SVO_NCCL(lib, call)                                                                              \
@@ -93,7 +105,7 @@ int svo_shard_unique_id(void *id128)
     SVO_CHECK_ARG(id128 != nullptr);
     Rccl *lib = rccl();
     if (!lib) {
-        svo_set_error("librccl could not be loaded (%s)", dlerror() ? dlerror() : "no loader message");
+        svo_set_error("librccl could not be loaded (%s)", rccl_why().c_str());
         return SVO_ERR_STATE;
     }
     static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
@@ -109,7 +121,7 @@ int svo_shard_comm_create(svo_ctx *ctx, int rank, int nranks, const void *id128,
     *out = nullptr;
     Rccl *lib = rccl();
     if (!lib) {
-        svo_set_error("librccl could not be loaded");
+        svo_set_error("librccl could not be loaded (%s)", rccl_why().c_str());
         return SVO_ERR_STATE;
     }
     SVO_HIP(hipSetDevice(ctx->device));

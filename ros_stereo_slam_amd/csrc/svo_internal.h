@@ -109,6 +109,11 @@ struct svo_ctx {
     void *pinned = nullptr;  // small pinned host block for scalar read-backs
     size_t pinned_bytes = 0;
     hipEvent_t wait_ev = nullptr;  // svo_wait(): event polled by the host
+    // svo_orb_extract's extractor (work buffers, grey pyramid) and output staging, kept between calls of the same shape
+    // (round 4: a call used to build and free them -- 1 ms per frame of allocation around 0.3 ms of kernels)
+    struct svo_orb *orb_cache = nullptr;
+    int orb_key[5] = {0, 0, 0, 0, 0};  // w, h, c, n_features, fast threshold
+    DevBuf orb_out;
 };
 
 // Low-latency host wait for everything queued on the context's stream: records an event and
