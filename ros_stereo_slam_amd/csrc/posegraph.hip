@@ -208,7 +208,7 @@ __global__ __launch_bounds__(128) void pg_linearize_kernel(const double *__restr
 //   T x_seg + E_a C_l x_l + E_z C_z^T x_r = r_seg   =>   x_seg = y - Wl x_l - Wr x_r,
 //   y = T^-1 r_seg,  Wl = T^-1 E_a C_l,  Wr = T^-1 E_z C_z^T.
 
-constexpr int SEG_L = 128;  // regular separator spacing (rows)
+constexpr int SEG_L = 104;  // regular separator spacing (rows): a segment and its 13 right-hand sides live in LDS
 constexpr int TB = 48;      // tile of the dense reduced solve (8 block rows)
 
 // hand-off of LDS data between the lanes of the ONE wave a workgroup consists of
@@ -288,6 +288,7 @@ __device__ __forceinline__ double pg_readlane(double v, int src)  // src: a comp
 // Row r of the matrix lives in the registers of lane r (six lanes work, the others shadow lane 0); what a lane needs of
 // another row arrives through v_readlane, so the six pivot steps and the forward substitution of the inverse touch
 // neither LDS nor a barrier.
+template <bool WANT_L = true>
 __device__ inline bool wave_chol6_inv(double *sS, double *sL, double *sLi, int lane)
 {
     const int row = lane < 6 ? lane : 0;
@@ -324,10 +325,12 @@ __device__ inline bool wave_chol6_inv(double *sS, double *sL, double *sLi, int l
                 sacc -= pg_readlane(a[k], r) * (k >= row ? x[k] : 0.);
         x[r] = r < row ? 0. : sacc * rinv[r];
     }
-    if (lane < 6) {
+    if (lane < 6) {  // (sLi may be sS: every lane has read its row long ago)
+        if (WANT_L) {
 #pragma unroll
-        for (int c = 0; c < 6; c++)
-            sL[6 * lane + c] = c <= lane ? a[c] : 0.;
+            for (int c = 0; c < 6; c++)
+                sL[6 * lane + c] = c <= lane ? a[c] : 0.;
+        }
 #pragma unroll
         for (int r = 0; r < 6; r++)
             sLi[6 * r + lane] = x[r];
@@ -336,281 +339,234 @@ __device__ inline bool wave_chol6_inv(double *sS, double *sL, double *sLi, int l
     return ok;
 }
 
-// Two wavefronts per segment, one from each end (a "twisted" factorisation): wave 0 eliminates rows a .. m-1 downwards,
-// wave 1 rows z .. m+1 upwards -- the same block-tridiagonal Cholesky on the reversed chain --, both meet at the middle
-// row m, whose Schur complement takes a term from either side; then both substitute back outwards from m.  The serial
-// chain of a segment is half as long as with one wave walking all of it.  Outputs as before: y, Wl, Wr of every row,
-//   x_b = y_b - Wl_b x_l - Wr_b x_r.
-// Per row b of a half with direction d (+1 / -1): N_b = H[b+d][b] L_bb^-T (the coupling to the next row of the half, for
-// the last row: to m), z_b = L_bb^-1 (rhs_b - N_{b-d} z_{b-d}) for 7 columns [r | coupling to the half's own separator].
-// Scratch Li (L_bb^-1), Lsub (N_b) and Z7 (z_b) are written in the forward sweep and read back by the same wave in the
-// backward sweep.  status[0] != 0 marks a non-positive pivot (1 + block row).
-struct PgHalfLds {
-    double sS[36], sL[36], sLi[36], sSub[36], sC[36], sT[80], sZ[80], sX[80];
-};
-__global__ __launch_bounds__(128) void pg_segment_kernel(int nb, const int *__restrict__ seg_start,
-                                                         const int *__restrict__ seg_len,
-                                                         const double *__restrict__ Dg, const double *__restrict__ Cc,
-                                                         const double *__restrict__ rneg, double *Li, double *Lsub,
-                                                         double *Z7, double *__restrict__ Y, double *__restrict__ Wl,
-                                                         double *__restrict__ Wr, int *__restrict__ status)
+// A segment = a block-tridiagonal system T X = B with 13 right-hand sides  B = [r | E_a H[a][a-1] | E_z H[z][z+1]],
+// X = [y | Wl | Wr].  Solved by BLOCK CYCLIC REDUCTION in LDS, one workgroup of 16 waves per segment: at level l (stride
+// s = 2^l) the rows q = s, 3s, 5s, ... (1-based) are eliminated -- all of them at once, a wave per row -- into their
+// neighbours q - s and q + s, which stay; log2(n) + 1 levels down, the same up for the substitution.  (Rounds 1-3 walked
+// a segment's rows one after the other, from both ends towards the middle: a serial chain of n / 2 block rows of
+// ~2.3 us, 170 us for the 100-row segments of a KITTI-sized graph; the levels are 7 + 7 steps of ~1-2 us.)  It is still a
+// Cholesky factorisation of T under a symmetric permutation (odd-even nested dissection): Schur complements of positive
+// definite blocks, every sum in a fixed order.
+//   eliminate q:  D_q = L L^T;  G-_q = L^-1 H[q][q-s],  G+_q = L^-1 H[q][q+s],  GB_q = L^-1 B_q
+//   into p = q -/+ s:  D_p -= G^T G,  B_p -= G^T GB,  and the new coupling  H[p+2s][p] = -G+_{p+s}^T G-_{p+s}
+//   substitute:  X_q = L^-T (GB_q - G-_q X_{q-s} - G+_q X_{q+s})
+// Row slot in LDS (doubles): D -> L^-1 [36] | F = H[q+s][q] -> G+ [36] | G- [36] | B -> GB -> X [6 x 13].
+constexpr int BCR_ROW = 186, BCR_F = 36, BCR_GM = 72, BCR_B = 108, BCR_WAVES = 16;
+constexpr int BCR_MAX_ROWS = (160 * 1024 - 256) / (BCR_ROW * 8);  // 110 rows of LDS
+
+__global__ __launch_bounds__(BCR_WAVES * 64) void pg_segment_kernel(int nb, const int *__restrict__ seg_start,
+                                                                    const int *__restrict__ seg_len,
+                                                                    const double *__restrict__ Dg,
+                                                                    const double *__restrict__ Cc,
+                                                                    const double *__restrict__ rneg,
+                                                                    double *__restrict__ Y, double *__restrict__ Wl,
+                                                                    double *__restrict__ Wr, int *__restrict__ status)
 {
-    __shared__ PgHalfLds sH[2];
-    __shared__ double sXm[80];  // x of the middle row, 13 columns [y | Wl | Wr], layout [6][13]
+    extern __shared__ double sm[];
     __shared__ int s_fail;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    PgHalfLds &S = sH[wave];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int a = seg_start[blockIdx.x], n = seg_len[blockIdx.x], z = a + n - 1;
-    const int m = a + n / 2;                      // the middle row: halves a .. m-1 and m+1 .. z
-    const int d = wave == 0 ? 1 : -1;
-    const int first = wave == 0 ? a : z;          // the half's first row (next to its separator)
-    const int cnt = wave == 0 ? m - a : z - m;    // its rows
-    const int i = lane / 6, j = lane - 6 * i;
-    const bool act = lane < 36;
-    const bool has_sep = wave == 0 ? a > 0 : z < nb - 1;  // the separator beside the half's first row exists
-    const int r7 = lane / 7, c7 = lane - 7 * r7;
-    if (threadIdx.x == 0)
+    if (tid == 0)
         s_fail = 0;
-    __syncthreads();
-    // H[p][q] for |p - q| = 1, entry (i, j): Cc[q] (p = q + 1) or Cc[p]^T (q = p + 1)
-    auto Hoff = [&](int p, int q, int ii, int jj) -> double {
-        return p > q ? Cc[(size_t)q * 36 + 6 * ii + jj] : Cc[(size_t)p * 36 + 6 * jj + ii];
-    };
-    // ---- forward sweep of this wave's half: 7 columns [r | coupling to the half's separator (first row only)] ----
-    // The rows of a half are a serial chain: the next row's blocks are requested while this row is worked on (their load
-    // latency was a third of a row's time).
-    bool failed = false;
-    double nDg = 0., nC = 0., nR = 0.;
-    if (cnt > 0) {
-        nDg = act ? Dg[(size_t)first * 36 + lane] : 0.;
-        nC = act ? Hoff(first + d, first, i, j) : 0.;
-        nR = lane < 42 ? (c7 == 0 ? rneg[(size_t)first * 6 + r7] : (has_sep ? Hoff(first, first - d, r7, c7 - 1) : 0.)) : 0.;
-    }
-    for (int k = 0; k < cnt; k++) {
-        const int b = first + d * k;
-        const double cDg = nDg, cC = nC, cR = nR;
-        if (k + 1 < cnt) {
-            const int bn = b + d;
-            nDg = act ? Dg[(size_t)bn * 36 + lane] : 0.;
-            nC = act ? Hoff(bn + d, bn, i, j) : 0.;
-            nR = lane < 42 && c7 == 0 ? rneg[(size_t)bn * 6 + r7] : 0.;
-        }
-        if (act) {
-            double sv = cDg;
-            if (k > 0) {
-#pragma unroll
-                for (int t = 0; t < 6; t++)
-                    sv -= S.sSub[6 * i + t] * S.sSub[6 * j + t];
-            }
-            S.sS[lane] = sv;
-            S.sC[lane] = cC;  // the coupling to the next row of the half (the last row's: to m)
-        }
-        if (lane < 42) {
-            double v = cR;
-            if (k > 0) {
-#pragma unroll
-                for (int t = 0; t < 6; t++)
-                    v -= S.sSub[6 * r7 + t] * S.sZ[7 * t + c7];
-            }
-            S.sT[lane] = v;
-        }
-        wave_sync();
-        if (!wave_chol6_inv(S.sS, S.sL, S.sLi, lane)) {
-            if (lane == 0) {
-                atomicMax(status, 1 + b);
-                s_fail = 1;
-            }
-            failed = true;
-            break;
-        }
-        if (act) {
-            Li[(size_t)b * 36 + lane] = S.sLi[lane];
-            double v = 0;  // N_b = H[b+d][b] L_bb^-T
-#pragma unroll
-            for (int t = 0; t < 6; t++)
-                v += S.sC[6 * i + t] * S.sLi[6 * j + t];
-            Lsub[(size_t)b * 36 + lane] = v;
-            S.sS[lane] = v;  // parked; becomes sSub after the z update below has read the old sSub
-        }
-        double zv = 0;
-        if (lane < 42) {
-#pragma unroll
-            for (int t = 0; t < 6; t++)
-                zv += S.sLi[6 * r7 + t] * S.sT[7 * t + c7];
-            Z7[(size_t)b * 42 + lane] = zv;
-        }
-        wave_sync();
-        if (lane < 42)
-            S.sZ[lane] = zv;
-        if (act)
-            S.sSub[lane] = S.sS[lane];
-        wave_sync();
-    }
-    (void)failed;
-    __syncthreads();  // both halves are factorised (or one has failed): sSub = N of the row beside m, sZ = its z
-    if (s_fail)
-        return;
-    // ---- the middle row, by wave 0: Schur complement with a term from either side, 13 right-hand sides ----
-    if (wave == 0) {
-        const PgHalfLds &U = sH[0], &D = sH[1];
-        const bool hu = m > a, hd = z > m;
-        if (act) {
-            double sv = Dg[(size_t)m * 36 + lane];
-#pragma unroll
-            for (int t = 0; t < 6; t++) {
-                if (hu)
-                    sv -= U.sSub[6 * i + t] * U.sSub[6 * j + t];
-                if (hd)
-                    sv -= D.sSub[6 * i + t] * D.sSub[6 * j + t];
-            }
-            S.sS[lane] = sv;
-        }
-        for (int e = lane; e < 78; e += 64) {
-            const int r = e / 13, c = e - 13 * r;
-            double v;
-            if (c == 0) {
-                v = rneg[(size_t)m * 6 + r];
-#pragma unroll
-                for (int t = 0; t < 6; t++) {
-                    if (hu)
-                        v -= U.sSub[6 * r + t] * U.sZ[7 * t];
-                    if (hd)
-                        v -= D.sSub[6 * r + t] * D.sZ[7 * t];
-                }
-            } else if (c < 7) {  // Wl: the left separator's coupling, directly (m == a) or through the upper half
-                v = !hu && a > 0 ? Hoff(m, m - 1, r, c - 1) : 0.;
-                if (hu) {
-#pragma unroll
-                    for (int t = 0; t < 6; t++)
-                        v -= U.sSub[6 * r + t] * U.sZ[7 * t + c];
-                }
-            } else {             // Wr: the right separator's, directly (m == z) or through the lower half
-                v = !hd && z < nb - 1 ? Hoff(m, m + 1, r, c - 7) : 0.;
-                if (hd) {
-#pragma unroll
-                    for (int t = 0; t < 6; t++)
-                        v -= D.sSub[6 * r + t] * D.sZ[7 * t + (c - 6)];
-                }
-            }
-            sXm[e] = v;  // right-hand sides for now
-        }
-        wave_sync();
-        if (!wave_chol6_inv(S.sS, S.sL, S.sLi, lane)) {
-            if (lane == 0) {
-                atomicMax(status, 1 + m);
-                s_fail = 1;
-            }
-        } else {
-            double t1[2];
-            for (int q = 0, e = lane; e < 78; e += 64, q++) {  // L^-1 rhs
-                const int r = e / 13, c = e - 13 * r;
-                double v = 0;
-#pragma unroll
-                for (int t = 0; t < 6; t++)
-                    v += S.sLi[6 * r + t] * sXm[13 * t + c];
-                t1[q] = v;
-            }
-            wave_sync();
-            for (int q = 0, e = lane; e < 78; e += 64, q++)
-                S.sT[e] = t1[q];
-            wave_sync();
-            for (int q = 0, e = lane; e < 78; e += 64, q++) {  // L^-T (L^-1 rhs)
-                const int r = e / 13, c = e - 13 * r;
-                double v = 0;
-#pragma unroll
-                for (int t = 0; t < 6; t++)
-                    v += S.sLi[6 * t + r] * S.sT[13 * t + c];
-                t1[q] = v;
-            }
-            wave_sync();
-            for (int q = 0, e = lane; e < 78; e += 64, q++) {
-                const int r = e / 13, c = e - 13 * r;
-                const double v = t1[q];
-                sXm[e] = v;
-                if (c == 0)
-                    Y[(size_t)m * 6 + r] = v;
-                else if (c < 7)
-                    Wl[(size_t)m * 36 + 6 * r + (c - 1)] = v;
-                else
-                    Wr[(size_t)m * 36 + 6 * r + (c - 7)] = v;
-            }
-        }
-    }
-    // the scratch written in the forward sweep is read back below by other lanes of the same wave
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    __syncthreads();
-    if (s_fail)
-        return;
-    // ---- backward sweep of this wave's half, outwards from m: x_b = L_bb^-T (z_b - N_b^T x_{b+d}), 13 columns ----
-    for (int e = lane; e < 78; e += 64)
-        S.sX[e] = sXm[e];
-    wave_sync();
-    // z of the 13 columns of row b: [r | this half's separator columns]; the other separator's columns start from zero
-    auto zval = [&](int b, int e) -> double {
-        const int r = e / 13, c = e - 13 * r;
-        if (e >= 78)
-            return 0.;
-        if (c == 0)
-            return Z7[(size_t)b * 42 + 7 * r];
-        if (c < 7)
-            return wave == 0 ? Z7[(size_t)b * 42 + 7 * r + c] : 0.;
-        return wave == 1 ? Z7[(size_t)b * 42 + 7 * r + (c - 6)] : 0.;
-    };
-    double nLi = 0., nSub = 0., nZa = 0., nZb = 0.;
-    if (cnt > 0) {
-        const int bl = first + d * (cnt - 1);
-        nLi = act ? Li[(size_t)bl * 36 + lane] : 0.;
-        nSub = act ? Lsub[(size_t)bl * 36 + lane] : 0.;
-        nZa = zval(bl, lane);
-        nZb = zval(bl, lane + 64);
-    }
-    for (int k = cnt - 1; k >= 0; k--) {
-        const int b = first + d * k;
-        const double cZ[2] = {nZa, nZb};
-        if (act) {
-            S.sLi[lane] = nLi;
-            S.sSub[lane] = nSub;
-        }
-        if (k > 0) {  // the row after this one, in flight while this one is combined
-            const int bn = b - d;
-            nLi = act ? Li[(size_t)bn * 36 + lane] : 0.;
-            nSub = act ? Lsub[(size_t)bn * 36 + lane] : 0.;
-            nZa = zval(bn, lane);
-            nZb = zval(bn, lane + 64);
-        }
-        wave_sync();
-        for (int q = 0, e = lane; e < 78; e += 64, q++) {
-            const int r = e / 13, c = e - 13 * r;
-            double v = cZ[q];
-#pragma unroll
-            for (int t = 0; t < 6; t++)
-                v -= S.sSub[6 * t + r] * S.sX[13 * t + c];  // - N_b^T x_{b+d}
-            S.sT[e] = v;
-        }
-        wave_sync();
-        double xv[2];
-        for (int q = 0, e = lane; e < 78; e += 64, q++) {
-            const int r = e / 13, c = e - 13 * r;
-            double v = 0;
-#pragma unroll
-            for (int t = 0; t < 6; t++)
-                v += S.sLi[6 * t + r] * S.sT[13 * t + c];  // L^-T
-            xv[q] = v;
-        }
-        wave_sync();
-        for (int q = 0, e = lane; e < 78; e += 64, q++) {
-            const int r = e / 13, c = e - 13 * r;
-            const double v = xv[q];
-            S.sX[e] = v;
+    for (int e = tid; e < n * BCR_ROW; e += BCR_WAVES * 64) {
+        const int p = e / BCR_ROW, k = e - p * BCR_ROW, b = a + p;
+        double v = 0.;
+        if (k < BCR_F)
+            v = Dg[(size_t)b * 36 + k];
+        else if (k < BCR_GM)
+            v = p < n - 1 ? Cc[(size_t)b * 36 + (k - BCR_F)] : 0.;  // H[b+1][b]
+        else if (k >= BCR_B) {
+            const int r = (k - BCR_B) / 13, c = (k - BCR_B) - 13 * r;
             if (c == 0)
-                Y[(size_t)b * 6 + r] = v;
+                v = rneg[(size_t)b * 6 + r];
             else if (c < 7)
-                Wl[(size_t)b * 36 + 6 * r + (c - 1)] = v;
+                v = p == 0 && a > 0 ? Cc[(size_t)(a - 1) * 36 + 6 * r + (c - 1)] : 0.;  // H[a][a-1]
             else
-                Wr[(size_t)b * 36 + 6 * r + (c - 7)] = v;
+                v = p == n - 1 && z < nb - 1 ? Cc[(size_t)z * 36 + 6 * (c - 7) + r] : 0.;  // H[z][z+1] = Cc[z]^T
         }
-        wave_sync();
+        sm[e] = v;
+    }
+    __syncthreads();
+    int levels = 0;
+    for (int s = 1; s <= n; s <<= 1, levels++) {
+        // ---- eliminate the rows q = s (2 t + 1): factor, and the three products with L^-1 (150 entries over the lanes) ----
+        const int cnt = (n / s + 1) / 2;
+        for (int t = wave; t < cnt; t += BCR_WAVES) {
+            const int q = s * (2 * t + 1);
+            double *Q = sm + (q - 1) * BCR_ROW;
+            const bool hl = q > s, hr = q + s <= n;
+            if (!wave_chol6_inv<false>(Q, nullptr, Q, lane)) {
+                if (lane == 0) {
+                    atomicMax(status, a + q);  // 1 + block row
+                    s_fail = 1;
+                }
+                continue;
+            }
+            const double *Fl = sm + (hl ? q - s - 1 : q - 1) * BCR_ROW + BCR_F;  // H[q][q-s], kept by the left neighbour
+            double out[3];
+#pragma unroll
+            for (int k3 = 0; k3 < 3; k3++) {
+                const int e = lane + 64 * k3;
+                // out = sum_t Linv[i][t] src[t * st]  (Linv is lower triangular with zeros above)
+                int i, st;
+                const double *src;
+                if (e < 36) {  // G- = Linv H[q][q-s]
+                    i = e / 6;
+                    src = Fl + (e - 6 * i);
+                    st = 6;
+                } else if (e < 72) {  // G+ = Linv F_q^T
+                    i = (e - 36) / 6;
+                    src = Q + BCR_F + 6 * ((e - 36) - 6 * i);
+                    st = 1;
+                } else {  // GB = Linv B
+                    i = (e - 72) / 13;
+                    src = Q + BCR_B + ((e - 72) - 13 * i);
+                    st = 13;
+                }
+                double acc = 0.;
+                if (e < 150) {
+#pragma unroll
+                    for (int u = 0; u < 6; u++)
+                        acc = fma(Q[6 * i + u], src[u * st], acc);
+                }
+                out[k3] = acc;
+            }
+            wave_sync();  // F_q and B_q have been read by every lane
+#pragma unroll
+            for (int k3 = 0; k3 < 3; k3++) {
+                const int e = lane + 64 * k3;
+                if (e < 36) {
+                    if (hl)
+                        Q[BCR_GM + e] = out[k3];
+                } else if (e < 72) {
+                    if (hr)
+                        Q[BCR_F + (e - 36)] = out[k3];
+                } else if (e < 150)
+                    Q[BCR_B + (e - 72)] = out[k3];
+            }
+        }
+        __syncthreads();
+        if (s_fail)
+            return;
+        // ---- into the rows that stay, p = 2 s (t + 1): every entry of D_p, B_p and the new coupling is a lane's own ----
+        const int cnt2 = n / (2 * s);
+        for (int t = wave; t < cnt2; t += BCR_WAVES) {
+            const int p = 2 * s * (t + 1);
+            double *P = sm + (p - 1) * BCR_ROW;
+            const bool hr = p + s <= n, hn = p + 2 * s <= n;
+            const double *Gl = sm + (p - s - 1) * BCR_ROW;                  // the eliminated row on the left: its G+ is ours
+            const double *Gr = sm + ((hr ? p + s : p - s) - 1) * BCR_ROW;   // on the right: its G-
+#pragma unroll
+            for (int k3 = 0; k3 < 3; k3++) {
+                const int e = lane + 64 * k3;
+                if (e >= 150)
+                    continue;
+                // out = base - sum_t A1[6 t] B1[t * s1] - sum_t A2[6 t] B2[t * s2]
+                double base;
+                const double *A1, *B1, *A2, *B2;
+                int s1, dst;
+                bool left = true, right = hr;
+                if (e < 36) {  // D_p[i][j]
+                    const int i = e / 6, j = e - 6 * i;
+                    dst = e;
+                    A1 = Gl + BCR_F + i, B1 = Gl + BCR_F + j, A2 = Gr + BCR_GM + i, B2 = Gr + BCR_GM + j;
+                    s1 = 6;
+                } else if (e < 72) {  // the coupling to the next row that stays: H[p+2s][p][i][j] = -sum_t G+[t][i] G-[t][j]
+                    const int i = (e - 36) / 6, j = (e - 36) - 6 * i;
+                    dst = BCR_F + (e - 36);
+                    A1 = A2 = Gr + BCR_F + i, B1 = B2 = Gr + BCR_GM + j;
+                    s1 = 6;
+                    left = false;
+                    right = hn;
+                } else {  // B_p[i][c]
+                    const int i = (e - 72) / 13, c = (e - 72) - 13 * i;
+                    dst = BCR_B + (e - 72);
+                    A1 = Gl + BCR_F + i, B1 = Gl + BCR_B + c, A2 = Gr + BCR_GM + i, B2 = Gr + BCR_B + c;
+                    s1 = 13;
+                }
+                base = e >= 36 && e < 72 ? 0. : P[dst];
+                double acc = 0.;
+                if (left) {
+#pragma unroll
+                    for (int u = 0; u < 6; u++)
+                        acc = fma(A1[6 * u], B1[u * s1], acc);
+                }
+                double acc2 = 0.;
+                if (right) {
+#pragma unroll
+                    for (int u = 0; u < 6; u++)
+                        acc2 = fma(A2[6 * u], B2[u * s1], acc2);
+                }
+                if (e < 36 || e >= 72 || hn)
+                    P[dst] = (base - acc) - acc2;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- substitution, the levels upwards: X_q = L^-T (GB_q - G-_q X_{q-s} - G+_q X_{q+s}), 6 x 13 ----
+    for (int lev = levels - 1; lev >= 0; lev--) {
+        const int s = 1 << lev, cnt = (n / s + 1) / 2;
+        for (int t = wave; t < cnt; t += BCR_WAVES) {
+            const int q = s * (2 * t + 1), b = a + q - 1;
+            double *Q = sm + (q - 1) * BCR_ROW;
+            const bool hl = q > s, hr = q + s <= n;
+            const double *Xl = sm + ((hl ? q - s : q) - 1) * BCR_ROW + BCR_B;
+            const double *Xr = sm + ((hr ? q + s : q) - 1) * BCR_ROW + BCR_B;
+            double v[2];
+#pragma unroll
+            for (int k2 = 0; k2 < 2; k2++) {
+                const int e = lane + 64 * k2;
+                double acc = 0.;
+                if (e < 78) {
+                    const int i = e / 13, c = e - 13 * i;
+                    acc = Q[BCR_B + e];
+                    if (hl) {
+#pragma unroll
+                        for (int u = 0; u < 6; u++)
+                            acc = fma(-Q[BCR_GM + 6 * i + u], Xl[13 * u + c], acc);
+                    }
+                    if (hr) {
+#pragma unroll
+                        for (int u = 0; u < 6; u++)
+                            acc = fma(-Q[BCR_F + 6 * i + u], Xr[13 * u + c], acc);
+                    }
+                }
+                v[k2] = acc;
+            }
+#pragma unroll
+            for (int k2 = 0; k2 < 2; k2++)
+                if (lane + 64 * k2 < 78)
+                    Q[BCR_B + lane + 64 * k2] = v[k2];  // a lane's own entries
+            wave_sync();
+#pragma unroll
+            for (int k2 = 0; k2 < 2; k2++) {
+                const int e = lane + 64 * k2;
+                double acc = 0.;
+                if (e < 78) {
+                    const int i = e / 13, c = e - 13 * i;
+#pragma unroll
+                    for (int u = 0; u < 6; u++)
+                        acc = fma(Q[6 * u + i], Q[BCR_B + 13 * u + c], acc);  // L^-T: Linv[u][i], zero for u < i
+                }
+                v[k2] = acc;
+            }
+            wave_sync();
+#pragma unroll
+            for (int k2 = 0; k2 < 2; k2++) {
+                const int e = lane + 64 * k2;
+                if (e < 78) {
+                    const int i = e / 13, c = e - 13 * i;
+                    Q[BCR_B + e] = v[k2];
+                    if (c == 0)
+                        Y[(size_t)b * 6 + i] = v[k2];
+                    else if (c < 7)
+                        Wl[(size_t)b * 36 + 6 * i + (c - 1)] = v[k2];
+                    else
+                        Wr[(size_t)b * 36 + 6 * i + (c - 7)] = v[k2];
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -704,117 +660,160 @@ __global__ __launch_bounds__(256) void pg_reduce_clear_kernel(double *__restrict
 }
 
 // ---- blocked dense Cholesky of the reduced system (lower triangle, row-major, ld = ldr) ------
-// step kb:  potf2: factor the diagonal tile (kb,kb) -> Lo, and its inverse -> Tinv[kb];
-//           update: every trailing tile (i,j), kb < j <= i: A_ij -= P_i P_j^T with
-//           P_i = A_i,kb * Tinv^T; the tile (i, kb+1) also stores P_i as the factor's block (i,kb).
+// Tile step kb:  every trailing tile (i, j), kb < j <= i:  A_ij -= P_i P_j^T with P_i = A_i,kb Tinv_kb^T (the tile
+//                (i, kb+1) also stores P_i as the factor's block (i, kb));
+//                the workgroup of the tile (kb+1, kb+1) goes on to factorise it in LDS -- the next step's diagonal tile --
+//                and leaves its factor in Lo and the factor's inverse in Tinv[kb+1].
+// ONE launch per tile step (round 3 had two: the critical path of a step was the diagonal tile's update followed, across a
+// launch boundary and a round trip through HBM, by its factorisation).  The first tile has a launch of its own.
 // Column kb of A is only read in step kb, the factor goes to a separate array: no races.
-__global__ __launch_bounds__(256) void pg_dense_potf2_kernel(const double *__restrict__ A, double *__restrict__ Lo,
-                                                             double *__restrict__ Tinv, int ldr, int kb,
-                                                             int *__restrict__ status, int status_base)
+
+// Cholesky of the 48 x 48 tile in sL (lower triangle; what is above the diagonal is never read) and the inverse of the
+// factor into sX (zeroed here).  Blocked by 6 inside the tile: eight steps of (1) Cholesky + inverse of the 6 x 6 diagonal
+// block by one wave (wave_chol6_inv, the segments' routine), (2) the panel below it, L21 = A21 L11^-T, an entry per thread,
+// (3) the trailing update A22 -= L21 L21^T as 3 x 3 blocks per thread on the 16 x 16 thread grid of the tile products.
+// The inverse grows with the factor, a block row per step: X[b][c] = -L_bb^-1 sum_{c <= k < b} L[b][k] X[k][c].  The sums
+// (they need the factor's block row b, final since step b-1, and the inverse's rows above) are formed by waves 1..3 WHILE
+// wave 0 is in the diagonal block's serial chain (1); the product with L_bb^-1 rides with the panel (2).  (Round 3 built the
+// inverse afterwards from inverted halves: 8 us of this routine's 22.)
+// sT: TB * TB / 4 doubles of scratch.  Returns (to every thread) 0 or 1 + the row of the first non-positive pivot.
+// -DPG_STAMPS: thread 0 of the first tile's workgroups leaves the 100 MHz clock at the phase boundaries (tools/pg_quick.sh)
+#ifdef PG_STAMPS
+__device__ long long pg_dbg[128];
+#define PGSTAMP(k)                                                                                                     \
+    do {                                                                                                               \
+        if (tid == 0 && dbg)                                                                                           \
+            pg_dbg[k] = wall_clock64();                                                                                \
+    } while (0)
+#else
+#define PGSTAMP(k) (void)dbg
+#endif
+__device__ __forceinline__ int pg_potf2_lds(bool dbg, double *sL, double *sX, double *sT, double *sS6, double *sL6, double *sLi6,
+                                            int *s_bad, int tid)
 {
-    // Blocked by 6 inside the 48 x 48 tile (LDS): eight steps of  (1) Cholesky + inverse of the 6 x 6 diagonal block by
-    // one wave (wave_chol6_inv, the segments' routine), (2) the panel below it, L21 = A21 L11^-T, an entry per thread,
-    // (3) the trailing update A22 -= L21 L21^T, six multiply-adds per entry.  Three barriers per step, 24 in all.
-    // (Right-looking by single columns -- the triangle in registers, a barrier per column -- was a chain of 48 steps of
-    // half a microsecond: 24 of this kernel's 35 us; with the tile in LDS and a square root + division + three barriers per
-    // column it had been 94 us.)
     constexpr int LD = TB + 1, NB6 = TB / 6;
-    __shared__ double sL[TB * LD], sX[TB * LD], sRd[TB], sT[TB * TB / 4];
-    __shared__ double sS6[36], sL6[36], sLi6[36];
-    __shared__ int s_bad;
-    const int tid = threadIdx.x;
-    for (int e = tid; e < TB * TB; e += 256) {
-        const int r = e / TB, c = e - TB * r;
-        sL[r * LD + c] = c <= r ? A[(size_t)(kb * TB + r) * ldr + kb * TB + c] : 0.;
-        sX[r * LD + c] = 0.;
-    }
+    const int tr = tid >> 4, tc = tid & 15;
+    for (int e = tid; e < TB * LD; e += 256)
+        sX[e] = 0.;
     if (tid == 0)
-        s_bad = 0;
+        *s_bad = 0;
     __syncthreads();
     for (int blk = 0; blk < NB6; blk++) {
         const int o = 6 * blk;
+        PGSTAMP(2 + 4 * blk);
         if (tid < 64) {  // (1) the diagonal block: L11 into the tile, L11^-1 into the inverse's diagonal block
             if (tid < 36) {
                 const int i = tid / 6, j = tid - 6 * i;
                 sS6[tid] = sL[(o + (i > j ? i : j)) * LD + o + (i > j ? j : i)];  // symmetric from the lower triangle
             }
             wave_sync();
-            if (!wave_chol6_inv(sS6, sL6, sLi6, tid) && tid == 0 && s_bad == 0)
-                s_bad = 1 + o;
+            if (!wave_chol6_inv(sS6, sL6, sLi6, tid) && tid == 0 && *s_bad == 0)
+                *s_bad = 1 + o;
             if (tid < 36) {
                 const int i = tid / 6, j = tid - 6 * i;
                 sL[(o + i) * LD + o + j] = sL6[tid];  // zero above the diagonal
                 sX[(o + i) * LD + o + j] = sLi6[tid];
             }
+        } else {  // meanwhile: Z[i][c] = sum_{k < o} L[o + i][k] X[k][c]  (X[k][c] = 0 for k < c)
+            for (int e = tid - 64; e < 6 * o; e += 192) {
+                const int i = e / o, c = e - o * i;
+                const double *pl = sL + (o + i) * LD, *px = sX + c;
+                double acc = 0.;
+#pragma unroll 6
+                for (int k = 0; k < o; k++)  // o is a multiple of 6
+                    acc = fma(pl[k], px[k * LD], acc);
+                sT[i * TB + c] = acc;
+            }
         }
         __syncthreads();
+        PGSTAMP(3 + 4 * blk);
         const int below = TB - o - 6;  // rows under the diagonal block
+        double pv = 0.;
         if (tid < below * 6) {         // (2) panel: (A21 L11^-T)[r][c] = sum_t A21[r][t] Li[c][t], t <= c
             const int r = o + 6 + tid / 6, c = tid % 6;
+#pragma unroll
+            for (int t = 0; t < 6; t++)
+                pv += t <= c ? sL[r * LD + o + t] * sLi6[6 * c + t] : 0.;
+        }
+        for (int e = 255 - tid; e < 6 * o; e += 256) {  // the inverse's block row: X[o + i][c] = -sum_{t <= i} Li[i][t] Z[t][c]
+            const int i = e / o, c = e - o * i;
             double acc = 0.;
 #pragma unroll
             for (int t = 0; t < 6; t++)
-                acc += t <= c ? sL[r * LD + o + t] * sLi6[6 * c + t] : 0.;
-            sT[tid] = acc;
+                acc -= t <= i ? sLi6[6 * i + t] * sT[t * TB + c] : 0.;
+            sX[(o + i) * LD + c] = acc;
         }
         __syncthreads();
         if (tid < below * 6)
-            sL[(o + 6 + tid / 6) * LD + o + tid % 6] = sT[tid];
+            sL[(o + 6 + tid / 6) * LD + o + tid % 6] = pv;
         __syncthreads();
-        const int ntri = below * (below + 1) / 2;
-        for (int e = tid; e < ntri; e += 256) {  // (3) trailing update, lower triangle of the rest
-            int r = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
-            while ((r + 1) * (r + 2) / 2 <= e)
-                r++;
-            while (r * (r + 1) / 2 > e)
-                r--;
-            const int c = e - r * (r + 1) / 2;
-            const double *pr = sL + (o + 6 + r) * LD + o, *pc = sL + (o + 6 + c) * LD + o;
-            double acc = 0.;
+        PGSTAMP(4 + 4 * blk);
+        if (3 * tc >= o + 6 && tc <= tr) {  // (3) trailing update: the 3 x 3 block (tr, tc) of the rest's lower triangle
+            const double *px = sL + (3 * tr) * LD + o, *py = sL + (3 * tc) * LD + o;
+            double acc[3][3] = {{0., 0., 0.}, {0., 0., 0.}, {0., 0., 0.}};
 #pragma unroll
-            for (int t = 0; t < 6; t++)
-                acc += pr[t] * pc[t];
-            sL[(o + 6 + r) * LD + o + 6 + c] -= acc;
+            for (int t = 0; t < 6; t++) {
+                const double x0 = px[t], x1 = px[LD + t], x2 = px[2 * LD + t];
+                const double y0 = py[t], y1 = py[LD + t], y2 = py[2 * LD + t];
+                acc[0][0] = fma(x0, y0, acc[0][0]);
+                acc[0][1] = fma(x0, y1, acc[0][1]);
+                acc[0][2] = fma(x0, y2, acc[0][2]);
+                acc[1][0] = fma(x1, y0, acc[1][0]);
+                acc[1][1] = fma(x1, y1, acc[1][1]);
+                acc[1][2] = fma(x1, y2, acc[1][2]);
+                acc[2][0] = fma(x2, y0, acc[2][0]);
+                acc[2][1] = fma(x2, y1, acc[2][1]);
+                acc[2][2] = fma(x2, y2, acc[2][2]);
+            }
+            // (a diagonal block's entries above the diagonal are written too: nobody reads them)
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+                for (int b2 = 0; b2 < 3; b2++)
+                    sL[(3 * tr + a) * LD + 3 * tc + b2] -= acc[a][b2];
         }
         __syncthreads();
     }
-    if (s_bad) {
-        if (tid == 0)
-            atomicMax(status, status_base + kb * TB + s_bad);
-        // keep going with whatever is there: the host reports the failure
-    }
+    PGSTAMP(50);
+    return *s_bad;
+}
+
+// the factor's diagonal tile kb and its inverse, from LDS to their arrays
+__device__ __forceinline__ void pg_store_factor_tile(const double *sL, const double *sX, double *__restrict__ Lo,
+                                                     double *__restrict__ Tinv, int ldr, int kb, int tid)
+{
+    constexpr int LD = TB + 1;
     for (int e = tid; e < TB * TB; e += 256) {
         const int r = e / TB, c = e - TB * r;
         Lo[(size_t)(kb * TB + r) * ldr + kb * TB + c] = c <= r ? sL[r * LD + c] : 0.;
-    }
-    // L^-1 by halves: the eight 6 x 6 diagonal blocks are inverted already (step 1 above), three levels put pairs of
-    // inverted halves together, X21 = -X22 (L21 X11), every entry of a product a thread's own dot product: two barriers
-    // per level.  (Forward substitution over the 48 rows -- four lanes per column, a hand-off per row -- was a chain of
-    // 48 x 12 steps: 20 us.)
-    (void)sRd;
-    for (int h = 6; h < TB; h *= 2) {  // halves of h rows -> inverted blocks of 2 h rows
-        const int pairs = TB / (2 * h), per = h * h;
-        for (int e = tid; e < pairs * per; e += 256) {  // T = L21 X11 (X11 lower triangular: k >= j)
-            const int pr = e / per, ij = e - pr * per, i = ij / h, j = ij - i * h, o = 2 * h * pr;
-            double acc = 0.;
-            for (int k = j; k < h; k++)
-                acc += sL[(o + h + i) * LD + o + k] * sX[(o + k) * LD + o + j];
-            sT[e] = acc;
-        }
-        __syncthreads();
-        for (int e = tid; e < pairs * per; e += 256) {  // X21 = -X22 T (X22 lower triangular: k <= i)
-            const int pr = e / per, ij = e - pr * per, i = ij / h, j = ij - i * h, o = 2 * h * pr;
-            double acc = 0.;
-            for (int k = 0; k <= i; k++)
-                acc -= sX[(o + h + i) * LD + o + h + k] * sT[pr * per + k * h + j];
-            sX[(o + h + i) * LD + o + j] = acc;
-        }
-        __syncthreads();
-    }
-    for (int e = tid; e < TB * TB; e += 256) {
-        const int r = e / TB, c = e - TB * r;
         Tinv[(size_t)kb * TB * TB + e] = c <= r ? sX[r * LD + c] : 0.;
     }
+}
+
+// the first diagonal tile (nothing to update before it)
+__global__ __launch_bounds__(256) void pg_dense_potf2_kernel(const double *__restrict__ A, double *__restrict__ Lo,
+                                                             double *__restrict__ Tinv, int ldr, int kb,
+                                                             int *__restrict__ status, int status_base)
+{
+    constexpr int LD = TB + 1;
+    __shared__ double sL[TB * LD], sX[TB * LD], sT[TB * TB / 4];
+    __shared__ double sS6[36], sL6[36], sLi6[36];
+    __shared__ int s_bad;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < TB * TB; e += 256) {
+        const int r = e / TB, c = e - TB * r;
+        sL[r * LD + c] = c <= r ? A[(size_t)(kb * TB + r) * ldr + kb * TB + c] : 0.;
+    }
+    const bool dbg = true;
+    PGSTAMP(0);
+    __syncthreads();
+    PGSTAMP(1);
+    const int bad = pg_potf2_lds(true, sL, sX, sT, sS6, sL6, sLi6, &s_bad, tid);
+    if (bad && tid == 0)
+        atomicMax(status, status_base + kb * TB + bad);  // keep going with whatever is there: the host reports the failure
+    pg_store_factor_tile(sL, sX, Lo, Tinv, ldr, kb, tid);
+    __syncthreads();
+    PGSTAMP(51);
 }
 
 // out[r][c] (-)= sum_k X[r][k] Y[c][k], k < kmax(c): a 3 x 3 block of the 48 x 48 result per thread (16 x 16 threads), so
@@ -831,30 +830,52 @@ __device__ __forceinline__ void pg_tile_mult(const double *sX, const double *sY,
             acc[a][b2] = 0;
     // TRI: Y is lower triangular (Y[c][k] = 0 for k > c): columns 3 tc .. 3 tc + 2 need k <= 3 tc + 2 only
     const int kend = TRI ? 3 * tc + 3 : TB;
-    for (int k = 0; k < kend; k++) {
-        const double x0 = sX[(3 * tr) * LD + k], x1 = sX[(3 * tr + 1) * LD + k], x2 = sX[(3 * tr + 2) * LD + k];
-        const double y0 = sY[(3 * tc) * LD + k], y1 = sY[(3 * tc + 1) * LD + k], y2 = sY[(3 * tc + 2) * LD + k];
-        acc[0][0] += x0 * y0;
-        acc[0][1] += x0 * y1;
-        acc[0][2] += x0 * y2;
-        acc[1][0] += x1 * y0;
-        acc[1][1] += x1 * y1;
-        acc[1][2] += x1 * y2;
-        acc[2][0] += x2 * y0;
-        acc[2][1] += x2 * y1;
-        acc[2][2] += x2 * y2;
+    const double *px = sX + (3 * tr) * LD, *py = sY + (3 * tc) * LD;
+    // three k at a time; the next three are on their way from LDS while these are multiplied (explicit fused
+    // multiply-adds: the library is built without contraction, and a step of this loop is 27 of them)
+    double x[3][3], y[3][3], nx[3][3], ny[3][3];
+    auto fetch = [&](int k, double (&fx)[3][3], double (&fy)[3][3]) {
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                fx[a][q] = px[a * LD + k + q];
+                fy[a][q] = py[a * LD + k + q];
+            }
+    };
+    fetch(0, x, y);
+    for (int k = 0; k < kend; k += 3) {
+        fetch(k + 3 < TB ? k + 3 : TB - 3, nx, ny);  // (past kend: fetched, not used)
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+                for (int b2 = 0; b2 < 3; b2++)
+                    acc[a][b2] = fma(x[a][q], y[b2][q], acc[a][b2]);
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                x[a][q] = nx[a][q];
+                y[a][q] = ny[a][q];
+            }
     }
 }
 
 // The forward substitution of the solve rides along: the workgroup of a diagonal tile (j, j) has the factor's block
 // L_j,kb = P_j at hand, forms y_kb = Tinv_kb b_kb (48 x 48, every such workgroup for itself) and takes L_j,kb y_kb off
 // b_j; the first of them leaves y_kb in `yout`.  The solve kernel is left with the last tile's y and the backward sweep.
-__global__ __launch_bounds__(256) void pg_dense_update_kernel(double *__restrict__ A, double *__restrict__ Lo,
-                                                              const double *__restrict__ Tinv, int ldr, int kb, int T,
-                                                              double *__restrict__ rhs, double *__restrict__ yout)
+// Workgroup 0 owns the tile (kb+1, kb+1): it keeps the updated tile in LDS and factorises it (see above).
+__global__ __launch_bounds__(256) void pg_dense_step_kernel(double *__restrict__ A, double *__restrict__ Lo,
+                                                            double *__restrict__ Tinv, int ldr, int kb,
+                                                            double *__restrict__ rhs, double *__restrict__ yout,
+                                                            int *__restrict__ status, int status_base)
 {
     __shared__ double sI[TB * (TB + 1)], sPi[TB * (TB + 1)], sPj[TB * (TB + 1)], sA[TB * (TB + 1)];
-    __shared__ double s_y[TB];
+    __shared__ double s_y[TB], s_b[TB];
+    __shared__ double sS6[36], sL6[36], sLi6[36];
+    __shared__ int s_bad;
     constexpr int LD = TB + 1;
     const int tid = threadIdx.x, tr = tid >> 4, tc = tid & 15;
     // linear tile index -> (i, j) with kb < j <= i < T
@@ -864,13 +885,27 @@ __global__ __launch_bounds__(256) void pg_dense_update_kernel(double *__restrict
         i++;
     }
     const int j = kb + 1 + t;
-    (void)T;
+    const bool diag = i == j, keep = !(diag && tc > tr);  // a diagonal tile: whole 3 x 3 blocks above it are skipped
+    const bool dbg = blockIdx.x == 0 && kb == 0;
+    PGSTAMP(60);
+    // the tile this workgroup updates: asked for now, used at the end
+    double old[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b2 = 0; b2 < 3; b2++)
+            old[a][b2] = keep ? A[(size_t)(i * TB + 3 * tr + a) * ldr + j * TB + 3 * tc + b2] : 0.;
     for (int e = tid; e < TB * TB; e += 256) {
         const int r = e / TB, c = e - TB * r;
         sI[r * LD + c] = c <= r ? Tinv[(size_t)kb * TB * TB + e] : 0.;  // lower triangular
         sA[r * LD + c] = A[(size_t)(i * TB + r) * ldr + kb * TB + c];
+        if (!diag)
+            sPj[r * LD + c] = A[(size_t)(j * TB + r) * ldr + kb * TB + c];  // A_j,kb for now
     }
+    if (diag && tid < TB)
+        s_b[tid] = rhs[kb * TB + tid];
     __syncthreads();
+    PGSTAMP(61);
     double acc[3][3];
     pg_tile_mult<true>(sA, sI, tr, tc, acc);  // P_i = A_i,kb * Tinv^T
 #pragma unroll
@@ -878,61 +913,90 @@ __global__ __launch_bounds__(256) void pg_dense_update_kernel(double *__restrict
 #pragma unroll
         for (int b2 = 0; b2 < 3; b2++)
             sPi[(3 * tr + a) * LD + 3 * tc + b2] = acc[a][b2];
+    if (!diag)
+        pg_tile_mult<true>(sPj, sI, tr, tc, acc);  // P_j = A_j,kb * Tinv^T: kept in registers until all have read A_j,kb
     __syncthreads();
-    if (i == j) {  // the right-hand side of block row j (see above); sI is the lower-triangular Tinv_kb
-        if (tid < TB) {
+    if (diag) {  // the right-hand side of block row j (see above); sI is the lower-triangular Tinv_kb; four lanes per row
+        const int rr = tid >> 2, part = tid & 3;
+        if (tid < 4 * TB) {
             double a = 0;
-            for (int c = 0; c <= tid; c++)
-                a += sI[tid * LD + c] * rhs[kb * TB + c];
-            s_y[tid] = a;
-            if (blockIdx.x == 0)
-                yout[kb * TB + tid] = a;
+#pragma unroll 4
+            for (int c = part; c < TB; c += 4)  // (zeros above the diagonal)
+                a += sI[rr * LD + c] * s_b[c];
+            a += __shfl_xor(a, 1, 64);
+            a += __shfl_xor(a, 2, 64);
+            if (part == 0) {
+                s_y[rr] = a;
+                if (blockIdx.x == 0)
+                    yout[kb * TB + rr] = a;
+            }
         }
         __syncthreads();
-        if (tid < TB) {
+        if (tid < 4 * TB) {
             double a = 0;
-            for (int c = 0; c < TB; c++)
-                a += sPi[tid * LD + c] * s_y[c];
-            rhs[j * TB + tid] -= a;
+#pragma unroll 4
+            for (int c = part; c < TB; c += 4)
+                a += sPi[rr * LD + c] * s_y[c];
+            a += __shfl_xor(a, 1, 64);
+            a += __shfl_xor(a, 2, 64);
+            if (part == 0)
+                rhs[j * TB + rr] -= a;
         }
-    }
-    if (i != j) {
-        for (int e = tid; e < TB * TB; e += 256) {
-            const int r = e / TB, c = e - TB * r;
-            sA[r * LD + c] = A[(size_t)(j * TB + r) * ldr + kb * TB + c];
-        }
-        __syncthreads();
-        pg_tile_mult<true>(sA, sI, tr, tc, acc);
+    } else {
 #pragma unroll
         for (int a = 0; a < 3; a++)
 #pragma unroll
             for (int b2 = 0; b2 < 3; b2++)
-                sPj[(3 * tr + a) * LD + 3 * tc + b2] = acc[a][b2];
+                sPj[(3 * tr + a) * LD + 3 * tc + b2] = acc[a][b2];  // every thread has read its rows of A_j,kb (barrier above)
         __syncthreads();
     }
-    const double *Pj = i == j ? sPi : sPj;
-    if (!(i == j && tc > tr)) {  // a diagonal tile keeps its lower triangle only (whole 3 x 3 blocks above it are skipped)
+    const double *Pj = diag ? sPi : sPj;
+    PGSTAMP(62);
+    if (keep)
         pg_tile_mult<false>(sPi, Pj, tr, tc, acc);
-#pragma unroll
-        for (int a = 0; a < 3; a++)
-#pragma unroll
-            for (int b2 = 0; b2 < 3; b2++) {
-                const int r = 3 * tr + a, c = 3 * tc + b2;
-                if (i == j && c > r)
-                    continue;
-                A[(size_t)(i * TB + r) * ldr + j * TB + c] -= acc[a][b2];
-            }
-    }
+    PGSTAMP(63);
     if (j == kb + 1)
         for (int e = tid; e < TB * TB; e += 256) {
             const int r = e / TB, c = e - TB * r;
             Lo[(size_t)(i * TB + r) * ldr + kb * TB + c] = sPi[r * LD + c];
         }
+    if (blockIdx.x != 0) {
+        if (keep) {
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+                for (int b2 = 0; b2 < 3; b2++) {
+                    const int r = 3 * tr + a, c = 3 * tc + b2;
+                    if (diag && c > r)
+                        continue;
+                    A[(size_t)(i * TB + r) * ldr + j * TB + c] = old[a][b2] - acc[a][b2];
+                }
+        }
+        return;
+    }
+    // workgroup 0: the tile (kb+1, kb+1) has had its last update -- it stays in LDS and is factorised here
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b2 = 0; b2 < 3; b2++)
+            sA[(3 * tr + a) * LD + 3 * tc + b2] = keep ? old[a][b2] - acc[a][b2] : 0.;
+    __syncthreads();  // also: sI, sPj and the right-hand side's use of sPi are over
+    PGSTAMP(64);
+    const int bad = pg_potf2_lds(false, sA, sPj, sI, sS6, sL6, sLi6, &s_bad, tid);
+    if (bad && tid == 0)
+        atomicMax(status, status_base + (kb + 1) * TB + bad);
+    PGSTAMP(65);
+    pg_store_factor_tile(sA, sPj, Lo, Tinv, ldr, kb + 1, tid);
+    __syncthreads();
+    PGSTAMP(66);
 }
 
-// L y = b, L^T x = y with the tiles' inverses; one workgroup of 384 threads = 48 rows x 8 column parts (the eight
-// lanes of a row read 64 contiguous bytes of the factor per step and combine their partial sums with three shuffles),
-// the vector lives in LDS; two barriers per tile step
+// L^T x = y with the tiles' inverses (the forward substitution came with the factorisation, except for the last tile).
+// One workgroup of 384 threads = 48 columns x 8 row parts; the vector and the running sums  acc_kb = sum_{i > kb}
+// L_i,kb^T x_i  live in LDS.  Tile step i: x_i = Tinv_i^T (y_i - acc_i), then x_i's terms go onto the acc of every tile
+// above -- the tile (i, i-1), the only one the next step waits for, first; it and Tinv_{i-1} are asked for one step ahead
+// (six loads per thread each), the others in batches of six loads.  (Round 3 walked each column panel row by row, a
+// dependent load per row: 94 us for 480 rows; two barriers per tile step as before.)
 constexpr int PG_SOLVE_THREADS = TB * 8;
 __device__ __forceinline__ double pg_sum8(double v)
 {
@@ -945,14 +1009,33 @@ __global__ __launch_bounds__(PG_SOLVE_THREADS) void pg_dense_solve_kernel(const 
                                                                           const double *__restrict__ Tinv, int ldr, int T,
                                                                           const double *__restrict__ rhs, double *x)
 {
-    extern __shared__ double sv[];  // ldr entries + TB
-    double *st = sv + ldr;
+    extern __shared__ double sv[];  // ldr entries (y, then x) + ldr (acc) + TB
+    double *sacc = sv + ldr, *st = sacc + ldr;
     const int tid = threadIdx.x;
     const int r = tid >> 3, part = tid & 7;
-    // forward: y of the tiles 0 .. T-2 came with the factorisation (pg_dense_update_kernel left them in x, and took their
+    // the eight lanes of column r take the rows part, part + 8, ... of a tile
+    auto load_tile = [&](int i, int kb, double (&l)[6]) {
+#pragma unroll
+        for (int q = 0; q < 6; q++)
+            l[q] = Lo[(size_t)(i * TB + part + 8 * q) * ldr + kb * TB + r];
+    };
+    auto load_tinv_t = [&](int kb, double (&l)[6]) {  // column r of Tinv_kb, rows r + part + 8 q (zero above the diagonal)
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            const int c = r + part + 8 * q;
+            l[q] = c < TB ? Tinv[(size_t)kb * TB * TB + c * TB + r] : 0.;
+        }
+    };
+    double nti[6], ntile[6];
+    load_tinv_t(T - 1, nti);
+    if (T > 1)
+        load_tile(T - 1, T - 2, ntile);
+    // forward: y of the tiles 0 .. T-2 came with the factorisation (pg_dense_step_kernel left them in x, and took their
     // terms off the later blocks of rhs); the last tile's y = Tinv (its block of rhs) here
-    for (int e = tid; e < ldr; e += PG_SOLVE_THREADS)
+    for (int e = tid; e < ldr; e += PG_SOLVE_THREADS) {
         sv[e] = e < (T - 1) * TB ? x[e] : rhs[e];
+        sacc[e] = 0.;
+    }
     __syncthreads();
     {
         const int kb = T - 1;
@@ -964,28 +1047,59 @@ __global__ __launch_bounds__(PG_SOLVE_THREADS) void pg_dense_solve_kernel(const 
         for (int c = part; c <= r; c += 8)
             a2 += ti[c] * st[c];
         a2 = pg_sum8(a2);
+        __syncthreads();
         if (part == 0)
             sv[kb * TB + r] = a2;
-        __syncthreads();
     }
-    for (int kb = T - 1; kb >= 0; kb--) {  // backward: x_kb = Tinv^T (y_kb - sum_{i>kb} L_i,kb^T x_i)
-        // column r of the panel below the tile: rows (kb+1) TB .. T TB; the eight parts take every eighth row
-        double acc = 0;
-        for (int rr = (kb + 1) * TB + part; rr < T * TB; rr += 8)
-            acc += Lo[(size_t)rr * ldr + kb * TB + r] * sv[rr];
-        acc = pg_sum8(acc);
+    for (int i = T - 1; i >= 0; i--) {  // backward: x_i = Tinv_i^T (y_i - acc_i)
+        double ti[6], tile[6];
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            ti[q] = nti[q];
+            tile[q] = ntile[q];
+        }
+        if (i > 0)
+            load_tinv_t(i - 1, nti);
+        if (i > 1)
+            load_tile(i - 1, i - 2, ntile);
         if (part == 0)
-            st[r] = sv[kb * TB + r] - acc;
+            st[r] = sv[i * TB + r] - sacc[i * TB + r];  // (r, part 0) is the only writer of sacc's column r
         __syncthreads();
         double a2 = 0;
-        const double *ti = Tinv + (size_t)kb * TB * TB;
-        for (int c = r + part; c < TB; c += 8)
-            a2 += ti[c * TB + r] * st[c];
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            const int c = r + part + 8 * q;
+            a2 += c < TB ? ti[q] * st[c] : 0.;
+        }
         a2 = pg_sum8(a2);
         if (part == 0)
-            sv[kb * TB + r] = a2;
+            sv[i * TB + r] = a2;
         __syncthreads();
+        const double *xi = sv + i * TB + part;
+        auto onto_acc = [&](int kb, const double (&l)[6]) {  // acc_kb += L_i,kb^T x_i
+            double a = 0;
+#pragma unroll
+            for (int q = 0; q < 6; q++)
+                a += l[q] * xi[8 * q];
+            a = pg_sum8(a);
+            if (part == 0)
+                sacc[kb * TB + r] += a;
+        };
+        if (i > 0)
+            onto_acc(i - 1, tile);
+        for (int kb0 = i - 2; kb0 >= 0; kb0 -= 4) {  // the tiles further up: four at a time in flight
+            double tl[4][6];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (kb0 - u >= 0)
+                    load_tile(i, kb0 - u, tl[u]);
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (kb0 - u >= 0)
+                    onto_acc(kb0 - u, tl[u]);
+        }
     }
+    __syncthreads();
     for (int e = tid; e < ldr; e += PG_SOLVE_THREADS)
         x[e] = sv[e];
 }
@@ -1098,10 +1212,10 @@ struct svo_posegraph {
     // need no synchronisation of their own.
     int built_nv = -1, built_ne = -1;
     std::vector<int> h_incptr, h_inc, h_struct;
-    int s_m = 0, s_nseg = 0, s_nrblocks = 0, s_T = 0, s_ldr = 0;
+    int s_m = 0, s_nseg = 0, s_nrblocks = 0, s_T = 0, s_ldr = 0, s_maxseg = 0;
     size_t o_seg_start = 0, o_seg_len = 0, o_sepidx = 0, o_lsep = 0, o_rsep = 0, o_rb_row = 0, o_rb_col = 0, o_rptr = 0,
            o_rsrc = 0;
-    DevBuf d_pose, d_from, d_to, d_meas, d_eo, d_incptr, d_inc, d_struct, d_Dg, d_Cc, d_rneg, d_Li, d_Lsub, d_Z7, d_Y,
+    DevBuf d_pose, d_from, d_to, d_meas, d_eo, d_incptr, d_inc, d_struct, d_Dg, d_Cc, d_rneg, d_Y,
         d_Wl, d_Wr, d_R, d_Lo, d_Tinv, d_rR, d_xR, d_dx, d_misc;
     int nv() const { return (int)(pose.size() / 7); }
     int ne() const { return (int)efrom.size(); }
@@ -1125,7 +1239,7 @@ int svo_pg_destroy(svo_posegraph *g)
     (void)hipSetDevice(g->ctx->device);
     (void)hipStreamSynchronize(g->ctx->stream);
     DevBuf *bufs[] = {&g->d_pose, &g->d_from, &g->d_to, &g->d_meas, &g->d_eo,  &g->d_incptr, &g->d_inc, &g->d_struct,
-                      &g->d_Dg,   &g->d_Cc,   &g->d_rneg, &g->d_Li, &g->d_Lsub, &g->d_Z7, &g->d_Y,     &g->d_Wl,
+                      &g->d_Dg,   &g->d_Cc,   &g->d_rneg, &g->d_Y,     &g->d_Wl,
                       &g->d_Wr,   &g->d_R,    &g->d_Lo, &g->d_Tinv, &g->d_rR,  &g->d_xR,  &g->d_dx,    &g->d_misc};
     for (DevBuf *b : bufs)
         b->release();
@@ -1328,6 +1442,9 @@ int svo_pg_optimize(svo_posegraph *g, int iters, double *chi2)
         }
         g->s_m = m;
         g->s_nseg = (int)seg_start.size();
+        g->s_maxseg = 0;
+        for (int l : seg_len)
+            g->s_maxseg = l > g->s_maxseg ? l : g->s_maxseg;
         g->s_nrblocks = (int)blocks.size();
         g->s_T = (6 * m + TB - 1) / TB;
         g->s_ldr = g->s_T * TB;
@@ -1371,8 +1488,7 @@ int svo_pg_optimize(svo_posegraph *g, int iters, double *chi2)
     if ((rc = g->d_eo.ensure((size_t)ne * sizeof(EdgeOut))) || (rc = g->d_incptr.ensure((size_t)(nv + 1) * 4)) ||
         (rc = g->d_inc.ensure((size_t)2 * ne * 4)) || (rc = g->d_struct.ensure(g->h_struct.size() * 4 + 16)) ||
         (rc = g->d_Dg.ensure((size_t)nb * 288)) || (rc = g->d_Cc.ensure((size_t)nb * 288)) ||
-        (rc = g->d_rneg.ensure((size_t)nb * 48)) || (rc = g->d_Li.ensure((size_t)nb * 288)) ||
-        (rc = g->d_Lsub.ensure((size_t)(nb + 1) * 288)) || (rc = g->d_Z7.ensure((size_t)nb * 42 * 8)) ||
+        (rc = g->d_rneg.ensure((size_t)nb * 48)) ||
         (rc = g->d_Y.ensure((size_t)nb * 48)) || (rc = g->d_Wl.ensure((size_t)nb * 288)) ||
         (rc = g->d_Wr.ensure((size_t)nb * 288)) || (rc = g->d_R.ensure((size_t)ldr * ldr * 8 + 64)) ||
         (rc = g->d_Lo.ensure((size_t)ldr * ldr * 8 + 64)) || (rc = g->d_Tinv.ensure((size_t)T * TB * TB * 8 + 64)) ||
@@ -1406,6 +1522,22 @@ int svo_pg_optimize(svo_posegraph *g, int iters, double *chi2)
     double *Y = g->d_Y.as<double>(), *Wl = g->d_Wl.as<double>(), *Wr = g->d_Wr.as<double>();
     double *R = g->d_R.as<double>(), *Lo = g->d_Lo.as<double>(), *Tinv = g->d_Tinv.as<double>();
     double *rR = g->d_rR.as<double>(), *xR = g->d_xR.as<double>(), *dx = g->d_dx.as<double>();
+    // the separator solve keeps its vector and its running sums in LDS
+    const size_t solve_lds = (size_t)(2 * ldr + TB) * 8;
+    if (solve_lds > 158 * 1024) {
+        svo_set_error("pose graph: %d separators (loop-closure endpoints) are more than the separator solve holds (%d)", m,
+                      (158 * 1024 / 16 - TB) / 6);
+        return SVO_ERR_ARG;
+    }
+    if (solve_lds > 48 * 1024)
+        SVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pg_dense_solve_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_lds));
+    // a segment's rows live in LDS (SEG_L - 1 of them at most: the regular separators see to that)
+    static_assert(SEG_L - 1 <= BCR_MAX_ROWS, "a segment must fit the LDS of one workgroup");
+    const size_t seg_lds = (size_t)g->s_maxseg * BCR_ROW * 8;
+    if (seg_lds > 48 * 1024)
+        SVO_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pg_segment_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)seg_lds));
     ScopedKernelTime tm(ctx, SVO_K_POSEGRAPH);
     for (int it = 0; it <= iters; it++) {
         hipLaunchKernelGGL(pg_linearize_kernel, dim3((ne + 127) / 128), dim3(128), 0, st, g->d_pose.as<double>(),
@@ -1416,9 +1548,8 @@ int svo_pg_optimize(svo_posegraph *g, int iters, double *chi2)
         hipLaunchKernelGGL(pg_assemble_kernel, dim3((nb + 127) / 128), dim3(128), 0, st, nb, g->d_incptr.as<int>(),
                            g->d_inc.as<int>(), g->d_from.as<int>(), g->d_to.as<int>(), eo, Dg, Cc, rneg);
         if (nseg > 0)
-            hipLaunchKernelGGL(pg_segment_kernel, dim3(nseg), dim3(128), 0, st, nb, ds + o_seg_start, ds + o_seg_len, Dg,
-                               Cc, rneg, g->d_Li.as<double>(), g->d_Lsub.as<double>(), g->d_Z7.as<double>(), Y, Wl, Wr,
-                               d_status);
+            hipLaunchKernelGGL(pg_segment_kernel, dim3(nseg), dim3(BCR_WAVES * 64), seg_lds, st, nb, ds + o_seg_start,
+                               ds + o_seg_len, Dg, Cc, rneg, Y, Wl, Wr, d_status);
         if (m > 0) {
             const size_t tot = (size_t)ldr * ldr;
             hipLaunchKernelGGL(pg_reduce_clear_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, R, ldr,
@@ -1426,16 +1557,14 @@ int svo_pg_optimize(svo_posegraph *g, int iters, double *chi2)
             hipLaunchKernelGGL(pg_reduce_kernel, dim3(n_rblocks + m), dim3(64), 0, st, n_rblocks, m, ds + o_rb_row,
                                ds + o_rb_col, ds + o_rptr, reinterpret_cast<const int2 *>(ds + o_rsrc), Dg, Cc, rneg, eo,
                                Y, Wl, Wr, R, ldr, rR);
-            for (int kb = 0; kb < T; kb++) {
-                hipLaunchKernelGGL(pg_dense_potf2_kernel, dim3(1), dim3(256), 0, st, R, Lo, Tinv, ldr, kb, d_status,
-                                   1 << 20);
+            hipLaunchKernelGGL(pg_dense_potf2_kernel, dim3(1), dim3(256), 0, st, R, Lo, Tinv, ldr, 0, d_status, 1 << 20);
+            for (int kb = 0; kb + 1 < T; kb++) {
                 const int nt = T - 1 - kb;
-                if (nt > 0)
-                    hipLaunchKernelGGL(pg_dense_update_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, st, R, Lo, Tinv,
-                                       ldr, kb, T, rR, xR);
+                hipLaunchKernelGGL(pg_dense_step_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, st, R, Lo, Tinv, ldr, kb,
+                                   rR, xR, d_status, 1 << 20);
             }
-            hipLaunchKernelGGL(pg_dense_solve_kernel, dim3(1), dim3(PG_SOLVE_THREADS), (size_t)(ldr + TB) * 8, st, Lo, Tinv, ldr,
-                               T, rR, xR);
+            hipLaunchKernelGGL(pg_dense_solve_kernel, dim3(1), dim3(PG_SOLVE_THREADS), (size_t)(2 * ldr + TB) * 8, st, Lo,
+                               Tinv, ldr, T, rR, xR);
         }
         hipLaunchKernelGGL(pg_backsub_kernel, dim3((nb * 6 + 255) / 256), dim3(256), 0, st, nb, ds + o_sepidx,
                            ds + o_lsep, ds + o_rsep, xR, Y, Wl, Wr, dx);
@@ -1460,6 +1589,20 @@ int svo_pg_optimize(svo_posegraph *g, int iters, double *chi2)
             svo_set_error("pose graph: normal matrix not positive definite at block row %d", hstatus - 1);
         return SVO_ERR_STATE;
     }
+#ifdef PG_STAMPS
+    {
+        long long h[128];
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(pg_dbg), sizeof(h));
+        fprintf(stderr, "first tile, us:");
+        for (int k = 1; k <= 51; k++)
+            if (h[k])
+                fprintf(stderr, " [%d]%.2f", k, (h[k] - h[0]) * 0.01);
+        fprintf(stderr, "\nfirst step, workgroup 0, us:");
+        for (int k = 61; k <= 66; k++)
+            fprintf(stderr, " [%d]%.2f", k, (h[k] - h[60]) * 0.01);
+        fprintf(stderr, "\n");
+    }
+#endif
     g->pose.swap(hpose);
     g->dev_nv = nv;  // device poses == host poses, edges unchanged: the next solve uploads what is appended
     g->dev_ne = ne;
