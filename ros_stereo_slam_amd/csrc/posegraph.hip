@@ -219,6 +219,16 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// A workgroup barrier that orders LDS traffic only.  __syncthreads() on gfx9 also waits for every global load and store of
+// the wave (one counter for both, and a release fence has to wait for the stores): loads asked for early would be drained
+// at the next barrier.  The kernels below exchange data between their waves through LDS alone.
+__device__ __forceinline__ void lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // assemble: one thread per block row.  Incident edges of vertex v are
 // inc[incptr[v] .. incptr[v+1]) = edge*2 + role (role 0: v is the edge's `from`, 1: `to`),
 // ascending in edge index, so every sum has a fixed order.
@@ -339,6 +349,18 @@ __device__ inline bool wave_chol6_inv(double *sS, double *sL, double *sLi, int l
     return ok;
 }
 
+// -DPG_STAMPS: thread 0 of the first tile's workgroups leaves the 100 MHz clock at the phase boundaries (tools/pg_quick.sh)
+#ifdef PG_STAMPS
+__device__ long long pg_dbg[128];
+__device__ int pg_dbg_claim;
+#define PGSTAMP(k)                                                                                                     \
+    do {                                                                                                               \
+        if (tid == 0 && dbg)                                                                                           \
+            pg_dbg[k] = wall_clock64();                                                                                \
+    } while (0)
+#else
+#define PGSTAMP(k) (void)dbg
+#endif
 // A segment = a block-tridiagonal system T X = B with 13 right-hand sides  B = [r | E_a H[a][a-1] | E_z H[z][z+1]],
 // X = [y | Wl | Wr].  Solved by BLOCK CYCLIC REDUCTION in LDS, one workgroup of 16 waves per segment: at level l (stride
 // s = 2^l) the rows q = s, 3s, 5s, ... (1-based) are eliminated -- all of them at once, a wave per row -- into their
@@ -354,6 +376,56 @@ __device__ inline bool wave_chol6_inv(double *sS, double *sL, double *sLi, int l
 constexpr int BCR_ROW = 186, BCR_F = 36, BCR_GM = 72, BCR_B = 108, BCR_WAVES = 16;
 constexpr int BCR_MAX_ROWS = (160 * 1024 - 256) / (BCR_ROW * 8);  // 110 rows of LDS
 
+// One 6 x 6 block per LANE: the same Cholesky + inverse as wave_chol6_inv, operation for operation (the results are
+// bit-identical), on the packed lower triangle in a lane's registers.  For the first levels of a long segment, where there
+// are more rows to eliminate than waves: 64 blocks in the time of one.  D (row-major) at `blk` becomes L^-1.
+__device__ inline bool lane_chol6_inv(double *blk)
+{
+    double a[21], x[21], rinv[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j <= i; j++)
+            a[i * (i + 1) / 2 + j] = blk[6 * i + j];
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const double piv = a[k * (k + 1) / 2 + k];
+        if (!(piv > 0))
+            ok = false;
+        double y = __builtin_amdgcn_rsq(piv);
+        const double hp = 0.5 * piv;
+        y = y * (1.5 - hp * y * y);
+        y = y * (1.5 - hp * y * y);
+        rinv[k] = y;
+        a[k * (k + 1) / 2 + k] = piv * y;
+#pragma unroll
+        for (int i = k + 1; i < 6; i++)
+            a[i * (i + 1) / 2 + k] = a[i * (i + 1) / 2 + k] * y;
+#pragma unroll
+        for (int j = k + 1; j < 6; j++)
+#pragma unroll
+            for (int i = j; i < 6; i++)
+                a[i * (i + 1) / 2 + j] -= a[i * (i + 1) / 2 + k] * a[j * (j + 1) / 2 + k];
+    }
+#pragma unroll
+    for (int j = 0; j < 6; j++)
+#pragma unroll
+        for (int r = j; r < 6; r++) {
+            double sacc = r == j ? 1. : 0.;
+#pragma unroll
+            for (int k = j; k < r; k++)
+                sacc -= a[r * (r + 1) / 2 + k] * x[k * (k + 1) / 2 + j];
+            x[r * (r + 1) / 2 + j] = sacc * rinv[r];
+        }
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = 0; j < 6; j++)
+            blk[6 * i + j] = j <= i ? x[i * (i + 1) / 2 + j] : 0.;
+    return ok;
+}
+
 __global__ __launch_bounds__(BCR_WAVES * 64) void pg_segment_kernel(int nb, const int *__restrict__ seg_start,
                                                                     const int *__restrict__ seg_len,
                                                                     const double *__restrict__ Dg,
@@ -364,88 +436,144 @@ __global__ __launch_bounds__(BCR_WAVES * 64) void pg_segment_kernel(int nb, cons
 {
     extern __shared__ double sm[];
     __shared__ int s_fail;
+    // which of the separator columns of a row's right-hand side are not structurally zero (bit 0: the left separator's
+    // six, bit 1: the right one's).  They start at the segment's first / last row and spread by one row that stays per
+    // level; on the way down only those rows carry them (on the way up every row's X is dense).
+    __shared__ unsigned char s_cols[BCR_MAX_ROWS + 2];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    constexpr int NT = BCR_WAVES * 64;
     const int a = seg_start[blockIdx.x], n = seg_len[blockIdx.x], z = a + n - 1;
+    const bool has_l = a > 0, has_r = z < nb - 1;
     if (tid == 0)
         s_fail = 0;
-    for (int e = tid; e < n * BCR_ROW; e += BCR_WAVES * 64) {
-        const int p = e / BCR_ROW, k = e - p * BCR_ROW, b = a + p;
-        double v = 0.;
-        if (k < BCR_F)
-            v = Dg[(size_t)b * 36 + k];
-        else if (k < BCR_GM)
-            v = p < n - 1 ? Cc[(size_t)b * 36 + (k - BCR_F)] : 0.;  // H[b+1][b]
-        else if (k >= BCR_B) {
-            const int r = (k - BCR_B) / 13, c = (k - BCR_B) - 13 * r;
-            if (c == 0)
-                v = rneg[(size_t)b * 6 + r];
-            else if (c < 7)
-                v = p == 0 && a > 0 ? Cc[(size_t)(a - 1) * 36 + 6 * r + (c - 1)] : 0.;  // H[a][a-1]
-            else
-                v = p == n - 1 && z < nb - 1 ? Cc[(size_t)z * 36 + 6 * (c - 7) + r] : 0.;  // H[z][z+1] = Cc[z]^T
+#ifdef PG_STAMPS
+    __shared__ int s_dbg;
+    if (tid == 0)
+        s_dbg = n >= 96 && atomicCAS(&pg_dbg_claim, 0, 1) == 0;
+    __syncthreads();
+    const bool dbg = s_dbg != 0;
+#else
+    const bool dbg = false;
+#endif
+    PGSTAMP(70);
+    if (tid < n)
+        s_cols[tid] = (unsigned char)((tid == 0 && has_l ? 1 : 0) | (tid == n - 1 && has_r ? 2 : 0));
+    {  // D and F: the segment's rows are contiguous in Dg / Cc; four loads in flight per thread and array
+        const double *gd = Dg + (size_t)a * 36, *gc = Cc + (size_t)a * 36;
+        const int tot = n * 36;
+        for (int e0 = tid; e0 < tot; e0 += 4 * NT) {
+            double vd[4], vc[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int e = e0 + u * NT;
+                vd[u] = e < tot ? gd[e] : 0.;
+                vc[u] = e < tot - 36 ? gc[e] : 0.;  // H[b+1][b]; the last row's coupling leaves the segment
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int e = e0 + u * NT;
+                if (e < tot) {
+                    const int p = e / 36, k = e - 36 * p;
+                    sm[p * BCR_ROW + k] = vd[u];
+                    sm[p * BCR_ROW + BCR_F + k] = vc[u];
+                }
+            }
         }
-        sm[e] = v;
+        for (int e = tid; e < n * 78; e += NT) {  // B = [r | H[a][a-1] in the first row | H[z][z+1] in the last]
+            const int p = e / 78, k = e - 78 * p, r = k / 13, c = k - 13 * r;
+            double v = 0.;
+            if (c == 0)
+                v = rneg[(size_t)(a + p) * 6 + r];
+            else if (c < 7) {
+                if (p == 0 && has_l)
+                    v = Cc[(size_t)(a - 1) * 36 + 6 * r + (c - 1)];
+            } else if (p == n - 1 && has_r)
+                v = Cc[(size_t)z * 36 + 6 * (c - 7) + r];  // Cc[z]^T
+            sm[p * BCR_ROW + BCR_B + k] = v;
+        }
     }
     __syncthreads();
+    PGSTAMP(71);
     int levels = 0;
     for (int s = 1; s <= n; s <<= 1, levels++) {
-        // ---- eliminate the rows q = s (2 t + 1): factor, and the three products with L^-1 (150 entries over the lanes) ----
+        // ---- eliminate the rows q = s (2 t + 1): factor, and the products with L^-1 ----
         const int cnt = (n / s + 1) / 2;
+        const bool by_lane = cnt > BCR_WAVES;  // more rows than waves: a lane per block first, the products after
+        if (by_lane) {
+            if (tid < cnt) {
+                const int q = s * (2 * tid + 1);
+                if (!lane_chol6_inv(sm + (q - 1) * BCR_ROW)) {
+                    atomicMax(status, a + q);  // 1 + block row
+                    s_fail = 1;
+                }
+            }
+            lds_barrier();
+            if (s_fail)
+                return;
+        }
         for (int t = wave; t < cnt; t += BCR_WAVES) {
             const int q = s * (2 * t + 1);
             double *Q = sm + (q - 1) * BCR_ROW;
             const bool hl = q > s, hr = q + s <= n;
-            if (!wave_chol6_inv<false>(Q, nullptr, Q, lane)) {
+            if (!by_lane && !wave_chol6_inv<false>(Q, nullptr, Q, lane)) {
                 if (lane == 0) {
-                    atomicMax(status, a + q);  // 1 + block row
+                    atomicMax(status, a + q);
                     s_fail = 1;
                 }
                 continue;
             }
+            const int cols = s_cols[q - 1];
             const double *Fl = sm + (hl ? q - s - 1 : q - 1) * BCR_ROW + BCR_F;  // H[q][q-s], kept by the left neighbour
+            // out[i][.] = sum_u Linv[i][u] src[u * st]  (Linv is lower triangular with zeros above).  Every lane runs the
+            // SAME code on its own (i, src, st, dst): round 0: G- (36 lanes) and 28 entries of G+; round 1: G+'s other 8,
+            // GB's first column (6), the left separator's columns (36, where the row carries them); round 2, for the rare
+            // row that carries the right separator's columns: those 36.
+            const int rounds = cols & 2 ? 3 : 2;
             double out[3];
+            int dsts[3];
 #pragma unroll
-            for (int k3 = 0; k3 < 3; k3++) {
-                const int e = lane + 64 * k3;
-                // out = sum_t Linv[i][t] src[t * st]  (Linv is lower triangular with zeros above)
-                int i, st;
-                const double *src;
-                if (e < 36) {  // G- = Linv H[q][q-s]
-                    i = e / 6;
-                    src = Fl + (e - 6 * i);
-                    st = 6;
-                } else if (e < 72) {  // G+ = Linv F_q^T
-                    i = (e - 36) / 6;
-                    src = Q + BCR_F + 6 * ((e - 36) - 6 * i);
-                    st = 1;
-                } else {  // GB = Linv B
-                    i = (e - 72) / 13;
-                    src = Q + BCR_B + ((e - 72) - 13 * i);
-                    st = 13;
+            for (int r = 0; r < 3; r++) {
+                int i = 0, st = 1, dst = -1;
+                const double *src = Q;
+                if (r == 0) {
+                    if (lane < 36) {
+                        i = lane / 6, src = Fl + lane % 6, st = 6, dst = hl ? BCR_GM + lane : -1;
+                    } else {
+                        const int g = lane - 36;
+                        i = g / 6, src = Q + BCR_F + 6 * (g % 6), st = 1, dst = hr ? BCR_F + g : -1;
+                    }
+                } else if (r == 1) {
+                    if (lane < 8) {
+                        const int g = 28 + lane;
+                        i = g / 6, src = Q + BCR_F + 6 * (g % 6), st = 1, dst = hr ? BCR_F + g : -1;
+                    } else if (lane < 14) {
+                        i = lane - 8, src = Q + BCR_B, st = 13, dst = BCR_B + 13 * i;
+                    } else if (lane < 50) {
+                        const int g = lane - 14, c = 1 + g % 6;
+                        i = g / 6, src = Q + BCR_B + c, st = 13, dst = cols & 1 ? BCR_B + 13 * i + c : -1;
+                    }
+                } else if (lane < 36) {
+                    const int c = 7 + lane % 6;
+                    i = lane / 6, src = Q + BCR_B + c, st = 13, dst = BCR_B + 13 * i + c;
                 }
                 double acc = 0.;
-                if (e < 150) {
+                if (r < rounds) {
 #pragma unroll
                     for (int u = 0; u < 6; u++)
                         acc = fma(Q[6 * i + u], src[u * st], acc);
-                }
-                out[k3] = acc;
+                } else
+                    dst = -1;
+                out[r] = acc;
+                dsts[r] = dst;
             }
             wave_sync();  // F_q and B_q have been read by every lane
 #pragma unroll
-            for (int k3 = 0; k3 < 3; k3++) {
-                const int e = lane + 64 * k3;
-                if (e < 36) {
-                    if (hl)
-                        Q[BCR_GM + e] = out[k3];
-                } else if (e < 72) {
-                    if (hr)
-                        Q[BCR_F + (e - 36)] = out[k3];
-                } else if (e < 150)
-                    Q[BCR_B + (e - 72)] = out[k3];
-            }
+            for (int r = 0; r < 3; r++)
+                if (dsts[r] >= 0)
+                    Q[dsts[r]] = out[r];
         }
-        __syncthreads();
+        lds_barrier();
+        PGSTAMP(72 + 2 * levels);
         if (s_fail)
             return;
         // ---- into the rows that stay, p = 2 s (t + 1): every entry of D_p, B_p and the new coupling is a lane's own ----
@@ -454,54 +582,60 @@ __global__ __launch_bounds__(BCR_WAVES * 64) void pg_segment_kernel(int nb, cons
             const int p = 2 * s * (t + 1);
             double *P = sm + (p - 1) * BCR_ROW;
             const bool hr = p + s <= n, hn = p + 2 * s <= n;
-            const double *Gl = sm + (p - s - 1) * BCR_ROW;                  // the eliminated row on the left: its G+ is ours
-            const double *Gr = sm + ((hr ? p + s : p - s) - 1) * BCR_ROW;   // on the right: its G-
+            const double *Gl = sm + (p - s - 1) * BCR_ROW;                 // the eliminated row on the left: its G+ is ours
+            const double *Gr = sm + ((hr ? p + s : p - s) - 1) * BCR_ROW;  // on the right: its G-
+            const int cols = s_cols[p - 1] | s_cols[p - s - 1] | (hr ? s_cols[p + s - 1] : 0);
+            // out = base - sum_u A1[6 u] B1[u * st] - sum_u A2[6 u] B2[u * st]: the same code in every lane (see above);
+            // round 0: D_p (36) and 28 entries of the new coupling, round 1: its other 8, B_p's first column (6), the left
+            // separator's columns (36), round 2: the right separator's columns
+            const int rounds = cols & 2 ? 3 : 2;
 #pragma unroll
-            for (int k3 = 0; k3 < 3; k3++) {
-                const int e = lane + 64 * k3;
-                if (e >= 150)
-                    continue;
-                // out = base - sum_t A1[6 t] B1[t * s1] - sum_t A2[6 t] B2[t * s2]
-                double base;
-                const double *A1, *B1, *A2, *B2;
-                int s1, dst;
-                bool left = true, right = hr;
-                if (e < 36) {  // D_p[i][j]
-                    const int i = e / 6, j = e - 6 * i;
-                    dst = e;
-                    A1 = Gl + BCR_F + i, B1 = Gl + BCR_F + j, A2 = Gr + BCR_GM + i, B2 = Gr + BCR_GM + j;
-                    s1 = 6;
-                } else if (e < 72) {  // the coupling to the next row that stays: H[p+2s][p][i][j] = -sum_t G+[t][i] G-[t][j]
-                    const int i = (e - 36) / 6, j = (e - 36) - 6 * i;
-                    dst = BCR_F + (e - 36);
-                    A1 = A2 = Gr + BCR_F + i, B1 = B2 = Gr + BCR_GM + j;
-                    s1 = 6;
-                    left = false;
-                    right = hn;
-                } else {  // B_p[i][c]
-                    const int i = (e - 72) / 13, c = (e - 72) - 13 * i;
-                    dst = BCR_B + (e - 72);
+            for (int r = 0; r < 3; r++) {
+                if (r >= rounds)
+                    break;
+                int st = 6, dst = -1;
+                bool use1 = true, use2 = hr, keep = true;
+                const double *A1 = Gl, *B1 = Gl, *A2 = Gl, *B2 = Gl;
+                auto coupling = [&](int g) {  // H[p+2s][p][i][j] = -sum_t G+r[t][i] G-r[t][j]
+                    const int i = g / 6, j = g - 6 * i;
+                    A2 = Gr + BCR_F + i, B2 = Gr + BCR_GM + j, dst = hn ? BCR_F + g : -1;
+                    use1 = false, use2 = hn, keep = false;
+                };
+                auto rhs = [&](int i, int c, bool on) {  // B_p[i][c] -= sum_t G+l[t][i] GBl[t][c] + sum_t G-r[t][i] GBr[t][c]
                     A1 = Gl + BCR_F + i, B1 = Gl + BCR_B + c, A2 = Gr + BCR_GM + i, B2 = Gr + BCR_B + c;
-                    s1 = 13;
-                }
-                base = e >= 36 && e < 72 ? 0. : P[dst];
-                double acc = 0.;
-                if (left) {
+                    st = 13, dst = on ? BCR_B + 13 * i + c : -1;
+                };
+                if (r == 0) {
+                    if (lane < 36) {  // D_p[i][j] -= sum_t G+l[t][i] G+l[t][j] + sum_t G-r[t][i] G-r[t][j]
+                        const int i = lane / 6, j = lane - 6 * i;
+                        A1 = Gl + BCR_F + i, B1 = Gl + BCR_F + j, A2 = Gr + BCR_GM + i, B2 = Gr + BCR_GM + j, dst = lane;
+                    } else
+                        coupling(lane - 36);
+                } else if (r == 1) {
+                    if (lane < 8)
+                        coupling(28 + lane);
+                    else if (lane < 14)
+                        rhs(lane - 8, 0, true);
+                    else if (lane < 50)
+                        rhs((lane - 14) / 6, 1 + (lane - 14) % 6, cols & 1);
+                } else if (lane < 36)
+                    rhs(lane / 6, 7 + lane % 6, true);
+                double acc1 = 0., acc2 = 0.;
 #pragma unroll
-                    for (int u = 0; u < 6; u++)
-                        acc = fma(A1[6 * u], B1[u * s1], acc);
+                for (int u = 0; u < 6; u++) {
+                    acc1 = fma(A1[6 * u], B1[u * st], acc1);
+                    acc2 = fma(A2[6 * u], B2[u * st], acc2);
                 }
-                double acc2 = 0.;
-                if (right) {
-#pragma unroll
-                    for (int u = 0; u < 6; u++)
-                        acc2 = fma(A2[6 * u], B2[u * s1], acc2);
+                if (dst >= 0) {
+                    const double base = keep ? P[dst] : 0.;
+                    P[dst] = (base - (use1 ? acc1 : 0.)) - (use2 ? acc2 : 0.);
                 }
-                if (e < 36 || e >= 72 || hn)
-                    P[dst] = (base - acc) - acc2;
             }
+            if (cols && lane == 0)
+                s_cols[p - 1] = (unsigned char)cols;
         }
-        __syncthreads();
+        lds_barrier();
+        PGSTAMP(73 + 2 * levels);
     }
     // ---- substitution, the levels upwards: X_q = L^-T (GB_q - G-_q X_{q-s} - G+_q X_{q+s}), 6 x 13 ----
     for (int lev = levels - 1; lev >= 0; lev--) {
@@ -566,7 +700,8 @@ __global__ __launch_bounds__(BCR_WAVES * 64) void pg_segment_kernel(int nb, cons
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
+        PGSTAMP(90 + lev);
     }
 }
 
@@ -663,32 +798,23 @@ __global__ __launch_bounds__(256) void pg_reduce_clear_kernel(double *__restrict
 // Tile step kb:  every trailing tile (i, j), kb < j <= i:  A_ij -= P_i P_j^T with P_i = A_i,kb Tinv_kb^T (the tile
 //                (i, kb+1) also stores P_i as the factor's block (i, kb));
 //                the workgroup of the tile (kb+1, kb+1) goes on to factorise it in LDS -- the next step's diagonal tile --
-//                and leaves its factor in Lo and the factor's inverse in Tinv[kb+1].
+//                and leaves the inverse of its factor in Tinv[kb+1] (the factor itself is not needed again).
 // ONE launch per tile step (round 3 had two: the critical path of a step was the diagonal tile's update followed, across a
 // launch boundary and a round trip through HBM, by its factorisation).  The first tile has a launch of its own.
 // Column kb of A is only read in step kb, the factor goes to a separate array: no races.
 
 // Cholesky of the 48 x 48 tile in sL (lower triangle; what is above the diagonal is never read) and the inverse of the
-// factor into sX (zeroed here).  Blocked by 6 inside the tile: eight steps of (1) Cholesky + inverse of the 6 x 6 diagonal
-// block by one wave (wave_chol6_inv, the segments' routine), (2) the panel below it, L21 = A21 L11^-T, an entry per thread,
-// (3) the trailing update A22 -= L21 L21^T as 3 x 3 blocks per thread on the 16 x 16 thread grid of the tile products.
-// The inverse grows with the factor, a block row per step: X[b][c] = -L_bb^-1 sum_{c <= k < b} L[b][k] X[k][c].  The sums
-// (they need the factor's block row b, final since step b-1, and the inverse's rows above) are formed by waves 1..3 WHILE
-// wave 0 is in the diagonal block's serial chain (1); the product with L_bb^-1 rides with the panel (2).  (Round 3 built the
-// inverse afterwards from inverted halves: 8 us of this routine's 22.)
-// sT: TB * TB / 4 doubles of scratch.  Returns (to every thread) 0 or 1 + the row of the first non-positive pivot.
-// -DPG_STAMPS: thread 0 of the first tile's workgroups leaves the 100 MHz clock at the phase boundaries (tools/pg_quick.sh)
-#ifdef PG_STAMPS
-__device__ long long pg_dbg[128];
-#define PGSTAMP(k)                                                                                                     \
-    do {                                                                                                               \
-        if (tid == 0 && dbg)                                                                                           \
-            pg_dbg[k] = wall_clock64();                                                                                \
-    } while (0)
-#else
-#define PGSTAMP(k) (void)dbg
-#endif
-__device__ __forceinline__ int pg_potf2_lds(bool dbg, double *sL, double *sX, double *sT, double *sS6, double *sL6, double *sLi6,
+// factor into sX (zeroed here), blocked by 6 inside the tile.  The serial chain is the eight 6 x 6 diagonal blocks
+// (wave_chol6_inv, the segments' routine, by wave 0); everything else is arranged around it, two barriers per block step:
+//   P  the panel below the diagonal block, L21 = A21 L11^-T (a thread per row), and the inverse's block row
+//      X[b][c] = -L_bb^-1 Z[b][c] (a thread per column; Z = sum_{c <= k < b} L[b][k] X[k][c] has been accumulated in place);
+//   Q  wave 0 takes the NEXT diagonal block's update out of the panel and factorises it, while waves 1..3 do the trailing
+//      update A22 -= L21 L21^T and add this step's terms to Z in the rows below -- 3 x 3 blocks per thread on the 16 x 16
+//      thread grid of the tile products, the same code for both (the rows of wave 0's threads are done with by then).
+// (Round 3: factor, panel, trailing update one after the other with three barriers, then the inverse from inverted
+// halves -- 26 us a tile; the inverse grown with the factor in the shadow of the diagonal block -- 17 us.)
+// Returns (to every thread) 0 or 1 + the row of the first non-positive pivot.
+__device__ __forceinline__ int pg_potf2_lds(bool dbg, double *sL, double *sX, double *sS6, double *sL6, double *sLi6,
                                             int *s_bad, int tid)
 {
     constexpr int LD = TB + 1, NB6 = TB / 6;
@@ -697,106 +823,154 @@ __device__ __forceinline__ int pg_potf2_lds(bool dbg, double *sL, double *sX, do
         sX[e] = 0.;
     if (tid == 0)
         *s_bad = 0;
-    __syncthreads();
+    lds_barrier();
+    // the diagonal block at o2, with the update from the panel columns o .. o+5 (o < 0: none), by wave 0
+    auto diag_block = [&](int o, int o2) {
+        if (tid < 36) {
+            const int i = tid / 6, j = tid - 6 * i, hi = o2 + (i > j ? i : j), lo = o2 + (i > j ? j : i);
+            double v = sL[hi * LD + lo];  // symmetric from the lower triangle
+            if (o >= 0) {
+#pragma unroll
+                for (int t = 0; t < 6; t++)
+                    v -= sL[hi * LD + o + t] * sL[lo * LD + o + t];
+            }
+            sS6[tid] = v;
+        }
+        wave_sync();
+        if (!wave_chol6_inv(sS6, sL6, sLi6, tid) && tid == 0 && *s_bad == 0)
+            *s_bad = 1 + o2;
+        if (tid < 36) {
+            const int i = tid / 6, j = tid - 6 * i;
+            sL[(o2 + i) * LD + o2 + j] = sL6[tid];  // zero above the diagonal
+            sX[(o2 + i) * LD + o2 + j] = sLi6[tid];
+        }
+    };
+    if (tid < 64)
+        diag_block(-1, 0);
+    lds_barrier();
     for (int blk = 0; blk < NB6; blk++) {
-        const int o = 6 * blk;
-        PGSTAMP(2 + 4 * blk);
-        if (tid < 64) {  // (1) the diagonal block: L11 into the tile, L11^-1 into the inverse's diagonal block
-            if (tid < 36) {
-                const int i = tid / 6, j = tid - 6 * i;
-                sS6[tid] = sL[(o + (i > j ? i : j)) * LD + o + (i > j ? j : i)];  // symmetric from the lower triangle
-            }
-            wave_sync();
-            if (!wave_chol6_inv(sS6, sL6, sLi6, tid) && tid == 0 && *s_bad == 0)
-                *s_bad = 1 + o;
-            if (tid < 36) {
-                const int i = tid / 6, j = tid - 6 * i;
-                sL[(o + i) * LD + o + j] = sL6[tid];  // zero above the diagonal
-                sX[(o + i) * LD + o + j] = sLi6[tid];
-            }
-        } else {  // meanwhile: Z[i][c] = sum_{k < o} L[o + i][k] X[k][c]  (X[k][c] = 0 for k < c)
-            for (int e = tid - 64; e < 6 * o; e += 192) {
-                const int i = e / o, c = e - o * i;
-                const double *pl = sL + (o + i) * LD, *px = sX + c;
+        const int o = 6 * blk, below = TB - o - 6;
+        PGSTAMP(2 + 2 * blk);
+        // ---- P ----
+        if (tid < below) {  // row o + 6 + tid of the panel: (A21 L11^-T)[r][c] = sum_{t <= c} A21[r][t] Li[c][t]
+            double *row = sL + (o + 6 + tid) * LD + o;
+            double av[6], out[6];
+#pragma unroll
+            for (int t = 0; t < 6; t++)
+                av[t] = row[t];
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
                 double acc = 0.;
-#pragma unroll 6
-                for (int k = 0; k < o; k++)  // o is a multiple of 6
-                    acc = fma(pl[k], px[k * LD], acc);
-                sT[i * TB + c] = acc;
+#pragma unroll
+                for (int t = 0; t <= c; t++)
+                    acc += av[t] * sLi6[6 * c + t];
+                out[c] = acc;
             }
-        }
-        __syncthreads();
-        PGSTAMP(3 + 4 * blk);
-        const int below = TB - o - 6;  // rows under the diagonal block
-        double pv = 0.;
-        if (tid < below * 6) {         // (2) panel: (A21 L11^-T)[r][c] = sum_t A21[r][t] Li[c][t], t <= c
-            const int r = o + 6 + tid / 6, c = tid % 6;
+#pragma unroll
+            for (int c = 0; c < 6; c++)
+                row[c] = out[c];
+        } else if (tid >= 64 && tid - 64 < o) {  // column tid - 64 of the inverse's block row: -Li Z, in place
+            double *col = sX + o * LD + (tid - 64);
+            double zv[6], out[6];
 #pragma unroll
             for (int t = 0; t < 6; t++)
-                pv += t <= c ? sL[r * LD + o + t] * sLi6[6 * c + t] : 0.;
-        }
-        for (int e = 255 - tid; e < 6 * o; e += 256) {  // the inverse's block row: X[o + i][c] = -sum_{t <= i} Li[i][t] Z[t][c]
-            const int i = e / o, c = e - o * i;
-            double acc = 0.;
+                zv[t] = col[t * LD];
 #pragma unroll
-            for (int t = 0; t < 6; t++)
-                acc -= t <= i ? sLi6[6 * i + t] * sT[t * TB + c] : 0.;
-            sX[(o + i) * LD + c] = acc;
-        }
-        __syncthreads();
-        if (tid < below * 6)
-            sL[(o + 6 + tid / 6) * LD + o + tid % 6] = pv;
-        __syncthreads();
-        PGSTAMP(4 + 4 * blk);
-        if (3 * tc >= o + 6 && tc <= tr) {  // (3) trailing update: the 3 x 3 block (tr, tc) of the rest's lower triangle
-            const double *px = sL + (3 * tr) * LD + o, *py = sL + (3 * tc) * LD + o;
-            double acc[3][3] = {{0., 0., 0.}, {0., 0., 0.}, {0., 0., 0.}};
+            for (int i = 0; i < 6; i++) {
+                double acc = 0.;
 #pragma unroll
-            for (int t = 0; t < 6; t++) {
-                const double x0 = px[t], x1 = px[LD + t], x2 = px[2 * LD + t];
-                const double y0 = py[t], y1 = py[LD + t], y2 = py[2 * LD + t];
-                acc[0][0] = fma(x0, y0, acc[0][0]);
-                acc[0][1] = fma(x0, y1, acc[0][1]);
-                acc[0][2] = fma(x0, y2, acc[0][2]);
-                acc[1][0] = fma(x1, y0, acc[1][0]);
-                acc[1][1] = fma(x1, y1, acc[1][1]);
-                acc[1][2] = fma(x1, y2, acc[1][2]);
-                acc[2][0] = fma(x2, y0, acc[2][0]);
-                acc[2][1] = fma(x2, y1, acc[2][1]);
-                acc[2][2] = fma(x2, y2, acc[2][2]);
+                for (int t = 0; t <= i; t++)
+                    acc -= sLi6[6 * i + t] * zv[t];
+                out[i] = acc;
             }
-            // (a diagonal block's entries above the diagonal are written too: nobody reads them)
 #pragma unroll
-            for (int a = 0; a < 3; a++)
-#pragma unroll
-                for (int b2 = 0; b2 < 3; b2++)
-                    sL[(3 * tr + a) * LD + 3 * tc + b2] -= acc[a][b2];
+            for (int i = 0; i < 6; i++)
+                col[i * LD] = out[i];
         }
-        __syncthreads();
+        lds_barrier();
+        PGSTAMP(3 + 2 * blk);
+        if (blk == NB6 - 1)
+            break;
+        // ---- Q ----
+        const int o2 = o + 6;
+        if (tid < 64)
+            diag_block(o, o2);
+        else {
+            // the 3 x 3 block (R, C) of this thread: out[a][b] (-/+)= sum_t sL[3R+a][o+t] * Y[b][t]
+            //   3C >= o2: trailing update, Y[b][t] = sL[3C+b][o+t] (the next diagonal block is wave 0's);
+            //   3C <  o2: Z of the rows below, Y[b][t] = sX[o+t][3C+b]
+            int R = tr, C = tc;
+            bool on = tc <= tr && 3 * tr >= o2;
+            if (blk == 0 && tr == 4 && tc >= 5 && tc <= 8) {  // rows 6 .. 11 belong to wave 0's threads: their Z blocks
+                R = 2 + ((tc - 5) >> 1);                      // (columns 0 .. 5) go to four threads that have nothing to do
+                C = (tc - 5) & 1;
+                on = true;
+            }
+            const bool trail = 3 * C >= o2;
+            if (trail && 3 * R < o2 + 6)
+                on = false;
+            if (on) {
+                const double *px = sL + (3 * R) * LD + o;
+                const double *py = trail ? sL + (3 * C) * LD + o : sX + o * LD + 3 * C;
+                const int sb = trail ? LD : 1, stt = trail ? 1 : LD;
+                double acc[3][3] = {{0., 0., 0.}, {0., 0., 0.}, {0., 0., 0.}};
+#pragma unroll
+                for (int t = 0; t < 6; t++) {
+                    const double x0 = px[t], x1 = px[LD + t], x2 = px[2 * LD + t];
+                    const double y0 = py[t * stt], y1 = py[sb + t * stt], y2 = py[2 * sb + t * stt];
+                    acc[0][0] = fma(x0, y0, acc[0][0]);
+                    acc[0][1] = fma(x0, y1, acc[0][1]);
+                    acc[0][2] = fma(x0, y2, acc[0][2]);
+                    acc[1][0] = fma(x1, y0, acc[1][0]);
+                    acc[1][1] = fma(x1, y1, acc[1][1]);
+                    acc[1][2] = fma(x1, y2, acc[1][2]);
+                    acc[2][0] = fma(x2, y0, acc[2][0]);
+                    acc[2][1] = fma(x2, y1, acc[2][1]);
+                    acc[2][2] = fma(x2, y2, acc[2][2]);
+                }
+                // (a diagonal block's entries above the diagonal are written too: nobody reads them)
+                double *dst = (trail ? sL : sX) + (3 * R) * LD + 3 * C;
+                const double sg = trail ? -1. : 1.;
+#pragma unroll
+                for (int a = 0; a < 3; a++)
+#pragma unroll
+                    for (int b2 = 0; b2 < 3; b2++)
+                        dst[a * LD + b2] += sg * acc[a][b2];
+            }
+        }
+        lds_barrier();
     }
     PGSTAMP(50);
     return *s_bad;
 }
 
-// the factor's diagonal tile kb and its inverse, from LDS to their arrays
-__device__ __forceinline__ void pg_store_factor_tile(const double *sL, const double *sX, double *__restrict__ Lo,
-                                                     double *__restrict__ Tinv, int ldr, int kb, int tid)
+// The solve's layout of a 48 x 48 block M (a factor block below the diagonal, or a diagonal tile's inverse): it applies
+// M^T to a vector with thread (r, part) of 48 x 8 taking the rows part, part + 8, ... of column r, so entry (row, col) lives
+// at col * 48 + (row % 8) * 6 + row / 8 -- a thread's six entries are 48 contiguous bytes, a wave's 3 KB.
+__device__ __forceinline__ int pg_solve_slot(int row, int col) { return col * TB + (row & 7) * 6 + (row >> 3); }
+
+// a diagonal tile's inverse, from LDS to its two arrays: row-major for the next step's products, the solve's layout
+__device__ __forceinline__ void pg_store_factor_tile(const double *sX, double *__restrict__ Tinv, double *__restrict__ Tp,
+                                                     int kb, int tid)
 {
     constexpr int LD = TB + 1;
     for (int e = tid; e < TB * TB; e += 256) {
         const int r = e / TB, c = e - TB * r;
-        Lo[(size_t)(kb * TB + r) * ldr + kb * TB + c] = c <= r ? sL[r * LD + c] : 0.;
         Tinv[(size_t)kb * TB * TB + e] = c <= r ? sX[r * LD + c] : 0.;
+    }
+    for (int d = tid; d < TB * TB; d += 256) {  // destination order: coalesced stores
+        const int c = d / TB, w = d - TB * c, r = (w / 6) + 8 * (w % 6);
+        Tp[(size_t)kb * TB * TB + d] = c <= r ? sX[r * LD + c] : 0.;
     }
 }
 
 // the first diagonal tile (nothing to update before it)
-__global__ __launch_bounds__(256) void pg_dense_potf2_kernel(const double *__restrict__ A, double *__restrict__ Lo,
-                                                             double *__restrict__ Tinv, int ldr, int kb,
+__global__ __launch_bounds__(256) void pg_dense_potf2_kernel(const double *__restrict__ A, double *__restrict__ Tinv,
+                                                             double *__restrict__ Tp, int ldr, int kb,
                                                              int *__restrict__ status, int status_base)
 {
     constexpr int LD = TB + 1;
-    __shared__ double sL[TB * LD], sX[TB * LD], sT[TB * TB / 4];
+    __shared__ double sL[TB * LD], sX[TB * LD];
     __shared__ double sS6[36], sL6[36], sLi6[36];
     __shared__ int s_bad;
     const int tid = threadIdx.x;
@@ -808,10 +982,10 @@ __global__ __launch_bounds__(256) void pg_dense_potf2_kernel(const double *__res
     PGSTAMP(0);
     __syncthreads();
     PGSTAMP(1);
-    const int bad = pg_potf2_lds(true, sL, sX, sT, sS6, sL6, sLi6, &s_bad, tid);
+    const int bad = pg_potf2_lds(true, sL, sX, sS6, sL6, sLi6, &s_bad, tid);
     if (bad && tid == 0)
         atomicMax(status, status_base + kb * TB + bad);  // keep going with whatever is there: the host reports the failure
-    pg_store_factor_tile(sL, sX, Lo, Tinv, ldr, kb, tid);
+    pg_store_factor_tile(sX, Tinv, Tp, kb, tid);
     __syncthreads();
     PGSTAMP(51);
 }
@@ -867,8 +1041,9 @@ __device__ __forceinline__ void pg_tile_mult(const double *sX, const double *sY,
 // L_j,kb = P_j at hand, forms y_kb = Tinv_kb b_kb (48 x 48, every such workgroup for itself) and takes L_j,kb y_kb off
 // b_j; the first of them leaves y_kb in `yout`.  The solve kernel is left with the last tile's y and the backward sweep.
 // Workgroup 0 owns the tile (kb+1, kb+1): it keeps the updated tile in LDS and factorises it (see above).
-__global__ __launch_bounds__(256) void pg_dense_step_kernel(double *__restrict__ A, double *__restrict__ Lo,
-                                                            double *__restrict__ Tinv, int ldr, int kb,
+__global__ __launch_bounds__(256) void pg_dense_step_kernel(double *__restrict__ A, double *__restrict__ Ls,
+                                                            double *__restrict__ Tinv, double *__restrict__ Tp, int ldr,
+                                                            int T, int kb,
                                                             double *__restrict__ rhs, double *__restrict__ yout,
                                                             int *__restrict__ status, int status_base)
 {
@@ -895,12 +1070,23 @@ __global__ __launch_bounds__(256) void pg_dense_step_kernel(double *__restrict__
 #pragma unroll
         for (int b2 = 0; b2 < 3; b2++)
             old[a][b2] = keep ? A[(size_t)(i * TB + 3 * tr + a) * ldr + j * TB + 3 * tc + b2] : 0.;
-    for (int e = tid; e < TB * TB; e += 256) {
-        const int r = e / TB, c = e - TB * r;
-        sI[r * LD + c] = c <= r ? Tinv[(size_t)kb * TB * TB + e] : 0.;  // lower triangular
-        sA[r * LD + c] = A[(size_t)(i * TB + r) * ldr + kb * TB + c];
-        if (!diag)
-            sPj[r * LD + c] = A[(size_t)(j * TB + r) * ldr + kb * TB + c];  // A_j,kb for now
+    {  // Tinv_kb, A_i,kb, A_j,kb: every load on its way before the first is waited for
+        double vI[9], vA[9], vJ[9];
+#pragma unroll
+        for (int q = 0; q < 9; q++) {
+            const int e = tid + 256 * q, r = e / TB, c = e - TB * r;
+            vI[q] = Tinv[(size_t)kb * TB * TB + e];
+            vA[q] = A[(size_t)(i * TB + r) * ldr + kb * TB + c];
+            vJ[q] = diag ? 0. : A[(size_t)(j * TB + r) * ldr + kb * TB + c];
+        }
+#pragma unroll
+        for (int q = 0; q < 9; q++) {
+            const int e = tid + 256 * q, r = e / TB, c = e - TB * r;
+            sI[r * LD + c] = c <= r ? vI[q] : 0.;  // lower triangular
+            sA[r * LD + c] = vA[q];
+            if (!diag)
+                sPj[r * LD + c] = vJ[q];  // A_j,kb for now
+        }
     }
     if (diag && tid < TB)
         s_b[tid] = rhs[kb * TB + tid];
@@ -955,10 +1141,10 @@ __global__ __launch_bounds__(256) void pg_dense_step_kernel(double *__restrict__
     if (keep)
         pg_tile_mult<false>(sPi, Pj, tr, tc, acc);
     PGSTAMP(63);
-    if (j == kb + 1)
-        for (int e = tid; e < TB * TB; e += 256) {
-            const int r = e / TB, c = e - TB * r;
-            Lo[(size_t)(i * TB + r) * ldr + kb * TB + c] = sPi[r * LD + c];
+    if (j == kb + 1)  // the factor's block (i, kb), in the solve's layout
+        for (int d = tid; d < TB * TB; d += 256) {
+            const int c = d / TB, w = d - TB * c, r = (w / 6) + 8 * (w % 6);
+            Ls[((size_t)i * T + kb) * TB * TB + d] = sPi[r * LD + c];
         }
     if (blockIdx.x != 0) {
         if (keep) {
@@ -982,11 +1168,11 @@ __global__ __launch_bounds__(256) void pg_dense_step_kernel(double *__restrict__
             sA[(3 * tr + a) * LD + 3 * tc + b2] = keep ? old[a][b2] - acc[a][b2] : 0.;
     __syncthreads();  // also: sI, sPj and the right-hand side's use of sPi are over
     PGSTAMP(64);
-    const int bad = pg_potf2_lds(false, sA, sPj, sI, sS6, sL6, sLi6, &s_bad, tid);
+    const int bad = pg_potf2_lds(false, sA, sPj, sS6, sL6, sLi6, &s_bad, tid);
     if (bad && tid == 0)
         atomicMax(status, status_base + (kb + 1) * TB + bad);
     PGSTAMP(65);
-    pg_store_factor_tile(sA, sPj, Lo, Tinv, ldr, kb + 1, tid);
+    pg_store_factor_tile(sPj, Tinv, Tp, kb + 1, tid);
     __syncthreads();
     PGSTAMP(66);
 }
@@ -997,7 +1183,7 @@ __global__ __launch_bounds__(256) void pg_dense_step_kernel(double *__restrict__
 // above -- the tile (i, i-1), the only one the next step waits for, first; it and Tinv_{i-1} are asked for one step ahead
 // (six loads per thread each), the others in batches of six loads.  (Round 3 walked each column panel row by row, a
 // dependent load per row: 94 us for 480 rows; two barriers per tile step as before.)
-constexpr int PG_SOLVE_THREADS = TB * 8;
+constexpr int PG_SOLVE_THREADS = TB * 8, PG_SOLVE_SLICES = 16;
 __device__ __forceinline__ double pg_sum8(double v)
 {
     v = v + __shfl_xor(v, 1, 64);
@@ -1005,76 +1191,106 @@ __device__ __forceinline__ double pg_sum8(double v)
     v = v + __shfl_xor(v, 4, 64);
     return v;
 }
-__global__ __launch_bounds__(PG_SOLVE_THREADS) void pg_dense_solve_kernel(const double *__restrict__ Lo,
-                                                                          const double *__restrict__ Tinv, int ldr, int T,
+__global__ __launch_bounds__(PG_SOLVE_THREADS) void pg_dense_solve_kernel(const double *__restrict__ Ls,
+                                                                          const double *__restrict__ Tinv,
+                                                                          const double *__restrict__ Tp, int ldr, int T,
                                                                           const double *__restrict__ rhs, double *x)
 {
     extern __shared__ double sv[];  // ldr entries (y, then x) + ldr (acc) + TB
     double *sacc = sv + ldr, *st = sacc + ldr;
     const int tid = threadIdx.x;
-    const int r = tid >> 3, part = tid & 7;
-    // the eight lanes of column r take the rows part, part + 8, ... of a tile
-    auto load_tile = [&](int i, int kb, double (&l)[6]) {
-#pragma unroll
-        for (int q = 0; q < 6; q++)
-            l[q] = Lo[(size_t)(i * TB + part + 8 * q) * ldr + kb * TB + r];
-    };
-    auto load_tinv_t = [&](int kb, double (&l)[6]) {  // column r of Tinv_kb, rows r + part + 8 q (zero above the diagonal)
-#pragma unroll
-        for (int q = 0; q < 6; q++) {
-            const int c = r + part + 8 * q;
-            l[q] = c < TB ? Tinv[(size_t)kb * TB * TB + c * TB + r] : 0.;
+    if (blockIdx.x > 0) {
+        // Helpers.  The solve is one workgroup that reads the whole factor (1 MB at 85 separators) once, and what ONE
+        // compute unit gets out of memory that other XCDs have just written is ~16 GB/s: 60 us, whatever the order of the
+        // loads.  These workgroups only READ the factor, 1/16 of its rows each, and the dispatcher deals workgroups to the
+        // XCDs in turn: eight consecutive helpers bring the same slice into the eight L2s, so the solving workgroup finds
+        // the factor in the L2 of whichever XCD it runs on, a few microseconds after the launch.
+        const int h = blockIdx.x - 1, slice = h >> 3;
+        double acc = 0.;
+        for (int i = 1; i < T; i++) {  // block row i: the blocks (i, 0 .. i-1) are contiguous
+            const double *row = Ls + (size_t)i * T * TB * TB;
+            for (int e = slice * PG_SOLVE_THREADS + tid; e < i * TB * TB; e += PG_SOLVE_SLICES * PG_SOLVE_THREADS)
+                acc += row[e];
         }
+        for (int e = slice * PG_SOLVE_THREADS + tid; e < T * TB * TB; e += PG_SOLVE_SLICES * PG_SOLVE_THREADS)
+            acc += Tp[e];
+        asm volatile("" ::"v"(acc));  // the loads are the point
+        return;
+    }
+    const int r = tid >> 3, part = tid & 7;
+#ifdef PG_STAMPS
+    if (tid == 0)
+        pg_dbg[99] = wall_clock64();
+#endif
+    // thread (r, part): the rows part, part + 8, ... of column r of a block -- six contiguous doubles in the solve's layout,
+    // at a wave-uniform block base (scalar registers) + ONE per-thread offset for all blocks
+    const int toff = r * TB + part * 6;
+    auto load_block = [&](const double *base, double (&l)[6]) {
+        const double2 *p2 = reinterpret_cast<const double2 *>(base + toff);
+        const double2 v0 = p2[0], v1 = p2[1], v2 = p2[2];
+        l[0] = v0.x, l[1] = v0.y, l[2] = v1.x, l[3] = v1.y, l[4] = v2.x, l[5] = v2.y;
     };
+    auto load_tile = [&](int i, int kb, double (&l)[6]) { load_block(Ls + ((size_t)i * T + kb) * TB * TB, l); };
+    auto load_tinv_t = [&](int kb, double (&l)[6]) { load_block(Tp + (size_t)kb * TB * TB, l); };
     double nti[6], ntile[6];
     load_tinv_t(T - 1, nti);
-    if (T > 1)
-        load_tile(T - 1, T - 2, ntile);
+    load_tile(T - 1, T > 1 ? T - 2 : 0, ntile);
     // forward: y of the tiles 0 .. T-2 came with the factorisation (pg_dense_step_kernel left them in x, and took their
     // terms off the later blocks of rhs); the last tile's y = Tinv (its block of rhs) here
     for (int e = tid; e < ldr; e += PG_SOLVE_THREADS) {
         sv[e] = e < (T - 1) * TB ? x[e] : rhs[e];
         sacc[e] = 0.;
     }
-    __syncthreads();
+    lds_barrier();
     {
         const int kb = T - 1;
         if (part == 0)
             st[r] = sv[kb * TB + r];
-        __syncthreads();
+        lds_barrier();
         double a2 = 0;
         const double *ti = Tinv + (size_t)kb * TB * TB + r * TB;
         for (int c = part; c <= r; c += 8)
             a2 += ti[c] * st[c];
         a2 = pg_sum8(a2);
-        __syncthreads();
+        lds_barrier();
         if (part == 0)
             sv[kb * TB + r] = a2;
     }
+    const bool dbg = true;
+    PGSTAMP(100);
     for (int i = T - 1; i >= 0; i--) {  // backward: x_i = Tinv_i^T (y_i - acc_i)
-        double ti[6], tile[6];
+        PGSTAMP(101 + 2 * (i < 12 ? i : 12));
+        double ti[6], tile[6], far[8][6];
 #pragma unroll
         for (int q = 0; q < 6; q++) {
+            // what was asked for a step ago is waited for HERE, with nothing else on its way (left to itself the compiler
+            // finds the wait a few instructions after this step's loads have been issued, and waits for those as well)
+            asm volatile("" : "+v"(nti[q]), "+v"(ntile[q]));
             ti[q] = nti[q];
             tile[q] = ntile[q];
         }
-        if (i > 0)
-            load_tinv_t(i - 1, nti);
-        if (i > 1)
-            load_tile(i - 1, i - 2, ntile);
+        // asked for now, used after x_i is known (two barriers further down): this step's tiles further up the column,
+        // and what the next step waits for
+        // (every load unconditional, on a clamped tile index: a load under a branch makes the compiler wait for all
+        // loads at the join, and the point of issuing them here is that nobody waits)
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (i - 2 - u >= 0)  // (wave-uniform)
+                load_tile(i, i - 2 - u, far[u]);
+        load_tinv_t(i > 0 ? i - 1 : 0, nti);
+        load_tile(i > 0 ? i - 1 : 0, i > 1 ? i - 2 : 0, ntile);
         if (part == 0)
             st[r] = sv[i * TB + r] - sacc[i * TB + r];  // (r, part 0) is the only writer of sacc's column r
-        __syncthreads();
+        lds_barrier();
         double a2 = 0;
 #pragma unroll
-        for (int q = 0; q < 6; q++) {
-            const int c = r + part + 8 * q;
-            a2 += c < TB ? ti[q] * st[c] : 0.;
-        }
+        for (int q = 0; q < 6; q++)
+            a2 += ti[q] * st[part + 8 * q];  // (zeros above the diagonal)
         a2 = pg_sum8(a2);
         if (part == 0)
             sv[i * TB + r] = a2;
-        __syncthreads();
+        lds_barrier();
+        PGSTAMP(102 + 2 * (i < 12 ? i : 12));
         const double *xi = sv + i * TB + part;
         auto onto_acc = [&](int kb, const double (&l)[6]) {  // acc_kb += L_i,kb^T x_i
             double a = 0;
@@ -1087,7 +1303,11 @@ __global__ __launch_bounds__(PG_SOLVE_THREADS) void pg_dense_solve_kernel(const 
         };
         if (i > 0)
             onto_acc(i - 1, tile);
-        for (int kb0 = i - 2; kb0 >= 0; kb0 -= 4) {  // the tiles further up: four at a time in flight
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (i - 2 - u >= 0)
+                onto_acc(i - 2 - u, far[u]);
+        for (int kb0 = i - 10; kb0 >= 0; kb0 -= 4) {  // a system of more than ten tiles: the rest, four at a time in flight
             double tl[4][6];
 #pragma unroll
             for (int u = 0; u < 4; u++)
@@ -1099,7 +1319,8 @@ __global__ __launch_bounds__(PG_SOLVE_THREADS) void pg_dense_solve_kernel(const 
                     onto_acc(kb0 - u, tl[u]);
         }
     }
-    __syncthreads();
+    lds_barrier();
+    PGSTAMP(127);
     for (int e = tid; e < ldr; e += PG_SOLVE_THREADS)
         x[e] = sv[e];
 }
@@ -1491,7 +1712,7 @@ int svo_pg_optimize(svo_posegraph *g, int iters, double *chi2)
         (rc = g->d_rneg.ensure((size_t)nb * 48)) ||
         (rc = g->d_Y.ensure((size_t)nb * 48)) || (rc = g->d_Wl.ensure((size_t)nb * 288)) ||
         (rc = g->d_Wr.ensure((size_t)nb * 288)) || (rc = g->d_R.ensure((size_t)ldr * ldr * 8 + 64)) ||
-        (rc = g->d_Lo.ensure((size_t)ldr * ldr * 8 + 64)) || (rc = g->d_Tinv.ensure((size_t)T * TB * TB * 8 + 64)) ||
+        (rc = g->d_Lo.ensure((size_t)ldr * ldr * 8 + 64)) || (rc = g->d_Tinv.ensure((size_t)2 * (T + 1) * TB * TB * 8 + 64)) ||
         (rc = g->d_rR.ensure((size_t)ldr * 8 + 64)) || (rc = g->d_xR.ensure((size_t)ldr * 8 + 64)) ||
         (rc = g->d_dx.ensure((size_t)nb * 48)) || (rc = g->d_misc.ensure(((size_t)iters + 4) * 8 + 64)))
         return rc;
@@ -1557,14 +1778,15 @@ int svo_pg_optimize(svo_posegraph *g, int iters, double *chi2)
             hipLaunchKernelGGL(pg_reduce_kernel, dim3(n_rblocks + m), dim3(64), 0, st, n_rblocks, m, ds + o_rb_row,
                                ds + o_rb_col, ds + o_rptr, reinterpret_cast<const int2 *>(ds + o_rsrc), Dg, Cc, rneg, eo,
                                Y, Wl, Wr, R, ldr, rR);
-            hipLaunchKernelGGL(pg_dense_potf2_kernel, dim3(1), dim3(256), 0, st, R, Lo, Tinv, ldr, 0, d_status, 1 << 20);
+            double *Tp = Tinv + (size_t)(T + 1) * TB * TB;  // the inverses again, in the solve's layout
+            hipLaunchKernelGGL(pg_dense_potf2_kernel, dim3(1), dim3(256), 0, st, R, Tinv, Tp, ldr, 0, d_status, 1 << 20);
             for (int kb = 0; kb + 1 < T; kb++) {
                 const int nt = T - 1 - kb;
-                hipLaunchKernelGGL(pg_dense_step_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, st, R, Lo, Tinv, ldr, kb,
+                hipLaunchKernelGGL(pg_dense_step_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, st, R, Lo, Tinv, Tp, ldr, T, kb,
                                    rR, xR, d_status, 1 << 20);
             }
-            hipLaunchKernelGGL(pg_dense_solve_kernel, dim3(1), dim3(PG_SOLVE_THREADS), (size_t)(2 * ldr + TB) * 8, st, Lo,
-                               Tinv, ldr, T, rR, xR);
+            hipLaunchKernelGGL(pg_dense_solve_kernel, dim3(T > 2 ? 1 + 8 * PG_SOLVE_SLICES : 1), dim3(PG_SOLVE_THREADS),
+                               (size_t)(2 * ldr + TB) * 8, st, Lo, Tinv, Tp, ldr, T, rR, xR);
         }
         hipLaunchKernelGGL(pg_backsub_kernel, dim3((nb * 6 + 255) / 256), dim3(256), 0, st, nb, ds + o_sepidx,
                            ds + o_lsep, ds + o_rsep, xR, Y, Wl, Wr, dx);
@@ -1600,6 +1822,14 @@ int svo_pg_optimize(svo_posegraph *g, int iters, double *chi2)
         fprintf(stderr, "\nfirst step, workgroup 0, us:");
         for (int k = 61; k <= 66; k++)
             fprintf(stderr, " [%d]%.2f", k, (h[k] - h[60]) * 0.01);
+        fprintf(stderr, "\nseparator solve, us (start of step i, x_i known):");
+        for (int k = 100; k <= 127; k++)
+            if (h[k])
+                fprintf(stderr, " [%d]%.2f", k, (h[k] - h[99]) * 0.01);
+        fprintf(stderr, "\na long segment, us:");
+        for (int k = 71; k <= 97; k++)
+            if (h[k])
+                fprintf(stderr, " [%d]%.2f", k, (h[k] - h[70]) * 0.01);
         fprintf(stderr, "\n");
     }
 #endif
