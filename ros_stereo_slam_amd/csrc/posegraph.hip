@@ -87,18 +87,19 @@ __device__ inline void q_to_R(const double *q, double *R)
     R[8] = 1 - 2 * (x * x + y * y);
 }
 
-// per-edge output slot: 3 blocks + 2 gradients + chi2
-struct EdgeOut {
-    double Hii[36], Hij[36], Hjj[36], bi[6], bj[6], chi2, pad;
-};
+// per-edge outputs: 3 blocks + 2 gradients + chi2, one record of EO_FIELDS doubles per edge
+enum { EO_HII = 0, EO_HIJ = 36, EO_HJJ = 72, EO_BI = 108, EO_BJ = 114, EO_CHI2 = 120, EO_FIELDS = 122 };
 
 __global__ __launch_bounds__(128) void pg_linearize_kernel(const double *__restrict__ pose, const int *__restrict__ efrom,
                                                            const int *__restrict__ eto, const double *__restrict__ meas,
-                                                           int ne, EdgeOut *__restrict__ out)
+                                                           int ne, double *__restrict__ out, double *__restrict__ part,
+                                                           unsigned *__restrict__ ticket, double *__restrict__ chi2_out)
 {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= ne)
-        return;
+    __shared__ double s_chi[128];
+    __shared__ bool s_last;
+    const int e_raw = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = e_raw < ne;
+    const int e = live ? e_raw : ne - 1;  // the threads past the end redo the last edge and write nothing
     const double *Xi = pose + 7 * efrom[e], *Xj = pose + 7 * eto[e], *Z = meas + 7 * e;
     double A[7], Xi_inv[7], B[7], E[7];
     se3_inv(Z, A);
@@ -107,6 +108,44 @@ __global__ __launch_bounds__(128) void pg_linearize_kernel(const double *__restr
     se3_mul(A, B, E);
     const double s = E[6] < 0 ? -1. : 1.;
     const double err[6] = {E[0], E[1], E[2], s * E[3], s * E[4], s * E[5]};
+    double chi = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+        chi += err[k] * err[k];
+    // chi2 of the whole graph rides along: a fixed tree per workgroup, and the workgroup that finishes last adds the
+    // workgroups' sums in index order (the ticket resets itself for the next launch) -- no launch of its own, and
+    // BEFORE the blocks are formed and stored, so that the fence has one store to wait for
+    s_chi[threadIdx.x] = live ? chi : 0.;
+    __syncthreads();
+    for (int off = 64; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off)
+            s_chi[threadIdx.x] += s_chi[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&part[blockIdx.x], s_chi[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        s_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (s_last) {
+        __threadfence();
+        double sum = 0;  // (thread 0's)
+        for (unsigned base = 0; base < gridDim.x; base += 128) {  // the sums arrive 128 at a time, thread 0 adds them in order
+            const unsigned k = base + threadIdx.x;
+            s_chi[threadIdx.x] =
+                k < gridDim.x ? __hip_atomic_load(&part[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.;
+            __syncthreads();
+            if (threadIdx.x == 0)
+                for (unsigned q = 0; q < 128 && base + q < gridDim.x; q++)
+                    sum += s_chi[q];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            *chi2_out = sum;
+            *ticket = 0;
+        }
+    }
     double Ji[36], Jj[36], Re[9], Ra[9];
 #pragma unroll
     for (int k = 0; k < 36; k++) {
@@ -155,34 +194,32 @@ __global__ __launch_bounds__(128) void pg_linearize_kernel(const double *__restr
                 Ji[6 * (3 + r - 1) + 3 + c - 1] = -s * acc;
             }
     }
-    EdgeOut &o = out[e];
-    double chi = 0;
+    if (live) {
+        double *o = out + (size_t)e * EO_FIELDS;
+        o[EO_CHI2] = chi;
 #pragma unroll
-    for (int k = 0; k < 6; k++)
-        chi += err[k] * err[k];
-    o.chi2 = chi;
-#pragma unroll
-    for (int p = 0; p < 6; p++) {
-        double si = 0, sj = 0;
-#pragma unroll
-        for (int k = 0; k < 6; k++) {
-            si += Ji[6 * k + p] * err[k];
-            sj += Jj[6 * k + p] * err[k];
-        }
-        o.bi[p] = si;
-        o.bj[p] = sj;
-#pragma unroll
-        for (int q = 0; q < 6; q++) {
-            double a = 0, b = 0, c = 0;
+        for (int p = 0; p < 6; p++) {
+            double si = 0, sj = 0;
 #pragma unroll
             for (int k = 0; k < 6; k++) {
-                a += Ji[6 * k + p] * Ji[6 * k + q];
-                b += Ji[6 * k + p] * Jj[6 * k + q];
-                c += Jj[6 * k + p] * Jj[6 * k + q];
+                si += Ji[6 * k + p] * err[k];
+                sj += Jj[6 * k + p] * err[k];
             }
-            o.Hii[6 * p + q] = a;
-            o.Hij[6 * p + q] = b;
-            o.Hjj[6 * p + q] = c;
+            o[EO_BI + p] = si;
+            o[EO_BJ + p] = sj;
+#pragma unroll
+            for (int q = 0; q < 6; q++) {
+                double a = 0, b = 0, c = 0;
+#pragma unroll
+                for (int k = 0; k < 6; k++) {
+                    a += Ji[6 * k + p] * Ji[6 * k + q];
+                    b += Ji[6 * k + p] * Jj[6 * k + q];
+                    c += Jj[6 * k + p] * Jj[6 * k + q];
+                }
+                o[EO_HII + 6 * p + q] = a;
+                o[EO_HIJ + 6 * p + q] = b;
+                o[EO_HJJ + 6 * p + q] = c;
+            }
         }
     }
 }
@@ -229,58 +266,46 @@ __device__ __forceinline__ void lds_barrier()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
-// assemble: one thread per block row.  Incident edges of vertex v are
-// inc[incptr[v] .. incptr[v+1]) = edge*2 + role (role 0: v is the edge's `from`, 1: `to`),
+// assemble: one thread per block row AND entry (36 of the diagonal block, 36 of the chain block, 6 of the gradient): the
+// 78 threads of a row read consecutive doubles of an edge's record and write consecutive doubles of the row's blocks.
+// (One thread per row with 78 sums in registers: 4540 threads and three dependent rounds of scattered loads, 15.7 us.)
+// Incident edges of vertex v are inc[incptr[v] .. incptr[v+1]) = edge*2 + role (role 0: v is the edge's `from`, 1: `to`),
 // ascending in edge index, so every sum has a fixed order.
 //   Dg[b]  = sum of the vertex's diagonal blocks,  rneg[b] = -(sum of its gradients),
 //   Cc[b]  = H[b+1][b], the blocks of the edges between vertices b+1 and b+2.
-__global__ __launch_bounds__(128) void pg_assemble_kernel(int nb, const int *__restrict__ incptr,
-                                                          const int *__restrict__ inc, const int *__restrict__ efrom,
-                                                          const int *__restrict__ eto, const EdgeOut *__restrict__ eo,
-                                                          double *__restrict__ Dg, double *__restrict__ Cc,
-                                                          double *__restrict__ rneg)
+constexpr int PG_ASM_ROWS = 3;  // rows per workgroup: 3 x 78 = 234 threads
+__global__ __launch_bounds__(PG_ASM_ROWS * 78) void pg_assemble_kernel(int nb, const int *__restrict__ incptr,
+                                                                       const int *__restrict__ inc,
+                                                                       const int *__restrict__ efrom,
+                                                                       const int *__restrict__ eto,
+                                                                       const double *__restrict__ eo,
+                                                                       double *__restrict__ Dg, double *__restrict__ Cc,
+                                                                       double *__restrict__ rneg)
 {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.x * PG_ASM_ROWS + threadIdx.x / 78, k = threadIdx.x % 78;
     if (b >= nb)
         return;
     const int v = b + 1;
-    double D[36], C[36], g[6];
-#pragma unroll
-    for (int k = 0; k < 36; k++) {
-        D[k] = 0;
-        C[k] = 0;
-    }
-#pragma unroll
-    for (int k = 0; k < 6; k++)
-        g[k] = 0;
+    double acc = 0;
     for (int t = incptr[v]; t < incptr[v + 1]; t++) {
         const int e = inc[t] >> 1, role = inc[t] & 1;
-        const EdgeOut &o = eo[e];
-        const double *Hd = role ? o.Hjj : o.Hii, *gd = role ? o.bj : o.bi;
-#pragma unroll
-        for (int k = 0; k < 36; k++)
-            D[k] += Hd[k];
-#pragma unroll
-        for (int k = 0; k < 6; k++)
-            g[k] += gd[k];
-        const int other = role ? efrom[e] : eto[e];
-        if (other == v + 1) {
+        const double *o = eo + (size_t)e * EO_FIELDS;
+        if (k < 36)
+            acc += o[(role ? EO_HJJ : EO_HII) + k];
+        else if (k >= 72)
+            acc += o[(role ? EO_BJ : EO_BI) + (k - 72)];
+        else if ((role ? efrom[e] : eto[e]) == v + 1) {
             // block(v+1, v) = J_{v+1}^T J_v: v = `to` (role 1): Ji^T Jj as stored; v = `from`: its transpose
-#pragma unroll
-            for (int p = 0; p < 6; p++)
-#pragma unroll
-                for (int q = 0; q < 6; q++)
-                    C[6 * p + q] += role ? o.Hij[6 * p + q] : o.Hij[6 * q + p];
+            const int p = (k - 36) / 6, q = (k - 36) - 6 * p;
+            acc += o[EO_HIJ + (role ? 6 * p + q : 6 * q + p)];
         }
     }
-#pragma unroll
-    for (int k = 0; k < 36; k++) {
-        Dg[(size_t)b * 36 + k] = D[k];
-        Cc[(size_t)b * 36 + k] = C[k];
-    }
-#pragma unroll
-    for (int k = 0; k < 6; k++)
-        rneg[(size_t)b * 6 + k] = -g[k];
+    if (k < 36)
+        Dg[(size_t)b * 36 + k] = acc;
+    else if (k < 72)
+        Cc[(size_t)b * 36 + (k - 36)] = acc;
+    else
+        rneg[(size_t)b * 6 + (k - 72)] = -acc;
 }
 
 // 6x6 Cholesky S = L L^T and the inverse of L, by the 64 lanes of one wave on LDS arrays
@@ -426,14 +451,29 @@ __device__ inline bool lane_chol6_inv(double *blk)
     return ok;
 }
 
-__global__ __launch_bounds__(BCR_WAVES * 64) void pg_segment_kernel(int nb, const int *__restrict__ seg_start,
+// The workgroups past the segments clear the reduced (separator) matrix for the gather that follows -- identity on the
+// padded diagonal, zeros elsewhere -- beside the segments instead of in a launch of its own.
+constexpr int PG_CLEAR_WGS = 48;
+__global__ __launch_bounds__(BCR_WAVES * 64) void pg_segment_kernel(int nb, int nseg, const int *__restrict__ seg_start,
                                                                     const int *__restrict__ seg_len,
                                                                     const double *__restrict__ Dg,
                                                                     const double *__restrict__ Cc,
                                                                     const double *__restrict__ rneg,
                                                                     double *__restrict__ Y, double *__restrict__ Wl,
-                                                                    double *__restrict__ Wr, int *__restrict__ status)
+                                                                    double *__restrict__ Wr, int *__restrict__ status,
+                                                                    double *__restrict__ R, int ldr, int n_used,
+                                                                    double *__restrict__ rR)
 {
+    if ((int)blockIdx.x >= nseg) {
+        const size_t total = (size_t)ldr * ldr, step = (size_t)(gridDim.x - nseg) * BCR_WAVES * 64;
+        for (size_t t = (size_t)(blockIdx.x - nseg) * BCR_WAVES * 64 + threadIdx.x; t < total; t += step) {
+            const int r = (int)(t / ldr), c = (int)(t - (size_t)r * ldr);
+            R[t] = (r == c && r >= n_used) ? 1. : 0.;
+            if (t < (size_t)ldr)
+                rR[t] = 0.;
+        }
+        return;
+    }
     extern __shared__ double sm[];
     __shared__ int s_fail;
     // which of the separator columns of a row's right-hand side are not structurally zero (bit 0: the left separator's
@@ -718,7 +758,7 @@ __global__ __launch_bounds__(64) void pg_reduce_kernel(int n_blocks, int m, cons
                                                        const int *__restrict__ rb_col, const int *__restrict__ ptr,
                                                        const int2 *__restrict__ src, const double *__restrict__ Dg,
                                                        const double *__restrict__ Cc, const double *__restrict__ rneg,
-                                                       const EdgeOut *__restrict__ eo, const double *__restrict__ Y,
+                                                       const double *__restrict__ eo, int ne, const double *__restrict__ Y,
                                                        const double *__restrict__ Wl, const double *__restrict__ Wr,
                                                        double *__restrict__ R, int ldr, double *__restrict__ rR)
 {
@@ -735,8 +775,8 @@ __global__ __launch_bounds__(64) void pg_reduce_kernel(int n_blocks, int m, cons
             switch (kind) {
             case 0: v = Dg[(size_t)idx * 36 + lane]; break;
             case 1: v = C[lane]; break;
-            case 2: v = eo[idx].Hij[lane]; break;
-            case 3: v = eo[idx].Hij[6 * q + p]; break;
+            case 2: v = eo[(size_t)idx * EO_FIELDS + EO_HIJ + lane]; break;
+            case 3: v = eo[(size_t)idx * EO_FIELDS + EO_HIJ + 6 * q + p]; break;
             case 4:
                 for (int t2 = 0; t2 < 6; t2++)
                     v -= C[6 * t2 + p] * Wl[(size_t)(idx + 1) * 36 + 6 * t2 + q];
@@ -778,20 +818,6 @@ __global__ __launch_bounds__(64) void pg_reduce_kernel(int n_blocks, int m, cons
         }
         rR[6 * sidx + lane] = acc;
     }
-}
-
-// identity on the padded diagonal of the reduced matrix, zeros elsewhere (runs before the gather)
-__global__ __launch_bounds__(256) void pg_reduce_clear_kernel(double *__restrict__ R, int ldr, int n_used,
-                                                              double *__restrict__ rR)
-{
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t total = (size_t)ldr * ldr;
-    if (t < total) {
-        const int r = (int)(t / ldr), c = (int)(t - (size_t)r * ldr);
-        R[t] = (r == c && r >= n_used) ? 1. : 0.;
-    }
-    if (t < (size_t)ldr)
-        rR[t] = 0.;
 }
 
 // ---- blocked dense Cholesky of the reduced system (lower triangle, row-major, ld = ldr) ------
@@ -1325,44 +1351,48 @@ __global__ __launch_bounds__(PG_SOLVE_THREADS) void pg_dense_solve_kernel(const 
         x[e] = sv[e];
 }
 
-// dx of every block row: separators copy their reduced solution, interior rows combine
-// y - Wl x_l - Wr x_r (lsep / rsep: separator indices of the row's segment, -1 = none)
-__global__ __launch_bounds__(256) void pg_backsub_kernel(int nb, const int *__restrict__ sepidx,
-                                                         const int *__restrict__ lsep, const int *__restrict__ rsep,
-                                                         const double *__restrict__ xR, const double *__restrict__ Y,
-                                                         const double *__restrict__ Wl, const double *__restrict__ Wr,
-                                                         double *__restrict__ dx)
+// dx of every block row -- separators copy their reduced solution, interior rows combine y - Wl x_l - Wr x_r (lsep /
+// rsep: separator indices of the row's segment, -1 = none) -- and the vertex's update X <- X * fromVectorMQT(dx) in the
+// same launch: six threads per row form dx, the first of them applies it.
+constexpr int PG_UPD_ROWS = 32;
+__global__ __launch_bounds__(PG_UPD_ROWS * 6) void pg_backsub_update_kernel(int nb, const int *__restrict__ sepidx,
+                                                                            const int *__restrict__ lsep,
+                                                                            const int *__restrict__ rsep,
+                                                                            const double *__restrict__ xR,
+                                                                            const double *__restrict__ Y,
+                                                                            const double *__restrict__ Wl,
+                                                                            const double *__restrict__ Wr,
+                                                                            double *__restrict__ pose)
 {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ double s_dx[PG_UPD_ROWS * 6];
+    const int t = blockIdx.x * (PG_UPD_ROWS * 6) + threadIdx.x;
     const int b = t / 6, r = t - 6 * b;
-    if (b >= nb)
-        return;
-    const int si = sepidx[b];
-    if (si >= 0) {
-        dx[t] = xR[6 * si + r];
-        return;
-    }
-    double v = Y[t];
-    const int l = lsep[b], rr = rsep[b];
-    if (l >= 0) {
+    if (b < nb) {
+        const int si = sepidx[b];
+        double v;
+        if (si >= 0)
+            v = xR[6 * si + r];
+        else {
+            v = Y[t];
+            const int l = lsep[b], rr = rsep[b];
+            if (l >= 0) {
 #pragma unroll
-        for (int c = 0; c < 6; c++)
-            v -= Wl[(size_t)b * 36 + 6 * r + c] * xR[6 * l + c];
-    }
-    if (rr >= 0) {
+                for (int c = 0; c < 6; c++)
+                    v -= Wl[(size_t)b * 36 + 6 * r + c] * xR[6 * l + c];
+            }
+            if (rr >= 0) {
 #pragma unroll
-        for (int c = 0; c < 6; c++)
-            v -= Wr[(size_t)b * 36 + 6 * r + c] * xR[6 * rr + c];
+                for (int c = 0; c < 6; c++)
+                    v -= Wr[(size_t)b * 36 + 6 * r + c] * xR[6 * rr + c];
+            }
+        }
+        s_dx[threadIdx.x] = v;
     }
-    dx[t] = v;
-}
-
-__global__ __launch_bounds__(128) void pg_update_kernel(int nv, double *__restrict__ pose, const double *__restrict__ dx)
-{
-    const int v = blockIdx.x * blockDim.x + threadIdx.x + 1;
-    if (v >= nv)
+    __syncthreads();
+    if (b >= nb || r != 0)
         return;
-    const double *d = dx + (size_t)(v - 1) * 6;
+    const double *d = s_dx + threadIdx.x;
+    const int v = b + 1;
     double D[7] = {d[0], d[1], d[2], 0, 0, 0, 1}, O[7];
     const double w = 1. - (d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
     if (w >= 0) {  // else: identity rotation (g2o fromCompactQuaternion)
@@ -1375,23 +1405,6 @@ __global__ __launch_bounds__(128) void pg_update_kernel(int nv, double *__restri
     q_normalize(O + 3);
     for (int k = 0; k < 7; k++)
         pose[7 * v + k] = O[k];
-}
-
-__global__ __launch_bounds__(256) void pg_chi2_kernel(const EdgeOut *__restrict__ eo, int ne, double *__restrict__ out)
-{
-    __shared__ double s_p[256];
-    double s = 0;
-    for (int e = threadIdx.x; e < ne; e += 256)
-        s += eo[e].chi2;
-    s_p[threadIdx.x] = s;
-    __syncthreads();
-    for (int off = 128; off >= 1; off >>= 1) {
-        if (threadIdx.x < off)
-            s_p[threadIdx.x] += s_p[threadIdx.x + off];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0)
-        *out = s_p[0];
 }
 
 }  // namespace
@@ -1437,7 +1450,7 @@ struct svo_posegraph {
     size_t o_seg_start = 0, o_seg_len = 0, o_sepidx = 0, o_lsep = 0, o_rsep = 0, o_rb_row = 0, o_rb_col = 0, o_rptr = 0,
            o_rsrc = 0;
     DevBuf d_pose, d_from, d_to, d_meas, d_eo, d_incptr, d_inc, d_struct, d_Dg, d_Cc, d_rneg, d_Y,
-        d_Wl, d_Wr, d_R, d_Lo, d_Tinv, d_rR, d_xR, d_dx, d_misc;
+        d_Wl, d_Wr, d_R, d_Lo, d_Tinv, d_rR, d_xR, d_misc;
     int nv() const { return (int)(pose.size() / 7); }
     int ne() const { return (int)efrom.size(); }
 };
@@ -1461,7 +1474,7 @@ int svo_pg_destroy(svo_posegraph *g)
     (void)hipStreamSynchronize(g->ctx->stream);
     DevBuf *bufs[] = {&g->d_pose, &g->d_from, &g->d_to, &g->d_meas, &g->d_eo,  &g->d_incptr, &g->d_inc, &g->d_struct,
                       &g->d_Dg,   &g->d_Cc,   &g->d_rneg, &g->d_Y,     &g->d_Wl,
-                      &g->d_Wr,   &g->d_R,    &g->d_Lo, &g->d_Tinv, &g->d_rR,  &g->d_xR,  &g->d_dx,    &g->d_misc};
+                      &g->d_Wr,   &g->d_R,    &g->d_Lo, &g->d_Tinv, &g->d_rR,  &g->d_xR,  &g->d_misc};
     for (DevBuf *b : bufs)
         b->release();
     delete g;
@@ -1706,7 +1719,7 @@ int svo_pg_optimize(svo_posegraph *g, int iters, double *chi2)
         (rc = ensure_keep(g->d_to, (size_t)ne * 4, (size_t)g->dev_ne * 4, st)) ||
         (rc = ensure_keep(g->d_meas, (size_t)ne * 56, (size_t)g->dev_ne * 56, st)))
         return rc;
-    if ((rc = g->d_eo.ensure((size_t)ne * sizeof(EdgeOut))) || (rc = g->d_incptr.ensure((size_t)(nv + 1) * 4)) ||
+    if ((rc = g->d_eo.ensure((size_t)ne * EO_FIELDS * 8)) || (rc = g->d_incptr.ensure((size_t)(nv + 1) * 4)) ||
         (rc = g->d_inc.ensure((size_t)2 * ne * 4)) || (rc = g->d_struct.ensure(g->h_struct.size() * 4 + 16)) ||
         (rc = g->d_Dg.ensure((size_t)nb * 288)) || (rc = g->d_Cc.ensure((size_t)nb * 288)) ||
         (rc = g->d_rneg.ensure((size_t)nb * 48)) ||
@@ -1714,7 +1727,7 @@ int svo_pg_optimize(svo_posegraph *g, int iters, double *chi2)
         (rc = g->d_Wr.ensure((size_t)nb * 288)) || (rc = g->d_R.ensure((size_t)ldr * ldr * 8 + 64)) ||
         (rc = g->d_Lo.ensure((size_t)ldr * ldr * 8 + 64)) || (rc = g->d_Tinv.ensure((size_t)2 * (T + 1) * TB * TB * 8 + 64)) ||
         (rc = g->d_rR.ensure((size_t)ldr * 8 + 64)) || (rc = g->d_xR.ensure((size_t)ldr * 8 + 64)) ||
-        (rc = g->d_dx.ensure((size_t)nb * 48)) || (rc = g->d_misc.ensure(((size_t)iters + 4) * 8 + 64)))
+        (rc = g->d_misc.ensure(((size_t)iters + 6 + (ne + 127) / 128) * 8 + 64)))
         return rc;
     // (g->pose / efrom / eto / meas and the structure vectors live in *g: the copies below need no sync)
     if (nv > g->dev_nv)
@@ -1737,12 +1750,14 @@ int svo_pg_optimize(svo_posegraph *g, int iters, double *chi2)
     const int *ds = g->d_struct.as<int>();
     double *d_chi = g->d_misc.as<double>();
     int *d_status = reinterpret_cast<int *>(d_chi + iters + 2);
-    SVO_HIP(hipMemsetAsync(d_status, 0, 4, st));
-    EdgeOut *eo = reinterpret_cast<EdgeOut *>(g->d_eo.p);
+    unsigned *d_ticket = reinterpret_cast<unsigned *>(d_chi + iters + 3);
+    double *d_part = d_chi + iters + 4;  // chi2 per linearize workgroup
+    SVO_HIP(hipMemsetAsync(d_status, 0, 16, st));  // status and ticket
+    double *eo = g->d_eo.as<double>();
     double *Dg = g->d_Dg.as<double>(), *Cc = g->d_Cc.as<double>(), *rneg = g->d_rneg.as<double>();
     double *Y = g->d_Y.as<double>(), *Wl = g->d_Wl.as<double>(), *Wr = g->d_Wr.as<double>();
     double *R = g->d_R.as<double>(), *Lo = g->d_Lo.as<double>(), *Tinv = g->d_Tinv.as<double>();
-    double *rR = g->d_rR.as<double>(), *xR = g->d_xR.as<double>(), *dx = g->d_dx.as<double>();
+    double *rR = g->d_rR.as<double>(), *xR = g->d_xR.as<double>();
     // the separator solve keeps its vector and its running sums in LDS
     const size_t solve_lds = (size_t)(2 * ldr + TB) * 8;
     if (solve_lds > 158 * 1024) {
@@ -1762,22 +1777,21 @@ int svo_pg_optimize(svo_posegraph *g, int iters, double *chi2)
     ScopedKernelTime tm(ctx, SVO_K_POSEGRAPH);
     for (int it = 0; it <= iters; it++) {
         hipLaunchKernelGGL(pg_linearize_kernel, dim3((ne + 127) / 128), dim3(128), 0, st, g->d_pose.as<double>(),
-                           g->d_from.as<int>(), g->d_to.as<int>(), g->d_meas.as<double>(), ne, eo);
-        hipLaunchKernelGGL(pg_chi2_kernel, dim3(1), dim3(256), 0, st, eo, ne, d_chi + it);
+                           g->d_from.as<int>(), g->d_to.as<int>(), g->d_meas.as<double>(), ne, eo, d_part, d_ticket,
+                           d_chi + it);
         if (it == iters)
             break;
-        hipLaunchKernelGGL(pg_assemble_kernel, dim3((nb + 127) / 128), dim3(128), 0, st, nb, g->d_incptr.as<int>(),
-                           g->d_inc.as<int>(), g->d_from.as<int>(), g->d_to.as<int>(), eo, Dg, Cc, rneg);
-        if (nseg > 0)
-            hipLaunchKernelGGL(pg_segment_kernel, dim3(nseg), dim3(BCR_WAVES * 64), seg_lds, st, nb, ds + o_seg_start,
-                               ds + o_seg_len, Dg, Cc, rneg, Y, Wl, Wr, d_status);
+        hipLaunchKernelGGL(pg_assemble_kernel, dim3((nb + PG_ASM_ROWS - 1) / PG_ASM_ROWS), dim3(PG_ASM_ROWS * 78), 0, st, nb,
+                           g->d_incptr.as<int>(), g->d_inc.as<int>(), g->d_from.as<int>(), g->d_to.as<int>(), eo, Dg, Cc,
+                           rneg);
+        if (nseg > 0 || m > 0)
+            hipLaunchKernelGGL(pg_segment_kernel, dim3(nseg + (m > 0 ? PG_CLEAR_WGS : 0)), dim3(BCR_WAVES * 64), seg_lds, st,
+                               nb, nseg, ds + o_seg_start, ds + o_seg_len, Dg, Cc, rneg, Y, Wl, Wr, d_status, R, ldr, 6 * m,
+                               rR);
         if (m > 0) {
-            const size_t tot = (size_t)ldr * ldr;
-            hipLaunchKernelGGL(pg_reduce_clear_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, R, ldr,
-                               6 * m, rR);
             hipLaunchKernelGGL(pg_reduce_kernel, dim3(n_rblocks + m), dim3(64), 0, st, n_rblocks, m, ds + o_rb_row,
                                ds + o_rb_col, ds + o_rptr, reinterpret_cast<const int2 *>(ds + o_rsrc), Dg, Cc, rneg, eo,
-                               Y, Wl, Wr, R, ldr, rR);
+                               ne, Y, Wl, Wr, R, ldr, rR);
             double *Tp = Tinv + (size_t)(T + 1) * TB * TB;  // the inverses again, in the solve's layout
             hipLaunchKernelGGL(pg_dense_potf2_kernel, dim3(1), dim3(256), 0, st, R, Tinv, Tp, ldr, 0, d_status, 1 << 20);
             for (int kb = 0; kb + 1 < T; kb++) {
@@ -1788,9 +1802,8 @@ int svo_pg_optimize(svo_posegraph *g, int iters, double *chi2)
             hipLaunchKernelGGL(pg_dense_solve_kernel, dim3(T > 2 ? 1 + 8 * PG_SOLVE_SLICES : 1), dim3(PG_SOLVE_THREADS),
                                (size_t)(2 * ldr + TB) * 8, st, Lo, Tinv, Tp, ldr, T, rR, xR);
         }
-        hipLaunchKernelGGL(pg_backsub_kernel, dim3((nb * 6 + 255) / 256), dim3(256), 0, st, nb, ds + o_sepidx,
-                           ds + o_lsep, ds + o_rsep, xR, Y, Wl, Wr, dx);
-        hipLaunchKernelGGL(pg_update_kernel, dim3((nv + 127) / 128), dim3(128), 0, st, nv, g->d_pose.as<double>(), dx);
+        hipLaunchKernelGGL(pg_backsub_update_kernel, dim3((nb + PG_UPD_ROWS - 1) / PG_UPD_ROWS), dim3(PG_UPD_ROWS * 6), 0, st,
+                           nb, ds + o_sepidx, ds + o_lsep, ds + o_rsep, xR, Y, Wl, Wr, g->d_pose.as<double>());
     }
     SVO_HIP(hipGetLastError());
     // the optimised poses go into a temporary: a failed solve must not destroy the caller's estimate
