@@ -1016,50 +1016,44 @@ __global__ __launch_bounds__(256) void pg_dense_potf2_kernel(const double *__res
     PGSTAMP(51);
 }
 
-// out[r][c] (-)= sum_k X[r][k] Y[c][k], k < kmax(c): a 3 x 3 block of the 48 x 48 result per thread (16 x 16 threads), so
-// that six LDS reads feed nine multiply-adds (one entry per thread and two reads per multiply-add made this kernel
-// LDS-bound at 35 us per tile)
-template <bool TRI>
-__device__ __forceinline__ void pg_tile_mult(const double *sX, const double *sY, int tr, int tc, double (&acc)[3][3])
+// C = X Y^T for 48 x 48 tiles in LDS on the matrix cores (v_mfma_f64_16x16x4_f64): waves 0..2 take a block row of three
+// 16 x 16 blocks each, twelve k-steps of four.  Lane l feeds A[i = l & 15][k = l >> 4] = X[16 I + i][4 s + k] and
+// B[k][j = l & 15] = Y[16 J + j][4 s + k], and holds D[row = (l >> 4) + 4 reg][col = l & 15] in its four results.  f64 MFMA
+// has the rate of the vector unit on this chip; what it buys is LDS traffic: two reads per 1024 multiply-adds instead of
+// six per nine (3 x 3 register blocks per thread on the vector unit were LDS-bound at 2.4 us a product; 1.0 us now).
+// TRI: Y is lower triangular (block column J needs k < 16 (J + 1) only).  LOWER: only the blocks J <= I are stored.
+// sC may be sX: a wave reads only its own 16 rows of X and writes only those rows of C.
+typedef double pg_double4 __attribute__((ext_vector_type(4)));
+template <bool TRI, bool LOWER>
+__device__ __forceinline__ void pg_tile_mult_mfma(const double *sX, const double *sY, double *sC, int tid)
 {
     constexpr int LD = TB + 1;
+    const int I = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+    if (I >= 3)
+        return;
+    const double *px = sX + (16 * I + li) * LD + lk, *py = sY + li * LD + lk;
+    pg_double4 acc[3];
 #pragma unroll
-    for (int a = 0; a < 3; a++)
+    for (int J = 0; J < 3; J++)
+        acc[J] = (pg_double4){0., 0., 0., 0.};
 #pragma unroll
-        for (int b2 = 0; b2 < 3; b2++)
-            acc[a][b2] = 0;
-    // TRI: Y is lower triangular (Y[c][k] = 0 for k > c): columns 3 tc .. 3 tc + 2 need k <= 3 tc + 2 only
-    const int kend = TRI ? 3 * tc + 3 : TB;
-    const double *px = sX + (3 * tr) * LD, *py = sY + (3 * tc) * LD;
-    // three k at a time; the next three are on their way from LDS while these are multiplied (explicit fused
-    // multiply-adds: the library is built without contraction, and a step of this loop is 27 of them)
-    double x[3][3], y[3][3], nx[3][3], ny[3][3];
-    auto fetch = [&](int k, double (&fx)[3][3], double (&fy)[3][3]) {
+    for (int s4 = 0; s4 < TB / 4; s4++) {
+        const double a = px[4 * s4];
 #pragma unroll
-        for (int a = 0; a < 3; a++)
+        for (int J = 0; J < 3; J++) {
+            if (TRI && s4 >= 4 * (J + 1))
+                continue;
+            const double b = py[16 * J * LD + 4 * s4];
+            acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[J], 0, 0, 0);
+        }
+    }
 #pragma unroll
-            for (int q = 0; q < 3; q++) {
-                fx[a][q] = px[a * LD + k + q];
-                fy[a][q] = py[a * LD + k + q];
-            }
-    };
-    fetch(0, x, y);
-    for (int k = 0; k < kend; k += 3) {
-        fetch(k + 3 < TB ? k + 3 : TB - 3, nx, ny);  // (past kend: fetched, not used)
+    for (int J = 0; J < 3; J++) {
+        if (LOWER && J > I)
+            continue;
 #pragma unroll
-        for (int q = 0; q < 3; q++)
-#pragma unroll
-            for (int a = 0; a < 3; a++)
-#pragma unroll
-                for (int b2 = 0; b2 < 3; b2++)
-                    acc[a][b2] = fma(x[a][q], y[b2][q], acc[a][b2]);
-#pragma unroll
-        for (int a = 0; a < 3; a++)
-#pragma unroll
-            for (int q = 0; q < 3; q++) {
-                x[a][q] = nx[a][q];
-                y[a][q] = ny[a][q];
-            }
+        for (int reg = 0; reg < 4; reg++)
+            sC[(16 * I + lk + 4 * reg) * LD + 16 * J + li] = acc[J][reg];
     }
 }
 
@@ -1079,8 +1073,10 @@ __global__ __launch_bounds__(256) void pg_dense_step_kernel(double *__restrict__
     __shared__ int s_bad;
     constexpr int LD = TB + 1;
     const int tid = threadIdx.x, tr = tid >> 4, tc = tid & 15;
-    // linear tile index -> (i, j) with kb < j <= i < T
-    int t = blockIdx.x, i = kb + 1;
+    // linear tile index -> (i, j) with kb < j <= i < T.  The LAST workgroup of the launch is workgroup 0's stand-in for the
+    // right-hand side of block row kb+1 (it forms P_kb+1 once more and leaves): workgroup 0 is the launch's critical path.
+    const bool rhs_only = blockIdx.x == gridDim.x - 1;
+    int t = rhs_only ? 0 : blockIdx.x, i = kb + 1;
     while (t >= i - kb) {
         t -= i - kb;
         i++;
@@ -1118,17 +1114,11 @@ __global__ __launch_bounds__(256) void pg_dense_step_kernel(double *__restrict__
         s_b[tid] = rhs[kb * TB + tid];
     __syncthreads();
     PGSTAMP(61);
-    double acc[3][3];
-    pg_tile_mult<true>(sA, sI, tr, tc, acc);  // P_i = A_i,kb * Tinv^T
-#pragma unroll
-    for (int a = 0; a < 3; a++)
-#pragma unroll
-        for (int b2 = 0; b2 < 3; b2++)
-            sPi[(3 * tr + a) * LD + 3 * tc + b2] = acc[a][b2];
+    pg_tile_mult_mfma<true, false>(sA, sI, sPi, tid);  // P_i = A_i,kb * Tinv^T
     if (!diag)
-        pg_tile_mult<true>(sPj, sI, tr, tc, acc);  // P_j = A_j,kb * Tinv^T: kept in registers until all have read A_j,kb
+        pg_tile_mult_mfma<true, false>(sPj, sI, sPj, tid);  // P_j = A_j,kb * Tinv^T, in place
     __syncthreads();
-    if (diag) {  // the right-hand side of block row j (see above); sI is the lower-triangular Tinv_kb; four lanes per row
+    if (diag && blockIdx.x != 0) {  // the right-hand side of block row j (see above); sI is the lower-triangular Tinv_kb; four lanes per row
         const int rr = tid >> 2, part = tid & 3;
         if (tid < 4 * TB) {
             double a = 0;
@@ -1139,7 +1129,7 @@ __global__ __launch_bounds__(256) void pg_dense_step_kernel(double *__restrict__
             a += __shfl_xor(a, 2, 64);
             if (part == 0) {
                 s_y[rr] = a;
-                if (blockIdx.x == 0)
+                if (rhs_only)
                     yout[kb * TB + rr] = a;
             }
         }
@@ -1154,18 +1144,22 @@ __global__ __launch_bounds__(256) void pg_dense_step_kernel(double *__restrict__
             if (part == 0)
                 rhs[j * TB + rr] -= a;
         }
-    } else {
-#pragma unroll
-        for (int a = 0; a < 3; a++)
-#pragma unroll
-            for (int b2 = 0; b2 < 3; b2++)
-                sPj[(3 * tr + a) * LD + 3 * tc + b2] = acc[a][b2];  // every thread has read its rows of A_j,kb (barrier above)
-        __syncthreads();
+        if (rhs_only)
+            return;
+        __syncthreads();  // Tinv_kb in sI has been used: the product below goes there
     }
-    const double *Pj = diag ? sPi : sPj;
     PGSTAMP(62);
-    if (keep)
-        pg_tile_mult<false>(sPi, Pj, tr, tc, acc);
+    if (diag)
+        pg_tile_mult_mfma<false, true>(sPi, sPi, sI, tid);
+    else
+        pg_tile_mult_mfma<false, false>(sPi, sPj, sI, tid);
+    __syncthreads();
+    double acc[3][3];  // this thread's 3 x 3 block of P_i P_j^T
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b2 = 0; b2 < 3; b2++)
+            acc[a][b2] = keep ? sI[(3 * tr + a) * LD + 3 * tc + b2] : 0.;
     PGSTAMP(63);
     if (j == kb + 1)  // the factor's block (i, kb), in the solve's layout
         for (int d = tid; d < TB * TB; d += 256) {
@@ -1796,7 +1790,7 @@ int svo_pg_optimize(svo_posegraph *g, int iters, double *chi2)
             hipLaunchKernelGGL(pg_dense_potf2_kernel, dim3(1), dim3(256), 0, st, R, Tinv, Tp, ldr, 0, d_status, 1 << 20);
             for (int kb = 0; kb + 1 < T; kb++) {
                 const int nt = T - 1 - kb;
-                hipLaunchKernelGGL(pg_dense_step_kernel, dim3(nt * (nt + 1) / 2), dim3(256), 0, st, R, Lo, Tinv, Tp, ldr, T, kb,
+                hipLaunchKernelGGL(pg_dense_step_kernel, dim3(nt * (nt + 1) / 2 + 1), dim3(256), 0, st, R, Lo, Tinv, Tp, ldr, T, kb,
                                    rR, xR, d_status, 1 << 20);
             }
             hipLaunchKernelGGL(pg_dense_solve_kernel, dim3(T > 2 ? 1 + 8 * PG_SOLVE_SLICES : 1), dim3(PG_SOLVE_THREADS),
