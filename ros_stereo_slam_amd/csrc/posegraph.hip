@@ -323,11 +323,10 @@ __device__ __forceinline__ double pg_readlane(double v, int src)  // src: a comp
 // Row r of the matrix lives in the registers of lane r (six lanes work, the others shadow lane 0); what a lane needs of
 // another row arrives through v_readlane, so the six pivot steps and the forward substitution of the inverse touch
 // neither LDS nor a barrier.
-template <bool WANT_L = true>
-__device__ inline bool wave_chol6_inv(double *sS, double *sL, double *sLi, int lane)
+// The two halves, on registers: the factor (row `row` of L in a[], the pivots' reciprocal square roots in rinv[]) ...
+__device__ __forceinline__ bool wave_chol6_regs(const double *sS, int lane, double (&a)[6], double (&rinv)[6])
 {
     const int row = lane < 6 ? lane : 0;
-    double a[6], rinv[6];
 #pragma unroll
     for (int c = 0; c < 6; c++)
         a[c] = sS[6 * row + c];
@@ -349,8 +348,12 @@ __device__ inline bool wave_chol6_inv(double *sS, double *sL, double *sLi, int l
             if (j > k)
                 a[j] -= lk * pg_readlane(lk, j);  // S[row][j] -= L[row][k] L[j][k]; used for j <= row only
     }
-    // column `row` of L^-1 by forward substitution
-    double x[6];
+    return ok;
+}
+// ... and column `row` of L^-1 by forward substitution (x[r] = L^-1[r][row])
+__device__ __forceinline__ void wave_inv6_regs(const double (&a)[6], const double (&rinv)[6], int lane, double (&x)[6])
+{
+    const int row = lane < 6 ? lane : 0;
 #pragma unroll
     for (int r = 0; r < 6; r++) {
         double sacc = r == row ? 1. : 0.;
@@ -360,6 +363,13 @@ __device__ inline bool wave_chol6_inv(double *sS, double *sL, double *sLi, int l
                 sacc -= pg_readlane(a[k], r) * (k >= row ? x[k] : 0.);
         x[r] = r < row ? 0. : sacc * rinv[r];
     }
+}
+template <bool WANT_L = true>
+__device__ inline bool wave_chol6_inv(double *sS, double *sL, double *sLi, int lane)
+{
+    double a[6], rinv[6], x[6];
+    const bool ok = wave_chol6_regs(sS, lane, a, rinv);
+    wave_inv6_regs(a, rinv, lane, x);
     if (lane < 6) {  // (sLi may be sS: every lane has read its row long ago)
         if (WANT_L) {
 #pragma unroll
@@ -830,17 +840,20 @@ __global__ __launch_bounds__(64) void pg_reduce_kernel(int n_blocks, int m, cons
 // Column kb of A is only read in step kb, the factor goes to a separate array: no races.
 
 // Cholesky of the 48 x 48 tile in sL (lower triangle; what is above the diagonal is never read) and the inverse of the
-// factor into sX (zeroed here), blocked by 6 inside the tile.  The serial chain is the eight 6 x 6 diagonal blocks
-// (wave_chol6_inv, the segments' routine, by wave 0); everything else is arranged around it, two barriers per block step:
-//   P  the panel below the diagonal block, L21 = A21 L11^-T (a thread per row), and the inverse's block row
-//      X[b][c] = -L_bb^-1 Z[b][c] (a thread per column; Z = sum_{c <= k < b} L[b][k] X[k][c] has been accumulated in place);
+// factor into sX (zeroed here), blocked by 6 inside the tile.  The serial chain is the eight 6 x 6 diagonal blocks'
+// FACTORS (wave_chol6_regs, by wave 0); everything else is arranged around it, two barriers per block step:
+//   P  the panel below the diagonal block, L21 L11^T = A21, and the inverse's block row, L11 X[b][c] = -Z[b][c] (Z =
+//      sum_{c <= k < b} L[b][k] X[k][c] has been accumulated in place): forward substitutions with L11 and the pivots'
+//      reciprocals, a thread per row / per column -- and wave 0 forms L11^-1 meanwhile (nobody waits for it: it is the
+//      inverse's diagonal block, read in Q);
 //   Q  wave 0 takes the NEXT diagonal block's update out of the panel and factorises it, while waves 1..3 do the trailing
-//      update A22 -= L21 L21^T and add this step's terms to Z in the rows below -- 3 x 3 blocks per thread on the 16 x 16
-//      thread grid of the tile products, the same code for both (the rows of wave 0's threads are done with by then).
+//      update A22 -= L21 L21^T and add this step's terms to Z in the rows below -- 3 x 3 blocks per thread on a 16 x 16
+//      thread grid, the same code for both (the rows of wave 0's threads are done with by then).
 // (Round 3: factor, panel, trailing update one after the other with three barriers, then the inverse from inverted
-// halves -- 26 us a tile; the inverse grown with the factor in the shadow of the diagonal block -- 17 us.)
-// Returns (to every thread) 0 or 1 + the row of the first non-positive pivot.
-__device__ __forceinline__ int pg_potf2_lds(bool dbg, double *sL, double *sX, double *sS6, double *sL6, double *sLi6,
+// halves -- 26 us a tile; 10.6 us with the 6 x 6 inverse still in wave 0's chain.)
+// sL6: L11 (zeros above the diagonal), sR6: the six reciprocals.  Returns (to every thread) 0 or 1 + the row of the first
+// non-positive pivot.
+__device__ __forceinline__ int pg_potf2_lds(bool dbg, double *sL, double *sX, double *sS6, double *sL6, double *sR6,
                                             int *s_bad, int tid)
 {
     constexpr int LD = TB + 1, NB6 = TB / 6;
@@ -850,6 +863,7 @@ __device__ __forceinline__ int pg_potf2_lds(bool dbg, double *sL, double *sX, do
     if (tid == 0)
         *s_bad = 0;
     lds_barrier();
+    double fa[6], fr[6];  // wave 0: the current diagonal block's factor, kept for its inverse
     // the diagonal block at o2, with the update from the panel columns o .. o+5 (o < 0: none), by wave 0
     auto diag_block = [&](int o, int o2) {
         if (tid < 36) {
@@ -863,12 +877,16 @@ __device__ __forceinline__ int pg_potf2_lds(bool dbg, double *sL, double *sX, do
             sS6[tid] = v;
         }
         wave_sync();
-        if (!wave_chol6_inv(sS6, sL6, sLi6, tid) && tid == 0 && *s_bad == 0)
+        if (!wave_chol6_regs(sS6, tid, fa, fr) && tid == 0 && *s_bad == 0)
             *s_bad = 1 + o2;
-        if (tid < 36) {
-            const int i = tid / 6, j = tid - 6 * i;
-            sL[(o2 + i) * LD + o2 + j] = sL6[tid];  // zero above the diagonal
-            sX[(o2 + i) * LD + o2 + j] = sLi6[tid];
+        if (tid < 6) {
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                const double v = c <= tid ? fa[c] : 0.;  // zero above the diagonal
+                sL6[6 * tid + c] = v;
+                sL[(o2 + tid) * LD + o2 + c] = v;
+            }
+            sR6[tid] = fr[tid];
         }
     };
     if (tid < 64)
@@ -878,40 +896,42 @@ __device__ __forceinline__ int pg_potf2_lds(bool dbg, double *sL, double *sX, do
         const int o = 6 * blk, below = TB - o - 6;
         PGSTAMP(2 + 2 * blk);
         // ---- P ----
-        if (tid < below) {  // row o + 6 + tid of the panel: (A21 L11^-T)[r][c] = sum_{t <= c} A21[r][t] Li[c][t]
-            double *row = sL + (o + 6 + tid) * LD + o;
-            double av[6], out[6];
+        if (tid < 64) {  // L11^-1, the inverse's diagonal block
+            double x[6];
+            wave_inv6_regs(fa, fr, tid, x);
+            if (tid < 6) {
 #pragma unroll
-            for (int t = 0; t < 6; t++)
-                av[t] = row[t];
-#pragma unroll
-            for (int c = 0; c < 6; c++) {
-                double acc = 0.;
-#pragma unroll
-                for (int t = 0; t <= c; t++)
-                    acc += av[t] * sLi6[6 * c + t];
-                out[c] = acc;
+                for (int r = 0; r < 6; r++)
+                    sX[(o + r) * LD + o + tid] = x[r];
             }
-#pragma unroll
-            for (int c = 0; c < 6; c++)
-                row[c] = out[c];
-        } else if (tid >= 64 && tid - 64 < o) {  // column tid - 64 of the inverse's block row: -Li Z, in place
+        } else if (tid - 64 < o) {  // column tid - 64 of the inverse's block row: L11 x = -z, in place
             double *col = sX + o * LD + (tid - 64);
-            double zv[6], out[6];
-#pragma unroll
-            for (int t = 0; t < 6; t++)
-                zv[t] = col[t * LD];
+            double x[6];
 #pragma unroll
             for (int i = 0; i < 6; i++) {
-                double acc = 0.;
+                double acc = -col[i * LD];
 #pragma unroll
-                for (int t = 0; t <= i; t++)
-                    acc -= sLi6[6 * i + t] * zv[t];
-                out[i] = acc;
+                for (int t = 0; t < i; t++)
+                    acc -= sL6[6 * i + t] * x[t];
+                x[i] = acc * sR6[i];
             }
 #pragma unroll
             for (int i = 0; i < 6; i++)
-                col[i * LD] = out[i];
+                col[i * LD] = x[i];
+        } else if (tid >= 128 && tid - 128 < below) {  // row o + 6 + (tid - 128) of the panel: x L11^T = a
+            double *row = sL + (o + 6 + tid - 128) * LD + o;
+            double x[6];
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                double acc = row[c];
+#pragma unroll
+                for (int t = 0; t < c; t++)
+                    acc -= x[t] * sL6[6 * c + t];
+                x[c] = acc * sR6[c];
+            }
+#pragma unroll
+            for (int c = 0; c < 6; c++)
+                row[c] = x[c];
         }
         lds_barrier();
         PGSTAMP(3 + 2 * blk);
@@ -997,7 +1017,7 @@ __global__ __launch_bounds__(256) void pg_dense_potf2_kernel(const double *__res
 {
     constexpr int LD = TB + 1;
     __shared__ double sL[TB * LD], sX[TB * LD];
-    __shared__ double sS6[36], sL6[36], sLi6[36];
+    __shared__ double sS6[36], sL6[36], sR6[6];
     __shared__ int s_bad;
     const int tid = threadIdx.x;
     for (int e = tid; e < TB * TB; e += 256) {
@@ -1008,7 +1028,7 @@ __global__ __launch_bounds__(256) void pg_dense_potf2_kernel(const double *__res
     PGSTAMP(0);
     __syncthreads();
     PGSTAMP(1);
-    const int bad = pg_potf2_lds(true, sL, sX, sS6, sL6, sLi6, &s_bad, tid);
+    const int bad = pg_potf2_lds(true, sL, sX, sS6, sL6, sR6, &s_bad, tid);
     if (bad && tid == 0)
         atomicMax(status, status_base + kb * TB + bad);  // keep going with whatever is there: the host reports the failure
     pg_store_factor_tile(sX, Tinv, Tp, kb, tid);
@@ -1069,7 +1089,7 @@ __global__ __launch_bounds__(256) void pg_dense_step_kernel(double *__restrict__
 {
     __shared__ double sI[TB * (TB + 1)], sPi[TB * (TB + 1)], sPj[TB * (TB + 1)], sA[TB * (TB + 1)];
     __shared__ double s_y[TB], s_b[TB];
-    __shared__ double sS6[36], sL6[36], sLi6[36];
+    __shared__ double sS6[36], sL6[36], sR6[6];
     __shared__ int s_bad;
     constexpr int LD = TB + 1;
     const int tid = threadIdx.x, tr = tid >> 4, tc = tid & 15;
@@ -1188,7 +1208,7 @@ __global__ __launch_bounds__(256) void pg_dense_step_kernel(double *__restrict__
             sA[(3 * tr + a) * LD + 3 * tc + b2] = keep ? old[a][b2] - acc[a][b2] : 0.;
     __syncthreads();  // also: sI, sPj and the right-hand side's use of sPi are over
     PGSTAMP(64);
-    const int bad = pg_potf2_lds(false, sA, sPj, sS6, sL6, sLi6, &s_bad, tid);
+    const int bad = pg_potf2_lds(false, sA, sPj, sS6, sL6, sR6, &s_bad, tid);
     if (bad && tid == 0)
         atomicMax(status, status_base + (kb + 1) * TB + bad);
     PGSTAMP(65);
