@@ -1220,10 +1220,13 @@ __global__ __launch_bounds__(256) void pg_dense_step_kernel(double *__restrict__
 // L^T x = y with the tiles' inverses (the forward substitution came with the factorisation, except for the last tile).
 // One workgroup of 384 threads = 48 columns x 8 row parts; the vector and the running sums  acc_kb = sum_{i > kb}
 // L_i,kb^T x_i  live in LDS.  Tile step i: x_i = Tinv_i^T (y_i - acc_i), then x_i's terms go onto the acc of every tile
-// above -- the tile (i, i-1), the only one the next step waits for, first; it and Tinv_{i-1} are asked for one step ahead
-// (six loads per thread each), the others in batches of six loads.  (Round 3 walked each column panel row by row, a
-// dependent load per row: 94 us for 480 rows; two barriers per tile step as before.)
-constexpr int PG_SOLVE_THREADS = TB * 8, PG_SOLVE_SLICES = 16;
+// above.  The tile (i, i-1) and Tinv_{i-1}, which the next step waits for, are asked for one step ahead; this step's other
+// blocks at the top of the step, two LDS-only barriers before they are used.  What made this kernel fast was the LAYOUT of
+// the factor: with row-major blocks a thread's six values were six rows apart and a wave's load touched eight 64-byte
+// pieces -- one compute unit got 16 GB/s out of it, 60 us for the megabyte of an 81-separator factor whatever the order
+// of the loads (round 3: 94 us with a dependent load per row); in the solve's own layout (pg_solve_slot) the same data
+// are three 16-byte loads per thread and 3 KB contiguous per wave: 25 us.
+constexpr int PG_SOLVE_THREADS = TB * 8;
 __device__ __forceinline__ double pg_sum8(double v)
 {
     v = v + __shfl_xor(v, 1, 64);
@@ -1239,24 +1242,6 @@ __global__ __launch_bounds__(PG_SOLVE_THREADS) void pg_dense_solve_kernel(const 
     extern __shared__ double sv[];  // ldr entries (y, then x) + ldr (acc) + TB
     double *sacc = sv + ldr, *st = sacc + ldr;
     const int tid = threadIdx.x;
-    if (blockIdx.x > 0) {
-        // Helpers.  The solve is one workgroup that reads the whole factor (1 MB at 85 separators) once, and what ONE
-        // compute unit gets out of memory that other XCDs have just written is ~16 GB/s: 60 us, whatever the order of the
-        // loads.  These workgroups only READ the factor, 1/16 of its rows each, and the dispatcher deals workgroups to the
-        // XCDs in turn: eight consecutive helpers bring the same slice into the eight L2s, so the solving workgroup finds
-        // the factor in the L2 of whichever XCD it runs on, a few microseconds after the launch.
-        const int h = blockIdx.x - 1, slice = h >> 3;
-        double acc = 0.;
-        for (int i = 1; i < T; i++) {  // block row i: the blocks (i, 0 .. i-1) are contiguous
-            const double *row = Ls + (size_t)i * T * TB * TB;
-            for (int e = slice * PG_SOLVE_THREADS + tid; e < i * TB * TB; e += PG_SOLVE_SLICES * PG_SOLVE_THREADS)
-                acc += row[e];
-        }
-        for (int e = slice * PG_SOLVE_THREADS + tid; e < T * TB * TB; e += PG_SOLVE_SLICES * PG_SOLVE_THREADS)
-            acc += Tp[e];
-        asm volatile("" ::"v"(acc));  // the loads are the point
-        return;
-    }
     const int r = tid >> 3, part = tid & 7;
 #ifdef PG_STAMPS
     if (tid == 0)
@@ -1813,7 +1798,7 @@ int svo_pg_optimize(svo_posegraph *g, int iters, double *chi2)
                 hipLaunchKernelGGL(pg_dense_step_kernel, dim3(nt * (nt + 1) / 2 + 1), dim3(256), 0, st, R, Lo, Tinv, Tp, ldr, T, kb,
                                    rR, xR, d_status, 1 << 20);
             }
-            hipLaunchKernelGGL(pg_dense_solve_kernel, dim3(T > 2 ? 1 + 8 * PG_SOLVE_SLICES : 1), dim3(PG_SOLVE_THREADS),
+            hipLaunchKernelGGL(pg_dense_solve_kernel, dim3(1), dim3(PG_SOLVE_THREADS),
                                (size_t)(2 * ldr + TB) * 8, st, Lo, Tinv, Tp, ldr, T, rR, xR);
         }
         hipLaunchKernelGGL(pg_backsub_update_kernel, dim3((nb + PG_UPD_ROWS - 1) / PG_UPD_ROWS), dim3(PG_UPD_ROWS * 6), 0, st,
