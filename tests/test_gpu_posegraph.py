@@ -45,6 +45,29 @@ def test_iterates_match_oracle(ctx, orc, n, laps, closures):
         g.close()
 
 
+def test_awkward_segment_shapes(ctx, orc):
+    """The elimination structure's corner cases in one graph of 760 vertices, four laps of a loop, every closure between
+    true revisits (vertex i + 190 k and vertex i): runs of 0, 1, 2, 3, 13, 16, 17, 29, 64, 73, 74, 83 and 103 rows
+    between separators (103: the longest a workgroup's LDS takes; every level count of the cyclic reduction from 1 to 7),
+    separators next to each other, closures that share an endpoint, closures to the fixed vertex 0 and to vertex 1 (the
+    first unknown), the first and the last unknown as separators."""
+    gt, est = drifting_loop(760, radius=60.0, yaw_drift=2e-4, scale_drift=1.0005, laps=4)
+    cuts = [1, 3, 6, 10, 12, 16, 33, 51, 116]
+    closures = [(190 + c, c) for c in cuts] + [(410, 220), (571, 1), (192, 2), (190, 0), (380, 0), (675, 485), (759, 569)]
+    closures.sort()
+    ends = sorted({a - 1 for a, b in closures} | {b - 1 for a, b in closures if b > 0})
+    runs = set(np.diff(ends) - 1)
+    assert {0, 1, 2, 3, 13, 16, 17, 64, 73, 103} <= runs, sorted(runs)
+    g = _build(lambda: capi.PoseGraph(ctx), est, closures)
+    o = _build(orc.PoseGraph, est, closures)
+    cg, co = g.optimize(6), o.optimize(6)
+    assert cg[0] == pytest.approx(co[0], rel=1e-12)
+    assert np.all(np.abs(cg[1:] - co[1:]) <= 1e-7 * co[:-1] + 1e-14), (cg, co)
+    assert _close(g.estimates(), o.estimates(), 1e-7)
+    assert cg[-1] < 1e-2 * cg[0]
+    g.close()
+
+
 def test_golden_and_odometry_only(ctx):
     gt, est = drifting_loop(40)
     g = _build(lambda: capi.PoseGraph(ctx), est, [(39, 0)])
