@@ -19,11 +19,24 @@
 //                    candidates, ties at the cut in raster order, ballot-scan write
 //   describe         ONE WAVEFRONT PER KEYPOINT: disc moments reduced with DPP, the 256 tests 64 at
 //                    a time, descriptor words straight from __ballot
+#include <cstring>
+#include <vector>
+
 #include "svo_internal.h"
 
 namespace {
 
-constexpr int EDGE = 19, HALF_PATCH = 15, STRIP = 1024;
+constexpr int EDGE = 19, HALF_PATCH = 15, STRIP = 1024, NLEV = 3;
+
+// The three octaves go through every stage in ONE launch (blockIdx.z / .y = the octave): 11 launches per image instead of
+// 29, on buffers that hold the octaves side by side.  (A launch per stage and octave was 0.46 ms per image, most of it the
+// 4-5 us each of two dozen launches that do microseconds of work.)
+struct OrbLevels {
+    const uint8_t *lvl[NLEV];
+    int pitch[NLEV], w[NLEV], h[NLEV], want[NLEV];
+    int pix_off[NLEV], strip_off[NLEV], cand_off[NLEV], cand_cap[NLEV];  // where an octave's part of a work buffer begins
+    int on[NLEV];                                                         // 0: too small for the border, or nothing wanted
+};
 
 __global__ __launch_bounds__(256) void gray_kernel(const uint8_t *__restrict__ img, int n, int c,
                                                    uint8_t *__restrict__ gray)
@@ -35,11 +48,13 @@ __global__ __launch_bounds__(256) void gray_kernel(const uint8_t *__restrict__ i
                      : (uint8_t)((1868 * img[3 * i] + 9617 * img[3 * i + 1] + 4899 * img[3 * i + 2] + 8192) >> 14);
 }
 
-__global__ __launch_bounds__(256) void blur5_kernel(const uint8_t *__restrict__ lvl, int pitch, int w, int h,
-                                                    uint8_t *__restrict__ out)
+__global__ __launch_bounds__(256) void blur5_kernel(OrbLevels L, uint8_t *__restrict__ out_all)
 {
+    const int l = blockIdx.z, w = L.w[l], h = L.h[l], pitch = L.pitch[l];
+    const uint8_t *__restrict__ lvl = L.lvl[l];
+    uint8_t *__restrict__ out = out_all + L.pix_off[l];
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= w || y >= h)
+    if (!L.on[l] || x >= w || y >= h)
         return;
     int s = 0;
 #pragma unroll
@@ -61,11 +76,15 @@ __device__ __forceinline__ bool nine_contiguous(unsigned m)
     return (r & 0xffffu) != 0;
 }
 
-__global__ __launch_bounds__(256) void fast_harris_kernel(const uint8_t *__restrict__ lvl, int pitch, int w, int h,
-                                                          int t, float *__restrict__ R, uint8_t *__restrict__ corner)
+__global__ __launch_bounds__(256) void fast_harris_kernel(OrbLevels L, int t, float *__restrict__ R_all,
+                                                          uint8_t *__restrict__ corner_all)
 {
+    const int l = blockIdx.z, w = L.w[l], h = L.h[l], pitch = L.pitch[l];
+    const uint8_t *__restrict__ lvl = L.lvl[l];
+    float *__restrict__ R = R_all + L.pix_off[l];
+    uint8_t *__restrict__ corner = corner_all + L.pix_off[l];
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= w || y >= h)
+    if (!L.on[l] || x >= w || y >= h)
         return;
     const size_t idx = (size_t)y * w + x;
     float resp = 0.f;
@@ -109,11 +128,18 @@ __global__ __launch_bounds__(256) void fast_harris_kernel(const uint8_t *__restr
 
 // 3x3 non-maximum suppression among corners (strictly above the raster-earlier neighbours, at
 // least equal to the later ones) + the number of survivors per 1024-pixel strip
-__global__ __launch_bounds__(STRIP) void nms_count_kernel(const float *__restrict__ R, const uint8_t *__restrict__ corner,
-                                                          int w, int h, uint8_t *__restrict__ keep,
-                                                          int *__restrict__ strip_count)
+__global__ __launch_bounds__(STRIP) void nms_count_kernel(OrbLevels L, const float *__restrict__ R_all,
+                                                          const uint8_t *__restrict__ corner_all,
+                                                          uint8_t *__restrict__ keep_all, int *__restrict__ strip_count_all)
 {
     __shared__ int s_w[16];
+    const int l = blockIdx.y, w = L.w[l], h = L.h[l];
+    if (!L.on[l] || (int)blockIdx.x * STRIP >= w * h)
+        return;
+    const float *__restrict__ R = R_all + L.pix_off[l];
+    const uint8_t *__restrict__ corner = corner_all + L.pix_off[l];
+    uint8_t *__restrict__ keep = keep_all + L.pix_off[l];
+    int *__restrict__ strip_count = strip_count_all + L.strip_off[l];
     const int idx = blockIdx.x * STRIP + threadIdx.x;
     bool k = false;
     if (idx < w * h && corner[idx]) {
@@ -149,10 +175,19 @@ __global__ __launch_bounds__(STRIP) void nms_count_kernel(const float *__restric
 }
 
 // exclusive scan of the strip counts (one workgroup; n_strips <= a few thousand)
-__global__ __launch_bounds__(1024) void strip_scan_kernel(const int *__restrict__ cnt, int n, int *__restrict__ off,
-                                                          int *__restrict__ total)
+__global__ __launch_bounds__(1024) void strip_scan_kernel(OrbLevels L, const int *__restrict__ cnt_all,
+                                                          int *__restrict__ off_all, int *__restrict__ totals)
 {
     __shared__ int s_part[1024];
+    const int l = blockIdx.x, n = (L.w[l] * L.h[l] + STRIP - 1) / STRIP;
+    const int *__restrict__ cnt = cnt_all + L.strip_off[l];
+    int *__restrict__ off = off_all + L.strip_off[l];
+    int *__restrict__ total = totals + l;
+    if (!L.on[l]) {
+        if (threadIdx.x == 0)
+            *total = 0;
+        return;
+    }
     const int t = threadIdx.x;
     const int per = (n + 1023) / 1024;
     int s = 0;
@@ -177,11 +212,19 @@ __global__ __launch_bounds__(1024) void strip_scan_kernel(const int *__restrict_
     }
 }
 
-__global__ __launch_bounds__(STRIP) void cand_write_kernel(const uint8_t *__restrict__ keep, const float *__restrict__ R,
-                                                           int n_pix, const int *__restrict__ off, int cap,
-                                                           int *__restrict__ cand_idx, float *__restrict__ cand_resp)
+__global__ __launch_bounds__(STRIP) void cand_write_kernel(OrbLevels L, const uint8_t *__restrict__ keep_all,
+                                                           const float *__restrict__ R_all, const int *__restrict__ off_all,
+                                                           int *__restrict__ cand_idx_all, float *__restrict__ cand_resp_all)
 {
     __shared__ int s_w[16];
+    const int l = blockIdx.y, n_pix = L.w[l] * L.h[l], cap = L.cand_cap[l];
+    if (!L.on[l] || (int)blockIdx.x * STRIP >= n_pix)
+        return;
+    const uint8_t *__restrict__ keep = keep_all + L.pix_off[l];
+    const float *__restrict__ R = R_all + L.pix_off[l];
+    const int *__restrict__ off = off_all + L.strip_off[l];
+    int *__restrict__ cand_idx = cand_idx_all + L.cand_off[l];
+    float *__restrict__ cand_resp = cand_resp_all + L.cand_off[l];
     const int idx = blockIdx.x * STRIP + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool k = idx < n_pix && keep[idx];
@@ -208,14 +251,26 @@ __device__ __forceinline__ unsigned sortable(float f)
 }
 
 // the `want` strongest candidates (ties at the cut: earlier pixel first), written in raster order
-__global__ __launch_bounds__(1024) void select_kernel(const int *__restrict__ cand_idx, const float *__restrict__ cand_resp,
-                                                      const int *__restrict__ d_nc, int cap, int want,
-                                                      int *__restrict__ sel_idx, float *__restrict__ sel_resp,
-                                                      int *__restrict__ d_nsel)
+__global__ __launch_bounds__(1024) void select_kernel(OrbLevels L, const int *__restrict__ cand_idx_all,
+                                                      const float *__restrict__ cand_resp_all,
+                                                      const int *__restrict__ d_nc_all, int n_features,
+                                                      int *__restrict__ sel_idx_all, float *__restrict__ sel_resp_all,
+                                                      int *__restrict__ d_nsel_all)
 {
     __shared__ int s_red[16], s_bcast, s_base, s_ties;
+    const int l = blockIdx.x, cap = L.cand_cap[l], want = L.want[l];
+    const int *__restrict__ cand_idx = cand_idx_all + L.cand_off[l];
+    const float *__restrict__ cand_resp = cand_resp_all + L.cand_off[l];
+    int *__restrict__ sel_idx = sel_idx_all + (size_t)l * n_features;
+    float *__restrict__ sel_resp = sel_resp_all + (size_t)l * n_features;
+    int *__restrict__ d_nsel = d_nsel_all + l;
+    if (!L.on[l]) {
+        if (threadIdx.x == 0)
+            *d_nsel = 0;
+        return;
+    }
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int nc = min(*d_nc, cap);
+    const int nc = min(d_nc_all[l], cap);
     auto block_sum = [&](int v) -> int {
         v += __shfl_xor(v, 32, 64);
         v += __shfl_xor(v, 16, 64);
@@ -310,18 +365,34 @@ __device__ __forceinline__ int wave_sum_int(int v)
 }
 
 // one wavefront per selected keypoint: orientation + descriptor, appended at out_base
-__global__ __launch_bounds__(256) void describe_kernel(const uint8_t *__restrict__ lvl, int pitch, int w,
-                                                       const uint8_t *__restrict__ blur, const int *__restrict__ sel_idx,
-                                                       const float *__restrict__ sel_resp, const int *__restrict__ d_nsel,
-                                                       const int8_t *__restrict__ pat, int octave,
-                                                       const int *__restrict__ d_out_base, float *__restrict__ xy,
-                                                       int *__restrict__ oct, float *__restrict__ resp,
-                                                       float *__restrict__ dir, uint32_t *__restrict__ desc)
+__global__ __launch_bounds__(256) void describe_kernel(OrbLevels L, const uint8_t *__restrict__ blur_all,
+                                                       const int *__restrict__ sel_idx_all,
+                                                       const float *__restrict__ sel_resp_all,
+                                                       const int *__restrict__ d_nsel_all, int n_features,
+                                                       const int8_t *__restrict__ pat, int *__restrict__ d_total,
+                                                       float *__restrict__ xy, int *__restrict__ oct,
+                                                       float *__restrict__ resp, float *__restrict__ dir,
+                                                       uint32_t *__restrict__ desc)
 {
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, octave = blockIdx.y;
+    // an octave's features follow those of the octaves before it; the first thread of the launch leaves the total
+    int out_base = 0, total = 0;
+#pragma unroll
+    for (int q = 0; q < NLEV; q++) {
+        const int nq = d_nsel_all[q];
+        out_base += q < octave ? nq : 0;
+        total += nq;
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+        *d_total = total;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= *d_nsel)
+    if (i >= d_nsel_all[octave])
         return;
+    const uint8_t *__restrict__ lvl = L.lvl[octave];
+    const int pitch = L.pitch[octave], w = L.w[octave];
+    const uint8_t *__restrict__ blur = blur_all + L.pix_off[octave];
+    const int *__restrict__ sel_idx = sel_idx_all + (size_t)octave * n_features;
+    const float *__restrict__ sel_resp = sel_resp_all + (size_t)octave * n_features;
     const int idx = sel_idx[i], x = idx % w, y = idx / w;
     int m10 = 0, m01 = 0;
     // the radius-15 disc, row by row; lanes take its 709 pixels in raster order
@@ -338,7 +409,7 @@ __global__ __launch_bounds__(256) void describe_kernel(const uint8_t *__restrict
     const float f10 = (float)m10, f01 = (float)m01;
     const float nrm = sqrtf(f10 * f10 + f01 * f01);
     const float cs = nrm > 0.f ? f10 / nrm : 1.f, sn = nrm > 0.f ? f01 / nrm : 0.f;
-    const int o = *d_out_base + i;
+    const int o = out_base + i;
     uint32_t *d = desc + (size_t)8 * o;
 #pragma unroll
     for (int pass = 0; pass < 4; pass++) {
@@ -364,8 +435,6 @@ __global__ __launch_bounds__(256) void describe_kernel(const uint8_t *__restrict
     }
 }
 
-__global__ void add_count_kernel(int *total, const int *add) { *total += *add; }
-__global__ void zero_int_kernel(int *p) { *p = 0; }
 
 void orb_pattern_host(int8_t *pat)
 {
@@ -393,7 +462,8 @@ struct svo_orb {
     int w = 0, h = 0, c = 0, n_features = 500, fast_t = 20;
     svo_pyramid *pyr = nullptr;  // grey, 3 octaves
     DevBuf gray, blur, R, corner, keep, strip_cnt, strip_off, cand_idx, cand_resp, sel_idx, sel_resp, pat, counts;
-    int cand_cap = 0;
+    OrbLevels lv;            // the octaves' geometry and their places in the work buffers
+    int max_strips = 0, max_want = 0;
 };
 
 int svo_orb_create(svo_ctx *ctx, int w, int h, int c, int n_features, int fast_t, svo_orb **out)
@@ -406,15 +476,40 @@ int svo_orb_create(svo_ctx *ctx, int w, int h, int c, int n_features, int fast_t
     o->c = c;
     o->n_features = n_features;
     o->fast_t = fast_t;
-    int rc = svo_pyramid_create(ctx, w, h, 1, 3, &o->pyr);
-    const size_t npix = (size_t)w * h;
-    o->cand_cap = (int)(npix / 4 + 1024);  // non-maximum suppression leaves at most one corner per 2x2
-    const int strips = (int)((npix + STRIP - 1) / STRIP);
-    if (rc || (rc = o->gray.ensure(npix)) || (rc = o->blur.ensure(npix)) || (rc = o->R.ensure(npix * 4)) ||
-        (rc = o->corner.ensure(npix)) || (rc = o->keep.ensure(npix)) || (rc = o->strip_cnt.ensure((size_t)strips * 4)) ||
-        (rc = o->strip_off.ensure((size_t)strips * 4)) || (rc = o->cand_idx.ensure((size_t)o->cand_cap * 4)) ||
-        (rc = o->cand_resp.ensure((size_t)o->cand_cap * 4)) || (rc = o->sel_idx.ensure((size_t)n_features * 4 + 64)) ||
-        (rc = o->sel_resp.ensure((size_t)n_features * 4 + 64)) || (rc = o->pat.ensure(1024)) ||
+    int rc = svo_pyramid_create(ctx, w, h, 1, NLEV, &o->pyr);
+    if (rc) {
+        svo_orb_destroy(o);
+        return rc;
+    }
+    OrbLevels &L = o->lv;
+    const PyrDev &pd = o->pyr->dev;
+    L.want[0] = (int)(n_features * 4.0 / 7.0 + 0.5);
+    L.want[1] = (int)(n_features * 2.0 / 7.0 + 0.5);
+    L.want[2] = n_features - L.want[0] - L.want[1];
+    size_t pix = 0, strips = 0, cand = 0;
+    for (int l = 0; l < NLEV; l++) {
+        L.lvl[l] = pd.lvl[l];
+        L.pitch[l] = pd.pitch[l];
+        L.w[l] = pd.w[l];
+        L.h[l] = pd.h[l];
+        L.on[l] = L.w[l] > 2 * EDGE && L.h[l] > 2 * EDGE && L.want[l] > 0;
+        const size_t npix = (size_t)L.w[l] * L.h[l];
+        L.pix_off[l] = (int)pix;
+        L.strip_off[l] = (int)strips;
+        L.cand_off[l] = (int)cand;
+        L.cand_cap[l] = (int)(npix / 4 + 1024);  // non-maximum suppression leaves at most one corner per 2x2
+        const int st = (int)((npix + STRIP - 1) / STRIP);
+        o->max_strips = st > o->max_strips ? st : o->max_strips;
+        o->max_want = L.want[l] > o->max_want ? L.want[l] : o->max_want;
+        pix += (npix + 63) & ~(size_t)63;
+        strips += st;
+        cand += L.cand_cap[l];
+    }
+    if ((rc = o->gray.ensure((size_t)w * h)) || (rc = o->blur.ensure(pix)) || (rc = o->R.ensure(pix * 4)) ||
+        (rc = o->corner.ensure(pix)) || (rc = o->keep.ensure(pix)) || (rc = o->strip_cnt.ensure(strips * 4)) ||
+        (rc = o->strip_off.ensure(strips * 4)) || (rc = o->cand_idx.ensure(cand * 4)) ||
+        (rc = o->cand_resp.ensure(cand * 4)) || (rc = o->sel_idx.ensure((size_t)NLEV * n_features * 4 + 64)) ||
+        (rc = o->sel_resp.ensure((size_t)NLEV * n_features * 4 + 64)) || (rc = o->pat.ensure(1024)) ||
         (rc = o->counts.ensure(64))) {
         svo_orb_destroy(o);
         return rc;
@@ -458,36 +553,22 @@ int svo_orb_launch(svo_orb *o, const uint8_t *d_image, float *d_xy, int *d_oct, 
     int rc = svo_build_pyramid_from_device(ctx, o->pyr, o->gray.as<uint8_t>());
     if (rc)
         return rc;
-    int *d_nc = o->counts.as<int>(), *d_nsel = d_nc + 1;
-    hipLaunchKernelGGL(zero_int_kernel, dim3(1), dim3(1), 0, st, d_n);
-    int want[3];
-    want[0] = (int)(o->n_features * 4.0 / 7.0 + 0.5);
-    want[1] = (int)(o->n_features * 2.0 / 7.0 + 0.5);
-    want[2] = o->n_features - want[0] - want[1];
-    const PyrDev &pd = o->pyr->dev;
-    for (int l = 0; l < 3; l++) {
-        const int w = pd.w[l], h = pd.h[l], pitch = pd.pitch[l], npix = w * h;
-        if (w <= 2 * EDGE || h <= 2 * EDGE || want[l] <= 0)
-            continue;
-        const uint8_t *lvl = pd.lvl[l];
-        const dim3 g2((w + 255) / 256, h), b2(256);
-        const int strips = (npix + STRIP - 1) / STRIP;
-        hipLaunchKernelGGL(blur5_kernel, g2, b2, 0, st, lvl, pitch, w, h, o->blur.as<uint8_t>());
-        hipLaunchKernelGGL(fast_harris_kernel, g2, b2, 0, st, lvl, pitch, w, h, o->fast_t, o->R.as<float>(),
-                           o->corner.as<uint8_t>());
-        hipLaunchKernelGGL(nms_count_kernel, dim3(strips), dim3(STRIP), 0, st, o->R.as<float>(), o->corner.as<uint8_t>(),
-                           w, h, o->keep.as<uint8_t>(), o->strip_cnt.as<int>());
-        hipLaunchKernelGGL(strip_scan_kernel, dim3(1), dim3(1024), 0, st, o->strip_cnt.as<int>(), strips,
-                           o->strip_off.as<int>(), d_nc);
-        hipLaunchKernelGGL(cand_write_kernel, dim3(strips), dim3(STRIP), 0, st, o->keep.as<uint8_t>(), o->R.as<float>(),
-                           npix, o->strip_off.as<int>(), o->cand_cap, o->cand_idx.as<int>(), o->cand_resp.as<float>());
-        hipLaunchKernelGGL(select_kernel, dim3(1), dim3(1024), 0, st, o->cand_idx.as<int>(), o->cand_resp.as<float>(),
-                           d_nc, o->cand_cap, want[l], o->sel_idx.as<int>(), o->sel_resp.as<float>(), d_nsel);
-        hipLaunchKernelGGL(describe_kernel, dim3((want[l] + 3) / 4), dim3(256), 0, st, lvl, pitch, w,
-                           o->blur.as<uint8_t>(), o->sel_idx.as<int>(), o->sel_resp.as<float>(), d_nsel,
-                           o->pat.as<int8_t>(), l, d_n, d_xy, d_oct, d_resp, d_dir, d_desc);
-        hipLaunchKernelGGL(add_count_kernel, dim3(1), dim3(1), 0, st, d_n, d_nsel);
-    }
+    int *d_nc = o->counts.as<int>(), *d_nsel = d_nc + NLEV;
+    const OrbLevels &L = o->lv;
+    const dim3 g2((L.w[0] + 255) / 256, L.h[0], NLEV), b2(256);
+    hipLaunchKernelGGL(blur5_kernel, g2, b2, 0, st, L, o->blur.as<uint8_t>());
+    hipLaunchKernelGGL(fast_harris_kernel, g2, b2, 0, st, L, o->fast_t, o->R.as<float>(), o->corner.as<uint8_t>());
+    hipLaunchKernelGGL(nms_count_kernel, dim3(o->max_strips, NLEV), dim3(STRIP), 0, st, L, o->R.as<float>(),
+                       o->corner.as<uint8_t>(), o->keep.as<uint8_t>(), o->strip_cnt.as<int>());
+    hipLaunchKernelGGL(strip_scan_kernel, dim3(NLEV), dim3(1024), 0, st, L, o->strip_cnt.as<int>(), o->strip_off.as<int>(),
+                       d_nc);
+    hipLaunchKernelGGL(cand_write_kernel, dim3(o->max_strips, NLEV), dim3(STRIP), 0, st, L, o->keep.as<uint8_t>(),
+                       o->R.as<float>(), o->strip_off.as<int>(), o->cand_idx.as<int>(), o->cand_resp.as<float>());
+    hipLaunchKernelGGL(select_kernel, dim3(NLEV), dim3(1024), 0, st, L, o->cand_idx.as<int>(), o->cand_resp.as<float>(), d_nc,
+                       o->n_features, o->sel_idx.as<int>(), o->sel_resp.as<float>(), d_nsel);
+    hipLaunchKernelGGL(describe_kernel, dim3((o->max_want + 3) / 4, NLEV), dim3(256), 0, st, L, o->blur.as<uint8_t>(),
+                       o->sel_idx.as<int>(), o->sel_resp.as<float>(), d_nsel, o->n_features, o->pat.as<int8_t>(), d_n, d_xy,
+                       d_oct, d_resp, d_dir, d_desc);
     SVO_HIP(hipGetLastError());
     return SVO_OK;
 }
@@ -522,29 +603,43 @@ extern "C" int svo_orb_extract(svo_ctx *ctx, const uint8_t *image, int w, int h,
     uint32_t *ddesc = reinterpret_cast<uint32_t *>(ddir + 2 * nf);
     int *dn = reinterpret_cast<int *>(ddesc + 8 * nf);
     hipError_t e = hipSuccess;
-    if (mem == SVO_MEM_HOST) {
+    int hn = 0;
+    if (mem == SVO_MEM_DEVICE) {
+        // straight into the caller's arrays (the ones it does not want: into the context's buffer); one 4-byte copy back
+        rc = svo_orb_launch(o, d_img, xy, octave ? octave : doct, response ? response : dresp, dir ? dir : ddir, desc, dn);
+        if (!rc) {
+            e = hipMemcpyAsync(&hn, dn, 4, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess)
+                e = hipStreamSynchronize(ctx->stream);
+        }
+    } else {
         e = hipMemcpyAsync(ctx->s_img.p, image, (size_t)w * h * c, hipMemcpyHostToDevice, ctx->stream);
         d_img = ctx->s_img.as<uint8_t>();
-    }
-    if (e == hipSuccess)
-        rc = svo_orb_launch(o, d_img, dxy, doct, dresp, ddir, ddesc, dn);
-    int hn = 0;
-    if (e == hipSuccess && !rc) {
-        e = hipMemcpyAsync(&hn, dn, 4, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess)
-            e = hipStreamSynchronize(ctx->stream);
-    }
-    if (e == hipSuccess && !rc && hn > 0) {
-        const hipMemcpyKind k = mem == SVO_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
-        (void)hipMemcpyAsync(xy, dxy, (size_t)hn * 8, k, ctx->stream);
-        if (octave)
-            (void)hipMemcpyAsync(octave, doct, (size_t)hn * 4, k, ctx->stream);
-        if (response)
-            (void)hipMemcpyAsync(response, dresp, (size_t)hn * 4, k, ctx->stream);
-        if (dir)
-            (void)hipMemcpyAsync(dir, ddir, (size_t)hn * 8, k, ctx->stream);
-        (void)hipMemcpyAsync(desc, ddesc, (size_t)hn * 32, k, ctx->stream);
-        e = hipStreamSynchronize(ctx->stream);
+            rc = svo_orb_launch(o, d_img, dxy, doct, dresp, ddir, ddesc, dn);
+        // the whole record block in ONE copy (28 KB at 500 features), taken apart on the host
+        const size_t bytes = nf * (8 + 4 + 4 + 8 + 32) + 4;
+        std::vector<unsigned char> &hb = ctx->orb_host;
+        if (hb.size() < bytes)
+            hb.resize(bytes);
+        if (e == hipSuccess && !rc) {
+            e = hipMemcpyAsync(hb.data(), out.p, bytes, hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess)
+                e = hipStreamSynchronize(ctx->stream);
+        }
+        if (e == hipSuccess && !rc) {
+            const unsigned char *b = hb.data();
+            memcpy(&hn, b + nf * 56, 4);
+            hn = hn < 0 ? 0 : (hn > n_features ? n_features : hn);
+            memcpy(xy, b, (size_t)hn * 8);
+            if (octave)
+                memcpy(octave, b + nf * 8, (size_t)hn * 4);
+            if (response)
+                memcpy(response, b + nf * 12, (size_t)hn * 4);
+            if (dir)
+                memcpy(dir, b + nf * 16, (size_t)hn * 8);
+            memcpy(desc, b + nf * 24, (size_t)hn * 32);
+        }
     }
     if (e != hipSuccess) {
         svo_set_error("svo_orb_extract -> %s", hipGetErrorString(e));

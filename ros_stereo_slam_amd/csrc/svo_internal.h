@@ -114,6 +114,7 @@ struct svo_ctx {
     struct svo_orb *orb_cache = nullptr;
     int orb_key[5] = {0, 0, 0, 0, 0};  // w, h, c, n_features, fast threshold
     DevBuf orb_out;
+    std::vector<unsigned char> orb_host;  // svo_orb_extract with host outputs: the record block lands here
 };
 
 // Low-latency host wait for everything queued on the context's stream: records an event and
