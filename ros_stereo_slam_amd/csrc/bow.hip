@@ -343,34 +343,38 @@ __global__ __launch_bounds__(512) void bow_vector_kernel(const int *__restrict__
                                                          int *__restrict__ row_w, double *__restrict__ row_v,
                                                          int *__restrict__ row_n, int *__restrict__ row_node)
 {
-    // s_w / s_x: the features' words and weights as loaded; s_sw / s_sx: the same sorted by (word, feature);
-    // s_acc: the weight sums of the distinct words in word order
-    __shared__ int s_w[BOW_MAX_F], s_sw[BOW_MAX_F], s_nv, s_m;
+    // s_key: a feature's word, or INT_MAX for a feature with weight 0 (it is in neither vector); s_x: the weights as
+    // loaded; s_sw / s_sx: words and weights sorted by (word, feature); s_acc: the weight sums of the distinct words
+    __shared__ __attribute__((aligned(16))) int s_key[BOW_MAX_F];
+    __shared__ int s_sw[BOW_MAX_F], s_wave[8], s_nv;
     __shared__ double s_x[BOW_MAX_F], s_sx[BOW_MAX_F], s_acc[BOW_MAX_F];
     __shared__ double s_norm;
-    const int t = threadIdx.x;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int n = min(d_n ? min(*d_n, n_host) : n_host, BOW_MAX_F);
-    if (t == 0) {
+    const int n4 = (n + 3) & ~3;
+    if (t == 0)
         s_nv = 0;
-        s_m = 0;
-    }
-    for (int i = t; i < n; i += 512) {
-        const double x = weight[i];
-        s_w[i] = word[i];
+    for (int i = t; i < n4; i += 512) {
+        const double x = i < n ? weight[i] : 0.;
+        s_key[i] = i < n && x > 0 ? word[i] : 0x7fffffff;
         s_x[i] = x;
-        if (row_node)
+        if (row_node && i < n)
             row_node[i] = x > 0 ? node[i] : -1;  // a feature with weight 0 is not in the FeatureVector either
     }
     __syncthreads();
-    // rank of (word, feature) among the features with a positive weight (LDS broadcasts)
+    // rank of (word, feature) among the features with a positive weight: a thread per feature against all keys, four keys
+    // per LDS read (every lane reads the same address: a broadcast)
     for (int i = t; i < n; i += 512) {
-        if (!(s_x[i] > 0))
+        const int wi = s_key[i];
+        if (wi == 0x7fffffff)
             continue;
-        const int wi = s_w[i];
         int r = 0;
-        for (int j = 0; j < n; j++) {
-            const int wj = s_w[j];
-            r += (s_x[j] > 0 && (wj < wi || (wj == wi && j < i))) ? 1 : 0;
+        for (int j = 0; j < n4; j += 4) {
+            const int4 k = *reinterpret_cast<const int4 *>(s_key + j);
+            r += (k.x < wi || (k.x == wi && j < i)) ? 1 : 0;
+            r += (k.y < wi || (k.y == wi && j + 1 < i)) ? 1 : 0;
+            r += (k.z < wi || (k.z == wi && j + 2 < i)) ? 1 : 0;
+            r += (k.w < wi || (k.w == wi && j + 3 < i)) ? 1 : 0;
         }
         s_sw[r] = wi;
         s_sx[r] = s_x[i];
@@ -378,26 +382,46 @@ __global__ __launch_bounds__(512) void bow_vector_kernel(const int *__restrict__
     }
     __syncthreads();
     const int nv = s_nv;
-    // a thread per distinct word: its place among the distinct words, its weights added in feature order
-    // (BowVector::addWeight sees the features in that order)
-    for (int r = t; r < nv; r += 512) {
-        if (r > 0 && s_sw[r] == s_sw[r - 1])
-            continue;
-        int u = 0;
-        for (int j = 1; j <= r; j++)
-            u += s_sw[j] != s_sw[j - 1] ? 1 : 0;
-        double acc = s_sx[r];
-        for (int q = r + 1; q < nv && s_sw[q] == s_sw[r]; q++)
-            acc += s_sx[q];
-        row_w[u] = s_sw[r];
-        s_acc[u] = acc;
-        atomicAdd(&s_m, 1);
+    // a thread per distinct word: its place among the distinct words (the number of word changes before it: a ballot and
+    // a count per round of 512), its weights added in feature order (BowVector::addWeight sees the features in that order)
+    int before = 0;  // distinct words in the rounds done
+    for (int r0 = 0; r0 < nv; r0 += 512) {
+        const int r = r0 + t;
+        const bool first = r < nv && (r == 0 || s_sw[r] != s_sw[r - 1]);
+        const unsigned long long b = __ballot(first);
+        if (lane == 0)
+            s_wave[wave] = __popcll(b);
+        __syncthreads();
+        int u = before + __popcll(b & ((1ull << lane) - 1ull)), tot = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < 8; w2++) {
+            u += w2 < wave ? s_wave[w2] : 0;
+            tot += s_wave[w2];
+        }
+        if (first) {
+            double acc = s_sx[r];
+            for (int q = r + 1; q < nv && s_sw[q] == s_sw[r]; q++)
+                acc += s_sx[q];
+            row_w[u] = s_sw[r];
+            s_acc[u] = acc;
+        }
+        before += tot;
+        __syncthreads();
     }
-    __syncthreads();
-    const int m = s_m;
-    if (t == 0) {  // the L1 norm in word order
+    const int m = before;
+    if (t == 0) {  // the L1 norm in word order: a chain of m additions, the values fetched sixteen at a time
         double norm = 0;
-        for (int u = 0; u < m; u++)
+        int u = 0;
+        for (; u + 16 <= m; u += 16) {
+            double v[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++)
+                v[q] = fabs(s_acc[u + q]);
+#pragma unroll
+            for (int q = 0; q < 16; q++)
+                norm += v[q];
+        }
+        for (; u < m; u++)
             norm += fabs(s_acc[u]);
         s_norm = norm;
         *row_n = m;
