@@ -257,7 +257,7 @@ __global__ __launch_bounds__(1024) void select_kernel(OrbLevels L, const int *__
                                                       int *__restrict__ sel_idx_all, float *__restrict__ sel_resp_all,
                                                       int *__restrict__ d_nsel_all)
 {
-    __shared__ int s_red[16], s_bcast, s_base, s_ties;
+    __shared__ int s_red[16], s_base, s_ties;
     const int l = blockIdx.x, cap = L.cand_cap[l], want = L.want[l];
     const int *__restrict__ cand_idx = cand_idx_all + L.cand_off[l];
     const float *__restrict__ cand_resp = cand_resp_all + L.cand_off[l];
@@ -271,41 +271,41 @@ __global__ __launch_bounds__(1024) void select_kernel(OrbLevels L, const int *__
     }
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int nc = min(d_nc_all[l], cap);
-    auto block_sum = [&](int v) -> int {
-        v += __shfl_xor(v, 32, 64);
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 8, 64);
-        v += __shfl_xor(v, 4, 64);
-        v += __shfl_xor(v, 2, 64);
-        v += __shfl_xor(v, 1, 64);
-        __syncthreads();
-        if (lane == 0)
-            s_red[wave] = v;
-        __syncthreads();
-        if (t == 0) {
-            int s = 0;
-            for (int i = 0; i < 16; i++)
-                s += s_red[i];
-            s_bcast = s;
-        }
-        __syncthreads();
-        return s_bcast;
-    };
+    // the want-th largest key, a byte at a time from the top: a 256-bin count of the keys that match the bytes found so
+    // far, then the bin the want-th largest falls into (a suffix sum over the bins by 256 threads).  Four rounds of one
+    // pass over the candidates; the search bit by bit was 32 passes with three barriers each (37 us of an image's 130).
+    __shared__ int s_hist[256], s_pick, s_left;
     unsigned thr = 0;  // everything is >= 0
     int n_above = 0;
     if (nc > want) {
-        for (int bit = 31; bit >= 0; bit--) {
-            const unsigned test = thr | (1u << bit);
-            int c = 0;
-            for (int i = t; i < nc; i += 1024)
-                c += sortable(cand_resp[i]) >= test ? 1 : 0;
-            if (block_sum(c) >= want)
-                thr = test;
+        int left = want;  // how many of the keys that match the prefix are still wanted
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            if (t < 256)
+                s_hist[t] = 0;
+            __syncthreads();
+            const unsigned himask = shift == 24 ? 0u : 0xffffffffu << (shift + 8);
+            for (int i = t; i < nc; i += 1024) {
+                const unsigned k = sortable(cand_resp[i]);
+                if ((k & himask) == (thr & himask))
+                    atomicAdd(&s_hist[(k >> shift) & 255u], 1);
+            }
+            __syncthreads();
+            if (t < 256) {  // above[t] = keys in the bins over t; the pick is the bin with above < left <= above + count
+                const int cnt = s_hist[t];
+                int above = 0;
+                for (int b = t + 1; b < 256; b++)
+                    above += s_hist[b];
+                if (above < left && left <= above + cnt) {
+                    s_pick = t;
+                    s_left = left - above;
+                }
+            }
+            __syncthreads();
+            thr |= (unsigned)s_pick << shift;
+            left = s_left;
+            __syncthreads();
         }
-        int c = 0;
-        for (int i = t; i < nc; i += 1024)
-            c += sortable(cand_resp[i]) > thr ? 1 : 0;
-        n_above = block_sum(c);
+        n_above = want - left;  // `left` of the keys equal to thr make up the rest
     }
     const int ties_allowed = nc > want ? want - n_above : 0;
     if (t == 0) {
