@@ -245,6 +245,7 @@ __global__ __launch_bounds__(128) void pg_linearize_kernel(const double *__restr
 //   T x_seg + E_a C_l x_l + E_z C_z^T x_r = r_seg   =>   x_seg = y - Wl x_l - Wr x_r,
 //   y = T^-1 r_seg,  Wl = T^-1 E_a C_l,  Wr = T^-1 E_z C_z^T.
 
+constexpr int PG_MAX_SEG_CHORDS = 4;  // closure endpoints a segment takes inside (six right-hand-side columns each)
 constexpr int SEG_L = 104;  // regular separator spacing (rows): a segment and its 13 right-hand sides live in LDS
 constexpr int TB = 48;      // tile of the dense reduced solve (8 block rows)
 
@@ -464,6 +465,16 @@ __device__ inline bool lane_chol6_inv(double *blk)
 // The workgroups past the segments clear the reduced (separator) matrix for the gather that follows -- identity on the
 // padded diagonal, zeros elsewhere -- beside the segments instead of in a launch of its own.
 constexpr int PG_CLEAR_WGS = 48;
+// A closure with only ONE endpoint among the separators leaves its other endpoint j inside a segment, coupled to that
+// separator by the edge's block H[j][i]: six more right-hand-side columns E_j H[j][i], solved in a pass of their own
+// over the factor that is in LDS anyway (no factorisation, six columns down and up) -> Wc, the segment's third W.
+struct PgSegChords {
+    const int *cptr;   // [nseg + 1] a segment's couplings in the arrays below
+    const int *lrow;   // the endpoint's row within the segment
+    const int *edge;   // the closure's edge
+    const int *tr;     // 0: the endpoint is the edge's `from` (block Hij), 1: its `to` (Hij^T)
+    const int *wbase;  // first 6 x 6 block of this coupling's Wc (one block per row of the segment)
+};
 __global__ __launch_bounds__(BCR_WAVES * 64) void pg_segment_kernel(int nb, int nseg, const int *__restrict__ seg_start,
                                                                     const int *__restrict__ seg_len,
                                                                     const double *__restrict__ Dg,
@@ -472,7 +483,8 @@ __global__ __launch_bounds__(BCR_WAVES * 64) void pg_segment_kernel(int nb, int 
                                                                     double *__restrict__ Y, double *__restrict__ Wl,
                                                                     double *__restrict__ Wr, int *__restrict__ status,
                                                                     double *__restrict__ R, int ldr, int n_used,
-                                                                    double *__restrict__ rR)
+                                                                    double *__restrict__ rR, PgSegChords ch,
+                                                                    const double *__restrict__ eo, double *__restrict__ Wc)
 {
     if ((int)blockIdx.x >= nseg) {
         const size_t total = (size_t)ldr * ldr, step = (size_t)(gridDim.x - nseg) * BCR_WAVES * 64;
@@ -545,10 +557,13 @@ __global__ __launch_bounds__(BCR_WAVES * 64) void pg_segment_kernel(int nb, int 
     __syncthreads();
     PGSTAMP(71);
     int levels = 0;
+    // chord_pass: the factor is there; only the six columns of a closure's coupling (kept where the left separator's live)
+    auto forward = [&](const bool chord_pass) -> bool {
+    levels = 0;
     for (int s = 1; s <= n; s <<= 1, levels++) {
         // ---- eliminate the rows q = s (2 t + 1): factor, and the products with L^-1 ----
         const int cnt = (n / s + 1) / 2;
-        const bool by_lane = cnt > BCR_WAVES;  // more rows than waves: a lane per block first, the products after
+        const bool by_lane = !chord_pass && cnt > BCR_WAVES;  // more rows than waves: a lane per block first, the products after
         if (by_lane) {
             if (tid < cnt) {
                 const int q = s * (2 * tid + 1);
@@ -559,13 +574,15 @@ __global__ __launch_bounds__(BCR_WAVES * 64) void pg_segment_kernel(int nb, int 
             }
             lds_barrier();
             if (s_fail)
-                return;
+                return false;
         }
         for (int t = wave; t < cnt; t += BCR_WAVES) {
             const int q = s * (2 * t + 1);
             double *Q = sm + (q - 1) * BCR_ROW;
             const bool hl = q > s, hr = q + s <= n;
-            if (!by_lane && !wave_chol6_inv<false>(Q, nullptr, Q, lane)) {
+            if (chord_pass && !(s_cols[q - 1] & 1))
+                continue;  // nothing of the coupling has reached this row
+            if (!chord_pass && !by_lane && !wave_chol6_inv<false>(Q, nullptr, Q, lane)) {
                 if (lane == 0) {
                     atomicMax(status, a + q);
                     s_fail = 1;
@@ -606,8 +623,10 @@ __global__ __launch_bounds__(BCR_WAVES * 64) void pg_segment_kernel(int nb, int 
                     const int c = 7 + lane % 6;
                     i = lane / 6, src = Q + BCR_B + c, st = 13, dst = BCR_B + 13 * i + c;
                 }
+                if (chord_pass && (r != 1 || lane < 14))
+                    dst = -1;  // the factor's blocks and the first column stay as they are
                 double acc = 0.;
-                if (r < rounds) {
+                if (r < rounds && (!chord_pass || r == 1)) {
 #pragma unroll
                     for (int u = 0; u < 6; u++)
                         acc = fma(Q[6 * i + u], src[u * st], acc);
@@ -625,7 +644,7 @@ __global__ __launch_bounds__(BCR_WAVES * 64) void pg_segment_kernel(int nb, int 
         lds_barrier();
         PGSTAMP(72 + 2 * levels);
         if (s_fail)
-            return;
+            return false;
         // ---- into the rows that stay, p = 2 s (t + 1): every entry of D_p, B_p and the new coupling is a lane's own ----
         const int cnt2 = n / (2 * s);
         for (int t = wave; t < cnt2; t += BCR_WAVES) {
@@ -635,6 +654,8 @@ __global__ __launch_bounds__(BCR_WAVES * 64) void pg_segment_kernel(int nb, int 
             const double *Gl = sm + (p - s - 1) * BCR_ROW;                 // the eliminated row on the left: its G+ is ours
             const double *Gr = sm + ((hr ? p + s : p - s) - 1) * BCR_ROW;  // on the right: its G-
             const int cols = s_cols[p - 1] | s_cols[p - s - 1] | (hr ? s_cols[p + s - 1] : 0);
+            if (chord_pass && !(cols & 1))
+                continue;
             // out = base - sum_u A1[6 u] B1[u * st] - sum_u A2[6 u] B2[u * st]: the same code in every lane (see above);
             // round 0: D_p (36) and 28 entries of the new coupling, round 1: its other 8, B_p's first column (6), the left
             // separator's columns (36), round 2: the right separator's columns
@@ -643,6 +664,8 @@ __global__ __launch_bounds__(BCR_WAVES * 64) void pg_segment_kernel(int nb, int 
             for (int r = 0; r < 3; r++) {
                 if (r >= rounds)
                     break;
+                if (chord_pass && r != 1)
+                    continue;
                 int st = 6, dst = -1;
                 bool use1 = true, use2 = hr, keep = true;
                 const double *A1 = Gl, *B1 = Gl, *A2 = Gl, *B2 = Gl;
@@ -676,6 +699,8 @@ __global__ __launch_bounds__(BCR_WAVES * 64) void pg_segment_kernel(int nb, int 
                     acc1 = fma(A1[6 * u], B1[u * st], acc1);
                     acc2 = fma(A2[6 * u], B2[u * st], acc2);
                 }
+                if (chord_pass && lane < 14)
+                    dst = -1;
                 if (dst >= 0) {
                     const double base = keep ? P[dst] : 0.;
                     P[dst] = (base - (use1 ? acc1 : 0.)) - (use2 ? acc2 : 0.);
@@ -687,6 +712,10 @@ __global__ __launch_bounds__(BCR_WAVES * 64) void pg_segment_kernel(int nb, int 
         lds_barrier();
         PGSTAMP(73 + 2 * levels);
     }
+    return true;
+    };
+    if (!forward(false))
+        return;
     // ---- substitution, the levels upwards: X_q = L^-T (GB_q - G-_q X_{q-s} - G+_q X_{q+s}), 6 x 13 ----
     for (int lev = levels - 1; lev >= 0; lev--) {
         const int s = 1 << lev, cnt = (n / s + 1) / 2;
@@ -753,26 +782,91 @@ __global__ __launch_bounds__(BCR_WAVES * 64) void pg_segment_kernel(int nb, int 
         lds_barrier();
         PGSTAMP(90 + lev);
     }
+    // ---- the closures that end inside this segment: six columns each, through the factor once more ----
+    for (int cc = ch.cptr[blockIdx.x]; cc < ch.cptr[blockIdx.x + 1]; cc++) {
+        const int jrow = ch.lrow[cc], tr = ch.tr[cc];
+        const double *H = eo + (size_t)ch.edge[cc] * EO_FIELDS + EO_HIJ;
+        double *wout = Wc + (size_t)ch.wbase[cc] * 36;
+        for (int e = tid; e < n * 78; e += NT) {  // B = E_j H[j][i] in the columns 1 .. 6
+            const int p = e / 78, k = e - 78 * p, r = k / 13, c = k - 13 * r;
+            sm[p * BCR_ROW + BCR_B + k] = p == jrow && c >= 1 && c < 7 ? (tr ? H[6 * (c - 1) + r] : H[6 * r + (c - 1)]) : 0.;
+        }
+        if (tid < n)
+            s_cols[tid] = tid == jrow ? 1 : 0;
+        lds_barrier();
+        (void)forward(true);
+        for (int lev = levels - 1; lev >= 0; lev--) {
+            const int s = 1 << lev, cnt = (n / s + 1) / 2;
+            for (int t = wave; t < cnt; t += BCR_WAVES) {
+                const int q = s * (2 * t + 1);
+                double *Q = sm + (q - 1) * BCR_ROW;
+                const bool hl = q > s, hr = q + s <= n;
+                const double *Xl = sm + ((hl ? q - s : q) - 1) * BCR_ROW + BCR_B;
+                const double *Xr = sm + ((hr ? q + s : q) - 1) * BCR_ROW + BCR_B;
+                const int i = lane / 6, c = 1 + lane % 6;  // lanes 0 .. 35: the six columns
+                double acc = 0.;
+                if (lane < 36) {
+                    acc = Q[BCR_B + 13 * i + c];
+                    if (hl) {
+#pragma unroll
+                        for (int u = 0; u < 6; u++)
+                            acc = fma(-Q[BCR_GM + 6 * i + u], Xl[13 * u + c], acc);
+                    }
+                    if (hr) {
+#pragma unroll
+                        for (int u = 0; u < 6; u++)
+                            acc = fma(-Q[BCR_F + 6 * i + u], Xr[13 * u + c], acc);
+                    }
+                    Q[BCR_B + 13 * i + c] = acc;  // a lane's own entry
+                }
+                wave_sync();
+                if (lane < 36) {
+                    acc = 0.;
+#pragma unroll
+                    for (int u = 0; u < 6; u++)
+                        acc = fma(Q[6 * u + i], Q[BCR_B + 13 * u + c], acc);
+                }
+                wave_sync();
+                if (lane < 36) {
+                    Q[BCR_B + 13 * i + c] = acc;
+                    wout[(size_t)(q - 1) * 36 + 6 * i + (c - 1)] = acc;
+                }
+            }
+            lds_barrier();
+        }
+    }
 }
 
 // Reduced (separator) system, assembled by gathers.  Block k of the launch owns one nonzero
 // 6x6 block (rb_row >= rb_col, in separator indices) or, for k >= n_blocks, the right-hand side
 // of separator k - n_blocks.  Sources src[ptr[k] .. ptr[k+1]) are added in list order:
-//   kind 0: + Dg[idx]                      kind 1: + Cc[idx]
-//   kind 2: + Hij of edge idx              kind 3: + Hij^T of edge idx
-//   kind 4: - Cc[idx]^T Wl[idx+1]          (segment right of separator row idx, onto the diagonal)
-//   kind 5: - Cc[idx]   Wr[idx]            (segment left of separator row idx+1, onto the diagonal)
-//   kind 6: - Cc[idx]   Wl[idx]            (segment between two separators, sub-diagonal block)
-// right-hand sides: kind 0: + rneg[idx], kind 4: - Cc[idx]^T Y[idx+1], kind 5: - Cc[idx] Y[idx].
+//   kind 0: + Dg[idx]  (right-hand side: + rneg[idx])        kind 1: + Cc[idx]
+//   kind 2: + Hij of edge idx                                 kind 3: + Hij^T of edge idx
+//   kind 7: - A^T W, term idx of the table: a segment couples to separator u through the block A = H[row_u][u] and to
+//           separator v through W_v = T^-1 E_{row_v} H[row_v][v]; the Schur complement takes A^T W_v[row_u] off the
+//           block (u, v) -- and A^T Y[row_u] off u's right-hand side.
+//           A: 0 Cc[a] (the segment's first row and the separator before it), 1 Cc[a]^T (its last row and the separator
+//              after it), 2 / 3 a closure's Hij / Hij^T (an endpoint inside the segment and the one that is a separator)
+//           W: 0 Wl, 1 Wr, 2 Wc (6 x 6 block w), 3 Y (6-vector w)
+struct PgTerm {
+    int a_kind, a, w_kind, w;
+};
 __global__ __launch_bounds__(64) void pg_reduce_kernel(int n_blocks, int m, const int *__restrict__ rb_row,
                                                        const int *__restrict__ rb_col, const int *__restrict__ ptr,
-                                                       const int2 *__restrict__ src, const double *__restrict__ Dg,
-                                                       const double *__restrict__ Cc, const double *__restrict__ rneg,
-                                                       const double *__restrict__ eo, int ne, const double *__restrict__ Y,
-                                                       const double *__restrict__ Wl, const double *__restrict__ Wr,
+                                                       const int2 *__restrict__ src, const PgTerm *__restrict__ terms,
+                                                       const double *__restrict__ Dg, const double *__restrict__ Cc,
+                                                       const double *__restrict__ rneg, const double *__restrict__ eo,
+                                                       const double *__restrict__ Y, const double *__restrict__ Wl,
+                                                       const double *__restrict__ Wr, const double *__restrict__ Wc,
                                                        double *__restrict__ R, int ldr, double *__restrict__ rR)
 {
     const int k = blockIdx.x, lane = threadIdx.x;
+    // A^T[p][t] = H[t][p] of a term = base[sa * t + sb * p]
+    auto a_of = [&](const PgTerm &tm, const double *&base, int &sa, int &sb) {
+        base = tm.a_kind < 2 ? Cc + (size_t)tm.a * 36 : eo + (size_t)tm.a * EO_FIELDS + EO_HIJ;
+        sa = (tm.a_kind & 1) ? 1 : 6;
+        sb = (tm.a_kind & 1) ? 6 : 1;
+    };
     if (k < n_blocks) {
         if (lane >= 36)
             return;
@@ -780,25 +874,20 @@ __global__ __launch_bounds__(64) void pg_reduce_kernel(int n_blocks, int m, cons
         double acc = 0;
         for (int t = ptr[k]; t < ptr[k + 1]; t++) {
             const int kind = src[t].x, idx = src[t].y;
-            const double *C = Cc + (size_t)idx * 36;
             double v = 0;
             switch (kind) {
             case 0: v = Dg[(size_t)idx * 36 + lane]; break;
-            case 1: v = C[lane]; break;
+            case 1: v = Cc[(size_t)idx * 36 + lane]; break;
             case 2: v = eo[(size_t)idx * EO_FIELDS + EO_HIJ + lane]; break;
             case 3: v = eo[(size_t)idx * EO_FIELDS + EO_HIJ + 6 * q + p]; break;
-            case 4:
+            default: {
+                const PgTerm tm = terms[idx];
+                const double *W = (tm.w_kind == 0 ? Wl : tm.w_kind == 1 ? Wr : Wc) + (size_t)tm.w * 36, *A;
+                int sa, sb;
+                a_of(tm, A, sa, sb);
                 for (int t2 = 0; t2 < 6; t2++)
-                    v -= C[6 * t2 + p] * Wl[(size_t)(idx + 1) * 36 + 6 * t2 + q];
-                break;
-            case 5:
-                for (int t2 = 0; t2 < 6; t2++)
-                    v -= C[6 * p + t2] * Wr[(size_t)idx * 36 + 6 * t2 + q];
-                break;
-            default:
-                for (int t2 = 0; t2 < 6; t2++)
-                    v -= C[6 * p + t2] * Wl[(size_t)idx * 36 + 6 * t2 + q];
-                break;
+                    v -= A[sa * t2 + sb * p] * W[6 * t2 + q];
+            }
             }
             acc += v;
         }
@@ -813,16 +902,16 @@ __global__ __launch_bounds__(64) void pg_reduce_kernel(int n_blocks, int m, cons
         double acc = 0;
         for (int t = ptr[kk]; t < ptr[kk + 1]; t++) {
             const int kind = src[t].x, idx = src[t].y;
-            const double *C = Cc + (size_t)idx * 36;
             double v = 0;
             if (kind == 0)
                 v = rneg[(size_t)idx * 6 + lane];
-            else if (kind == 4) {
+            else {
+                const PgTerm tm = terms[idx];
+                const double *A;
+                int sa, sb;
+                a_of(tm, A, sa, sb);
                 for (int t2 = 0; t2 < 6; t2++)
-                    v -= C[6 * t2 + lane] * Y[(size_t)(idx + 1) * 6 + t2];
-            } else {
-                for (int t2 = 0; t2 < 6; t2++)
-                    v -= C[6 * lane + t2] * Y[(size_t)idx * 6 + t2];
+                    v -= A[sa * t2 + sb * lane] * Y[(size_t)tm.w * 6 + t2];
             }
             acc += v;
         }
@@ -1361,6 +1450,12 @@ __global__ __launch_bounds__(PG_UPD_ROWS * 6) void pg_backsub_update_kernel(int 
                                                                             const double *__restrict__ Y,
                                                                             const double *__restrict__ Wl,
                                                                             const double *__restrict__ Wr,
+                                                                            const int *__restrict__ rowseg,
+                                                                            const int *__restrict__ seg_start,
+                                                                            const int *__restrict__ cptr,
+                                                                            const int *__restrict__ csep,
+                                                                            const int *__restrict__ cwbase,
+                                                                            const double *__restrict__ Wc,
                                                                             double *__restrict__ pose)
 {
     __shared__ double s_dx[PG_UPD_ROWS * 6];
@@ -1383,6 +1478,14 @@ __global__ __launch_bounds__(PG_UPD_ROWS * 6) void pg_backsub_update_kernel(int 
 #pragma unroll
                 for (int c = 0; c < 6; c++)
                     v -= Wr[(size_t)b * 36 + 6 * r + c] * xR[6 * rr + c];
+            }
+            const int sg = rowseg[b];  // the closures that end inside this row's segment
+            for (int cc = cptr[sg]; cc < cptr[sg + 1]; cc++) {
+                const double *W = Wc + (size_t)(cwbase[cc] + (b - seg_start[sg])) * 36 + 6 * r;
+                const double *xs = xR + 6 * csep[cc];
+#pragma unroll
+                for (int c = 0; c < 6; c++)
+                    v -= W[c] * xs[c];
             }
         }
         s_dx[threadIdx.x] = v;
@@ -1446,10 +1549,11 @@ struct svo_posegraph {
     int built_nv = -1, built_ne = -1;
     std::vector<int> h_incptr, h_inc, h_struct;
     int s_m = 0, s_nseg = 0, s_nrblocks = 0, s_T = 0, s_ldr = 0, s_maxseg = 0;
+    size_t s_wc_blocks = 0;
     size_t o_seg_start = 0, o_seg_len = 0, o_sepidx = 0, o_lsep = 0, o_rsep = 0, o_rb_row = 0, o_rb_col = 0, o_rptr = 0,
-           o_rsrc = 0;
+           o_rsrc = 0, o_rowseg = 0, o_cptr = 0, o_clrow = 0, o_cedge = 0, o_ctr = 0, o_cwbase = 0, o_csep = 0, o_terms = 0;
     DevBuf d_pose, d_from, d_to, d_meas, d_eo, d_incptr, d_inc, d_struct, d_Dg, d_Cc, d_rneg, d_Y,
-        d_Wl, d_Wr, d_R, d_Lo, d_Tinv, d_rR, d_xR, d_misc;
+        d_Wl, d_Wr, d_Wc, d_R, d_Lo, d_Tinv, d_rR, d_xR, d_misc;
     int nv() const { return (int)(pose.size() / 7); }
     int ne() const { return (int)efrom.size(); }
 };
@@ -1473,7 +1577,7 @@ int svo_pg_destroy(svo_posegraph *g)
     (void)hipStreamSynchronize(g->ctx->stream);
     DevBuf *bufs[] = {&g->d_pose, &g->d_from, &g->d_to, &g->d_meas, &g->d_eo,  &g->d_incptr, &g->d_inc, &g->d_struct,
                       &g->d_Dg,   &g->d_Cc,   &g->d_rneg, &g->d_Y,     &g->d_Wl,
-                      &g->d_Wr,   &g->d_R,    &g->d_Lo, &g->d_Tinv, &g->d_rR,  &g->d_xR,  &g->d_misc};
+                      &g->d_Wr,   &g->d_Wc,   &g->d_R,    &g->d_Lo, &g->d_Tinv, &g->d_rR,  &g->d_xR,  &g->d_misc};
     for (DevBuf *b : bufs)
         b->release();
     delete g;
@@ -1577,85 +1681,163 @@ int svo_pg_optimize(svo_posegraph *g, int iters, double *chi2)
                 inc[fill[g->eto[e]]++] = 2 * e + 1;
             }
         }
-        // separators: both ends of every chord (edge between non-neighbouring unknowns) + every SEG_L-th row
-        std::vector<int> sepidx(nb, -1);
-        std::vector<char> is_sep(nb, 0);
+        // chords: the edges between non-neighbouring unknowns (loop closures)
+        struct Chord {
+            int e, i, j;  // rows of `from` and `to`
+        };
+        std::vector<Chord> chords;
         for (int e = 0; e < ne; e++) {
             const int i = g->efrom[e] - 1, j = g->eto[e] - 1;
             if (i < 0 || j < 0 || i == j || i - j == 1 || j - i == 1)
                 continue;
-            is_sep[i] = 1;
-            is_sep[j] = 1;
+            chords.push_back({e, i, j});
         }
-        // regular separators only where the chord endpoints leave a run longer than SEG_L rows: every separator adds six
-        // rows to the dense reduced system, whose cost is what a solve's time is made of (a fixed grid of every 128th row
-        // gave 115 separators at 4541 vertices / 40 closures, the endpoints alone cut that chain into runs of ~100 rows)
-        for (int b = 0, run = 0; b < nb - 1; b++) {
-            if (is_sep[b]) {
-                run = 0;
-                continue;
+        // Separators: BOTH endpoints of every chord + a regular one only where that leaves a run longer than SEG_L - 1 rows
+        // (every separator adds six rows to the dense reduced system, whose tile steps are what a solve's time is made of).
+        // SVO_PG_COVER=1 selects the other structure this file can run: separators = a COVER of the chords (where neither
+        // endpoint of a chord is one yet, the later row becomes one); a chord's other endpoint then stays inside its segment
+        // and costs that segment a pass of six more right-hand-side columns (pg_segment_kernel; at most PG_MAX_SEG_CHORDS
+        // per segment, the ones beyond that become separators after all).  Measured at 4541 vertices / 40 closures whose
+        // matches all lie in the first lap: 62 separators instead of 81 (7 tile steps instead of 9, -39 us) but four passes
+        // in each of the first lap's segments (+59 us): 0.288 against 0.277 ms per iteration -- so it is not the default.
+        const bool both_ends = getenv("SVO_PG_COVER") == nullptr;
+        std::vector<char> cover(nb, 0), is_sep;
+        for (const Chord &c : chords) {
+            if (both_ends)
+                cover[c.i] = cover[c.j] = 1;
+            else if (!cover[c.i] && !cover[c.j])
+                cover[c.i > c.j ? c.i : c.j] = 1;
+        }
+        std::vector<int> sepidx, seps, seg_start, seg_len, lsep, rsep, rowseg;
+        for (;;) {
+            is_sep = cover;
+            for (int b = 0, run = 0; b < nb - 1; b++) {
+                if (is_sep[b]) {
+                    run = 0;
+                    continue;
+                }
+                if (++run >= SEG_L) {
+                    is_sep[b] = 1;
+                    run = 0;
+                }
             }
-            if (++run >= SEG_L) {
-                is_sep[b] = 1;
-                run = 0;
+            sepidx.assign(nb, -1);
+            seps.clear();
+            for (int b = 0; b < nb; b++)
+                if (is_sep[b]) {
+                    sepidx[b] = (int)seps.size();
+                    seps.push_back(b);
+                }
+            seg_start.clear();
+            seg_len.clear();
+            lsep.assign(nb, -1);
+            rsep.assign(nb, -1);
+            rowseg.assign(nb, -1);
+            for (int b = 0; b < nb;) {
+                if (is_sep[b]) {
+                    b++;
+                    continue;
+                }
+                int z = b;
+                while (z + 1 < nb && !is_sep[z + 1])
+                    z++;
+                for (int r = b; r <= z; r++) {
+                    lsep[r] = b > 0 ? sepidx[b - 1] : -1;
+                    rsep[r] = z + 1 < nb ? sepidx[z + 1] : -1;
+                    rowseg[r] = (int)seg_start.size();
+                }
+                seg_start.push_back(b);
+                seg_len.push_back(z - b + 1);
+                b = z + 1;
+            }
+            // a segment with too many closure endpoints inside: the surplus becomes separators, and once more
+            std::vector<int> inside(seg_start.size(), 0);
+            bool again = false;
+            for (const Chord &c : chords)
+                for (const int r : {c.i, c.j})
+                    if (!is_sep[r] && ++inside[rowseg[r]] > PG_MAX_SEG_CHORDS) {
+                        cover[r] = 1;
+                        again = true;
+                    }
+            if (!again)
+                break;
+        }
+        const int m = (int)seps.size(), n_seg = (int)seg_start.size();
+        // what couples a segment to the separators: its two neighbours in the chain, and the closures that end inside it
+        struct Coupling {
+            int row, sep, a_kind, a, w_kind, wbase;  // W block of row r: Wl / Wr: r itself; Wc: wbase + (r - segment start)
+        };
+        std::vector<std::vector<Coupling>> coup(n_seg);
+        std::vector<int> cptr(n_seg + 1, 0), c_lrow, c_edge, c_tr, c_wbase, c_sep;
+        for (int sg = 0; sg < n_seg; sg++) {
+            const int a = seg_start[sg], z = a + seg_len[sg] - 1;
+            if (a > 0)
+                coup[sg].push_back({a, sepidx[a - 1], 0, a - 1, 0, 0});
+            if (z < nb - 1)
+                coup[sg].push_back({z, sepidx[z + 1], 1, z, 1, 0});
+        }
+        size_t wc_blocks = 0;
+        {
+            std::vector<std::vector<Coupling>> inner(n_seg);
+            for (const Chord &c : chords) {
+                if (is_sep[c.i] && is_sep[c.j])
+                    continue;
+                // (the cover: at least one endpoint is a separator)
+                const bool from_inside = !is_sep[c.i];
+                const int r = from_inside ? c.i : c.j, sp = from_inside ? c.j : c.i, sg = rowseg[r];
+                // H[r][sp]: r = `from`: Hij; r = `to`: Hij^T
+                inner[sg].push_back({r, sepidx[sp], from_inside ? 2 : 3, c.e, 2, 0});
+            }
+            for (int sg = 0; sg < n_seg; sg++) {
+                for (Coupling &k : inner[sg]) {
+                    k.wbase = (int)wc_blocks;
+                    wc_blocks += seg_len[sg];
+                    c_lrow.push_back(k.row - seg_start[sg]);
+                    c_edge.push_back(k.a);
+                    c_tr.push_back(k.a_kind == 3 ? 1 : 0);
+                    c_wbase.push_back(k.wbase);
+                    c_sep.push_back(k.sep);
+                    coup[sg].push_back(k);
+                }
+                cptr[sg + 1] = (int)c_lrow.size();
             }
         }
-        std::vector<int> seps;
-        for (int b = 0; b < nb; b++)
-            if (is_sep[b]) {
-                sepidx[b] = (int)seps.size();
-                seps.push_back(b);
-            }
-        const int m = (int)seps.size();
-        std::vector<int> seg_start, seg_len, lsep(nb, -1), rsep(nb, -1);
-        for (int b = 0; b < nb;) {
-            if (is_sep[b]) {
-                b++;
-                continue;
-            }
-            int z = b;
-            while (z + 1 < nb && !is_sep[z + 1])
-                z++;
-            seg_start.push_back(b);
-            seg_len.push_back(z - b + 1);
-            for (int r = b; r <= z; r++) {
-                lsep[r] = b > 0 ? sepidx[b - 1] : -1;
-                rsep[r] = z + 1 < nb ? sepidx[z + 1] : -1;
-            }
-            b = z + 1;
-        }
-        // gather lists of the reduced system: diagonal + sub-diagonal blocks in separator order, chords
+        // gather lists of the reduced system
         struct Key {
             int r, c;
             bool operator<(const Key &o) const { return r != o.r ? r < o.r : c < o.c; }
         };
         std::map<Key, std::vector<int2>> blocks;
+        std::vector<std::vector<int2>> rhs_src(m);
+        std::vector<int> terms;  // PgTerm: a_kind, a, w_kind, w
+        auto term = [&](const Coupling &u, int w_kind, int w) {
+            terms.insert(terms.end(), {u.a_kind, u.a, w_kind, w});
+            return make_int2(7, (int)(terms.size() / 4 - 1));
+        };
         for (int k = 0; k < m; k++) {
             const int sr = seps[k];
-            std::vector<int2> &d = blocks[{k, k}];
-            d.push_back(make_int2(0, sr));
-            if (sr + 1 < nb && !is_sep[sr + 1])
-                d.push_back(make_int2(4, sr));  // segment to the right
-            if (sr > 0 && !is_sep[sr - 1])
-                d.push_back(make_int2(5, sr - 1));  // segment to the left
-            if (k > 0) {
-                const int sl = seps[k - 1];
-                if (sl + 1 == sr)
-                    blocks[{k, k - 1}].push_back(make_int2(1, sl));
+            blocks[{k, k}].push_back(make_int2(0, sr));
+            rhs_src[k].push_back(make_int2(0, sr));
+            if (k > 0 && seps[k - 1] + 1 == sr)
+                blocks[{k, k - 1}].push_back(make_int2(1, seps[k - 1]));
+        }
+        for (const Chord &c : chords)
+            if (is_sep[c.i] && is_sep[c.j]) {  // block(row i, col j) = Ji^T Jj; stored at (hi, lo)
+                if (c.i > c.j)
+                    blocks[{sepidx[c.i], sepidx[c.j]}].push_back(make_int2(2, c.e));
                 else
-                    blocks[{k, k - 1}].push_back(make_int2(6, sr - 1));
+                    blocks[{sepidx[c.j], sepidx[c.i]}].push_back(make_int2(3, c.e));
             }
-        }
-        for (int e = 0; e < ne; e++) {
-            const int i = g->efrom[e] - 1, j = g->eto[e] - 1;
-            if (i < 0 || j < 0 || i == j || i - j == 1 || j - i == 1)
-                continue;
-            // block(row i, col j) = Ji^T Jj; stored at (hi, lo)
-            if (i > j)
-                blocks[{sepidx[i], sepidx[j]}].push_back(make_int2(2, e));
-            else
-                blocks[{sepidx[j], sepidx[i]}].push_back(make_int2(3, e));
-        }
+        for (int sg = 0; sg < n_seg; sg++)
+            for (const Coupling &u : coup[sg]) {
+                rhs_src[u.sep].push_back(term(u, 3, u.row));
+                for (const Coupling &v : coup[sg]) {
+                    if (u.sep < v.sep)
+                        continue;  // the lower triangle; for u.sep == v.sep both orders are terms of the diagonal block
+                    const int w = v.w_kind == 2 ? v.wbase + (u.row - seg_start[sg]) : u.row;
+                    blocks[{u.sep, v.sep}].push_back(term(u, v.w_kind, w));
+                }
+            }
         std::vector<int> rb_row, rb_col, rptr(1, 0);
         std::vector<int2> rsrc;
         for (auto &kv : blocks) {
@@ -1665,22 +1847,18 @@ int svo_pg_optimize(svo_posegraph *g, int iters, double *chi2)
             rptr.push_back((int)rsrc.size());
         }
         for (int k = 0; k < m; k++) {  // right-hand sides
-            const int sr = seps[k];
-            rsrc.push_back(make_int2(0, sr));
-            if (sr + 1 < nb && !is_sep[sr + 1])
-                rsrc.push_back(make_int2(4, sr));
-            if (sr > 0 && !is_sep[sr - 1])
-                rsrc.push_back(make_int2(5, sr - 1));
+            rsrc.insert(rsrc.end(), rhs_src[k].begin(), rhs_src[k].end());
             rptr.push_back((int)rsrc.size());
         }
         g->s_m = m;
-        g->s_nseg = (int)seg_start.size();
+        g->s_nseg = n_seg;
         g->s_maxseg = 0;
         for (int l : seg_len)
             g->s_maxseg = l > g->s_maxseg ? l : g->s_maxseg;
         g->s_nrblocks = (int)blocks.size();
         g->s_T = (6 * m + TB - 1) / TB;
         g->s_ldr = g->s_T * TB;
+        g->s_wc_blocks = wc_blocks;
         // one int buffer for all the structure arrays
         hs.clear();
         auto put = [&](const std::vector<int> &v) {
@@ -1693,11 +1871,19 @@ int svo_pg_optimize(svo_posegraph *g, int iters, double *chi2)
         g->o_sepidx = put(sepidx);
         g->o_lsep = put(lsep);
         g->o_rsep = put(rsep);
+        g->o_rowseg = put(rowseg);
+        g->o_cptr = put(cptr);
+        g->o_clrow = put(c_lrow);
+        g->o_cedge = put(c_edge);
+        g->o_ctr = put(c_tr);
+        g->o_cwbase = put(c_wbase);
+        g->o_csep = put(c_sep);
         g->o_rb_row = put(rb_row);
         g->o_rb_col = put(rb_col);
         g->o_rptr = put(rptr);
-        if (hs.size() & 1)
+        while (hs.size() & 3)
             hs.push_back(0);
+        g->o_terms = put(terms);
         g->o_rsrc = hs.size();
         for (const int2 &v : rsrc) {
             hs.push_back(v.x);
@@ -1708,6 +1894,7 @@ int svo_pg_optimize(svo_posegraph *g, int iters, double *chi2)
     const size_t o_seg_start = g->o_seg_start, o_seg_len = g->o_seg_len, o_sepidx = g->o_sepidx, o_lsep = g->o_lsep,
                  o_rsep = g->o_rsep, o_rb_row = g->o_rb_row, o_rb_col = g->o_rb_col, o_rptr = g->o_rptr,
                  o_rsrc = g->o_rsrc;
+    const size_t o_rowseg = g->o_rowseg, o_cptr = g->o_cptr, o_terms = g->o_terms;
     hipStream_t st = ctx->stream;
     int rc;
     // the graph itself: grown buffers keep what the device already holds, only the tail is uploaded
@@ -1723,7 +1910,7 @@ int svo_pg_optimize(svo_posegraph *g, int iters, double *chi2)
         (rc = g->d_Dg.ensure((size_t)nb * 288)) || (rc = g->d_Cc.ensure((size_t)nb * 288)) ||
         (rc = g->d_rneg.ensure((size_t)nb * 48)) ||
         (rc = g->d_Y.ensure((size_t)nb * 48)) || (rc = g->d_Wl.ensure((size_t)nb * 288)) ||
-        (rc = g->d_Wr.ensure((size_t)nb * 288)) || (rc = g->d_R.ensure((size_t)ldr * ldr * 8 + 64)) ||
+        (rc = g->d_Wr.ensure((size_t)nb * 288)) || (rc = g->d_Wc.ensure(g->s_wc_blocks * 288 + 64)) || (rc = g->d_R.ensure((size_t)ldr * ldr * 8 + 64)) ||
         (rc = g->d_Lo.ensure((size_t)ldr * ldr * 8 + 64)) || (rc = g->d_Tinv.ensure((size_t)2 * (T + 1) * TB * TB * 8 + 64)) ||
         (rc = g->d_rR.ensure((size_t)ldr * 8 + 64)) || (rc = g->d_xR.ensure((size_t)ldr * 8 + 64)) ||
         (rc = g->d_misc.ensure(((size_t)iters + 6 + (ne + 127) / 128) * 8 + 64)))
@@ -1754,7 +1941,8 @@ int svo_pg_optimize(svo_posegraph *g, int iters, double *chi2)
     SVO_HIP(hipMemsetAsync(d_status, 0, 16, st));  // status and ticket
     double *eo = g->d_eo.as<double>();
     double *Dg = g->d_Dg.as<double>(), *Cc = g->d_Cc.as<double>(), *rneg = g->d_rneg.as<double>();
-    double *Y = g->d_Y.as<double>(), *Wl = g->d_Wl.as<double>(), *Wr = g->d_Wr.as<double>();
+    double *Y = g->d_Y.as<double>(), *Wl = g->d_Wl.as<double>(), *Wr = g->d_Wr.as<double>(), *Wc = g->d_Wc.as<double>();
+    const PgSegChords seg_chords = {ds + o_cptr, ds + g->o_clrow, ds + g->o_cedge, ds + g->o_ctr, ds + g->o_cwbase};
     double *R = g->d_R.as<double>(), *Lo = g->d_Lo.as<double>(), *Tinv = g->d_Tinv.as<double>();
     double *rR = g->d_rR.as<double>(), *xR = g->d_xR.as<double>();
     // the separator solve keeps its vector and its running sums in LDS
@@ -1786,11 +1974,11 @@ int svo_pg_optimize(svo_posegraph *g, int iters, double *chi2)
         if (nseg > 0 || m > 0)
             hipLaunchKernelGGL(pg_segment_kernel, dim3(nseg + (m > 0 ? PG_CLEAR_WGS : 0)), dim3(BCR_WAVES * 64), seg_lds, st,
                                nb, nseg, ds + o_seg_start, ds + o_seg_len, Dg, Cc, rneg, Y, Wl, Wr, d_status, R, ldr, 6 * m,
-                               rR);
+                               rR, seg_chords, eo, Wc);
         if (m > 0) {
             hipLaunchKernelGGL(pg_reduce_kernel, dim3(n_rblocks + m), dim3(64), 0, st, n_rblocks, m, ds + o_rb_row,
-                               ds + o_rb_col, ds + o_rptr, reinterpret_cast<const int2 *>(ds + o_rsrc), Dg, Cc, rneg, eo,
-                               ne, Y, Wl, Wr, R, ldr, rR);
+                               ds + o_rb_col, ds + o_rptr, reinterpret_cast<const int2 *>(ds + o_rsrc),
+                               reinterpret_cast<const PgTerm *>(ds + o_terms), Dg, Cc, rneg, eo, Y, Wl, Wr, Wc, R, ldr, rR);
             double *Tp = Tinv + (size_t)(T + 1) * TB * TB;  // the inverses again, in the solve's layout
             hipLaunchKernelGGL(pg_dense_potf2_kernel, dim3(1), dim3(256), 0, st, R, Tinv, Tp, ldr, 0, d_status, 1 << 20);
             for (int kb = 0; kb + 1 < T; kb++) {
@@ -1802,7 +1990,8 @@ int svo_pg_optimize(svo_posegraph *g, int iters, double *chi2)
                                (size_t)(2 * ldr + TB) * 8, st, Lo, Tinv, Tp, ldr, T, rR, xR);
         }
         hipLaunchKernelGGL(pg_backsub_update_kernel, dim3((nb + PG_UPD_ROWS - 1) / PG_UPD_ROWS), dim3(PG_UPD_ROWS * 6), 0, st,
-                           nb, ds + o_sepidx, ds + o_lsep, ds + o_rsep, xR, Y, Wl, Wr, g->d_pose.as<double>());
+                           nb, ds + o_sepidx, ds + o_lsep, ds + o_rsep, xR, Y, Wl, Wr, ds + o_rowseg, ds + o_seg_start,
+                           ds + o_cptr, ds + g->o_csep, ds + g->o_cwbase, Wc, g->d_pose.as<double>());
     }
     SVO_HIP(hipGetLastError());
     // the optimised poses go into a temporary: a failed solve must not destroy the caller's estimate

@@ -68,6 +68,27 @@ def test_awkward_segment_shapes(ctx, orc):
     g.close()
 
 
+def test_cover_structure(ctx, orc, monkeypatch):
+    """SVO_PG_COVER=1: one endpoint per closure among the separators, the other inside a segment with a pass of six more
+    right-hand-side columns (posegraph.hip, pg_segment_kernel).  Same answers as the oracle on the corner-case graph (closures
+    that share endpoints, several closure endpoints inside one segment: the cap of four is exceeded and re-covered) and on a
+    graph whose matches all lie in the first lap."""
+    monkeypatch.setenv("SVO_PG_COVER", "1")
+    gt, est = drifting_loop(760, radius=60.0, yaw_drift=2e-4, scale_drift=1.0005, laps=4)
+    cuts = [1, 3, 6, 10, 12, 16, 33, 51, 116]
+    a = [(190 + c, c) for c in cuts] + [(410, 220), (571, 1), (192, 2), (190, 0), (380, 0), (675, 485), (759, 569)]
+    b = [(200 + 40 * k + 190 * (k % 3), 10 + 40 * k) for k in range(4)] + [(700 + k, 130 + k) for k in (0, 7, 19, 31, 44)]
+    for closures in (sorted(a), sorted(b)):
+        g = _build(lambda: capi.PoseGraph(ctx), est, closures)
+        o = _build(orc.PoseGraph, est, closures)
+        cg, co = g.optimize(6), o.optimize(6)
+        assert cg[0] == pytest.approx(co[0], rel=1e-12)
+        assert np.all(np.abs(cg[1:] - co[1:]) <= 1e-7 * co[:-1] + 1e-14), (cg, co)
+        assert _close(g.estimates(), o.estimates(), 1e-7)
+        assert cg[-1] < 1e-2 * cg[0]
+        g.close()
+
+
 def test_golden_and_odometry_only(ctx):
     gt, est = drifting_loop(40)
     g = _build(lambda: capi.PoseGraph(ctx), est, [(39, 0)])
