@@ -245,7 +245,7 @@ __global__ __launch_bounds__(128) void pg_linearize_kernel(const double *__restr
 //   T x_seg + E_a C_l x_l + E_z C_z^T x_r = r_seg   =>   x_seg = y - Wl x_l - Wr x_r,
 //   y = T^-1 r_seg,  Wl = T^-1 E_a C_l,  Wr = T^-1 E_z C_z^T.
 
-constexpr int PG_MAX_SEG_CHORDS = 4;  // closure endpoints a segment takes inside (six right-hand-side columns each)
+constexpr int PG_MAX_SEG_CHORDS = 8;  // closure endpoints a segment takes inside (six right-hand-side columns each, two to a pass)
 constexpr int SEG_L = 104;  // regular separator spacing (rows): a segment and its 13 right-hand sides live in LDS
 constexpr int TB = 48;      // tile of the dense reduced solve (8 block rows)
 
@@ -557,7 +557,8 @@ __global__ __launch_bounds__(BCR_WAVES * 64) void pg_segment_kernel(int nb, int 
     __syncthreads();
     PGSTAMP(71);
     int levels = 0;
-    // chord_pass: the factor is there; only the six columns of a closure's coupling (kept where the left separator's live)
+    // chord_pass: the factor is there; only the columns of one or two closures' couplings go down (one where the left
+    // separator's columns live, a second where the right one's do)
     auto forward = [&](const bool chord_pass) -> bool {
     levels = 0;
     for (int s = 1; s <= n; s <<= 1, levels++) {
@@ -580,8 +581,8 @@ __global__ __launch_bounds__(BCR_WAVES * 64) void pg_segment_kernel(int nb, int 
             const int q = s * (2 * t + 1);
             double *Q = sm + (q - 1) * BCR_ROW;
             const bool hl = q > s, hr = q + s <= n;
-            if (chord_pass && !(s_cols[q - 1] & 1))
-                continue;  // nothing of the coupling has reached this row
+            if (chord_pass && !s_cols[q - 1])
+                continue;  // nothing of the couplings has reached this row
             if (!chord_pass && !by_lane && !wave_chol6_inv<false>(Q, nullptr, Q, lane)) {
                 if (lane == 0) {
                     atomicMax(status, a + q);
@@ -623,10 +624,10 @@ __global__ __launch_bounds__(BCR_WAVES * 64) void pg_segment_kernel(int nb, int 
                     const int c = 7 + lane % 6;
                     i = lane / 6, src = Q + BCR_B + c, st = 13, dst = BCR_B + 13 * i + c;
                 }
-                if (chord_pass && (r != 1 || lane < 14))
+                if (chord_pass && (r == 0 || (r == 1 && lane < 14)))
                     dst = -1;  // the factor's blocks and the first column stay as they are
                 double acc = 0.;
-                if (r < rounds && (!chord_pass || r == 1)) {
+                if (r < rounds && (!chord_pass || r >= 1)) {
 #pragma unroll
                     for (int u = 0; u < 6; u++)
                         acc = fma(Q[6 * i + u], src[u * st], acc);
@@ -654,7 +655,7 @@ __global__ __launch_bounds__(BCR_WAVES * 64) void pg_segment_kernel(int nb, int 
             const double *Gl = sm + (p - s - 1) * BCR_ROW;                 // the eliminated row on the left: its G+ is ours
             const double *Gr = sm + ((hr ? p + s : p - s) - 1) * BCR_ROW;  // on the right: its G-
             const int cols = s_cols[p - 1] | s_cols[p - s - 1] | (hr ? s_cols[p + s - 1] : 0);
-            if (chord_pass && !(cols & 1))
+            if (chord_pass && !cols)
                 continue;
             // out = base - sum_u A1[6 u] B1[u * st] - sum_u A2[6 u] B2[u * st]: the same code in every lane (see above);
             // round 0: D_p (36) and 28 entries of the new coupling, round 1: its other 8, B_p's first column (6), the left
@@ -664,7 +665,7 @@ __global__ __launch_bounds__(BCR_WAVES * 64) void pg_segment_kernel(int nb, int 
             for (int r = 0; r < 3; r++) {
                 if (r >= rounds)
                     break;
-                if (chord_pass && r != 1)
+                if (chord_pass && r == 0)
                     continue;
                 int st = 6, dst = -1;
                 bool use1 = true, use2 = hr, keep = true;
@@ -699,7 +700,7 @@ __global__ __launch_bounds__(BCR_WAVES * 64) void pg_segment_kernel(int nb, int 
                     acc1 = fma(A1[6 * u], B1[u * st], acc1);
                     acc2 = fma(A2[6 * u], B2[u * st], acc2);
                 }
-                if (chord_pass && lane < 14)
+                if (chord_pass && r == 1 && lane < 14)
                     dst = -1;
                 if (dst >= 0) {
                     const double base = keep ? P[dst] : 0.;
@@ -782,19 +783,28 @@ __global__ __launch_bounds__(BCR_WAVES * 64) void pg_segment_kernel(int nb, int 
         lds_barrier();
         PGSTAMP(90 + lev);
     }
-    // ---- the closures that end inside this segment: six columns each, through the factor once more ----
-    for (int cc = ch.cptr[blockIdx.x]; cc < ch.cptr[blockIdx.x + 1]; cc++) {
-        const int jrow = ch.lrow[cc], tr = ch.tr[cc];
-        const double *H = eo + (size_t)ch.edge[cc] * EO_FIELDS + EO_HIJ;
-        double *wout = Wc + (size_t)ch.wbase[cc] * 36;
-        for (int e = tid; e < n * 78; e += NT) {  // B = E_j H[j][i] in the columns 1 .. 6
+    // ---- the closures that end inside this segment: six columns each, two closures to a pass through the factor ----
+    for (int cc = ch.cptr[blockIdx.x]; cc < ch.cptr[blockIdx.x + 1]; cc += 2) {
+        const bool two = cc + 1 < ch.cptr[blockIdx.x + 1];
+        const int jr[2] = {ch.lrow[cc], two ? ch.lrow[cc + 1] : -1}, trs[2] = {ch.tr[cc], two ? ch.tr[cc + 1] : 0};
+        const double *Hs[2] = {eo + (size_t)ch.edge[cc] * EO_FIELDS + EO_HIJ,
+                               eo + (size_t)ch.edge[two ? cc + 1 : cc] * EO_FIELDS + EO_HIJ};
+        double *wouts[2] = {Wc + (size_t)ch.wbase[cc] * 36, Wc + (size_t)ch.wbase[two ? cc + 1 : cc] * 36};
+        for (int e = tid; e < n * 78; e += NT) {  // B = E_j H[j][i]: the first closure in the columns 1 .. 6, the second in 7 .. 12
             const int p = e / 78, k = e - 78 * p, r = k / 13, c = k - 13 * r;
-            sm[p * BCR_ROW + BCR_B + k] = p == jrow && c >= 1 && c < 7 ? (tr ? H[6 * (c - 1) + r] : H[6 * r + (c - 1)]) : 0.;
+            double v = 0.;
+            if (c >= 1) {
+                const int g2 = c >= 7 ? 1 : 0, cl = c - (g2 ? 7 : 1);
+                if (p == jr[g2])
+                    v = trs[g2] ? Hs[g2][6 * cl + r] : Hs[g2][6 * r + cl];
+            }
+            sm[p * BCR_ROW + BCR_B + k] = v;
         }
         if (tid < n)
-            s_cols[tid] = tid == jrow ? 1 : 0;
+            s_cols[tid] = (unsigned char)((tid == jr[0] ? 1 : 0) | (tid == jr[1] ? 2 : 0));
         lds_barrier();
         (void)forward(true);
+        const int ncols = two ? 72 : 36;
         for (int lev = levels - 1; lev >= 0; lev--) {
             const int s = 1 << lev, cnt = (n / s + 1) / 2;
             for (int t = wave; t < cnt; t += BCR_WAVES) {
@@ -803,33 +813,50 @@ __global__ __launch_bounds__(BCR_WAVES * 64) void pg_segment_kernel(int nb, int 
                 const bool hl = q > s, hr = q + s <= n;
                 const double *Xl = sm + ((hl ? q - s : q) - 1) * BCR_ROW + BCR_B;
                 const double *Xr = sm + ((hr ? q + s : q) - 1) * BCR_ROW + BCR_B;
-                const int i = lane / 6, c = 1 + lane % 6;  // lanes 0 .. 35: the six columns
-                double acc = 0.;
-                if (lane < 36) {
-                    acc = Q[BCR_B + 13 * i + c];
-                    if (hl) {
+                double v[2];
+                int ii[2], cs2[2];
 #pragma unroll
-                        for (int u = 0; u < 6; u++)
-                            acc = fma(-Q[BCR_GM + 6 * i + u], Xl[13 * u + c], acc);
-                    }
-                    if (hr) {
+                for (int k2 = 0; k2 < 2; k2++) {  // entry e: the first closure's 36, then the second's
+                    const int e = lane + 64 * k2, g2 = e >= 36 ? 1 : 0, el = e - 36 * g2;
+                    const int i = el / 6, c = (g2 ? 7 : 1) + el % 6;
+                    ii[k2] = i, cs2[k2] = c;
+                    double acc = 0.;
+                    if (e < ncols) {
+                        acc = Q[BCR_B + 13 * i + c];
+                        if (hl) {
 #pragma unroll
-                        for (int u = 0; u < 6; u++)
-                            acc = fma(-Q[BCR_F + 6 * i + u], Xr[13 * u + c], acc);
+                            for (int u = 0; u < 6; u++)
+                                acc = fma(-Q[BCR_GM + 6 * i + u], Xl[13 * u + c], acc);
+                        }
+                        if (hr) {
+#pragma unroll
+                            for (int u = 0; u < 6; u++)
+                                acc = fma(-Q[BCR_F + 6 * i + u], Xr[13 * u + c], acc);
+                        }
+                        Q[BCR_B + 13 * i + c] = acc;  // a lane's own entry
                     }
-                    Q[BCR_B + 13 * i + c] = acc;  // a lane's own entry
+                    v[k2] = acc;
                 }
                 wave_sync();
-                if (lane < 36) {
-                    acc = 0.;
 #pragma unroll
-                    for (int u = 0; u < 6; u++)
-                        acc = fma(Q[6 * u + i], Q[BCR_B + 13 * u + c], acc);
+                for (int k2 = 0; k2 < 2; k2++) {
+                    double acc = 0.;
+                    if (lane + 64 * k2 < ncols) {
+#pragma unroll
+                        for (int u = 0; u < 6; u++)
+                            acc = fma(Q[6 * u + ii[k2]], Q[BCR_B + 13 * u + cs2[k2]], acc);
+                    }
+                    v[k2] = acc;
                 }
                 wave_sync();
-                if (lane < 36) {
-                    Q[BCR_B + 13 * i + c] = acc;
-                    wout[(size_t)(q - 1) * 36 + 6 * i + (c - 1)] = acc;
+#pragma unroll
+                for (int k2 = 0; k2 < 2; k2++) {
+                    const int e = lane + 64 * k2;
+                    if (e < ncols) {
+                        Q[BCR_B + 13 * ii[k2] + cs2[k2]] = v[k2];
+                        const int g2 = e >= 36 ? 1 : 0;
+                        wouts[g2][(size_t)(q - 1) * 36 + 6 * ii[k2] + (cs2[k2] - (g2 ? 7 : 1))] = v[k2];
+                    }
                 }
             }
             lds_barrier();
@@ -1697,9 +1724,10 @@ int svo_pg_optimize(svo_posegraph *g, int iters, double *chi2)
         // SVO_PG_COVER=1 selects the other structure this file can run: separators = a COVER of the chords (where neither
         // endpoint of a chord is one yet, the later row becomes one); a chord's other endpoint then stays inside its segment
         // and costs that segment a pass of six more right-hand-side columns (pg_segment_kernel; at most PG_MAX_SEG_CHORDS
-        // per segment, the ones beyond that become separators after all).  Measured at 4541 vertices / 40 closures whose
-        // matches all lie in the first lap: 62 separators instead of 81 (7 tile steps instead of 9, -39 us) but four passes
-        // in each of the first lap's segments (+59 us): 0.288 against 0.277 ms per iteration -- so it is not the default.
+        // per segment, two to a pass, the ones beyond that become separators after all).  Measured at 4541 vertices / 40
+        // closures whose matches all lie in the first lap: 45 separators instead of 81 (5 tile steps instead of 9, the solve
+        // 12 us instead of 25: -80 us) but four passes of 27 us in each of the first lap's segments (+109 us): 0.310 against
+        // 0.277 ms per iteration -- so it is not the default.
         const bool both_ends = getenv("SVO_PG_COVER") == nullptr;
         std::vector<char> cover(nb, 0), is_sep;
         for (const Chord &c : chords) {
