@@ -516,33 +516,90 @@ __global__ __launch_bounds__(1024) void bow_topk_kernel(const double *__restrict
                                                         int entry_id, svo_lc_bow_record *rec)
 {
     constexpr int PER = 8;      // 8192 entries at most
-    constexpr int LIST = 4096;  // entries with a common word that fit the rank-counting path
+    constexpr int LIST = 2048;  // the entries at or above the cut: k_want of them and the ties of the last
     __shared__ double s_s[LIST];
     __shared__ int s_e[LIST];
     __shared__ double s_v[16];
-    __shared__ int s_id[16], s_c;
+    __shared__ int s_id[16], s_c, s_hist[256], s_pick, s_left, s_neg;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     double v[PER];
-    if (t == 0)
+    unsigned long long key[PER];  // an entry with a common word: the bits of -sum (the larger the better); the others 0
+    if (t == 0) {
         s_c = 0;
+        s_neg = 0;
+    }
     __syncthreads();
+    int mine = 0;
 #pragma unroll
     for (int u = 0; u < PER; u++) {
         const int e = u * 1024 + t;
         v[u] = e < max_id ? sums[e] : 0.;
-        if (v[u] < 0.) {  // the entry shares a word with the query
+        key[u] = v[u] < 0. ? (unsigned long long)__double_as_longlong(-v[u]) : 0ull;
+        mine += v[u] < 0. ? 1 : 0;
+    }
+    if (mine)
+        atomicAdd(&s_neg, mine);
+    __syncthreads();
+    // The cut: the key of the k_want-th best entry, a byte at a time from the top -- a 256-bin count of the keys that match
+    // the bytes found so far, then the bin the k_want-th falls into.  Eight passes over registers, whatever the database
+    // holds (ranking every entry with a common word against every other grew with the square of their number: 30 us at a
+    // few hundred entries, the iterative fallback beyond 4096).
+    unsigned long long thr = 0;
+    if (s_neg > k_want && s_neg > 512) {  // (a few hundred candidates are ranked among themselves directly, below)
+        int left = k_want;
+        for (int shift = 56; shift >= 0; shift -= 8) {
+            if (t < 256)
+                s_hist[t] = 0;
+            __syncthreads();
+            const unsigned long long himask = shift == 56 ? 0ull : ~0ull << (shift + 8);
+#pragma unroll
+            for (int u = 0; u < PER; u++)
+                if (key[u] && (key[u] & himask) == (thr & himask))
+                    atomicAdd(&s_hist[(int)((key[u] >> shift) & 255ull)], 1);
+            __syncthreads();
+            // above = keys in the bins over t: a suffix sum -- shuffles inside each of the four waves, their totals across
+            int cnt = 0, incl = 0;
+            if (t < 256) {
+                cnt = s_hist[t];
+                incl = cnt;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int o = __shfl_down(incl, off, 64);
+                    incl += lane + off < 64 ? o : 0;
+                }
+                if (lane == 0)
+                    s_id[wave] = incl;  // this wave's 64 bins
+            }
+            __syncthreads();
+            if (t < 256) {
+                int above = incl - cnt;
+                for (int w2 = wave + 1; w2 < 4; w2++)
+                    above += s_id[w2];
+                if (above < left && left <= above + cnt) {
+                    s_pick = t;
+                    s_left = left - above;
+                }
+            }
+            __syncthreads();
+            thr |= (unsigned long long)s_pick << shift;
+            left = s_left;
+            __syncthreads();
+        }
+    }
+    // the entries at or above the cut, then their order among themselves (sum ascending, id ascending)
+#pragma unroll
+    for (int u = 0; u < PER; u++)
+        if (key[u] && key[u] >= thr) {
             const int slot = atomicAdd(&s_c, 1);
             if (slot < LIST) {
                 s_s[slot] = v[u];
-                s_e[slot] = e;
+                s_e[slot] = u * 1024 + t;
             }
         }
-    }
     __syncthreads();
     const int c = s_c;
     int n_out = 0;
     if (c <= LIST) {
-        // the usual case: few entries share a word.  Rank of an entry = how many come before it in (sum ascending, id ascending)
         for (int a = t; a < c; a += 1024) {
             const double sa = s_s[a];
             const int ea = s_e[a];
@@ -559,7 +616,7 @@ __global__ __launch_bounds__(1024) void bow_topk_kernel(const double *__restrict
         }
         n_out = c < k_want ? c : k_want;
     } else {
-        for (int round = 0; round < k_want; round++) {  // more than LIST: k_want rounds of a block-wide minimum
+        for (int round = 0; round < k_want; round++) {  // thousands of equal sums at the cut: k_want rounds of a block-wide minimum
             double bv = 0.;
             int be = 1 << 30;
 #pragma unroll

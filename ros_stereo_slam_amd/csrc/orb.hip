@@ -290,11 +290,25 @@ __global__ __launch_bounds__(1024) void select_kernel(OrbLevels L, const int *__
                     atomicAdd(&s_hist[(k >> shift) & 255u], 1);
             }
             __syncthreads();
-            if (t < 256) {  // above[t] = keys in the bins over t; the pick is the bin with above < left <= above + count
-                const int cnt = s_hist[t];
-                int above = 0;
-                for (int b = t + 1; b < 256; b++)
-                    above += s_hist[b];
+            // above[t] = keys in the bins over t (a suffix sum: shuffles inside each of the four waves, their totals
+            // across); the pick is the bin with above < left <= above + count
+            int cnt = 0, incl = 0;
+            if (t < 256) {
+                cnt = s_hist[t];
+                incl = cnt;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int o = __shfl_down(incl, off, 64);
+                    incl += lane + off < 64 ? o : 0;
+                }
+                if (lane == 0)
+                    s_red[wave] = incl;
+            }
+            __syncthreads();
+            if (t < 256) {
+                int above = incl - cnt;
+                for (int w2 = wave + 1; w2 < 4; w2++)
+                    above += s_red[w2];
                 if (above < left && left <= above + cnt) {
                     s_pick = t;
                     s_left = left - above;
