@@ -235,7 +235,11 @@ template <int KPW> __global__ __launch_bounds__(64) void anms_decide_kernel(Anms
 
 // kept[] = order[s] for every s with radius[s] >= decision radius, in sorted order (single workgroup scan);
 // the payload arrays of the kept keypoints are gathered in the same pass
-template <int NJ> __global__ __launch_bounds__(1024) void anms_gather_kernel(AnmsBatchN<NJ> batch, int n)
+// 256 threads: a workgroup of one wave per SIMD starts beside the tracking launches at once (four tracking waves leave 96
+// registers of a SIMD free; the 1024-thread form of rounds 1-3 needed four waves on every SIMD of one compute unit and fitted
+// only because it stayed under 24 registers: 76 us on average in the bench for 13 us of work).
+constexpr int GATHER_T = 256;
+template <int NJ> __global__ __launch_bounds__(GATHER_T) void anms_gather_kernel(AnmsBatchN<NJ> batch, int n)
 {
     svo_chain_priority();
     const AnmsJob &job = batch.j[blockIdx.x];  // one workgroup per job
@@ -246,24 +250,32 @@ template <int NJ> __global__ __launch_bounds__(1024) void anms_gather_kernel(Anm
     const int *__restrict__ order = job.order;
     int *__restrict__ out_idx = job.out_idx;
     int *__restrict__ d_count = job.d_count;
-    __shared__ int s_sum[1024];
-    const int t = threadIdx.x;
-    const int per = (n + 1023) / 1024;
+    __shared__ int s_wave[GATHER_T / 64];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int per = (n + GATHER_T - 1) / GATHER_T;
     const int b = t * per, e = min(b + per, n);
     int cnt = 0;
     for (int i = b; i < e; i++)
         cnt += radius_sq[i] >= decision ? 1 : 0;
-    s_sum[t] = cnt;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        int v = t >= off ? s_sum[t - off] : 0;
-        __syncthreads();
-        s_sum[t] += v;
-        __syncthreads();
+    // exclusive prefix of the threads' counts: shuffles inside a wave, the wave totals through LDS -- one barrier
+    int incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(incl, off, 64);
+        incl += lane >= off ? o : 0;
     }
-    int pos = s_sum[t] - cnt;
-    if (t == 1023)
-        *d_count = s_sum[1023];
+    if (lane == 63)
+        s_wave[wave] = incl;
+    __syncthreads();
+    int pos = incl - cnt, total = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < GATHER_T / 64; w2++) {
+        const int wt = s_wave[w2];
+        pos += w2 < wave ? wt : 0;
+        total += wt;
+    }
+    if (t == 0)
+        *d_count = total;
     for (int i = b; i < e; i++)
         if (radius_sq[i] >= decision) {
             const int j = order[i];
@@ -360,11 +372,11 @@ int svo_launch_anms_batch(svo_ctx *ctx, int k, const float *const *xy, const flo
     if (lone) {
         hipLaunchKernelGGL(anms_radius_kernel<KPW_LONE>, wgrid, block, 0, ctx->stream, one, n);
         hipLaunchKernelGGL(anms_decide_kernel<KPW_LONE>, wgrid, block, 0, ctx->stream, one, n, keep);
-        hipLaunchKernelGGL(anms_gather_kernel<1>, dim3(k), dim3(1024), 0, ctx->stream, one, n);
+        hipLaunchKernelGGL(anms_gather_kernel<1>, dim3(k), dim3(GATHER_T), 0, ctx->stream, one, n);
     } else {
         hipLaunchKernelGGL(anms_radius_kernel<KPW_GROUP>, wgrid, block, 0, ctx->stream, batch, n);
         hipLaunchKernelGGL(anms_decide_kernel<KPW_GROUP>, wgrid, block, 0, ctx->stream, batch, n, keep);
-        hipLaunchKernelGGL(anms_gather_kernel<SVO_LK_MAX_JOBS>, dim3(k), dim3(1024), 0, ctx->stream, batch, n);
+        hipLaunchKernelGGL(anms_gather_kernel<SVO_LK_MAX_JOBS>, dim3(k), dim3(GATHER_T), 0, ctx->stream, batch, n);
     }
     SVO_HIP(hipGetLastError());
     return SVO_OK;
