@@ -68,6 +68,25 @@ def test_awkward_segment_shapes(ctx, orc):
     g.close()
 
 
+def test_many_separators(ctx, orc):
+    """3000 vertices, 75 closures with both endpoints spread over the laps: about 150 separators, a 19-tile separator system
+    -- the tile steps, the separator solve's far blocks beyond the eight it keeps in flight, and the gather lists at a size
+    the bench graph (11 tiles) does not reach."""
+    gt, est = drifting_loop(3000, radius=200.0, yaw_drift=2e-5, scale_drift=1.0002, laps=5)
+    rng = np.random.default_rng(11)
+    at = sorted(rng.choice(np.arange(640, 3000), size=75, replace=False).tolist())
+    closures = [(a, a - 600 * int(rng.integers(1, a // 600 + 1))) for a in at]
+    closures = [(a, b) for a, b in closures if b >= 1]
+    g = _build(lambda: capi.PoseGraph(ctx), est, closures)
+    o = _build(orc.PoseGraph, est, closures)
+    cg, co = g.optimize(5), o.optimize(5)
+    assert cg[0] == pytest.approx(co[0], rel=1e-12)
+    assert np.all(np.abs(cg[1:] - co[1:]) <= 1e-6 * co[:-1] + 1e-12), (cg, co)
+    assert _close(g.estimates(), o.estimates(), 1e-6)
+    assert cg[-1] < 1e-2 * cg[0]
+    g.close()
+
+
 def test_cover_structure(ctx, orc, monkeypatch):
     """SVO_PG_COVER=1: one endpoint per closure among the separators, the other inside a segment with a pass of six more
     right-hand-side columns (posegraph.hip, pg_segment_kernel).  Same answers as the oracle on the corner-case graph (closures
