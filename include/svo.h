@@ -489,7 +489,10 @@ int svo_pg_augment_node(svo_posegraph *pg, const double *pose7);
  * IDENTITY measurement (T is unused by the reference) */
 int svo_pg_add_loop_closure(svo_posegraph *pg, int from_id);
 /* globalOptimize, poseGraph.h:128-138: `iters` Gauss-Newton iterations (the reference: 10).
- * chi2 (optional, iters+1 doubles): the error before each iteration and after the last.        */
+ * chi2 (optional, iters+1 doubles): the error before each iteration and after the last.
+ * SVO_ERR_STATE: the normal matrix was not positive definite (the graph is left as it was);
+ * SVO_ERR_ARG: more than about 1600 distinct loop-closure endpoints (the separator solve keeps
+ * its vector in one workgroup's LDS; KITTI 00 with the reference's 100-frame cooldown has < 100). */
 int svo_pg_optimize(svo_posegraph *pg, int iters, double *chi2);
 int svo_pg_num_vertices(const svo_posegraph *pg);
 int svo_pg_num_edges(const svo_posegraph *pg);
