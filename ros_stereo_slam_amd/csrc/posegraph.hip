@@ -1719,24 +1719,28 @@ int svo_pg_optimize(svo_posegraph *g, int iters, double *chi2)
                 continue;
             chords.push_back({e, i, j});
         }
-        // Separators: BOTH endpoints of every chord + a regular one only where that leaves a run longer than SEG_L - 1 rows
-        // (every separator adds six rows to the dense reduced system, whose tile steps are what a solve's time is made of).
-        // SVO_PG_COVER=1 selects the other structure this file can run: separators = a COVER of the chords (where neither
-        // endpoint of a chord is one yet, the later row becomes one); a chord's other endpoint then stays inside its segment
-        // and costs that segment a pass of six more right-hand-side columns (pg_segment_kernel; at most PG_MAX_SEG_CHORDS
-        // per segment, two to a pass, the ones beyond that become separators after all).  Measured at 4541 vertices / 40
-        // closures whose matches all lie in the first lap: 45 separators instead of 81 (5 tile steps instead of 9, the solve
-        // 12 us instead of 25: -80 us) but four passes of 27 us in each of the first lap's segments (+109 us): 0.310 against
-        // 0.277 ms per iteration -- so it is not the default.
-        const bool both_ends = getenv("SVO_PG_COVER") == nullptr;
-        std::vector<char> cover(nb, 0), is_sep;
+        // Separators: every separator adds six rows to the dense reduced system, whose tile steps are what a solve's time is
+        // made of.  Two structures, the cheaper by a small cost model (measured constants) is taken:
+        //   both   BOTH endpoints of every chord + a regular one only where that leaves a run longer than SEG_L - 1 rows;
+        //   cover  a COVER of the chords (where neither endpoint of a chord is a separator yet, the later row becomes one);
+        //          a chord's other endpoint stays inside its segment and costs that segment a pass of six more right-hand-
+        //          side columns (pg_segment_kernel: two closures to a pass, at most PG_MAX_SEG_CHORDS per segment, the
+        //          ones beyond that become separators after all).
+        // At 4541 vertices / 40 closures whose matches all lie in the first lap: cover = 45 separators instead of 81 (5 tile
+        // steps instead of 9, the solve 12 us instead of 25: -80 us) but four passes of 27 us in each of the first lap's
+        // segments (+109 us): 0.310 against 0.277 ms per iteration, and the model says so; closures whose endpoints spread
+        // take one pass per segment and the cover.  SVO_PG_COVER=1 / 0 forces one or the other (the tests run both).
+        std::vector<char> cover, is_sep;
+        std::vector<int> sepidx, seps, seg_start, seg_len, lsep, rsep, rowseg;
+        auto select = [&](const bool both_ends) -> int {  // -> closure endpoints inside the fullest segment
+        cover.assign(nb, 0);
         for (const Chord &c : chords) {
             if (both_ends)
                 cover[c.i] = cover[c.j] = 1;
             else if (!cover[c.i] && !cover[c.j])
                 cover[c.i > c.j ? c.i : c.j] = 1;
         }
-        std::vector<int> sepidx, seps, seg_start, seg_len, lsep, rsep, rowseg;
+        int fullest = 0;
         for (;;) {
             is_sep = cover;
             for (int b = 0, run = 0; b < nb - 1; b++) {
@@ -1781,14 +1785,34 @@ int svo_pg_optimize(svo_posegraph *g, int iters, double *chi2)
             // a segment with too many closure endpoints inside: the surplus becomes separators, and once more
             std::vector<int> inside(seg_start.size(), 0);
             bool again = false;
+            fullest = 0;
             for (const Chord &c : chords)
                 for (const int r : {c.i, c.j})
-                    if (!is_sep[r] && ++inside[rowseg[r]] > PG_MAX_SEG_CHORDS) {
-                        cover[r] = 1;
-                        again = true;
+                    if (!is_sep[r]) {
+                        if (++inside[rowseg[r]] > PG_MAX_SEG_CHORDS) {
+                            cover[r] = 1;
+                            again = true;
+                        } else if (inside[rowseg[r]] > fullest)
+                            fullest = inside[rowseg[r]];
                     }
             if (!again)
                 break;
+        }
+        return fullest;
+        };
+        {
+            const char *force = getenv("SVO_PG_COVER");
+            bool both_ends;
+            if (force)
+                both_ends = force[0] == '0';
+            else {
+                auto cost_us = [&](const bool b) {
+                    const int fullest = select(b), tiles = (6 * (int)seps.size() + TB - 1) / TB;
+                    return 16.7 * (tiles > 1 ? tiles - 1 : 0) + 2.3 * tiles + 27.0 * ((fullest + 1) / 2);
+                };
+                both_ends = cost_us(true) <= cost_us(false);
+            }
+            (void)select(both_ends);
         }
         const int m = (int)seps.size(), n_seg = (int)seg_start.size();
         // what couples a segment to the separators: its two neighbours in the chain, and the closures that end inside it
