@@ -557,14 +557,12 @@ __global__ __launch_bounds__(BCR_WAVES * 64) void pg_segment_kernel(int nb, int 
     __syncthreads();
     PGSTAMP(71);
     int levels = 0;
-    // chord_pass: the factor is there; only the columns of one or two closures' couplings go down (one where the left
-    // separator's columns live, a second where the right one's do)
-    auto forward = [&](const bool chord_pass) -> bool {
+    auto forward = [&]() -> bool {
     levels = 0;
     for (int s = 1; s <= n; s <<= 1, levels++) {
         // ---- eliminate the rows q = s (2 t + 1): factor, and the products with L^-1 ----
         const int cnt = (n / s + 1) / 2;
-        const bool by_lane = !chord_pass && cnt > BCR_WAVES;  // more rows than waves: a lane per block first, the products after
+        const bool by_lane = cnt > BCR_WAVES;  // more rows than waves: a lane per block first, the products after
         if (by_lane) {
             if (tid < cnt) {
                 const int q = s * (2 * tid + 1);
@@ -581,9 +579,7 @@ __global__ __launch_bounds__(BCR_WAVES * 64) void pg_segment_kernel(int nb, int 
             const int q = s * (2 * t + 1);
             double *Q = sm + (q - 1) * BCR_ROW;
             const bool hl = q > s, hr = q + s <= n;
-            if (chord_pass && !s_cols[q - 1])
-                continue;  // nothing of the couplings has reached this row
-            if (!chord_pass && !by_lane && !wave_chol6_inv<false>(Q, nullptr, Q, lane)) {
+            if (!by_lane && !wave_chol6_inv<false>(Q, nullptr, Q, lane)) {
                 if (lane == 0) {
                     atomicMax(status, a + q);
                     s_fail = 1;
@@ -624,10 +620,8 @@ __global__ __launch_bounds__(BCR_WAVES * 64) void pg_segment_kernel(int nb, int 
                     const int c = 7 + lane % 6;
                     i = lane / 6, src = Q + BCR_B + c, st = 13, dst = BCR_B + 13 * i + c;
                 }
-                if (chord_pass && (r == 0 || (r == 1 && lane < 14)))
-                    dst = -1;  // the factor's blocks and the first column stay as they are
                 double acc = 0.;
-                if (r < rounds && (!chord_pass || r >= 1)) {
+                if (r < rounds) {
 #pragma unroll
                     for (int u = 0; u < 6; u++)
                         acc = fma(Q[6 * i + u], src[u * st], acc);
@@ -655,8 +649,6 @@ __global__ __launch_bounds__(BCR_WAVES * 64) void pg_segment_kernel(int nb, int 
             const double *Gl = sm + (p - s - 1) * BCR_ROW;                 // the eliminated row on the left: its G+ is ours
             const double *Gr = sm + ((hr ? p + s : p - s) - 1) * BCR_ROW;  // on the right: its G-
             const int cols = s_cols[p - 1] | s_cols[p - s - 1] | (hr ? s_cols[p + s - 1] : 0);
-            if (chord_pass && !cols)
-                continue;
             // out = base - sum_u A1[6 u] B1[u * st] - sum_u A2[6 u] B2[u * st]: the same code in every lane (see above);
             // round 0: D_p (36) and 28 entries of the new coupling, round 1: its other 8, B_p's first column (6), the left
             // separator's columns (36), round 2: the right separator's columns
@@ -665,8 +657,6 @@ __global__ __launch_bounds__(BCR_WAVES * 64) void pg_segment_kernel(int nb, int 
             for (int r = 0; r < 3; r++) {
                 if (r >= rounds)
                     break;
-                if (chord_pass && r == 0)
-                    continue;
                 int st = 6, dst = -1;
                 bool use1 = true, use2 = hr, keep = true;
                 const double *A1 = Gl, *B1 = Gl, *A2 = Gl, *B2 = Gl;
@@ -700,8 +690,6 @@ __global__ __launch_bounds__(BCR_WAVES * 64) void pg_segment_kernel(int nb, int 
                     acc1 = fma(A1[6 * u], B1[u * st], acc1);
                     acc2 = fma(A2[6 * u], B2[u * st], acc2);
                 }
-                if (chord_pass && r == 1 && lane < 14)
-                    dst = -1;
                 if (dst >= 0) {
                     const double base = keep ? P[dst] : 0.;
                     P[dst] = (base - (use1 ? acc1 : 0.)) - (use2 ? acc2 : 0.);
@@ -715,7 +703,7 @@ __global__ __launch_bounds__(BCR_WAVES * 64) void pg_segment_kernel(int nb, int 
     }
     return true;
     };
-    if (!forward(false))
+    if (!forward())
         return;
     // ---- substitution, the levels upwards: X_q = L^-T (GB_q - G-_q X_{q-s} - G+_q X_{q+s}), 6 x 13 ----
     for (int lev = levels - 1; lev >= 0; lev--) {
@@ -800,10 +788,63 @@ __global__ __launch_bounds__(BCR_WAVES * 64) void pg_segment_kernel(int nb, int 
             }
             sm[p * BCR_ROW + BCR_B + k] = v;
         }
-        if (tid < n)
-            s_cols[tid] = (unsigned char)((tid == jr[0] ? 1 : 0) | (tid == jr[1] ? 2 : 0));
         lds_barrier();
-        (void)forward(true);
+        // Down: a closure's columns live in ONE row that is eliminated per level (the endpoint itself at its own level,
+        // then whichever of the two rows it was folded into goes next), so a wave walks them up the elimination tree on its
+        // own -- wave 0 the first closure's columns, wave 1 the second's -- with no workgroup barrier; the same operations
+        // in the same order as the general sweep would do for these columns.  (The general sweep -- every wave through every
+        // level with two barriers each, nearly all of them idle -- was 12 of a pass's 27 us.)
+        if (wave < (two ? 2 : 1)) {
+            const int c0 = wave ? 7 : 1;
+            int flagged[4], nf = 1;
+            flagged[0] = jr[wave] + 1;  // 1-based rows that carry the columns and have not been eliminated
+            for (int s = 1; s <= n; s <<= 1) {
+                int q = 0;
+                for (int f = 0; f < nf; f++)
+                    if ((flagged[f] & (2 * s - 1)) == s)
+                        q = flagged[f];  // the one eliminated at this level (at most one: see above)
+                if (!q)
+                    continue;
+                double *Q = sm + (q - 1) * BCR_ROW;
+                const int i = lane / 6, c = c0 + lane % 6;
+                double acc = 0.;
+                if (lane < 36) {  // GB = Linv B, these six columns
+#pragma unroll
+                    for (int u = 0; u < 6; u++)
+                        acc = fma(Q[6 * i + u], Q[BCR_B + 13 * u + c], acc);
+                }
+                wave_sync();
+                if (lane < 36)
+                    Q[BCR_B + 13 * i + c] = acc;
+                wave_sync();
+                int keep = 0;
+                for (int f = 0; f < nf; f++)
+                    if (flagged[f] != q)
+                        flagged[keep++] = flagged[f];
+                nf = keep;
+                for (int side = 0; side < 2; side++) {  // into q - s through G-, into q + s through G+
+                    const int p = side ? q + s : q - s;
+                    if (p < 1 || p > n)
+                        continue;
+                    double *P = sm + (p - 1) * BCR_ROW;
+                    const double *G = Q + (side ? BCR_F : BCR_GM);
+                    if (lane < 36) {
+                        double a2 = 0.;
+#pragma unroll
+                        for (int u = 0; u < 6; u++)
+                            a2 = fma(G[6 * u + i], Q[BCR_B + 13 * u + c], a2);
+                        P[BCR_B + 13 * i + c] -= a2;
+                    }
+                    bool known = false;
+                    for (int f = 0; f < nf; f++)
+                        known |= flagged[f] == p;
+                    if (!known && nf < 4)
+                        flagged[nf++] = p;
+                }
+                wave_sync();
+            }
+        }
+        lds_barrier();
         const int ncols = two ? 72 : 36;
         for (int lev = levels - 1; lev >= 0; lev--) {
             const int s = 1 << lev, cnt = (n / s + 1) / 2;
@@ -1727,8 +1768,8 @@ int svo_pg_optimize(svo_posegraph *g, int iters, double *chi2)
         //          side columns (pg_segment_kernel: two closures to a pass, at most PG_MAX_SEG_CHORDS per segment, the
         //          ones beyond that become separators after all).
         // At 4541 vertices / 40 closures whose matches all lie in the first lap: cover = 45 separators instead of 81 (5 tile
-        // steps instead of 9, the solve 12 us instead of 25: -80 us) but four passes of 27 us in each of the first lap's
-        // segments (+109 us): 0.310 against 0.277 ms per iteration, and the model says so; closures whose endpoints spread
+        // steps instead of 9, the solve 12 us instead of 25: -80 us) but four passes of 23 us in each of the first lap's
+        // segments (+91 us): 0.292 against 0.279 ms per iteration, and the model says so; closures whose endpoints spread
         // take one pass per segment and the cover.  SVO_PG_COVER=1 / 0 forces one or the other (the tests run both).
         std::vector<char> cover, is_sep;
         std::vector<int> sepidx, seps, seg_start, seg_len, lsep, rsep, rowseg;
@@ -1808,7 +1849,7 @@ int svo_pg_optimize(svo_posegraph *g, int iters, double *chi2)
             else {
                 auto cost_us = [&](const bool b) {
                     const int fullest = select(b), tiles = (6 * (int)seps.size() + TB - 1) / TB;
-                    return 16.7 * (tiles > 1 ? tiles - 1 : 0) + 2.3 * tiles + 27.0 * ((fullest + 1) / 2);
+                    return 16.7 * (tiles > 1 ? tiles - 1 : 0) + 2.3 * tiles + 23.0 * ((fullest + 1) / 2);
                 };
                 both_ends = cost_us(true) <= cost_us(false);
             }
